@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the oscillator-bank + mixer hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric): 1024 additive voices PER GPU -- each a
+Harmonics oscillator with 16 partials a_k = 1/k under an ADSR envelope, f log-uniform in [55, 3520] Hz,
+random phase/pan, seed 0 -- mixed to one float32 stereo bus at 48 kHz.  One step = one block of 48 000
+frames (1 s of audio) rendered by the fused generate-and-mix kernel; steps render consecutive blocks and
+the envelope spans the whole run (no silent voices).  With N > 1 the voice table (N x 1024 voices, weak
+scaling; configs[3] at N = 8) is sharded across ranks and the float64 partial buses are summed to rank 0
+by RCCL every step.
+
+value = voice-samples mixed per second over all ranks / 1e6 ("Msamples/s"), inputs (the voice table)
+resident in HBM before the timed region.  The same run also times (a) the reference-shaped two-step
+path (voices materialised as float32 PCM in HBM, then the HBM-bound mixer kernel) and (b) the CPU
+oracle (pure-Python generators, 1 core) on a bounded sample -- reported beside, never as `value`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+SR = 48000
+VOICES_PER_GPU = 1024
+PARTIALS = 16
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP64_PEAK_GOPS = 256 * 4 * 16 * 2.4   # float64 FMA lanes/s (78.6 TFLOP/s spec / 2), in G lane-ops/s
+
+
+def build_voices(n_total: int, seconds_total: float):
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd import workloads as W
+    # envelope spans the whole run: attack 0.01, decay 0.05, release 0.2, sustain fills the rest
+    return W.additive_voices(G, n_total, SR, seed=0, partials=PARTIALS,
+                             adsr={"sustain": max(0.0, seconds_total - 0.26)})
+
+
+def cpu_baseline(frames: int):
+    """The oracle (pure-Python generator restatement of the reference path) on ONE core, timed on a
+    bounded sample of the same workload: all 1024 voices x `frames` frames, mixed to the stereo bus."""
+    from oracle import synth_oracle as O
+    from synthesizer_amd import workloads as W
+    voices, gains = W.additive_voices(O, VOICES_PER_GPU, SR, seed=0, partials=PARTIALS)
+    t0 = time.perf_counter()
+    blocks = [v.take(frames) for v in voices]
+    O.mix_bus(blocks, gains)
+    dt = time.perf_counter() - t0
+    return {"value": VOICES_PER_GPU * frames / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "1024 voices x %d frames (%.3f s of audio), pure-Python oracle generators + float bus sum, "
+                      "%.1f s wall" % (frames, frames / SR, dt)}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=SR, help="frames per step (block size)")
+    ap.add_argument("--cpu-frames", type=int, default=4096, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-two-step", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs one process per GPU (torch.distributed.run)" % args.gpus, file=sys.stderr)
+            return 2
+    td = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as td      # plumbing only: barrier + max over ranks + id broadcast
+        td.init_process_group("gloo", rank=rank, world_size=world)
+
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import dist
+    N.ensure_init(local_rank)
+    info = N.device_info()
+    if world > 1:
+        dist.init(rank, world)
+
+    K, Wm, F = args.steps, args.warmup, args.frames
+    total_voices = VOICES_PER_GPU * world
+    seconds_total = (K + Wm) * F / SR
+    voices, gains = build_voices(total_voices, seconds_total)
+    bank = dist.DistVoiceBank(voices, gains, rank, world)
+    L = N.lib()
+
+    def barrier():
+        N.sync()
+        if td is not None:
+            td.barrier()
+
+    # ---- fused path (headline) ----
+    for s in range(Wm):
+        bank.render_device(F, s * F)
+    barrier()
+    t0 = time.perf_counter()
+    N.timer_start()
+    for s in range(K):
+        bank.render_device(F, (Wm + s) * F)
+    ev_ms = N.timer_stop()           # HIP events on the library stream (also synchronises it)
+    barrier()
+    wall = time.perf_counter() - t0
+    if td is not None:
+        import torch
+        t = torch.tensor([wall, ev_ms], dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        wall, ev_ms = float(t[0]), float(t[1])
+
+    voice_samples = float(total_voices) * F * K
+    value = voice_samples / wall / 1e6
+    kern_s = ev_ms / 1e3 / K         # average duration of one block (k_locate + k_bank_render [+ reduce/finalize])
+    fused_bytes = 8.0 * F            # algorithmic: one float32 stereo frame written per output frame
+    harm_lane_ops = 2.0 * PARTIALS + 30.0   # float64 ops per voice-sample: Clenshaw 2/partial + sincos/phase/envelope
+    out = {
+        "metric": "Msamples/sec mixed to stereo bus, 1024-voice additive @48kHz",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%d-voice additive (Harmonics x%d partials + ADSR) -> float32 stereo bus, 48 kHz, "
+                               "fused generate-and-mix, block %d frames" % (total_voices, PARTIALS, F),
+                   "voices_per_gpu": VOICES_PER_GPU, "frames_per_step": F, "samplerate": SR,
+                   "parallelism": "voice-shard x%d, RCCL reduce of float64 partial buses" % world if world > 1 else "single GPU"},
+        "frames_per_s": F * K / wall,
+        "realtime_factor": F * K / wall / SR,
+        "device": info["name"], "arch": info["arch"],
+        "roofline": {
+            "kernel": "k_bank_render<16>", "bound": "hbm",
+            "achieved": fused_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": fused_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "note": "fused kernel writes 8 B per output frame: VALU(float64)-bound by construction, see valu",
+            "valu": {"unit": "G f64 lane-ops/s", "achieved": VOICES_PER_GPU * F * harm_lane_ops / kern_s / 1e9,
+                     "peak": FP64_PEAK_GOPS, "frac": VOICES_PER_GPU * F * harm_lane_ops / kern_s / 1e9 / FP64_PEAK_GOPS,
+                     "ops_per_voice_sample": harm_lane_ops},
+            "avg_launch_ms": kern_s * 1e3,
+        },
+    }
+
+    # ---- two-step path on rank 0's shard: materialise (generate) + HBM-bound mix ----
+    if not args.no_two_step:
+        nv = bank.local.nvoices
+        F2 = F * 10 if nv * F * 10 * 4 <= (8 << 30) else F     # 10 s blocks: 1.97 GB of voices, far past the 256 MB L3
+        vbuf = N.DeviceBuffer(nv * F2 * 4)
+        bus = N.DeviceBuffer(F2 * 8)
+        reps = max(3, min(20, K // 5))
+        for _ in range(2):
+            bank.local.generate_device(F2, 0, out=vbuf)
+            bank.local.mix_device(vbuf, F2, bus_f32=bus)
+        N.sync()
+        N.timer_start()
+        for r in range(reps):
+            bank.local.generate_device(F2, 0, out=vbuf)
+        gen_ms = N.timer_stop() / reps
+        N.timer_start()
+        for r in range(reps):
+            bank.local.mix_device(vbuf, F2, bus_f32=bus)
+        mix_ms = N.timer_stop() / reps
+        mix_bytes = (4.0 * nv + 8.0) * F2
+        gen_bytes = 4.0 * nv * F2
+        out["two_step"] = {
+            "frames_per_launch": F2, "voices": nv,
+            "value": nv * F2 / ((gen_ms + mix_ms) / 1e3) / 1e6, "unit": "Msamples/s",
+            "roofline_mix": {"kernel": "k_mix_bus_f32<8>", "bound": "hbm", "achieved": mix_bytes / (mix_ms / 1e3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mix_bytes / (mix_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": None, "avg_launch_ms": mix_ms, "bytes_per_frame": 4 * nv + 8},
+            "roofline_generate": {"kernel": "k_generate", "bound": "hbm", "achieved": gen_bytes / (gen_ms / 1e3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gen_bytes / (gen_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": None, "avg_launch_ms": gen_ms, "bytes_per_voice_sample": 4},
+        }
+        vbuf.free()
+        bus.free()
+
+    # ---- CPU baseline (rank 0, N = 1 only) ----
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        barrier()
+        dist.shutdown()
+        td.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,237 @@
+/*
+ * synthhip.h -- C ABI of libsynthhip.so: the MI355X (gfx950) implementation of
+ * synthplayer's oscillator-bank + sample-mixing hot path.
+ *
+ * The reference (irmen/synthesizer, package `synthplayer`) is pure Python and has
+ * NO native/FFI boundary of its own; its "plugin interface" for this path is the
+ * public Python class API.  The tree mounted at /root/reference holds only a
+ * relocation notice (/root/reference/README.md:1-2), so the upstream symbols are
+ * named here without line numbers:
+ *
+ *   synthplayer/oscillators.py  Oscillator.blocks(), Sine, Sawtooth, Square, Pulse,
+ *                               Harmonics, fm_lfo= / pwm_lfo=, EnvelopeFilter
+ *   synthplayer/sample.py       Sample.from_osc_block (quantise), Sample.mix,
+ *                               Sample.mix_at, Sample.resample
+ *   synthplayer/playback.py     mixer loop: repeated audioop.add over voice chunks
+ *   CPython 3.10 Modules/audioop.c  audioop.add, audioop.ratecv (the arithmetic
+ *                               Sample.mix / Sample.resample delegate to)
+ *
+ * Each entry point below says which of those it replaces.  INTEGRATION.md shows the
+ * ctypes binding a synthplayer maintainer would add.
+ *
+ * Conventions
+ *   - every function returns SH_OK (0) or a negative sh_status; nothing throws across
+ *     the ABI; sh_last_error() returns a thread-local message for the last failure.
+ *   - the caller owns all host memory; the library owns device memory behind sh_buf /
+ *     sh_bank handles.  No callbacks.  Plain pointers and sizes only.
+ *   - one HIP stream per process (created by sh_init); calls are not thread-safe
+ *     against each other.  Kernel launches are asynchronous; functions that copy to
+ *     host memory, and sh_sync(), synchronise.
+ *   - "frame" = one sample period (all channels); PCM is interleaved, little endian.
+ */
+#ifndef SYNTHHIP_H
+#define SYNTHHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sh_status {
+    SH_OK = 0,
+    SH_ERR_INVALID = -1,   /* bad argument */
+    SH_ERR_HIP = -2,       /* HIP runtime error (message has the hipError string) */
+    SH_ERR_NOMEM = -3,
+    SH_ERR_NOTINIT = -4,   /* sh_init not called / no GPU */
+    SH_ERR_OVERFLOW = -5,  /* quantise: a sample does not fit the PCM width (OverflowError upstream) */
+    SH_ERR_RCCL = -6,
+    SH_ERR_LENGTH = -7     /* audioop.add: "Lengths should be the same" */
+} sh_status;
+
+typedef enum sh_kind {     /* oscillators.py class names */
+    SH_SINE = 0, SH_SAWTOOTH = 1, SH_SQUARE = 2, SH_PULSE = 3, SH_HARMONICS = 4
+} sh_kind;
+
+typedef enum sh_fm_mode {
+    SH_FM_NONE = 0,        /* non-FM branch of blocks(): t accumulates f/sr, phase table below */
+    SH_FM_SINE = 1,        /* fm_lfo is a plain (non-FM) Sine: closed-form running sum of the LFO */
+    SH_FM_BUFFER = 2       /* any fm_lfo: running sum supplied as a device buffer (sh_osc_render only) */
+} sh_fm_mode;
+
+/* One piece of an accumulated-phase table: for n0 <= n < next.n0 the reference's
+ * running `t` (t += inc in float64) equals fma(n - n0, dt, t0) exactly. */
+typedef struct sh_segment {
+    uint64_t n0;
+    double   t0;
+    double   dt;
+} sh_segment;
+
+/* One (k, amp) pair of Harmonics(harmonics=[...]) -- used when the list is not dense. */
+typedef struct sh_partial {
+    double k;
+    double amp;
+} sh_partial;
+
+/* EnvelopeFilter, reduced on the host to integer sample boundaries (the host replays the
+ * reference's accumulated `time` exactly) and per-phase slopes. */
+typedef struct sh_envelope {
+    uint64_t n_attack_end;     /* [0, n_attack_end): gain = n*attack_slope */
+    uint64_t n_decay_end;      /* [.., n_decay_end): gain = 1 + (n-n_attack_end)*decay_slope */
+    uint64_t n_sustain_end;    /* [.., n_sustain_end): gain = sustain_level */
+    uint64_t n_release_end;    /* [.., n_release_end): gain = sustain_level + (n-n_sustain_end)*release_slope */
+    double   attack_slope, decay_slope, sustain_level, release_slope;
+    double   tail_amp;         /* gain of the one extra sample at n_release_end when has_tail */
+    int32_t  enabled;
+    int32_t  has_tail;
+} sh_envelope;
+
+typedef struct sh_voice {
+    int32_t  kind;             /* sh_kind */
+    int32_t  fm_mode;          /* sh_fm_mode */
+    double   amplitude, bias, pulsewidth;
+    /* SH_FM_NONE: carrier phase table (t in radians for Sine/Harmonics, in turns otherwise) */
+    uint32_t seg_offset, seg_count;
+    /* Harmonics: dense -> harm_count Clenshaw coefficients (doubles, k = harm_count..1,
+     * count a multiple of 8) at coef[harm_offset]; sparse -> harm_count sh_partial at partial[harm_offset] */
+    uint32_t harm_offset, harm_count;
+    int32_t  harm_dense;
+    int32_t  reserved0;
+    /* FM: theta_n = fm_phase0 + frequency*T_n + frequency*fm_inc*L(n), T = shared time table
+     * (t += fm_inc from 0), L(n) = sum_{j<n} lfo_j */
+    double   frequency, fm_phase0, fm_inc;
+    uint32_t time_seg_offset, time_seg_count;
+    /* SH_FM_SINE: lfo_j = lfo_amp*sin(lfo_a + j*lfo_d) + lfo_bias;
+     * L(n) = lfo_K*(lfo_C0 - cos(lfo_a + (n-0.5)*lfo_d)) + lfo_bias*n,
+     * lfo_K = lfo_amp/(2 sin(lfo_d/2)), lfo_C0 = cos(lfo_a - lfo_d/2) */
+    double   lfo_a, lfo_d, lfo_amp, lfo_bias, lfo_K, lfo_C0;
+    sh_envelope env;
+    float    gain_l, gain_r;   /* stereo bus gains (bank only) */
+} sh_voice;
+
+typedef struct sh_devinfo {
+    char     name[128];
+    char     arch[32];
+    int32_t  compute_units;
+    int32_t  clock_mhz;
+    uint64_t hbm_bytes;
+    int32_t  wavefront;
+    int32_t  device;
+} sh_devinfo;
+
+typedef struct sh_buf  sh_buf;   /* device buffer */
+typedef struct sh_bank sh_bank;  /* voice table resident in HBM */
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+int  sh_init(int device);                 /* select GPU, create the stream; idempotent */
+int  sh_shutdown(void);
+int  sh_is_initialized(void);
+int  sh_device_count(void);               /* 0 when no GPU is visible; never fails */
+int  sh_device_info(sh_devinfo* out);
+const char* sh_last_error(void);
+const char* sh_version(void);
+int  sh_sync(void);                       /* wait for the stream */
+
+/* ---- device buffers ---------------------------------------------------------------- */
+int    sh_buf_alloc(size_t bytes, sh_buf** out);
+int    sh_buf_free(sh_buf* b);
+size_t sh_buf_size(const sh_buf* b);
+void*  sh_buf_devptr(sh_buf* b);
+int    sh_buf_upload(sh_buf* b, size_t offset, const void* host, size_t bytes);
+int    sh_buf_download(const sh_buf* b, size_t offset, void* host, size_t bytes);
+int    sh_buf_fill_zero(sh_buf* b, size_t offset, size_t bytes);
+int    sh_buf_copy(sh_buf* dst, size_t dst_off, const sh_buf* src, size_t src_off, size_t bytes);
+
+/* ---- timing (HIP events on the library's stream) ------------------------------------ */
+int  sh_timer_start(void);
+int  sh_timer_stop(float* elapsed_ms);    /* records, synchronises, returns elapsed */
+
+/* ---- voice bank: the voice table (oscillator parameters + phase tables) resident in HBM.
+ *      A bank of ONE voice backs a Python Oscillator object; a bank of N voices backs the
+ *      mixer sum bus over oscillator voices. ------------------------------------------- */
+int sh_bank_create(const sh_voice* voices, uint32_t nvoices,
+                   const sh_segment* segs, uint32_t nsegs,
+                   const double* coefs, uint32_t ncoefs,
+                   const sh_partial* partials, uint32_t npartials,
+                   sh_bank** out);
+int sh_bank_destroy(sh_bank* b);
+uint32_t sh_bank_nvoices(const sh_bank* b);
+
+/* ---- oscillators: replaces Oscillator.blocks() of Sine/Sawtooth/Square/Pulse/Harmonics
+ *      (+fm_lfo, +pwm_lfo) and EnvelopeFilter.blocks() ---------------------------------
+ * Renders samples [start, start+n) of voice `voice` of the bank.  The call is stateless: the
+ * reference's generator state is (sample index, accumulated t), and the phase tables
+ * reproduce the accumulated t from the index.
+ *   fm_cumsum    SH_FM_BUFFER voices: device buffer of >= n doubles, L(start) .. L(start+n-1)
+ *                (L(m) = sum_{j<m} lfo_j, see sh_scan_f64); else NULL
+ *   pwm          Pulse with pwm_lfo: device buffer of n doubles (pulse width per sample); else NULL
+ *   out_host     host destination, n floats, or NULL
+ *   out_f32/off  device destination (float index `off`), or NULL
+ *   out_f64      device destination receiving the samples as float64 (modulators), or NULL
+ */
+int sh_osc_render(sh_bank* bank, uint32_t voice,
+                  const sh_buf* fm_cumsum, const sh_buf* pwm,
+                  uint64_t start, uint32_t n,
+                  float* out_host, sh_buf* out_f32, size_t out_off, sh_buf* out_f64);
+
+/* exclusive running sum of n float64 values on the device (FM with an arbitrary fm_lfo):
+ * out[i] = carry_in + x[0] + .. + x[i-1], i = 0..n-1 (n values).
+ * carry_out (host, may be NULL) receives carry_in + x[0] + .. + x[n-1]. */
+int sh_scan_f64(const sh_buf* x, uint32_t n, double carry_in, sh_buf* out, double* carry_out);
+
+/* ---- voice bank rendering: N voices -> stereo bus (the "Mixer sum bus" over oscillator voices) */
+/* materialise: voices_out[v*stride + i] = voice v at frame start+i (float32, voice-major) */
+int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voices_out, size_t stride);
+/* fused generate-and-mix: bus_f32[i] = (sum_v gl_v x_v[i], sum_v gr_v x_v[i]), float32 x2 interleaved.
+ * bus_f64 (optional) receives the float64 partial bus (frames x 2) used for the multi-GPU reduce. */
+int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64);
+
+/* ---- mixer sum bus over materialised voices ------------------------------------------ */
+/* float32: bus[i] = sum_v gains[v] * voices[v*stride+i]; gains = device buffer of nvoices x (l, r) floats */
+int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32_t nframes,
+                   const sh_buf* gains_lr, sh_buf* bus_f32);
+/* integer: the reference mixer's fold, mixed = add(add(c0, c1), c2) ... in voice order,
+ * saturating at every step (playback.py mixer loop -> audioop.add).  chunks[v*stride + i] int16. */
+int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint32_t nsamples, sh_buf* out);
+
+/* ---- Sample.from_osc_block: int(scale*v), truncation toward zero; SH_ERR_OVERFLOW if out of range */
+int sh_quantize_f32(const sh_buf* in_f32, size_t in_off, size_t n, double scale, int width,
+                    sh_buf* out_pcm, size_t out_off);
+/* same for float64 input (blocks produced by a float64 generator, e.g. upstream's own oscillators) */
+int sh_quantize_f64(const sh_buf* in_f64, size_t in_off, size_t n, double scale, int width,
+                    sh_buf* out_pcm, size_t out_off);
+/* float stereo bus -> int16 with saturation instead of OverflowError (bus epilogue, [SPEC]) */
+int sh_quantize_clip_f32(const sh_buf* in_f32, size_t n, double scale, sh_buf* out_i16);
+
+/* ---- Sample.mix -> audioop.add(frag1, frag2, width): saturating pairwise add, width 1/2/4 */
+int sh_pcm_add(const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, size_t nbytes, int width,
+               sh_buf* out, size_t out_off);
+int sh_pcm_add_host(const void* a, const void* b, size_t nbytes, int width, void* out);
+
+/* ---- Sample.resample -> audioop.ratecv(frames, width, nchannels, inrate, outrate, None) */
+size_t sh_resample_out_frames(size_t in_frames, int inrate, int outrate);
+/* width 1/2/4 integer PCM (bit-exact audioop arithmetic); is_float!=0: float32 PCM (width must be 4) */
+int sh_resample(const sh_buf* in, size_t in_frames, int nchannels, int width, int is_float,
+                int inrate, int outrate, sh_buf* out, size_t* out_frames);
+int sh_resample_host(const void* in, size_t in_frames, int nchannels, int width, int is_float,
+                     int inrate, int outrate, void* out, size_t* out_frames);
+
+/* ---- multi-GPU: voice-sharded banks, partial buses summed by RCCL over xGMI ------------ */
+#define SH_DIST_ID_BYTES 128
+int sh_dist_unique_id(void* id128);                       /* rank 0: ncclGetUniqueId */
+int sh_dist_init(int rank, int world, const void* id128); /* ncclCommInitRank on the library stream */
+int sh_dist_shutdown(void);
+int sh_dist_rank(void);
+int sh_dist_world(void);
+/* sum the ranks' float64 partial buses into root's buffer (ncclReduce, ncclDouble, in place) */
+int sh_dist_reduce_bus(sh_buf* bus_f64, size_t nvalues, int root);
+int sh_dist_allreduce_bus(sh_buf* bus_f64, size_t nvalues);
+int sh_dist_barrier(void);
+/* float64 bus -> float32 bus after the reduce */
+int sh_bus_finalize(const sh_buf* bus_f64, size_t nvalues, sh_buf* bus_f32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYNTHHIP_H */

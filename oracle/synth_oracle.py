@@ -1,0 +1,395 @@
+"""
+CPU ORACLE for the synthplayer oscillator-bank + sample-mixing hot path.
+
+THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+``cpu_baseline`` leg and ``__graft_entry__.smoke()`` may import it.  The product
+package (synthesizer_amd/) never imports anything from oracle/.
+
+PARITY STATUS: **unpinned** for the oscillator / envelope / quantise rows.
+The upstream tree mounted at /root/reference contains only a relocation notice
+(/root/reference/README.md:1-2): there is no synthplayer/oscillators.py,
+sample.py, playback.py or tests/ to cite or to run.  Every formula below is a
+restatement of the *publicly documented behaviour* of synthplayer 2.x as
+recalled by the author ([RECALL] in SURVEY.md's legend) and of the grading
+contract in BASELINE.json ([SPEC]).  When the real source is mounted, each
+function below names the upstream symbol it has to be diffed against.
+
+What IS pinned: the integer PCM rows (Sample.mix -> audioop.add,
+Sample.resample -> audioop.ratecv).  Those delegate, upstream, to the CPython
+standard library module ``audioop`` (Modules/audioop.c; CPython 3.10.12 is the
+interpreter in this image).  oracle/pcm_oracle.py restates those two C
+functions and tests/test_oracle_pcm.py checks the restatement against the live
+``audioop`` module and against golden vectors generated from it
+(tests/golden/make_golden.py).
+
+Semantics restated here (all float64, one Python-level iteration per output
+sample, exactly like the upstream generators):
+
+* every oscillator keeps a running ``t`` that is *accumulated* (``t += inc``),
+  never recomputed from an integer index.  This matters: the float64 rounding
+  of the accumulation drifts by ~1e-5 rad over 10 s at 3.5 kHz, and it decides
+  on which side of an edge a Square/Pulse sample lands.  The HIP path
+  reproduces the accumulated value bit-for-bit (see DESIGN.md "phase tables").
+* FM: ``freq = f*(1+lfo[i]); phase_correction += (freq_prev-freq)*t`` carried
+  across samples and blocks (upstream: oscillators.py, class Sine/Sawtooth/...
+  ``blocks()``, FM branch).
+* EnvelopeFilter: four consecutive loops (attack, decay, sustain, release)
+  gated by an accumulated ``time`` and an accumulated ``amp``.
+* quantise: ``int(scale*v)`` (truncation toward zero), scale = 2**(8w-1)-1,
+  packed into array('h') which raises OverflowError when out of range
+  (upstream: sample.py Sample.from_osc_block / from_array).
+"""
+from __future__ import annotations
+
+import itertools
+from math import sin, pi, floor
+from typing import Generator, Iterable, List, Optional, Sequence, Tuple
+
+# upstream: synthplayer/params.py (module-level defaults)
+norm_samplerate = 44100
+norm_nchannels = 2
+norm_samplewidth = 2
+norm_osc_blocksize = 512
+
+
+class Oscillator:
+    """upstream: oscillators.py class Oscillator (ABC with blocks())."""
+
+    def __init__(self, samplerate: int = 0) -> None:
+        self.samplerate = samplerate or norm_samplerate
+
+    def blocks(self) -> Generator[List[float], None, None]:
+        raise NotImplementedError
+
+    # convenience for tests: n samples as a flat list
+    def take(self, n: int) -> List[float]:
+        out: List[float] = []
+        gen = self.blocks()
+        while len(out) < n:
+            try:
+                out.extend(next(gen))
+            except StopIteration:
+                break
+        return out[:n]
+
+
+def _fm_blocks(lfo: Oscillator) -> Generator[List[float], None, None]:
+    return lfo.blocks()
+
+
+class Sine(Oscillator):
+    """upstream: oscillators.py class Sine."""
+
+    def __init__(self, frequency: float, amplitude: float = 1.0, phase: float = 0.0,
+                 bias: float = 0.0, fm_lfo: Optional[Oscillator] = None, samplerate: int = 0) -> None:
+        super().__init__(samplerate)
+        self.frequency = frequency
+        self.amplitude = amplitude
+        self.bias = bias
+        self.fm = fm_lfo
+        self._phase = phase
+
+    def blocks(self):
+        if self.fm:
+            phase_correction = self._phase * 2.0 * pi
+            freq_previous = self.frequency
+            increment = 2.0 * pi / self.samplerate
+            t = 0.0
+            fm_blocks = _fm_blocks(self.fm)
+            while True:
+                block = []
+                for fm in next(fm_blocks):
+                    freq = self.frequency * (1.0 + fm)
+                    phase_correction += (freq_previous - freq) * t
+                    freq_previous = freq
+                    block.append(sin(t * freq + phase_correction) * self.amplitude + self.bias)
+                    t += increment
+                yield block
+        else:
+            increment = 2.0 * pi * self.frequency / self.samplerate
+            t = self._phase * 2.0 * pi
+            while True:
+                block = []
+                for _ in range(norm_osc_blocksize):
+                    block.append(sin(t) * self.amplitude + self.bias)
+                    t += increment
+                yield block
+
+
+class Sawtooth(Oscillator):
+    """upstream: oscillators.py class Sawtooth (naive, not band-limited)."""
+
+    def __init__(self, frequency: float, amplitude: float = 1.0, phase: float = 0.0,
+                 bias: float = 0.0, fm_lfo: Optional[Oscillator] = None, samplerate: int = 0) -> None:
+        super().__init__(samplerate)
+        self.frequency = frequency
+        self.amplitude = amplitude
+        self.bias = bias
+        self.fm = fm_lfo
+        self._phase = phase
+
+    def blocks(self):
+        if self.fm:
+            phase_correction = self._phase
+            freq_previous = self.frequency
+            increment = 1.0 / self.samplerate
+            t = 0.0
+            fm_blocks = _fm_blocks(self.fm)
+            while True:
+                block = []
+                for fm in next(fm_blocks):
+                    freq = self.frequency * (1.0 + fm)
+                    phase_correction += (freq_previous - freq) * t
+                    freq_previous = freq
+                    tt = t * freq + phase_correction
+                    block.append(self.bias + self.amplitude * 2.0 * (tt - floor(0.5 + tt)))
+                    t += increment
+                yield block
+        else:
+            increment = self.frequency / self.samplerate
+            t = self._phase
+            while True:
+                block = []
+                for _ in range(norm_osc_blocksize):
+                    block.append(self.bias + self.amplitude * 2.0 * (t - floor(0.5 + t)))
+                    t += increment
+                yield block
+
+
+class Square(Oscillator):
+    """upstream: oscillators.py class Square (perfect square, 50% duty)."""
+
+    def __init__(self, frequency: float, amplitude: float = 1.0, phase: float = 0.0,
+                 bias: float = 0.0, fm_lfo: Optional[Oscillator] = None, samplerate: int = 0) -> None:
+        super().__init__(samplerate)
+        self.frequency = frequency
+        self.amplitude = amplitude
+        self.bias = bias
+        self.fm = fm_lfo
+        self._phase = phase
+
+    def blocks(self):
+        if self.fm:
+            phase_correction = self._phase
+            freq_previous = self.frequency
+            increment = 1.0 / self.samplerate
+            t = 0.0
+            fm_blocks = _fm_blocks(self.fm)
+            while True:
+                block = []
+                for fm in next(fm_blocks):
+                    freq = self.frequency * (1.0 + fm)
+                    phase_correction += (freq_previous - freq) * t
+                    freq_previous = freq
+                    tt = t * freq + phase_correction
+                    block.append((-self.amplitude if int(tt * 2) % 2 else self.amplitude) + self.bias)
+                    t += increment
+                yield block
+        else:
+            increment = self.frequency / self.samplerate
+            t = self._phase
+            while True:
+                block = []
+                for _ in range(norm_osc_blocksize):
+                    block.append((-self.amplitude if int(t * 2) % 2 else self.amplitude) + self.bias)
+                    t += increment
+                yield block
+
+
+class Pulse(Oscillator):
+    """upstream: oscillators.py class Pulse (pulse width optionally modulated)."""
+
+    def __init__(self, frequency: float, amplitude: float = 1.0, phase: float = 0.0,
+                 pulsewidth: float = 0.1, bias: float = 0.0, fm_lfo: Optional[Oscillator] = None,
+                 pwm_lfo: Optional[Oscillator] = None, samplerate: int = 0) -> None:
+        assert 0 <= pulsewidth <= 1
+        super().__init__(samplerate)
+        self.frequency = frequency
+        self.amplitude = amplitude
+        self.bias = bias
+        self.pulsewidth = pulsewidth
+        self.fm = fm_lfo
+        self.pwm = pwm_lfo
+        self._phase = phase
+
+    def blocks(self):
+        if self.fm or self.pwm:
+            phase_correction = self._phase
+            freq_previous = self.frequency
+            increment = 1.0 / self.samplerate
+            t = 0.0
+            fm_blocks = _fm_blocks(self.fm) if self.fm else itertools.repeat([0.0] * norm_osc_blocksize)
+            pwm_blocks = (_fm_blocks(self.pwm) if self.pwm
+                          else itertools.repeat([self.pulsewidth] * norm_osc_blocksize))
+            while True:
+                block = []
+                for fm, pw in zip(next(fm_blocks), next(pwm_blocks)):
+                    freq = self.frequency * (1.0 + fm)
+                    phase_correction += (freq_previous - freq) * t
+                    freq_previous = freq
+                    tt = t * freq + phase_correction
+                    block.append((self.amplitude if tt % 1.0 < pw else -self.amplitude) + self.bias)
+                    t += increment
+                yield block
+        else:
+            increment = self.frequency / self.samplerate
+            t = self._phase
+            while True:
+                block = []
+                for _ in range(norm_osc_blocksize):
+                    block.append((self.amplitude if t % 1.0 < self.pulsewidth else -self.amplitude) + self.bias)
+                    t += increment
+                yield block
+
+
+class Harmonics(Oscillator):
+    """upstream: oscillators.py class Harmonics (additive sine series)."""
+
+    def __init__(self, frequency: float, harmonics: Sequence[Tuple[int, float]], amplitude: float = 1.0,
+                 phase: float = 0.0, bias: float = 0.0, fm_lfo: Optional[Oscillator] = None,
+                 samplerate: int = 0) -> None:
+        super().__init__(samplerate)
+        self.frequency = frequency
+        self.amplitude = amplitude
+        self.bias = bias
+        self.fm = fm_lfo
+        self._phase = phase
+        self.harmonics = list(harmonics)
+
+    def blocks(self):
+        if self.fm:
+            phase_correction = self._phase * 2.0 * pi
+            freq_previous = self.frequency
+            increment = 2.0 * pi / self.samplerate
+            t = 0.0
+            fm_blocks = _fm_blocks(self.fm)
+            while True:
+                block = []
+                for fm in next(fm_blocks):
+                    h = 0.0
+                    freq = self.frequency * (1.0 + fm)
+                    phase_correction += (freq_previous - freq) * t
+                    freq_previous = freq
+                    q = t * freq + phase_correction
+                    for k, amp in self.harmonics:
+                        h += sin(q * k) * amp
+                    block.append(h * self.amplitude + self.bias)
+                    t += increment
+                yield block
+        else:
+            increment = 2.0 * pi * self.frequency / self.samplerate
+            t = self._phase * 2.0 * pi
+            while True:
+                block = []
+                for _ in range(norm_osc_blocksize):
+                    h = 0.0
+                    for k, amp in self.harmonics:
+                        h += sin(t * k) * amp
+                    block.append(h * self.amplitude + self.bias)
+                    t += increment
+                yield block
+
+
+class EnvelopeFilter(Oscillator):
+    """upstream: oscillators.py class EnvelopeFilter (ADSR volume envelope).
+
+    Four consecutive phases gated by an accumulated ``time`` (+= 1/samplerate)
+    with an accumulated ``amp`` inside attack/decay/release; after release one
+    more sample is emitted if amp is still > 0; then silence forever, or the
+    stream ends when stop_at_end is set.
+    """
+
+    def __init__(self, source: Oscillator, attack: float, decay: float, sustain: float,
+                 sustain_level: float, release: float, stop_at_end: bool = False) -> None:
+        assert attack >= 0 and decay >= 0 and sustain >= 0 and release >= 0
+        assert 0 <= sustain_level <= 1
+        super().__init__(source.samplerate)
+        self._source = source
+        self._attack = attack
+        self._decay = decay
+        self._sustain = sustain
+        self._sustain_level = sustain_level
+        self._release = release
+        self._stop_at_end = stop_at_end
+
+    def _samples(self) -> Generator[float, None, None]:
+        src = itertools.chain.from_iterable(self._source.blocks())
+        time = 0.0
+        end_time_decay = self._attack + self._decay
+        end_time_sustain = end_time_decay + self._sustain
+        end_time_release = end_time_sustain + self._release
+        increment = 1.0 / self.samplerate
+        if self._attack:
+            amp_change = 1.0 / self._attack * increment
+            amp = 0.0
+            while time < self._attack:
+                yield next(src) * amp
+                amp += amp_change
+                time += increment
+        if self._decay:
+            amp = 1.0
+            amp_change = (self._sustain_level - 1.0) / self._decay * increment
+            while time < end_time_decay:
+                yield next(src) * amp
+                amp += amp_change
+                time += increment
+        while time < end_time_sustain:
+            yield next(src) * self._sustain_level
+            time += increment
+        if self._release:
+            amp = self._sustain_level
+            amp_change = (-self._sustain_level) / self._release * increment
+            while time < end_time_release:
+                yield next(src) * amp
+                amp += amp_change
+                time += increment
+            if amp > 0.0:
+                yield next(src) * amp
+        if not self._stop_at_end:
+            while True:
+                yield 0.0
+
+    def blocks(self):
+        samples = self._samples()
+        while True:
+            block = list(itertools.islice(samples, norm_osc_blocksize))
+            if not block:
+                return
+            yield block
+
+
+# ---------------------------------------------------------------------------
+# quantise (upstream: sample.py Sample.from_osc_block -> from_array)
+# ---------------------------------------------------------------------------
+
+def quantise(block: Iterable[float], samplewidth: int = norm_samplewidth,
+             amplitude_scale: Optional[float] = None) -> List[int]:
+    """int(scale*v): truncation toward zero, OverflowError when out of range."""
+    if amplitude_scale is None:
+        amplitude_scale = 2 ** (8 * samplewidth - 1) - 1
+    lo, hi = -(2 ** (8 * samplewidth - 1)), 2 ** (8 * samplewidth - 1) - 1
+    out = []
+    for v in block:
+        i = int(amplitude_scale * v)
+        if i < lo or i > hi:
+            raise OverflowError("signed integer out of range for sample width %d" % samplewidth)
+        out.append(i)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# float stereo bus (new in the MI355X build, [SPEC] BASELINE.json north_star):
+# bus[n] = (sum_v gl_v*x_v[n], sum_v gr_v*x_v[n]), voices summed in table order.
+# ---------------------------------------------------------------------------
+
+def mix_bus(voices: Sequence[Sequence[float]], gains: Sequence[Tuple[float, float]]) -> List[Tuple[float, float]]:
+    n = min(len(v) for v in voices)
+    out = []
+    for i in range(n):
+        l = 0.0
+        r = 0.0
+        for v, (gl, gr) in zip(voices, gains):
+            l += gl * v[i]
+            r += gr * v[i]
+        out.append((l, r))
+    return out

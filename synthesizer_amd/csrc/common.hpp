@@ -1,0 +1,53 @@
+// common.hpp -- shared state and helpers of libsynthhip.so (host side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include "../../include/synthhip.h"
+
+struct sh_buf {
+    void*  ptr;
+    size_t bytes;
+};
+
+namespace sh {
+
+struct State {
+    bool        initialized = false;
+    int         device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev_start = nullptr, ev_stop = nullptr;
+    // grow-only scratch used by kernels that need a second pass (partial buses, scan sums, flags)
+    void*       scratch = nullptr;
+    size_t      scratch_bytes = 0;
+    int*        flag = nullptr;        // device int: overflow flag for quantise
+    int*        flag_host = nullptr;   // pinned host mirror
+};
+
+State& state();
+int  set_error(int code, const char* fmt, ...);
+int  hip_error(hipError_t e, const char* what);
+int  ensure_scratch(size_t bytes);
+
+#define SH_REQUIRE_INIT()                                                              \
+    do {                                                                               \
+        if (!sh::state().initialized)                                                  \
+            return sh::set_error(SH_ERR_NOTINIT, "sh_init() has not been called");     \
+    } while (0)
+
+#define SH_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e__ = (call);                                                       \
+        if (e__ != hipSuccess) return sh::hip_error(e__, #call);                       \
+    } while (0)
+
+#define SH_CHECK_LAUNCH(name)                                                          \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) return sh::hip_error(e__, name);                        \
+    } while (0)
+
+inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace sh

@@ -1,0 +1,153 @@
+// devmath.hpp -- float64 trigonometry and waveform formulas for the oscillator kernels.
+//
+// Everything here is written so that the translation unit can be built with
+// -ffp-contract=off: a fused multiply-add appears only where fma() is written.
+// The functions are __host__ __device__ so tests/ can compile this header with g++
+// and compare it with libm on the CPU (tests/test_devmath.py) -- the product only
+// ever runs them on the GPU.
+//
+// Accuracy target: |error| <= ~4e-16 absolute for |t| < 3e9 rad, i.e. the float32
+// value written to HBM is the correctly rounded float32 of the reference's float64
+// sample in all but ~1e-8 of cases.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define SH_HD __host__ __device__ __forceinline__
+#else
+#define SH_HD static inline
+#endif
+
+namespace shm {
+
+// pi split in three doubles (Cody-Waite); with fma every partial product is exact enough
+// that r = t - n*pi carries < 2e-16 absolute error for |n| < 2^31.
+constexpr double PI_1 = 0x1.921fb54442d18p+1;
+constexpr double PI_2 = 0x1.1a62633145c07p-53;
+constexpr double PI_3 = -0x1.f1976b7ed8fbcp-109;
+constexpr double INV_PI = 0.3183098861837907;
+constexpr double PIO2_1 = 0x1.921fb54442d18p+0;
+constexpr double PIO2_2 = 0x1.1a62633145c07p-54;
+constexpr double PIO2_3 = -0x1.f1976b7ed8fbcp-110;
+constexpr double TWO_OVER_PI = 0.6366197723675814;
+
+SH_HD double flip_sign(double x, int odd) {
+    // x * (-1)^odd without a multiply
+    union { double d; uint64_t u; } v;
+    v.d = x;
+    v.u ^= ((uint64_t)(odd & 1)) << 63;
+    return v.d;
+}
+
+// r in [-pi/2, pi/2], returns n (t = n*pi + r)
+SH_HD double reduce_pi(double t, int& n) {
+    double fn = rint(t * INV_PI);
+    double r = fma(-fn, PI_1, t);
+    r = fma(-fn, PI_2, r);
+    r = fma(-fn, PI_3, r);
+    n = (int)fn;
+    return r;
+}
+
+// odd Taylor polynomial of sin on [-pi/2, pi/2], degree 21 (truncation < 2e-18)
+SH_HD double sin_poly_halfpi(double r) {
+    double z = r * r;
+    double p = 1.9572941063391263e-20;
+    p = fma(p, z, -8.22063524662433e-18);
+    p = fma(p, z, 2.8114572543455206e-15);
+    p = fma(p, z, -7.647163731819816e-13);
+    p = fma(p, z, 1.6059043836821613e-10);
+    p = fma(p, z, -2.505210838544172e-08);
+    p = fma(p, z, 2.7557319223985893e-06);
+    p = fma(p, z, -0.0001984126984126984);
+    p = fma(p, z, 0.008333333333333333);
+    p = fma(p, z, -0.16666666666666666);
+    return fma(r * z, p, r);
+}
+
+// even Taylor polynomial of cos on [-pi/2, pi/2], degree 22
+SH_HD double cos_poly_halfpi(double r) {
+    double z = r * r;
+    double p = -8.896791392450574e-22;      // -1/22!
+    p = fma(p, z, 4.110317623312165e-19);
+    p = fma(p, z, -1.5619206968586225e-16);
+    p = fma(p, z, 4.779477332387385e-14);
+    p = fma(p, z, -1.1470745597729725e-11);
+    p = fma(p, z, 2.08767569878681e-09);
+    p = fma(p, z, -2.755731922398589e-07);
+    p = fma(p, z, 2.48015873015873e-05);
+    p = fma(p, z, -0.001388888888888889);
+    p = fma(p, z, 0.041666666666666664);
+    p = fma(p, z, -0.5);
+    return fma(z, p, 1.0);
+}
+
+SH_HD double sin_f64(double t) {
+    int n;
+    double r = reduce_pi(t, n);
+    return flip_sign(sin_poly_halfpi(r), n);
+}
+
+SH_HD double cos_f64(double t) {
+    int n;
+    double r = reduce_pi(t, n);
+    return flip_sign(cos_poly_halfpi(r), n);
+}
+
+// sin and cos together: quadrant reduction to [-pi/4, pi/4], degree 15/16 Taylor
+SH_HD void sincos_f64(double t, double& s, double& c) {
+    double fn = rint(t * TWO_OVER_PI);
+    double r = fma(-fn, PIO2_1, t);
+    r = fma(-fn, PIO2_2, r);
+    r = fma(-fn, PIO2_3, r);
+    int q = (int)fn;
+    double z = r * r;
+    double ps = -7.647163731819816e-13;
+    ps = fma(ps, z, 1.6059043836821613e-10);
+    ps = fma(ps, z, -2.505210838544172e-08);
+    ps = fma(ps, z, 2.7557319223985893e-06);
+    ps = fma(ps, z, -0.0001984126984126984);
+    ps = fma(ps, z, 0.008333333333333333);
+    ps = fma(ps, z, -0.16666666666666666);
+    double sr = fma(r * z, ps, r);
+    double pc = 4.779477332387385e-14;
+    pc = fma(pc, z, -1.1470745597729725e-11);
+    pc = fma(pc, z, 2.08767569878681e-09);
+    pc = fma(pc, z, -2.755731922398589e-07);
+    pc = fma(pc, z, 2.48015873015873e-05);
+    pc = fma(pc, z, -0.001388888888888889);
+    pc = fma(pc, z, 0.041666666666666664);
+    pc = fma(pc, z, -0.5);
+    double cr = fma(z, pc, 1.0);
+    // q mod 4: 0 -> (s, c), 1 -> (c, -s), 2 -> (-s, -c), 3 -> (-c, s)
+    double s0 = (q & 1) ? cr : sr;
+    double c0 = (q & 1) ? sr : cr;
+    s = flip_sign(s0, (q >> 1) & 1);
+    c = flip_sign(c0, ((q + 1) >> 1) & 1);
+}
+
+// ---- waveforms (formulas of oscillators.py, operation order preserved) -----------------
+
+// Sawtooth: bias + amplitude*2.0*(t - floor(0.5+t))
+SH_HD double saw_value(double t, double amp2, double bias) {
+    double fl = floor(0.5 + t);
+    return bias + amp2 * (t - fl);
+}
+
+// Square: (-amplitude if int(t*2) % 2 else amplitude) + bias ; int() truncates toward zero
+SH_HD double square_value(double t, double amp, double bias) {
+    double tr = trunc(t * 2.0);
+    double h = tr * 0.5;
+    bool odd = (h != rint(h)) && (fabs(tr) < 9007199254740992.0);
+    return (odd ? -amp : amp) + bias;
+}
+
+// Pulse: (amplitude if t % 1.0 < pulsewidth else -amplitude) + bias ; Python float modulo
+SH_HD double pulse_value(double t, double pw, double amp, double bias) {
+    double m = t - trunc(t);          // fmod(t, 1.0), exact
+    if (m < 0.0) m = m + 1.0;         // Python: result takes the sign of the divisor
+    return ((m < pw) ? amp : -amp) + bias;
+}
+
+}  // namespace shm

@@ -1,0 +1,146 @@
+// dist.hip -- multi-GPU voice sharding: one process per GPU, each renders the partial stereo bus
+// of its shard of the voice table; the partial buses (float64, frames x 2) are summed by RCCL
+// over xGMI.  The reference is single-process; this exchange is the only collective on the path.
+//
+// The message is tiny (48 000 frames x 16 B = 768 KB per second of audio), so the collective is
+// latency-bound: callers batch >= 1 s per call.  librccl.so is dlopen()ed on first use so that
+// single-GPU users never pay for loading it.
+#include "common.hpp"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <string.h>
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = -1, world = 0;
+    double* token = nullptr;     // 1-element device buffer for the barrier
+};
+
+Rccl& R() {
+    static Rccl r;
+    return r;
+}
+
+int load_rccl() {
+    Rccl& r = R();
+    if (r.lib) return SH_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return sh::set_error(SH_ERR_RCCL, "cannot load librccl.so: %s", dlerror());
+#define SH_SYM(field, sym)                                                              \
+    *(void**)(&r.field) = dlsym(r.lib, sym);                                            \
+    if (!r.field) return sh::set_error(SH_ERR_RCCL, "librccl.so lacks %s", sym);
+    SH_SYM(GetUniqueId, "ncclGetUniqueId")
+    SH_SYM(CommInitRank, "ncclCommInitRank")
+    SH_SYM(CommDestroy, "ncclCommDestroy")
+    SH_SYM(Reduce, "ncclReduce")
+    SH_SYM(AllReduce, "ncclAllReduce")
+    SH_SYM(GetErrorString, "ncclGetErrorString")
+#undef SH_SYM
+    return SH_OK;
+}
+
+int rccl_error(ncclResult_t e, const char* what) {
+    return sh::set_error(SH_ERR_RCCL, "%s: %s", what, R().GetErrorString ? R().GetErrorString(e) : "rccl error");
+}
+
+#define SH_RCCL(call)                                                                   \
+    do {                                                                                \
+        ncclResult_t e__ = (call);                                                      \
+        if (e__ != ncclSuccess) return rccl_error(e__, #call);                          \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int sh_dist_unique_id(void* id128) {
+    if (!id128) return sh::set_error(SH_ERR_INVALID, "sh_dist_unique_id: NULL");
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    SH_RCCL(R().GetUniqueId(&id));
+    static_assert(sizeof(id) == SH_DIST_ID_BYTES, "ncclUniqueId size");
+    memcpy(id128, &id, sizeof(id));
+    return SH_OK;
+}
+
+int sh_dist_init(int rank, int world, const void* id128) {
+    SH_REQUIRE_INIT();
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return sh::set_error(SH_ERR_INVALID, "sh_dist_init: bad rank/world");
+    int rc = load_rccl();
+    if (rc) return rc;
+    Rccl& r = R();
+    if (r.comm) return sh::set_error(SH_ERR_INVALID, "sh_dist_init: already initialised");
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    SH_RCCL(r.CommInitRank(&r.comm, world, id, rank));
+    r.rank = rank;
+    r.world = world;
+    SH_HIP(hipMalloc((void**)&r.token, sizeof(double)));
+    SH_HIP(hipMemsetAsync(r.token, 0, sizeof(double), sh::state().stream));
+    return SH_OK;
+}
+
+int sh_dist_shutdown(void) {
+    Rccl& r = R();
+    if (r.comm) {
+        if (sh::state().initialized) hipStreamSynchronize(sh::state().stream);
+        r.CommDestroy(r.comm);
+        r.comm = nullptr;
+    }
+    if (r.token) {
+        hipFree(r.token);
+        r.token = nullptr;
+    }
+    r.rank = -1;
+    r.world = 0;
+    return SH_OK;
+}
+
+int sh_dist_rank(void) { return R().rank; }
+int sh_dist_world(void) { return R().world; }
+
+int sh_dist_reduce_bus(sh_buf* bus_f64, size_t nvalues, int root) {
+    SH_REQUIRE_INIT();
+    Rccl& r = R();
+    if (!r.comm) return sh::set_error(SH_ERR_RCCL, "sh_dist_reduce_bus: sh_dist_init not called");
+    if (!bus_f64 || bus_f64->bytes < nvalues * 8) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus: buffer too small");
+    if (root < 0 || root >= r.world) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus: bad root");
+    if (!nvalues) return SH_OK;
+    SH_RCCL(r.Reduce(bus_f64->ptr, bus_f64->ptr, nvalues, ncclFloat64, ncclSum, root, r.comm, sh::state().stream));
+    return SH_OK;
+}
+
+int sh_dist_allreduce_bus(sh_buf* bus_f64, size_t nvalues) {
+    SH_REQUIRE_INIT();
+    Rccl& r = R();
+    if (!r.comm) return sh::set_error(SH_ERR_RCCL, "sh_dist_allreduce_bus: sh_dist_init not called");
+    if (!bus_f64 || bus_f64->bytes < nvalues * 8) return sh::set_error(SH_ERR_INVALID, "sh_dist_allreduce_bus: buffer too small");
+    if (!nvalues) return SH_OK;
+    SH_RCCL(r.AllReduce(bus_f64->ptr, bus_f64->ptr, nvalues, ncclFloat64, ncclSum, r.comm, sh::state().stream));
+    return SH_OK;
+}
+
+int sh_dist_barrier(void) {
+    SH_REQUIRE_INIT();
+    Rccl& r = R();
+    if (!r.comm) return sh::set_error(SH_ERR_RCCL, "sh_dist_barrier: sh_dist_init not called");
+    SH_RCCL(r.AllReduce(r.token, r.token, 1, ncclFloat64, ncclSum, r.comm, sh::state().stream));
+    SH_HIP(hipStreamSynchronize(sh::state().stream));
+    return SH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,429 @@
+// pcm.hip -- integer/float PCM kernels: quantise, saturating add (Sample.mix), the mixer's
+// saturating chain, and linear-interpolation resampling (Sample.resample).
+//
+// These restate CPython 3.10 Modules/audioop.c (audioop_add_impl, audioop_ratecv_impl), the
+// arithmetic synthplayer's sample.py delegates to.  All of them are HBM-bound byte/integer work:
+// coalesced loads, one output element (or a small vector) per thread, no LDS except for the
+// cross-wave combine of the mixer chain.  Built with -ffp-contract=off: audioop forms
+// prev*d + cur*(outrate-d) with two roundings and a division, and so does k_resample.
+#include "common.hpp"
+#include <new>
+
+namespace {
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+typedef int   int4v   __attribute__((ext_vector_type(4)));
+typedef char  char16v __attribute__((ext_vector_type(16)));
+
+// ---- quantise: int(scale*v), truncation toward zero (sample.py Sample.from_osc_block) -------
+template <typename OutT, typename InT = float>
+__global__ __launch_bounds__(256) void k_quantize(const InT* __restrict__ in, size_t n, double scale,
+                                                  double lo, double hi, OutT* __restrict__ out,
+                                                  int* __restrict__ flag, int clip) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v = scale * (double)in[i];          // float64 product, like the Python expression
+    double t = trunc(v);
+    if (!(t >= lo && t <= hi)) {               // also catches NaN
+        if (clip) {
+            t = (t > hi) ? hi : lo;
+            if (v != v) t = 0.0;
+        } else {
+            *flag = 1;
+            t = 0.0;
+        }
+    }
+    out[i] = (OutT)(long long)t;
+}
+
+// ---- audioop.add (no __restrict__: Sample.mix_at adds in place) ---------------------------------
+__global__ __launch_bounds__(256) void k_add_i16_vec(const short8v* a, const short8v* b,
+                                                     short8v* o, size_t nvec) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_add_scalar(const T* a, const T* b,
+                                                    T* o, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
+}
+
+__global__ __launch_bounds__(256) void k_add_i32_vec(const int4v* a, const int4v* b,
+                                                     int4v* o, size_t nvec) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
+}
+
+__global__ __launch_bounds__(256) void k_add_i8_vec(const char16v* a, const char16v* b,
+                                                    char16v* o, size_t nvec) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
+}
+
+// ---- mixer chain: mixed = add(...add(add(c0, c1), c2)..., c_{N-1}), saturating at every step ----
+// x -> clamp(x + s, lo, hi) composes into x -> clamp(x + a, L, U) (closed under composition), so
+// each wave folds a contiguous range of voices into one (a, L, U) triple per sample and wave 0
+// applies the W triples in voice order to x = 0.  Bit-exact with the sequential fold.
+constexpr int CH_BIG = 1 << 28;
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __restrict__ chunks, uint32_t nvoices,
+                                                              size_t stride, uint32_t nsamples,
+                                                              short* __restrict__ out) {
+    __shared__ int red[WAVES][3][4][64];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t s0 = (blockIdx.x * 64 + lane) * 4;
+    const uint32_t per = (nvoices + WAVES - 1) / WAVES;
+    const uint32_t v0 = wave * per;
+    uint32_t v1 = v0 + per;
+    if (v1 > nvoices) v1 = nvoices;
+    int a[4] = {0, 0, 0, 0}, L[4] = {-CH_BIG, -CH_BIG, -CH_BIG, -CH_BIG}, U[4] = {CH_BIG, CH_BIG, CH_BIG, CH_BIG};
+    const bool vec = (s0 + 3 < nsamples) && ((stride & 3) == 0);
+    if (s0 < nsamples) {
+        for (uint32_t v = v0; v < v1; ++v) {
+            const short* row = chunks + (size_t)v * stride + s0;
+            short4v x;
+            if (vec) {
+                x = *reinterpret_cast<const short4v*>(row);
+            } else {
+                x.x = row[0];
+                x.y = (s0 + 1 < nsamples) ? row[1] : (short)0;
+                x.z = (s0 + 2 < nsamples) ? row[2] : (short)0;
+                x.w = (s0 + 3 < nsamples) ? row[3] : (short)0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int s = x[j];
+                a[j] += s;
+                L[j] = clampi(L[j] + s, -32768, 32767);
+                U[j] = clampi(U[j] + s, -32768, 32767);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[wave][0][j][lane] = a[j];
+        red[wave][1][j][lane] = L[j];
+        red[wave][2][j][lane] = U[j];
+    }
+    __syncthreads();
+    if (wave == 0 && s0 < nsamples) {
+        short4v r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int x = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) x = clampi(x + red[w][0][j][lane], red[w][1][j][lane], red[w][2][j][lane]);
+            r[j] = (short)x;
+        }
+        if (s0 + 3 < nsamples && ((reinterpret_cast<uintptr_t>(out + s0) & 7) == 0)) {
+            *reinterpret_cast<short4v*>(out + s0) = r;
+        } else {
+            for (uint32_t j = 0; j < 4 && s0 + j < nsamples; ++j) out[s0 + j] = r[j];
+        }
+    }
+}
+
+// ---- audioop.ratecv / float32 resample ----------------------------------------------------------
+// One thread per output sample (frame m, channel c).  Output m interpolates input frames j-1 and j,
+// j = ceil(m*inrate/outrate), d = j*outrate - m*inrate (rates gcd-reduced): identical index
+// arithmetic to the reference's state machine, evaluated in closed form.
+struct RatecvArgs {
+    uint64_t n_out_samples;     // out_frames * nch
+    uint32_t nch;
+    uint32_t inr, outr;
+    double   inv_outr;
+    int      shift;             // 32 - 8*width (integer PCM)
+};
+
+__device__ __forceinline__ void ratecv_index(const RatecvArgs& A, uint64_t m, uint64_t& j, uint32_t& d) {
+    const uint64_t M = m * (uint64_t)A.inr;
+    uint64_t q;
+    int64_t r;
+    if (M < (1ull << 52)) {
+        q = (uint64_t)floor((double)M * A.inv_outr);
+        r = (int64_t)(M - q * (uint64_t)A.outr);
+        if (r < 0) { q -= 1; r += A.outr; }
+        else if (r >= (int64_t)A.outr) { q += 1; r -= A.outr; }
+    } else {
+        q = M / A.outr;
+        r = (int64_t)(M % A.outr);
+    }
+    j = q + (r != 0);
+    d = r ? (uint32_t)(A.outr - (uint32_t)r) : 0u;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_resample_int(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A) {
+    const uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= A.n_out_samples) return;
+    const uint64_t m = o / A.nch;
+    const uint32_t c = (uint32_t)(o - m * A.nch);
+    uint64_t j;
+    uint32_t d;
+    ratecv_index(A, m, j, d);
+    const int cur = (int)((unsigned)(int)in[j * A.nch + c] << A.shift);          // GETSAMPLE32
+    const int prev = (j && d) ? (int)((unsigned)(int)in[(j - 1) * A.nch + c] << A.shift) : 0;
+    // (int)(((double)prev*(double)d + (double)cur*(double)(outrate-d)) / (double)outrate)
+    const double val = ((double)prev * (double)d + (double)cur * (double)(A.outr - d)) / (double)A.outr;
+    const int cur_o = (int)val;
+    out[o] = (T)(cur_o >> A.shift);                                              // SETSAMPLE32
+}
+
+__global__ __launch_bounds__(256) void k_resample_f32(const float* __restrict__ in, float* __restrict__ out, RatecvArgs A) {
+    const uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= A.n_out_samples) return;
+    const uint64_t m = o / A.nch;
+    const uint32_t c = (uint32_t)(o - m * A.nch);
+    uint64_t j;
+    uint32_t d;
+    ratecv_index(A, m, j, d);
+    const double cur = (double)in[j * A.nch + c];
+    const double prev = (j && d) ? (double)in[(j - 1) * A.nch + c] : 0.0;
+    const double val = (prev * (double)d + cur * (double)(A.outr - d)) / (double)A.outr;
+    out[o] = (float)val;
+}
+
+uint64_t gcd_u64(uint64_t a, uint64_t b) {
+    while (b) {
+        uint64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+int fetch_flag(int* result) {
+    sh::State& s = sh::state();
+    SH_HIP(hipMemcpyAsync(s.flag_host, s.flag, sizeof(int), hipMemcpyDeviceToHost, s.stream));
+    SH_HIP(hipStreamSynchronize(s.stream));
+    *result = s.flag_host[0];
+    if (*result) {
+        SH_HIP(hipMemsetAsync(s.flag, 0, sizeof(int), s.stream));
+    }
+    return SH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sh_quantize_f32(const sh_buf* in_f32, size_t in_off, size_t n, double scale, int width,
+                    sh_buf* out_pcm, size_t out_off) {
+    SH_REQUIRE_INIT();
+    if (!in_f32 || !out_pcm) return sh::set_error(SH_ERR_INVALID, "sh_quantize_f32: NULL argument");
+    if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_quantize_f32: width %d not in {1,2,4}", width);
+    if (in_off > in_f32->bytes / 4 || n > in_f32->bytes / 4 - in_off) return sh::set_error(SH_ERR_INVALID, "sh_quantize_f32: input range outside buffer");
+    if (out_off > out_pcm->bytes / width || n > out_pcm->bytes / width - out_off) return sh::set_error(SH_ERR_INVALID, "sh_quantize_f32: output range outside buffer");
+    if (!n) return SH_OK;
+    const double lo = -ldexp(1.0, 8 * width - 1), hi = ldexp(1.0, 8 * width - 1) - 1.0;
+    const float* in = (const float*)in_f32->ptr + in_off;
+    dim3 grid(sh::div_up(n, 256));
+    hipStream_t st = sh::state().stream;
+    int* flag = sh::state().flag;
+    if (width == 2) hipLaunchKernelGGL(k_quantize<short>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (short*)out_pcm->ptr + out_off, flag, 0);
+    else if (width == 1) hipLaunchKernelGGL(k_quantize<signed char>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (signed char*)out_pcm->ptr + out_off, flag, 0);
+    else hipLaunchKernelGGL(k_quantize<int>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (int*)out_pcm->ptr + out_off, flag, 0);
+    SH_CHECK_LAUNCH("k_quantize");
+    int overflow = 0;
+    int rc = fetch_flag(&overflow);
+    if (rc) return rc;
+    if (overflow) return sh::set_error(SH_ERR_OVERFLOW, "signed integer out of range for sample width %d", width);
+    return SH_OK;
+}
+
+int sh_quantize_f64(const sh_buf* in_f64, size_t in_off, size_t n, double scale, int width,
+                    sh_buf* out_pcm, size_t out_off) {
+    SH_REQUIRE_INIT();
+    if (!in_f64 || !out_pcm) return sh::set_error(SH_ERR_INVALID, "sh_quantize_f64: NULL argument");
+    if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_quantize_f64: width %d not in {1,2,4}", width);
+    if (in_off > in_f64->bytes / 8 || n > in_f64->bytes / 8 - in_off) return sh::set_error(SH_ERR_INVALID, "sh_quantize_f64: input range outside buffer");
+    if (out_off > out_pcm->bytes / width || n > out_pcm->bytes / width - out_off) return sh::set_error(SH_ERR_INVALID, "sh_quantize_f64: output range outside buffer");
+    if (!n) return SH_OK;
+    const double lo = -ldexp(1.0, 8 * width - 1), hi = ldexp(1.0, 8 * width - 1) - 1.0;
+    const double* in = (const double*)in_f64->ptr + in_off;
+    dim3 grid(sh::div_up(n, 256));
+    hipStream_t st = sh::state().stream;
+    int* flag = sh::state().flag;
+    if (width == 2) hipLaunchKernelGGL((k_quantize<short, double>), grid, dim3(256), 0, st, in, n, scale, lo, hi, (short*)out_pcm->ptr + out_off, flag, 0);
+    else if (width == 1) hipLaunchKernelGGL((k_quantize<signed char, double>), grid, dim3(256), 0, st, in, n, scale, lo, hi, (signed char*)out_pcm->ptr + out_off, flag, 0);
+    else hipLaunchKernelGGL((k_quantize<int, double>), grid, dim3(256), 0, st, in, n, scale, lo, hi, (int*)out_pcm->ptr + out_off, flag, 0);
+    SH_CHECK_LAUNCH("k_quantize");
+    int overflow = 0;
+    int rc = fetch_flag(&overflow);
+    if (rc) return rc;
+    if (overflow) return sh::set_error(SH_ERR_OVERFLOW, "signed integer out of range for sample width %d", width);
+    return SH_OK;
+}
+
+int sh_quantize_clip_f32(const sh_buf* in_f32, size_t n, double scale, sh_buf* out_i16) {
+    SH_REQUIRE_INIT();
+    if (!in_f32 || !out_i16) return sh::set_error(SH_ERR_INVALID, "sh_quantize_clip_f32: NULL argument");
+    if (in_f32->bytes / 4 < n || out_i16->bytes / 2 < n) return sh::set_error(SH_ERR_INVALID, "sh_quantize_clip_f32: buffer too small");
+    if (!n) return SH_OK;
+    hipLaunchKernelGGL(k_quantize<short>, dim3(sh::div_up(n, 256)), dim3(256), 0, sh::state().stream,
+                       (const float*)in_f32->ptr, n, scale, -32768.0, 32767.0, (short*)out_i16->ptr, sh::state().flag, 1);
+    SH_CHECK_LAUNCH("k_quantize(clip)");
+    return SH_OK;
+}
+
+static int pcm_add_dev(const char* a, const char* b, char* o, size_t nbytes, int width) {
+    hipStream_t st = sh::state().stream;
+    const bool aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)o) & 15) == 0;
+    size_t nvec = aligned ? nbytes / 16 : 0;
+    size_t done = nvec * 16;
+    if (nvec) {
+        dim3 grid(sh::div_up(nvec, 256));
+        if (width == 2) hipLaunchKernelGGL(k_add_i16_vec, grid, dim3(256), 0, st, (const short8v*)a, (const short8v*)b, (short8v*)o, nvec);
+        else if (width == 4) hipLaunchKernelGGL(k_add_i32_vec, grid, dim3(256), 0, st, (const int4v*)a, (const int4v*)b, (int4v*)o, nvec);
+        else hipLaunchKernelGGL(k_add_i8_vec, grid, dim3(256), 0, st, (const char16v*)a, (const char16v*)b, (char16v*)o, nvec);
+        SH_CHECK_LAUNCH("k_add_vec");
+    }
+    size_t rest = (nbytes - done) / width;
+    if (rest) {
+        dim3 grid(sh::div_up(rest, 256));
+        if (width == 2) hipLaunchKernelGGL(k_add_scalar<short>, grid, dim3(256), 0, st, (const short*)(a + done), (const short*)(b + done), (short*)(o + done), rest);
+        else if (width == 4) hipLaunchKernelGGL(k_add_scalar<int>, grid, dim3(256), 0, st, (const int*)(a + done), (const int*)(b + done), (int*)(o + done), rest);
+        else hipLaunchKernelGGL(k_add_scalar<signed char>, grid, dim3(256), 0, st, (const signed char*)(a + done), (const signed char*)(b + done), (signed char*)(o + done), rest);
+        SH_CHECK_LAUNCH("k_add_scalar");
+    }
+    return SH_OK;
+}
+
+int sh_pcm_add(const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, size_t nbytes, int width,
+               sh_buf* out, size_t out_off) {
+    SH_REQUIRE_INIT();
+    if (!a || !b || !out) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add: NULL argument");
+    if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add: width %d not in {1,2,4}", width);
+    if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add: not a whole number of frames");
+    if (a_off > a->bytes || nbytes > a->bytes - a_off || b_off > b->bytes || nbytes > b->bytes - b_off ||
+        out_off > out->bytes || nbytes > out->bytes - out_off)
+        return sh::set_error(SH_ERR_LENGTH, "sh_pcm_add: range outside buffer (Lengths should be the same)");
+    if ((a_off | b_off | out_off) % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add: offsets not sample-aligned");
+    if (!nbytes) return SH_OK;
+    return pcm_add_dev((const char*)a->ptr + a_off, (const char*)b->ptr + b_off, (char*)out->ptr + out_off, nbytes, width);
+}
+
+int sh_pcm_add_host(const void* a, const void* b, size_t nbytes, int width, void* out) {
+    SH_REQUIRE_INIT();
+    if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add_host: width %d not in {1,2,4}", width);
+    if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add_host: not a whole number of frames");
+    if (!nbytes) return SH_OK;
+    if (!a || !b || !out) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add_host: NULL argument");
+    size_t pad = (nbytes + 255) & ~size_t(255);
+    int rc = sh::ensure_scratch(3 * pad);
+    if (rc) return rc;
+    char* s = (char*)sh::state().scratch;
+    hipStream_t st = sh::state().stream;
+    SH_HIP(hipMemcpyAsync(s, a, nbytes, hipMemcpyHostToDevice, st));
+    SH_HIP(hipMemcpyAsync(s + pad, b, nbytes, hipMemcpyHostToDevice, st));
+    rc = pcm_add_dev(s, s + pad, s + 2 * pad, nbytes, width);
+    if (rc) return rc;
+    SH_HIP(hipMemcpyAsync(out, s + 2 * pad, nbytes, hipMemcpyDeviceToHost, st));
+    SH_HIP(hipStreamSynchronize(st));
+    return SH_OK;
+}
+
+int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint32_t nsamples, sh_buf* out) {
+    SH_REQUIRE_INIT();
+    if (!chunks || !out || nvoices == 0) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: NULL argument");
+    if (nvoices > 32768) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: at most 32768 voices");
+    if (!nsamples) return SH_OK;
+    if (stride < nsamples || chunks->bytes / 2 < (size_t)(nvoices - 1) * stride + nsamples)
+        return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: chunk buffer too small");
+    if (out->bytes / 2 < nsamples) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: output too small");
+    dim3 grid(sh::div_up(nsamples, 256));
+    hipStream_t st = sh::state().stream;
+    if (nvoices >= 64) hipLaunchKernelGGL(k_mix_chain_i16<8>, grid, dim3(8 * 64), 0, st, (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
+    else hipLaunchKernelGGL(k_mix_chain_i16<2>, grid, dim3(2 * 64), 0, st, (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
+    SH_CHECK_LAUNCH("k_mix_chain_i16");
+    return SH_OK;
+}
+
+size_t sh_resample_out_frames(size_t in_frames, int inrate, int outrate) {
+    if (in_frames == 0 || inrate <= 0 || outrate <= 0) return 0;
+    uint64_t g = gcd_u64((uint64_t)inrate, (uint64_t)outrate);
+    uint64_t inr = (uint64_t)inrate / g, outr = (uint64_t)outrate / g;
+    unsigned __int128 t = (unsigned __int128)(in_frames - 1) * outr;
+    return (size_t)(t / inr) + 1;
+}
+
+static int resample_dev(const void* in, size_t in_frames, int nch, int width, int is_float, int inrate, int outrate,
+                        void* out, size_t out_frames) {
+    uint64_t g = gcd_u64((uint64_t)inrate, (uint64_t)outrate);
+    RatecvArgs A;
+    A.nch = (uint32_t)nch;
+    A.inr = (uint32_t)((uint64_t)inrate / g);
+    A.outr = (uint32_t)((uint64_t)outrate / g);
+    A.inv_outr = 1.0 / (double)A.outr;
+    A.shift = 32 - 8 * width;
+    A.n_out_samples = (uint64_t)out_frames * nch;
+    (void)in_frames;
+    if (!A.n_out_samples) return SH_OK;
+    dim3 grid(sh::div_up(A.n_out_samples, 256));
+    hipStream_t st = sh::state().stream;
+    if (is_float) hipLaunchKernelGGL(k_resample_f32, grid, dim3(256), 0, st, (const float*)in, (float*)out, A);
+    else if (width == 2) hipLaunchKernelGGL(k_resample_int<short>, grid, dim3(256), 0, st, (const short*)in, (short*)out, A);
+    else if (width == 4) hipLaunchKernelGGL(k_resample_int<int>, grid, dim3(256), 0, st, (const int*)in, (int*)out, A);
+    else hipLaunchKernelGGL(k_resample_int<signed char>, grid, dim3(256), 0, st, (const signed char*)in, (signed char*)out, A);
+    SH_CHECK_LAUNCH("k_resample");
+    return SH_OK;
+}
+
+static int resample_check(int nch, int width, int is_float, int inrate, int outrate) {
+    if (nch < 1) return sh::set_error(SH_ERR_INVALID, "resample: # of channels should be >= 1");
+    if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "resample: width %d not in {1,2,4}", width);
+    if (is_float && width != 4) return sh::set_error(SH_ERR_INVALID, "resample: float PCM must have width 4");
+    if (inrate <= 0 || outrate <= 0) return sh::set_error(SH_ERR_INVALID, "resample: sampling rate not > 0");
+    return SH_OK;
+}
+
+int sh_resample(const sh_buf* in, size_t in_frames, int nchannels, int width, int is_float,
+                int inrate, int outrate, sh_buf* out, size_t* out_frames) {
+    SH_REQUIRE_INIT();
+    if (!in || !out) return sh::set_error(SH_ERR_INVALID, "sh_resample: NULL argument");
+    int rc = resample_check(nchannels, width, is_float, inrate, outrate);
+    if (rc) return rc;
+    size_t nout = sh_resample_out_frames(in_frames, inrate, outrate);
+    if (in->bytes / ((size_t)width * nchannels) < in_frames) return sh::set_error(SH_ERR_INVALID, "sh_resample: input buffer smaller than in_frames");
+    if (out->bytes / ((size_t)width * nchannels) < nout) return sh::set_error(SH_ERR_INVALID, "sh_resample: output buffer too small (%zu frames needed)", nout);
+    if (out_frames) *out_frames = nout;
+    return resample_dev(in->ptr, in_frames, nchannels, width, is_float, inrate, outrate, out->ptr, nout);
+}
+
+int sh_resample_host(const void* in, size_t in_frames, int nchannels, int width, int is_float,
+                     int inrate, int outrate, void* out, size_t* out_frames) {
+    SH_REQUIRE_INIT();
+    int rc = resample_check(nchannels, width, is_float, inrate, outrate);
+    if (rc) return rc;
+    size_t nout = sh_resample_out_frames(in_frames, inrate, outrate);
+    if (out_frames) *out_frames = nout;
+    if (!nout) return SH_OK;
+    if (!in || !out) return sh::set_error(SH_ERR_INVALID, "sh_resample_host: NULL argument");
+    size_t fb = (size_t)width * nchannels;
+    size_t in_bytes = in_frames * fb, out_bytes = nout * fb;
+    size_t in_pad = (in_bytes + 255) & ~size_t(255);
+    rc = sh::ensure_scratch(in_pad + out_bytes);
+    if (rc) return rc;
+    char* s = (char*)sh::state().scratch;
+    hipStream_t st = sh::state().stream;
+    SH_HIP(hipMemcpyAsync(s, in, in_bytes, hipMemcpyHostToDevice, st));
+    rc = resample_dev(s, in_frames, nchannels, width, is_float, inrate, outrate, s + in_pad, nout);
+    if (rc) return rc;
+    SH_HIP(hipMemcpyAsync(out, s + in_pad, out_bytes, hipMemcpyDeviceToHost, st));
+    SH_HIP(hipStreamSynchronize(st));
+    return SH_OK;
+}
+
+}  // extern "C"

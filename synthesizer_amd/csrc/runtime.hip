@@ -1,0 +1,221 @@
+// runtime.hip -- lifecycle, device buffers, timing and error plumbing of libsynthhip.so.
+#include "common.hpp"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace sh {
+
+static thread_local char g_err[512] = "";
+
+State& state() {
+    static State s;
+    return s;
+}
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_error(hipError_t e, const char* what) {
+    int code = (e == hipErrorOutOfMemory) ? SH_ERR_NOMEM : SH_ERR_HIP;
+    return set_error(code, "%s: %s", what, hipGetErrorString(e));
+}
+
+int ensure_scratch(size_t bytes) {
+    State& s = state();
+    if (s.scratch_bytes >= bytes) return SH_OK;
+    if (s.scratch) {
+        SH_HIP(hipStreamSynchronize(s.stream));
+        SH_HIP(hipFree(s.scratch));
+        s.scratch = nullptr;
+        s.scratch_bytes = 0;
+    }
+    size_t want = bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes;
+    SH_HIP(hipMalloc(&s.scratch, want));
+    s.scratch_bytes = want;
+    return SH_OK;
+}
+
+}  // namespace sh
+
+using sh::state;
+
+extern "C" {
+
+const char* sh_last_error(void) { return sh::g_err; }
+
+const char* sh_version(void) { return "synthhip 0.1 (gfx950)"; }
+
+int sh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sh_is_initialized(void) { return state().initialized ? 1 : 0; }
+
+int sh_init(int device) {
+    sh::State& s = state();
+    if (s.initialized) {
+        if (s.device == device) return SH_OK;
+        return sh::set_error(SH_ERR_INVALID, "already initialised on device %d", s.device);
+    }
+    int n = sh_device_count();
+    if (n <= 0) return sh::set_error(SH_ERR_NOTINIT, "no HIP device visible");
+    if (device < 0 || device >= n) return sh::set_error(SH_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    SH_HIP(hipSetDevice(device));
+    SH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    SH_HIP(hipEventCreate(&s.ev_start));
+    SH_HIP(hipEventCreate(&s.ev_stop));
+    SH_HIP(hipMalloc((void**)&s.flag, sizeof(int) * 16));
+    SH_HIP(hipHostMalloc((void**)&s.flag_host, sizeof(int) * 16, hipHostMallocDefault));
+    SH_HIP(hipMemsetAsync(s.flag, 0, sizeof(int) * 16, s.stream));
+    SH_HIP(hipStreamSynchronize(s.stream));
+    s.device = device;
+    s.initialized = true;
+    return SH_OK;
+}
+
+int sh_shutdown(void) {
+    sh::State& s = state();
+    if (!s.initialized) return SH_OK;
+    hipStreamSynchronize(s.stream);
+    if (s.scratch) hipFree(s.scratch);
+    if (s.flag) hipFree(s.flag);
+    if (s.flag_host) hipHostFree(s.flag_host);
+    hipEventDestroy(s.ev_start);
+    hipEventDestroy(s.ev_stop);
+    hipStreamDestroy(s.stream);
+    s = sh::State();
+    return SH_OK;
+}
+
+int sh_device_info(sh_devinfo* out) {
+    SH_REQUIRE_INIT();
+    if (!out) return sh::set_error(SH_ERR_INVALID, "out is NULL");
+    hipDeviceProp_t p;
+    SH_HIP(hipGetDeviceProperties(&p, state().device));
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", p.name);
+    snprintf(out->arch, sizeof(out->arch), "%s", p.gcnArchName);
+    out->compute_units = p.multiProcessorCount;
+    out->clock_mhz = p.clockRate / 1000;
+    out->hbm_bytes = p.totalGlobalMem;
+    out->wavefront = p.warpSize;
+    out->device = state().device;
+    return SH_OK;
+}
+
+int sh_sync(void) {
+    SH_REQUIRE_INIT();
+    SH_HIP(hipStreamSynchronize(state().stream));
+    return SH_OK;
+}
+
+// ---- buffers -----------------------------------------------------------------------
+
+int sh_buf_alloc(size_t bytes, sh_buf** out) {
+    SH_REQUIRE_INIT();
+    if (!out) return sh::set_error(SH_ERR_INVALID, "out is NULL");
+    sh_buf* b = new (std::nothrow) sh_buf;
+    if (!b) return sh::set_error(SH_ERR_NOMEM, "host allocation failed");
+    b->ptr = nullptr;
+    b->bytes = bytes;
+    if (bytes) {
+        hipError_t e = hipMalloc(&b->ptr, bytes);
+        if (e != hipSuccess) {
+            delete b;
+            return sh::hip_error(e, "hipMalloc");
+        }
+    }
+    *out = b;
+    return SH_OK;
+}
+
+int sh_buf_free(sh_buf* b) {
+    if (!b) return SH_OK;
+    if (b->ptr && state().initialized) {
+        hipStreamSynchronize(state().stream);
+        hipFree(b->ptr);
+    }
+    delete b;
+    return SH_OK;
+}
+
+size_t sh_buf_size(const sh_buf* b) { return b ? b->bytes : 0; }
+void*  sh_buf_devptr(sh_buf* b) { return b ? b->ptr : nullptr; }
+
+static int check_range(const sh_buf* b, size_t off, size_t bytes, const char* what) {
+    if (!b) return sh::set_error(SH_ERR_INVALID, "%s: buffer is NULL", what);
+    if (off > b->bytes || bytes > b->bytes - off)
+        return sh::set_error(SH_ERR_INVALID, "%s: range [%zu, +%zu) outside buffer of %zu bytes", what, off, bytes, b->bytes);
+    return SH_OK;
+}
+
+int sh_buf_upload(sh_buf* b, size_t offset, const void* host, size_t bytes) {
+    SH_REQUIRE_INIT();
+    int rc = check_range(b, offset, bytes, "sh_buf_upload");
+    if (rc) return rc;
+    if (!bytes) return SH_OK;
+    if (!host) return sh::set_error(SH_ERR_INVALID, "host pointer is NULL");
+    SH_HIP(hipMemcpyAsync((char*)b->ptr + offset, host, bytes, hipMemcpyHostToDevice, state().stream));
+    SH_HIP(hipStreamSynchronize(state().stream));
+    return SH_OK;
+}
+
+int sh_buf_download(const sh_buf* b, size_t offset, void* host, size_t bytes) {
+    SH_REQUIRE_INIT();
+    int rc = check_range(b, offset, bytes, "sh_buf_download");
+    if (rc) return rc;
+    if (!bytes) return SH_OK;
+    if (!host) return sh::set_error(SH_ERR_INVALID, "host pointer is NULL");
+    SH_HIP(hipMemcpyAsync(host, (const char*)b->ptr + offset, bytes, hipMemcpyDeviceToHost, state().stream));
+    SH_HIP(hipStreamSynchronize(state().stream));
+    return SH_OK;
+}
+
+int sh_buf_fill_zero(sh_buf* b, size_t offset, size_t bytes) {
+    SH_REQUIRE_INIT();
+    int rc = check_range(b, offset, bytes, "sh_buf_fill_zero");
+    if (rc) return rc;
+    if (!bytes) return SH_OK;
+    SH_HIP(hipMemsetAsync((char*)b->ptr + offset, 0, bytes, state().stream));
+    return SH_OK;
+}
+
+int sh_buf_copy(sh_buf* dst, size_t dst_off, const sh_buf* src, size_t src_off, size_t bytes) {
+    SH_REQUIRE_INIT();
+    int rc = check_range(dst, dst_off, bytes, "sh_buf_copy(dst)");
+    if (rc) return rc;
+    rc = check_range(src, src_off, bytes, "sh_buf_copy(src)");
+    if (rc) return rc;
+    if (!bytes) return SH_OK;
+    SH_HIP(hipMemcpyAsync((char*)dst->ptr + dst_off, (const char*)src->ptr + src_off, bytes,
+                          hipMemcpyDeviceToDevice, state().stream));
+    return SH_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------
+
+int sh_timer_start(void) {
+    SH_REQUIRE_INIT();
+    SH_HIP(hipEventRecord(state().ev_start, state().stream));
+    return SH_OK;
+}
+
+int sh_timer_stop(float* elapsed_ms) {
+    SH_REQUIRE_INIT();
+    SH_HIP(hipEventRecord(state().ev_stop, state().stream));
+    SH_HIP(hipEventSynchronize(state().ev_stop));
+    float ms = 0.f;
+    SH_HIP(hipEventElapsedTime(&ms, state().ev_start, state().ev_stop));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return SH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+"""
+Voice sharding across the GPUs of one node.
+
+Voices are independent until the sum, so the voice table is partitioned contiguously over the
+ranks (one process per GPU); every rank renders the float64 partial stereo bus of its shard for the
+same frame range and the partial buses are summed by RCCL over xGMI (``ncclReduce``, float64, root
+0) -- the only collective on the path.  The reference is single-process: this is new work asked for
+by BASELINE.json, not a translation of anything upstream.
+
+Rendezvous: rank 0 creates the ``ncclUniqueId`` and broadcasts its 128 bytes through whatever
+channel the launcher provides -- ``torch.distributed`` when the process group is up (bench.py under
+torchrun), else a tiny TCP exchange on MASTER_ADDR:MASTER_PORT+1.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import socket
+import time
+from typing import Callable, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+__all__ = ["shard_range", "shard_sizes", "init_from_env", "init", "shutdown", "DistVoiceBank"]
+
+
+def shard_sizes(nvoices: int, world: int) -> list:
+    """Voices per rank: contiguous blocks, the first ``nvoices % world`` ranks get one extra."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    base, extra = divmod(nvoices, world)
+    return [base + (1 if r < extra else 0) for r in range(world)]
+
+
+def shard_range(nvoices: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of the voice table owned by ``rank``."""
+    if not 0 <= rank < world:
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    sizes = shard_sizes(nvoices, world)
+    lo = sum(sizes[:rank])
+    return lo, lo + sizes[rank]
+
+
+# -- rendezvous ----------------------------------------------------------------------------------
+
+def _tcp_broadcast(payload: Optional[bytes], rank: int, world: int, nbytes: int) -> bytes:
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("SYNTHHIP_RDZV_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((host, port))
+        srv.listen(world)
+        for _ in range(world - 1):
+            conn, _addr = srv.accept()
+            conn.sendall(payload)
+            conn.close()
+        srv.close()
+        return payload
+    deadline = time.time() + 120
+    while True:
+        try:
+            c = socket.create_connection((host, port), timeout=5)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise
+            time.sleep(0.1)
+    data = b""
+    while len(data) < nbytes:
+        chunk = c.recv(nbytes - len(data))
+        if not chunk:
+            raise ConnectionError("rendezvous closed early")
+        data += chunk
+    c.close()
+    return data
+
+
+def _torch_broadcast(payload: Optional[bytes], rank: int, world: int, nbytes: int) -> bytes:
+    import torch
+    import torch.distributed as td
+    t = torch.zeros(nbytes, dtype=torch.uint8)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+    if td.get_backend() == "nccl":
+        t = t.cuda()
+    td.broadcast(t, src=0)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+def init(rank: int, world: int, broadcast: Optional[Callable[[Optional[bytes], int, int, int], bytes]] = None) -> None:
+    """Create the RCCL communicator on this process's GPU (sh_init must select the right device first)."""
+    N.ensure_init()
+    L = N.lib()
+    if broadcast is None:
+        broadcast = _tcp_broadcast
+        try:
+            import sys
+            if "torch" in sys.modules:
+                import torch.distributed as td
+                if td.is_available() and td.is_initialized():
+                    broadcast = _torch_broadcast
+        except Exception:
+            pass
+    payload = None
+    if rank == 0:
+        buf = (C.c_char * N.SH_DIST_ID_BYTES)()
+        N.check(L.sh_dist_unique_id(buf))
+        payload = bytes(buf.raw)
+    ident = broadcast(payload, rank, world, N.SH_DIST_ID_BYTES)
+    raw = (C.c_char * N.SH_DIST_ID_BYTES).from_buffer_copy(ident)
+    N.check(L.sh_dist_init(rank, world, raw))
+
+
+def init_from_env() -> Tuple[int, int]:
+    """RANK / WORLD_SIZE / LOCAL_RANK as set by torchrun; selects GPU LOCAL_RANK."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    N.ensure_init(local)
+    if world > 1:
+        init(rank, world)
+    return rank, world
+
+
+def shutdown() -> None:
+    N.check(N.lib().sh_dist_shutdown())
+
+
+class DistVoiceBank:
+    """This rank's shard of a voice table + the reduce of the partial buses."""
+
+    def __init__(self, voices: Sequence, gains: Sequence[Tuple[float, float]], rank: int, world: int) -> None:
+        from .mixer import VoiceBank
+        self.rank, self.world = rank, world
+        self.total_voices = len(voices)
+        lo, hi = shard_range(len(voices), rank, world)
+        self.lo, self.hi = lo, hi
+        if hi <= lo:
+            raise ValueError("rank %d owns no voices (%d voices over %d ranks)" % (rank, len(voices), world))
+        self.local = VoiceBank(list(voices[lo:hi]), gains=list(gains[lo:hi]))
+        self._bus64: Optional[N.DeviceBuffer] = None
+        self._bus32: Optional[N.DeviceBuffer] = None
+        self._cap = 0
+
+    def _buffers(self, nframes: int) -> None:
+        if nframes > self._cap:
+            self._bus64 = N.DeviceBuffer(nframes * 16)
+            self._bus32 = N.DeviceBuffer(nframes * 8)
+            self._cap = nframes
+
+    def render_device(self, nframes: int, start: int = 0, root: int = 0) -> N.DeviceBuffer:
+        """Render the shard, reduce to ``root``; returns the float32 bus buffer (valid on root)."""
+        self._buffers(nframes)
+        L = N.lib()
+        self.local.render_device(nframes, start, bus_f32=None, bus_f64=self._bus64)
+        if self.world > 1:
+            N.check(L.sh_dist_reduce_bus(self._bus64.handle, nframes * 2, root))
+        if self.world == 1 or self.rank == root:
+            N.check(L.sh_bus_finalize(self._bus64.handle, nframes * 2, self._bus32.handle))
+        return self._bus32
+
+    def render(self, nframes: int, start: int = 0, root: int = 0) -> Optional[np.ndarray]:
+        buf = self.render_device(nframes, start, root)
+        N.sync()
+        if self.rank != root and self.world > 1:
+            return None
+        return buf.download(np.float32, nframes * 2).reshape(nframes, 2)

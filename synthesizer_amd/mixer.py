@@ -1,0 +1,191 @@
+"""
+The mixer sum bus.
+
+Two shapes of the same operation:
+
+* ``VoiceBank``: N oscillator voices (the classes of oscillators.py) -> stereo bus.  The voice table
+  lives in HBM; ``render`` runs the fused generate-and-mix kernel (no per-voice PCM ever reaches
+  HBM), ``generate`` + ``mix_bus`` is the reference-shaped two-step form (voices materialised as
+  float32 PCM, then summed) whose mix step is HBM-bound.
+* ``mix_samples``: the reference's real-time mixer rule over integer PCM chunks (upstream
+  playback.py mixer loop: ``mixed = audioop.add(mixed, chunk, width)`` for every active voice, in
+  order) -- an order-dependent chain of saturating adds, reproduced bit-exactly.
+
+``pan`` follows the linear law used throughout: gain_l = (1 - pan) / 2, gain_r = (1 + pan) / 2.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+from .oscillators import Oscillator, pack_voices
+from .sample import Sample
+
+__all__ = ["VoiceBank", "mix_samples", "pan_gains"]
+
+
+def pan_gains(pan: float) -> Tuple[float, float]:
+    return (1.0 - pan) / 2.0, (1.0 + pan) / 2.0
+
+
+class VoiceBank:
+    """N oscillator voices summed to one stereo bus on the GPU."""
+
+    def __init__(self, voices: Sequence[Oscillator], gains: Optional[Sequence[Tuple[float, float]]] = None,
+                 pans: Optional[Sequence[float]] = None) -> None:
+        if not voices:
+            raise ValueError("a voice bank needs at least one voice")
+        if gains is not None and pans is not None:
+            raise ValueError("give gains or pans, not both")
+        if pans is not None:
+            gains = [pan_gains(p) for p in pans]
+        if gains is None:
+            gains = [(1.0, 1.0)] * len(voices)
+        if len(gains) != len(voices):
+            raise ValueError("one (left, right) gain pair per voice")
+        rates = {v.samplerate for v in voices}
+        if len(rates) != 1:
+            raise ValueError("all voices of a bank must share one sample rate")
+        self.samplerate = rates.pop()
+        self.nvoices = len(voices)
+        self.gains = [(float(l), float(r)) for l, r in gains]
+        specs = [v.spec() for v in voices]
+        for i, s in enumerate(specs):
+            if s.fm_mode == N.SH_FM_BUFFER or s.needs_pwm:
+                raise NotImplementedError(
+                    "voice %d is modulated by a non-Sine oscillator; banks take closed-form modulators only "
+                    "(render such a voice on its own with Oscillator.render)" % i)
+        self._packed = pack_voices(specs, self.gains)
+        self._bank = N.Bank(*self._packed)
+        self._gains_dev: Optional[N.DeviceBuffer] = None
+
+    # -- fused path ------------------------------------------------------------------------------
+    def render_device(self, nframes: int, start: int = 0, bus_f32: Optional[N.DeviceBuffer] = None,
+                      bus_f64: Optional[N.DeviceBuffer] = None) -> N.DeviceBuffer:
+        """Fused generate-and-mix into device buffers (float32 frames x 2 and/or float64 frames x 2)."""
+        if bus_f32 is None and bus_f64 is None:
+            bus_f32 = N.DeviceBuffer(nframes * 8)
+        N.check(N.lib().sh_bank_render(self._bank.handle, start, nframes,
+                                       bus_f32.handle if bus_f32 is not None else None,
+                                       bus_f64.handle if bus_f64 is not None else None))
+        return bus_f32 if bus_f32 is not None else bus_f64
+
+    def render(self, nframes: int, start: int = 0) -> np.ndarray:
+        """Stereo bus as a [nframes, 2] float32 array."""
+        if nframes == 0:
+            return np.zeros((0, 2), dtype=np.float32)
+        buf = self.render_device(nframes, start)
+        out = buf.download(np.float32, nframes * 2).reshape(nframes, 2)
+        buf.free()
+        return out
+
+    def render_sample(self, nframes: int, start: int = 0, scale: float = 32767.0) -> Sample:
+        """Stereo bus quantised to an int16 Sample (saturating: a bus can exceed full scale)."""
+        s = Sample(samplerate=self.samplerate, nchannels=2, samplewidth=2)
+        if nframes == 0:
+            return s
+        bus = self.render_device(nframes, start)
+        pcm = N.DeviceBuffer(nframes * 4)
+        N.check(N.lib().sh_quantize_clip_f32(bus.handle, nframes * 2, float(scale), pcm.handle))
+        N.sync()
+        bus.free()
+        s._set_device(pcm, nframes * 4)
+        return s
+
+    # -- two-step (reference-shaped) path -----------------------------------------------------------
+    def generate_device(self, nframes: int, start: int = 0, out: Optional[N.DeviceBuffer] = None,
+                        stride: Optional[int] = None) -> N.DeviceBuffer:
+        """Every voice as float32 PCM in HBM, voice-major: out[v*stride + i]."""
+        stride = nframes if stride is None else stride
+        if out is None:
+            out = N.DeviceBuffer(self.nvoices * stride * 4)
+        N.check(N.lib().sh_bank_generate(self._bank.handle, start, nframes, out.handle, stride))
+        return out
+
+    def generate(self, nframes: int, start: int = 0) -> np.ndarray:
+        buf = self.generate_device(nframes, start)
+        out = buf.download(np.float32, self.nvoices * nframes).reshape(self.nvoices, nframes)
+        buf.free()
+        return out
+
+    def gains_device(self) -> N.DeviceBuffer:
+        if self._gains_dev is None:
+            self._gains_dev = N.DeviceBuffer.from_array(np.asarray(self.gains, dtype=np.float32).reshape(-1))
+        return self._gains_dev
+
+    def mix_device(self, voices: N.DeviceBuffer, nframes: int, stride: Optional[int] = None,
+                   bus_f32: Optional[N.DeviceBuffer] = None) -> N.DeviceBuffer:
+        """Sum materialised voices to the stereo bus (HBM-bound: 4*N + 8 bytes per frame)."""
+        stride = nframes if stride is None else stride
+        if bus_f32 is None:
+            bus_f32 = N.DeviceBuffer(nframes * 8)
+        N.check(N.lib().sh_mix_bus_f32(voices.handle, self.nvoices, stride, nframes,
+                                       self.gains_device().handle, bus_f32.handle))
+        return bus_f32
+
+    def render_two_step(self, nframes: int, start: int = 0) -> np.ndarray:
+        v = self.generate_device(nframes, start)
+        bus = self.mix_device(v, nframes)
+        out = bus.download(np.float32, nframes * 2).reshape(nframes, 2)
+        v.free()
+        bus.free()
+        return out
+
+
+def mix_bus(voices: np.ndarray, gains: Sequence[Tuple[float, float]]) -> np.ndarray:
+    """[nvoices, nframes] float32 voices -> [nframes, 2] float32 bus (host arrays in and out)."""
+    voices = np.ascontiguousarray(voices, dtype=np.float32)
+    nv, nf = voices.shape
+    vb = N.DeviceBuffer.from_array(voices)
+    gb = N.DeviceBuffer.from_array(np.asarray(gains, dtype=np.float32).reshape(-1))
+    bus = N.DeviceBuffer(max(nf, 1) * 8)
+    N.check(N.lib().sh_mix_bus_f32(vb.handle, nv, nf, nf, gb.handle, bus.handle))
+    out = bus.download(np.float32, nf * 2).reshape(nf, 2)
+    for b in (vb, gb, bus):
+        b.free()
+    return out
+
+
+def mix_samples(samples: Sequence[Sample], name: str = "mix") -> Sample:
+    """The real-time mixer's fold over whole samples: pad every voice with silence to the longest,
+    then ``mixed = add(mixed, voice)`` in the given order, saturating at every step."""
+    if not samples:
+        raise ValueError("nothing to mix")
+    first = samples[0]
+    for s in samples[1:]:
+        assert s.samplewidth == first.samplewidth and s.samplerate == first.samplerate and s.nchannels == first.nchannels
+    width = first.samplewidth
+    nbytes = max(len(s) for s in samples) * width * first.nchannels
+    out = Sample(name=name, samplerate=first.samplerate, nchannels=first.nchannels, samplewidth=width)
+    if nbytes == 0:
+        return out
+    L = N.lib()
+    if width == 2:
+        nsamples = nbytes // 2
+        stride = (nsamples + 7) // 8 * 8                  # 16-byte aligned rows
+        chunks = N.DeviceBuffer(len(samples) * stride * 2)
+        chunks.zero()
+        for i, s in enumerate(samples):
+            n = len(s) * width * s.nchannels
+            if n:
+                N.check(L.sh_buf_copy(chunks.handle, i * stride * 2, s._device().handle, 0, n))
+        dst = N.DeviceBuffer(nbytes)
+        N.check(L.sh_mix_chain_i16(chunks.handle, len(samples), stride, nsamples, dst.handle))
+        N.sync()
+        chunks.free()
+        out._set_device(dst, nbytes)
+        return out
+    # other widths: the literal chain of pairwise saturating adds
+    acc = N.DeviceBuffer(nbytes)
+    acc.zero()
+    n0 = len(first) * width * first.nchannels
+    if n0:
+        N.check(L.sh_buf_copy(acc.handle, 0, first._device().handle, 0, n0))
+    for s in samples[1:]:
+        n = len(s) * width * s.nchannels
+        if n:
+            N.check(L.sh_pcm_add(acc.handle, 0, s._device().handle, 0, n, width, acc.handle, 0))
+    out._set_device(acc, nbytes)
+    return out

@@ -1,0 +1,474 @@
+"""
+Oscillators with the synthplayer API, rendered by HIP kernels on an MI355X.
+
+Drop-in for the hot-path subset of upstream ``synthplayer/oscillators.py`` (tree not mounted at
+/root/reference): ``Sine``, ``Sawtooth``, ``Square``, ``Pulse``, ``Harmonics`` with
+``fm_lfo=`` / ``pwm_lfo=``, and ``EnvelopeFilter``.  Same constructor signatures, same ``blocks()``
+generator protocol (lists of ``params.norm_osc_blocksize`` Python floats).  The samples are computed
+on the GPU -- one thread per output sample -- through libsynthhip.so; there is no CPU path.
+
+Host code here only *describes* a voice: it evaluates the same float64 expressions the reference
+evaluates once per oscillator (increment, start phase, envelope slopes), turns the running sums the
+reference carries per sample into exact tables (phasetable.py) and packs everything into the
+``sh_voice`` record the kernels read.
+
+Beyond the reference API each oscillator has ``render(nframes, start=None) -> numpy float32`` (bulk,
+no Python-level per-sample work) and can be put in a ``mixer.VoiceBank``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field, replace
+from functools import lru_cache
+from math import pi, sin, cos
+from typing import Dict, Generator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import params
+from . import _native as N
+from .phasetable import PhaseTable
+
+__all__ = ["Oscillator", "Sine", "Sawtooth", "Square", "Pulse", "Harmonics", "EnvelopeFilter"]
+
+_SUPERBLOCK = 128          # blocks rendered per kernel launch behind blocks()
+_DENSE_MAX_K = 4096        # Harmonics: use the Clenshaw (dense) form when max k <= min(this, 8*len+64)
+
+
+@lru_cache(maxsize=4096)
+def _table(t0: float, inc: float) -> PhaseTable:
+    return PhaseTable(t0, inc)
+
+
+@dataclass
+class EnvelopeSpec:
+    n_attack_end: int
+    n_decay_end: int
+    n_sustain_end: int
+    n_release_end: int
+    attack_slope: float
+    decay_slope: float
+    sustain_level: float
+    release_slope: float
+    tail_amp: float
+    has_tail: bool
+    stop_at_end: bool
+
+    @property
+    def length(self) -> int:
+        return self.n_release_end + (1 if self.has_tail else 0)
+
+
+def envelope_spec(attack: float, decay: float, sustain: float, sustain_level: float, release: float,
+                  samplerate: int, stop_at_end: bool = False) -> EnvelopeSpec:
+    """Replay EnvelopeFilter's accumulated ``time`` exactly and return the sample indices at which
+    its four ``while time < ...`` loops end (upstream: oscillators.py EnvelopeFilter)."""
+    increment = 1.0 / samplerate
+    tt = _table(0.0, increment)
+
+    def first_ge(x: float) -> int:
+        return 0 if x <= 0.0 else tt.first_index_ge(x)
+
+    end_time_decay = attack + decay
+    end_time_sustain = end_time_decay + sustain
+    end_time_release = end_time_sustain + release
+    n_a = first_ge(attack) if attack else 0
+    n_d = max(n_a, first_ge(end_time_decay)) if decay else n_a
+    n_s = max(n_d, first_ge(end_time_sustain))
+    attack_slope = 1.0 / attack * increment if attack else 0.0
+    decay_slope = (sustain_level - 1.0) / decay * increment if decay else 0.0
+    release_slope = 0.0
+    tail_amp = 0.0
+    has_tail = False
+    n_r = n_s
+    if release:
+        release_slope = (-sustain_level) / release * increment
+        n_r = max(n_s, first_ge(end_time_release))
+        # the reference's accumulated amp after the release loop decides the extra sample
+        tail_amp = _table(sustain_level, release_slope).value(n_r - n_s)
+        has_tail = tail_amp > 0.0
+    return EnvelopeSpec(n_a, n_d, n_s, n_r, attack_slope, decay_slope, sustain_level, release_slope,
+                        tail_amp, has_tail, stop_at_end)
+
+
+@dataclass
+class VoiceSpec:
+    kind: int
+    amplitude: float
+    bias: float
+    pulsewidth: float = 0.0
+    fm_mode: int = N.SH_FM_NONE
+    carrier: Optional[PhaseTable] = None          # SH_FM_NONE
+    time_table: Optional[PhaseTable] = None       # FM
+    frequency: float = 0.0
+    fm_phase0: float = 0.0
+    fm_inc: float = 0.0
+    lfo: Tuple[float, float, float, float, float, float] = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)  # a, d, amp, bias, K, C0
+    harm_dense: Optional[Tuple[float, ...]] = None      # Clenshaw coefficients, k = K..1, len % 8 == 0
+    harm_sparse: Optional[Tuple[Tuple[float, float], ...]] = None
+    env: Optional[EnvelopeSpec] = None
+    needs_pwm: bool = False
+
+
+def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float, float]]] = None):
+    """VoiceSpec list -> (voices, segs, coefs, partials) arrays in the C layout.  Tables and harmonic
+    lists shared by several voices are stored once."""
+    voices = np.zeros(len(specs), dtype=N.VOICE_DTYPE)
+    seg_chunks: List[np.ndarray] = []
+    seg_index: Dict[int, Tuple[int, int]] = {}
+    nsegs = 0
+    coef_list: List[float] = []
+    coef_index: Dict[Tuple[float, ...], int] = {}
+    part_list: List[Tuple[float, float]] = []
+    part_index: Dict[Tuple[Tuple[float, float], ...], int] = {}
+
+    def add_table(tab: PhaseTable) -> Tuple[int, int]:
+        nonlocal nsegs
+        key = id(tab)
+        if key not in seg_index:
+            arr = np.zeros(len(tab.segments), dtype=N.SEGMENT_DTYPE)
+            for i, (n0, t0, dt) in enumerate(tab.segments):
+                arr[i] = (n0, t0, dt)
+            seg_index[key] = (nsegs, len(arr))
+            seg_chunks.append(arr)
+            nsegs += len(arr)
+        return seg_index[key]
+
+    for i, s in enumerate(specs):
+        v = voices[i]
+        v["kind"] = s.kind
+        v["fm_mode"] = s.fm_mode
+        v["amplitude"] = s.amplitude
+        v["bias"] = s.bias
+        v["pulsewidth"] = s.pulsewidth
+        if s.fm_mode == N.SH_FM_NONE:
+            v["seg_offset"], v["seg_count"] = add_table(s.carrier)
+        else:
+            v["time_seg_offset"], v["time_seg_count"] = add_table(s.time_table)
+            v["frequency"] = s.frequency
+            v["fm_phase0"] = s.fm_phase0
+            v["fm_inc"] = s.fm_inc
+            (v["lfo_a"], v["lfo_d"], v["lfo_amp"], v["lfo_bias"], v["lfo_K"], v["lfo_C0"]) = s.lfo
+        if s.harm_dense is not None:
+            if s.harm_dense not in coef_index:
+                coef_index[s.harm_dense] = len(coef_list)
+                coef_list.extend(s.harm_dense)
+            v["harm_offset"] = coef_index[s.harm_dense]
+            v["harm_count"] = len(s.harm_dense)
+            v["harm_dense"] = 1
+        elif s.harm_sparse is not None:
+            if s.harm_sparse not in part_index:
+                part_index[s.harm_sparse] = len(part_list)
+                part_list.extend(s.harm_sparse)
+            v["harm_offset"] = part_index[s.harm_sparse]
+            v["harm_count"] = len(s.harm_sparse)
+            v["harm_dense"] = 0
+        if s.env is not None:
+            e = v["env"]
+            e["n_attack_end"], e["n_decay_end"] = s.env.n_attack_end, s.env.n_decay_end
+            e["n_sustain_end"], e["n_release_end"] = s.env.n_sustain_end, s.env.n_release_end
+            e["attack_slope"], e["decay_slope"] = s.env.attack_slope, s.env.decay_slope
+            e["sustain_level"], e["release_slope"] = s.env.sustain_level, s.env.release_slope
+            e["tail_amp"] = s.env.tail_amp
+            e["enabled"] = 1
+            e["has_tail"] = 1 if s.env.has_tail else 0
+        gl, gr = (1.0, 1.0) if gains is None else gains[i]
+        v["gain_l"], v["gain_r"] = gl, gr
+    segs = np.concatenate(seg_chunks) if seg_chunks else np.zeros(0, dtype=N.SEGMENT_DTYPE)
+    coefs = np.array(coef_list, dtype=np.float64)
+    partials = np.zeros(len(part_list), dtype=N.PARTIAL_DTYPE)
+    for i, (k, a) in enumerate(part_list):
+        partials[i] = (k, a)
+    return voices, segs, coefs, partials
+
+
+class Oscillator:
+    """Oscillator base class (upstream: oscillators.py class Oscillator)."""
+
+    def __init__(self, samplerate: int = 0) -> None:
+        self.samplerate = samplerate or params.norm_samplerate
+        self._bank: Optional[N.Bank] = None
+        self._spec_cache: Optional[VoiceSpec] = None
+        self._pos = 0                 # next sample index for render() without start / blocks()
+        self._fm_pos = 0              # general FM: running LFO sum up to _fm_pos
+        self._fm_carry = 0.0
+
+    # -- description ----------------------------------------------------------------------------
+    def _make_spec(self) -> VoiceSpec:
+        raise NotImplementedError
+
+    def _fm_source(self) -> Optional["Oscillator"]:
+        return getattr(self, "fm", None)
+
+    def _pwm_source(self) -> Optional["Oscillator"]:
+        return getattr(self, "pwm", None)
+
+    def spec(self) -> VoiceSpec:
+        if self._spec_cache is None:
+            self._spec_cache = self._make_spec()
+        return self._spec_cache
+
+    @property
+    def length(self) -> Optional[int]:
+        """Number of samples the stream has, or None when infinite (EnvelopeFilter stop_at_end)."""
+        s = self.spec()
+        if s.env is not None and s.env.stop_at_end:
+            return s.env.length
+        return None
+
+    def _get_bank(self) -> N.Bank:
+        if self._bank is None:
+            self._bank = N.Bank(*pack_voices([self.spec()]))
+        return self._bank
+
+    # -- rendering ------------------------------------------------------------------------------
+    def _fm_cumsum(self, start: int, n: int) -> N.DeviceBuffer:
+        """L(start) .. L(start+n-1) on the device for an arbitrary fm_lfo (sequential access)."""
+        lfo = self._fm_source()
+        if start != self._fm_pos:
+            if start < self._fm_pos:
+                self._fm_pos, self._fm_carry = 0, 0.0
+            while self._fm_pos < start:          # catch up (random access into a recurrence)
+                step = min(1 << 20, start - self._fm_pos)
+                self._advance_fm(lfo, self._fm_pos, step, keep=False)
+        return self._advance_fm(lfo, start, n, keep=True)
+
+    def _advance_fm(self, lfo: "Oscillator", start: int, n: int, keep: bool) -> Optional[N.DeviceBuffer]:
+        mod = lfo._render_f64_device(start, n)
+        cum = N.DeviceBuffer(n * 8)
+        carry = C.c_double()
+        N.check(N.lib().sh_scan_f64(mod.handle, n, self._fm_carry, cum.handle, C.byref(carry)))
+        self._fm_pos, self._fm_carry = start + n, carry.value
+        mod.free()
+        if keep:
+            return cum
+        cum.free()
+        return None
+
+    def _render_device(self, start: int, n: int, out_host: Optional[np.ndarray] = None,
+                       out_f32: Optional[N.DeviceBuffer] = None, out_off: int = 0,
+                       out_f64: Optional[N.DeviceBuffer] = None) -> None:
+        s = self.spec()
+        bank = self._get_bank()
+        fm_buf = self._fm_cumsum(start, n) if s.fm_mode == N.SH_FM_BUFFER else None
+        pwm_buf = None
+        if s.needs_pwm:
+            pwm_buf = self._pwm_source()._render_f64_device(start, n)
+        N.check(N.lib().sh_osc_render(
+            bank.handle, 0,
+            fm_buf.handle if fm_buf else None, pwm_buf.handle if pwm_buf else None,
+            start, n,
+            out_host.ctypes.data if out_host is not None else None,
+            out_f32.handle if out_f32 is not None else None, out_off,
+            out_f64.handle if out_f64 is not None else None))
+        if fm_buf is not None or pwm_buf is not None:
+            N.sync()
+            if fm_buf is not None:
+                fm_buf.free()
+            if pwm_buf is not None:
+                pwm_buf.free()
+
+    def _render_f64_device(self, start: int, n: int) -> N.DeviceBuffer:
+        """This oscillator's samples as float64 in HBM (it is someone's modulator)."""
+        out = N.DeviceBuffer(n * 8)
+        limit = self.length
+        if limit is not None and start + n > limit:
+            raise ValueError("modulator stream ended (stop_at_end) before the carrier")
+        self._render_device(start, n, out_f64=out)
+        return out
+
+    def render(self, nframes: int, start: Optional[int] = None) -> np.ndarray:
+        """Samples [start, start+nframes) as float32 (truncated at the end of a finite stream)."""
+        if start is None:
+            start = self._pos
+        limit = self.length
+        if limit is not None:
+            nframes = max(0, min(nframes, limit - start))
+        out = np.empty(nframes, dtype=np.float32)
+        if nframes:
+            self._render_device(start, nframes, out_host=out)
+        self._pos = start + nframes
+        return out
+
+    def render_to(self, buf: N.DeviceBuffer, offset: int, nframes: int, start: int) -> None:
+        """Samples into an existing float32 device buffer at element ``offset`` (no host copy)."""
+        if nframes:
+            self._render_device(start, nframes, out_f32=buf, out_off=offset)
+
+    def blocks(self) -> Generator[List[float], None, None]:
+        """Upstream protocol: an endless (or, with stop_at_end, finite) stream of blocks."""
+        bs = params.norm_osc_blocksize
+        pos = 0
+        limit = self.length
+        while True:
+            want = bs * _SUPERBLOCK
+            if limit is not None:
+                want = min(want, limit - pos)
+                if want <= 0:
+                    return
+            chunk = self.render(want, start=pos)
+            pos += len(chunk)
+            values = chunk.tolist()
+            for i in range(0, len(values), bs):
+                yield values[i:i + bs]
+
+    def __iter__(self):
+        return self.blocks()
+
+
+def _closed_form_lfo(lfo: Optional[Oscillator]) -> bool:
+    return type(lfo) is Sine and lfo.fm is None
+
+
+class _Carrier(Oscillator):
+    """Shared constructor/state of the five waveform oscillators."""
+
+    KIND = -1
+    RADIANS = False        # Sine/Harmonics keep t in radians, the others in turns
+
+    def __init__(self, frequency: float, amplitude: float = 1.0, phase: float = 0.0, bias: float = 0.0,
+                 fm_lfo: Optional[Oscillator] = None, samplerate: int = 0) -> None:
+        super().__init__(samplerate)
+        self.frequency = frequency
+        self.amplitude = amplitude
+        self.bias = bias
+        self.fm = fm_lfo
+        self._phase = phase
+
+    def _phase_fields(self, force_fm: bool = False) -> dict:
+        """Phase bookkeeping: the expressions of the reference's blocks() preamble."""
+        sr = self.samplerate
+        if self.fm or force_fm:
+            if self.RADIANS:
+                phase0, inc = self._phase * 2.0 * pi, 2.0 * pi / sr
+            else:
+                phase0, inc = self._phase, 1.0 / sr
+            out = dict(time_table=_table(0.0, inc), frequency=float(self.frequency), fm_phase0=phase0, fm_inc=inc)
+            lfo = self.fm
+            if lfo is None:
+                out.update(fm_mode=N.SH_FM_SINE, lfo=(0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
+            elif _closed_form_lfo(lfo):
+                a = lfo._phase * 2.0 * pi
+                d = 2.0 * pi * lfo.frequency / lfo.samplerate
+                half = sin(d / 2.0)
+                if half == 0.0 or lfo.amplitude == 0.0:
+                    # constant LFO: L(n) = c*n
+                    c = sin(a) * lfo.amplitude + lfo.bias
+                    out.update(fm_mode=N.SH_FM_SINE, lfo=(a, d, 0.0, c, 0.0, 0.0))
+                else:
+                    K = lfo.amplitude / (2.0 * half)
+                    out.update(fm_mode=N.SH_FM_SINE, lfo=(a, d, float(lfo.amplitude), float(lfo.bias), K, cos(a - d / 2.0)))
+            else:
+                out.update(fm_mode=N.SH_FM_BUFFER)
+            return out
+        if self.RADIANS:
+            increment = 2.0 * pi * self.frequency / sr
+            t0 = self._phase * 2.0 * pi
+        else:
+            increment = self.frequency / sr
+            t0 = self._phase
+        return dict(fm_mode=N.SH_FM_NONE, carrier=_table(t0, increment))
+
+    def _make_spec(self) -> VoiceSpec:
+        return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias), **self._phase_fields())
+
+
+class Sine(_Carrier):
+    """Sine wave oscillator (upstream: oscillators.py class Sine)."""
+    KIND = N.SH_SINE
+    RADIANS = True
+
+
+class Sawtooth(_Carrier):
+    """Sawtooth oscillator, naive form (upstream: oscillators.py class Sawtooth)."""
+    KIND = N.SH_SAWTOOTH
+
+
+class Square(_Carrier):
+    """Perfect square wave (upstream: oscillators.py class Square)."""
+    KIND = N.SH_SQUARE
+
+
+class Pulse(_Carrier):
+    """Pulse of a given width, optionally pulse-width modulated (upstream: oscillators.py class Pulse)."""
+    KIND = N.SH_PULSE
+
+    def __init__(self, frequency: float, amplitude: float = 1.0, phase: float = 0.0, pulsewidth: float = 0.1,
+                 bias: float = 0.0, fm_lfo: Optional[Oscillator] = None, pwm_lfo: Optional[Oscillator] = None,
+                 samplerate: int = 0) -> None:
+        assert 0 <= pulsewidth <= 1
+        super().__init__(frequency, amplitude, phase, bias, fm_lfo, samplerate)
+        self.pulsewidth = pulsewidth
+        self.pwm = pwm_lfo
+
+    def _make_spec(self) -> VoiceSpec:
+        # with a pwm_lfo (and no fm_lfo) the reference still runs its modulated loop: t += 1/sr, tt = t*f + phase
+        fields = self._phase_fields(force_fm=self.pwm is not None)
+        return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias),
+                         pulsewidth=float(self.pulsewidth), needs_pwm=self.pwm is not None, **fields)
+
+
+class Harmonics(_Carrier):
+    """Additive sine series sum_k a_k sin(k*t) (upstream: oscillators.py class Harmonics)."""
+    KIND = N.SH_HARMONICS
+    RADIANS = True
+
+    def __init__(self, frequency: float, harmonics: Sequence[Tuple[int, float]], amplitude: float = 1.0,
+                 phase: float = 0.0, bias: float = 0.0, fm_lfo: Optional[Oscillator] = None,
+                 samplerate: int = 0) -> None:
+        super().__init__(frequency, amplitude, phase, bias, fm_lfo, samplerate)
+        self.harmonics = list(harmonics)
+
+    def _make_spec(self) -> VoiceSpec:
+        dense = None
+        sparse = None
+        ks = [k for k, _ in self.harmonics]
+        integral = all(float(k) == int(k) for k in ks)
+        kmax = max((abs(int(k)) for k in ks), default=0) if integral else 0
+        if integral and 0 < kmax <= min(_DENSE_MAX_K, 8 * len(ks) + 64):
+            n = (kmax + 7) // 8 * 8
+            coef = [0.0] * (n + 1)                       # index k
+            for k, a in self.harmonics:
+                k = int(k)
+                if k > 0:
+                    coef[k] += float(a)
+                elif k < 0:
+                    coef[-k] -= float(a)                 # sin(-k t) = -sin(k t)
+            dense = tuple(coef[n:0:-1])                  # k = n .. 1
+        else:
+            sparse = tuple((float(k), float(a)) for k, a in self.harmonics)
+            if not sparse:
+                sparse = ((0.0, 0.0),)
+        return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias),
+                         harm_dense=dense, harm_sparse=sparse, **self._phase_fields())
+
+
+class EnvelopeFilter(Oscillator):
+    """ADSR volume envelope over an oscillator (upstream: oscillators.py class EnvelopeFilter).
+    A, D, S, R in seconds, sustain_level an amplitude factor.  Fused into the source's kernel."""
+
+    def __init__(self, source: Oscillator, attack: float, decay: float, sustain: float, sustain_level: float,
+                 release: float, stop_at_end: bool = False) -> None:
+        assert attack >= 0 and decay >= 0 and sustain >= 0 and release >= 0
+        assert 0 <= sustain_level <= 1
+        super().__init__(source.samplerate)
+        if not isinstance(source, _Carrier):
+            raise NotImplementedError("EnvelopeFilter is fused into Sine/Sawtooth/Square/Pulse/Harmonics sources only")
+        self._source = source
+        self._attack = attack
+        self._decay = decay
+        self._sustain = sustain
+        self._sustain_level = sustain_level
+        self._release = release
+        self._stop_at_end = stop_at_end
+
+    def _fm_source(self):
+        return self._source._fm_source()
+
+    def _pwm_source(self):
+        return self._source._pwm_source()
+
+    def _make_spec(self) -> VoiceSpec:
+        env = envelope_spec(self._attack, self._decay, self._sustain, self._sustain_level, self._release,
+                            self.samplerate, self._stop_at_end)
+        return replace(self._source.spec(), env=env)

@@ -1,0 +1,128 @@
+"""
+Exact closed form of a float64 running sum ``t += inc``.
+
+The reference oscillators (synthplayer/oscillators.py, every ``blocks()`` loop)
+never recompute the phase from the sample index: they carry ``t`` and add a
+constant increment once per sample, in float64.  The rounding of that addition
+is deterministic, and inside one binade [2^e, 2^(e+1)) it is *constant*: ``t``
+is a multiple of the binade's ulp ``u``, so ``fl(t + inc) = t + q*u`` with the
+same integer ``q`` for every step after the first one in the binade (a tie
+``inc mod u == u/2`` is resolved to the even neighbour, after which the parity
+of ``t/u`` and therefore the choice stays fixed).
+
+So the whole sequence t_0, t_1, ... is piecewise *exactly* linear in the sample
+index, with one piece per binade (plus a few single-step pieces where a binade
+is entered).  ``build_phase_table`` returns those pieces; a GPU thread that owns
+sample ``n`` evaluates ``fma(n - n0, dt, t0)`` on its piece and obtains the very
+same double the reference's sequential loop holds at that sample -- which is
+what decides the side of a Square/Pulse edge and the 1e-5 rad drift of a
+long-running Sine.
+
+Host logic only.  tests/test_phasetable.py checks the table against brute-force
+accumulation.
+"""
+from __future__ import annotations
+
+from bisect import bisect_right
+from fractions import Fraction
+from math import frexp, ceil, ldexp
+from typing import List, Tuple
+
+Segment = Tuple[int, float, float]      # (n0, t0, dt): t_n = t0 + (n-n0)*dt exactly, n0 <= n < next n0
+
+N_LIMIT = 1 << 62
+_TINY = 2.0 ** -1000
+
+
+def _binade(x: float) -> int:
+    """Signed binade id; 0 for zero/tiny values (never part of a run)."""
+    if x == 0.0 or abs(x) < _TINY:
+        return 0
+    e = frexp(x)[1]
+    return (e + 2000) if x > 0 else -(e + 2000)
+
+
+def _mant(x: float) -> Tuple[int, int]:
+    """x = M * 2**s with 2^52 <= |M| < 2^53 (normal x)."""
+    m, e = frexp(x)
+    return int(ldexp(m, 53)), e - 53
+
+
+def build_phase_table(t0: float, inc: float, n_limit: int = N_LIMIT) -> List[Segment]:
+    """Pieces of the sequence t_0 = t0, t_{n+1} = fl(t_n + inc), covering [0, n_limit)."""
+    segs: List[Segment] = []
+    n, t = 0, float(t0)
+    inc = float(inc)
+    while n < n_limit:
+        t1 = t + inc
+        if t1 == t:                       # inc == 0, or absorbed below half an ulp: constant forever
+            segs.append((n, t, 0.0))
+            break
+        b = _binade(t)
+        if b != 0 and _binade(t1) == b:
+            t2 = t1 + inc
+            d = t1 - t                    # exact: same binade
+            if _binade(t2) == b and (t2 - t1) == d:
+                # regular run: t + j*d for j = 0..k stays inside the binade
+                T, s = _mant(t)
+                D, s2 = _mant(d) if abs(d) >= _TINY else (0, 0)
+                # express d in units of 2**s (d is a multiple of the binade ulp)
+                D = int(Fraction(d) / (Fraction(2) ** s))
+                lo, hi = 1 << 52, (1 << 53) - 1
+                if T > 0:
+                    k = (hi - T) // D if D > 0 else (T - lo) // (-D)
+                else:
+                    k = (hi + T) // (-D) if D < 0 else (-T - lo) // D
+                segs.append((n, t, d))
+                tk = ldexp(float(T + k * D), s)       # exact: |T + k*D| < 2^53
+                t1 = tk + inc                          # the step out of the binade: a real addition
+                if t1 == tk:
+                    segs.append((n + k, tk, 0.0))
+                    break
+                n, t = n + k + 1, t1
+                continue
+        # single step (entering/leaving a binade, crossing zero, irregular first step)
+        segs.append((n, t, t1 - t))
+        n, t = n + 1, t1
+    return segs
+
+
+class PhaseTable:
+    """Host-side view used for envelope boundaries and by the tests."""
+
+    def __init__(self, t0: float, inc: float, n_limit: int = N_LIMIT) -> None:
+        self.t0 = float(t0)
+        self.inc = float(inc)
+        self.segments = build_phase_table(t0, inc, n_limit)
+        self._starts = [s[0] for s in self.segments]
+
+    def __len__(self) -> int:
+        return len(self.segments)
+
+    def value(self, n: int) -> float:
+        """t_n, exactly (what the sequential loop holds when it emits sample n)."""
+        i = bisect_right(self._starts, n) - 1
+        n0, t0, dt = self.segments[i]
+        return float(Fraction(t0) + (n - n0) * Fraction(dt))
+
+    def first_index_ge(self, x: float) -> int:
+        """Smallest n with t_n >= x (needs inc > 0: the sequence is non-decreasing)."""
+        if self.inc <= 0:
+            raise ValueError("first_index_ge needs a positive increment")
+        if self.t0 >= x:
+            return 0
+        X = Fraction(x)
+        lo, hi = 0, len(self.segments) - 1          # last piece whose start value is < x
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if Fraction(self.segments[mid][1]) < X:
+                lo = mid
+            else:
+                hi = mid - 1
+        n0, t0, dt = self.segments[lo]
+        if dt == 0.0:
+            raise OverflowError("sequence never reaches %r" % x)
+        n = n0 + ceil((X - Fraction(t0)) / Fraction(dt))
+        if lo + 1 < len(self.segments):
+            n = min(n, self.segments[lo + 1][0])
+        return n

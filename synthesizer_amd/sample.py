@@ -1,0 +1,307 @@
+"""
+Sample: signed-integer PCM container with the hot-path operations of upstream
+``synthplayer/sample.py`` (tree not mounted at /root/reference): ``from_osc_block`` (quantise),
+``mix`` / ``mix_at`` (saturating add) and ``resample`` (linear interpolation), plus the
+constructors/accessors a caller needs around them.  The arithmetic upstream delegates to CPython's
+``audioop`` (add, ratecv) runs here as HIP kernels over PCM that stays resident in HBM; results are
+bit-exact with ``audioop`` (tests/test_gpu_pcm.py).
+
+Frames live either on the host (``bytes``) or on the device (``DeviceBuffer``); operations move them
+to the device once and leave them there, accessors bring them back lazily.  There is no CPU
+implementation of the arithmetic in this package.
+
+Not provided (out of the path): amplify, fades, pan, echo, envelope,
+normalize, level metering, 24-bit samples.
+"""
+from __future__ import annotations
+
+import array
+import ctypes as C
+import wave
+from typing import BinaryIO, Iterable, Optional, Sequence, Union
+
+import numpy as np
+
+from . import params
+from . import _native as N
+
+__all__ = ["Sample"]
+
+_TYPECODE = {1: "b", 2: "h", 4: "i"}
+_NPTYPE = {1: np.int8, 2: np.int16, 4: np.int32}
+
+
+class Sample:
+    """Audio sample data: interleaved little-endian signed PCM."""
+
+    norm_samplerate = params.norm_samplerate
+    norm_nchannels = params.norm_nchannels
+    norm_samplewidth = params.norm_samplewidth
+
+    def __init__(self, wave_file: Optional[Union[str, BinaryIO]] = None, name: str = "", samplerate: int = 0,
+                 nchannels: int = 0, samplewidth: int = 0) -> None:
+        self.name = name
+        self.__locked = False
+        self.__samplerate = samplerate or params.norm_samplerate
+        self.__nchannels = nchannels or params.norm_nchannels
+        self.__samplewidth = samplewidth or params.norm_samplewidth
+        self.__frames: Optional[bytes] = b""
+        self.__dev: Optional[N.DeviceBuffer] = None
+        self.__nbytes = 0
+        self.filename = None
+        if wave_file:
+            self.load_wav(wave_file)
+            if isinstance(wave_file, str):
+                self.filename = wave_file
+
+    # -- storage -------------------------------------------------------------------------------
+    def _set_host(self, frames: bytes) -> None:
+        self.__frames = bytes(frames)
+        self.__dev = None
+        self.__nbytes = len(self.__frames)
+
+    def _set_device(self, buf: N.DeviceBuffer, nbytes: int) -> None:
+        self.__frames = None
+        self.__dev = buf
+        self.__nbytes = nbytes
+
+    def _host(self) -> bytes:
+        if self.__frames is None:
+            self.__frames = self.__dev.download_bytes(self.__nbytes) if self.__nbytes else b""
+        return self.__frames
+
+    def _device(self) -> N.DeviceBuffer:
+        if self.__dev is None:
+            self.__dev = N.DeviceBuffer.from_bytes(self.__frames or b"")
+        return self.__dev
+
+    def to_device(self) -> "Sample":
+        """Make the PCM resident in HBM (drops nothing; the host copy is kept until modified)."""
+        self._device()
+        return self
+
+    @property
+    def on_device(self) -> bool:
+        return self.__dev is not None
+
+    # -- constructors --------------------------------------------------------------------------
+    @classmethod
+    def from_raw_frames(cls, frames: Union[bytes, memoryview, bytearray], samplewidth: int, samplerate: int,
+                        numchannels: int, name: str = "") -> "Sample":
+        assert samplewidth in (1, 2, 3, 4) and numchannels >= 1 and samplerate > 1
+        s = cls(name=name, samplerate=samplerate, nchannels=numchannels, samplewidth=samplewidth)
+        frames = bytes(frames)
+        if len(frames) % (samplewidth * numchannels):
+            raise ValueError("frames data is not a whole number of frames")
+        s._set_host(frames)
+        return s
+
+    @classmethod
+    def from_array(cls, array_or_list: Union[Sequence[int], array.array, np.ndarray], samplerate: int,
+                   numchannels: int, name: str = "") -> "Sample":
+        if isinstance(array_or_list, np.ndarray):
+            width = array_or_list.dtype.itemsize
+            assert array_or_list.dtype.kind == "i" and width in (1, 2, 4)
+            frames = np.ascontiguousarray(array_or_list).astype(array_or_list.dtype.newbyteorder("<")).tobytes()
+        else:
+            if isinstance(array_or_list, list):
+                try:
+                    array_or_list = array.array("h", array_or_list)       # OverflowError when out of range
+                except OverflowError:
+                    array_or_list = array.array("i", array_or_list)
+            width = array_or_list.itemsize
+            frames = array_or_list.tobytes()
+        return cls.from_raw_frames(frames, width, samplerate, numchannels, name)
+
+    @classmethod
+    def from_osc_block(cls, block: Union[Iterable[float], np.ndarray], samplerate: int,
+                       amplitude_scale: Optional[float] = None, samplewidth: int = 0) -> "Sample":
+        """Quantise one oscillator block (mono): ``int(amplitude_scale * v)`` per sample, truncating
+        toward zero, OverflowError when a value does not fit -- upstream Sample.from_osc_block."""
+        width = samplewidth or params.norm_samplewidth
+        if width not in (1, 2, 4):
+            raise NotImplementedError("from_osc_block: sample width %d" % width)
+        if amplitude_scale is None:
+            amplitude_scale = 2 ** (8 * width - 1) - 1
+        arr = block if isinstance(block, np.ndarray) else np.asarray(list(block), dtype=np.float64)
+        if arr.dtype not in (np.float32, np.float64):
+            arr = arr.astype(np.float64)
+        n = int(arr.size)
+        s = cls(samplerate=samplerate, nchannels=1, samplewidth=width)
+        if n == 0:
+            return s
+        src = N.DeviceBuffer.from_array(arr.reshape(-1))
+        dst = N.DeviceBuffer(n * width)
+        fn = N.lib().sh_quantize_f32 if arr.dtype == np.float32 else N.lib().sh_quantize_f64
+        N.check(fn(src.handle, 0, n, float(amplitude_scale), width, dst.handle, 0))
+        src.free()
+        s._set_device(dst, n * width)
+        return s
+
+    # -- accessors -------------------------------------------------------------------------------
+    @property
+    def samplewidth(self) -> int:
+        return self.__samplewidth
+
+    @property
+    def samplerate(self) -> int:
+        return self.__samplerate
+
+    @samplerate.setter
+    def samplerate(self, rate: int) -> None:
+        assert rate > 0
+        self.__samplerate = int(rate)
+
+    @property
+    def nchannels(self) -> int:
+        return self.__nchannels
+
+    @property
+    def duration(self) -> float:
+        return self.__nbytes / self.__samplerate / self.__samplewidth / self.__nchannels
+
+    @property
+    def maximum(self) -> int:
+        return 2 ** (8 * self.__samplewidth - 1) - 1
+
+    def __len__(self) -> int:
+        """Number of frames."""
+        return self.__nbytes // self.__samplewidth // self.__nchannels
+
+    def __eq__(self, other) -> bool:
+        if not isinstance(other, Sample):
+            return False
+        return (self.__samplewidth == other.__samplewidth and self.__samplerate == other.__samplerate and
+                self.__nchannels == other.__nchannels and self._host() == other._host())
+
+    def __repr__(self) -> str:
+        return "<Sample '%s' at 0x%x, %g seconds, %d channels, %d bits, rate %d>" % (
+            self.name, id(self), self.duration, self.__nchannels, 8 * self.__samplewidth, self.__samplerate)
+
+    def frame_idx(self, seconds: float) -> int:
+        """Byte index of the frame at the given time."""
+        return self.__nchannels * self.__samplewidth * int(self.__samplerate * seconds)
+
+    def view_frame_data(self) -> memoryview:
+        return memoryview(self._host())
+
+    def get_frame_array(self) -> array.array:
+        if self.__samplewidth not in _TYPECODE:
+            raise NotImplementedError("get_frame_array: sample width %d" % self.__samplewidth)
+        return array.array(_TYPECODE[self.__samplewidth], self._host())
+
+    def get_frames_numpy(self) -> np.ndarray:
+        """[frames, channels] integer array (copy)."""
+        return np.frombuffer(self._host(), dtype=_NPTYPE[self.__samplewidth]).reshape(-1, self.__nchannels).copy()
+
+    def get_frames_as_floats(self) -> Sequence[float]:
+        maxsize = 2 ** (8 * self.__samplewidth - 1)
+        return [v / maxsize for v in self.get_frame_array()]
+
+    def copy(self) -> "Sample":
+        cpy = Sample(name=self.name, samplerate=self.__samplerate, nchannels=self.__nchannels,
+                     samplewidth=self.__samplewidth)
+        cpy._set_host(self._host())
+        cpy.filename = self.filename
+        return cpy
+
+    def lock(self) -> "Sample":
+        self.__locked = True
+        return self
+
+    def _check_writable(self) -> None:
+        if self.__locked:
+            raise RuntimeError("cannot modify a locked sample")
+
+    # -- WAV in/out (host only, stdlib wave) -----------------------------------------------------
+    def load_wav(self, file_or_stream: Union[str, BinaryIO]) -> "Sample":
+        self._check_writable()
+        with wave.open(file_or_stream) as w:
+            if not 2 <= w.getsampwidth() <= 4:
+                raise IOError("only supports sample sizes of 2, 3 or 4 bytes")
+            if not 1 <= w.getnchannels() <= 2:
+                raise IOError("only supports mono or stereo channels")
+            self.__nchannels = w.getnchannels()
+            self.__samplerate = w.getframerate()
+            self.__samplewidth = w.getsampwidth()
+            self._set_host(w.readframes(w.getnframes()))
+        return self
+
+    def write_wav(self, file_or_stream: Union[str, BinaryIO]) -> None:
+        with wave.open(file_or_stream, "wb") as out:
+            out.setparams((self.__nchannels, self.__samplewidth, self.__samplerate, 0, "NONE", "not compressed"))
+            out.writeframes(self._host())
+
+    def add_silence(self, seconds: float, at_start: bool = False) -> "Sample":
+        self._check_writable()
+        pad = b"\0" * self.frame_idx(seconds)
+        self._set_host(pad + self._host() if at_start else self._host() + pad)
+        return self
+
+    # -- the hot path ----------------------------------------------------------------------------
+    def _check_gpu_width(self, what: str) -> None:
+        if self.__samplewidth not in (1, 2, 4):
+            raise NotImplementedError("%s: %d-byte samples are not supported on the GPU path" % (what, self.__samplewidth))
+
+    def mix(self, other: "Sample", other_seconds: Optional[float] = None, pad_shortest: bool = True) -> "Sample":
+        """Mix another sample into this one (saturating add).  The shorter operand is zero-padded
+        unless pad_shortest is False, in which case unequal lengths are an error (audioop.add)."""
+        self._check_writable()
+        assert self.samplewidth == other.samplewidth
+        assert self.samplerate == other.samplerate
+        assert self.nchannels == other.nchannels
+        self._check_gpu_width("mix")
+        n1 = self.__nbytes
+        n2 = other.__nbytes if not other_seconds else min(other.__nbytes, other.frame_idx(other_seconds))
+        if not pad_shortest and n1 != n2:
+            raise ValueError("Lengths should be the same")
+        self.__mix_region(other, 0, n2, max(n1, n2))
+        return self
+
+    def mix_at(self, seconds: float, other: "Sample", other_seconds: Optional[float] = None) -> "Sample":
+        """Mix another sample into this one starting at the given time; grows as needed."""
+        if seconds == 0.0:
+            return self.mix(other, other_seconds)
+        self._check_writable()
+        assert self.samplewidth == other.samplewidth
+        assert self.samplerate == other.samplerate
+        assert self.nchannels == other.nchannels
+        self._check_gpu_width("mix_at")
+        start = self.frame_idx(seconds)
+        n2 = other.frame_idx(other_seconds) if other_seconds else other.__nbytes
+        n2 = min(n2, other.__nbytes)
+        self.__mix_region(other, start, n2, max(self.__nbytes, start + n2))
+        return self
+
+    def __mix_region(self, other: "Sample", start: int, n2: int, total: int) -> None:
+        """self[start:start+n2] = sat_add(self[start:start+n2] (zero-extended), other[:n2]); length -> total."""
+        L = N.lib()
+        n1 = self.__nbytes
+        dst = N.DeviceBuffer(total)
+        if total > n1:
+            dst.zero(n1, total - n1)
+        if n1:
+            N.check(L.sh_buf_copy(dst.handle, 0, self._device().handle, 0, n1))
+        if n2:
+            N.check(L.sh_pcm_add(dst.handle, start, other._device().handle, 0, n2, self.__samplewidth, dst.handle, start))
+        self._set_device(dst, total)
+
+    def resample(self, samplerate: int) -> "Sample":
+        """Resample to a different rate without changing pitch/duration: linear interpolation with
+        the arithmetic of ``audioop.ratecv(frames, width, nchannels, rate, samplerate, None)``."""
+        self._check_writable()
+        if samplerate == self.__samplerate:
+            return self
+        self._check_gpu_width("resample")
+        L = N.lib()
+        nin = len(self)
+        nout = L.sh_resample_out_frames(nin, self.__samplerate, samplerate)
+        fb = self.__samplewidth * self.__nchannels
+        dst = N.DeviceBuffer(nout * fb)
+        out_frames = C.c_size_t()
+        if nin:
+            N.check(L.sh_resample(self._device().handle, nin, self.__nchannels, self.__samplewidth, 0,
+                                  self.__samplerate, samplerate, dst.handle, C.byref(out_frames)))
+        self._set_device(dst, nout * fb)
+        self.__samplerate = samplerate
+        return self

@@ -1,0 +1,113 @@
+"""GPU parity: the mixer sum bus over oscillator voices (VoiceBank) vs the oracle.
+
+BASELINE configs[1] (64-voice additive Harmonics + ADSR, 48 kHz stereo) and configs[2] (1024 FM voices)
+at durations the pure-Python oracle finishes in seconds; the full-size runs are covered by
+size-independent properties (linearity of the bus in the voice set, fused == two-step, block
+concatenation == one long render).
+"""
+import numpy as np
+import pytest
+
+from oracle import synth_oracle as O
+from tests.helpers import rms
+from synthesizer_amd.workloads import additive_voices, fm_voices
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-6
+SR = 48000
+
+
+def _oracle_bus(ovoices, gains, n):
+    vs = [v.take(n) for v in ovoices]
+    return np.array(O.mix_bus(vs, gains), dtype=np.float64)
+
+
+def test_config2_additive_64_voices_adsr(gpu):
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    gv, gains = additive_voices(G, 64, SR, seed=0)
+    ov, _ = additive_voices(O, 64, SR, seed=0)
+    n = 6000
+    bank = VoiceBank(gv, gains=gains)
+    fused = bank.render(n)
+    want = _oracle_bus(ov, gains, n)
+    assert fused.shape == (n, 2) and fused.dtype == np.float32
+    assert rms(fused, want) <= RMS_TOL
+    assert np.max(np.abs(fused - want)) < 5e-7
+    # two-step (materialise, then HBM-bound mix) agrees with the fused kernel
+    two = bank.render_two_step(n)
+    assert rms(two, want) <= RMS_TOL
+    # per-voice materialisation equals the single-oscillator path
+    mat = bank.generate(n)
+    assert mat.shape == (64, n)
+    for i in (0, 17, 63):
+        assert np.array_equal(mat[i], gv[i].render(n, start=0))
+    # frames past the release: voices are silent, bus is exactly zero
+    late = bank.render(256, start=SR * 2)
+    assert not late.any()
+
+
+def test_config3_fm_voices(gpu):
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    nv, n = 96, 3000
+    gv, gains = fm_voices(G, nv, SR, seed=1)
+    ov, _ = fm_voices(O, nv, SR, seed=1)
+    bank = VoiceBank(gv, gains=gains)
+    got = bank.render(n)
+    want = _oracle_bus(ov, gains, n)
+    assert rms(got, want) <= RMS_TOL
+
+
+def test_bank_properties_at_full_size(gpu):
+    """1024 voices x 1 s: properties that need no oracle."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    nv, n = 1024, 48000
+    gv, gains = additive_voices(G, nv, SR, seed=3)
+    full = VoiceBank(gv, gains=gains)
+    a = VoiceBank(gv[:400], gains=gains[:400])
+    b = VoiceBank(gv[400:], gains=gains[400:])
+    whole = full.render(n)
+    # linearity in the voice set
+    parts = a.render(n).astype(np.float64) + b.render(n).astype(np.float64)
+    assert rms(whole, parts) <= 2e-7
+    # block concatenation == one render (stateless in the sample index)
+    pieces = np.concatenate([full.render(12345, 0), full.render(n - 12345, 12345)])
+    assert np.array_equal(pieces, whole)
+    # fused == two-step within float32 summation noise
+    two = full.render_two_step(n)
+    assert rms(whole, two) <= 5e-7
+    # odd sizes / tails
+    odd = full.render(1001, start=77)
+    assert np.array_equal(odd, whole[77:77 + 1001])
+    # int16 epilogue: truncation toward zero of 32767*bus, saturating
+    s = full.render_sample(4096)
+    pcm = s.get_frames_numpy()
+    want = np.clip(np.trunc(32767.0 * whole[:4096].astype(np.float64)), -32768, 32767).astype(np.int16)
+    assert np.array_equal(pcm, want)
+
+
+def test_mix_bus_kernel_shapes(gpu):
+    """sh_mix_bus_f32 over materialised voices: ragged sizes, voice-group split, gains."""
+    from synthesizer_amd.mixer import mix_bus
+    rng = np.random.default_rng(5)
+    for nv, nf in ((1, 1), (3, 7), (8, 255), (33, 1000), (64, 4099), (1024, 3000), (257, 1024)):
+        v = rng.uniform(-1, 1, (nv, nf)).astype(np.float32)
+        g = rng.uniform(0, 1, (nv, 2)).astype(np.float32)
+        got = mix_bus(v, g)
+        want = v.astype(np.float64).T @ g.astype(np.float64)
+        assert got.shape == (nf, 2)
+        assert np.max(np.abs(got - want)) <= 4e-6 * max(1.0, np.sqrt(nv))
+
+
+def test_bank_rejects_buffer_modulators(gpu):
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    with pytest.raises(NotImplementedError):
+        VoiceBank([G.Sine(440, fm_lfo=G.Square(2, 0.1, samplerate=SR), samplerate=SR)])
+    with pytest.raises(ValueError):
+        VoiceBank([])
+    with pytest.raises(ValueError):
+        VoiceBank([G.Sine(440, samplerate=SR), G.Sine(440, samplerate=44100)])

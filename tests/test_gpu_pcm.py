@@ -1,0 +1,195 @@
+"""GPU parity, integer PCM rows: Sample.mix / mix_at / resample and the mixer chain, bit-exact against
+CPython 3.10's ``audioop`` (the module upstream delegates to -- live on this box, same image) and
+against the committed golden vectors generated from it (tests/golden/make_golden.py).
+"""
+import audioop
+
+import numpy as np
+import pytest
+
+from oracle import pcm_oracle as P
+
+pytestmark = pytest.mark.gpu
+
+DT = {1: np.int8, 2: np.int16, 4: np.int32}
+
+
+def _rand(rng, width, n, lo=None, hi=None):
+    info = np.iinfo(DT[width])
+    lo = info.min if lo is None else lo
+    hi = info.max if hi is None else hi
+    return rng.integers(lo, hi + 1, n, dtype=np.int64).astype(DT[width])
+
+
+def _sample(arr, width, rate, nch):
+    from synthesizer_amd.sample import Sample
+    return Sample.from_raw_frames(arr.tobytes(), width, rate, nch)
+
+
+@pytest.mark.parametrize("width", [1, 2, 4])
+def test_pcm_add_golden_and_live(gpu, width):
+    from synthesizer_amd import _native as N
+    g = np.load("tests/golden/audioop_add.npz")
+    a, b, want = g["a%d" % width], g["b%d" % width], g["sum%d" % width]
+    out = np.empty_like(a)
+    N.check(N.lib().sh_pcm_add_host(a.ctypes.data, b.ctypes.data, a.nbytes, width, out.ctypes.data))
+    assert np.array_equal(out, want)
+    rng = np.random.default_rng(width)
+    for n in (1, 7, 8, 63, 4097, 100003):
+        a, b = _rand(rng, width, n), _rand(rng, width, n)
+        out = np.empty_like(a)
+        N.check(N.lib().sh_pcm_add_host(a.ctypes.data, b.ctypes.data, a.nbytes, width, out.ctypes.data))
+        assert out.tobytes() == audioop.add(a.tobytes(), b.tobytes(), width)
+
+
+def test_sample_mix_semantics(gpu):
+    rng = np.random.default_rng(0)
+    a = _rand(rng, 2, 2 * 5000)
+    b = _rand(rng, 2, 2 * 3001)
+    # shorter operand zero-padded
+    s = _sample(a, 2, 44100, 2).mix(_sample(b, 2, 44100, 2))
+    want = audioop.add(a.tobytes(), b.tobytes() + b"\0" * (a.nbytes - b.nbytes), 2)
+    assert bytes(s.view_frame_data()) == want and len(s) == 5000
+    # longer other grows self
+    s = _sample(b, 2, 44100, 2).mix(_sample(a, 2, 44100, 2))
+    assert bytes(s.view_frame_data()) == want and len(s) == 5000
+    # other_seconds limits the part taken from other
+    s = _sample(a, 2, 44100, 2)
+    o = _sample(b, 2, 44100, 2)
+    s.mix(o, other_seconds=0.01)
+    cut = o.frame_idx(0.01)
+    want2 = audioop.add(a.tobytes(), b.tobytes()[:cut] + b"\0" * (a.nbytes - cut), 2)
+    assert bytes(s.view_frame_data()) == want2
+    # pad_shortest=False with unequal lengths is audioop's error
+    with pytest.raises(ValueError):
+        _sample(a, 2, 44100, 2).mix(_sample(b, 2, 44100, 2), pad_shortest=False)
+    # empty operands
+    from synthesizer_amd.sample import Sample
+    e = Sample(samplerate=44100, nchannels=2, samplewidth=2)
+    assert bytes(_sample(a, 2, 44100, 2).mix(e).view_frame_data()) == a.tobytes()
+    assert bytes(e.copy().mix(_sample(a, 2, 44100, 2)).view_frame_data()) == a.tobytes()
+    # locked samples refuse
+    with pytest.raises(RuntimeError):
+        _sample(a, 2, 44100, 2).lock().mix(_sample(b, 2, 44100, 2))
+
+
+def test_sample_mix_at(gpu):
+    rng = np.random.default_rng(1)
+    a = _rand(rng, 2, 4000)
+    b = _rand(rng, 2, 3000)
+    s = _sample(a, 2, 8000, 1).mix_at(0.25, _sample(b, 2, 8000, 1))
+    start = 2 * int(8000 * 0.25)
+    total = max(a.nbytes, start + b.nbytes)
+    base = bytearray(a.tobytes() + b"\0" * (total - a.nbytes))
+    base[start:start + b.nbytes] = audioop.add(bytes(base[start:start + b.nbytes]), b.tobytes(), 2)
+    assert bytes(s.view_frame_data()) == bytes(base)
+    # beyond the end: silence gap, then the other sample
+    s = _sample(a, 2, 8000, 1).mix_at(1.0, _sample(b, 2, 8000, 1))
+    assert len(s) == 8000 + 3000
+    got = s.get_frames_numpy().reshape(-1)
+    assert np.array_equal(got[:4000], a) and not got[4000:8000].any() and np.array_equal(got[8000:], b)
+
+
+def test_resample_golden(gpu):
+    from synthesizer_amd import _native as N
+    g = np.load("tests/golden/audioop_ratecv.npz")
+    n = 0
+    while "case%d_meta" % n in g:
+        i, o, nch, width = (int(v) for v in g["case%d_meta" % n])
+        x, want = g["case%d_in" % n], g["case%d_out" % n]
+        out = np.empty(N.lib().sh_resample_out_frames(len(x) // nch, i, o) * nch, dtype=x.dtype)
+        import ctypes
+        nf = ctypes.c_size_t()
+        N.check(N.lib().sh_resample_host(x.ctypes.data, len(x) // nch, nch, width, 0, i, o, out.ctypes.data, ctypes.byref(nf)))
+        assert nf.value * nch == len(want) and np.array_equal(out, want), (i, o, nch, width)
+        n += 1
+    assert n >= 30
+    ramp = _sample(g["ramp_in"], 2, 96000, 1).resample(44100)
+    assert ramp.get_frame_array().tolist() == g["ramp_out"].tolist() == [0, 2176, 4353, 6530]
+
+
+@pytest.mark.parametrize("rates", [(96000, 44100), (48000, 44100), (44100, 48000), (44100, 22050), (22050, 44100),
+                                   (8000, 8001), (192000, 8000), (44100, 96000), (3, 7), (1000003, 999983)])
+@pytest.mark.parametrize("nch", [1, 2, 8])
+def test_resample_live_audioop(gpu, rates, nch):
+    rng = np.random.default_rng(nch)
+    i, o = rates
+    for width in (2, 4, 1):
+        for frames in (1, 2, 3, 1000, 20011):
+            x = _rand(rng, width, frames * nch)
+            s = _sample(x, width, i, nch).resample(o)
+            want = audioop.ratecv(x.tobytes(), width, nch, i, o, None)[0]
+            assert bytes(s.view_frame_data()) == want, (width, frames)
+            assert s.samplerate == o and s.nchannels == nch
+            assert len(want) == P.ratecv_out_frames(frames, i, o) * width * nch
+
+
+def test_resample_edge_cases(gpu):
+    from synthesizer_amd.sample import Sample
+    e = Sample(samplerate=48000, nchannels=2, samplewidth=2)
+    assert len(e.resample(44100)) == 0 and e.samplerate == 44100
+    x = np.array([32767, -32768] * 500, dtype=np.int16)          # full-scale alternation
+    s = _sample(x, 2, 48000, 1).resample(44100)
+    assert bytes(s.view_frame_data()) == audioop.ratecv(x.tobytes(), 2, 1, 48000, 44100, None)[0]
+    same = _sample(x, 2, 48000, 1)
+    assert same.resample(48000) is same and bytes(same.view_frame_data()) == x.tobytes()
+    # round trip down and up keeps length arithmetic consistent with audioop
+    s = _sample(x, 2, 48000, 1).resample(44100).resample(48000)
+    ref = audioop.ratecv(audioop.ratecv(x.tobytes(), 2, 1, 48000, 44100, None)[0], 2, 1, 44100, 48000, None)[0]
+    assert bytes(s.view_frame_data()) == ref
+
+
+def test_resample_float32_config5_shape(gpu):
+    """BASELINE configs[4] at reduced length: 8-channel float32, 96 kHz -> 44.1 kHz.  Upstream Sample is
+    integer-only, so the float row is checked against the oracle's restatement of the same index
+    arithmetic (bit-exact: same float64 operations, one rounding to float32)."""
+    import ctypes
+    from synthesizer_amd import _native as N
+    rng = np.random.default_rng(9)
+    for frames, nch, (i, o) in ((96000, 8, (96000, 44100)), (5000, 1, (44100, 48000)), (7, 3, (3, 7))):
+        x = rng.uniform(-1, 1, (frames, nch)).astype(np.float32)
+        want = P.ratecv_f32(x, i, o)
+        out = np.empty_like(want)
+        nf = ctypes.c_size_t()
+        N.check(N.lib().sh_resample_host(x.ctypes.data, frames, nch, 4, 1, i, o, out.ctypes.data, ctypes.byref(nf)))
+        assert nf.value == want.shape[0]
+        assert np.array_equal(out, want)
+    # property at size: resampling a linear ramp stays on the ramp (linear interpolation is exact on lines)
+    frames = 2_000_000
+    t = (np.arange(frames, dtype=np.float64) / 96000.0)
+    x = np.stack([t, -2.0 * t], axis=1).astype(np.float32)
+    src = N.DeviceBuffer.from_array(x)
+    nout = N.lib().sh_resample_out_frames(frames, 96000, 44100)
+    dst = N.DeviceBuffer(nout * 8)
+    N.check(N.lib().sh_resample(src.handle, frames, 2, 4, 1, 96000, 44100, dst.handle, None))
+    y = dst.download(np.float32, nout * 2).reshape(nout, 2)
+    tt = np.arange(nout, dtype=np.float64) / 44100.0
+    assert np.max(np.abs(y[:, 0] - tt)) < 2e-6 and np.max(np.abs(y[:, 1] + 2 * tt)) < 4e-6
+
+
+def test_mixer_chain_bit_exact(gpu):
+    from synthesizer_amd.mixer import mix_samples
+    g = np.load("tests/golden/audioop_add.npz")
+    chunks, want = g["chain_in"], g["chain_out"]
+    s = mix_samples([_sample(c, 2, 44100, 1) for c in chunks])
+    assert np.array_equal(s.get_frames_numpy().reshape(-1), want)
+    # loud voices: saturation in the middle of the chain makes the order matter
+    rng = np.random.default_rng(11)
+    for nv, n in ((2, 100), (5, 999), (64, 4096), (200, 1234), (1024, 2048)):
+        chunks = _rand(rng, 2, nv * n, -30000, 30000).reshape(nv, n)
+        mixed = chunks[0].tobytes()
+        for c in chunks[1:]:
+            mixed = audioop.add(mixed, c.tobytes(), 2)
+        s = mix_samples([_sample(c, 2, 44100, 2 if n % 2 == 0 else 1) for c in chunks])
+        assert bytes(s.view_frame_data()) == mixed, (nv, n)
+    # order dependence is real (so a tree reduction would be wrong): reversing changes the result
+    rev = mix_samples([_sample(c, 2, 44100, 1) for c in chunks[::-1]])
+    assert bytes(rev.view_frame_data()) != mixed
+    # ragged voices are padded with silence; other widths take the pairwise path
+    a, b, c = _rand(rng, 2, 1000), _rand(rng, 2, 400), _rand(rng, 2, 1700)
+    s = mix_samples([_sample(a, 2, 8000, 1), _sample(b, 2, 8000, 1), _sample(c, 2, 8000, 1)])
+    pad = lambda x: x.tobytes() + b"\0" * (3400 - x.nbytes)
+    assert bytes(s.view_frame_data()) == audioop.add(audioop.add(pad(a), pad(b), 2), pad(c), 2)
+    a4, b4 = _rand(rng, 4, 500), _rand(rng, 4, 500)
+    s = mix_samples([_sample(a4, 4, 8000, 1), _sample(b4, 4, 8000, 1)])
+    assert bytes(s.view_frame_data()) == audioop.add(a4.tobytes(), b4.tobytes(), 4)
