@@ -93,8 +93,12 @@ typedef struct sh_voice {
     double   amplitude, bias, pulsewidth;
     /* SH_FM_NONE: carrier phase table (t in radians for Sine/Harmonics, in turns otherwise) */
     uint32_t seg_offset, seg_count;
-    /* Harmonics: dense -> harm_count Clenshaw coefficients (doubles, k = harm_count..1,
-     * count a multiple of 8) at coef[harm_offset]; sparse -> harm_count sh_partial at partial[harm_offset] */
+    /* Harmonics, by harm_dense:
+     *   0 sparse  -> harm_count sh_partial at partial[harm_offset], summed term by term
+     *   1 dense   -> harm_count Clenshaw coefficients (doubles, k = harm_count..1, count a multiple of 8)
+     *                at coef[harm_offset]
+     *   2 poly    -> 16 doubles at coef[harm_offset], highest power first: sum_k a_k sin(k t) =
+     *                sin(t) * P(cos t), P of degree 15 (all k <= 16; converted exactly on the host) */
     uint32_t harm_offset, harm_count;
     int32_t  harm_dense;
     int32_t  reserved0;

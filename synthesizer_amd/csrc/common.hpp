@@ -23,6 +23,7 @@ struct State {
     size_t      scratch_bytes = 0;
     int*        flag = nullptr;        // device int: overflow flag for quantise
     int*        flag_host = nullptr;   // pinned host mirror
+    void*       trig = nullptr;        // device: 512 x (sin, cos) of k*2pi/512, float64 (devmath.hpp sincos_tab)
 };
 
 State& state();

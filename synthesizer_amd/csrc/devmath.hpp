@@ -127,6 +127,39 @@ SH_HD void sincos_f64(double t, double& s, double& c) {
     c = flip_sign(c0, ((q + 1) >> 1) & 1);
 }
 
+// ---- table-driven sincos ------------------------------------------------------------------
+// t = k*(2pi/N) + r with k = rint(t*N/2pi), |r| <= pi/N; (sin, cos)(k*2pi/N) comes from an N-entry
+// table (LDS on the GPU), the small angle from degree-5/4 Taylor polynomials, and one rotation
+// combines them.  6 constants instead of ~30: on gfx950 every float64 constant costs scalar-ALU
+// instructions to materialise, and the scalar unit (one per CU) was the bottleneck of the long
+// polynomials above.  Error: table entries are correctly rounded doubles, the truncation of the
+// polynomials is < 1e-16 for N = 512, the rotation adds ~2 ulp.
+constexpr int    TRIG_N = 512;
+constexpr double TRIG_STEP_1 = PI_1 / 256.0;        // 2pi/512 split like pi (power-of-two scaling is exact)
+constexpr double TRIG_STEP_2 = PI_2 / 256.0;
+constexpr double TRIG_STEP_3 = PI_3 / 256.0;
+constexpr double TRIG_INV_STEP = 81.48733086305042;  // 512/(2pi)
+
+struct sc_pair { double s, c; };
+
+template <typename TablePtr>
+SH_HD void sincos_tab(double t, TablePtr tab, double& s, double& c) {
+    // m = nearest integer to t*N/2pi, obtained by adding 1.5*2^52: the low mantissa bits of m ARE that
+    // integer (two's complement), so no rint / float->int conversion is needed; valid for |t*N/2pi| < 2^51
+    union { double d; uint64_t u; } m;
+    m.d = fma(t, TRIG_INV_STEP, 6755399441055744.0);
+    const double fk = m.d - 6755399441055744.0;
+    double r = fma(-fk, TRIG_STEP_1, t);       // two-term Cody-Waite: the third term is < 1e-19 for |fk| < 2^51
+    r = fma(-fk, TRIG_STEP_2, r);
+    const uint32_t k = (uint32_t)m.u & (uint32_t)(TRIG_N - 1);
+    const double S = tab[k].s, C = tab[k].c;
+    const double z = r * r;
+    const double sr = fma(r * z, fma(z, 0.008333333333333333, -0.16666666666666666), r);
+    const double cr = fma(z, fma(z, 0.041666666666666664, -0.5), 1.0);
+    s = fma(S, cr, C * sr);
+    c = fma(C, cr, -(S * sr));
+}
+
 // ---- waveforms (formulas of oscillators.py, operation order preserved) -----------------
 
 // Sawtooth: bias + amplitude*2.0*(t - floor(0.5+t))

@@ -11,7 +11,8 @@
 // -ffp-contract=off so that a*b+c is fused only where fma() is written.
 //
 // Kernels
-//   k_locate        one thread per voice: find the table piece that holds `start`
+//   k_prepare       one thread per voice: resolve everything that depends on `start` (phase-table piece,
+//                   envelope lines) into a 160-byte launch record
 //   k_generate      grid (frame tiles, voices): voice-major float32 PCM in HBM (4 B per voice-sample)
 //   k_bank_render   fused generate-and-mix: block = 64 frames x W waves, each wave walks a strided
 //                   subset of the voices with the voice record in SGPRs, float64 partial (L, R)
@@ -21,15 +22,9 @@
 #include "devmath.hpp"
 #include <new>
 #include <vector>
+#include <stdlib.h>
 
 namespace {
-
-struct Located {           // where `start` falls in a voice's phase (or time) table
-    double   t_base;       // table value at `start`
-    double   dt;           // increment of that piece
-    uint32_t remain;       // frames from `start` that stay on the piece (saturated)
-    uint32_t seg;          // piece index inside the voice's table
-};
 
 struct BankPtrs {
     const sh_voice*   voices;
@@ -38,161 +33,470 @@ struct BankPtrs {
     const sh_partial* partials;
 };
 
-__device__ __forceinline__ double table_value(const sh_segment* __restrict__ tab, uint32_t cnt,
-                                              const Located& L, uint64_t start, uint32_t i) {
-    if (i < L.remain) return fma((double)i, L.dt, L.t_base);          // exact: stays on the piece
-    uint64_t n = start + i;                                            // rare: the tile straddles a binade
-    uint32_t s = L.seg;
-    while (s + 1 < cnt && tab[s + 1].n0 <= n) ++s;
-    return fma((double)(n - tab[s].n0), tab[s].dt, tab[s].t0);
+// Pointers to data that no thread of the running kernel writes are cast to the constant address space:
+// a wave-uniform load through such a pointer is a scalar load (s_load_dwordxN into SGPRs) instead of a
+// per-lane vector load.
+#define SH_CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const T SH_CONST_AS* as_const(const T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const T SH_CONST_AS*)p;
+#pragma clang diagnostic pop
 }
 
-__device__ __forceinline__ double env_gain(const sh_envelope& e, uint64_t n) {
-    if (n < e.n_attack_end) return (double)n * e.attack_slope;
-    if (n < e.n_decay_end) return fma((double)(n - e.n_attack_end), e.decay_slope, 1.0);
-    if (n < e.n_sustain_end) return e.sustain_level;
-    if (n < e.n_release_end) return fma((double)(n - e.n_sustain_end), e.release_slope, e.sustain_level);
-    if (n == e.n_release_end && e.has_tail) return e.tail_amp;
-    return 0.0;
-}
+// Per-launch voice record, written by k_prepare and read (as one batch of scalar loads) by the render
+// kernels.  Everything that depends on `start` is resolved here once per voice instead of once per
+// wave: the phase-table piece that holds `start`, and the envelope as lines in the launch-relative frame
+// index i = n - start.  The scalar unit (one per CU) is the scarce resource of these kernels, so the
+// record is laid out to cost the hot path one batch of loads and almost no scalar arithmetic.
+constexpr uint32_t FL_KIND = 0x7, FL_FM_SHIFT = 4, FL_FM = 0x30, FL_DENSE = 0x40, FL_ENV_UNIFORM = 0x80,
+                   FL_POLY = 0x100, FL_FOLDED = 0x200;
+constexpr uint32_t NO_TAIL = 0xFFFFFFFFu;
 
-// One sample of one voice, float64.  `v` is wave-uniform in every kernel below, so the
-// branches on kind / fm_mode do not diverge.
-__device__ __forceinline__ double voice_sample(const sh_voice& v, const BankPtrs& B, const Located& L,
-                                               uint64_t start, uint32_t i,
-                                               const double* __restrict__ fm_cumsum,
-                                               const double* __restrict__ pwm) {
-    double theta;
-    if (v.fm_mode == SH_FM_NONE) {
-        theta = table_value(B.segs + v.seg_offset, v.seg_count, L, start, i);
-    } else {
-        double T = table_value(B.segs + v.time_seg_offset, v.time_seg_count, L, start, i);
-        double Ln;
-        if (v.fm_mode == SH_FM_SINE) {
-            double n = (double)(start + i);
-            double arg = fma(n - 0.5, v.lfo_d, v.lfo_a);
-            Ln = fma(v.lfo_K, v.lfo_C0 - shm::cos_f64(arg), v.lfo_bias * n);
-        } else {
-            Ln = fm_cumsum[i];
-        }
-        theta = fma(v.frequency * v.fm_inc, Ln, fma(v.frequency, T, v.fm_phase0));
-    }
-    double val;
-    switch (v.kind) {
-    case SH_SINE:
-        val = shm::sin_f64(theta) * v.amplitude + v.bias;
-        break;
-    case SH_SAWTOOTH:
-        val = shm::saw_value(theta, v.amplitude * 2.0, v.bias);
-        break;
-    case SH_SQUARE:
-        val = shm::square_value(theta, v.amplitude, v.bias);
-        break;
-    case SH_PULSE:
-        val = shm::pulse_value(theta, pwm ? pwm[i] : v.pulsewidth, v.amplitude, v.bias);
-        break;
-    default: {   // SH_HARMONICS
-        double h;
-        if (v.harm_dense) {
-            // sum_k a_k sin(k*theta) by Clenshaw: b_k = a_k + 2cos(theta) b_{k+1} - b_{k+2}; sum = b_1 sin(theta)
-            double s, c;
-            shm::sincos_f64(theta, s, c);
-            const double c2 = c + c;
-            const double* __restrict__ a = B.coefs + v.harm_offset;
-            double b1 = 0.0, b2 = 0.0;
-            for (uint32_t k = 0; k < v.harm_count; k += 8) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    double bn = fma(c2, b1, a[k + u] - b2);
-                    b2 = b1;
-                    b1 = bn;
-                }
-            }
-            h = b1 * s;
-        } else {
-            const sh_partial* __restrict__ p = B.partials + v.harm_offset;
-            h = 0.0;
-            for (uint32_t k = 0; k < v.harm_count; ++k) h += shm::sin_f64(theta * p[k].k) * p[k].amp;
-        }
-        val = h * v.amplitude + v.bias;
-    } break;
-    }
-    if (v.env.enabled) val = val * env_gain(v.env, start + i);
-    return val;
-}
+struct alignas(16) VoiceLaunch {
+    // ---- hot part (96 bytes) ----
+    double   t_base, dt;          // table value at `start` and the increment of its piece
+    uint32_t remain;              // frames from `start` that stay on the piece (saturated)
+    uint32_t flags;               // kind | fm_mode << 4 | dense << 6 | env_uniform << 7 | poly << 8
+    const double* harm;           // coefficients (dense / poly) or partials (sparse), absolute address
+    double   amplitude, bias;
+    double   gain_l, gain_r;
+    double   g0u, slu;            // FL_ENV_UNIFORM: the whole launch lies on one envelope piece, gain(i) = fma(i, slu, g0u)
+    uint32_t harm_cnt;
+    uint32_t seg;                 // piece index (slow path resumes the walk here)
+    uint32_t tail_i;              // launch-relative index of the post-release extra sample, or NO_TAIL
+    uint32_t pad0;
+    double   poly[16];            // FL_POLY: the 16 polynomial coefficients, copied here so that the record
+                                  // and the coefficients arrive in ONE batch of scalar loads
+    // ---- cold part: launches that cross an envelope boundary, Pulse ----
+    uint32_t eb[4];               // launch-relative ends of attack / decay / sustain / release (saturated)
+    double   g0[4], slope[4];     // gain(i) = fma(i, slope[p], g0[p]) on piece p; 0 after release
+    double   tail_amp;
+    double   pulsewidth;
+};
+static_assert(sizeof(VoiceLaunch) == 320, "VoiceLaunch layout");
 
-__global__ void k_locate(BankPtrs B, uint32_t first, uint32_t nvoices, uint64_t start, Located* __restrict__ out) {
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nvoices) return;
-    const sh_voice& vo = B.voices[first + v];
-    const bool fm = vo.fm_mode != SH_FM_NONE;
-    const uint32_t off = fm ? vo.time_seg_offset : vo.seg_offset;
-    const uint32_t cnt = fm ? vo.time_seg_count : vo.seg_count;
+struct alignas(16) VoiceFM {      // only read for FM voices
+    double frequency, phase0, f_inc;      // theta = frequency*T + fma(f_inc, L, phase0)
+    double lfo_a_rel, lfo_d, lfo_K, lfo_C0, lfo_bias;   // L(i) = K*(C0 - cos(a_rel + i*d)) + bias*(start+i)
+};
+static_assert(sizeof(VoiceFM) == 64, "VoiceFM layout");
+
+__global__ void k_prepare(BankPtrs B, uint32_t first, uint32_t nvoices, uint64_t start, uint32_t nframes,
+                          VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm) {
+    uint32_t vi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vi >= nvoices) return;
+    const sh_voice& v = B.voices[first + vi];
+    const bool fm = v.fm_mode != SH_FM_NONE;
+    const uint32_t off = fm ? v.time_seg_offset : v.seg_offset;
+    const uint32_t cnt = fm ? v.time_seg_count : v.seg_count;
     const sh_segment* tab = B.segs + off;
     uint32_t lo = 0, hi = cnt - 1;
     while (lo < hi) {
         uint32_t mid = (lo + hi + 1) >> 1;
         if (tab[mid].n0 <= start) lo = mid; else hi = mid - 1;
     }
-    Located L;
-    L.t_base = fma((double)(start - tab[lo].n0), tab[lo].dt, tab[lo].t0);
-    L.dt = tab[lo].dt;
+    VoiceLaunch r;
+    r.t_base = fma((double)(start - tab[lo].n0), tab[lo].dt, tab[lo].t0);
+    r.dt = tab[lo].dt;
     uint64_t rem = (lo + 1 < cnt) ? (tab[lo + 1].n0 - start) : 0xFFFFFFFFull;
-    L.remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
-    L.seg = lo;
-    out[v] = L;
+    r.remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
+    r.seg = lo;
+    r.pad0 = 0;
+    r.flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
+              (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u);
+    r.harm = v.harm_dense ? (B.coefs + v.harm_offset) : reinterpret_cast<const double*>(B.partials + v.harm_offset);
+    r.harm_cnt = v.harm_count;
+    r.amplitude = v.amplitude;
+    r.bias = v.bias;
+    r.gain_l = (double)v.gain_l;
+    r.gain_r = (double)v.gain_r;
+    r.pulsewidth = v.pulsewidth;
+    r.tail_i = NO_TAIL;
+    r.tail_amp = 0.0;
+    const sh_envelope& e = v.env;
+    if (e.enabled) {
+        const uint64_t ends[4] = {e.n_attack_end, e.n_decay_end, e.n_sustain_end, e.n_release_end};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint64_t d = ends[j] > start ? ends[j] - start : 0;
+            r.eb[j] = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d;
+        }
+        const double s0 = (double)start;
+        r.g0[0] = s0 * e.attack_slope;                                  // gain(n) = n * attack_slope
+        r.slope[0] = e.attack_slope;
+        r.g0[1] = fma(s0 - (double)e.n_attack_end, e.decay_slope, 1.0);  // 1 + (n - nA) * decay_slope
+        r.slope[1] = e.decay_slope;
+        r.g0[2] = e.sustain_level;
+        r.slope[2] = 0.0;
+        r.g0[3] = fma(s0 - (double)e.n_sustain_end, e.release_slope, e.sustain_level);
+        r.slope[3] = e.release_slope;
+        if (e.has_tail && e.n_release_end >= start && e.n_release_end - start < 0xFFFFFFFFull) {
+            r.tail_i = (uint32_t)(e.n_release_end - start);
+            r.tail_amp = e.tail_amp;
+        }
+    } else {                       // no envelope: an endless sustain piece of gain 1
+        r.eb[0] = 0; r.eb[1] = 0; r.eb[2] = 0xFFFFFFFFu; r.eb[3] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { r.g0[j] = 1.0; r.slope[j] = 0.0; }
+    }
+    // does the whole launch [0, nframes) sit on one envelope piece?
+    {
+        const uint32_t last = nframes ? nframes - 1 : 0;
+        const uint32_t p = (0u >= r.eb[0]) + (0u >= r.eb[1]) + (0u >= r.eb[2]) + (0u >= r.eb[3]);
+        const bool tail_here = r.tail_i != NO_TAIL && r.tail_i <= last;
+        r.g0u = 0.0;
+        r.slu = 0.0;
+        if (p == 4) {
+            if (!tail_here) r.flags |= FL_ENV_UNIFORM;                 // silent for the whole launch
+        } else if (last < r.eb[p]) {
+            r.flags |= FL_ENV_UNIFORM;
+            r.g0u = r.g0[p];
+            r.slu = r.slope[p];
+        }
+    }
+    if (r.flags & FL_POLY) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) r.poly[u] = r.harm[u];
+        // bias == 0 and a constant envelope gain: fold amplitude and envelope into the bus gains, so the
+        // inner loop is h = P(c)*s; L += GL*h; R += GR*h.  (Differs from the unfolded order by float64
+        // rounding only, ~1e-16 relative.)  Bank kernels only: k_generate needs the voice sample itself.
+        if (v.bias == 0.0 && (r.flags & FL_ENV_UNIFORM) && r.slu == 0.0) {
+            r.flags |= FL_FOLDED;
+            r.gain_l = (r.amplitude * r.g0u) * r.gain_l;
+            r.gain_r = (r.amplitude * r.g0u) * r.gain_r;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) r.poly[u] = 0.0;
+    }
+    out[vi] = r;
+    if (fm) {
+        VoiceFM f;
+        f.frequency = v.frequency;
+        f.phase0 = v.fm_phase0;
+        f.f_inc = v.frequency * v.fm_inc;
+        f.lfo_a_rel = fma((double)start - 0.5, v.lfo_d, v.lfo_a);     // arg(i) = a + (start + i - 0.5) * d
+        f.lfo_d = v.lfo_d;
+        f.lfo_K = v.lfo_K;
+        f.lfo_C0 = v.lfo_C0;
+        f.lfo_bias = v.lfo_bias;
+        out_fm[vi] = f;
+    }
 }
 
-// voice-major materialisation: out[v*stride + i]
-__global__ __launch_bounds__(256) void k_generate(BankPtrs B, uint32_t first, const Located* __restrict__ loc,
+struct VoiceRegs {                // the hot part of the launch record as plain scalars (SGPRs)
+    double   t_base, dt;
+    uint32_t remain, flags;
+    const double SH_CONST_AS* harm;
+    double   amplitude, bias, gain_l, gain_r, g0u, slu;
+    uint32_t harm_cnt;
+    double   poly[16];            // loaded unconditionally with the rest: one batch, one wait per voice
+    const VoiceLaunch SH_CONST_AS* rec;   // cold fields are read through this where needed
+};
+
+__device__ __forceinline__ VoiceRegs load_record(const VoiceLaunch SH_CONST_AS* p) {
+    VoiceRegs r;
+    r.t_base = p->t_base; r.dt = p->dt;
+    r.remain = p->remain; r.flags = p->flags;
+    r.harm = as_const(p->harm);
+    r.amplitude = p->amplitude; r.bias = p->bias;
+    r.gain_l = p->gain_l; r.gain_r = p->gain_r;
+    r.g0u = p->g0u; r.slu = p->slu;
+    r.harm_cnt = p->harm_cnt;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) r.poly[u] = p->poly[u];
+    r.rec = p;
+    return r;
+}
+
+typedef const shm::sc_pair* TrigTab;     // LDS
+
+// FPL samples per lane of one voice (frames i[j], launch-relative), float64.  Every argument except
+// i/di is wave-uniform, so the branches on kind / fm_mode / envelope do not diverge.
+//   tile_last: last frame index any lane of this wave touches (uniform)
+template <int FPL, bool BANK>
+__device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* __restrict__ fmrec,
+                                            const BankPtrs& B, const sh_voice* __restrict__ vfull,
+                                            uint64_t start, uint32_t tile_last,
+                                            const uint32_t (&i)[FPL], const double (&di)[FPL],
+                                            const double* __restrict__ fm_cumsum, const double* __restrict__ pwm,
+                                            TrigTab trig, double (&x)[FPL]) {
+    double th[FPL];
+    // ---- phase: the reference's accumulated t at each frame ----
+    if (tile_last < r.remain) {
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) th[j] = fma(di[j], r.dt, r.t_base);      // exact (stays on the piece)
+    } else {                                                                   // rare: tile straddles a binade
+        const bool fm = (r.flags & FL_FM) != 0;
+        const sh_segment* tab = B.segs + (fm ? vfull->time_seg_offset : vfull->seg_offset);
+        const uint32_t cnt = fm ? vfull->time_seg_count : vfull->seg_count;
+        const uint32_t seg0 = r.rec->seg;
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            if (i[j] < r.remain) {
+                th[j] = fma(di[j], r.dt, r.t_base);
+            } else {
+                uint64_t n = start + i[j];
+                uint32_t sgi = seg0;
+                while (sgi + 1 < cnt && tab[sgi + 1].n0 <= n) ++sgi;
+                th[j] = fma((double)(n - tab[sgi].n0), tab[sgi].dt, tab[sgi].t0);
+            }
+        }
+    }
+    if (r.flags & FL_FM) {
+        const uint32_t fm_mode = (r.flags & FL_FM) >> FL_FM_SHIFT;
+        const VoiceFM SH_CONST_AS* fp = as_const(fmrec);
+        struct { double frequency, phase0, f_inc, lfo_a_rel, lfo_d, lfo_K, lfo_C0, lfo_bias; } f;
+        f.frequency = fp->frequency; f.phase0 = fp->phase0; f.f_inc = fp->f_inc; f.lfo_a_rel = fp->lfo_a_rel;
+        f.lfo_d = fp->lfo_d; f.lfo_K = fp->lfo_K; f.lfo_C0 = fp->lfo_C0; f.lfo_bias = fp->lfo_bias;
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            double Ln;
+            if (fm_mode == SH_FM_SINE) {
+                double arg = fma(di[j], f.lfo_d, f.lfo_a_rel), ls, lc;
+                shm::sincos_tab(arg, trig, ls, lc);
+                Ln = fma(f.lfo_K, f.lfo_C0 - lc, f.lfo_bias * ((double)start + di[j]));
+            } else {
+                Ln = fm_cumsum[i[j]];
+            }
+            th[j] = f.frequency * th[j] + fma(f.f_inc, Ln, f.phase0);          // t*freq + phase_correction
+        }
+    }
+    // ---- waveform ----
+    if (r.flags & FL_POLY) {
+        // Harmonics with k <= 16: sum_k a_k sin(k t) = sin(t) * P(cos t), P of degree 15 (coefficients
+        // converted on the host in exact rational arithmetic), Horner: 15 FMAs instead of 32 Clenshaw ops
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            double sn, c;
+            shm::sincos_tab(th[j], trig, sn, c);
+            double p = r.poly[0];
+#pragma unroll
+            for (int u = 1; u < 16; ++u) p = fma(p, c, r.poly[u]);
+            x[j] = p * sn;
+        }
+        if (BANK && (r.flags & FL_FOLDED)) return;          // amplitude and envelope live in the bus gains
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) x[j] = x[j] * r.amplitude + r.bias;
+    } else {
+        switch (r.flags & FL_KIND) {
+        case SH_SINE:
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                double sn, cs;
+                shm::sincos_tab(th[j], trig, sn, cs);
+                x[j] = sn * r.amplitude + r.bias;
+            }
+            break;
+        case SH_SAWTOOTH:
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = shm::saw_value(th[j], r.amplitude * 2.0, r.bias);
+            break;
+        case SH_SQUARE:
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = shm::square_value(th[j], r.amplitude, r.bias);
+            break;
+        case SH_PULSE: {
+            const double pw = r.rec->pulsewidth;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = shm::pulse_value(th[j], pwm ? pwm[i[j]] : pw, r.amplitude, r.bias);
+        } break;
+        default: {   // SH_HARMONICS, general forms
+            double h[FPL];
+            if (r.flags & FL_DENSE) {
+                // Clenshaw: b_k = a_k + 2cos(t) b_{k+1} - b_{k+2}; sum_k a_k sin(k t) = b_1 sin(t)
+                double sn[FPL], c2[FPL], b1[FPL], b2[FPL];
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    double c;
+                    shm::sincos_tab(th[j], trig, sn[j], c);
+                    c2[j] = c + c;
+                    b1[j] = 0.0;
+                    b2[j] = 0.0;
+                }
+                for (uint32_t k = 0; k < r.harm_cnt; k += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double ak = r.harm[k + u];
+#pragma unroll
+                        for (int j = 0; j < FPL; ++j) {
+                            double bn = fma(c2[j], b1[j], ak - b2[j]);
+                            b2[j] = b1[j];
+                            b1[j] = bn;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) h[j] = b1[j] * sn[j];
+            } else {
+                const sh_partial SH_CONST_AS* p = reinterpret_cast<const sh_partial SH_CONST_AS*>(r.harm);
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) h[j] = 0.0;
+                for (uint32_t k = 0; k < r.harm_cnt; ++k) {
+                    const double pk = p[k].k, pa = p[k].amp;
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) {
+                        double sn, cs;
+                        shm::sincos_tab(th[j] * pk, trig, sn, cs);
+                        h[j] += sn * pa;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = h[j] * r.amplitude + r.bias;
+        } break;
+        }
+    }
+    // ---- envelope ----
+    if (r.flags & FL_ENV_UNIFORM) {            // the whole launch lies on one piece (the common case)
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) x[j] = x[j] * fma(di[j], r.slu, r.g0u);
+    } else {                                   // this launch crosses attack/decay/sustain/release ends
+        const VoiceLaunch SH_CONST_AS* q = r.rec;
+        const uint32_t e0 = q->eb[0], e1 = q->eb[1], e2 = q->eb[2], e3 = q->eb[3], ti = q->tail_i;
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const uint32_t ii = i[j];
+            double g;
+            if (ii < e0) g = fma(di[j], q->slope[0], q->g0[0]);
+            else if (ii < e1) g = fma(di[j], q->slope[1], q->g0[1]);
+            else if (ii < e2) g = fma(di[j], q->slope[2], q->g0[2]);
+            else if (ii < e3) g = fma(di[j], q->slope[3], q->g0[3]);
+            else g = (ii == ti) ? q->tail_amp : 0.0;
+            x[j] = x[j] * g;
+        }
+    }
+}
+
+// voice-major materialisation: out[v*stride + i].  block = 4 waves on 4 consecutive tiles of one voice.
+template <int FPL>
+__global__ __launch_bounds__(256) void k_generate(BankPtrs B, const shm::sc_pair* __restrict__ trig_g, uint32_t first,
+                                                  const VoiceLaunch* __restrict__ launch,
+                                                  const VoiceFM* __restrict__ launch_fm,
                                                   uint64_t start, uint32_t n,
                                                   const double* __restrict__ fm_cumsum,
                                                   const double* __restrict__ pwm,
                                                   float* __restrict__ out32, double* __restrict__ out64,
                                                   size_t stride) {
+    __shared__ shm::sc_pair trig[shm::TRIG_N];
+    for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
+    __syncthreads();
     const uint32_t vi = blockIdx.y;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const sh_voice& v = B.voices[first + vi];
-    const Located L = loc[vi];
-    double x = voice_sample(v, B, L, start, i, fm_cumsum, pwm);
-    if (out32) out32[(size_t)vi * stride + i] = (float)x;
-    if (out64) out64[(size_t)vi * stride + i] = x;
-}
-
-// fused generate-and-mix
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_bank_render(BankPtrs B, uint32_t nvoices,
-                                                            const Located* __restrict__ loc,
-                                                            uint64_t start, uint32_t nframes,
-                                                            float2* __restrict__ bus32,
-                                                            double2* __restrict__ bus64) {
-    __shared__ double red[WAVES][2][64];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t i_raw = blockIdx.x * 64 + lane;
-    const uint32_t i = i_raw < nframes ? i_raw : nframes - 1;
-    double accl = 0.0, accr = 0.0;
-    for (uint32_t vi = wave; vi < nvoices; vi += WAVES) {
-        const sh_voice& v = B.voices[vi];
-        const Located L = loc[vi];
-        double x = voice_sample(v, B, L, start, i, nullptr, nullptr);
-        accl = fma((double)v.gain_l, x, accl);
-        accr = fma((double)v.gain_r, x, accr);
-    }
-    red[wave][0][lane] = accl;
-    red[wave][1][lane] = accr;
-    __syncthreads();
-    if (wave == 0 && i_raw < nframes) {
-        double l = red[0][0][lane], r = red[0][1][lane];
+    const uint32_t tile0 = (blockIdx.x * 4 + wave) * (64 * FPL);
+    if (tile0 >= n) return;
+    uint32_t tile_last = tile0 + 64 * FPL - 1;
+    if (tile_last > n - 1) tile_last = n - 1;
+    uint32_t i[FPL];
+    double di[FPL];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) {
-            l += red[w][0][lane];
-            r += red[w][1][lane];
-        }
-        if (bus32) bus32[i_raw] = make_float2((float)l, (float)r);
-        if (bus64) bus64[i_raw] = make_double2(l, r);
+    for (int j = 0; j < FPL; ++j) {
+        uint32_t raw = tile0 + j * 64 + lane;
+        i[j] = raw < n ? raw : n - 1;
+        di[j] = (double)i[j];
     }
+    const VoiceRegs r = load_record(as_const(launch) + vi);
+    double x[FPL];
+    voice_block<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, start, tile_last, i, di, fm_cumsum, pwm, trig, x);
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        uint32_t raw = tile0 + j * 64 + lane;
+        if (raw < n) {
+            if (out32) out32[(size_t)vi * stride + raw] = (float)x[j];
+            if (out64) out64[(size_t)vi * stride + raw] = x[j];
+        }
+    }
+}
+
+// fused generate-and-mix.  grid = (frame tiles, voice groups); block = WAVES waves on ONE tile of 64*FPL
+// frames; wave w walks voices v0+w, v0+w+WAVES, ... of its group with the voice record in SGPRs; float64
+// partial (L, R) per lane; LDS-staged sum across the waves; one store per frame.  With one group the block
+// writes the final bus; with several it writes a float64 partial bus per group and k_bus_combine folds
+// them in group order -- either way voices are summed in a fixed order (reproducible run to run).
+template <int WAVES, int FPL, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
+                                                                  uint32_t nvoices, uint32_t voices_per_group,
+                                                                  const VoiceLaunch* __restrict__ launch,
+                                                                  const VoiceFM* __restrict__ launch_fm,
+                                                                  uint64_t start, uint32_t nframes,
+                                                                  float2* __restrict__ bus32,
+                                                                  double2* __restrict__ bus64,
+                                                                  double2* __restrict__ parts) {
+    __shared__ double red[WAVES][2][64 * FPL];
+    __shared__ shm::sc_pair trig[shm::TRIG_N];
+    for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += WAVES * 64) trig[k] = trig_g[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile0 = blockIdx.x * (64 * FPL);
+    uint32_t tile_last = tile0 + 64 * FPL - 1;
+    if (tile_last > nframes - 1) tile_last = nframes - 1;
+    const uint32_t v0 = blockIdx.y * voices_per_group;
+    uint32_t v1 = v0 + voices_per_group;
+    if (v1 > nvoices) v1 = nvoices;
+    uint32_t i[FPL];
+    double di[FPL], accl[FPL], accr[FPL];
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        uint32_t raw = tile0 + j * 64 + lane;
+        i[j] = raw < nframes ? raw : nframes - 1;
+        di[j] = (double)i[j];
+        accl[j] = 0.0;
+        accr[j] = 0.0;
+    }
+    const VoiceLaunch SH_CONST_AS* rp = as_const(launch) + v0 + wave;
+    for (uint32_t vi = v0 + wave; vi < v1; vi += WAVES, rp += WAVES) {
+        const VoiceRegs r = load_record(rp);
+        double x[FPL];
+        voice_block<FPL, true>(r, launch_fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            accl[j] = fma(r.gain_l, x[j], accl[j]);
+            accr[j] = fma(r.gain_r, x[j], accr[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        red[wave][0][j * 64 + lane] = accl[j];
+        red[wave][1][j * 64 + lane] = accr[j];
+    }
+    __syncthreads();
+    // waves 0..FPL-1 each finish 64 frames
+    if (wave < FPL) {
+        const uint32_t f = wave * 64 + lane;
+        const uint32_t raw = tile0 + f;
+        if (raw < nframes) {
+            double l = red[0][0][f], rr = red[0][1][f];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                l += red[w][0][f];
+                rr += red[w][1][f];
+            }
+            if (parts) {
+                parts[(size_t)blockIdx.y * nframes + raw] = make_double2(l, rr);
+            } else {
+                if (bus32) bus32[raw] = make_float2((float)l, (float)rr);
+                if (bus64) bus64[raw] = make_double2(l, rr);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bus_combine(const double2* __restrict__ parts, uint32_t ngroups, uint32_t nframes,
+                                                     float2* __restrict__ bus32, double2* __restrict__ bus64) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nframes) return;
+    double2 s = parts[i];
+    for (uint32_t g = 1; g < ngroups; ++g) {
+        const double2 p = parts[(size_t)g * nframes + i];
+        s.x += p.x;
+        s.y += p.y;
+    }
+    if (bus32) bus32[i] = make_float2((float)s.x, (float)s.y);
+    if (bus64) bus64[i] = s;
 }
 
 // ---- mixer over materialised float32 voices ------------------------------------------
@@ -369,7 +673,8 @@ struct sh_bank {
     sh_segment* d_segs = nullptr;
     double*     d_coefs = nullptr;
     sh_partial* d_partials = nullptr;
-    Located*    d_loc = nullptr;
+    VoiceLaunch* d_launch = nullptr;
+    VoiceFM*    d_launch_fm = nullptr;
     float2*     d_gains = nullptr;
     uint32_t    nsegs = 0, ncoefs = 0, npartials = 0;
     std::vector<sh_voice> h_voices;    // for validation of per-call arguments
@@ -413,10 +718,12 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             return sh::set_error(SH_ERR_INVALID, "voice %u: phase table [%u,+%u) outside %u pieces", i, off, cnt, nsegs);
         if (segs[off].n0 != 0) return sh::set_error(SH_ERR_INVALID, "voice %u: phase table does not start at sample 0", i);
         if (v.kind == SH_HARMONICS) {
+            if (v.harm_dense < 0 || v.harm_dense > 2) return sh::set_error(SH_ERR_INVALID, "voice %u: harm_dense %d not in {0,1,2}", i, v.harm_dense);
+            if (v.harm_dense == 2 && v.harm_count != 16) return sh::set_error(SH_ERR_INVALID, "voice %u: polynomial form needs 16 coefficients", i);
             uint32_t lim = v.harm_dense ? ncoefs : npartials;
             if (v.harm_offset > lim || v.harm_count > lim - v.harm_offset)
                 return sh::set_error(SH_ERR_INVALID, "voice %u: harmonics [%u,+%u) outside table of %u", i, v.harm_offset, v.harm_count, lim);
-            if (v.harm_dense && (v.harm_count & 7))
+            if (v.harm_dense == 1 && (v.harm_count & 7))
                 return sh::set_error(SH_ERR_INVALID, "voice %u: dense harmonic count %u is not a multiple of 8", i, v.harm_count);
         }
     }
@@ -436,8 +743,9 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     if (!rc) rc = upload_array(&b->d_partials, partials, npartials, st);
     if (!rc) rc = upload_array(&b->d_gains, gains.data(), nvoices, st);
     if (!rc) {
-        hipError_t e = hipMalloc((void**)&b->d_loc, sizeof(Located) * nvoices);
-        if (e != hipSuccess) rc = sh::hip_error(e, "hipMalloc(loc)");
+        hipError_t e = hipMalloc((void**)&b->d_launch, sizeof(VoiceLaunch) * nvoices);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_launch_fm, sizeof(VoiceFM) * nvoices);
+        if (e != hipSuccess) rc = sh::hip_error(e, "hipMalloc(launch records)");
     }
     if (!rc) {
         hipError_t e = hipStreamSynchronize(st);
@@ -459,7 +767,8 @@ int sh_bank_destroy(sh_bank* b) {
         if (b->d_segs) hipFree(b->d_segs);
         if (b->d_coefs) hipFree(b->d_coefs);
         if (b->d_partials) hipFree(b->d_partials);
-        if (b->d_loc) hipFree(b->d_loc);
+        if (b->d_launch) hipFree(b->d_launch);
+        if (b->d_launch_fm) hipFree(b->d_launch_fm);
         if (b->d_gains) hipFree(b->d_gains);
     }
     delete b;
@@ -468,10 +777,12 @@ int sh_bank_destroy(sh_bank* b) {
 
 uint32_t sh_bank_nvoices(const sh_bank* b) { return b ? b->nvoices : 0; }
 
-static int locate(sh_bank* b, uint32_t first, uint32_t count, uint64_t start) {
-    hipLaunchKernelGGL(k_locate, dim3(sh::div_up(count, 64)), dim3(64), 0, sh::state().stream,
-                       ptrs(b), first, count, start, b->d_loc);
-    SH_CHECK_LAUNCH("k_locate");
+static const shm::sc_pair* trig_table() { return (const shm::sc_pair*)sh::state().trig; }
+
+static int prepare(sh_bank* b, uint32_t first, uint32_t count, uint64_t start, uint32_t nframes) {
+    hipLaunchKernelGGL(k_prepare, dim3(sh::div_up(count, 64)), dim3(64), 0, sh::state().stream,
+                       ptrs(b), first, count, start, nframes, b->d_launch, b->d_launch_fm);
+    SH_CHECK_LAUNCH("k_prepare");
     return SH_OK;
 }
 
@@ -494,10 +805,10 @@ int sh_osc_render(sh_bank* bank, uint32_t voice, const sh_buf* fm_cumsum, const 
         if (rc) return rc;
         d32 = (float*)sh::state().scratch;
     }
-    int rc = locate(bank, voice, 1, start);
+    int rc = prepare(bank, voice, 1, start, n);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_generate, dim3(sh::div_up(n, 256), 1), dim3(256), 0, sh::state().stream,
-                       ptrs(bank), voice, bank->d_loc, start, n,
+    hipLaunchKernelGGL(k_generate<1>, dim3(sh::div_up(n, 256), 1), dim3(256), 0, sh::state().stream,
+                       ptrs(bank), trig_table(), voice, bank->d_launch, bank->d_launch_fm, start, n,
                        fm_cumsum ? (const double*)fm_cumsum->ptr : nullptr,
                        pwm ? (const double*)pwm->ptr : nullptr,
                        d32, out_f64 ? (double*)out_f64->ptr : nullptr, (size_t)0);
@@ -525,14 +836,21 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
         return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: output buffer too small");
     int rc = bank_check_plain(b, "sh_bank_generate");
     if (rc) return rc;
-    rc = locate(b, 0, b->nvoices, start);
+    rc = prepare(b, 0, b->nvoices, start, nframes);
     if (rc) return rc;
     // gridDim.y is limited to 65535 voices per launch
+    const int fpl = nframes >= 2048 ? 2 : 1;
     for (uint32_t first = 0; first < b->nvoices; first += 65535) {
         uint32_t cnt = b->nvoices - first < 65535 ? b->nvoices - first : 65535;
-        hipLaunchKernelGGL(k_generate, dim3(sh::div_up(nframes, 256), cnt), dim3(256), 0, sh::state().stream,
-                           ptrs(b), first, b->d_loc + first, start, nframes, (const double*)nullptr, (const double*)nullptr,
-                           (float*)voices_out->ptr + (size_t)first * stride, (double*)nullptr, stride);
+        float* o = (float*)voices_out->ptr + (size_t)first * stride;
+        if (fpl == 2)
+            hipLaunchKernelGGL(k_generate<2>, dim3(sh::div_up(nframes, 512), cnt), dim3(256), 0, sh::state().stream,
+                               ptrs(b), trig_table(), first, b->d_launch + first, b->d_launch_fm + first, start, nframes,
+                               (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride);
+        else
+            hipLaunchKernelGGL(k_generate<1>, dim3(sh::div_up(nframes, 256), cnt), dim3(256), 0, sh::state().stream,
+                               ptrs(b), trig_table(), first, b->d_launch + first, b->d_launch_fm + first, start, nframes,
+                               (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride);
         SH_CHECK_LAUNCH("k_generate");
     }
     return SH_OK;
@@ -546,20 +864,68 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     if (bus_f64 && bus_f64->bytes < (size_t)nframes * 16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f64 too small");
     int rc = bank_check_plain(b, "sh_bank_render");
     if (rc) return rc;
-    rc = locate(b, 0, b->nvoices, start);
+    rc = prepare(b, 0, b->nvoices, start, nframes);
     if (rc) return rc;
     float2* o32 = bus_f32 ? (float2*)bus_f32->ptr : nullptr;
     double2* o64 = bus_f64 ? (double2*)bus_f64->ptr : nullptr;
-    dim3 grid(sh::div_up(nframes, 64));
     hipStream_t st = sh::state().stream;
-    if (b->nvoices >= 128) {
-        hipLaunchKernelGGL(k_bank_render<16>, grid, dim3(16 * 64), 0, st, ptrs(b), b->nvoices, b->d_loc, start, nframes, o32, o64);
-    } else if (b->nvoices >= 16) {
-        hipLaunchKernelGGL(k_bank_render<8>, grid, dim3(8 * 64), 0, st, ptrs(b), b->nvoices, b->d_loc, start, nframes, o32, o64);
-    } else {
-        hipLaunchKernelGGL(k_bank_render<2>, grid, dim3(2 * 64), 0, st, ptrs(b), b->nvoices, b->d_loc, start, nframes, o32, o64);
+    // variant = WAVES*100 + FPL*10 + MINW (SYNTHHIP_VARIANT overrides the tuned default)
+    static int variant = -1;
+    if (variant < 0) {
+        const char* e = getenv("SYNTHHIP_VARIANT");
+        variant = e ? atoi(e) : 0;
     }
+    int var = variant;
+    if (var == 0) var = b->nvoices >= 64 ? 826 : (b->nvoices >= 8 ? 421 : 211);
+    const int W = var / 100, F = (var / 10) % 10;
+    // enough workgroups to cover the 256 CUs several times over: split the voices into groups when the
+    // frame range alone gives too few tiles (SYNTHHIP_GROUPS overrides)
+    const uint32_t tiles = sh::div_up(nframes, 64 * F);
+    uint32_t groups = 1;
+    while (tiles * groups < 1024 && b->nvoices / (groups * 2) >= (uint32_t)(4 * W)) groups *= 2;
+    {
+        static int forced = -1;
+        if (forced < 0) { const char* e = getenv("SYNTHHIP_GROUPS"); forced = e ? atoi(e) : 0; }
+        if (forced > 0) groups = (uint32_t)forced;
+    }
+    const uint32_t vpg = (b->nvoices + groups - 1) / groups;
+    double2* parts = nullptr;
+    if (groups > 1) {
+        rc = sh::ensure_scratch((size_t)groups * nframes * sizeof(double2));
+        if (rc) return rc;
+        parts = (double2*)sh::state().scratch;
+    }
+#define SH_LAUNCH_RENDER(W_, F_, M_)                                                                          \
+    hipLaunchKernelGGL((k_bank_render<W_, F_, M_>), dim3(tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),       \
+                       trig_table(), b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, o32, o64, parts)
+    switch (var) {
+    case 1621: SH_LAUNCH_RENDER(16, 2, 1); break;
+    case 1611: SH_LAUNCH_RENDER(16, 1, 1); break;
+    case 821: SH_LAUNCH_RENDER(8, 2, 1); break;
+    case 822: SH_LAUNCH_RENDER(8, 2, 2); break;
+    case 826: SH_LAUNCH_RENDER(8, 2, 6); break;
+    case 828: SH_LAUNCH_RENDER(8, 2, 8); break;
+    case 426: SH_LAUNCH_RENDER(4, 2, 6); break;
+    case 428: SH_LAUNCH_RENDER(4, 2, 8); break;
+    case 811: SH_LAUNCH_RENDER(8, 1, 1); break;
+    case 814: SH_LAUNCH_RENDER(8, 1, 4); break;
+    case 841: SH_LAUNCH_RENDER(8, 4, 1); break;
+    case 421: SH_LAUNCH_RENDER(4, 2, 1); break;
+    case 424: SH_LAUNCH_RENDER(4, 2, 4); break;
+    case 411: SH_LAUNCH_RENDER(4, 1, 1); break;
+    case 418: SH_LAUNCH_RENDER(4, 1, 8); break;
+    case 441: SH_LAUNCH_RENDER(4, 4, 1); break;
+    case 211: SH_LAUNCH_RENDER(2, 1, 1); break;
+    case 221: SH_LAUNCH_RENDER(2, 2, 1); break;
+    default: return sh::set_error(SH_ERR_INVALID, "sh_bank_render: unknown SYNTHHIP_VARIANT %d", var);
+    }
+#undef SH_LAUNCH_RENDER
     SH_CHECK_LAUNCH("k_bank_render");
+    if (groups > 1) {
+        hipLaunchKernelGGL(k_bus_combine, dim3(sh::div_up(nframes, 256)), dim3(256), 0, st,
+                           (const double2*)parts, groups, nframes, o32, o64);
+        SH_CHECK_LAUNCH("k_bus_combine");
+    }
     return SH_OK;
 }
 

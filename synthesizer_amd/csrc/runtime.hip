@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
+#include <vector>
 
 namespace sh {
 
@@ -75,6 +77,17 @@ int sh_init(int device) {
     SH_HIP(hipMalloc((void**)&s.flag, sizeof(int) * 16));
     SH_HIP(hipHostMalloc((void**)&s.flag_host, sizeof(int) * 16, hipHostMallocDefault));
     SH_HIP(hipMemsetAsync(s.flag, 0, sizeof(int) * 16, s.stream));
+    {   // sin/cos table for the oscillator kernels: correctly rounded doubles of sin/cos(k*2pi/512)
+        std::vector<double> tab(2 * 512);
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        for (int k = 0; k < 512; ++k) {
+            long double a = two_pi * (long double)k / 512.0L;
+            tab[2 * k] = (double)sinl(a);
+            tab[2 * k + 1] = (double)cosl(a);
+        }
+        SH_HIP(hipMalloc(&s.trig, tab.size() * sizeof(double)));
+        SH_HIP(hipMemcpy(s.trig, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     SH_HIP(hipStreamSynchronize(s.stream));
     s.device = device;
     s.initialized = true;
@@ -87,6 +100,7 @@ int sh_shutdown(void) {
     hipStreamSynchronize(s.stream);
     if (s.scratch) hipFree(s.scratch);
     if (s.flag) hipFree(s.flag);
+    if (s.trig) hipFree(s.trig);
     if (s.flag_host) hipHostFree(s.flag_host);
     hipEventDestroy(s.ev_start);
     hipEventDestroy(s.ev_stop);

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass, field, replace
+from fractions import Fraction
 from functools import lru_cache
 from math import pi, sin, cos
 from typing import Dict, Generator, List, Optional, Sequence, Tuple
@@ -38,6 +39,38 @@ _DENSE_MAX_K = 4096        # Harmonics: use the Clenshaw (dense) form when max k
 @lru_cache(maxsize=4096)
 def _table(t0: float, inc: float) -> PhaseTable:
     return PhaseTable(t0, inc)
+
+
+@lru_cache(maxsize=None)
+def _cheb_u(n: int) -> Tuple[Tuple[int, ...], ...]:
+    """Monomial coefficients (ascending powers) of the Chebyshev polynomials U_0 .. U_n."""
+    U = [[1], [0, 2]]
+    for _ in range(2, n + 1):
+        a = [0] + [2 * c for c in U[-1]]
+        b = U[-2] + [0] * (len(a) - len(U[-2]))
+        U.append([x - y for x, y in zip(a, b)])
+    return tuple(tuple(u) for u in U[:n + 1])
+
+
+@lru_cache(maxsize=1024)
+def series_polynomial(coef_by_k: Tuple[float, ...]) -> Optional[Tuple[float, ...]]:
+    """sum_{k=1..16} a_k sin(k t) = sin(t) * P(cos t): the 16 coefficients of P, highest power first,
+    converted in exact rational arithmetic (coef_by_k[k-1] = a_k).  None when the monomial form would
+    lose accuracy (its coefficients grow like 2^k; bounded here so that the float64 Horner evaluation
+    stays ~1e-11 of the largest partial)."""
+    assert len(coef_by_k) == 16
+    U = _cheb_u(15)
+    p = [Fraction(0)] * 16
+    for k in range(1, 17):
+        a = Fraction(coef_by_k[k - 1])
+        if a:
+            for j, c in enumerate(U[k - 1]):
+                p[j] += a * c
+    pf = [float(x) for x in p]
+    scale = max((abs(a) for a in coef_by_k), default=0.0)
+    if scale == 0.0 or max(abs(x) for x in pf) > scale * float(1 << 20):
+        return None
+    return tuple(reversed(pf))
 
 
 @dataclass
@@ -104,6 +137,7 @@ class VoiceSpec:
     fm_phase0: float = 0.0
     fm_inc: float = 0.0
     lfo: Tuple[float, float, float, float, float, float] = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)  # a, d, amp, bias, K, C0
+    harm_poly: Optional[Tuple[float, ...]] = None       # 16 polynomial coefficients (all k <= 16), highest power first
     harm_dense: Optional[Tuple[float, ...]] = None      # Clenshaw coefficients, k = K..1, len % 8 == 0
     harm_sparse: Optional[Tuple[Tuple[float, float], ...]] = None
     env: Optional[EnvelopeSpec] = None
@@ -149,7 +183,14 @@ def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float
             v["fm_phase0"] = s.fm_phase0
             v["fm_inc"] = s.fm_inc
             (v["lfo_a"], v["lfo_d"], v["lfo_amp"], v["lfo_bias"], v["lfo_K"], v["lfo_C0"]) = s.lfo
-        if s.harm_dense is not None:
+        if s.harm_poly is not None:
+            if s.harm_poly not in coef_index:
+                coef_index[s.harm_poly] = len(coef_list)
+                coef_list.extend(s.harm_poly)
+            v["harm_offset"] = coef_index[s.harm_poly]
+            v["harm_count"] = 16
+            v["harm_dense"] = 2
+        elif s.harm_dense is not None:
             if s.harm_dense not in coef_index:
                 coef_index[s.harm_dense] = len(coef_list)
                 coef_list.extend(s.harm_dense)
@@ -422,6 +463,7 @@ class Harmonics(_Carrier):
     def _make_spec(self) -> VoiceSpec:
         dense = None
         sparse = None
+        poly = None
         ks = [k for k, _ in self.harmonics]
         integral = all(float(k) == int(k) for k in ks)
         kmax = max((abs(int(k)) for k in ks), default=0) if integral else 0
@@ -434,13 +476,16 @@ class Harmonics(_Carrier):
                     coef[k] += float(a)
                 elif k < 0:
                     coef[-k] -= float(a)                 # sin(-k t) = -sin(k t)
-            dense = tuple(coef[n:0:-1])                  # k = n .. 1
+            if kmax <= 16:
+                poly = series_polynomial(tuple((coef[1:] + [0.0] * 16)[:16]))
+            if poly is None:
+                dense = tuple(coef[n:0:-1])              # k = n .. 1
         else:
             sparse = tuple((float(k), float(a)) for k, a in self.harmonics)
             if not sparse:
                 sparse = ((0.0, 0.0),)
         return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias),
-                         harm_dense=dense, harm_sparse=sparse, **self._phase_fields())
+                         harm_poly=poly, harm_dense=dense, harm_sparse=sparse, **self._phase_fields())
 
 
 class EnvelopeFilter(Oscillator):

@@ -82,14 +82,24 @@ def test_negative_phase_and_frequency(gpu):
         _check(g, o, 5000, exact=kind in ("Square", "Pulse"))
 
 
-def test_harmonics_dense_and_sparse(gpu):
+def test_harmonics_poly_dense_and_sparse(gpu):
+    """The three evaluation forms of Harmonics: degree-15 polynomial in cos t (all k <= 16), Clenshaw
+    (larger integer k), term by term (non-integer or very sparse k)."""
     partials = [(k, 1.0 / k) for k in range(1, 17)]
     g, o = _pair("Harmonics", 220.0, partials, amplitude=0.4, phase=0.2, bias=0.01, samplerate=SR)
-    assert g.spec().harm_dense is not None
+    assert g.spec().harm_poly is not None
     _check(g, o, 20000, max_ulp=2)
     odd = [(1, 1.0), (3, 0.3), (5, 0.2), (9, -0.1), (3, 0.05), (-2, 0.1), (0, 0.5)]
     g, o = _pair("Harmonics", 330.0, odd, samplerate=SR)
-    assert g.spec().harm_dense is not None
+    assert g.spec().harm_poly is not None
+    _check(g, o, 20000, max_ulp=2)
+    big = [(k, 1.0) for k in range(1, 17)]                       # worst case for the monomial form
+    g, o = _pair("Harmonics", 97.0, big, amplitude=0.1, samplerate=SR)
+    assert g.spec().harm_poly is not None
+    _check(g, o, 20000, max_ulp=2)
+    many = [(k, 1.0 / k) for k in range(1, 41)]
+    g, o = _pair("Harmonics", 110.0, many, amplitude=0.4, samplerate=SR)
+    assert g.spec().harm_poly is None and g.spec().harm_dense is not None
     _check(g, o, 20000, max_ulp=2)
     sparse = [(1, 1.0), (1000, 0.05), (2.5, 0.1)]
     g, o = _pair("Harmonics", 5.0, sparse, samplerate=SR)
