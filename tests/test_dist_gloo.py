@@ -1,0 +1,91 @@
+"""Multi-process path on CPU (gloo, world_size 2): the voice table is partitioned with
+synthesizer_amd.dist.shard_range, every rank renders the partial bus of its shard (here with the oracle --
+no GPU in this container), the partial buses are summed by the collective, and the result must equal the
+single-process bus.  This is the data flow of dist.DistVoiceBank with RCCL replaced by gloo."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nvoices, nframes, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as td
+    from oracle import synth_oracle as O
+    from synthesizer_amd.dist import shard_range
+    from synthesizer_amd.workloads import additive_voices
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    voices, gains = additive_voices(O, nvoices, 48000, seed=5, partials=4)
+    lo, hi = shard_range(nvoices, rank, world)
+    part = np.array(O.mix_bus([v.take(nframes) for v in voices[lo:hi]], gains[lo:hi]), dtype=np.float64)
+    t = torch.from_numpy(part.copy())
+    td.reduce(t, dst=0, op=td.ReduceOp.SUM)            # float64 partial buses summed to rank 0
+    # the rendezvous used for the RCCL unique id: 128 opaque bytes broadcast from rank 0
+    from synthesizer_amd.dist import _torch_broadcast
+    ident = _torch_broadcast(bytes(range(128)) if rank == 0 else None, rank, world, 128)
+    td.barrier()
+    if rank == 0:
+        q.put((t.numpy().copy(), ident, (lo, hi)))
+    else:
+        q.put((None, ident, (lo, hi)))
+    td.destroy_process_group()
+
+
+def test_voice_sharded_bus_equals_single_process():
+    import torch.multiprocessing as mp
+    from oracle import synth_oracle as O
+    from synthesizer_amd.workloads import additive_voices
+    nvoices, nframes, world = 13, 600, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nvoices, nframes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bus = next(r[0] for r in results if r[0] is not None)
+    assert all(r[1] == bytes(range(128)) for r in results)
+    assert sorted(r[2] for r in results) == [(0, 7), (7, 13)]
+    voices, gains = additive_voices(O, nvoices, 48000, seed=5, partials=4)
+    want = np.array(O.mix_bus([v.take(nframes) for v in voices], gains), dtype=np.float64)
+    assert np.max(np.abs(bus - want)) < 1e-14
+
+
+def test_tcp_rendezvous_broadcast():
+    """The torch-free rendezvous (MASTER_ADDR:MASTER_PORT+1) used when no process group exists."""
+    import multiprocessing as mp
+    from synthesizer_amd.dist import _tcp_broadcast
+    port = _free_port()
+    os.environ["SYNTHHIP_RDZV_PORT"] = str(port)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    payload = os.urandom(128)
+
+    def client(q):
+        q.put(_tcp_broadcast(None, 1, 2, 128))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=client, args=(q,))
+    p.start()
+    assert _tcp_broadcast(payload, 0, 2, 128) == payload
+    assert q.get(timeout=60) == payload
+    p.join(timeout=30)
+    del os.environ["SYNTHHIP_RDZV_PORT"]

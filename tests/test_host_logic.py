@@ -1,0 +1,146 @@
+"""Host-side logic of the package that needs no GPU: envelope boundaries, voice packing, the harmonic
+polynomial, sharding, Sample bookkeeping."""
+import itertools
+import math
+
+import numpy as np
+import pytest
+
+from oracle import synth_oracle as O
+from synthesizer_amd import _native as N
+from synthesizer_amd import oscillators as G
+from synthesizer_amd.dist import shard_range, shard_sizes
+from synthesizer_amd.sample import Sample
+
+
+def oracle_envelope_gains(a, d, s, sl, r, sr, n):
+    """gain per sample of the reference EnvelopeFilter: feed it the constant 1."""
+    class One(O.Oscillator):
+        def blocks(self):
+            while True:
+                yield [1.0] * O.norm_osc_blocksize
+    return O.EnvelopeFilter(One(sr), a, d, s, sl, r).take(n)
+
+
+@pytest.mark.parametrize("adsr", [(0.01, 0.05, 0.5, 0.6, 0.2), (0.0, 0.05, 0.1, 0.6, 0.1), (0.02, 0.0, 0.0, 1.0, 0.05),
+                                   (0.013, 0.007, 0.0, 0.3, 0.0), (0.0, 0.0, 0.01, 0.5, 0.0), (0.05, 0.05, 0.05, 0.0, 0.05),
+                                   (0.001, 0.001, 0.001, 0.9, 0.001)])
+@pytest.mark.parametrize("sr", [48000, 44100, 8000])
+def test_envelope_spec_replays_the_reference_loops(adsr, sr):
+    a, d, s, sl, r = adsr
+    e = G.envelope_spec(a, d, s, sl, r, sr)
+    n = e.n_release_end + 10
+    want = np.array(oracle_envelope_gains(a, d, s, sl, r, sr, n))
+    idx = np.arange(n, dtype=np.float64)
+    got = np.zeros(n)
+    A, D, S, R = e.n_attack_end, e.n_decay_end, e.n_sustain_end, e.n_release_end
+    got[:A] = idx[:A] * e.attack_slope
+    got[A:D] = 1.0 + (idx[A:D] - A) * e.decay_slope
+    got[D:S] = e.sustain_level
+    got[S:R] = e.sustain_level + (idx[S:R] - S) * e.release_slope
+    if e.has_tail:
+        got[R] = e.tail_amp
+    assert A <= D <= S <= R
+    assert np.max(np.abs(got - want)) < 1e-12
+    # piece boundaries are exact: the first sample of every piece matches to rounding, no off-by-one
+    for b in (A, D, S, R):
+        if 0 < b < n:
+            assert abs(got[b] - want[b]) < 1e-12 and abs(got[b - 1] - want[b - 1]) < 1e-12
+    # stream length with stop_at_end
+    o = O.EnvelopeFilter(O.Sine(1.0, samplerate=sr), a, d, s, sl, r, stop_at_end=True)
+    assert sum(len(b) for b in o.blocks()) == e.length
+
+
+def test_pack_voices_layout_and_sharing():
+    sr = 48000
+    lfo = G.Sine(5, 0.02, samplerate=sr)
+    voices = [G.Sine(440, samplerate=sr), G.Sine(440, samplerate=sr), G.Square(100, phase=0.5, samplerate=sr),
+              G.Harmonics(220, [(1, 1), (3, 0.5)], samplerate=sr, fm_lfo=lfo),
+              G.Harmonics(330, [(1, 1), (3, 0.5)], samplerate=sr),
+              G.Harmonics(110, [(k, 1.0 / k) for k in range(1, 30)], samplerate=sr),
+              G.EnvelopeFilter(G.Pulse(50, pulsewidth=0.2, samplerate=sr), 0.1, 0.1, 0.1, 0.5, 0.1)]
+    v, segs, coefs, partials = G.pack_voices([x.spec() for x in voices], [(0.25, 0.75)] * len(voices))
+    assert v.dtype == N.VOICE_DTYPE and segs.dtype == N.SEGMENT_DTYPE
+    assert (v["seg_offset"][0], v["seg_count"][0]) == (v["seg_offset"][1], v["seg_count"][1])      # shared table
+    assert v["kind"].tolist() == [0, 0, 2, 4, 4, 4, 3]
+    assert v["fm_mode"].tolist() == [0, 0, 0, 1, 0, 0, 0]
+    assert v["harm_dense"][3] == 2 and v["harm_dense"][4] == 2 and v["harm_offset"][3] == v["harm_offset"][4]
+    assert v["harm_dense"][5] == 1 and v["harm_count"][5] == 32
+    assert v["env"]["enabled"].tolist() == [0, 0, 0, 0, 0, 0, 1]
+    assert np.allclose(v["gain_l"], 0.25) and np.allclose(v["gain_r"], 0.75)
+    for i in range(len(voices)):
+        off = v["time_seg_offset"][i] if v["fm_mode"][i] else v["seg_offset"][i]
+        assert segs["n0"][off] == 0
+    # closed-form LFO constants
+    d = 2.0 * math.pi * 5 / sr
+    assert v["lfo_d"][3] == d and v["lfo_K"][3] == 0.02 / (2.0 * math.sin(d / 2.0))
+    assert partials.dtype == N.PARTIAL_DTYPE and len(partials) == 0
+
+
+def test_harmonics_form_selection():
+    sr = 48000
+    assert G.Harmonics(100, [(k, 1.0 / k) for k in range(1, 17)], samplerate=sr).spec().harm_poly is not None
+    assert G.Harmonics(100, [(17, 1.0)], samplerate=sr).spec().harm_dense is not None
+    assert G.Harmonics(100, [(2.5, 1.0)], samplerate=sr).spec().harm_sparse is not None
+    assert G.Harmonics(100, [(1, 1.0), (5000, 1.0)], samplerate=sr).spec().harm_sparse is not None
+    assert G.Harmonics(100, [], samplerate=sr).spec().harm_sparse is not None
+
+
+def test_series_polynomial_is_accurate():
+    rng = np.random.default_rng(0)
+    th = rng.uniform(0, 2 * np.pi, 20000)
+    c, s = np.cos(th), np.sin(th)
+    for amps in ([1.0 / k for k in range(1, 17)], [1.0] * 16, list(rng.uniform(-1, 1, 16)), [0.0] * 15 + [1.0]):
+        p = G.series_polynomial(tuple(float(a) for a in amps))
+        assert p is not None and len(p) == 16
+        acc = np.full_like(c, p[0])
+        for u in range(1, 16):
+            acc = acc * c + p[u]
+        want = sum(a * np.sin(k * th) for k, a in enumerate(amps, 1))
+        assert np.max(np.abs(acc * s - want)) < 5e-11 * max(1.0, sum(abs(a) for a in amps))
+    assert G.series_polynomial(tuple([0.0] * 16)) is None
+
+
+def test_closed_form_lfo_selection():
+    sr = 48000
+    assert G.Sine(440, fm_lfo=G.Sine(5, 0.1, samplerate=sr), samplerate=sr).spec().fm_mode == N.SH_FM_SINE
+    assert G.Sine(440, fm_lfo=G.Sawtooth(5, 0.1, samplerate=sr), samplerate=sr).spec().fm_mode == N.SH_FM_BUFFER
+    assert G.Sine(440, fm_lfo=G.Sine(5, 0.1, fm_lfo=G.Sine(1, 0.1, samplerate=sr), samplerate=sr), samplerate=sr).spec().fm_mode == N.SH_FM_BUFFER
+    assert G.Pulse(440, pwm_lfo=G.Sine(1, 0.1, samplerate=sr), samplerate=sr).spec().needs_pwm
+    with pytest.raises(NotImplementedError):
+        G.EnvelopeFilter(G.EnvelopeFilter(G.Sine(1), 0, 0, 1, 1, 0), 0, 0, 1, 1, 0)
+
+
+def test_shard_ranges_partition_the_voice_table():
+    for n in (1, 7, 8, 1024, 8192, 1000):
+        for world in (1, 2, 3, 8):
+            sizes = shard_sizes(n, world)
+            assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+            ranges = [shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    with pytest.raises(ValueError):
+        shard_range(10, 3, 3)
+
+
+def test_sample_bookkeeping_without_gpu():
+    raw = np.arange(-8, 8, dtype=np.int16)
+    s = Sample.from_raw_frames(raw.tobytes(), 2, 8000, 2, name="x")
+    assert len(s) == 8 and s.nchannels == 2 and s.samplewidth == 2 and s.samplerate == 8000
+    assert s.duration == 8 / 8000 and s.frame_idx(0.0005) == 2 * 2 * 4
+    assert s.get_frame_array().tolist() == raw.tolist()
+    assert s.get_frames_numpy().shape == (8, 2)
+    assert s.copy() == s and s.copy() is not s
+    assert Sample.from_array(raw.tolist(), 8000, 2) == s
+    assert Sample.from_array(np.array(raw), 8000, 2) == s
+    assert s.maximum == 32767
+    assert abs(s.get_frames_as_floats()[0] + 8 / 32768) < 1e-12
+    with pytest.raises(ValueError):
+        Sample.from_raw_frames(b"\0\0\0", 2, 8000, 1)
+    with pytest.raises(RuntimeError):
+        s.lock().add_silence(1.0)
+    import io
+    buf = io.BytesIO()
+    Sample.from_raw_frames(raw.tobytes(), 2, 8000, 2).write_wav(buf)
+    buf.seek(0)
+    assert Sample(buf) == Sample.from_raw_frames(raw.tobytes(), 2, 8000, 2)

@@ -1,0 +1,71 @@
+"""Host logic: the exact closed form of a float64 running sum (synthesizer_amd/phasetable.py)."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+from synthesizer_amd.phasetable import PhaseTable, build_phase_table
+from tests.helpers import accumulated
+
+
+def brute(t0, inc, n):
+    out = []
+    t = t0
+    for _ in range(n):
+        out.append(t)
+        t += inc
+    return out
+
+
+CASES = [(0.0, 1 / 48000), (0.0, 2 * math.pi / 48000), (0.3, 440 / 44100), (0.0, 2 * math.pi * 3520 / 48000),
+         (-0.7, 0.013), (5.0, -0.013), (0.25, 0.25), (0.0, 0.0), (1e-3, 1e-20), (0.0, 1000 / 48000.0),
+         (0.1, 1e-7), (-3.0, 1.0), (0.5, 0.5), (1e6, 0.3)]
+
+
+@pytest.mark.parametrize("t0,inc", CASES)
+def test_table_equals_sequential_accumulation(t0, inc):
+    n = 60000
+    ref = brute(t0, inc, n)
+    pt = PhaseTable(t0, inc)
+    rng = random.Random(1)
+    idx = list(range(0, 1500)) + [rng.randrange(n) for _ in range(1500)] + list(range(n - 300, n))
+    assert all(pt.value(i) == ref[i] for i in idx)
+    # pieces are sorted, start at 0 and are few
+    starts = [s[0] for s in pt.segments]
+    assert starts[0] == 0 and starts == sorted(starts) and len(starts) < 200
+
+
+def test_random_tables_far_out():
+    rng = random.Random(7)
+    for _ in range(6):
+        t0 = rng.uniform(-2, 2)
+        inc = rng.uniform(55, 3520) / 48000 * rng.choice([1.0, 2 * math.pi])
+        pt = PhaseTable(t0, inc)
+        start = rng.randrange(5_000_000, 9_000_000)
+        ref = accumulated(t0, inc, start, 256)
+        assert all(pt.value(start + i) == ref[i] for i in range(256))
+
+
+def test_numpy_cumsum_is_sequential():
+    # the oracle helpers rely on this
+    x = np.full(50000, 1 / 48000.0)
+    x[0] = 0.0
+    assert np.cumsum(x).tolist() == brute(0.0, 1 / 48000.0, 50000)
+
+
+def test_first_index_ge():
+    pt = PhaseTable(0.0, 1 / 48000.0)
+    ref = brute(0.0, 1 / 48000.0, 60000)
+    for x in (0.01, 0.06, 0.56, 0.76, 1.0, 0.5, 1e-9, 0.0, -1.0, 0.123456):
+        want = next(i for i, v in enumerate(ref) if v >= x)
+        assert pt.first_index_ge(x) == want
+    # the accumulated time reaches 0.01 one sample later than the ideal 480
+    assert pt.first_index_ge(0.01) == 481
+    with pytest.raises(ValueError):
+        PhaseTable(0.0, -1.0).first_index_ge(1.0)
+
+
+def test_constant_sequences():
+    assert build_phase_table(1.5, 0.0) == [(0, 1.5, 0.0)]
+    assert build_phase_table(1.0, 1e-30)[-1][2] == 0.0
