@@ -111,3 +111,40 @@ def test_bank_rejects_buffer_modulators(gpu):
         VoiceBank([])
     with pytest.raises(ValueError):
         VoiceBank([G.Sine(440, samplerate=SR), G.Sine(440, samplerate=44100)])
+
+
+def _c_oracle_bus(ovoices, gains, n):
+    from oracle import c_oracle as CO
+    voices = np.stack([CO.render(v, n) for v in ovoices])
+    return CO.mix_bus(voices, gains)
+
+
+def test_configs_at_full_size_vs_c_oracle(gpu):
+    """BASELINE configs[1] and configs[2] at their full voice counts and 1 s of audio, and the headline
+    1024-voice additive workload over the whole note, against the C restatement of the oracle
+    (oracle/oracle.c, itself checked bit for bit against the Python oracle in tests/test_oracle_c.py)."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    # configs[1]: 64-voice additive + ADSR, 48 kHz stereo, 1 s
+    gv, gains = additive_voices(G, 64, SR, seed=0)
+    ov, _ = additive_voices(O, 64, SR, seed=0)
+    got = VoiceBank(gv, gains=gains).render(SR)
+    want = _c_oracle_bus(ov, gains, SR)
+    assert rms(got, want) <= RMS_TOL and np.max(np.abs(got - want)) < 5e-7
+    # configs[2]: 1024 FM voices, 1 s
+    gv, gains = fm_voices(G, 1024, SR, seed=1)
+    ov, _ = fm_voices(O, 1024, SR, seed=1)
+    got = VoiceBank(gv, gains=gains).render(SR)
+    want = _c_oracle_bus(ov, gains, SR)
+    assert rms(got, want) <= RMS_TOL and np.max(np.abs(got - want)) < 5e-7
+    # headline: 1024-voice additive, the attack/decay part and a window across the release end
+    gv, gains = additive_voices(G, 1024, SR, seed=0)
+    ov, _ = additive_voices(O, 1024, SR, seed=0)
+    bank = VoiceBank(gv, gains=gains)
+    n = 6000
+    want = _c_oracle_bus(ov, gains, 37000)
+    assert rms(bank.render(n), want[:n]) <= RMS_TOL
+    tail = bank.render(1000, start=36000)                  # release ends at sample 36480
+    assert rms(tail, want[36000:37000]) <= RMS_TOL and np.max(np.abs(tail - want[36000:37000])) < 5e-7
+    two = bank.render_two_step(n)
+    assert rms(two, want[:n]) <= RMS_TOL

@@ -193,3 +193,23 @@ def test_mixer_chain_bit_exact(gpu):
     a4, b4 = _rand(rng, 4, 500), _rand(rng, 4, 500)
     s = mix_samples([_sample(a4, 4, 8000, 1), _sample(b4, 4, 8000, 1)])
     assert bytes(s.view_frame_data()) == audioop.add(a4.tobytes(), b4.tobytes(), 4)
+
+
+def test_resample_large_vs_c_oracle(gpu):
+    """configs[4] shape at 30 s: 8-channel float32 96 kHz -> 44.1 kHz (92 MB in), bit-exact against the C
+    restatement; and a 2-channel int16 minute against audioop itself."""
+    import ctypes
+    from oracle import c_oracle as CO
+    from synthesizer_amd import _native as N
+    rng = np.random.default_rng(21)
+    frames = 96000 * 30
+    x = rng.uniform(-1, 1, (frames, 8)).astype(np.float32)
+    src = N.DeviceBuffer.from_array(x)
+    nout = N.lib().sh_resample_out_frames(frames, 96000, 44100)
+    dst = N.DeviceBuffer(nout * 8 * 4)
+    N.check(N.lib().sh_resample(src.handle, frames, 8, 4, 1, 96000, 44100, dst.handle, None))
+    got = dst.download(np.float32, nout * 8).reshape(nout, 8)
+    assert np.array_equal(got, CO.ratecv_f32(x, 96000, 44100))
+    pcm = rng.integers(-32768, 32768, 48000 * 60 * 2, dtype=np.int64).astype(np.int16)
+    s = _sample(pcm, 2, 48000, 2).resample(44100)
+    assert bytes(s.view_frame_data()) == audioop.ratecv(pcm.tobytes(), 2, 2, 48000, 44100, None)[0]
