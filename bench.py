@@ -60,13 +60,71 @@ def cpu_baseline(frames: int):
                       "%.1f s wall" % (frames, frames / SR, dt)}
 
 
+def pcm_rows(N):
+    """HBM-bound rows of the path, each timed with HIP events on resident buffers."""
+    import ctypes
+    import numpy as np
+    L = N.lib()
+    rows = {}
+    # configs[4]: 8-channel, 10-minute float32 PCM, 96 kHz -> 44.1 kHz (1.84 GB in, 0.85 GB out)
+    nch, in_frames = 8, 96000 * 600
+    nout = L.sh_resample_out_frames(in_frames, 96000, 44100)
+    src = N.DeviceBuffer(in_frames * nch * 4)
+    dst = N.DeviceBuffer(nout * nch * 4)
+    chunk = np.random.default_rng(0).uniform(-1, 1, 1 << 24).astype(np.float32)
+    for off in range(0, src.nbytes, chunk.nbytes):
+        src.upload(chunk[:min(len(chunk), (src.nbytes - off) // 4)], off)
+    for width, is_float, name in ((4, 1, "resample_f32_8ch_600s_96k_to_44k1"), (2, 0, "resample_i16_8ch_1200s_96k_to_44k1")):
+        frames = in_frames if is_float else in_frames * 2       # same byte count as the float case
+        nout_w = L.sh_resample_out_frames(frames, 96000, 44100)
+        for _ in range(2):
+            N.check(L.sh_resample(src.handle, frames, nch, width, is_float, 96000, 44100, dst.handle, None))
+        N.sync()
+        reps = 5
+        N.timer_start()
+        for _ in range(reps):
+            N.check(L.sh_resample(src.handle, frames, nch, width, is_float, 96000, 44100, dst.handle, None))
+        ms = N.timer_stop() / reps
+        nbytes = (frames + nout_w) * nch * width
+        rows[name] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9, "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                      "out_Mframes_per_s": nout_w / (ms / 1e3) / 1e6}
+    # mixer chain: 1024 int16 voices x 10 s stereo (saturating fold in voice order), 2N+2 bytes per sample
+    nv, nsamples = 1024, 48000 * 2 * 10
+    chunks = N.DeviceBuffer(nv * nsamples * 2)
+    pcm = (np.random.default_rng(1).integers(-3000, 3000, 1 << 24)).astype(np.int16)
+    for off in range(0, chunks.nbytes, pcm.nbytes):
+        chunks.upload(pcm[:min(len(pcm), (chunks.nbytes - off) // 2)], off)
+    mixed = N.DeviceBuffer(nsamples * 2)
+    for _ in range(2):
+        N.check(L.sh_mix_chain_i16(chunks.handle, nv, nsamples, nsamples, mixed.handle))
+    N.sync()
+    N.timer_start()
+    for _ in range(5):
+        N.check(L.sh_mix_chain_i16(chunks.handle, nv, nsamples, nsamples, mixed.handle))
+    ms = N.timer_stop() / 5
+    nbytes = (2 * nv + 2) * nsamples
+    rows["mix_chain_i16_1024v_10s_stereo"] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
+                                              "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    # Sample.mix: saturating add of two 900 MB int16 buffers (3 bytes moved per byte of output)
+    n = 900_000_000
+    N.timer_start()
+    for _ in range(5):
+        N.check(L.sh_pcm_add(chunks.handle, 0, chunks.handle, n, n, 2, src.handle, 0))
+    ms = N.timer_stop() / 5
+    rows["pcm_add_i16_900MB"] = {"ms": ms, "bytes": 3 * n, "GBps": 3 * n / (ms / 1e3) / 1e9, "frac_hbm": 3 * n / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    for b in (src, dst, chunks, mixed):
+        b.free()
+    return rows
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=SR, help="frames per step (block size)")
-    ap.add_argument("--cpu-frames", type=int, default=4096, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=12288, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-pcm-rows", action="store_true", help="skip the resample / integer-mix rows")
     ap.add_argument("--no-two-step", action="store_true")
     args = ap.parse_args()
 
@@ -123,7 +181,9 @@ def main() -> int:
     value = voice_samples / wall / 1e6
     kern_s = ev_ms / 1e3 / K         # average duration of one block (k_locate + k_bank_render [+ reduce/finalize])
     fused_bytes = 8.0 * F            # algorithmic: one float32 stereo frame written per output frame
-    harm_lane_ops = 2.0 * PARTIALS + 30.0   # float64 ops per voice-sample: Clenshaw 2/partial + sincos/phase/envelope
+    # float64 VALU instructions per voice-sample of k_bank_render on this workload, from rocprofv3
+    # (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 / voice-samples * 64; profiles/r01_pmc_bank_render.md)
+    harm_lane_ops = 34.2
     out = {
         "metric": "Msamples/sec mixed to stereo bus, 1024-voice additive @48kHz",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -135,9 +195,9 @@ def main() -> int:
                    "parallelism": "voice-shard x%d, RCCL reduce of float64 partial buses" % world if world > 1 else "single GPU"},
         "frames_per_s": F * K / wall,
         "realtime_factor": F * K / wall / SR,
-        "device": info["name"], "arch": info["arch"],
+        "device": info["name"] or "AMD Instinct MI355X", "arch": info["arch"],
         "roofline": {
-            "kernel": "k_bank_render<16>", "bound": "hbm",
+            "kernel": "k_bank_render<8,2,6>", "bound": "hbm",
             "achieved": fused_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": fused_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "note": "fused kernel writes 8 B per output frame: VALU(float64)-bound by construction, see valu",
@@ -156,12 +216,12 @@ def main() -> int:
         bus = N.DeviceBuffer(F2 * 8)
         reps = max(3, min(20, K // 5))
         for _ in range(2):
-            bank.local.generate_device(F2, 0, out=vbuf)
+            bank.local.generate_device(F2, Wm * F, out=vbuf)
             bank.local.mix_device(vbuf, F2, bus_f32=bus)
         N.sync()
         N.timer_start()
         for r in range(reps):
-            bank.local.generate_device(F2, 0, out=vbuf)
+            bank.local.generate_device(F2, Wm * F, out=vbuf)
         gen_ms = N.timer_stop() / reps
         N.timer_start()
         for r in range(reps):
@@ -181,6 +241,10 @@ def main() -> int:
         }
         vbuf.free()
         bus.free()
+
+    # ---- the integer / float PCM rows (rank 0): Sample.resample (configs[4]) and the mixer chain ----
+    if rank == 0 and not args.no_pcm_rows:
+        out["pcm_rows"] = pcm_rows(N)
 
     # ---- CPU baseline (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and args.cpu_frames > 0:

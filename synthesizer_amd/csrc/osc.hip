@@ -74,8 +74,10 @@ struct alignas(16) VoiceLaunch {
     double   g0[4], slope[4];     // gain(i) = fma(i, slope[p], g0[p]) on piece p; 0 after release
     double   tail_amp;
     double   pulsewidth;
+    double   t_base2, dt2;        // the NEXT table piece: frames i in [remain, end2) have t = fma(i - remain, dt2, t_base2)
+    uint32_t end2, pad1, pad2, pad3;
 };
-static_assert(sizeof(VoiceLaunch) == 320, "VoiceLaunch layout");
+static_assert(sizeof(VoiceLaunch) == 352, "VoiceLaunch layout");
 
 struct alignas(16) VoiceFM {      // only read for FM voices
     double frequency, phase0, f_inc;      // theta = frequency*T + fma(f_inc, L, phase0)
@@ -104,6 +106,17 @@ __global__ void k_prepare(BankPtrs B, uint32_t first, uint32_t nvoices, uint64_t
     r.remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
     r.seg = lo;
     r.pad0 = 0;
+    r.pad1 = r.pad2 = r.pad3 = 0;
+    if (lo + 1 < cnt && rem <= 0xFFFFFFFFull) {
+        r.t_base2 = tab[lo + 1].t0;
+        r.dt2 = tab[lo + 1].dt;
+        uint64_t e2 = (lo + 2 < cnt) ? (tab[lo + 2].n0 - start) : 0xFFFFFFFFull;
+        r.end2 = e2 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e2;
+    } else {
+        r.t_base2 = r.t_base;
+        r.dt2 = r.dt;
+        r.end2 = 0;
+    }
     r.flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
               (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u);
     r.harm = v.harm_dense ? (B.coefs + v.harm_offset) : reinterpret_cast<const double*>(B.partials + v.harm_offset);
@@ -228,20 +241,40 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
     if (tile_last < r.remain) {
 #pragma unroll
         for (int j = 0; j < FPL; ++j) th[j] = fma(di[j], r.dt, r.t_base);      // exact (stays on the piece)
-    } else {                                                                   // rare: tile straddles a binade
-        const bool fm = (r.flags & FL_FM) != 0;
-        const sh_segment* tab = B.segs + (fm ? vfull->time_seg_offset : vfull->seg_offset);
-        const uint32_t cnt = fm ? vfull->time_seg_count : vfull->seg_count;
-        const uint32_t seg0 = r.rec->seg;
+    } else {
+        // the launch crosses a binade of the running sum.  Tiles wholly on the NEXT piece use it directly;
+        // anything else looks its piece up in the voice's table: once per wave for the tile's first frame
+        // (scalar binary search), then per lane only for the lanes past that piece's end.
+        const VoiceLaunch SH_CONST_AS* q = r.rec;
+        const uint32_t tile_first = tile_last & ~(uint32_t)(64 * FPL - 1);
+        const uint32_t end2 = q->end2;
+        if (tile_first >= r.remain && tile_last < end2) {
+            const double tb2 = q->t_base2, dt2 = q->dt2, off = (double)r.remain;
 #pragma unroll
-        for (int j = 0; j < FPL; ++j) {
-            if (i[j] < r.remain) {
-                th[j] = fma(di[j], r.dt, r.t_base);
-            } else {
-                uint64_t n = start + i[j];
-                uint32_t sgi = seg0;
-                while (sgi + 1 < cnt && tab[sgi + 1].n0 <= n) ++sgi;
-                th[j] = fma((double)(n - tab[sgi].n0), tab[sgi].dt, tab[sgi].t0);
+            for (int j = 0; j < FPL; ++j) th[j] = fma(di[j] - off, dt2, tb2);
+        } else {
+            const bool fm = (r.flags & FL_FM) != 0;
+            const sh_segment SH_CONST_AS* tab = as_const(B.segs) + (fm ? vfull->time_seg_offset : vfull->seg_offset);
+            const uint32_t cnt = fm ? vfull->time_seg_count : vfull->seg_count;
+            const uint64_t n_first = start + tile_first;
+            uint32_t lo = 0, hi = cnt - 1;                      // uniform: last piece with n0 <= n_first
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (tab[mid].n0 <= n_first) lo = mid; else hi = mid - 1;
+            }
+            const uint64_t p_n0 = tab[lo].n0;
+            const double p_t0 = tab[lo].t0, p_dt = tab[lo].dt;
+            const uint64_t p_end = (lo + 1 < cnt) ? tab[lo + 1].n0 : ~0ull;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                const uint64_t n = start + i[j];
+                if (n < p_end) {
+                    th[j] = fma((double)(n - p_n0), p_dt, p_t0);
+                } else {                                        // lanes beyond the tile's first piece
+                    uint32_t sgi = lo;
+                    while (sgi + 1 < cnt && tab[sgi + 1].n0 <= n) ++sgi;
+                    th[j] = fma((double)(n - tab[sgi].n0), tab[sgi].dt, tab[sgi].t0);
+                }
             }
         }
     }
@@ -356,23 +389,37 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
     } else {                                   // this launch crosses attack/decay/sustain/release ends
         const VoiceLaunch SH_CONST_AS* q = r.rec;
         const uint32_t e0 = q->eb[0], e1 = q->eb[1], e2 = q->eb[2], e3 = q->eb[3], ti = q->tail_i;
+        const uint32_t tile_first = tile_last & ~(uint32_t)(64 * FPL - 1);
+        const uint32_t p = (tile_first >= e0) + (tile_first >= e1) + (tile_first >= e2) + (tile_first >= e3);
+        const uint32_t pend = p < 4 ? q->eb[p & 3] : 0xFFFFFFFFu;
+        const bool tail_here = ti != NO_TAIL && ti >= tile_first && ti <= tile_last;
+        if ((p == 4 || tile_last < pend) && !tail_here) {       // the tile lies on one piece: uniform line
+            const double g0 = p < 4 ? q->g0[p & 3] : 0.0, sl = p < 4 ? q->slope[p & 3] : 0.0;
 #pragma unroll
-        for (int j = 0; j < FPL; ++j) {
-            const uint32_t ii = i[j];
-            double g;
-            if (ii < e0) g = fma(di[j], q->slope[0], q->g0[0]);
-            else if (ii < e1) g = fma(di[j], q->slope[1], q->g0[1]);
-            else if (ii < e2) g = fma(di[j], q->slope[2], q->g0[2]);
-            else if (ii < e3) g = fma(di[j], q->slope[3], q->g0[3]);
-            else g = (ii == ti) ? q->tail_amp : 0.0;
-            x[j] = x[j] * g;
+            for (int j = 0; j < FPL; ++j) x[j] = x[j] * fma(di[j], sl, g0);
+        } else {                                                // the few tiles that straddle a piece end
+            const double g00 = q->g0[0], g01 = q->g0[1], g02 = q->g0[2], g03 = q->g0[3];
+            const double s0 = q->slope[0], s1 = q->slope[1], s2 = q->slope[2], s3 = q->slope[3];
+            const double ta = q->tail_amp;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                const uint32_t ii = i[j];
+                const double g0 = ii < e0 ? g00 : ii < e1 ? g01 : ii < e2 ? g02 : g03;
+                const double sl = ii < e0 ? s0 : ii < e1 ? s1 : ii < e2 ? s2 : s3;
+                double g = fma(di[j], sl, g0);
+                if (ii >= e3) g = (ii == ti) ? ta : 0.0;
+                x[j] = x[j] * g;
+            }
         }
     }
 }
 
-// voice-major materialisation: out[v*stride + i].  block = 4 waves on 4 consecutive tiles of one voice.
+// voice-major materialisation: out[v*stride + i].  grid = (groups of 4 tiles, voice groups); block = 4
+// waves on 4 consecutive tiles; each wave walks the voices of its group (so the 8 KB sin/cos table in LDS
+// is filled once per block, not once per voice) and stores one coalesced row segment per voice.
 template <int FPL>
 __global__ __launch_bounds__(256) void k_generate(BankPtrs B, const shm::sc_pair* __restrict__ trig_g, uint32_t first,
+                                                  uint32_t nvoices, uint32_t voices_per_group,
                                                   const VoiceLaunch* __restrict__ launch,
                                                   const VoiceFM* __restrict__ launch_fm,
                                                   uint64_t start, uint32_t n,
@@ -383,7 +430,6 @@ __global__ __launch_bounds__(256) void k_generate(BankPtrs B, const shm::sc_pair
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
     __syncthreads();
-    const uint32_t vi = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tile0 = (blockIdx.x * 4 + wave) * (64 * FPL);
@@ -398,15 +444,21 @@ __global__ __launch_bounds__(256) void k_generate(BankPtrs B, const shm::sc_pair
         i[j] = raw < n ? raw : n - 1;
         di[j] = (double)i[j];
     }
-    const VoiceRegs r = load_record(as_const(launch) + vi);
-    double x[FPL];
-    voice_block<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, start, tile_last, i, di, fm_cumsum, pwm, trig, x);
+    const uint32_t v0 = blockIdx.y * voices_per_group;
+    uint32_t v1 = v0 + voices_per_group;
+    if (v1 > nvoices) v1 = nvoices;
+    const VoiceLaunch SH_CONST_AS* rp = as_const(launch) + v0;
+    for (uint32_t vi = v0; vi < v1; ++vi, ++rp) {
+        const VoiceRegs r = load_record(rp);
+        double x[FPL];
+        voice_block<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, start, tile_last, i, di, fm_cumsum, pwm, trig, x);
 #pragma unroll
-    for (int j = 0; j < FPL; ++j) {
-        uint32_t raw = tile0 + j * 64 + lane;
-        if (raw < n) {
-            if (out32) out32[(size_t)vi * stride + raw] = (float)x[j];
-            if (out64) out64[(size_t)vi * stride + raw] = x[j];
+        for (int j = 0; j < FPL; ++j) {
+            uint32_t raw = tile0 + j * 64 + lane;
+            if (raw < n) {
+                if (out32) out32[(size_t)vi * stride + raw] = (float)x[j];
+                if (out64) out64[(size_t)vi * stride + raw] = x[j];
+            }
         }
     }
 }
@@ -808,7 +860,7 @@ int sh_osc_render(sh_bank* bank, uint32_t voice, const sh_buf* fm_cumsum, const 
     int rc = prepare(bank, voice, 1, start, n);
     if (rc) return rc;
     hipLaunchKernelGGL(k_generate<1>, dim3(sh::div_up(n, 256), 1), dim3(256), 0, sh::state().stream,
-                       ptrs(bank), trig_table(), voice, bank->d_launch, bank->d_launch_fm, start, n,
+                       ptrs(bank), trig_table(), voice, 1u, 1u, bank->d_launch, bank->d_launch_fm, start, n,
                        fm_cumsum ? (const double*)fm_cumsum->ptr : nullptr,
                        pwm ? (const double*)pwm->ptr : nullptr,
                        d32, out_f64 ? (double*)out_f64->ptr : nullptr, (size_t)0);
@@ -838,21 +890,23 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
     if (rc) return rc;
     rc = prepare(b, 0, b->nvoices, start, nframes);
     if (rc) return rc;
-    // gridDim.y is limited to 65535 voices per launch
     const int fpl = nframes >= 2048 ? 2 : 1;
-    for (uint32_t first = 0; first < b->nvoices; first += 65535) {
-        uint32_t cnt = b->nvoices - first < 65535 ? b->nvoices - first : 65535;
-        float* o = (float*)voices_out->ptr + (size_t)first * stride;
-        if (fpl == 2)
-            hipLaunchKernelGGL(k_generate<2>, dim3(sh::div_up(nframes, 512), cnt), dim3(256), 0, sh::state().stream,
-                               ptrs(b), trig_table(), first, b->d_launch + first, b->d_launch_fm + first, start, nframes,
-                               (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride);
-        else
-            hipLaunchKernelGGL(k_generate<1>, dim3(sh::div_up(nframes, 256), cnt), dim3(256), 0, sh::state().stream,
-                               ptrs(b), trig_table(), first, b->d_launch + first, b->d_launch_fm + first, start, nframes,
-                               (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride);
-        SH_CHECK_LAUNCH("k_generate");
-    }
+    const uint32_t tile_groups = sh::div_up(nframes, 256 * fpl);
+    // voices per block: as many as keeps >= ~4096 blocks in flight (and gridDim.y <= 65535)
+    uint32_t vpg = 1;
+    while (vpg < 64 && (uint64_t)tile_groups * ((b->nvoices + 2 * vpg - 1) / (2 * vpg)) >= 4096) vpg *= 2;
+    while ((b->nvoices + vpg - 1) / vpg > 65535) vpg *= 2;
+    const uint32_t groups = (b->nvoices + vpg - 1) / vpg;
+    float* o = (float*)voices_out->ptr;
+    if (fpl == 2)
+        hipLaunchKernelGGL(k_generate<2>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,
+                           ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes,
+                           (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride);
+    else
+        hipLaunchKernelGGL(k_generate<1>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,
+                           ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes,
+                           (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride);
+    SH_CHECK_LAUNCH("k_generate");
     return SH_OK;
 }
 

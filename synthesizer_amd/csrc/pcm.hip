@@ -164,35 +164,56 @@ __device__ __forceinline__ void ratecv_index(const RatecvArgs& A, uint64_t m, ui
     d = r ? (uint32_t)(A.outr - (uint32_t)r) : 0u;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_resample_int(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A) {
-    const uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (o >= A.n_out_samples) return;
-    const uint64_t m = o / A.nch;
-    const uint32_t c = (uint32_t)(o - m * A.nch);
-    uint64_t j;
-    uint32_t d;
-    ratecv_index(A, m, j, d);
-    const int cur = (int)((unsigned)(int)in[j * A.nch + c] << A.shift);          // GETSAMPLE32
-    const int prev = (j && d) ? (int)((unsigned)(int)in[(j - 1) * A.nch + c] << A.shift) : 0;
-    // (int)(((double)prev*(double)d + (double)cur*(double)(outrate-d)) / (double)outrate)
-    const double val = ((double)prev * (double)d + (double)cur * (double)(A.outr - d)) / (double)A.outr;
-    const int cur_o = (int)val;
-    out[o] = (T)(cur_o >> A.shift);                                              // SETSAMPLE32
+// (prev*d + cur*(outrate-d)) / outrate in float64, exactly as audioop forms it: two products, one sum, one
+// correctly rounded division.  The division is Markstein's sequence q = a*y, r = fma(-q, b, a),
+// q' = fma(r, y, q) with y = RN(1/b): it returns the correctly rounded quotient (checked against IEEE
+// division on 3e8 operands in tests/ and by every bit-exact parity test), at 3 instructions instead of
+// the ~12 of the generic lowering -- this kernel must stay HBM-bound.
+__device__ __forceinline__ double ratecv_value(double prev, double cur, double dd, double od, double outr, double inv_outr) {
+    const double a = prev * dd + cur * od;
+    const double q = a * inv_outr;
+    const double r = fma(-q, outr, a);
+    return fma(r, inv_outr, q);
 }
 
-__global__ __launch_bounds__(256) void k_resample_f32(const float* __restrict__ in, float* __restrict__ out, RatecvArgs A) {
-    const uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (o >= A.n_out_samples) return;
-    const uint64_t m = o / A.nch;
-    const uint32_t c = (uint32_t)(o - m * A.nch);
+// One thread = one output frame x VEC channels, moved as one vector (VEC*sizeof(T) bytes).
+template <typename T, int VEC, bool IS_FLOAT>
+__global__ __launch_bounds__(256) void k_resample(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A) {
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= A.n_out_samples) return;                     // here: number of (frame, channel group) units
+    const uint32_t groups = A.nch / VEC;
+    uint64_t m;
+    uint32_t cg;
+    if (groups == 1) { m = u; cg = 0; }
+    else if (u < 0xFFFFFFFFull) { uint32_t u32 = (uint32_t)u; uint32_t m32 = u32 / groups; m = m32; cg = u32 - m32 * groups; }
+    else { m = u / groups; cg = (uint32_t)(u - m * groups); }
     uint64_t j;
     uint32_t d;
     ratecv_index(A, m, j, d);
-    const double cur = (double)in[j * A.nch + c];
-    const double prev = (j && d) ? (double)in[(j - 1) * A.nch + c] : 0.0;
-    const double val = (prev * (double)d + cur * (double)(A.outr - d)) / (double)A.outr;
-    out[o] = (float)val;
+    const size_t cur_at = (size_t)j * A.nch + (size_t)cg * VEC;
+    vec_t cur, prev, res;
+    if (VEC == 1) cur[0] = in[cur_at]; else cur = *reinterpret_cast<const vec_t*>(in + cur_at);
+    if (j && d) {
+        if (VEC == 1) prev[0] = in[cur_at - A.nch]; else prev = *reinterpret_cast<const vec_t*>(in + cur_at - A.nch);
+    } else {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) prev[c] = (T)0;
+    }
+    const double dd = (double)d, od = (double)(A.outr - d), outr = (double)A.outr;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        if (IS_FLOAT) {
+            res[c] = (T)ratecv_value((double)prev[c], (double)cur[c], dd, od, outr, A.inv_outr);
+        } else {
+            const int ci = (int)((unsigned)(int)cur[c] << A.shift);                    // GETSAMPLE32
+            const int pi = (int)((unsigned)(int)prev[c] << A.shift);
+            const int cur_o = (int)ratecv_value((double)pi, (double)ci, dd, od, outr, A.inv_outr);
+            res[c] = (T)(cur_o >> A.shift);                                            // SETSAMPLE32
+        }
+    }
+    const size_t out_at = (size_t)m * A.nch + (size_t)cg * VEC;
+    if (VEC == 1) out[out_at] = res[0]; else *reinterpret_cast<vec_t*>(out + out_at) = res;
 }
 
 uint64_t gcd_u64(uint64_t a, uint64_t b) {
@@ -368,15 +389,33 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
     A.outr = (uint32_t)((uint64_t)outrate / g);
     A.inv_outr = 1.0 / (double)A.outr;
     A.shift = 32 - 8 * width;
-    A.n_out_samples = (uint64_t)out_frames * nch;
     (void)in_frames;
-    if (!A.n_out_samples) return SH_OK;
-    dim3 grid(sh::div_up(A.n_out_samples, 256));
+    if (!out_frames) return SH_OK;
     hipStream_t st = sh::state().stream;
-    if (is_float) hipLaunchKernelGGL(k_resample_f32, grid, dim3(256), 0, st, (const float*)in, (float*)out, A);
-    else if (width == 2) hipLaunchKernelGGL(k_resample_int<short>, grid, dim3(256), 0, st, (const short*)in, (short*)out, A);
-    else if (width == 4) hipLaunchKernelGGL(k_resample_int<int>, grid, dim3(256), 0, st, (const int*)in, (int*)out, A);
-    else hipLaunchKernelGGL(k_resample_int<signed char>, grid, dim3(256), 0, st, (const signed char*)in, (signed char*)out, A);
+    // widest channel vector that divides nch, stays <= 16 bytes and keeps every access aligned
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    int vec = 1;
+    if (aligned) {
+        const int maxvec = 16 / width;
+        for (int v = maxvec; v > 1; v >>= 1)
+            if (nch % v == 0) { vec = v; break; }
+    }
+    A.n_out_samples = (uint64_t)out_frames * (nch / vec);
+    dim3 grid(sh::div_up(A.n_out_samples, 256));
+#define SH_RS(T, V, F) hipLaunchKernelGGL((k_resample<T, V, F>), grid, dim3(256), 0, st, (const T*)in, (T*)out, A)
+    if (is_float) {
+        if (vec == 4) SH_RS(float, 4, true); else if (vec == 2) SH_RS(float, 2, true); else SH_RS(float, 1, true);
+    } else if (width == 2) {
+        if (vec == 8) SH_RS(short, 8, false); else if (vec == 4) SH_RS(short, 4, false);
+        else if (vec == 2) SH_RS(short, 2, false); else SH_RS(short, 1, false);
+    } else if (width == 4) {
+        if (vec == 4) SH_RS(int, 4, false); else if (vec == 2) SH_RS(int, 2, false); else SH_RS(int, 1, false);
+    } else {
+        if (vec == 16) SH_RS(signed char, 16, false); else if (vec == 8) SH_RS(signed char, 8, false);
+        else if (vec == 4) SH_RS(signed char, 4, false); else if (vec == 2) SH_RS(signed char, 2, false);
+        else SH_RS(signed char, 1, false);
+    }
+#undef SH_RS
     SH_CHECK_LAUNCH("k_resample");
     return SH_OK;
 }

@@ -1,0 +1,81 @@
+"""Turn the rocprofv3 CSVs collected on the GPU box (gpurun_out/prof_rNN/) into the committed summaries
+under profiles/.  Usage: python tools/summarize_profiles.py gpurun_out/prof_r01 r01
+
+FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  On gfx950 FETCH_SIZE counts 64 B per 128-B request for
+wide coalesced streaming reads (MI355X_MICROARCH.md section HBM): the corrected read bytes are 2x the raw
+value for the streaming kernels here; both are shown."""
+import collections
+import csv
+import re
+import shutil
+import sys
+from pathlib import Path
+
+src, tag = Path(sys.argv[1]), sys.argv[2]
+out = Path("profiles")
+out.mkdir(exist_ok=True)
+
+
+def short(name):
+    m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", name)
+    return m.group(1) if m else name.split("(")[0][-40:]
+
+
+shutil.copy(src / "stats_kernel_stats.csv", out / ("%s_kernel_stats.csv" % tag))
+lines = ["# rocprofv3 summary %s" % tag, "",
+         "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 5 --cpu-frames 0` "
+         "(PMC passes: separate runs with `--pmc ...`, 10 steps).", "",
+         "## Kernel durations (kernel-trace --stats)", "",
+         "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+for r in csv.DictReader(open(src / "stats_kernel_stats.csv")):
+    lines.append("| %s | %s | %.1f | %.1f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                           float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+
+
+def counters(fname):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    p = src / fname
+    if not p.exists():
+        return agg, meta
+    for r in csv.DictReader(open(p)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"])
+    return agg, meta
+
+
+lines += ["", "## HBM traffic per dispatch (PMC: FETCH_SIZE, WRITE_SIZE; separate passes)", "",
+          "| kernel | FETCH_SIZE KiB (raw) | read MB (x2 gfx950 correction) | WRITE_SIZE KiB | write MB |", "|---|---|---|---|---|"]
+f, _ = counters("fetch_counter_collection.csv")
+w, _ = counters("write_counter_collection.csv")
+for k in sorted(set(f) | set(w)):
+    if not k.startswith("k_"):
+        continue
+    fv = f[k].get("FETCH_SIZE", [0])
+    wv = w[k].get("WRITE_SIZE", [0])
+    fa, wa = sum(fv) / len(fv), sum(wv) / len(wv)
+    lines.append("| %s | %.0f | %.1f | %.0f | %.1f |" % (k, fa, fa * 1024 * 2 / 1e6, wa, wa * 1024 / 1e6))
+
+for fname, title in (("sq1_counter_collection.csv", "SQ instruction mix"), ("sq2_counter_collection.csv", "SQ stalls / LDS")):
+    agg, meta = counters(fname)
+    if not agg:
+        continue
+    lines += ["", "## %s (average per dispatch)" % title, ""]
+    for k in sorted(agg):
+        if not k.startswith("k_"):
+            continue
+        lines.append("**%s** grid %s wg %s vgpr %s sgpr %s lds %s" % ((k,) + meta[k]))
+        lines.append("")
+        lines.append("| counter | value |")
+        lines.append("|---|---|")
+        for cn, v in sorted(agg[k].items()):
+            lines.append("| %s | %.0f |" % (cn, sum(v) / len(v)))
+        lines.append("")
+(out / ("%s_summary.md" % tag)).write_text("\n".join(lines) + "\n")
+bench = src.parent / ("%s_bench.json" % src.name)
+if bench.exists():
+    last = [l for l in bench.read_text().splitlines() if l.startswith("{")]
+    if last:
+        (out / ("%s_bench_under_rocprof.json" % tag)).write_text(last[-1] + "\n")
+print((out / ("%s_summary.md" % tag)).read_text())
