@@ -168,6 +168,7 @@ def main() -> int:
     N.timer_start()
     for s in range(K):
         bank.render_device(F, (Wm + s) * F)
+    host_enqueue = time.perf_counter() - t0      # host time to enqueue all K steps (launches are asynchronous)
     ev_ms = N.timer_stop()           # HIP events on the library stream (also synchronises it)
     barrier()
     wall = time.perf_counter() - t0
@@ -194,6 +195,7 @@ def main() -> int:
                    "voices_per_gpu": VOICES_PER_GPU, "frames_per_step": F, "samplerate": SR,
                    "parallelism": "voice-shard x%d, RCCL reduce of float64 partial buses" % world if world > 1 else "single GPU"},
         "frames_per_s": F * K / wall,
+        "host_enqueue_ms_per_step": host_enqueue * 1e3 / K,
         "realtime_factor": F * K / wall / SR,
         "device": info["name"] or "AMD Instinct MI355X", "arch": info["arch"],
         "roofline": {

@@ -160,6 +160,30 @@ SH_HD void sincos_tab(double t, TablePtr tab, double& s, double& c) {
     c = fma(C, cr, -(S * sr));
 }
 
+// The same for N independent angles in lockstep: each stage is issued for all angles before the next
+// stage starts, so the table reads are in flight together and the dependent float64 chains interleave.
+template <int N, typename TablePtr>
+SH_HD void sincos_tab_n(const double (&t)[N], TablePtr tab, double (&s)[N], double (&c)[N]) {
+    double r[N], S[N], C[N];
+    for (int j = 0; j < N; ++j) {
+        union { double d; uint64_t u; } m;
+        m.d = fma(t[j], TRIG_INV_STEP, 6755399441055744.0);
+        const double fk = m.d - 6755399441055744.0;
+        const uint32_t k = (uint32_t)m.u & (uint32_t)(TRIG_N - 1);
+        S[j] = tab[k].s;
+        C[j] = tab[k].c;
+        r[j] = fma(-fk, TRIG_STEP_2, fma(-fk, TRIG_STEP_1, t[j]));
+    }
+    double z[N], sr[N], cr[N];
+    for (int j = 0; j < N; ++j) z[j] = r[j] * r[j];
+    for (int j = 0; j < N; ++j) sr[j] = fma(z[j], 0.008333333333333333, -0.16666666666666666);
+    for (int j = 0; j < N; ++j) cr[j] = fma(z[j], 0.041666666666666664, -0.5);
+    for (int j = 0; j < N; ++j) sr[j] = fma(r[j] * z[j], sr[j], r[j]);
+    for (int j = 0; j < N; ++j) cr[j] = fma(z[j], cr[j], 1.0);
+    for (int j = 0; j < N; ++j) s[j] = fma(S[j], cr[j], C[j] * sr[j]);
+    for (int j = 0; j < N; ++j) c[j] = fma(C[j], cr[j], -(S[j] * sr[j]));
+}
+
 // ---- waveforms (formulas of oscillators.py, operation order preserved) -----------------
 
 // Sawtooth: bias + amplitude*2.0*(t - floor(0.5+t))

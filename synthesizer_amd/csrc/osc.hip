@@ -85,10 +85,8 @@ struct alignas(16) VoiceFM {      // only read for FM voices
 };
 static_assert(sizeof(VoiceFM) == 64, "VoiceFM layout");
 
-__global__ void k_prepare(BankPtrs B, uint32_t first, uint32_t nvoices, uint64_t start, uint32_t nframes,
-                          VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm) {
-    uint32_t vi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (vi >= nvoices) return;
+__device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first, uint32_t vi, uint64_t start, uint32_t nframes,
+                                              VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm) {
     const sh_voice& v = B.voices[first + vi];
     const bool fm = v.fm_mode != SH_FM_NONE;
     const uint32_t off = fm ? v.time_seg_offset : v.seg_offset;
@@ -199,6 +197,12 @@ __global__ void k_prepare(BankPtrs B, uint32_t first, uint32_t nvoices, uint64_t
     }
 }
 
+__global__ void k_prepare(BankPtrs B, uint32_t first, uint32_t nvoices, uint64_t start, uint32_t nframes,
+                          VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm) {
+    uint32_t vi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vi < nvoices) prepare_voice(B, first, vi, start, nframes, out, out_fm);
+}
+
 struct VoiceRegs {                // the hot part of the launch record as plain scalars (SGPRs)
     double   t_base, dt;
     uint32_t remain, flags;
@@ -301,15 +305,17 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
     if (r.flags & FL_POLY) {
         // Harmonics with k <= 16: sum_k a_k sin(k t) = sin(t) * P(cos t), P of degree 15 (coefficients
         // converted on the host in exact rational arithmetic), Horner: 15 FMAs instead of 32 Clenshaw ops
+        double sn[FPL], cs[FPL], pv[FPL];
+        shm::sincos_tab_n<FPL>(th, trig, sn, cs);
 #pragma unroll
-        for (int j = 0; j < FPL; ++j) {
-            double sn, c;
-            shm::sincos_tab(th[j], trig, sn, c);
-            double p = r.poly[0];
+        for (int j = 0; j < FPL; ++j) pv[j] = fma(r.poly[0], cs[j], r.poly[1]);
 #pragma unroll
-            for (int u = 1; u < 16; ++u) p = fma(p, c, r.poly[u]);
-            x[j] = p * sn;
+        for (int u = 2; u < 16; ++u) {                // Horner, the FPL chains interleaved
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) pv[j] = fma(pv[j], cs[j], r.poly[u]);
         }
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) x[j] = pv[j] * sn[j];
         if (BANK && (r.flags & FL_FOLDED)) return;          // amplitude and envelope live in the bus gains
 #pragma unroll
         for (int j = 0; j < FPL; ++j) x[j] = x[j] * r.amplitude + r.bias;
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(256) void k_generate(BankPtrs B, const shm::sc_pair
 // partial (L, R) per lane; LDS-staged sum across the waves; one store per frame.  With one group the block
 // writes the final bus; with several it writes a float64 partial bus per group and k_bus_combine folds
 // them in group order -- either way voices are summed in a fixed order (reproducible run to run).
-template <int WAVES, int FPL, int MINW>
+template <int WAVES, int FPL, int MINW, bool PREFETCH = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                   uint32_t nvoices, uint32_t voices_per_group,
                                                                   const VoiceLaunch* __restrict__ launch,
@@ -476,7 +482,16 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                                                                   uint64_t start, uint32_t nframes,
                                                                   float2* __restrict__ bus32,
                                                                   double2* __restrict__ bus64,
-                                                                  double2* __restrict__ parts) {
+                                                                  double2* __restrict__ parts,
+                                                                  VoiceLaunch* __restrict__ next_launch,
+                                                                  VoiceFM* __restrict__ next_fm) {
+    // Sequential streaming is the common call pattern: the first workgroup also resolves the launch records
+    // of the block that is expected next (start + nframes) into the other record set, so that launch needs
+    // no k_prepare of its own (a 7 us kernel + a launch boundary per block otherwise).
+    if (next_launch && blockIdx.x == 0 && blockIdx.y == 0) {
+        for (uint32_t vi = threadIdx.x; vi < nvoices; vi += WAVES * 64)
+            prepare_voice(B, 0u, vi, start + nframes, nframes, next_launch, next_fm);
+    }
     __shared__ double red[WAVES][2][64 * FPL];
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += WAVES * 64) trig[k] = trig_g[k];
@@ -502,6 +517,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     const VoiceLaunch SH_CONST_AS* rp = as_const(launch) + v0 + wave;
     for (uint32_t vi = v0 + wave; vi < v1; vi += WAVES, rp += WAVES) {
         const VoiceRegs r = load_record(rp);
+        // touch the hot cache lines of this wave's NEXT record (one dword per 64-byte line, 4 lines) so that
+        // its loads hit the scalar cache: gfx950 has no scalar prefetch instruction.  The values are only
+        // kept alive until the end of the iteration.
+        uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
+        if (PREFETCH && vi + WAVES < v1) {
+            const uint32_t SH_CONST_AS* nx = reinterpret_cast<const uint32_t SH_CONST_AS*>(rp + WAVES);
+            pf0 = nx[0]; pf1 = nx[16]; pf2 = nx[32]; pf3 = nx[48];
+        }
         double x[FPL];
         voice_block<FPL, true>(r, launch_fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
 #pragma unroll
@@ -509,6 +532,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             accl[j] = fma(r.gain_l, x[j], accl[j]);
             accr[j] = fma(r.gain_r, x[j], accr[j]);
         }
+        if (PREFETCH) asm volatile("" :: "s"(pf0), "s"(pf1), "s"(pf2), "s"(pf3));
     }
 #pragma unroll
     for (int j = 0; j < FPL; ++j) {
@@ -725,8 +749,16 @@ struct sh_bank {
     sh_segment* d_segs = nullptr;
     double*     d_coefs = nullptr;
     sh_partial* d_partials = nullptr;
-    VoiceLaunch* d_launch = nullptr;
+    // launch records, double-buffered: while a render kernel reads one set, its first workgroup fills the
+    // other for the block that is expected next (start + nframes)
+    VoiceLaunch* d_launch_buf[2] = {nullptr, nullptr};
+    VoiceFM*    d_launch_fm_buf[2] = {nullptr, nullptr};
+    VoiceLaunch* d_launch = nullptr;       // the set the next kernel reads
     VoiceFM*    d_launch_fm = nullptr;
+    int         cur = 0;
+    bool        spec_valid = false;
+    uint64_t    spec_start = 0;
+    uint32_t    spec_nframes = 0;
     float2*     d_gains = nullptr;
     uint32_t    nsegs = 0, ncoefs = 0, npartials = 0;
     std::vector<sh_voice> h_voices;    // for validation of per-call arguments
@@ -795,9 +827,14 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     if (!rc) rc = upload_array(&b->d_partials, partials, npartials, st);
     if (!rc) rc = upload_array(&b->d_gains, gains.data(), nvoices, st);
     if (!rc) {
-        hipError_t e = hipMalloc((void**)&b->d_launch, sizeof(VoiceLaunch) * nvoices);
-        if (e == hipSuccess) e = hipMalloc((void**)&b->d_launch_fm, sizeof(VoiceFM) * nvoices);
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+            e = hipMalloc((void**)&b->d_launch_buf[k], sizeof(VoiceLaunch) * nvoices);
+            if (e == hipSuccess) e = hipMalloc((void**)&b->d_launch_fm_buf[k], sizeof(VoiceFM) * nvoices);
+        }
         if (e != hipSuccess) rc = sh::hip_error(e, "hipMalloc(launch records)");
+        b->d_launch = b->d_launch_buf[0];
+        b->d_launch_fm = b->d_launch_fm_buf[0];
     }
     if (!rc) {
         hipError_t e = hipStreamSynchronize(st);
@@ -819,8 +856,10 @@ int sh_bank_destroy(sh_bank* b) {
         if (b->d_segs) hipFree(b->d_segs);
         if (b->d_coefs) hipFree(b->d_coefs);
         if (b->d_partials) hipFree(b->d_partials);
-        if (b->d_launch) hipFree(b->d_launch);
-        if (b->d_launch_fm) hipFree(b->d_launch_fm);
+        for (int k = 0; k < 2; ++k) {
+            if (b->d_launch_buf[k]) hipFree(b->d_launch_buf[k]);
+            if (b->d_launch_fm_buf[k]) hipFree(b->d_launch_fm_buf[k]);
+        }
         if (b->d_gains) hipFree(b->d_gains);
     }
     delete b;
@@ -832,10 +871,35 @@ uint32_t sh_bank_nvoices(const sh_bank* b) { return b ? b->nvoices : 0; }
 static const shm::sc_pair* trig_table() { return (const shm::sc_pair*)sh::state().trig; }
 
 static int prepare(sh_bank* b, uint32_t first, uint32_t count, uint64_t start, uint32_t nframes) {
+    // single-voice path (sh_osc_render): records go to slot 0 of the current set; any speculation is void
+    b->spec_valid = false;
     hipLaunchKernelGGL(k_prepare, dim3(sh::div_up(count, 64)), dim3(64), 0, sh::state().stream,
                        ptrs(b), first, count, start, nframes, b->d_launch, b->d_launch_fm);
     SH_CHECK_LAUNCH("k_prepare");
     return SH_OK;
+}
+
+// Whole-bank launches: use the records the previous render kernel prepared if the caller asks for the block
+// that was predicted (sequential streaming), else run k_prepare.
+static int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes) {
+    hipStream_t st = sh::state().stream;
+    if (b->spec_valid && b->spec_start == start && b->spec_nframes == nframes) {
+        b->cur ^= 1;
+    } else {
+        hipLaunchKernelGGL(k_prepare, dim3(sh::div_up(b->nvoices, 64)), dim3(64), 0, st,
+                           ptrs(b), 0u, b->nvoices, start, nframes, b->d_launch_buf[b->cur], b->d_launch_fm_buf[b->cur]);
+        SH_CHECK_LAUNCH("k_prepare");
+    }
+    b->spec_valid = false;
+    b->d_launch = b->d_launch_buf[b->cur];
+    b->d_launch_fm = b->d_launch_fm_buf[b->cur];
+    return SH_OK;
+}
+
+static bool speculation_enabled() {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("SYNTHHIP_NO_SPECULATION"); enabled = (e && e[0] == '1') ? 0 : 1; }
+    return enabled != 0;
 }
 
 int sh_osc_render(sh_bank* bank, uint32_t voice, const sh_buf* fm_cumsum, const sh_buf* pwm,
@@ -888,7 +952,7 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
         return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: output buffer too small");
     int rc = bank_check_plain(b, "sh_bank_generate");
     if (rc) return rc;
-    rc = prepare(b, 0, b->nvoices, start, nframes);
+    rc = acquire_records(b, start, nframes);
     if (rc) return rc;
     const int fpl = nframes >= 2048 ? 2 : 1;
     const uint32_t tile_groups = sh::div_up(nframes, 256 * fpl);
@@ -918,7 +982,7 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     if (bus_f64 && bus_f64->bytes < (size_t)nframes * 16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f64 too small");
     int rc = bank_check_plain(b, "sh_bank_render");
     if (rc) return rc;
-    rc = prepare(b, 0, b->nvoices, start, nframes);
+    rc = acquire_records(b, start, nframes);
     if (rc) return rc;
     float2* o32 = bus_f32 ? (float2*)bus_f32->ptr : nullptr;
     double2* o64 = bus_f64 ? (double2*)bus_f64->ptr : nullptr;
@@ -949,15 +1013,25 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
         if (rc) return rc;
         parts = (double2*)sh::state().scratch;
     }
+    VoiceLaunch* nl = speculation_enabled() ? b->d_launch_buf[b->cur ^ 1] : nullptr;
+    VoiceFM* nf = speculation_enabled() ? b->d_launch_fm_buf[b->cur ^ 1] : nullptr;
 #define SH_LAUNCH_RENDER(W_, F_, M_)                                                                          \
     hipLaunchKernelGGL((k_bank_render<W_, F_, M_>), dim3(tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),       \
-                       trig_table(), b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, o32, o64, parts)
+                       trig_table(), b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, o32, o64, parts, nl, nf)
     switch (var) {
     case 1621: SH_LAUNCH_RENDER(16, 2, 1); break;
     case 1611: SH_LAUNCH_RENDER(16, 1, 1); break;
     case 821: SH_LAUNCH_RENDER(8, 2, 1); break;
     case 822: SH_LAUNCH_RENDER(8, 2, 2); break;
     case 826: SH_LAUNCH_RENDER(8, 2, 6); break;
+    case 827:                                          // 826 + scalar-cache prefetch of the next record
+        hipLaunchKernelGGL((k_bank_render<8, 2, 6, true>), dim3(tiles, groups), dim3(8 * 64), 0, st, ptrs(b),
+                           trig_table(), b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, o32, o64, parts, nl, nf);
+        break;
+    case 427:
+        hipLaunchKernelGGL((k_bank_render<4, 2, 6, true>), dim3(tiles, groups), dim3(4 * 64), 0, st, ptrs(b),
+                           trig_table(), b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, o32, o64, parts, nl, nf);
+        break;
     case 828: SH_LAUNCH_RENDER(8, 2, 8); break;
     case 426: SH_LAUNCH_RENDER(4, 2, 6); break;
     case 428: SH_LAUNCH_RENDER(4, 2, 8); break;
@@ -979,6 +1053,11 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
         hipLaunchKernelGGL(k_bus_combine, dim3(sh::div_up(nframes, 256)), dim3(256), 0, st,
                            (const double2*)parts, groups, nframes, o32, o64);
         SH_CHECK_LAUNCH("k_bus_combine");
+    }
+    if (nl) {
+        b->spec_valid = true;
+        b->spec_start = start + nframes;
+        b->spec_nframes = nframes;
     }
     return SH_OK;
 }

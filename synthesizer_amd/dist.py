@@ -155,10 +155,12 @@ class DistVoiceBank:
         """Render the shard, reduce to ``root``; returns the float32 bus buffer (valid on root)."""
         self._buffers(nframes)
         L = N.lib()
+        if self.world == 1:                      # nothing to exchange: the kernel rounds to float32 itself
+            self.local.render_device(nframes, start, bus_f32=self._bus32)
+            return self._bus32
         self.local.render_device(nframes, start, bus_f32=None, bus_f64=self._bus64)
-        if self.world > 1:
-            N.check(L.sh_dist_reduce_bus(self._bus64.handle, nframes * 2, root))
-        if self.world == 1 or self.rank == root:
+        N.check(L.sh_dist_reduce_bus(self._bus64.handle, nframes * 2, root))
+        if self.rank == root:
             N.check(L.sh_bus_finalize(self._bus64.handle, nframes * 2, self._bus32.handle))
         return self._bus32
 

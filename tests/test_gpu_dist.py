@@ -1,0 +1,37 @@
+"""GPU: the RCCL leg of the voice-sharded path, as far as ONE GPU can exercise it -- librccl is dlopen()ed,
+a 1-rank communicator is created on the library's stream, and the reduce / all-reduce / barrier entry
+points run on the float64 partial bus.  (world_size 2 data flow: tests/test_dist_gloo.py on CPU; the
+8-GPU run is the driver's.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_rccl_reduce(gpu):
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import dist
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.workloads import additive_voices
+    L = N.lib()
+    dist.init(0, 1, broadcast=lambda payload, rank, world, n: payload)
+    try:
+        assert L.sh_dist_rank() == 0 and L.sh_dist_world() == 1
+        voices, gains = additive_voices(G, 32, 48000, seed=2)
+        bank = dist.DistVoiceBank(voices, gains, 0, 1)
+        n = 4096
+        ref = bank.local.render(n)
+        bank._buffers(n)
+        bank.local.render_device(n, 0, bus_f32=None, bus_f64=bank._bus64)
+        N.check(L.sh_dist_reduce_bus(bank._bus64.handle, n * 2, 0))
+        N.check(L.sh_dist_allreduce_bus(bank._bus64.handle, n * 2))
+        N.check(L.sh_dist_barrier())
+        N.check(L.sh_bus_finalize(bank._bus64.handle, n * 2, bank._bus32.handle))
+        got = bank._bus32.download(np.float32, n * 2).reshape(n, 2)
+        assert np.array_equal(got, ref)
+        assert np.array_equal(bank.render(n), ref)
+        with pytest.raises(ValueError):
+            N.check(L.sh_dist_reduce_bus(bank._bus64.handle, n * 2, 3))
+    finally:
+        dist.shutdown()
+    assert L.sh_dist_world() == 0
