@@ -69,6 +69,8 @@ struct alignas(16) VoiceLaunch {
     uint32_t pad0;
     double   poly[16];            // FL_POLY: the 16 polynomial coefficients, copied here so that the record
                                   // and the coefficients arrive in ONE batch of scalar loads
+    double   rot_c, rot_s;        // cos / sin of 64*dt: a lane's second frame is 64 samples after its first, so its
+                                  // (sin, cos) is one rotation of the first frame's instead of a second table lookup
     // ---- cold part: launches that cross an envelope boundary, Pulse ----
     uint32_t eb[4];               // launch-relative ends of attack / decay / sustain / release (saturated)
     double   g0[4], slope[4];     // gain(i) = fma(i, slope[p], g0[p]) on piece p; 0 after release
@@ -77,7 +79,7 @@ struct alignas(16) VoiceLaunch {
     double   t_base2, dt2;        // the NEXT table piece: frames i in [remain, end2) have t = fma(i - remain, dt2, t_base2)
     uint32_t end2, pad1, pad2, pad3;
 };
-static_assert(sizeof(VoiceLaunch) == 352, "VoiceLaunch layout");
+static_assert(sizeof(VoiceLaunch) == 368, "VoiceLaunch layout");
 
 struct alignas(16) VoiceFM {      // only read for FM voices
     double frequency, phase0, f_inc;      // theta = frequency*T + fma(f_inc, L, phase0)
@@ -87,7 +89,10 @@ static_assert(sizeof(VoiceFM) == 64, "VoiceFM layout");
 
 __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first, uint32_t vi, uint64_t start, uint32_t nframes,
                                               VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm) {
+    // Fields are stored straight to the record (no local struct: a 368-byte private array would give
+    // every wave of the render kernel a scratch allocation).
     const sh_voice& v = B.voices[first + vi];
+    VoiceLaunch* __restrict__ o = out + vi;
     const bool fm = v.fm_mode != SH_FM_NONE;
     const uint32_t off = fm ? v.time_seg_offset : v.seg_offset;
     const uint32_t cnt = fm ? v.time_seg_count : v.seg_count;
@@ -97,103 +102,114 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         uint32_t mid = (lo + hi + 1) >> 1;
         if (tab[mid].n0 <= start) lo = mid; else hi = mid - 1;
     }
-    VoiceLaunch r;
-    r.t_base = fma((double)(start - tab[lo].n0), tab[lo].dt, tab[lo].t0);
-    r.dt = tab[lo].dt;
-    uint64_t rem = (lo + 1 < cnt) ? (tab[lo + 1].n0 - start) : 0xFFFFFFFFull;
-    r.remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
-    r.seg = lo;
-    r.pad0 = 0;
-    r.pad1 = r.pad2 = r.pad3 = 0;
+    const double dt = tab[lo].dt;
+    const double t_base = fma((double)(start - tab[lo].n0), dt, tab[lo].t0);
+    const uint64_t rem = (lo + 1 < cnt) ? (tab[lo + 1].n0 - start) : 0xFFFFFFFFull;
+    o->t_base = t_base;
+    o->dt = dt;
+    o->remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
+    o->seg = lo;
+    o->pad0 = 0; o->pad1 = 0; o->pad2 = 0; o->pad3 = 0;
     if (lo + 1 < cnt && rem <= 0xFFFFFFFFull) {
-        r.t_base2 = tab[lo + 1].t0;
-        r.dt2 = tab[lo + 1].dt;
-        uint64_t e2 = (lo + 2 < cnt) ? (tab[lo + 2].n0 - start) : 0xFFFFFFFFull;
-        r.end2 = e2 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e2;
+        o->t_base2 = tab[lo + 1].t0;
+        o->dt2 = tab[lo + 1].dt;
+        const uint64_t e2 = (lo + 2 < cnt) ? (tab[lo + 2].n0 - start) : 0xFFFFFFFFull;
+        o->end2 = e2 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e2;
     } else {
-        r.t_base2 = r.t_base;
-        r.dt2 = r.dt;
-        r.end2 = 0;
+        o->t_base2 = t_base;
+        o->dt2 = dt;
+        o->end2 = 0;
     }
-    r.flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
-              (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u);
-    r.harm = v.harm_dense ? (B.coefs + v.harm_offset) : reinterpret_cast<const double*>(B.partials + v.harm_offset);
-    r.harm_cnt = v.harm_count;
-    r.amplitude = v.amplitude;
-    r.bias = v.bias;
-    r.gain_l = (double)v.gain_l;
-    r.gain_r = (double)v.gain_r;
-    r.pulsewidth = v.pulsewidth;
-    r.tail_i = NO_TAIL;
-    r.tail_amp = 0.0;
+    uint32_t flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
+                     (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u);
+    const double* harm = v.harm_dense ? (B.coefs + v.harm_offset) : reinterpret_cast<const double*>(B.partials + v.harm_offset);
+    o->harm = harm;
+    o->harm_cnt = v.harm_count;
+    o->amplitude = v.amplitude;
+    o->bias = v.bias;
+    o->pulsewidth = v.pulsewidth;
+    double gain_l = (double)v.gain_l, gain_r = (double)v.gain_r;
+    // envelope as four lines in the launch-relative frame index
+    uint32_t eb0, eb1, eb2, eb3, tail_i = NO_TAIL;
+    double g00, g01, g02, g03, s0, s1, s2, s3, tail_amp = 0.0;
     const sh_envelope& e = v.env;
     if (e.enabled) {
-        const uint64_t ends[4] = {e.n_attack_end, e.n_decay_end, e.n_sustain_end, e.n_release_end};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint64_t d = ends[j] > start ? ends[j] - start : 0;
-            r.eb[j] = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d;
-        }
-        const double s0 = (double)start;
-        r.g0[0] = s0 * e.attack_slope;                                  // gain(n) = n * attack_slope
-        r.slope[0] = e.attack_slope;
-        r.g0[1] = fma(s0 - (double)e.n_attack_end, e.decay_slope, 1.0);  // 1 + (n - nA) * decay_slope
-        r.slope[1] = e.decay_slope;
-        r.g0[2] = e.sustain_level;
-        r.slope[2] = 0.0;
-        r.g0[3] = fma(s0 - (double)e.n_sustain_end, e.release_slope, e.sustain_level);
-        r.slope[3] = e.release_slope;
+        const uint64_t d0 = e.n_attack_end > start ? e.n_attack_end - start : 0;
+        const uint64_t d1 = e.n_decay_end > start ? e.n_decay_end - start : 0;
+        const uint64_t d2 = e.n_sustain_end > start ? e.n_sustain_end - start : 0;
+        const uint64_t d3 = e.n_release_end > start ? e.n_release_end - start : 0;
+        eb0 = d0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d0;
+        eb1 = d1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d1;
+        eb2 = d2 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d2;
+        eb3 = d3 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d3;
+        const double st = (double)start;
+        g00 = st * e.attack_slope;                                      // gain(n) = n * attack_slope
+        s0 = e.attack_slope;
+        g01 = fma(st - (double)e.n_attack_end, e.decay_slope, 1.0);     // 1 + (n - nA) * decay_slope
+        s1 = e.decay_slope;
+        g02 = e.sustain_level;
+        s2 = 0.0;
+        g03 = fma(st - (double)e.n_sustain_end, e.release_slope, e.sustain_level);
+        s3 = e.release_slope;
         if (e.has_tail && e.n_release_end >= start && e.n_release_end - start < 0xFFFFFFFFull) {
-            r.tail_i = (uint32_t)(e.n_release_end - start);
-            r.tail_amp = e.tail_amp;
+            tail_i = (uint32_t)(e.n_release_end - start);
+            tail_amp = e.tail_amp;
         }
     } else {                       // no envelope: an endless sustain piece of gain 1
-        r.eb[0] = 0; r.eb[1] = 0; r.eb[2] = 0xFFFFFFFFu; r.eb[3] = 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { r.g0[j] = 1.0; r.slope[j] = 0.0; }
+        eb0 = 0; eb1 = 0; eb2 = 0xFFFFFFFFu; eb3 = 0xFFFFFFFFu;
+        g00 = g01 = g02 = g03 = 1.0;
+        s0 = s1 = s2 = s3 = 0.0;
     }
+    o->eb[0] = eb0; o->eb[1] = eb1; o->eb[2] = eb2; o->eb[3] = eb3;
+    o->g0[0] = g00; o->g0[1] = g01; o->g0[2] = g02; o->g0[3] = g03;
+    o->slope[0] = s0; o->slope[1] = s1; o->slope[2] = s2; o->slope[3] = s3;
+    o->tail_i = tail_i;
+    o->tail_amp = tail_amp;
     // does the whole launch [0, nframes) sit on one envelope piece?
+    double g0u = 0.0, slu = 0.0;
     {
         const uint32_t last = nframes ? nframes - 1 : 0;
-        const uint32_t p = (0u >= r.eb[0]) + (0u >= r.eb[1]) + (0u >= r.eb[2]) + (0u >= r.eb[3]);
-        const bool tail_here = r.tail_i != NO_TAIL && r.tail_i <= last;
-        r.g0u = 0.0;
-        r.slu = 0.0;
-        if (p == 4) {
-            if (!tail_here) r.flags |= FL_ENV_UNIFORM;                 // silent for the whole launch
-        } else if (last < r.eb[p]) {
-            r.flags |= FL_ENV_UNIFORM;
-            r.g0u = r.g0[p];
-            r.slu = r.slope[p];
-        }
+        const bool tail_here = tail_i != NO_TAIL && tail_i <= last;
+        if (eb0 > 0) { if (last < eb0) { flags |= FL_ENV_UNIFORM; g0u = g00; slu = s0; } }
+        else if (eb1 > 0) { if (last < eb1) { flags |= FL_ENV_UNIFORM; g0u = g01; slu = s1; } }
+        else if (eb2 > 0) { if (last < eb2) { flags |= FL_ENV_UNIFORM; g0u = g02; slu = s2; } }
+        else if (eb3 > 0) { if (last < eb3) { flags |= FL_ENV_UNIFORM; g0u = g03; slu = s3; } }
+        else if (!tail_here) flags |= FL_ENV_UNIFORM;                  // silent for the whole launch
     }
-    if (r.flags & FL_POLY) {
+    o->g0u = g0u;
+    o->slu = slu;
+    double rc, rs;
+    shm::sincos_f64(64.0 * dt, rs, rc);
+    o->rot_c = rc;
+    o->rot_s = rs;
+    if (flags & FL_POLY) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) r.poly[u] = r.harm[u];
+        for (int u = 0; u < 16; ++u) o->poly[u] = harm[u];
         // bias == 0 and a constant envelope gain: fold amplitude and envelope into the bus gains, so the
         // inner loop is h = P(c)*s; L += GL*h; R += GR*h.  (Differs from the unfolded order by float64
         // rounding only, ~1e-16 relative.)  Bank kernels only: k_generate needs the voice sample itself.
-        if (v.bias == 0.0 && (r.flags & FL_ENV_UNIFORM) && r.slu == 0.0) {
-            r.flags |= FL_FOLDED;
-            r.gain_l = (r.amplitude * r.g0u) * r.gain_l;
-            r.gain_r = (r.amplitude * r.g0u) * r.gain_r;
+        if (v.bias == 0.0 && (flags & FL_ENV_UNIFORM) && slu == 0.0) {
+            flags |= FL_FOLDED;
+            gain_l = (v.amplitude * g0u) * gain_l;
+            gain_r = (v.amplitude * g0u) * gain_r;
         }
     } else {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) r.poly[u] = 0.0;
+        for (int u = 0; u < 16; ++u) o->poly[u] = 0.0;
     }
-    out[vi] = r;
+    o->gain_l = gain_l;
+    o->gain_r = gain_r;
+    o->flags = flags;
     if (fm) {
-        VoiceFM f;
-        f.frequency = v.frequency;
-        f.phase0 = v.fm_phase0;
-        f.f_inc = v.frequency * v.fm_inc;
-        f.lfo_a_rel = fma((double)start - 0.5, v.lfo_d, v.lfo_a);     // arg(i) = a + (start + i - 0.5) * d
-        f.lfo_d = v.lfo_d;
-        f.lfo_K = v.lfo_K;
-        f.lfo_C0 = v.lfo_C0;
-        f.lfo_bias = v.lfo_bias;
-        out_fm[vi] = f;
+        VoiceFM* __restrict__ f = out_fm + vi;
+        f->frequency = v.frequency;
+        f->phase0 = v.fm_phase0;
+        f->f_inc = v.frequency * v.fm_inc;
+        f->lfo_a_rel = fma((double)start - 0.5, v.lfo_d, v.lfo_a);     // arg(i) = a + (start + i - 0.5) * d
+        f->lfo_d = v.lfo_d;
+        f->lfo_K = v.lfo_K;
+        f->lfo_C0 = v.lfo_C0;
+        f->lfo_bias = v.lfo_bias;
     }
 }
 
@@ -210,6 +226,7 @@ struct VoiceRegs {                // the hot part of the launch record as plain 
     double   amplitude, bias, gain_l, gain_r, g0u, slu;
     uint32_t harm_cnt;
     double   poly[16];            // loaded unconditionally with the rest: one batch, one wait per voice
+    double   rot_c, rot_s;
     const VoiceLaunch SH_CONST_AS* rec;   // cold fields are read through this where needed
 };
 
@@ -224,6 +241,7 @@ __device__ __forceinline__ VoiceRegs load_record(const VoiceLaunch SH_CONST_AS* 
     r.harm_cnt = p->harm_cnt;
 #pragma unroll
     for (int u = 0; u < 16; ++u) r.poly[u] = p->poly[u];
+    r.rot_c = p->rot_c; r.rot_s = p->rot_s;
     r.rec = p;
     return r;
 }
@@ -241,8 +259,10 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
                                             const double* __restrict__ fm_cumsum, const double* __restrict__ pwm,
                                             TrigTab trig, double (&x)[FPL]) {
     double th[FPL];
+    bool linear = false;          // th[j] = th[0] + 64*j*dt exactly (all frames on the launch's first table piece, no FM)
     // ---- phase: the reference's accumulated t at each frame ----
     if (tile_last < r.remain) {
+        linear = (r.flags & FL_FM) == 0;
 #pragma unroll
         for (int j = 0; j < FPL; ++j) th[j] = fma(di[j], r.dt, r.t_base);      // exact (stays on the piece)
     } else {
@@ -306,7 +326,16 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
         // Harmonics with k <= 16: sum_k a_k sin(k t) = sin(t) * P(cos t), P of degree 15 (coefficients
         // converted on the host in exact rational arithmetic), Horner: 15 FMAs instead of 32 Clenshaw ops
         double sn[FPL], cs[FPL], pv[FPL];
-        shm::sincos_tab_n<FPL>(th, trig, sn, cs);
+        if (FPL > 1 && linear) {
+            shm::sincos_tab(th[0], trig, sn[0], cs[0]);
+#pragma unroll
+            for (int j = 1; j < FPL; ++j) {               // rotate by 64*dt: 4 float64 ops instead of 17
+                sn[j] = fma(sn[j - 1], r.rot_c, cs[j - 1] * r.rot_s);
+                cs[j] = fma(cs[j - 1], r.rot_c, -(sn[j - 1] * r.rot_s));
+            }
+        } else {
+            shm::sincos_tab_n<FPL>(th, trig, sn, cs);
+        }
 #pragma unroll
         for (int j = 0; j < FPL; ++j) pv[j] = fma(r.poly[0], cs[j], r.poly[1]);
 #pragma unroll
