@@ -112,6 +112,19 @@ def pcm_rows(N):
         N.check(L.sh_pcm_add(chunks.handle, 0, chunks.handle, n, n, 2, src.handle, 0))
     ms = N.timer_stop() / 5
     rows["pcm_add_i16_900MB"] = {"ms": ms, "bytes": 3 * n, "GBps": 3 * n / (ms / 1e3) / 1e9, "frac_hbm": 3 * n / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    # Sample.amplify (audioop.mul), Sample.mono (audioop.tomono), peak/rms
+    n = 900_000_000
+    for name, call, moved in (
+            ("pcm_mul_i16_900MB", lambda: L.sh_pcm_mul(chunks.handle, 0, n, 2, 0.7071, src.handle, 0), 2 * n),
+            ("pcm_tomono_i16_900MB", lambda: L.sh_pcm_tomono(chunks.handle, n // 4, 2, 0.5, 0.5, src.handle), n + n // 2),
+            ("pcm_stats_i16_900MB", lambda: L.sh_pcm_stats(chunks.handle, n, 2, ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_double())), n)):
+        N.check(call())
+        N.sync()
+        N.timer_start()
+        for _ in range(5):
+            N.check(call())
+        ms = N.timer_stop() / 5
+        rows[name] = {"ms": ms, "bytes": moved, "GBps": moved / (ms / 1e3) / 1e9, "frac_hbm": moved / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
     for b in (src, dst, chunks, mixed):
         b.free()
     return rows

@@ -213,6 +213,26 @@ int sh_pcm_add(const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, siz
                sh_buf* out, size_t out_off);
 int sh_pcm_add_host(const void* a, const void* b, size_t nbytes, int width, void* out);
 
+/* ---- the other elementwise Sample operations that delegate to audioop ----
+ * Sample.amplify / invert -> audioop.mul: fbound(sample * factor) (clamp, then floor) */
+int sh_pcm_mul(const sh_buf* in, size_t in_off, size_t nbytes, int width, double factor, sh_buf* out, size_t out_off);
+/* Sample.fadeout (fadeout != 0): int(sample_i * (1 - i*slope/numsamples)); Sample.fadein: int(sample_i *
+ * (i*slope/numsamples + offset)); i = sample index in the range, numsamples = nbytes/width, truncation */
+int sh_pcm_fade(const sh_buf* in, size_t in_off, size_t nbytes, int width, int fadeout, double slope, double offset,
+                sh_buf* out, size_t out_off);
+/* Sample.bias -> audioop.bias: wrapping add */
+int sh_pcm_bias(const sh_buf* in, size_t nbytes, int width, int bias, sh_buf* out);
+/* Sample.reverse -> audioop.reverse: sample order reversed (out must not alias in) */
+int sh_pcm_reverse(const sh_buf* in, size_t nbytes, int width, sh_buf* out);
+/* Sample.mono / left / right -> audioop.tomono; Sample.stereo (mono source) -> audioop.tostereo */
+int sh_pcm_tomono(const sh_buf* in, size_t nframes, int width, double lfactor, double rfactor, sh_buf* out);
+int sh_pcm_tostereo(const sh_buf* in, size_t nframes, int width, double lfactor, double rfactor, sh_buf* out);
+/* Sample.normalize / make_16bit / make_32bit -> audioop.lin2lin */
+int sh_pcm_lin2lin(const sh_buf* in, size_t nsamples, int width, int new_width, sh_buf* out);
+/* audioop.max (maximum absolute sample) and the sum of squares audioop.rms takes the root of
+ * (exact for widths 1 and 2; width 4 is summed in float64 in a fixed tree order) */
+int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, double* sum_squares);
+
 /* ---- Sample.resample -> audioop.ratecv(frames, width, nchannels, inrate, outrate, None) */
 size_t sh_resample_out_frames(size_t in_frames, int inrate, int outrate);
 /* width 1/2/4 integer PCM (bit-exact audioop arithmetic); is_float!=0: float32 PCM (width must be 4) */

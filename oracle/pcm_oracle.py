@@ -167,3 +167,72 @@ def ratecv_f32(x: np.ndarray, inrate: int, outrate: int) -> np.ndarray:
     dd = d.astype(np.float64)[:, None]
     val = (prev * dd + cur * (float(outr) - dd)) / float(outr)
     return val.astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the other audioop functions Sample delegates to, restated from
+# CPython 3.10 Modules/audioop.c and checked against the live module in tests/test_oracle_pcm.py
+# ---------------------------------------------------------------------------------------------------
+
+def _fbound(val: np.ndarray, width: int) -> np.ndarray:
+    """audioop.c fbound(): clamp to [minval, maxval] (values below minval+1 go to minval), then floor."""
+    lo, hi = float(-(1 << (8 * width - 1))), float((1 << (8 * width - 1)) - 1)
+    v = np.where(val > hi, hi, np.where(val < lo + 1.0, lo, val))
+    return np.floor(v).astype(np.int64)
+
+
+def mul(frames: bytes, width: int, factor: float) -> bytes:
+    return _encode(_fbound(_decode(frames, width).astype(np.float64) * float(factor), width), width)
+
+
+def bias(frames: bytes, width: int, bias_value: int) -> bytes:
+    v = (_decode(frames, width) + int(bias_value)) & ((1 << (8 * width)) - 1)
+    v = np.where(v >= 1 << (8 * width - 1), v - (1 << (8 * width)), v)
+    return _encode(v, width)
+
+
+def reverse(frames: bytes, width: int) -> bytes:
+    return _encode(_decode(frames, width)[::-1], width)
+
+
+def tomono(frames: bytes, width: int, lfactor: float, rfactor: float) -> bytes:
+    x = _decode(frames, width).reshape(-1, 2).astype(np.float64)
+    return _encode(_fbound(x[:, 0] * float(lfactor) + x[:, 1] * float(rfactor), width), width)
+
+
+def tostereo(frames: bytes, width: int, lfactor: float, rfactor: float) -> bytes:
+    x = _decode(frames, width).astype(np.float64)
+    out = np.stack([_fbound(x * float(lfactor), width), _fbound(x * float(rfactor), width)], axis=1)
+    return _encode(out.reshape(-1), width)
+
+
+def lin2lin(frames: bytes, width: int, new_width: int) -> bytes:
+    v32 = _decode(frames, width) << (32 - 8 * width)
+    return _encode(v32 >> (32 - 8 * new_width), new_width)
+
+
+def amax(frames: bytes, width: int) -> int:
+    x = _decode(frames, width)
+    return int(np.max(np.abs(x))) if len(x) else 0
+
+
+def rms(frames: bytes, width: int) -> int:
+    x = _decode(frames, width)
+    if len(x) == 0:
+        return 0
+    total = 0.0
+    for v in x.tolist():            # audioop: sequential float64 sum of squares
+        total += float(v) * float(v)
+    return int(np.sqrt(total / float(len(x))))
+
+
+def fade(frames: bytes, width: int, fadeout: bool, slope: float, offset: float) -> bytes:
+    """Sample.fadeout / fadein inner expression (upstream sample.py, recalled): per sample index i,
+    int(sample * (1.0 - i*slope/numsamples)) or int(sample * (i*slope/numsamples + offset))."""
+    x = _decode(frames, width)
+    numsamples = len(frames) / width
+    out = []
+    for i, v in enumerate(x.tolist()):
+        f = (1.0 - i * slope / numsamples) if fadeout else (i * slope / numsamples + offset)
+        out.append(int(v * f))
+    return _encode(np.array(out, dtype=np.int64), width)

@@ -95,6 +95,14 @@ _SIGNATURES = {
     "sh_quantize_clip_f32": (C.c_int, [_P, C.c_size_t, C.c_double, _P]),
     "sh_pcm_add": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_int, _P, C.c_size_t]),
     "sh_pcm_add_host": (C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
+    "sh_pcm_mul": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_int, C.c_double, _P, C.c_size_t]),
+    "sh_pcm_fade": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, _P, C.c_size_t]),
+    "sh_pcm_bias": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, _P]),
+    "sh_pcm_reverse": (C.c_int, [_P, C.c_size_t, C.c_int, _P]),
+    "sh_pcm_tomono": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_double, C.c_double, _P]),
+    "sh_pcm_tostereo": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_double, C.c_double, _P]),
+    "sh_pcm_lin2lin": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, _P]),
+    "sh_pcm_stats": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
     "sh_resample_out_frames": (C.c_size_t, [C.c_size_t, C.c_int, C.c_int]),
     "sh_resample": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_size_t)]),
     "sh_resample_host": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_size_t)]),

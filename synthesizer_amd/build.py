@@ -15,7 +15,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libsynthhip.so"
-SOURCES = ["runtime.hip", "osc.hip", "pcm.hip", "dist.hip"]
+SOURCES = ["runtime.hip", "osc.hip", "pcm.hip", "pcm_ops.hip", "dist.hip"]
 HEADERS = ["common.hpp", "devmath.hpp", "../../include/synthhip.h"]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

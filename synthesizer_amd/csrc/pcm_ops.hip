@@ -1,0 +1,343 @@
+// pcm_ops.hip -- the remaining elementwise / reduction operations that synthplayer's Sample delegates to
+// CPython's audioop (Modules/audioop.c, 3.10): mul (amplify, invert), bias, reverse, tomono, tostereo,
+// lin2lin, max, rms -- plus the per-sample fade ramps of Sample.fadein / fadeout.  SURVEY.md section 8(f)
+// item 2.  HBM-bound byte/integer work: 16-byte vectors per thread where alignment allows, wavefront
+// shuffle (DPP) reductions + one integer atomic per workgroup for max / sum of squares.
+// Built with -ffp-contract=off: audioop forms val1*lfactor + val2*rfactor with separate roundings.
+#include "common.hpp"
+#include <vector>
+
+namespace {
+
+// audioop's fbound(): clamp, then round toward minus infinity
+__device__ __forceinline__ int fbound(double val, double minval, double maxval) {
+    if (val > maxval) val = maxval;
+    else if (val < minval + 1.0) val = minval;
+    return (int)floor(val);
+}
+
+template <typename T> struct Lim;
+template <> struct Lim<signed char> { static constexpr double lo = -128.0, hi = 127.0; };
+template <> struct Lim<short> { static constexpr double lo = -32768.0, hi = 32767.0; };
+template <> struct Lim<int> { static constexpr double lo = -2147483648.0, hi = 2147483647.0; };
+
+// out[i] = fbound(in[i] * factor)            (audioop.mul)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_mul(const T* in, T* out, size_t nvec, double factor) {
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    vec_t v = reinterpret_cast<const vec_t*>(in)[i], r;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) r[c] = (T)fbound((double)v[c] * factor, Lim<T>::lo, Lim<T>::hi);
+    reinterpret_cast<vec_t*>(out)[i] = r;
+}
+
+// per-sample linear ramp: out[i] = int(in[i] * (i*slope/numsamples + offset)), truncation toward zero
+// (Sample.fadeout: offset 1, slope -decrease; Sample.fadein: offset start_volume, slope increase)
+template <typename T>
+__global__ __launch_bounds__(256) void k_fade(const T* in, T* out, size_t n, double slope, double numsamples, double offset, int fadeout) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double ramp = (double)i * slope / numsamples;
+    const double f = fadeout ? (1.0 - ramp) : (ramp + offset);
+    out[i] = (T)(long long)trunc((double)in[i] * f);
+}
+
+// out[i] = in[i] + bias, wrapping                (audioop.bias)
+template <typename T>
+__global__ __launch_bounds__(256) void k_bias(const T* in, T* out, size_t n, int bias) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (T)((unsigned)(int)in[i] + (unsigned)bias);
+}
+
+// out[i] = in[n-1-i]                             (audioop.reverse: samples, not frames)
+template <typename T>
+__global__ __launch_bounds__(256) void k_reverse(const T* __restrict__ in, T* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = in[n - 1 - i];
+}
+
+// stereo -> mono: fbound(l*lfactor + r*rfactor)  (audioop.tomono)
+template <typename T>
+__global__ __launch_bounds__(256) void k_tomono(const T* __restrict__ in, T* __restrict__ out, size_t nframes, double lf, double rf) {
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nframes) return;
+    const vec2 v = reinterpret_cast<const vec2*>(in)[i];
+    out[i] = (T)fbound((double)v.x * lf + (double)v.y * rf, Lim<T>::lo, Lim<T>::hi);
+}
+
+// mono -> stereo: (fbound(v*lfactor), fbound(v*rfactor))   (audioop.tostereo)
+template <typename T>
+__global__ __launch_bounds__(256) void k_tostereo(const T* __restrict__ in, T* __restrict__ out, size_t nframes, double lf, double rf) {
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nframes) return;
+    const double v = (double)in[i];
+    vec2 r;
+    r.x = (T)fbound(v * lf, Lim<T>::lo, Lim<T>::hi);
+    r.y = (T)fbound(v * rf, Lim<T>::lo, Lim<T>::hi);
+    reinterpret_cast<vec2*>(out)[i] = r;
+}
+
+// width conversion through the 32-bit form (GETSAMPLE32 / SETSAMPLE32)   (audioop.lin2lin)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_lin2lin(const TI* __restrict__ in, TO* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int v32 = (int)((unsigned)(int)in[i] << (32 - 8 * (int)sizeof(TI)));
+    out[i] = (TO)(v32 >> (32 - 8 * (int)sizeof(TO)));
+}
+
+// reductions: acc[0] = max |v| (unsigned), acc[1] = sum v*v (u64, exact for widths 1 and 2)
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned w = __shfl_down(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_absmax_sumsq(const T* __restrict__ in, size_t n, unsigned long long* __restrict__ acc) {
+    __shared__ unsigned long long s_sum[4];
+    __shared__ unsigned s_max[4];
+    unsigned mx = 0;
+    unsigned long long sq = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const long long v = (long long)in[i];
+        const unsigned a = (unsigned)(v < 0 ? -v : v);
+        mx = a > mx ? a : mx;
+        sq += (unsigned long long)(v * v);
+    }
+    mx = wave_max_u32(mx);
+    sq = wave_sum_u64(sq);
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_sum[wave] = sq; s_max[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        unsigned m = s_max[0];
+        for (int w = 1; w < 4; ++w) m = s_max[w] > m ? s_max[w] : m;
+        atomicMax(&acc[0], (unsigned long long)m);
+        atomicAdd(&acc[1], t);
+    }
+}
+
+// width 4: squares do not fit u64 sums exactly; accumulate the squares in float64 per thread, then a fixed
+// tree -- close to, but not bit-identical with, audioop's sequential float64 sum (documented).
+__global__ __launch_bounds__(256) void k_sumsq_f64(const int* __restrict__ in, size_t n, double* __restrict__ part) {
+    __shared__ double s[256];
+    double sq = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = (double)in[i];
+        sq += v * v;
+    }
+    s[threadIdx.x] = sq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0];
+}
+
+template <typename F>
+int dispatch_width(int width, F&& f) {
+    if (width == 1) return f((signed char)0);
+    if (width == 2) return f((short)0);
+    if (width == 4) return f((int)0);
+    return sh::set_error(SH_ERR_INVALID, "sample width %d not in {1,2,4}", width);
+}
+
+int check_io(const sh_buf* in, size_t in_off, size_t in_bytes, const sh_buf* out, size_t out_off, size_t out_bytes, const char* who) {
+    if (!in || !out) return sh::set_error(SH_ERR_INVALID, "%s: NULL buffer", who);
+    if (in_off > in->bytes || in_bytes > in->bytes - in_off) return sh::set_error(SH_ERR_INVALID, "%s: input range outside buffer", who);
+    if (out_off > out->bytes || out_bytes > out->bytes - out_off) return sh::set_error(SH_ERR_INVALID, "%s: output range outside buffer", who);
+    return SH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sh_pcm_mul(const sh_buf* in, size_t in_off, size_t nbytes, int width, double factor, sh_buf* out, size_t out_off) {
+    SH_REQUIRE_INIT();
+    int rc = check_io(in, in_off, nbytes, out, out_off, nbytes, "sh_pcm_mul");
+    if (rc) return rc;
+    if (nbytes % width || (in_off | out_off) % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_mul: not a whole number of frames");
+    if (!nbytes) return SH_OK;
+    const char* ip = (const char*)in->ptr + in_off;
+    char* op = (char*)out->ptr + out_off;
+    hipStream_t st = sh::state().stream;
+    return dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        constexpr int V = 16 / sizeof(T);
+        const bool aligned = (((uintptr_t)ip | (uintptr_t)op) & 15) == 0;
+        size_t nvec = aligned ? nbytes / 16 : 0, done = nvec * 16, rest = (nbytes - done) / sizeof(T);
+        if (nvec) hipLaunchKernelGGL((k_mul<T, V>), dim3(sh::div_up(nvec, 256)), dim3(256), 0, st, (const T*)ip, (T*)op, nvec, factor);
+        if (rest) hipLaunchKernelGGL((k_mul<T, 1>), dim3(sh::div_up(rest, 256)), dim3(256), 0, st, (const T*)(ip + done), (T*)(op + done), rest, factor);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_mul");
+    });
+}
+
+int sh_pcm_fade(const sh_buf* in, size_t in_off, size_t nbytes, int width, int fadeout, double slope, double offset,
+                sh_buf* out, size_t out_off) {
+    SH_REQUIRE_INIT();
+    int rc = check_io(in, in_off, nbytes, out, out_off, nbytes, "sh_pcm_fade");
+    if (rc) return rc;
+    if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_fade: not a whole number of samples");
+    if (!nbytes) return SH_OK;
+    const size_t n = nbytes / width;
+    hipStream_t st = sh::state().stream;
+    return dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        hipLaunchKernelGGL(k_fade<T>, dim3(sh::div_up(n, 256)), dim3(256), 0, st, (const T*)((const char*)in->ptr + in_off),
+                           (T*)((char*)out->ptr + out_off), n, slope, (double)nbytes / (double)width, offset, fadeout);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_fade");
+    });
+}
+
+int sh_pcm_bias(const sh_buf* in, size_t nbytes, int width, int bias, sh_buf* out) {
+    SH_REQUIRE_INIT();
+    int rc = check_io(in, 0, nbytes, out, 0, nbytes, "sh_pcm_bias");
+    if (rc) return rc;
+    if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_bias: not a whole number of frames");
+    if (!nbytes) return SH_OK;
+    const size_t n = nbytes / width;
+    hipStream_t st = sh::state().stream;
+    return dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        hipLaunchKernelGGL(k_bias<T>, dim3(sh::div_up(n, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, n, bias);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_bias");
+    });
+}
+
+int sh_pcm_reverse(const sh_buf* in, size_t nbytes, int width, sh_buf* out) {
+    SH_REQUIRE_INIT();
+    int rc = check_io(in, 0, nbytes, out, 0, nbytes, "sh_pcm_reverse");
+    if (rc) return rc;
+    if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_reverse: not a whole number of frames");
+    if (!nbytes) return SH_OK;
+    if (in == out || in->ptr == out->ptr) return sh::set_error(SH_ERR_INVALID, "sh_pcm_reverse: cannot reverse in place");
+    const size_t n = nbytes / width;
+    hipStream_t st = sh::state().stream;
+    return dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        hipLaunchKernelGGL(k_reverse<T>, dim3(sh::div_up(n, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, n);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_reverse");
+    });
+}
+
+int sh_pcm_tomono(const sh_buf* in, size_t nframes, int width, double lfactor, double rfactor, sh_buf* out) {
+    SH_REQUIRE_INIT();
+    int rc = check_io(in, 0, nframes * 2 * width, out, 0, nframes * width, "sh_pcm_tomono");
+    if (rc) return rc;
+    if (!nframes) return SH_OK;
+    hipStream_t st = sh::state().stream;
+    return dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        hipLaunchKernelGGL(k_tomono<T>, dim3(sh::div_up(nframes, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, nframes, lfactor, rfactor);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_tomono");
+    });
+}
+
+int sh_pcm_tostereo(const sh_buf* in, size_t nframes, int width, double lfactor, double rfactor, sh_buf* out) {
+    SH_REQUIRE_INIT();
+    int rc = check_io(in, 0, nframes * width, out, 0, nframes * 2 * width, "sh_pcm_tostereo");
+    if (rc) return rc;
+    if (!nframes) return SH_OK;
+    hipStream_t st = sh::state().stream;
+    return dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        hipLaunchKernelGGL(k_tostereo<T>, dim3(sh::div_up(nframes, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, nframes, lfactor, rfactor);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_tostereo");
+    });
+}
+
+int sh_pcm_lin2lin(const sh_buf* in, size_t nsamples, int width, int new_width, sh_buf* out) {
+    SH_REQUIRE_INIT();
+    int rc = check_io(in, 0, nsamples * width, out, 0, nsamples * new_width, "sh_pcm_lin2lin");
+    if (rc) return rc;
+    if (!nsamples) return SH_OK;
+    hipStream_t st = sh::state().stream;
+    dim3 grid(sh::div_up(nsamples, 256));
+#define SH_L2L(TI, TO) hipLaunchKernelGGL((k_lin2lin<TI, TO>), grid, dim3(256), 0, st, (const TI*)in->ptr, (TO*)out->ptr, nsamples)
+    if (width == 1 && new_width == 1) SH_L2L(signed char, signed char);
+    else if (width == 1 && new_width == 2) SH_L2L(signed char, short);
+    else if (width == 1 && new_width == 4) SH_L2L(signed char, int);
+    else if (width == 2 && new_width == 1) SH_L2L(short, signed char);
+    else if (width == 2 && new_width == 2) SH_L2L(short, short);
+    else if (width == 2 && new_width == 4) SH_L2L(short, int);
+    else if (width == 4 && new_width == 1) SH_L2L(int, signed char);
+    else if (width == 4 && new_width == 2) SH_L2L(int, short);
+    else if (width == 4 && new_width == 4) SH_L2L(int, int);
+    else return sh::set_error(SH_ERR_INVALID, "sh_pcm_lin2lin: widths %d -> %d not in {1,2,4}", width, new_width);
+#undef SH_L2L
+    SH_CHECK_LAUNCH("k_lin2lin");
+    return SH_OK;
+}
+
+int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, double* sum_squares) {
+    SH_REQUIRE_INIT();
+    if (!in || nbytes > in->bytes) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats: range outside buffer");
+    if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats: not a whole number of frames");
+    if (max_abs) *max_abs = 0;
+    if (sum_squares) *sum_squares = 0.0;
+    if (!nbytes) return SH_OK;
+    const size_t n = nbytes / width;
+    const unsigned blocks = n / 256 < 2048 ? (unsigned)(n / 256 + 1) : 2048u;
+    int rc = sh::ensure_scratch(16 + (size_t)blocks * 8);
+    if (rc) return rc;
+    hipStream_t st = sh::state().stream;
+    unsigned long long* acc = (unsigned long long*)sh::state().scratch;
+    double* part = (double*)(acc + 2);
+    SH_HIP(hipMemsetAsync(acc, 0, 16, st));
+    rc = dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        hipLaunchKernelGGL(k_absmax_sumsq<T>, dim3(blocks), dim3(256), 0, st, (const T*)in->ptr, n, acc);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_absmax_sumsq");
+    });
+    if (rc) return rc;
+    if (width == 4) {
+        hipLaunchKernelGGL(k_sumsq_f64, dim3(blocks), dim3(256), 0, st, (const int*)in->ptr, n, part);
+        SH_CHECK_LAUNCH("k_sumsq_f64");
+    }
+    unsigned long long host_acc[2];
+    SH_HIP(hipMemcpyAsync(host_acc, acc, 16, hipMemcpyDeviceToHost, st));
+    std::vector<double> host_part;
+    if (width == 4) {
+        host_part.resize(blocks);
+        SH_HIP(hipMemcpyAsync(host_part.data(), part, (size_t)blocks * 8, hipMemcpyDeviceToHost, st));
+    }
+    SH_HIP(hipStreamSynchronize(st));
+    if (max_abs) *max_abs = (uint32_t)host_acc[0];
+    if (sum_squares) {
+        if (width == 4) {
+            double t = 0.0;
+            for (double p : host_part) t += p;
+            *sum_squares = t;
+        } else {
+            *sum_squares = (double)host_acc[1];
+        }
+    }
+    return SH_OK;
+}
+
+}  // extern "C"

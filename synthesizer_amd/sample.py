@@ -10,8 +10,10 @@ Frames live either on the host (``bytes``) or on the device (``DeviceBuffer``); 
 to the device once and leave them there, accessors bring them back lazily.  There is no CPU
 implementation of the arithmetic in this package.
 
-Not provided (out of the path): amplify, fades, pan, echo, envelope,
-normalize, level metering, 24-bit samples.
+Also here (the elementwise operations upstream delegates to audioop):
+amplify / amplify_max / invert (``audioop.mul``), bias, reverse, mono / left / right (``tomono``),
+stereo / pan (``tostereo``), normalize / make_16bit / make_32bit (``lin2lin``), peak / rms, fadein / fadeout.
+Not provided: echo, envelope, modulate_amp, split / join / clip, level meter objects, 24-bit samples.
 """
 from __future__ import annotations
 
@@ -285,6 +287,177 @@ class Sample:
         if n2:
             N.check(L.sh_pcm_add(dst.handle, start, other._device().handle, 0, n2, self.__samplewidth, dst.handle, start))
         self._set_device(dst, total)
+
+    # -- elementwise operations (upstream: thin wrappers over audioop) ---------------------------------
+    def __unary(self, fn_name: str, out_nbytes: int, *args) -> "Sample":
+        """frames = op(frames): run sh_<fn_name>(in, ..., out) into a fresh device buffer."""
+        dst = N.DeviceBuffer(out_nbytes)
+        N.check(getattr(N.lib(), fn_name)(self._device().handle, *args, dst.handle))
+        self._set_device(dst, out_nbytes)
+        return self
+
+    def amplify(self, factor: float) -> "Sample":
+        """Amplify (or attenuate, or with a negative factor invert) the sample: audioop.mul."""
+        self._check_writable()
+        self._check_gpu_width("amplify")
+        n = self.__nbytes
+        dst = N.DeviceBuffer(n)
+        N.check(N.lib().sh_pcm_mul(self._device().handle, 0, n, self.__samplewidth, float(factor), dst.handle, 0))
+        self._set_device(dst, n)
+        return self
+
+    def peak(self) -> int:
+        """Maximum absolute sample value (audioop.max)."""
+        self._check_gpu_width("peak")
+        mx = C.c_uint32()
+        N.check(N.lib().sh_pcm_stats(self._device().handle, self.__nbytes, self.__samplewidth, C.byref(mx), None))
+        return int(mx.value)
+
+    def rms(self) -> int:
+        """Root mean square of the samples, truncated (audioop.rms)."""
+        self._check_gpu_width("rms")
+        n = self.__nbytes // self.__samplewidth
+        if n == 0:
+            return 0
+        sq = C.c_double()
+        N.check(N.lib().sh_pcm_stats(self._device().handle, self.__nbytes, self.__samplewidth, None, C.byref(sq)))
+        from math import sqrt
+        return int(sqrt(sq.value / float(n)))
+
+    def amplify_max(self) -> "Sample":
+        """Amplify to the maximum volume without clipping."""
+        self._check_writable()
+        max_amp = self.peak()
+        max_target = 2 ** (8 * self.__samplewidth - 1) - 2
+        if max_amp > 0:
+            self.amplify(max_target / max_amp)
+        return self
+
+    def invert(self) -> "Sample":
+        return self.amplify(-1)
+
+    def bias(self, bias: int) -> "Sample":
+        """Add a constant to every sample (wrapping, like audioop.bias)."""
+        self._check_writable()
+        self._check_gpu_width("bias")
+        return self.__unary("sh_pcm_bias", self.__nbytes, self.__nbytes, self.__samplewidth, int(bias))
+
+    def reverse(self) -> "Sample":
+        """Reverse the sound (audioop.reverse: the order of the samples, channels included)."""
+        self._check_writable()
+        self._check_gpu_width("reverse")
+        return self.__unary("sh_pcm_reverse", self.__nbytes, self.__nbytes, self.__samplewidth)
+
+    def mono(self, left_factor: float = 1.0, right_factor: float = 1.0) -> "Sample":
+        """Stereo -> mono with per-channel factors (audioop.tomono)."""
+        self._check_writable()
+        if self.__nchannels == 1:
+            return self
+        if self.__nchannels != 2:
+            raise ValueError("sample must be stereo or mono already")
+        self._check_gpu_width("mono")
+        nframes = len(self)
+        self.__unary("sh_pcm_tomono", nframes * self.__samplewidth, nframes, self.__samplewidth, float(left_factor), float(right_factor))
+        self.__nchannels = 1
+        return self
+
+    def left(self) -> "Sample":
+        return self.mono(1.0, 0)
+
+    def right(self) -> "Sample":
+        return self.mono(0, 1.0)
+
+    def stereo(self, left_factor: float = 1.0, right_factor: float = 1.0) -> "Sample":
+        """Mono -> stereo with per-channel factors (audioop.tostereo); a stereo sample gets its channels scaled."""
+        self._check_writable()
+        self._check_gpu_width("stereo")
+        if self.__nchannels == 2:
+            # upstream: left().amplify(lf) mixed with right().amplify(rf) -> (fbound(L*lf), fbound(R*rf))
+            right = self.copy().right().amplify(right_factor).stereo(0, 1.0)
+            self.left().amplify(left_factor).stereo(1.0, 0)
+            return self.mix(right)
+        if self.__nchannels != 1:
+            raise ValueError("sample must be mono or stereo already")
+        nframes = len(self)
+        self.__unary("sh_pcm_tostereo", nframes * 2 * self.__samplewidth, nframes, self.__samplewidth, float(left_factor), float(right_factor))
+        self.__nchannels = 2
+        return self
+
+    def pan(self, panning: float = 0.0, lfo=None) -> "Sample":
+        """Linear stereo panning, -1.0 (left) .. 1.0 (right); the sample becomes stereo."""
+        if lfo is not None:
+            raise NotImplementedError("pan with an lfo is outside the GPU path")
+        assert -1.0 <= panning <= 1.0
+        left_volume = (1.0 - panning) / 2.0
+        right_volume = (1.0 + panning) / 2.0
+        return self.mono().stereo(left_volume, right_volume)
+
+    def __lin2lin(self, new_width: int) -> None:
+        n = self.__nbytes // self.__samplewidth
+        self.__unary("sh_pcm_lin2lin", n * new_width, n, self.__samplewidth, new_width)
+        self.__samplewidth = new_width
+
+    def normalize(self) -> "Sample":
+        """Bring the sample to the default rate, width and channel count (params.norm_*)."""
+        self._check_writable()
+        self._check_gpu_width("normalize")
+        self.resample(params.norm_samplerate)
+        if self.__samplewidth != params.norm_samplewidth:
+            self.__lin2lin(params.norm_samplewidth)
+        if self.__nchannels == 1 and params.norm_nchannels == 2:
+            self.stereo(1, 1)
+        return self
+
+    def make_32bit(self, scale_amplitude: bool = True) -> "Sample":
+        """Convert to 32-bit samples; without scaling the integer values are kept as they were."""
+        self._check_writable()
+        self._check_gpu_width("make_32bit")
+        old = self.__samplewidth
+        if old != 4:
+            self.__lin2lin(4)
+            if not scale_amplitude:
+                self.amplify(1.0 / 2 ** (8 * (4 - old)))
+        return self
+
+    def make_16bit(self, maximize_amplitude: bool = True) -> "Sample":
+        """Convert to 16-bit samples, optionally maximising the amplitude first."""
+        self._check_writable()
+        self._check_gpu_width("make_16bit")
+        assert self.__samplewidth >= 2
+        if maximize_amplitude:
+            self.amplify_max()
+        if self.__samplewidth > 2:
+            self.__lin2lin(2)
+        return self
+
+    def __fade(self, first_byte: int, nbytes: int, fadeout: bool, slope: float, offset: float) -> None:
+        n = self.__nbytes
+        dst = N.DeviceBuffer(n)
+        L = N.lib()
+        if n:
+            N.check(L.sh_buf_copy(dst.handle, 0, self._device().handle, 0, n))
+        if nbytes:
+            N.check(L.sh_pcm_fade(self._device().handle, first_byte, nbytes, self.__samplewidth, 1 if fadeout else 0,
+                                  float(slope), float(offset), dst.handle, first_byte))
+        self._set_device(dst, n)
+
+    def fadeout(self, seconds: float, target_volume: float = 0.0) -> "Sample":
+        """Fade the end of the sample out to the target volume: int(sample_i * (1 - i*decrease/numsamples))."""
+        self._check_writable()
+        self._check_gpu_width("fadeout")
+        seconds = min(seconds, self.duration)
+        i = self.frame_idx(self.duration - seconds)
+        self.__fade(i, self.__nbytes - i, True, 1.0 - target_volume, 0.0)
+        return self
+
+    def fadein(self, seconds: float, start_volume: float = 0.0) -> "Sample":
+        """Fade the start of the sample in from the start volume: int(sample_i * (i*increase/numsamples + start))."""
+        self._check_writable()
+        self._check_gpu_width("fadein")
+        seconds = min(seconds, self.duration)
+        i = self.frame_idx(seconds)
+        self.__fade(0, i, False, 1.0 - start_volume, start_volume)
+        return self
 
     def resample(self, samplerate: int) -> "Sample":
         """Resample to a different rate without changing pitch/duration: linear interpolation with

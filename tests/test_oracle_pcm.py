@@ -75,3 +75,24 @@ def test_ratecv_f32_is_linear_interpolation():
     want = np.interp(pos, np.arange(1000), x[:, 0].astype(np.float64))
     assert np.max(np.abs(y[:, 0] - want)) < 1e-6
     assert P.ratecv_f32(np.zeros((0, 2), np.float32), 3, 7).shape == (0, 2)
+
+
+@pytest.mark.parametrize("width", [1, 2, 4])
+def test_elementwise_ops_match_audioop(width):
+    rng = np.random.default_rng(50 + width)
+    raw = _rand_bytes(rng, width, 2000)
+    info = np.iinfo(DT[width])
+    corners = np.array([info.max, info.min, info.min + 1, info.max - 1, 0, -1, 1, 3, -3, 5, -5, 100], dtype=DT[width]).tobytes()
+    for frames in (raw, corners, b""):
+        for factor in (1.5, 0.5, -1.0, 1.00001, 0.0, 2.0, -0.333, 1.0 / 65536):
+            assert P.mul(frames, width, factor) == audioop.mul(frames, width, factor)
+        for b in (1, -1, 12345, -70000 if width > 1 else -70):
+            assert P.bias(frames, width, b) == audioop.bias(frames, width, b)
+        assert P.reverse(frames, width) == audioop.reverse(frames, width)
+        for lf, rf in ((1.0, 1.0), (0.5, 0.25), (1.0, 0.0), (0.0, 1.0), (-1.0, 0.7)):
+            assert P.tomono(frames, width, lf, rf) == audioop.tomono(frames, width, lf, rf)
+            assert P.tostereo(frames, width, lf, rf) == audioop.tostereo(frames, width, lf, rf)
+        for nw in (1, 2, 4):
+            assert P.lin2lin(frames, width, nw) == audioop.lin2lin(frames, width, nw)
+        assert P.amax(frames, width) == audioop.max(frames, width)
+        assert P.rms(frames, width) == audioop.rms(frames, width)
