@@ -252,6 +252,14 @@ int sh_dist_world(void);
 int sh_dist_reduce_bus(sh_buf* bus_f64, size_t nvalues, int root);
 int sh_dist_allreduce_bus(sh_buf* bus_f64, size_t nvalues);
 int sh_dist_barrier(void);
+/* pipelined form: the collective (and, on root, the float64 -> float32 rounding into bus_f32) is enqueued on
+ * the library's communication stream behind everything already enqueued on the main stream, so block s is
+ * reduced while block s+1 renders.  `slot` (0 .. sh_dist_slots()-1) names the buffer pair; call
+ * sh_dist_wait_slot(slot) before the main stream overwrites that slot's buffers again.  sh_sync() waits
+ * for both streams. */
+int sh_dist_slots(void);
+int sh_dist_reduce_bus_async(sh_buf* bus_f64, size_t nvalues, int root, sh_buf* bus_f32, int slot);
+int sh_dist_wait_slot(int slot);
 /* float64 bus -> float32 bus after the reduce */
 int sh_bus_finalize(const sh_buf* bus_f64, size_t nvalues, sh_buf* bus_f32);
 

@@ -114,6 +114,9 @@ _SIGNATURES = {
     "sh_dist_reduce_bus": (C.c_int, [_P, C.c_size_t, C.c_int]),
     "sh_dist_allreduce_bus": (C.c_int, [_P, C.c_size_t]),
     "sh_dist_barrier": (C.c_int, []),
+    "sh_dist_slots": (C.c_int, []),
+    "sh_dist_reduce_bus_async": (C.c_int, [_P, C.c_size_t, C.c_int, _P, C.c_int]),
+    "sh_dist_wait_slot": (C.c_int, [C.c_int]),
     "sh_bus_finalize": (C.c_int, [_P, C.c_size_t, _P]),
 }
 

@@ -17,6 +17,7 @@ struct State {
     bool        initialized = false;
     int         device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;     // collectives (created by sh_dist_init): the reduce of block s overlaps the render of block s+1
     hipEvent_t  ev_start = nullptr, ev_stop = nullptr;
     // grow-only scratch used by kernels that need a second pass (partial buses, scan sums, flags)
     void*       scratch = nullptr;
@@ -30,6 +31,7 @@ State& state();
 int  set_error(int code, const char* fmt, ...);
 int  hip_error(hipError_t e, const char* what);
 int  ensure_scratch(size_t bytes);
+int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out);   // float64 bus -> float32 (osc.hip)
 
 #define SH_REQUIRE_INIT()                                                              \
     do {                                                                               \

@@ -23,6 +23,10 @@ struct Rccl {
     ncclComm_t comm = nullptr;
     int rank = -1, world = 0;
     double* token = nullptr;     // 1-element device buffer for the barrier
+    // pipelined reduce: the collective of block s runs on comm_stream while the main stream renders s+1
+    static constexpr int SLOTS = 4;
+    hipEvent_t ev_rendered[SLOTS] = {};
+    hipEvent_t ev_done[SLOTS] = {};
 };
 
 Rccl& R() {
@@ -91,15 +95,28 @@ int sh_dist_init(int rank, int world, const void* id128) {
     r.world = world;
     SH_HIP(hipMalloc((void**)&r.token, sizeof(double)));
     SH_HIP(hipMemsetAsync(r.token, 0, sizeof(double), sh::state().stream));
+    SH_HIP(hipStreamCreateWithFlags(&sh::state().comm_stream, hipStreamNonBlocking));
+    for (int k = 0; k < Rccl::SLOTS; ++k) {
+        SH_HIP(hipEventCreateWithFlags(&r.ev_rendered[k], hipEventDisableTiming));
+        SH_HIP(hipEventCreateWithFlags(&r.ev_done[k], hipEventDisableTiming));
+    }
     return SH_OK;
 }
 
 int sh_dist_shutdown(void) {
     Rccl& r = R();
     if (r.comm) {
-        if (sh::state().initialized) hipStreamSynchronize(sh::state().stream);
+        if (sh::state().initialized) {
+            hipStreamSynchronize(sh::state().stream);
+            if (sh::state().comm_stream) hipStreamSynchronize(sh::state().comm_stream);
+        }
         r.CommDestroy(r.comm);
         r.comm = nullptr;
+        for (int k = 0; k < Rccl::SLOTS; ++k) {
+            if (r.ev_rendered[k]) { hipEventDestroy(r.ev_rendered[k]); r.ev_rendered[k] = nullptr; }
+            if (r.ev_done[k]) { hipEventDestroy(r.ev_done[k]); r.ev_done[k] = nullptr; }
+        }
+        if (sh::state().comm_stream) { hipStreamDestroy(sh::state().comm_stream); sh::state().comm_stream = nullptr; }
     }
     if (r.token) {
         hipFree(r.token);
@@ -131,6 +148,37 @@ int sh_dist_allreduce_bus(sh_buf* bus_f64, size_t nvalues) {
     if (!bus_f64 || bus_f64->bytes < nvalues * 8) return sh::set_error(SH_ERR_INVALID, "sh_dist_allreduce_bus: buffer too small");
     if (!nvalues) return SH_OK;
     SH_RCCL(r.AllReduce(bus_f64->ptr, bus_f64->ptr, nvalues, ncclFloat64, ncclSum, r.comm, sh::state().stream));
+    return SH_OK;
+}
+
+int sh_dist_slots(void) { return Rccl::SLOTS; }
+
+int sh_dist_reduce_bus_async(sh_buf* bus_f64, size_t nvalues, int root, sh_buf* bus_f32, int slot) {
+    SH_REQUIRE_INIT();
+    Rccl& r = R();
+    if (!r.comm) return sh::set_error(SH_ERR_RCCL, "sh_dist_reduce_bus_async: sh_dist_init not called");
+    if (!bus_f64 || bus_f64->bytes < nvalues * 8) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_async: buffer too small");
+    if (bus_f32 && bus_f32->bytes < nvalues * 4) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_async: bus_f32 too small");
+    if (root < 0 || root >= r.world) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_async: bad root");
+    if (slot < 0 || slot >= Rccl::SLOTS) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_async: slot %d outside 0..%d", slot, Rccl::SLOTS - 1);
+    hipStream_t main = sh::state().stream, comm = sh::state().comm_stream;
+    SH_HIP(hipEventRecord(r.ev_rendered[slot], main));
+    SH_HIP(hipStreamWaitEvent(comm, r.ev_rendered[slot], 0));
+    if (nvalues) SH_RCCL(r.Reduce(bus_f64->ptr, bus_f64->ptr, nvalues, ncclFloat64, ncclSum, root, r.comm, comm));
+    if (r.rank == root && bus_f32) {
+        int rc = sh::bus_finalize_on(comm, (const double*)bus_f64->ptr, nvalues, (float*)bus_f32->ptr);
+        if (rc) return rc;
+    }
+    SH_HIP(hipEventRecord(r.ev_done[slot], comm));
+    return SH_OK;
+}
+
+int sh_dist_wait_slot(int slot) {
+    SH_REQUIRE_INIT();
+    Rccl& r = R();
+    if (!r.comm) return sh::set_error(SH_ERR_RCCL, "sh_dist_wait_slot: sh_dist_init not called");
+    if (slot < 0 || slot >= Rccl::SLOTS) return sh::set_error(SH_ERR_INVALID, "sh_dist_wait_slot: bad slot");
+    SH_HIP(hipStreamWaitEvent(sh::state().stream, r.ev_done[slot], 0));    // no-op until the slot has been used
     return SH_OK;
 }
 

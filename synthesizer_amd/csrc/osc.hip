@@ -811,6 +811,15 @@ static int upload_array(T** dst, const T* src, size_t count, hipStream_t st) {
     return SH_OK;
 }
 
+namespace sh {
+int bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out) {
+    if (!nvalues) return SH_OK;
+    hipLaunchKernelGGL(k_bus_finalize, dim3(div_up(nvalues, 256)), dim3(256), 0, st, in, nvalues, out);
+    SH_CHECK_LAUNCH("k_bus_finalize");
+    return SH_OK;
+}
+}  // namespace sh
+
 extern "C" {
 
 int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* segs, uint32_t nsegs,
@@ -1129,11 +1138,7 @@ int sh_bus_finalize(const sh_buf* bus_f64, size_t nvalues, sh_buf* bus_f32) {
     SH_REQUIRE_INIT();
     if (!bus_f64 || !bus_f32) return sh::set_error(SH_ERR_INVALID, "sh_bus_finalize: NULL argument");
     if (bus_f64->bytes < nvalues * 8 || bus_f32->bytes < nvalues * 4) return sh::set_error(SH_ERR_INVALID, "sh_bus_finalize: buffer too small");
-    if (!nvalues) return SH_OK;
-    hipLaunchKernelGGL(k_bus_finalize, dim3(sh::div_up(nvalues, 256)), dim3(256), 0, sh::state().stream,
-                       (const double*)bus_f64->ptr, nvalues, (float*)bus_f32->ptr);
-    SH_CHECK_LAUNCH("k_bus_finalize");
-    return SH_OK;
+    return sh::bus_finalize_on(sh::state().stream, (const double*)bus_f64->ptr, nvalues, (float*)bus_f32->ptr);
 }
 
 int sh_scan_f64(const sh_buf* x, uint32_t n, double carry_in, sh_buf* out, double* carry_out) {

@@ -128,6 +128,7 @@ int sh_device_info(sh_devinfo* out) {
 int sh_sync(void) {
     SH_REQUIRE_INIT();
     SH_HIP(hipStreamSynchronize(state().stream));
+    if (state().comm_stream) SH_HIP(hipStreamSynchronize(state().comm_stream));
     return SH_OK;
 }
 

@@ -141,28 +141,35 @@ class DistVoiceBank:
         if hi <= lo:
             raise ValueError("rank %d owns no voices (%d voices over %d ranks)" % (rank, len(voices), world))
         self.local = VoiceBank(list(voices[lo:hi]), gains=list(gains[lo:hi]))
-        self._bus64: Optional[N.DeviceBuffer] = None
-        self._bus32: Optional[N.DeviceBuffer] = None
+        self._bus64 = []          # one (float64 partial, float32 result) buffer pair per pipeline slot
+        self._bus32 = []
         self._cap = 0
+        self._slot = 0
 
     def _buffers(self, nframes: int) -> None:
         if nframes > self._cap:
-            self._bus64 = N.DeviceBuffer(nframes * 16)
-            self._bus32 = N.DeviceBuffer(nframes * 8)
+            N.sync()
+            nslots = N.lib().sh_dist_slots() if self.world > 1 else 1
+            self._bus64 = [N.DeviceBuffer(nframes * 16) for _ in range(nslots)]
+            self._bus32 = [N.DeviceBuffer(nframes * 8) for _ in range(nslots)]
             self._cap = nframes
+            self._slot = 0
 
     def render_device(self, nframes: int, start: int = 0, root: int = 0) -> N.DeviceBuffer:
-        """Render the shard, reduce to ``root``; returns the float32 bus buffer (valid on root)."""
+        """Render the shard and reduce to ``root``; returns the float32 bus buffer (meaningful on root, after
+        ``_native.sync()``).  With several ranks the reduce of this block is enqueued on the communication
+        stream and overlaps the render of the following blocks (a ring of pipeline slots)."""
         self._buffers(nframes)
         L = N.lib()
         if self.world == 1:                      # nothing to exchange: the kernel rounds to float32 itself
-            self.local.render_device(nframes, start, bus_f32=self._bus32)
-            return self._bus32
-        self.local.render_device(nframes, start, bus_f32=None, bus_f64=self._bus64)
-        N.check(L.sh_dist_reduce_bus(self._bus64.handle, nframes * 2, root))
-        if self.rank == root:
-            N.check(L.sh_bus_finalize(self._bus64.handle, nframes * 2, self._bus32.handle))
-        return self._bus32
+            self.local.render_device(nframes, start, bus_f32=self._bus32[0])
+            return self._bus32[0]
+        k = self._slot
+        self._slot = (k + 1) % len(self._bus64)
+        N.check(L.sh_dist_wait_slot(k))          # the reduce that last used this slot must have finished
+        self.local.render_device(nframes, start, bus_f32=None, bus_f64=self._bus64[k])
+        N.check(L.sh_dist_reduce_bus_async(self._bus64[k].handle, nframes * 2, root, self._bus32[k].handle, k))
+        return self._bus32[k]
 
     def render(self, nframes: int, start: int = 0, root: int = 0) -> Optional[np.ndarray]:
         buf = self.render_device(nframes, start, root)

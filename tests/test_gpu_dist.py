@@ -22,16 +22,34 @@ def test_single_rank_rccl_reduce(gpu):
         n = 4096
         ref = bank.local.render(n)
         bank._buffers(n)
-        bank.local.render_device(n, 0, bus_f32=None, bus_f64=bank._bus64)
-        N.check(L.sh_dist_reduce_bus(bank._bus64.handle, n * 2, 0))
-        N.check(L.sh_dist_allreduce_bus(bank._bus64.handle, n * 2))
+        bank.local.render_device(n, 0, bus_f32=None, bus_f64=bank._bus64[0])
+        N.check(L.sh_dist_reduce_bus(bank._bus64[0].handle, n * 2, 0))
+        N.check(L.sh_dist_allreduce_bus(bank._bus64[0].handle, n * 2))
         N.check(L.sh_dist_barrier())
-        N.check(L.sh_bus_finalize(bank._bus64.handle, n * 2, bank._bus32.handle))
-        got = bank._bus32.download(np.float32, n * 2).reshape(n, 2)
+        N.check(L.sh_bus_finalize(bank._bus64[0].handle, n * 2, bank._bus32[0].handle))
+        got = bank._bus32[0].download(np.float32, n * 2).reshape(n, 2)
         assert np.array_equal(got, ref)
         assert np.array_equal(bank.render(n), ref)
         with pytest.raises(ValueError):
-            N.check(L.sh_dist_reduce_bus(bank._bus64.handle, n * 2, 3))
+            N.check(L.sh_dist_reduce_bus(bank._bus64[0].handle, n * 2, 3))
+        # the pipelined form: reduce of block s on the communication stream while block s+1 renders
+        nslots = L.sh_dist_slots()
+        b64 = [N.DeviceBuffer(n * 16) for _ in range(nslots)]
+        b32 = [N.DeviceBuffer(n * 8) for _ in range(nslots)]
+        outs = []
+        for s in range(2 * nslots + 1):
+            k = s % nslots
+            N.check(L.sh_dist_wait_slot(k))
+            if s >= nslots:                      # slot reuse: fetch the block rendered nslots steps ago first
+                N.sync()
+                outs.append(b32[k].download(np.float32, n * 2).reshape(n, 2))
+            bank.local.render_device(n, s * n, bus_f32=None, bus_f64=b64[k])
+            N.check(L.sh_dist_reduce_bus_async(b64[k].handle, n * 2, 0, b32[k].handle, k))
+        N.sync()
+        for j, got_j in enumerate(outs):
+            assert np.array_equal(got_j, bank.local.render(n, j * n)), j
+        with pytest.raises(ValueError):
+            N.check(L.sh_dist_reduce_bus_async(b64[0].handle, n * 2, 0, b32[0].handle, nslots))
     finally:
         dist.shutdown()
     assert L.sh_dist_world() == 0
