@@ -51,7 +51,7 @@ typedef enum sh_status {
 } sh_status;
 
 typedef enum sh_kind {     /* oscillators.py class names */
-    SH_SINE = 0, SH_SAWTOOTH = 1, SH_SQUARE = 2, SH_PULSE = 3, SH_HARMONICS = 4
+    SH_SINE = 0, SH_SAWTOOTH = 1, SH_SQUARE = 2, SH_PULSE = 3, SH_HARMONICS = 4, SH_TRIANGLE = 5
 } sh_kind;
 
 typedef enum sh_fm_mode {
@@ -101,7 +101,7 @@ typedef struct sh_voice {
      *                sin(t) * P(cos t), P of degree 15 (all k <= 16; converted exactly on the host) */
     uint32_t harm_offset, harm_count;
     int32_t  harm_dense;
-    int32_t  reserved0;
+    int32_t  flip;             /* SawtoothH: the sample is mirrored around the bias, value = bias*2.0 - value */
     /* FM: theta_n = fm_phase0 + frequency*T_n + frequency*fm_inc*L(n), T = shared time table
      * (t += fm_inc from 0), L(n) = sum_{j<n} lfo_j */
     double   frequency, fm_phase0, fm_inc;
@@ -178,6 +178,13 @@ int sh_osc_render(sh_bank* bank, uint32_t voice,
                   const sh_buf* fm_cumsum, const sh_buf* pwm,
                   uint64_t start, uint32_t n,
                   float* out_host, sh_buf* out_f32, size_t out_off, sh_buf* out_f64);
+
+/* ---- filters over rendered oscillator blocks: MixingFilter (a+b),
+ *      AmpModulationFilter (a*b), ClipFilter (max(min(a, p1), p0)), AbsFilter (|a|), copy / constant fill.
+ *      a, b, out_f64: float64 device buffers; out_f32 (+ element offset) / out_host: optional float32 copies */
+typedef enum sh_ew_op { SH_EW_ADD = 0, SH_EW_MUL = 1, SH_EW_CLIP = 2, SH_EW_ABS = 3, SH_EW_COPY = 4, SH_EW_FILL = 5 } sh_ew_op;
+int sh_ew_f64(int op, const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, size_t n, double p0, double p1,
+              sh_buf* out_f64, size_t out64_off, sh_buf* out_f32, size_t out32_off, float* out_host);
 
 /* exclusive running sum of n float64 values on the device (FM with an arbitrary fm_lfo):
  * out[i] = carry_in + x[0] + .. + x[i-1], i = 0..n-1 (n values).

@@ -393,3 +393,156 @@ def mix_bus(voices: Sequence[Sequence[float]], gains: Sequence[Tuple[float, floa
             r += gr * v[i]
         out.append((l, r))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# further oscillators and filters (all [RECALL], parity unpinned)
+# ---------------------------------------------------------------------------------------------------
+
+class Triangle(Oscillator):
+    """upstream: oscillators.py class Triangle."""
+
+    def __init__(self, frequency: float, amplitude: float = 1.0, phase: float = 0.0,
+                 bias: float = 0.0, fm_lfo: Optional[Oscillator] = None, samplerate: int = 0) -> None:
+        super().__init__(samplerate)
+        self.frequency = frequency
+        self.amplitude = amplitude
+        self.bias = bias
+        self.fm = fm_lfo
+        self._phase = phase
+
+    def blocks(self):
+        if self.fm:
+            phase_correction = self._phase
+            freq_previous = self.frequency
+            increment = 1.0 / self.samplerate
+            t = 0.0
+            fm_blocks = _fm_blocks(self.fm)
+            while True:
+                block = []
+                for fm in next(fm_blocks):
+                    freq = self.frequency * (1.0 + fm)
+                    phase_correction += (freq_previous - freq) * t
+                    freq_previous = freq
+                    tt = t * freq + phase_correction
+                    block.append(4.0 * self.amplitude * (abs((tt + 0.75) % 1.0 - 0.5) - 0.25) + self.bias)
+                    t += increment
+                yield block
+        else:
+            increment = self.frequency / self.samplerate
+            t = self._phase
+            while True:
+                block = []
+                for _ in range(norm_osc_blocksize):
+                    block.append(4.0 * self.amplitude * (abs((t + 0.75) % 1.0 - 0.5) - 0.25) + self.bias)
+                    t += increment
+                yield block
+
+
+class SquareH(Harmonics):
+    """upstream: oscillators.py class SquareH (odd harmonics, 1/n)."""
+
+    def __init__(self, frequency: float, num_harmonics: int = 16, amplitude: float = 0.9999, phase: float = 0.0,
+                 bias: float = 0.0, fm_lfo: Optional[Oscillator] = None, samplerate: int = 0) -> None:
+        harmonics = [(n, 1.0 / n) for n in range(1, num_harmonics * 2, 2)]
+        super().__init__(frequency, harmonics, amplitude, phase, bias, fm_lfo, samplerate)
+
+
+class SawtoothH(Harmonics):
+    """upstream: oscillators.py class SawtoothH (all harmonics, 1/n, phase + 0.5, flipped)."""
+
+    def __init__(self, frequency: float, num_harmonics: int = 16, amplitude: float = 0.9999, phase: float = 0.0,
+                 bias: float = 0.0, fm_lfo: Optional[Oscillator] = None, samplerate: int = 0) -> None:
+        harmonics = [(n, 1.0 / n) for n in range(1, num_harmonics + 1)]
+        super().__init__(frequency, harmonics, amplitude, phase + 0.5, bias, fm_lfo, samplerate)
+
+    def blocks(self):
+        for block in super().blocks():
+            yield [self.bias * 2.0 - value for value in block]
+
+
+class MixingFilter(Oscillator):
+    """upstream: oscillators.py class MixingFilter."""
+
+    def __init__(self, *sources: Oscillator) -> None:
+        super().__init__(sources[0].samplerate)
+        self._sources = sources
+
+    def blocks(self):
+        source_blocks = zip(*[src.blocks() for src in self._sources])
+        for blocks in source_blocks:
+            yield [sum(v) for v in zip(*blocks)]
+
+
+class AmpModulationFilter(Oscillator):
+    """upstream: oscillators.py class AmpModulationFilter."""
+
+    def __init__(self, source: Oscillator, modulator: Oscillator) -> None:
+        super().__init__(source.samplerate)
+        self._source, self._modulator = source, modulator
+
+    def blocks(self):
+        for sb, mb in zip(self._source.blocks(), self._modulator.blocks()):
+            yield [v * m for v, m in zip(sb, mb)]
+
+
+class ClipFilter(Oscillator):
+    """upstream: oscillators.py class ClipFilter."""
+
+    def __init__(self, source: Oscillator, minimum: float = -1.0, maximum: float = 1.0) -> None:
+        super().__init__(source.samplerate)
+        self._source, self.min, self.max = source, minimum, maximum
+
+    def blocks(self):
+        for block in self._source.blocks():
+            yield [max(min(v, self.max), self.min) for v in block]
+
+
+class AbsFilter(Oscillator):
+    """upstream: oscillators.py class AbsFilter."""
+
+    def __init__(self, source: Oscillator) -> None:
+        super().__init__(source.samplerate)
+        self._source = source
+
+    def blocks(self):
+        from math import fabs
+        for block in self._source.blocks():
+            yield [fabs(v) for v in block]
+
+
+class NullFilter(Oscillator):
+    """upstream: oscillators.py class NullFilter."""
+
+    def __init__(self, source: Oscillator) -> None:
+        super().__init__(source.samplerate)
+        self._source = source
+
+    def blocks(self):
+        yield from self._source.blocks()
+
+
+class DelayFilter(Oscillator):
+    """upstream: oscillators.py class DelayFilter."""
+
+    def __init__(self, source: Oscillator, seconds: float) -> None:
+        super().__init__(source.samplerate)
+        self._source, self._seconds = source, seconds
+
+    def _samples(self):
+        src = itertools.chain.from_iterable(self._source.blocks())
+        if self._seconds > 0.0:
+            for _ in range(int(self.samplerate * self._seconds)):
+                yield 0.0
+        elif self._seconds < 0.0:
+            for _ in range(int(-self.samplerate * self._seconds)):
+                next(src)
+        yield from src
+
+    def blocks(self):
+        samples = self._samples()
+        while True:
+            block = list(itertools.islice(samples, norm_osc_blocksize))
+            if not block:
+                return
+            yield block

@@ -17,7 +17,8 @@ LIB_PATH = Path(os.environ.get("SYNTHHIP_LIB", HERE / "libsynthhip.so"))
 
 SH_OK = 0
 SH_ERR_INVALID, SH_ERR_HIP, SH_ERR_NOMEM, SH_ERR_NOTINIT, SH_ERR_OVERFLOW, SH_ERR_RCCL, SH_ERR_LENGTH = -1, -2, -3, -4, -5, -6, -7
-SH_SINE, SH_SAWTOOTH, SH_SQUARE, SH_PULSE, SH_HARMONICS = range(5)
+SH_SINE, SH_SAWTOOTH, SH_SQUARE, SH_PULSE, SH_HARMONICS, SH_TRIANGLE = range(6)
+SH_EW_ADD, SH_EW_MUL, SH_EW_CLIP, SH_EW_ABS, SH_EW_COPY, SH_EW_FILL = range(6)
 SH_FM_NONE, SH_FM_SINE, SH_FM_BUFFER = range(3)
 SH_DIST_ID_BYTES = 128
 
@@ -43,7 +44,7 @@ VOICE_DTYPE = np.dtype([
     ("kind", "<i4"), ("fm_mode", "<i4"),
     ("amplitude", "<f8"), ("bias", "<f8"), ("pulsewidth", "<f8"),
     ("seg_offset", "<u4"), ("seg_count", "<u4"),
-    ("harm_offset", "<u4"), ("harm_count", "<u4"), ("harm_dense", "<i4"), ("reserved0", "<i4"),
+    ("harm_offset", "<u4"), ("harm_count", "<u4"), ("harm_dense", "<i4"), ("flip", "<i4"),
     ("frequency", "<f8"), ("fm_phase0", "<f8"), ("fm_inc", "<f8"),
     ("time_seg_offset", "<u4"), ("time_seg_count", "<u4"),
     ("lfo_a", "<f8"), ("lfo_d", "<f8"), ("lfo_amp", "<f8"), ("lfo_bias", "<f8"), ("lfo_K", "<f8"), ("lfo_C0", "<f8"),
@@ -85,6 +86,7 @@ _SIGNATURES = {
     "sh_bank_destroy": (C.c_int, [_P]),
     "sh_bank_nvoices": (C.c_uint32, [_P]),
     "sh_osc_render": (C.c_int, [_P, C.c_uint32, _P, _P, C.c_uint64, C.c_uint32, _P, _P, C.c_size_t, _P]),
+    "sh_ew_f64": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_double, C.c_double, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "sh_scan_f64": (C.c_int, [_P, C.c_uint32, C.c_double, _P, C.POINTER(C.c_double)]),
     "sh_bank_generate": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t]),
     "sh_bank_render": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, _P]),

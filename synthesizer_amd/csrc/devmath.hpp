@@ -207,4 +207,12 @@ SH_HD double pulse_value(double t, double pw, double amp, double bias) {
     return ((m < pw) ? amp : -amp) + bias;
 }
 
+// Triangle: 4.0*amplitude*(abs((t+0.75) % 1.0 - 0.5) - 0.25) + bias ; Python float modulo
+SH_HD double triangle_value(double t, double amp4, double bias) {
+    double u = t + 0.75;
+    double m = u - trunc(u);
+    if (m < 0.0) m = m + 1.0;
+    return amp4 * (fabs(m - 0.5) - 0.25) + bias;
+}
+
 }  // namespace shm

@@ -51,7 +51,7 @@ __device__ __forceinline__ const T SH_CONST_AS* as_const(const T* p) {
 // index i = n - start.  The scalar unit (one per CU) is the scarce resource of these kernels, so the
 // record is laid out to cost the hot path one batch of loads and almost no scalar arithmetic.
 constexpr uint32_t FL_KIND = 0x7, FL_FM_SHIFT = 4, FL_FM = 0x30, FL_DENSE = 0x40, FL_ENV_UNIFORM = 0x80,
-                   FL_POLY = 0x100, FL_FOLDED = 0x200;
+                   FL_POLY = 0x100, FL_FOLDED = 0x200, FL_FLIP = 0x400;
 constexpr uint32_t NO_TAIL = 0xFFFFFFFFu;
 
 struct alignas(16) VoiceLaunch {
@@ -121,7 +121,7 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         o->end2 = 0;
     }
     uint32_t flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
-                     (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u);
+                     (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u) | (v.flip ? FL_FLIP : 0u);
     const double* harm = v.harm_dense ? (B.coefs + v.harm_offset) : reinterpret_cast<const double*>(B.partials + v.harm_offset);
     o->harm = harm;
     o->harm_cnt = v.harm_count;
@@ -188,7 +188,7 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         // bias == 0 and a constant envelope gain: fold amplitude and envelope into the bus gains, so the
         // inner loop is h = P(c)*s; L += GL*h; R += GR*h.  (Differs from the unfolded order by float64
         // rounding only, ~1e-16 relative.)  Bank kernels only: k_generate needs the voice sample itself.
-        if (v.bias == 0.0 && (flags & FL_ENV_UNIFORM) && slu == 0.0) {
+        if (v.bias == 0.0 && !v.flip && (flags & FL_ENV_UNIFORM) && slu == 0.0) {
             flags |= FL_FOLDED;
             gain_l = (v.amplitude * g0u) * gain_l;
             gain_r = (v.amplitude * g0u) * gain_r;
@@ -366,6 +366,10 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
 #pragma unroll
             for (int j = 0; j < FPL; ++j) x[j] = shm::square_value(th[j], r.amplitude, r.bias);
             break;
+        case SH_TRIANGLE:
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = shm::triangle_value(th[j], 4.0 * r.amplitude, r.bias);
+            break;
         case SH_PULSE: {
             const double pw = r.rec->pulsewidth;
 #pragma unroll
@@ -416,6 +420,10 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
             for (int j = 0; j < FPL; ++j) x[j] = h[j] * r.amplitude + r.bias;
         } break;
         }
+    }
+    if (r.flags & FL_FLIP) {                    // SawtoothH: "we have to flip the wave"
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) x[j] = r.bias * 2.0 - x[j];
     }
     // ---- envelope ----
     if (r.flags & FL_ENV_UNIFORM) {            // the whole launch lies on one piece (the common case)
@@ -697,6 +705,24 @@ __global__ void k_bus_finalize(const double* __restrict__ in, size_t n, float* _
     if (i < n) out[i] = (float)in[i];
 }
 
+// ---- elementwise filters over float64 blocks ----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ew_f64(int op, const double* a, const double* b, size_t n, double p0, double p1,
+                                                double* out64, float* out32) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v;
+    switch (op) {
+    case SH_EW_ADD: v = a[i] + b[i]; break;
+    case SH_EW_MUL: v = a[i] * b[i]; break;
+    case SH_EW_CLIP: { double t = a[i] < p1 ? a[i] : p1; v = t > p0 ? t : p0; } break;    // max(min(v, maximum), minimum)
+    case SH_EW_ABS: v = fabs(a[i]); break;
+    case SH_EW_COPY: v = a[i]; break;
+    default: v = p0; break;
+    }
+    if (out64) out64[i] = v;
+    if (out32) out32[i] = (float)v;
+}
+
 // ---- float64 exclusive scan (FM with an arbitrary modulator) ---------------------------
 constexpr int SCAN_TILE = 2048;   // values per block (256 threads x 8)
 
@@ -830,7 +856,7 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     if (!segs || nsegs == 0) return sh::set_error(SH_ERR_INVALID, "sh_bank_create: no phase tables");
     for (uint32_t i = 0; i < nvoices; ++i) {
         const sh_voice& v = voices[i];
-        if (v.kind < SH_SINE || v.kind > SH_HARMONICS)
+        if (v.kind < SH_SINE || v.kind > SH_TRIANGLE)
             return sh::set_error(SH_ERR_INVALID, "voice %u: unknown kind %d", i, v.kind);
         if (v.fm_mode < SH_FM_NONE || v.fm_mode > SH_FM_BUFFER)
             return sh::set_error(SH_ERR_INVALID, "voice %u: unknown fm_mode %d", i, v.fm_mode);
@@ -1139,6 +1165,35 @@ int sh_bus_finalize(const sh_buf* bus_f64, size_t nvalues, sh_buf* bus_f32) {
     if (!bus_f64 || !bus_f32) return sh::set_error(SH_ERR_INVALID, "sh_bus_finalize: NULL argument");
     if (bus_f64->bytes < nvalues * 8 || bus_f32->bytes < nvalues * 4) return sh::set_error(SH_ERR_INVALID, "sh_bus_finalize: buffer too small");
     return sh::bus_finalize_on(sh::state().stream, (const double*)bus_f64->ptr, nvalues, (float*)bus_f32->ptr);
+}
+
+int sh_ew_f64(int op, const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, size_t n, double p0, double p1,
+              sh_buf* out_f64, size_t out64_off, sh_buf* out_f32, size_t out32_off, float* out_host) {
+    SH_REQUIRE_INIT();
+    if (op < SH_EW_ADD || op > SH_EW_FILL) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: unknown op %d", op);
+    const bool need_a = op != SH_EW_FILL, need_b = op == SH_EW_ADD || op == SH_EW_MUL;
+    if (need_a && (!a || a_off > a->bytes / 8 || n > a->bytes / 8 - a_off)) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: operand a too small");
+    if (need_b && (!b || b_off > b->bytes / 8 || n > b->bytes / 8 - b_off)) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: operand b too small");
+    if (out_f64 && (out64_off > out_f64->bytes / 8 || n > out_f64->bytes / 8 - out64_off)) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: out_f64 too small");
+    if (out_f32 && (out32_off > out_f32->bytes / 4 || n > out_f32->bytes / 4 - out32_off)) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: out_f32 too small");
+    if (!out_f64 && !out_f32 && !out_host) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: no destination");
+    if (!n) return SH_OK;
+    float* d32 = out_f32 ? (float*)out_f32->ptr + out32_off : nullptr;
+    if (!d32 && out_host) {
+        int rc = sh::ensure_scratch(n * 4);
+        if (rc) return rc;
+        d32 = (float*)sh::state().scratch;
+    }
+    hipStream_t st = sh::state().stream;
+    hipLaunchKernelGGL(k_ew_f64, dim3(sh::div_up(n, 256)), dim3(256), 0, st, op,
+                       need_a ? (const double*)a->ptr + a_off : nullptr, need_b ? (const double*)b->ptr + b_off : nullptr,
+                       n, p0, p1, out_f64 ? (double*)out_f64->ptr + out64_off : nullptr, d32);
+    SH_CHECK_LAUNCH("k_ew_f64");
+    if (out_host) {
+        SH_HIP(hipMemcpyAsync(out_host, d32, n * 4, hipMemcpyDeviceToHost, st));
+        SH_HIP(hipStreamSynchronize(st));
+    }
+    return SH_OK;
 }
 
 int sh_scan_f64(const sh_buf* x, uint32_t n, double carry_in, sh_buf* out, double* carry_out) {

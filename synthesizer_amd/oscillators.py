@@ -30,7 +30,8 @@ from . import params
 from . import _native as N
 from .phasetable import PhaseTable
 
-__all__ = ["Oscillator", "Sine", "Sawtooth", "Square", "Pulse", "Harmonics", "EnvelopeFilter"]
+__all__ = ["Oscillator", "Sine", "Triangle", "Sawtooth", "Square", "Pulse", "Harmonics", "SquareH", "SawtoothH",
+           "EnvelopeFilter", "MixingFilter", "AmpModulationFilter", "ClipFilter", "AbsFilter", "NullFilter", "DelayFilter"]
 
 _SUPERBLOCK = 128          # blocks rendered per kernel launch behind blocks()
 _DENSE_MAX_K = 4096        # Harmonics: use the Clenshaw (dense) form when max k <= min(this, 8*len+64)
@@ -142,6 +143,7 @@ class VoiceSpec:
     harm_sparse: Optional[Tuple[Tuple[float, float], ...]] = None
     env: Optional[EnvelopeSpec] = None
     needs_pwm: bool = False
+    flip: bool = False                                  # SawtoothH mirrors the wave around the bias
 
 
 def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float, float]]] = None):
@@ -204,6 +206,7 @@ def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float
             v["harm_offset"] = part_index[s.harm_sparse]
             v["harm_count"] = len(s.harm_sparse)
             v["harm_dense"] = 0
+        v["flip"] = 1 if s.flip else 0
         if s.env is not None:
             e = v["env"]
             e["n_attack_end"], e["n_decay_end"] = s.env.n_attack_end, s.env.n_decay_end
@@ -420,6 +423,11 @@ class Sine(_Carrier):
     RADIANS = True
 
 
+class Triangle(_Carrier):
+    """Perfect triangle wave (upstream: oscillators.py class Triangle)."""
+    KIND = N.SH_TRIANGLE
+
+
 class Sawtooth(_Carrier):
     """Sawtooth oscillator, naive form (upstream: oscillators.py class Sawtooth)."""
     KIND = N.SH_SAWTOOTH
@@ -488,6 +496,27 @@ class Harmonics(_Carrier):
                          harm_poly=poly, harm_dense=dense, harm_sparse=sparse, **self._phase_fields())
 
 
+class SquareH(Harmonics):
+    """Square wave built from odd sine harmonics, 1/n amplitudes (upstream: oscillators.py class SquareH)."""
+
+    def __init__(self, frequency: float, num_harmonics: int = 16, amplitude: float = 0.9999, phase: float = 0.0,
+                 bias: float = 0.0, fm_lfo: Optional[Oscillator] = None, samplerate: int = 0) -> None:
+        harmonics = [(n, 1.0 / n) for n in range(1, num_harmonics * 2, 2)]
+        super().__init__(frequency, harmonics, amplitude, phase, bias, fm_lfo, samplerate)
+
+
+class SawtoothH(Harmonics):
+    """Sawtooth built from all sine harmonics, 1/n amplitudes, flipped (upstream: oscillators.py class SawtoothH)."""
+
+    def __init__(self, frequency: float, num_harmonics: int = 16, amplitude: float = 0.9999, phase: float = 0.0,
+                 bias: float = 0.0, fm_lfo: Optional[Oscillator] = None, samplerate: int = 0) -> None:
+        harmonics = [(n, 1.0 / n) for n in range(1, num_harmonics + 1)]
+        super().__init__(frequency, harmonics, amplitude, phase + 0.5, bias, fm_lfo, samplerate)
+
+    def _make_spec(self) -> VoiceSpec:
+        return replace(super()._make_spec(), flip=True)        # value -> bias*2.0 - value
+
+
 class EnvelopeFilter(Oscillator):
     """ADSR volume envelope over an oscillator (upstream: oscillators.py class EnvelopeFilter).
     A, D, S, R in seconds, sustain_level an amplitude factor.  Fused into the source's kernel."""
@@ -517,3 +546,145 @@ class EnvelopeFilter(Oscillator):
         env = envelope_spec(self._attack, self._decay, self._sustain, self._sustain_level, self._release,
                             self.samplerate, self._stop_at_end)
         return replace(self._source.spec(), env=env)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Filters over oscillator blocks.  They are not voices of a bank: each
+# renders its sources as float64 blocks in HBM and combines them with an elementwise kernel.
+# ---------------------------------------------------------------------------------------------------
+
+class _Filter(Oscillator):
+    def __init__(self, sources: Sequence[Oscillator]) -> None:
+        super().__init__(sources[0].samplerate)
+        self._sources = list(sources)
+
+    def spec(self) -> VoiceSpec:
+        raise NotImplementedError("%s is a filter over rendered blocks, not a voice of a bank" % type(self).__name__)
+
+    @property
+    def length(self) -> Optional[int]:
+        lens = [s.length for s in self._sources if s.length is not None]
+        return min(lens) if lens else None
+
+    def _f64(self, start: int, n: int) -> N.DeviceBuffer:
+        raise NotImplementedError
+
+    def _render_f64_device(self, start: int, n: int) -> N.DeviceBuffer:
+        limit = self.length
+        if limit is not None and start + n > limit:
+            raise ValueError("stream ended before the requested range")
+        return self._f64(start, n)
+
+    def _render_device(self, start, n, out_host=None, out_f32=None, out_off=0, out_f64=None) -> None:
+        buf = self._f64(start, n)
+        N.check(N.lib().sh_ew_f64(N.SH_EW_COPY, buf.handle, 0, None, 0, n, 0.0, 0.0,
+                                  out_f64.handle if out_f64 is not None else None, 0,
+                                  out_f32.handle if out_f32 is not None else None, out_off,
+                                  out_host.ctypes.data if out_host is not None else None))
+        N.sync()
+        buf.free()
+
+    @staticmethod
+    def _ew(op: int, a: N.DeviceBuffer, b: Optional[N.DeviceBuffer], n: int, p0: float = 0.0, p1: float = 0.0) -> N.DeviceBuffer:
+        """a = op(a, b) in place."""
+        N.check(N.lib().sh_ew_f64(op, a.handle, 0, b.handle if b is not None else None, 0, n, p0, p1,
+                                  a.handle, 0, None, 0, None))
+        return a
+
+
+class MixingFilter(_Filter):
+    """Mixes (adds) the waves of several sources (upstream: oscillators.py class MixingFilter).
+    Per sample ``sum(values)``: left to right, like Python's sum."""
+
+    def __init__(self, *sources: Oscillator) -> None:
+        super().__init__(sources)
+
+    def _f64(self, start: int, n: int) -> N.DeviceBuffer:
+        acc = self._sources[0]._render_f64_device(start, n)
+        for src in self._sources[1:]:
+            other = src._render_f64_device(start, n)
+            self._ew(N.SH_EW_ADD, acc, other, n)
+            N.sync()
+            other.free()
+        return acc
+
+
+class AmpModulationFilter(_Filter):
+    """Modulates the amplitude of the source by another oscillator (upstream: class AmpModulationFilter)."""
+
+    def __init__(self, source: Oscillator, modulator: Oscillator) -> None:
+        super().__init__([source, modulator])
+
+    def _f64(self, start: int, n: int) -> N.DeviceBuffer:
+        acc = self._sources[0]._render_f64_device(start, n)
+        mod = self._sources[1]._render_f64_device(start, n)
+        self._ew(N.SH_EW_MUL, acc, mod, n)
+        N.sync()
+        mod.free()
+        return acc
+
+
+class ClipFilter(_Filter):
+    """Clips the source between a minimum and a maximum: max(min(v, maximum), minimum) (upstream: class ClipFilter)."""
+
+    def __init__(self, source: Oscillator, minimum: float = -1.0, maximum: float = 1.0) -> None:
+        super().__init__([source])
+        self.min = minimum
+        self.max = maximum
+
+    def _f64(self, start: int, n: int) -> N.DeviceBuffer:
+        return self._ew(N.SH_EW_CLIP, self._sources[0]._render_f64_device(start, n), None, n, float(self.min), float(self.max))
+
+
+class AbsFilter(_Filter):
+    """Returns the absolute value of the source (upstream: class AbsFilter)."""
+
+    def __init__(self, source: Oscillator) -> None:
+        super().__init__([source])
+
+    def _f64(self, start: int, n: int) -> N.DeviceBuffer:
+        return self._ew(N.SH_EW_ABS, self._sources[0]._render_f64_device(start, n), None, n)
+
+
+class NullFilter(_Filter):
+    """Passes the source through unchanged (upstream: class NullFilter)."""
+
+    def __init__(self, source: Oscillator) -> None:
+        super().__init__([source])
+
+    def _f64(self, start: int, n: int) -> N.DeviceBuffer:
+        return self._sources[0]._render_f64_device(start, n)
+
+
+class DelayFilter(_Filter):
+    """Delays the source by a number of seconds (zeros first), or skips into it when negative
+    (upstream: class DelayFilter)."""
+
+    def __init__(self, source: Oscillator, seconds: float) -> None:
+        super().__init__([source])
+        self._seconds = seconds
+
+    @property
+    def _shift(self) -> int:
+        if self._seconds > 0.0:
+            return int(self.samplerate * self._seconds)
+        return -int(-self.samplerate * self._seconds) if self._seconds < 0.0 else 0
+
+    @property
+    def length(self) -> Optional[int]:
+        src = self._sources[0].length
+        return None if src is None else max(0, src + self._shift)
+
+    def _f64(self, start: int, n: int) -> N.DeviceBuffer:
+        d = self._shift
+        out = N.DeviceBuffer(n * 8)
+        nzero = min(n, max(0, d - start))                 # output samples that fall in the leading silence
+        L = N.lib()
+        if nzero:
+            N.check(L.sh_ew_f64(N.SH_EW_FILL, None, 0, None, 0, nzero, 0.0, 0.0, out.handle, 0, None, 0, None))
+        if n > nzero:
+            src = self._sources[0]._render_f64_device(start + nzero - d, n - nzero)
+            N.check(L.sh_ew_f64(N.SH_EW_COPY, src.handle, 0, None, 0, n - nzero, 0.0, 0.0, out.handle, nzero, None, 0, None))
+            N.sync()
+            src.free()
+        return out

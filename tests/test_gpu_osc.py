@@ -234,3 +234,65 @@ def test_quantise_bit_exact_and_overflow(gpu):
         O.quantise([0.5, 1.01])
     # the overflow flag does not stick
     assert list(Sample.from_osc_block(np.array([0.5], dtype=np.float32), SR).get_frame_array()) == [16383]
+
+
+def test_triangle_and_band_limited_harmonics(gpu):
+    """Triangle, SquareH, SawtoothH."""
+    from synthesizer_amd import oscillators as G
+    for args, kw in (((440.0,), dict(amplitude=0.8, phase=0.3, bias=0.1)), ((1000.0,), {}), ((-300.0,), dict(phase=-0.4))):
+        g, o = _pair("Triangle", *args, samplerate=SR, **kw)
+        _check(g, o, 20000)
+    g = G.Triangle(330.0, fm_lfo=G.Sine(4.0, 0.03, samplerate=SR), samplerate=SR)
+    o = O.Triangle(330.0, fm_lfo=O.Sine(4.0, 0.03, samplerate=SR), samplerate=SR)
+    assert rms(g.render(20000), np.array(o.take(20000))) <= RMS_TOL
+    for cls in ("SquareH", "SawtoothH"):
+        for nh in (4, 16):
+            g, o = _pair(cls, 220.0, nh, samplerate=SR, bias=0.05, phase=0.1)
+            _check(g, o, 20000, max_ulp=2)
+        g = getattr(G, cls)(220.0, fm_lfo=G.Sine(3.0, 0.02, samplerate=SR), samplerate=SR)
+        o = getattr(O, cls)(220.0, fm_lfo=O.Sine(3.0, 0.02, samplerate=SR), samplerate=SR)
+        assert rms(g.render(20000), np.array(o.take(20000))) <= RMS_TOL
+    # in a bank
+    from synthesizer_amd.mixer import VoiceBank
+    gv = [G.Triangle(200.0, 0.3, samplerate=SR), G.SawtoothH(150.0, 8, 0.3, samplerate=SR), G.SquareH(100.0, 6, 0.3, samplerate=SR)]
+    ov = [O.Triangle(200.0, 0.3, samplerate=SR), O.SawtoothH(150.0, 8, 0.3, samplerate=SR), O.SquareH(100.0, 6, 0.3, samplerate=SR)]
+    gains = [(0.5, 0.25), (1.0, 0.0), (0.125, 0.75)]
+    got = VoiceBank(gv, gains=gains).render(5000)
+    want = np.array(O.mix_bus([v.take(5000) for v in ov], gains))
+    assert rms(got, want) <= RMS_TOL
+
+
+def test_filters(gpu):
+    """MixingFilter, AmpModulationFilter, ClipFilter, AbsFilter, NullFilter, DelayFilter."""
+    from synthesizer_amd import oscillators as G
+
+    def build(M):
+        a = M.Sine(440.0, 0.6, samplerate=SR)
+        b = M.Sawtooth(111.0, 0.5, phase=0.2, samplerate=SR)
+        c = M.EnvelopeFilter(M.Square(50.0, 0.4, samplerate=SR), 0.01, 0.02, 0.05, 0.5, 0.02)
+        return {
+            "mix": M.MixingFilter(a, b, c),
+            "am": M.AmpModulationFilter(a, M.Sine(3.0, 0.5, bias=0.5, samplerate=SR)),
+            "clip": M.ClipFilter(M.MixingFilter(a, b), -0.5, 0.7),
+            "abs": M.AbsFilter(b),
+            "null": M.NullFilter(a),
+            "delay": M.DelayFilter(a, 0.01),
+            "advance": M.DelayFilter(b, -0.02),
+            "nested": M.AbsFilter(M.ClipFilter(M.AmpModulationFilter(M.MixingFilter(a, b), c), -0.2, 0.2)),
+        }
+
+    g, o = build(G), build(O)
+    n = 6000
+    for name in g:
+        got = g[name].render(n)
+        want = np.array(o[name].take(n))
+        assert got.shape == (n,), name
+        assert rms(got, want) <= RMS_TOL, name
+        assert np.max(np.abs(got - want)) < 3e-7, name
+    # random access and the blocks() protocol go through the same path
+    assert np.array_equal(g["mix"].render(1000, start=2500), g["mix"].render(n, start=0)[2500:3500])
+    assert np.array_equal(g["delay"].render(300, start=400), g["delay"].render(n, start=0)[400:700])
+    assert rms(next(g["clip"].blocks()), next(o["clip"].blocks())) <= RMS_TOL
+    from synthesizer_amd.mixer import VoiceBank
+    with pytest.raises(NotImplementedError):
+        VoiceBank([g["mix"]])
