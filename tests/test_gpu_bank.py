@@ -148,3 +148,39 @@ def test_configs_at_full_size_vs_c_oracle(gpu):
     assert rms(tail, want[36000:37000]) <= RMS_TOL and np.max(np.abs(tail - want[36000:37000])) < 5e-7
     two = bank.render_two_step(n)
     assert rms(two, want[:n]) <= RMS_TOL
+
+
+def test_edge_sizes_and_positions(gpu):
+    """Empty and ragged launches, single voices, very late start positions."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank, mix_bus
+    from synthesizer_amd import _native as N
+    v = [G.Sine(440.0, 0.5, samplerate=SR), G.Square(1000.0, 0.25, samplerate=SR), G.Harmonics(55.0, [(1, 1.0), (2, 0.5)], 0.25, samplerate=SR)]
+    bank = VoiceBank(v, pans=[-1.0, 0.0, 1.0])
+    assert bank.render(0).shape == (0, 2)
+    assert bank.generate(0).shape == (3, 0)
+    one = bank.render(1)
+    assert one.shape == (1, 2)
+    for n in (1, 63, 64, 65, 127, 128, 129, 255, 257, 1000):
+        got = bank.render(n, start=5)
+        assert np.array_equal(got, bank.render(2000, start=0)[5:5 + n]), n
+        assert np.array_equal(bank.generate(n, start=5), bank.generate(2000, start=0)[:, 5:5 + n]), n
+    # pan law: left-only, centre, right-only
+    g = bank.gains
+    assert g[0] == (1.0, 0.0) and g[1] == (0.5, 0.5) and g[2] == (0.0, 1.0)
+    # a position far into the stream (2^40 samples = 265 days at 48 kHz): tables still cover it
+    far = 1 << 40
+    a = bank.render(512, start=far)
+    b = np.concatenate([bank.render(200, start=far), bank.render(312, start=far + 200)])
+    assert np.array_equal(a, b) and np.isfinite(a).all() and np.abs(a).max() <= 1.0
+    sq = G.Square(1000.0, samplerate=SR).render(96, start=far)
+    assert set(np.unique(sq)) <= {-1.0, 1.0} and np.array_equal(sq[:24], sq[48:72])      # 48-sample period, exact edges
+    # single-voice bank == the oscillator itself
+    solo = VoiceBank([v[0]], gains=[(1.0, 1.0)])
+    x = v[0].render(3000, start=100)
+    assert np.array_equal(solo.render(3000, start=100)[:, 0], x)
+    # mix_bus with one frame / one voice
+    assert np.allclose(mix_bus(np.array([[0.5]], dtype=np.float32), [(0.5, 2.0)]), [[0.25, 1.0]])
+    small = N.DeviceBuffer(16)
+    with pytest.raises(ValueError):
+        N.check(N.lib().sh_bank_generate(bank._bank.handle, 0, 100, small.handle, 100))
