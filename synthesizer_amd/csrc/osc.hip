@@ -634,16 +634,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_bus_f32(const float* __restr
     const bool full = (f0 + 3 < nframes) && ((stride & 3) == 0);
     if (full) {
         uint32_t v = v_begin + wave;
-        // 4 rows in flight per wave
+#define SH_ACC(X_, G_)                                                     \
+    l0 = fmaf(G_.x, X_.x, l0); l1 = fmaf(G_.x, X_.y, l1); l2 = fmaf(G_.x, X_.z, l2); l3 = fmaf(G_.x, X_.w, l3); \
+    r0 = fmaf(G_.y, X_.x, r0); r1 = fmaf(G_.y, X_.y, r1); r2 = fmaf(G_.y, X_.z, r2); r3 = fmaf(G_.y, X_.w, r3);
+        // 8 rows (8 KB per wave) in flight, then 4, then 1
+        for (; v + 7 * WAVES < v_end; v += 8 * WAVES) {
+            float4 x[8];
+            float2 gg[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = *reinterpret_cast<const float4*>(voices + (size_t)(v + k * WAVES) * stride + f0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gg[k] = gains[v + k * WAVES];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { SH_ACC(x[k], gg[k]) }
+        }
         for (; v + 3 * WAVES < v_end; v += 4 * WAVES) {
             float4 x0 = *reinterpret_cast<const float4*>(voices + (size_t)v * stride + f0);
             float4 x1 = *reinterpret_cast<const float4*>(voices + (size_t)(v + WAVES) * stride + f0);
             float4 x2 = *reinterpret_cast<const float4*>(voices + (size_t)(v + 2 * WAVES) * stride + f0);
             float4 x3 = *reinterpret_cast<const float4*>(voices + (size_t)(v + 3 * WAVES) * stride + f0);
             float2 g0 = gains[v], g1 = gains[v + WAVES], g2 = gains[v + 2 * WAVES], g3 = gains[v + 3 * WAVES];
-#define SH_ACC(X_, G_)                                                     \
-    l0 = fmaf(G_.x, X_.x, l0); l1 = fmaf(G_.x, X_.y, l1); l2 = fmaf(G_.x, X_.z, l2); l3 = fmaf(G_.x, X_.w, l3); \
-    r0 = fmaf(G_.y, X_.x, r0); r1 = fmaf(G_.y, X_.y, r1); r2 = fmaf(G_.y, X_.z, r2); r3 = fmaf(G_.y, X_.w, r3);
             SH_ACC(x0, g0) SH_ACC(x1, g1) SH_ACC(x2, g2) SH_ACC(x3, g3)
         }
         for (; v < v_end; v += WAVES) {

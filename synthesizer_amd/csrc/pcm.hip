@@ -38,6 +38,29 @@ __global__ __launch_bounds__(256) void k_quantize(const InT* __restrict__ in, si
     out[i] = (OutT)(long long)t;
 }
 
+// float32 -> int16, 8 samples per thread (two 16-byte loads, one 16-byte store)
+__global__ __launch_bounds__(256) void k_quantize_f32_i16_vec(const float4* __restrict__ in, size_t nvec, double scale,
+                                                              short8v* __restrict__ out, int* __restrict__ flag, int clip) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    const float4 lo4 = in[2 * i], hi4 = in[2 * i + 1];
+    const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    short8v r;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double p = scale * (double)v[j];
+        double t = trunc(p);
+        if (!(t >= -32768.0 && t <= 32767.0)) {
+            if (clip) { t = (t > 32767.0) ? 32767.0 : -32768.0; if (p != p) t = 0.0; }
+            else { bad = true; t = 0.0; }
+        }
+        r[j] = (short)(int)t;
+    }
+    if (bad) *flag = 1;
+    out[i] = r;
+}
+
 // ---- audioop.add (no __restrict__: Sample.mix_at adds in place) ---------------------------------
 __global__ __launch_bounds__(256) void k_add_i16_vec(const short8v* a, const short8v* b,
                                                      short8v* o, size_t nvec) {
@@ -80,57 +103,71 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __restrict__ chunks, uint32_t nvoices,
                                                               size_t stride, uint32_t nsamples,
                                                               short* __restrict__ out) {
-    __shared__ int red[WAVES][3][4][64];
+    constexpr int S = 8;                                  // samples per lane: one 16-byte load per voice row
+    __shared__ int red[WAVES][3][S][64];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t s0 = (blockIdx.x * 64 + lane) * 4;
+    const uint32_t s0 = (blockIdx.x * 64 + lane) * S;
     const uint32_t per = (nvoices + WAVES - 1) / WAVES;
     const uint32_t v0 = wave * per;
     uint32_t v1 = v0 + per;
     if (v1 > nvoices) v1 = nvoices;
-    int a[4] = {0, 0, 0, 0}, L[4] = {-CH_BIG, -CH_BIG, -CH_BIG, -CH_BIG}, U[4] = {CH_BIG, CH_BIG, CH_BIG, CH_BIG};
-    const bool vec = (s0 + 3 < nsamples) && ((stride & 3) == 0);
-    if (s0 < nsamples) {
-        for (uint32_t v = v0; v < v1; ++v) {
-            const short* row = chunks + (size_t)v * stride + s0;
-            short4v x;
-            if (vec) {
-                x = *reinterpret_cast<const short4v*>(row);
-            } else {
-                x.x = row[0];
-                x.y = (s0 + 1 < nsamples) ? row[1] : (short)0;
-                x.z = (s0 + 2 < nsamples) ? row[2] : (short)0;
-                x.w = (s0 + 3 < nsamples) ? row[3] : (short)0;
-            }
+    int a[S], L[S], U[S];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int s = x[j];
-                a[j] += s;
-                L[j] = clampi(L[j] + s, -32768, 32767);
-                U[j] = clampi(U[j] + s, -32768, 32767);
+    for (int j = 0; j < S; ++j) { a[j] = 0; L[j] = -CH_BIG; U[j] = CH_BIG; }
+    const bool vec = (s0 + S - 1 < nsamples) && ((stride & (S - 1)) == 0);
+#define SH_FOLD(X_)                                                   \
+    _Pragma("unroll") for (int j = 0; j < S; ++j) {                   \
+        const int s_ = (X_)[j];                                        \
+        a[j] += s_;                                                    \
+        L[j] = clampi(L[j] + s_, -32768, 32767);                       \
+        U[j] = clampi(U[j] + s_, -32768, 32767);                       \
+    }
+    if (s0 < nsamples) {
+        if (vec) {
+            uint32_t v = v0;
+            for (; v + 3 < v1; v += 4) {                  // four voice rows in flight
+                const short8v x0 = *reinterpret_cast<const short8v*>(chunks + (size_t)v * stride + s0);
+                const short8v x1 = *reinterpret_cast<const short8v*>(chunks + (size_t)(v + 1) * stride + s0);
+                const short8v x2 = *reinterpret_cast<const short8v*>(chunks + (size_t)(v + 2) * stride + s0);
+                const short8v x3 = *reinterpret_cast<const short8v*>(chunks + (size_t)(v + 3) * stride + s0);
+                SH_FOLD(x0) SH_FOLD(x1) SH_FOLD(x2) SH_FOLD(x3)
+            }
+            for (; v < v1; ++v) {
+                const short8v x0 = *reinterpret_cast<const short8v*>(chunks + (size_t)v * stride + s0);
+                SH_FOLD(x0)
+            }
+        } else {
+            for (uint32_t v = v0; v < v1; ++v) {
+                const short* row = chunks + (size_t)v * stride + s0;
+                short8v x;
+#pragma unroll
+                for (int j = 0; j < S; ++j) x[j] = (s0 + j < nsamples) ? row[j] : (short)0;
+                SH_FOLD(x)
             }
         }
     }
+#undef SH_FOLD
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < S; ++j) {
         red[wave][0][j][lane] = a[j];
         red[wave][1][j][lane] = L[j];
         red[wave][2][j][lane] = U[j];
     }
     __syncthreads();
     if (wave == 0 && s0 < nsamples) {
-        short4v r;
+        short8v r;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < S; ++j) {
             int x = 0;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) x = clampi(x + red[w][0][j][lane], red[w][1][j][lane], red[w][2][j][lane]);
             r[j] = (short)x;
         }
-        if (s0 + 3 < nsamples && ((reinterpret_cast<uintptr_t>(out + s0) & 7) == 0)) {
-            *reinterpret_cast<short4v*>(out + s0) = r;
+        if (s0 + S - 1 < nsamples && ((reinterpret_cast<uintptr_t>(out + s0) & 15) == 0)) {
+            *reinterpret_cast<short8v*>(out + s0) = r;
         } else {
-            for (uint32_t j = 0; j < 4 && s0 + j < nsamples; ++j) out[s0 + j] = r[j];
+            for (uint32_t j = 0; j < S && s0 + j < nsamples; ++j) out[s0 + j] = r[j];
         }
     }
 }
@@ -253,7 +290,13 @@ int sh_quantize_f32(const sh_buf* in_f32, size_t in_off, size_t n, double scale,
     dim3 grid(sh::div_up(n, 256));
     hipStream_t st = sh::state().stream;
     int* flag = sh::state().flag;
-    if (width == 2) hipLaunchKernelGGL(k_quantize<short>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (short*)out_pcm->ptr + out_off, flag, 0);
+    if (width == 2) {
+        short* o = (short*)out_pcm->ptr + out_off;
+        const bool aligned = (((uintptr_t)in | (uintptr_t)o) & 15) == 0;
+        const size_t nvec = aligned ? n / 8 : 0, done = nvec * 8;
+        if (nvec) hipLaunchKernelGGL(k_quantize_f32_i16_vec, dim3(sh::div_up(nvec, 256)), dim3(256), 0, st, (const float4*)in, nvec, scale, (short8v*)o, flag, 0);
+        if (n > done) hipLaunchKernelGGL(k_quantize<short>, dim3(sh::div_up(n - done, 256)), dim3(256), 0, st, in + done, n - done, scale, lo, hi, o + done, flag, 0);
+    }
     else if (width == 1) hipLaunchKernelGGL(k_quantize<signed char>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (signed char*)out_pcm->ptr + out_off, flag, 0);
     else hipLaunchKernelGGL(k_quantize<int>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (int*)out_pcm->ptr + out_off, flag, 0);
     SH_CHECK_LAUNCH("k_quantize");
@@ -293,8 +336,13 @@ int sh_quantize_clip_f32(const sh_buf* in_f32, size_t n, double scale, sh_buf* o
     if (!in_f32 || !out_i16) return sh::set_error(SH_ERR_INVALID, "sh_quantize_clip_f32: NULL argument");
     if (in_f32->bytes / 4 < n || out_i16->bytes / 2 < n) return sh::set_error(SH_ERR_INVALID, "sh_quantize_clip_f32: buffer too small");
     if (!n) return SH_OK;
-    hipLaunchKernelGGL(k_quantize<short>, dim3(sh::div_up(n, 256)), dim3(256), 0, sh::state().stream,
-                       (const float*)in_f32->ptr, n, scale, -32768.0, 32767.0, (short*)out_i16->ptr, sh::state().flag, 1);
+    {
+        hipStream_t st = sh::state().stream;
+        const size_t nvec = n / 8, done = nvec * 8;
+        if (nvec) hipLaunchKernelGGL(k_quantize_f32_i16_vec, dim3(sh::div_up(nvec, 256)), dim3(256), 0, st, (const float4*)in_f32->ptr, nvec, scale, (short8v*)out_i16->ptr, sh::state().flag, 1);
+        if (n > done) hipLaunchKernelGGL(k_quantize<short>, dim3(sh::div_up(n - done, 256)), dim3(256), 0, st,
+                                         (const float*)in_f32->ptr + done, n - done, scale, -32768.0, 32767.0, (short*)out_i16->ptr + done, sh::state().flag, 1);
+    }
     SH_CHECK_LAUNCH("k_quantize(clip)");
     return SH_OK;
 }
@@ -364,7 +412,7 @@ int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint
     if (stride < nsamples || chunks->bytes / 2 < (size_t)(nvoices - 1) * stride + nsamples)
         return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: chunk buffer too small");
     if (out->bytes / 2 < nsamples) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: output too small");
-    dim3 grid(sh::div_up(nsamples, 256));
+    dim3 grid(sh::div_up(nsamples, 512));
     hipStream_t st = sh::state().stream;
     if (nvoices >= 64) hipLaunchKernelGGL(k_mix_chain_i16<8>, grid, dim3(8 * 64), 0, st, (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
     else hipLaunchKernelGGL(k_mix_chain_i16<2>, grid, dim3(2 * 64), 0, st, (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);

@@ -60,27 +60,37 @@ __global__ __launch_bounds__(256) void k_reverse(const T* __restrict__ in, T* __
     out[i] = in[n - 1 - i];
 }
 
-// stereo -> mono: fbound(l*lfactor + r*rfactor)  (audioop.tomono)
-template <typename T>
-__global__ __launch_bounds__(256) void k_tomono(const T* __restrict__ in, T* __restrict__ out, size_t nframes, double lf, double rf) {
-    typedef T vec2 __attribute__((ext_vector_type(2)));
+// stereo -> mono: fbound(l*lfactor + r*rfactor)  (audioop.tomono); F frames per thread (16-byte loads)
+template <typename T, int F>
+__global__ __launch_bounds__(256) void k_tomono(const T* __restrict__ in, T* __restrict__ out, size_t nunits, double lf, double rf) {
+    typedef T vin __attribute__((ext_vector_type(2 * F)));
+    typedef T vout __attribute__((ext_vector_type(F)));
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nframes) return;
-    const vec2 v = reinterpret_cast<const vec2*>(in)[i];
-    out[i] = (T)fbound((double)v.x * lf + (double)v.y * rf, Lim<T>::lo, Lim<T>::hi);
+    if (i >= nunits) return;
+    const vin v = reinterpret_cast<const vin*>(in)[i];
+    vout r;
+#pragma unroll
+    for (int f = 0; f < F; ++f) r[f] = (T)fbound((double)v[2 * f] * lf + (double)v[2 * f + 1] * rf, Lim<T>::lo, Lim<T>::hi);
+    if (F == 1) out[i] = r[0]; else reinterpret_cast<vout*>(out)[i] = r;
 }
 
 // mono -> stereo: (fbound(v*lfactor), fbound(v*rfactor))   (audioop.tostereo)
-template <typename T>
-__global__ __launch_bounds__(256) void k_tostereo(const T* __restrict__ in, T* __restrict__ out, size_t nframes, double lf, double rf) {
-    typedef T vec2 __attribute__((ext_vector_type(2)));
+template <typename T, int F>
+__global__ __launch_bounds__(256) void k_tostereo(const T* __restrict__ in, T* __restrict__ out, size_t nunits, double lf, double rf) {
+    typedef T vin __attribute__((ext_vector_type(F)));
+    typedef T vout __attribute__((ext_vector_type(2 * F)));
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nframes) return;
-    const double v = (double)in[i];
-    vec2 r;
-    r.x = (T)fbound(v * lf, Lim<T>::lo, Lim<T>::hi);
-    r.y = (T)fbound(v * rf, Lim<T>::lo, Lim<T>::hi);
-    reinterpret_cast<vec2*>(out)[i] = r;
+    if (i >= nunits) return;
+    vin v;
+    if (F == 1) v[0] = in[i]; else v = reinterpret_cast<const vin*>(in)[i];
+    vout r;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const double x = (double)v[f];
+        r[2 * f] = (T)fbound(x * lf, Lim<T>::lo, Lim<T>::hi);
+        r[2 * f + 1] = (T)fbound(x * rf, Lim<T>::lo, Lim<T>::hi);
+    }
+    reinterpret_cast<vout*>(out)[i] = r;
 }
 
 // width conversion through the 32-bit form (GETSAMPLE32 / SETSAMPLE32)   (audioop.lin2lin)
@@ -113,7 +123,20 @@ __global__ __launch_bounds__(256) void k_absmax_sumsq(const T* __restrict__ in, 
     __shared__ unsigned s_max[4];
     unsigned mx = 0;
     unsigned long long sq = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    constexpr int V = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const size_t nvec = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) ? n / V : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const vec_t x = reinterpret_cast<const vec_t*>(in)[i];
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+            const long long v = (long long)x[c];
+            const unsigned a = (unsigned)(v < 0 ? -v : v);
+            mx = a > mx ? a : mx;
+            sq += (unsigned long long)(v * v);
+        }
+    }
+    for (size_t i = nvec * V + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const long long v = (long long)in[i];
         const unsigned a = (unsigned)(v < 0 ? -v : v);
         mx = a > mx ? a : mx;
@@ -250,7 +273,11 @@ int sh_pcm_tomono(const sh_buf* in, size_t nframes, int width, double lfactor, d
     hipStream_t st = sh::state().stream;
     return dispatch_width(width, [&](auto tag) {
         typedef decltype(tag) T;
-        hipLaunchKernelGGL(k_tomono<T>, dim3(sh::div_up(nframes, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, nframes, lfactor, rfactor);
+        constexpr int F = 8 / sizeof(T);                       // frames per 16-byte load
+        const size_t nvec = nframes / F, done = nvec * F;
+        if (nvec) hipLaunchKernelGGL((k_tomono<T, F>), dim3(sh::div_up(nvec, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, nvec, lfactor, rfactor);
+        if (nframes > done) hipLaunchKernelGGL((k_tomono<T, 1>), dim3(sh::div_up(nframes - done, 256)), dim3(256), 0, st,
+                                               (const T*)in->ptr + 2 * done, (T*)out->ptr + done, nframes - done, lfactor, rfactor);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_tomono");
     });
@@ -264,7 +291,11 @@ int sh_pcm_tostereo(const sh_buf* in, size_t nframes, int width, double lfactor,
     hipStream_t st = sh::state().stream;
     return dispatch_width(width, [&](auto tag) {
         typedef decltype(tag) T;
-        hipLaunchKernelGGL(k_tostereo<T>, dim3(sh::div_up(nframes, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, nframes, lfactor, rfactor);
+        constexpr int F = 8 / sizeof(T);                       // frames per 16-byte store
+        const size_t nvec = nframes / F, done = nvec * F;
+        if (nvec) hipLaunchKernelGGL((k_tostereo<T, F>), dim3(sh::div_up(nvec, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, nvec, lfactor, rfactor);
+        if (nframes > done) hipLaunchKernelGGL((k_tostereo<T, 1>), dim3(sh::div_up(nframes - done, 256)), dim3(256), 0, st,
+                                               (const T*)in->ptr + done, (T*)out->ptr + 2 * done, nframes - done, lfactor, rfactor);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_tostereo");
     });
@@ -301,7 +332,7 @@ int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, 
     if (sum_squares) *sum_squares = 0.0;
     if (!nbytes) return SH_OK;
     const size_t n = nbytes / width;
-    const unsigned blocks = n / 256 < 2048 ? (unsigned)(n / 256 + 1) : 2048u;
+    const unsigned blocks = n / 2048 < 4096 ? (unsigned)(n / 2048 + 1) : 4096u;
     int rc = sh::ensure_scratch(16 + (size_t)blocks * 8);
     if (rc) return rc;
     hipStream_t st = sh::state().stream;
