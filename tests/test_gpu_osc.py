@@ -296,3 +296,31 @@ def test_filters(gpu):
     from synthesizer_amd.mixer import VoiceBank
     with pytest.raises(NotImplementedError):
         VoiceBank([g["mix"]])
+
+
+def test_wavesynth_facade(gpu):
+    """WaveSynth methods = oscillator + Sample.from_osc_block, bit-exact int16."""
+    from synthesizer_amd.synth import WaveSynth
+    ws = WaveSynth(samplerate=22050, samplewidth=2)
+    dur = 0.25
+    n = int(22050 * dur)
+    cases = {
+        "sine": (ws.sine(440, dur), O.Sine(440, 0.9999, samplerate=22050)),
+        "square": (ws.square(440, dur, amplitude=0.5), O.Square(440, 0.5, samplerate=22050)),
+        "triangle": (ws.triangle(220, dur), O.Triangle(220, 0.9999, samplerate=22050)),
+        "sawtooth": (ws.sawtooth(330, dur, phase=0.2), O.Sawtooth(330, 0.75, phase=0.2, samplerate=22050)),
+        "pulse": (ws.pulse(110, dur, pulsewidth=0.3), O.Pulse(110, 0.75, pulsewidth=0.3, samplerate=22050)),
+        "square_h": (ws.square_h(220, dur, 5, amplitude=0.5), O.SquareH(220, 5, 0.5, samplerate=22050)),
+        "sawtooth_h": (ws.sawtooth_h(220, dur, 6, amplitude=0.3), O.SawtoothH(220, 6, 0.3, samplerate=22050)),
+        "harmonics": (ws.harmonics(220, dur, [(1, 1.0), (2, 0.5)], amplitude=0.4), O.Harmonics(220, [(1, 1.0), (2, 0.5)], 0.4, samplerate=22050)),
+        "fm": (ws.sine(440, dur, fm_lfo=ws.sine_gen(5, 0.05)), O.Sine(440, 0.9999, fm_lfo=O.Sine(5, 0.05, samplerate=22050), samplerate=22050)),
+    }
+    for name, (sample, osc) in cases.items():
+        assert sample.samplerate == 22050 and sample.nchannels == 1 and sample.samplewidth == 2 and len(sample) == n, name
+        got = np.array(sample.get_frame_array())
+        want = np.array(O.quantise(osc.take(n)))
+        # the float32 block differs from the float64 oracle by <= 1e-7, so a sample sitting within that of an
+        # integer boundary may land one step away; everything else is identical
+        assert np.max(np.abs(got - want)) <= 1, name
+        assert np.mean(got != want) < 0.02, name
+    assert WaveSynth(samplewidth=4).sine(100, 0.01).samplewidth == 4

@@ -144,3 +144,12 @@ def test_sample_bookkeeping_without_gpu():
     Sample.from_raw_frames(raw.tobytes(), 2, 8000, 2).write_wav(buf)
     buf.seek(0)
     assert Sample(buf) == Sample.from_raw_frames(raw.tobytes(), 2, 8000, 2)
+
+
+def test_note_tables():
+    from synthesizer_amd import synth as S
+    assert S.key_num("A", 4) == 49 and S.key_freq(49) == 440.0 and S.note_freq("A4") == 440.0
+    assert abs(S.note_freq("C4") - 261.6256) < 1e-3 and abs(S.note_freq("C#", 3) - 138.5913) < 1e-3
+    assert S.major_chord_keys("C", 4) == (40, 44, 47) and S.major_chord_keys("G", 4) == (47, 51, 54)
+    with pytest.raises(ValueError):
+        S.WaveSynth(samplewidth=3)
