@@ -60,6 +60,20 @@ def cpu_baseline(frames: int):
                       "%.1f s wall" % (frames, frames / SR, dt)}
 
 
+def measured_traffic():
+    """HBM bytes per dispatch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, profiles/rNN_traffic.json written by tools/summarize_profiles.py); None when absent."""
+    best = None
+    for p in sorted((ROOT / "profiles").glob("r*_traffic.json")):
+        best = p
+    if best is None:
+        return {}, None
+    try:
+        return json.loads(best.read_text()), best.name
+    except Exception:
+        return {}, None
+
+
 def pcm_rows(N):
     """HBM-bound rows of the path, each timed with HIP events on resident buffers."""
     import ctypes
@@ -191,6 +205,14 @@ def main() -> int:
         td.all_reduce(t, op=td.ReduceOp.MAX)
         wall, ev_ms = float(t[0]), float(t[1])
 
+    traffic, traffic_src = measured_traffic()
+
+    def traffic_of(prefix):
+        for k, v in traffic.items():
+            if k.startswith(prefix):
+                return v["hbm_bytes"]
+        return None
+
     voice_samples = float(total_voices) * F * K
     value = voice_samples / wall / 1e6
     kern_s = ev_ms / 1e3 / K         # average duration of one block (k_locate + k_bank_render [+ reduce/finalize])
@@ -214,7 +236,8 @@ def main() -> int:
         "roofline": {
             "kernel": "k_bank_render<8,2,6>", "bound": "hbm",
             "achieved": fused_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": fused_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": fused_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("k_bank_render"),
+            "traffic_source": traffic_src,
             "note": "fused kernel writes 8 B per output frame: VALU(float64)-bound by construction, see valu",
             "valu": {"unit": "G f64 lane-ops/s", "achieved": VOICES_PER_GPU * F * harm_lane_ops / kern_s / 1e9,
                      "peak": FP64_PEAK_GOPS, "frac": VOICES_PER_GPU * F * harm_lane_ops / kern_s / 1e9 / FP64_PEAK_GOPS,
@@ -249,10 +272,12 @@ def main() -> int:
             "value": nv * F2 / ((gen_ms + mix_ms) / 1e3) / 1e6, "unit": "Msamples/s",
             "roofline_mix": {"kernel": "k_mix_bus_f32<8>", "bound": "hbm", "achieved": mix_bytes / (mix_ms / 1e3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mix_bytes / (mix_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": None, "avg_launch_ms": mix_ms, "bytes_per_frame": 4 * nv + 8},
+                             "traffic": traffic_of("k_mix_bus_f32"), "avg_launch_ms": mix_ms, "bytes_per_frame": 4 * nv + 8,
+                             "algorithmic_bytes": mix_bytes},
             "roofline_generate": {"kernel": "k_generate", "bound": "hbm", "achieved": gen_bytes / (gen_ms / 1e3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gen_bytes / (gen_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": None, "avg_launch_ms": gen_ms, "bytes_per_voice_sample": 4},
+                                  "traffic": traffic_of("k_generate"), "avg_launch_ms": gen_ms, "bytes_per_voice_sample": 4,
+                                  "algorithmic_bytes": gen_bytes},
         }
         vbuf.free()
         bus.free()

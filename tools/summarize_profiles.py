@@ -73,6 +73,19 @@ for fname, title in (("sq1_counter_collection.csv", "SQ instruction mix"), ("sq2
             lines.append("| %s | %.0f |" % (cn, sum(v) / len(v)))
         lines.append("")
 (out / ("%s_summary.md" % tag)).write_text("\n".join(lines) + "\n")
+# machine-readable traffic per dispatch (bytes), read by bench.py for roofline.traffic
+import json
+traffic = {}
+for k in sorted(set(f) | set(w)):
+    if not k.startswith("k_"):
+        continue
+    fv = f[k].get("FETCH_SIZE", [0])
+    wv = w[k].get("WRITE_SIZE", [0])
+    fa, wa = sum(fv) / len(fv), sum(wv) / len(wv)
+    traffic[k] = {"fetch_size_kib_raw": fa, "write_size_kib": wa,
+                  "read_bytes_corrected_x2": fa * 1024 * 2, "write_bytes": wa * 1024,
+                  "hbm_bytes": fa * 1024 * 2 + wa * 1024}
+(out / ("%s_traffic.json" % tag)).write_text(json.dumps(traffic, indent=1) + "\n")
 bench = src.parent / ("%s_bench.json" % src.name)
 if bench.exists():
     last = [l for l in bench.read_text().splitlines() if l.startswith("{")]
