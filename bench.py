@@ -153,6 +153,7 @@ def main() -> int:
     ap.add_argument("--cpu-frames", type=int, default=12288, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-pcm-rows", action="store_true", help="skip the resample / integer-mix rows")
     ap.add_argument("--no-two-step", action="store_true")
+    ap.add_argument("--reduce-batch", type=int, default=4, help="blocks per RCCL reduce when --gpus > 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,7 +180,7 @@ def main() -> int:
     total_voices = VOICES_PER_GPU * world
     seconds_total = (K + Wm) * F / SR
     voices, gains = build_voices(total_voices, seconds_total)
-    bank = dist.DistVoiceBank(voices, gains, rank, world)
+    bank = dist.DistVoiceBank(voices, gains, rank, world, batch=args.reduce_batch)
     L = N.lib()
 
     def barrier():
@@ -190,11 +191,13 @@ def main() -> int:
     # ---- fused path (headline) ----
     for s in range(Wm):
         bank.render_device(F, s * F)
+    bank.flush()
     barrier()
     t0 = time.perf_counter()
     N.timer_start()
     for s in range(K):
         bank.render_device(F, (Wm + s) * F)
+    bank.flush()
     host_enqueue = time.perf_counter() - t0      # host time to enqueue all K steps (launches are asynchronous)
     ev_ms = N.timer_stop()           # HIP events on the library stream (also synchronises it)
     barrier()
@@ -228,7 +231,7 @@ def main() -> int:
         "config": {"workload": "%d-voice additive (Harmonics x%d partials + ADSR) -> float32 stereo bus, 48 kHz, "
                                "fused generate-and-mix, block %d frames" % (total_voices, PARTIALS, F),
                    "voices_per_gpu": VOICES_PER_GPU, "frames_per_step": F, "samplerate": SR,
-                   "parallelism": "voice-shard x%d, RCCL reduce of float64 partial buses" % world if world > 1 else "single GPU"},
+                   "parallelism": ("voice-shard x%d, pipelined RCCL reduce of float64 partial buses every %d blocks" % (world, bank.batch)) if world > 1 else "single GPU"},
         "frames_per_s": F * K / wall,
         "host_enqueue_ms_per_step": host_enqueue * 1e3 / K,
         "realtime_factor": F * K / wall / SR,

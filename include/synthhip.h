@@ -140,6 +140,8 @@ int  sh_sync(void);                       /* wait for the stream */
 /* ---- device buffers ---------------------------------------------------------------- */
 int    sh_buf_alloc(size_t bytes, sh_buf** out);
 int    sh_buf_free(sh_buf* b);
+/* a non-owning window [offset, offset+bytes) of `parent` (must be freed before the parent) */
+int    sh_buf_view(sh_buf* parent, size_t offset, size_t bytes, sh_buf** out);
 size_t sh_buf_size(const sh_buf* b);
 void*  sh_buf_devptr(sh_buf* b);
 int    sh_buf_upload(sh_buf* b, size_t offset, const void* host, size_t bytes);

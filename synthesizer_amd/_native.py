@@ -74,6 +74,7 @@ _SIGNATURES = {
     "sh_sync": (C.c_int, []),
     "sh_buf_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
     "sh_buf_free": (C.c_int, [_P]),
+    "sh_buf_view": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
     "sh_buf_size": (C.c_size_t, [_P]),
     "sh_buf_devptr": (_P, [_P]),
     "sh_buf_upload": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),
@@ -203,6 +204,15 @@ class DeviceBuffer:
     @property
     def handle(self):
         return self._h
+
+    def view(self, offset: int, nbytes: int) -> "DeviceBuffer":
+        """A non-owning window of this buffer (keeps the parent alive)."""
+        v = DeviceBuffer.__new__(DeviceBuffer)
+        v._h = _P()
+        v.nbytes = int(nbytes)
+        v._parent = self
+        check(lib().sh_buf_view(self._h, offset, nbytes, C.byref(v._h)))
+        return v
 
     @classmethod
     def from_array(cls, arr: np.ndarray) -> "DeviceBuffer":

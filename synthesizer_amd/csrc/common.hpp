@@ -9,6 +9,7 @@
 struct sh_buf {
     void*  ptr;
     size_t bytes;
+    bool   owner;      // false for views created by sh_buf_view (they alias a parent allocation)
 };
 
 namespace sh {

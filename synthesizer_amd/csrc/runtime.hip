@@ -141,6 +141,7 @@ int sh_buf_alloc(size_t bytes, sh_buf** out) {
     if (!b) return sh::set_error(SH_ERR_NOMEM, "host allocation failed");
     b->ptr = nullptr;
     b->bytes = bytes;
+    b->owner = true;
     if (bytes) {
         hipError_t e = hipMalloc(&b->ptr, bytes);
         if (e != hipSuccess) {
@@ -152,8 +153,25 @@ int sh_buf_alloc(size_t bytes, sh_buf** out) {
     return SH_OK;
 }
 
+int sh_buf_view(sh_buf* parent, size_t offset, size_t bytes, sh_buf** out) {
+    SH_REQUIRE_INIT();
+    if (!parent || !out) return sh::set_error(SH_ERR_INVALID, "sh_buf_view: NULL argument");
+    if (offset > parent->bytes || bytes > parent->bytes - offset) return sh::set_error(SH_ERR_INVALID, "sh_buf_view: range outside the parent buffer");
+    sh_buf* b = new (std::nothrow) sh_buf;
+    if (!b) return sh::set_error(SH_ERR_NOMEM, "host allocation failed");
+    b->ptr = (char*)parent->ptr + offset;
+    b->bytes = bytes;
+    b->owner = false;
+    *out = b;
+    return SH_OK;
+}
+
 int sh_buf_free(sh_buf* b) {
     if (!b) return SH_OK;
+    if (!b->owner) {
+        delete b;
+        return SH_OK;
+    }
     if (b->ptr && state().initialized) {
         hipStreamSynchronize(state().stream);
         hipFree(b->ptr);

@@ -130,49 +130,75 @@ def shutdown() -> None:
 
 
 class DistVoiceBank:
-    """This rank's shard of a voice table + the reduce of the partial buses."""
+    """This rank's shard of a voice table + the reduce of the partial buses.
 
-    def __init__(self, voices: Sequence, gains: Sequence[Tuple[float, float]], rank: int, world: int) -> None:
+    With several ranks the exchange is pipelined and batched: blocks are rendered into a ring of slots, each
+    slot holding ``batch`` consecutive blocks; when a slot is full one ``ncclReduce`` (and, on root, the
+    rounding to float32) is enqueued for it on the communication stream, overlapping the render of the
+    following blocks.  ``flush()`` sends a partly filled slot; ``_native.sync()`` waits for everything."""
+
+    def __init__(self, voices: Sequence, gains: Sequence[Tuple[float, float]], rank: int, world: int, batch: int = 1) -> None:
         from .mixer import VoiceBank
         self.rank, self.world = rank, world
+        self.batch = max(1, int(batch)) if world > 1 else 1
         self.total_voices = len(voices)
         lo, hi = shard_range(len(voices), rank, world)
         self.lo, self.hi = lo, hi
         if hi <= lo:
             raise ValueError("rank %d owns no voices (%d voices over %d ranks)" % (rank, len(voices), world))
         self.local = VoiceBank(list(voices[lo:hi]), gains=list(gains[lo:hi]))
-        self._bus64 = []          # one (float64 partial, float32 result) buffer pair per pipeline slot
-        self._bus32 = []
+        self._bus64 = []          # per slot: float64 partial buses of `batch` blocks
+        self._bus32 = []          # per slot: float32 results (meaningful on root)
+        self._views = []          # per slot, per block: (float64 view, float32 view)
         self._cap = 0
         self._slot = 0
+        self._fill = 0            # blocks rendered into the current slot
+        self._root = 0
 
     def _buffers(self, nframes: int) -> None:
-        if nframes > self._cap:
+        if nframes != self._cap:
+            self.flush()
             N.sync()
             nslots = N.lib().sh_dist_slots() if self.world > 1 else 1
-            self._bus64 = [N.DeviceBuffer(nframes * 16) for _ in range(nslots)]
-            self._bus32 = [N.DeviceBuffer(nframes * 8) for _ in range(nslots)]
+            self._bus64 = [N.DeviceBuffer(self.batch * nframes * 16) for _ in range(nslots)]
+            self._bus32 = [N.DeviceBuffer(self.batch * nframes * 8) for _ in range(nslots)]
+            self._views = [[(b64.view(j * nframes * 16, nframes * 16), b32.view(j * nframes * 8, nframes * 8))
+                            for j in range(self.batch)] for b64, b32 in zip(self._bus64, self._bus32)]
             self._cap = nframes
             self._slot = 0
+            self._fill = 0
+
+    def flush(self) -> None:
+        """Enqueue the reduce of the current, partly filled slot."""
+        if self.world > 1 and self._fill:
+            k = self._slot
+            n = self._fill * self._cap * 2
+            N.check(N.lib().sh_dist_reduce_bus_async(self._bus64[k].handle, n, self._root, self._bus32[k].handle, k))
+            self._slot = (k + 1) % len(self._bus64)
+            self._fill = 0
 
     def render_device(self, nframes: int, start: int = 0, root: int = 0) -> N.DeviceBuffer:
-        """Render the shard and reduce to ``root``; returns the float32 bus buffer (meaningful on root, after
-        ``_native.sync()``).  With several ranks the reduce of this block is enqueued on the communication
-        stream and overlaps the render of the following blocks (a ring of pipeline slots)."""
+        """Render the shard's block; returns the float32 bus buffer of this block (meaningful on root once the
+        slot's reduce has run: after ``flush()`` + ``_native.sync()``)."""
         self._buffers(nframes)
-        L = N.lib()
         if self.world == 1:                      # nothing to exchange: the kernel rounds to float32 itself
             self.local.render_device(nframes, start, bus_f32=self._bus32[0])
             return self._bus32[0]
-        k = self._slot
-        self._slot = (k + 1) % len(self._bus64)
-        N.check(L.sh_dist_wait_slot(k))          # the reduce that last used this slot must have finished
-        self.local.render_device(nframes, start, bus_f32=None, bus_f64=self._bus64[k])
-        N.check(L.sh_dist_reduce_bus_async(self._bus64[k].handle, nframes * 2, root, self._bus32[k].handle, k))
-        return self._bus32[k]
+        L = N.lib()
+        self._root = root
+        k, j = self._slot, self._fill
+        if j == 0:
+            N.check(L.sh_dist_wait_slot(k))      # the reduce that last used this slot must have finished
+        v64, v32 = self._views[k][j]
+        self.local.render_device(nframes, start, bus_f32=None, bus_f64=v64)
+        self._fill += 1
+        if self._fill == self.batch:
+            self.flush()
+        return v32
 
     def render(self, nframes: int, start: int = 0, root: int = 0) -> Optional[np.ndarray]:
         buf = self.render_device(nframes, start, root)
+        self.flush()
         N.sync()
         if self.rank != root and self.world > 1:
             return None

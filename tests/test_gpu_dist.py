@@ -50,6 +50,14 @@ def test_single_rank_rccl_reduce(gpu):
             assert np.array_equal(got_j, bank.local.render(n, j * n)), j
         with pytest.raises(ValueError):
             N.check(L.sh_dist_reduce_bus_async(b64[0].handle, n * 2, 0, b32[0].handle, nslots))
+        # DistVoiceBank's batched ring, forced through the multi-rank code path on this 1-rank communicator
+        ring = dist.DistVoiceBank(voices, gains, 0, 1, batch=3)
+        ring.world, ring.batch = 2, 3          # pretend there are peers: same calls, the reduce is the identity
+        got_blocks = [ring.render_device(1000, s * 1000) for s in range(3 * nslots + 2)]    # wraps the ring, ends mid-slot
+        ring.flush()
+        N.sync()
+        for s in (3 * nslots + 1, 3 * nslots, 3 * nslots - 1, 2 * 3):           # blocks whose slots have not been reused
+            assert np.array_equal(got_blocks[s].download(np.float32, 2000).reshape(1000, 2), bank.local.render(1000, s * 1000)), s
     finally:
         dist.shutdown()
     assert L.sh_dist_world() == 0
