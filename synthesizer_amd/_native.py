@@ -130,6 +130,14 @@ def lib() -> C.CDLL:
     """Load libsynthhip.so (CDLL: the GIL is released around every call)."""
     global _lib
     if _lib is None:
+        if not LIB_PATH.exists() and "SYNTHHIP_LIB" not in os.environ:
+            try:                                    # in-tree build (hipcc cross-compiles gfx950 in seconds)
+                from . import build as _build
+                _build.build(verbose=False)
+            except Exception as exc:
+                raise NativeLibraryMissing(
+                    "%s not found and building it failed (%s): run `python -m synthesizer_amd.build` "
+                    "(hipcc, gfx950).  There is no CPU fallback." % (LIB_PATH, exc))
         if not LIB_PATH.exists():
             raise NativeLibraryMissing(
                 "%s not found: build it with `python -m synthesizer_amd.build` (hipcc, gfx950). "

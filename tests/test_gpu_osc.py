@@ -324,3 +324,52 @@ def test_wavesynth_facade(gpu):
         assert np.max(np.abs(got - want)) <= 1, name
         assert np.mean(got != want) < 0.02, name
     assert WaveSynth(samplewidth=4).sine(100, 0.01).samplewidth == 4
+
+
+def test_randomised_voices_vs_c_oracle(gpu):
+    """Seeded sweep over kinds x FM x envelope x parameters, 30 000 samples each, against the C oracle."""
+    from oracle import c_oracle as CO
+    from synthesizer_amd import oscillators as G
+    rng = np.random.default_rng(777)
+    kinds = ["Sine", "Sawtooth", "Square", "Pulse", "Harmonics"]
+    n = 30000
+    worst = 0.0
+    for case in range(60):
+        kind = kinds[case % 5]
+        sr = int(rng.choice([22050, 44100, 48000, 96000]))
+        f = float(np.exp(rng.uniform(np.log(20), np.log(0.45 * sr))))
+        kw = dict(amplitude=float(rng.uniform(0.05, 1.0)), phase=float(rng.uniform(-1, 1)), bias=float(rng.uniform(-0.3, 0.3)), samplerate=sr)
+        args = [f]
+        if kind == "Pulse":
+            kw["pulsewidth"] = float(rng.uniform(0.02, 0.98))
+        if kind == "Harmonics":
+            nh = int(rng.integers(1, 25))
+            args.append([(int(k), float(rng.uniform(-1, 1))) for k in rng.choice(np.arange(1, 40), size=nh, replace=False)])
+        fm = case % 3 == 1
+        lfo_args = (float(rng.uniform(0.1, 30)), float(rng.uniform(0, 0.2)), float(rng.uniform(0, 1)), float(rng.uniform(-0.05, 0.05)))
+
+        def make(M):
+            lfo = M.Sine(lfo_args[0], lfo_args[1], phase=lfo_args[2], bias=lfo_args[3], samplerate=sr) if fm else None
+            osc = getattr(M, kind)(*args, fm_lfo=lfo, **kw)
+            if case % 4 == 2:
+                a, d, s, sl, r = (float(x) for x in rng2.uniform(0, 0.1, 5))
+                osc = M.EnvelopeFilter(osc, a, d, s, min(sl * 10, 1.0), r)
+            return osc
+
+        rng2 = np.random.default_rng(case)
+        g = make(G)
+        rng2 = np.random.default_rng(case)
+        o = make(O)
+        got = g.render(n)
+        want = CO.render(o, n)
+        if kind in ("Square", "Pulse"):
+            flips = int(np.sum(got != want.astype(np.float32)))
+            assert flips <= (2 if fm else 0), (case, kind, flips)
+        elif kind == "Sawtooth" and fm:
+            ok = np.abs(np.abs(want - kw["bias"]) - kw["amplitude"]) > 1e-3 * kw["amplitude"]      # away from the wrap
+            assert rms(got[ok], want[ok]) <= RMS_TOL, case
+        else:
+            e = rms(got, want)
+            worst = max(worst, e)
+            assert e <= RMS_TOL, (case, kind, e)
+    assert worst < 1e-7

@@ -69,3 +69,27 @@ def test_first_index_ge():
 def test_constant_sequences():
     assert build_phase_table(1.5, 0.0) == [(0, 1.5, 0.0)]
     assert build_phase_table(1.0, 1e-30)[-1][2] == 0.0
+
+
+def test_property_random_sequences():
+    """Randomised check (seeded): any (t0, inc) -- negative, tiny, huge, zero-crossing -- is reproduced."""
+    rng = random.Random(20260926)
+    for case in range(120):
+        kind = case % 6
+        if kind == 0:
+            t0, inc = rng.uniform(-10, 10), rng.uniform(-1, 1)
+        elif kind == 1:
+            t0, inc = rng.uniform(-1e-3, 1e-3), rng.uniform(1e-6, 1e-2)
+        elif kind == 2:
+            t0, inc = rng.uniform(1e5, 1e7), rng.uniform(0.01, 3.0)
+        elif kind == 3:
+            t0, inc = -rng.uniform(1, 50), rng.uniform(0.001, 0.5)          # crosses zero
+        elif kind == 4:
+            t0, inc = float(rng.randrange(-5, 6)) * 0.25, 1.0 / rng.choice([3, 7, 48, 147, 441, 48000])
+        else:
+            t0, inc = rng.uniform(0, 1) * 2 * math.pi, 2 * math.pi * rng.uniform(20, 20000) / rng.choice([44100, 48000, 96000])
+        n = 6000
+        ref = brute(t0, inc, n)
+        pt = PhaseTable(t0, inc)
+        for i in [0, 1, 2, 3, 5, 17, 100, 1023, 1024, 4095, n - 1] + [rng.randrange(n) for _ in range(40)]:
+            assert pt.value(i) == ref[i], (t0, inc, i)
