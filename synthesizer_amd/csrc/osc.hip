@@ -31,6 +31,7 @@ struct BankPtrs {
     const sh_segment* segs;
     const double*     coefs;
     const sh_partial* partials;
+    uint32_t*         hint;       // per voice: table piece of the last prepared launch (streaming: same or next piece)
 };
 
 // Pointers to data that no thread of the running kernel writes are cast to the constant address space:
@@ -76,10 +77,12 @@ struct alignas(16) VoiceLaunch {
     double   g0[4], slope[4];     // gain(i) = fma(i, slope[p], g0[p]) on piece p; 0 after release
     double   tail_amp;
     double   pulsewidth;
-    double   t_base2, dt2;        // the NEXT table piece: frames i in [remain, end2) have t = fma(i - remain, dt2, t_base2)
-    uint32_t end2, pad1, pad2, pad3;
+    // the NEXT four table pieces: frames i in [nx_start(k), nx_end[k]) have t = fma(i - nx_start(k), nx_dt[k], nx_t0[k]),
+    // nx_start(0) = remain, nx_start(k) = nx_end[k-1]; unused entries have nx_end = 0
+    uint32_t nx_end[4];
+    double   nx_t0[4], nx_dt[4];
 };
-static_assert(sizeof(VoiceLaunch) == 368, "VoiceLaunch layout");
+static_assert(sizeof(VoiceLaunch) == 416, "VoiceLaunch layout");
 
 struct alignas(16) VoiceFM {      // only read for FM voices
     double frequency, phase0, f_inc;      // theta = frequency*T + fma(f_inc, L, phase0)
@@ -97,11 +100,18 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     const uint32_t off = fm ? v.time_seg_offset : v.seg_offset;
     const uint32_t cnt = fm ? v.time_seg_count : v.seg_count;
     const sh_segment* tab = B.segs + off;
-    uint32_t lo = 0, hi = cnt - 1;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi + 1) >> 1;
-        if (tab[mid].n0 <= start) lo = mid; else hi = mid - 1;
+    uint32_t lo = B.hint[first + vi];
+    if (lo < cnt && tab[lo].n0 <= start && lo + 2 < cnt && start < tab[lo + 2].n0) {
+        if (start >= tab[lo + 1].n0) ++lo;                     // streaming: still on the piece, or on the next one
+    } else {
+        lo = 0;
+        uint32_t hi = cnt - 1;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (tab[mid].n0 <= start) lo = mid; else hi = mid - 1;
+        }
     }
+    B.hint[first + vi] = lo;
     const double dt = tab[lo].dt;
     const double t_base = fma((double)(start - tab[lo].n0), dt, tab[lo].t0);
     const uint64_t rem = (lo + 1 < cnt) ? (tab[lo + 1].n0 - start) : 0xFFFFFFFFull;
@@ -109,16 +119,21 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     o->dt = dt;
     o->remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
     o->seg = lo;
-    o->pad0 = 0; o->pad1 = 0; o->pad2 = 0; o->pad3 = 0;
-    if (lo + 1 < cnt && rem <= 0xFFFFFFFFull) {
-        o->t_base2 = tab[lo + 1].t0;
-        o->dt2 = tab[lo + 1].dt;
-        const uint64_t e2 = (lo + 2 < cnt) ? (tab[lo + 2].n0 - start) : 0xFFFFFFFFull;
-        o->end2 = e2 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e2;
-    } else {
-        o->t_base2 = t_base;
-        o->dt2 = dt;
-        o->end2 = 0;
+    o->pad0 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t pi = lo + 1 + k;                       // table piece that follows
+        uint32_t end = 0;
+        double t0 = t_base, d0 = dt;
+        if (pi < cnt && tab[pi].n0 - start <= 0xFFFFFFFFull) {
+            t0 = tab[pi].t0;
+            d0 = tab[pi].dt;
+            const uint64_t e = (pi + 1 < cnt) ? (tab[pi + 1].n0 - start) : 0xFFFFFFFFull;
+            end = e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
+        }
+        o->nx_end[k] = end;
+        o->nx_t0[k] = t0;
+        o->nx_dt[k] = d0;
     }
     uint32_t flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
                      (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u) | (v.flip ? FL_FLIP : 0u);
@@ -271,11 +286,15 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
         // (scalar binary search), then per lane only for the lanes past that piece's end.
         const VoiceLaunch SH_CONST_AS* q = r.rec;
         const uint32_t tile_first = tile_last & ~(uint32_t)(64 * FPL - 1);
-        const uint32_t end2 = q->end2;
-        if (tile_first >= r.remain && tile_last < end2) {
-            const double tb2 = q->t_base2, dt2 = q->dt2, off = (double)r.remain;
+        const uint32_t e0 = q->nx_end[0], e1 = q->nx_end[1], e2 = q->nx_end[2], e3 = q->nx_end[3];
+        // k = index of the following piece that holds the tile's first frame (uniform)
+        const uint32_t k = (tile_first >= e0) + (tile_first >= e1) + (tile_first >= e2) + (tile_first >= e3);
+        const uint32_t k_end = k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : k == 3 ? e3 : 0u;
+        const uint32_t k_start = k == 0 ? r.remain : k == 1 ? e0 : k == 2 ? e1 : e2;
+        if (tile_first >= r.remain && k < 4 && tile_last < k_end) {
+            const double tb = q->nx_t0[k & 3], dk = q->nx_dt[k & 3], off = (double)k_start;
 #pragma unroll
-            for (int j = 0; j < FPL; ++j) th[j] = fma(di[j] - off, dt2, tb2);
+            for (int j = 0; j < FPL; ++j) th[j] = fma(di[j] - off, dk, tb);
         } else {
             const bool fm = (r.flags & FL_FM) != 0;
             const sh_segment SH_CONST_AS* tab = as_const(B.segs) + (fm ? vfull->time_seg_offset : vfull->seg_offset);
@@ -461,7 +480,7 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
 // waves on 4 consecutive tiles; each wave walks the voices of its group (so the 8 KB sin/cos table in LDS
 // is filled once per block, not once per voice) and stores one coalesced row segment per voice.
 template <int FPL>
-__global__ __launch_bounds__(256) void k_generate(BankPtrs B, const shm::sc_pair* __restrict__ trig_g, uint32_t first,
+__global__ __launch_bounds__(256, 6) void k_generate(BankPtrs B, const shm::sc_pair* __restrict__ trig_g, uint32_t first,
                                                   uint32_t nvoices, uint32_t voices_per_group,
                                                   const VoiceLaunch* __restrict__ launch,
                                                   const VoiceFM* __restrict__ launch_fm,
@@ -818,6 +837,7 @@ struct sh_bank {
     // other for the block that is expected next (start + nframes)
     VoiceLaunch* d_launch_buf[2] = {nullptr, nullptr};
     VoiceFM*    d_launch_fm_buf[2] = {nullptr, nullptr};
+    uint32_t*   d_hint = nullptr;
     VoiceLaunch* d_launch = nullptr;       // the set the next kernel reads
     VoiceFM*    d_launch_fm = nullptr;
     int         cur = 0;
@@ -835,6 +855,7 @@ static BankPtrs ptrs(const sh_bank* b) {
     p.segs = b->d_segs;
     p.coefs = b->d_coefs;
     p.partials = b->d_partials;
+    p.hint = b->d_hint;
     return p;
 }
 
@@ -906,6 +927,8 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             e = hipMalloc((void**)&b->d_launch_buf[k], sizeof(VoiceLaunch) * nvoices);
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_launch_fm_buf[k], sizeof(VoiceFM) * nvoices);
         }
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_hint, sizeof(uint32_t) * nvoices);
+        if (e == hipSuccess) e = hipMemsetAsync(b->d_hint, 0, sizeof(uint32_t) * nvoices, st);
         if (e != hipSuccess) rc = sh::hip_error(e, "hipMalloc(launch records)");
         b->d_launch = b->d_launch_buf[0];
         b->d_launch_fm = b->d_launch_fm_buf[0];
@@ -935,6 +958,7 @@ int sh_bank_destroy(sh_bank* b) {
             if (b->d_launch_fm_buf[k]) hipFree(b->d_launch_fm_buf[k]);
         }
         if (b->d_gains) hipFree(b->d_gains);
+        if (b->d_hint) hipFree(b->d_hint);
     }
     delete b;
     return SH_OK;
