@@ -52,7 +52,7 @@ __device__ __forceinline__ const T SH_CONST_AS* as_const(const T* p) {
 // index i = n - start.  The scalar unit (one per CU) is the scarce resource of these kernels, so the
 // record is laid out to cost the hot path one batch of loads and almost no scalar arithmetic.
 constexpr uint32_t FL_KIND = 0x7, FL_FM_SHIFT = 4, FL_FM = 0x30, FL_DENSE = 0x40, FL_ENV_UNIFORM = 0x80,
-                   FL_POLY = 0x100, FL_FOLDED = 0x200, FL_FLIP = 0x400;
+                   FL_POLY = 0x100, FL_FOLDED = 0x200, FL_FLIP = 0x400, FL_SILENT = 0x800;
 constexpr uint32_t NO_TAIL = 0xFFFFFFFFu;
 
 struct alignas(16) VoiceLaunch {
@@ -189,7 +189,7 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         else if (eb1 > 0) { if (last < eb1) { flags |= FL_ENV_UNIFORM; g0u = g01; slu = s1; } }
         else if (eb2 > 0) { if (last < eb2) { flags |= FL_ENV_UNIFORM; g0u = g02; slu = s2; } }
         else if (eb3 > 0) { if (last < eb3) { flags |= FL_ENV_UNIFORM; g0u = g03; slu = s3; } }
-        else if (!tail_here) flags |= FL_ENV_UNIFORM;                  // silent for the whole launch
+        else if (!tail_here) flags |= FL_ENV_UNIFORM | FL_SILENT;      // released before this launch: silent throughout
     }
     o->g0u = g0u;
     o->slu = slu;
@@ -513,7 +513,12 @@ __global__ __launch_bounds__(256, 6) void k_generate(BankPtrs B, const shm::sc_p
     for (uint32_t vi = v0; vi < v1; ++vi, ++rp) {
         const VoiceRegs r = load_record(rp);
         double x[FPL];
-        voice_block<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, start, tile_last, i, di, fm_cumsum, pwm, trig, x);
+        if (r.flags & FL_SILENT) {
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = 0.0;
+        } else {
+            voice_block<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, start, tile_last, i, di, fm_cumsum, pwm, trig, x);
+        }
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
             uint32_t raw = tile0 + j * 64 + lane;
@@ -573,6 +578,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     const VoiceLaunch SH_CONST_AS* rp = as_const(launch) + v0 + wave;
     for (uint32_t vi = v0 + wave; vi < v1; vi += WAVES, rp += WAVES) {
         const VoiceRegs r = load_record(rp);
+        if (r.flags & FL_SILENT) continue;       // the note was released before this block: contributes exact zeros
         // touch the hot cache lines of this wave's NEXT record (one dword per 64-byte line, 4 lines) so that
         // its loads hit the scalar cache: gfx950 has no scalar prefetch instruction.  The values are only
         // kept alive until the end of the iteration.

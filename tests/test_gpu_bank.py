@@ -184,3 +184,33 @@ def test_edge_sizes_and_positions(gpu):
     small = N.DeviceBuffer(16)
     with pytest.raises(ValueError):
         N.check(N.lib().sh_bank_generate(bank._bank.handle, 0, 100, small.handle, 100))
+
+
+def test_bank_with_released_voices(gpu):
+    """Voices whose note has ended before the block are skipped by the kernel; the others are unaffected."""
+    from oracle import c_oracle as CO
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    rng = np.random.default_rng(12)
+    n_v = 24
+    f = rng.uniform(80, 2000, n_v)
+    sustain = rng.uniform(0.0, 0.5, n_v)           # notes end between 0.11 s and 0.61 s
+    gains = [(float(np.float32(a)), float(np.float32(b))) for a, b in rng.uniform(0, 1, (n_v, 2))]
+
+    def make(M):
+        return [M.EnvelopeFilter(M.Harmonics(float(f[i]), [(1, 1.0), (2, 0.4), (3, 0.2)], 0.2, samplerate=SR),
+                                 0.01, 0.05, float(sustain[i]), 0.5, 0.05) for i in range(n_v)]
+
+    bank = VoiceBank(make(G), gains=gains)
+    ov = make(O)
+    total = int(0.7 * SR)
+    want = CO.mix_bus(np.stack([CO.render(v, total) for v in ov]), gains)
+    for start in (0, int(0.2 * SR), int(0.4 * SR), int(0.62 * SR)):
+        n = min(6000, total - start)
+        got = bank.render(n, start=start)
+        assert rms(got, want[start:start + n]) <= RMS_TOL, start
+        assert np.max(np.abs(got - want[start:start + n])) < 3e-7, start
+    assert not bank.render(1000, start=int(0.65 * SR)).any()
+    mat = bank.generate(2000, start=int(0.3 * SR))
+    for i in range(n_v):
+        assert np.array_equal(mat[i], make(G)[i].render(2000, start=int(0.3 * SR)))
