@@ -87,8 +87,9 @@ static_assert(sizeof(VoiceLaunch) == 416, "VoiceLaunch layout");
 struct alignas(16) VoiceFM {      // only read for FM voices
     double frequency, phase0, f_inc;      // theta = frequency*T + fma(f_inc, L, phase0)
     double lfo_a_rel, lfo_d, lfo_K, lfo_C0, lfo_bias;   // L(i) = K*(C0 - cos(a_rel + i*d)) + bias*(start+i)
+    double lfo_rot_c, lfo_rot_s;          // cos / sin of 64*lfo_d: the LFO angle of a lane's next frame is one rotation away
 };
-static_assert(sizeof(VoiceFM) == 64, "VoiceFM layout");
+static_assert(sizeof(VoiceFM) == 80, "VoiceFM layout");
 
 __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first, uint32_t vi, uint64_t start, uint32_t nframes,
                                               VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm) {
@@ -225,6 +226,10 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         f->lfo_K = v.lfo_K;
         f->lfo_C0 = v.lfo_C0;
         f->lfo_bias = v.lfo_bias;
+        double lrc, lrs;
+        shm::sincos_f64(64.0 * v.lfo_d, lrs, lrc);
+        f->lfo_rot_c = lrc;
+        f->lfo_rot_s = lrs;
     }
 }
 
@@ -327,17 +332,25 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
         struct { double frequency, phase0, f_inc, lfo_a_rel, lfo_d, lfo_K, lfo_C0, lfo_bias; } f;
         f.frequency = fp->frequency; f.phase0 = fp->phase0; f.f_inc = fp->f_inc; f.lfo_a_rel = fp->lfo_a_rel;
         f.lfo_d = fp->lfo_d; f.lfo_K = fp->lfo_K; f.lfo_C0 = fp->lfo_C0; f.lfo_bias = fp->lfo_bias;
+        if (fm_mode == SH_FM_SINE) {
+            // LFO angle a_rel + i*d is exactly linear in i: table lookup for the lane's first frame, rotation
+            // by 64*d for the following ones
+            double ls, lc;
+            shm::sincos_tab(fma(di[0], f.lfo_d, f.lfo_a_rel), trig, ls, lc);
+            const double rc = fp->lfo_rot_c, rs = fp->lfo_rot_s;
 #pragma unroll
-        for (int j = 0; j < FPL; ++j) {
-            double Ln;
-            if (fm_mode == SH_FM_SINE) {
-                double arg = fma(di[j], f.lfo_d, f.lfo_a_rel), ls, lc;
-                shm::sincos_tab(arg, trig, ls, lc);
-                Ln = fma(f.lfo_K, f.lfo_C0 - lc, f.lfo_bias * ((double)start + di[j]));
-            } else {
-                Ln = fm_cumsum[i[j]];
+            for (int j = 0; j < FPL; ++j) {
+                if (j > 0) {
+                    const double ns = fma(ls, rc, lc * rs), nc = fma(lc, rc, -(ls * rs));
+                    ls = ns;
+                    lc = nc;
+                }
+                const double Ln = fma(f.lfo_K, f.lfo_C0 - lc, f.lfo_bias * ((double)start + di[j]));
+                th[j] = f.frequency * th[j] + fma(f.f_inc, Ln, f.phase0);      // t*freq + phase_correction
             }
-            th[j] = f.frequency * th[j] + fma(f.f_inc, Ln, f.phase0);          // t*freq + phase_correction
+        } else {
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) th[j] = f.frequency * th[j] + fma(f.f_inc, fm_cumsum[i[j]], f.phase0);
         }
     }
     // ---- waveform ----

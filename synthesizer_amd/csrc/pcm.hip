@@ -180,6 +180,7 @@ struct RatecvArgs {
     uint64_t n_out_samples;     // out_frames * nch
     uint32_t nch;
     uint32_t inr, outr;
+    uint32_t step_q, step_r;    // inr / outr and inr % outr: output frame m+1 starts (step_q, step_r) after frame m
     double   inv_outr;
     int      shift;             // 32 - 8*width (integer PCM)
 };
@@ -251,6 +252,58 @@ __global__ __launch_bounds__(256) void k_resample(const T* __restrict__ in, T* _
     }
     const size_t out_at = (size_t)m * A.nch + (size_t)cg * VEC;
     if (VEC == 1) out[out_at] = res[0]; else *reinterpret_cast<vec_t*>(out + out_at) = res;
+}
+
+// Few channels (nch == VEC): one thread = FR consecutive output frames x all channels, so that the store
+// is one 8..16-byte vector even for mono 16-bit PCM (a 2-byte store per lane reaches ~1/4 of the bandwidth).
+template <typename T, int VEC, int FR, bool IS_FLOAT>
+__global__ __launch_bounds__(256) void k_resample_frames(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A, uint64_t out_frames) {
+    typedef T vec_t __attribute__((ext_vector_type(VEC * FR)));
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t m0 = u * FR;
+    if (m0 >= out_frames) return;
+    const double outr = (double)A.outr;
+    vec_t res;
+    // position of frame m0 in input frames: q + r/outr (exact), then (step_q, step_r) per output frame
+    uint64_t q;
+    uint32_t r;
+    {
+        uint64_t j0;
+        uint32_t d0;
+        ratecv_index(A, m0, j0, d0);
+        r = d0 ? A.outr - d0 : 0u;
+        q = j0 - (r != 0);
+    }
+    const uint64_t last_q_frames = out_frames - 1 - m0;           // frames after m0 that exist
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+        const uint64_t j = q + (r != 0);
+        const uint32_t d = r ? A.outr - r : 0u;
+        if ((uint64_t)f < last_q_frames) {                        // advance, but never past the last output frame
+            r += A.step_r;
+            q += A.step_q;
+            if (r >= A.outr) { r -= A.outr; q += 1; }
+        }
+        const double dd = (double)d, od = (double)(A.outr - d);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const T cur = in[j * VEC + c];
+            const T prev = (j && d) ? in[(j - 1) * VEC + c] : (T)0;
+            if (IS_FLOAT) {
+                res[f * VEC + c] = (T)ratecv_value((double)prev, (double)cur, dd, od, outr, A.inv_outr);
+            } else {
+                const int ci = (int)((unsigned)(int)cur << A.shift);
+                const int pi = (int)((unsigned)(int)prev << A.shift);
+                res[f * VEC + c] = (T)((int)ratecv_value((double)pi, (double)ci, dd, od, outr, A.inv_outr) >> A.shift);
+            }
+        }
+    }
+    if (m0 + FR <= out_frames) {
+        *reinterpret_cast<vec_t*>(out + m0 * VEC) = res;
+    } else {
+        for (int f = 0; f < FR && m0 + f < out_frames; ++f)
+            for (int c = 0; c < VEC; ++c) out[(m0 + f) * VEC + c] = res[f * VEC + c];
+    }
 }
 
 uint64_t gcd_u64(uint64_t a, uint64_t b) {
@@ -436,6 +489,8 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
     A.inr = (uint32_t)((uint64_t)inrate / g);
     A.outr = (uint32_t)((uint64_t)outrate / g);
     A.inv_outr = 1.0 / (double)A.outr;
+    A.step_q = A.inr / A.outr;
+    A.step_r = A.inr % A.outr;
     A.shift = 32 - 8 * width;
     (void)in_frames;
     if (!out_frames) return SH_OK;
@@ -447,6 +502,28 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
         const int maxvec = 16 / width;
         for (int v = maxvec; v > 1; v >>= 1)
             if (nch % v == 0) { vec = v; break; }
+    }
+    // mono / stereo (and other narrow layouts that fit one vector): several frames per thread
+    if (aligned && nch * width <= 8 && (nch == 1 || nch == 2 || nch == 4)) {
+        const int fr = 16 / (nch * width) > 8 ? 8 : 16 / (nch * width);        // 16-byte stores, at most 8 frames per thread
+        A.n_out_samples = (uint64_t)out_frames;
+        dim3 g2(sh::div_up(sh::div_up(out_frames, fr), 256));
+#define SH_RF(T, V, F, FL) hipLaunchKernelGGL((k_resample_frames<T, V, F, FL>), g2, dim3(256), 0, st, (const T*)in, (T*)out, A, (uint64_t)out_frames)
+        bool launched = true;
+        if (is_float) {
+            if (nch == 1) SH_RF(float, 1, 4, true); else if (nch == 2) SH_RF(float, 2, 2, true); else launched = false;
+        } else if (width == 2) {
+            if (nch == 1) SH_RF(short, 1, 8, false); else if (nch == 2) SH_RF(short, 2, 4, false); else SH_RF(short, 4, 2, false);
+        } else if (width == 4) {
+            if (nch == 1) SH_RF(int, 1, 4, false); else if (nch == 2) SH_RF(int, 2, 2, false); else launched = false;
+        } else {
+            if (nch == 1) SH_RF(signed char, 1, 8, false); else if (nch == 2) SH_RF(signed char, 2, 8, false); else SH_RF(signed char, 4, 4, false);
+        }
+#undef SH_RF
+        if (launched) {
+            SH_CHECK_LAUNCH("k_resample_frames");
+            return SH_OK;
+        }
     }
     A.n_out_samples = (uint64_t)out_frames * (nch / vec);
     dim3 grid(sh::div_up(A.n_out_samples, 256));
