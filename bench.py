@@ -102,21 +102,24 @@ def pcm_rows(N):
         nbytes = (frames + nout_w) * nch * width
         rows[name] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9, "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                       "out_Mframes_per_s": nout_w / (ms / 1e3) / 1e6}
-    # mono 16-bit, the shape WaveSynth samples have: 44.1 kHz -> 48 kHz, 900 MB in
-    frames = 450_000_000
-    nout_m = L.sh_resample_out_frames(frames, 44100, 48000)
-    big = N.DeviceBuffer(nout_m * 2)
-    for _ in range(2):
-        N.check(L.sh_resample(src.handle, frames, 1, 2, 0, 44100, 48000, big.handle, None))
-    N.sync()
-    N.timer_start()
-    for _ in range(5):
-        N.check(L.sh_resample(src.handle, frames, 1, 2, 0, 44100, 48000, big.handle, None))
-    ms = N.timer_stop() / 5
-    nbytes = (frames + nout_m) * 2
-    rows["resample_i16_mono_44k1_to_48k_900MB"] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
-                                                    "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
-    big.free()
+    # 16-bit mono / stereo, the shapes Sample.resample sees in practice (WaveSynth output, loaded WAVs): 900 MB in
+    for name, nch, inr, outr in (("resample_i16_mono_44k1_to_48k_900MB", 1, 44100, 48000),
+                                 ("resample_i16_stereo_44k1_to_48k_900MB", 2, 44100, 48000),
+                                 ("resample_i16_stereo_96k_to_44k1_900MB", 2, 96000, 44100)):
+        frames = 450_000_000 // nch
+        nout_m = L.sh_resample_out_frames(frames, inr, outr)
+        big = N.DeviceBuffer(nout_m * 2 * nch)
+        for _ in range(2):
+            N.check(L.sh_resample(src.handle, frames, nch, 2, 0, inr, outr, big.handle, None))
+        N.sync()
+        N.timer_start()
+        for _ in range(5):
+            N.check(L.sh_resample(src.handle, frames, nch, 2, 0, inr, outr, big.handle, None))
+        ms = N.timer_stop() / 5
+        nbytes = (frames + nout_m) * 2 * nch
+        rows[name] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
+                      "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+        big.free()
     # mixer chain: 1024 int16 voices x 10 s stereo (saturating fold in voice order), 2N+2 bytes per sample
     nv, nsamples = 1024, 48000 * 2 * 10
     chunks = N.DeviceBuffer(nv * nsamples * 2)

@@ -229,6 +229,13 @@ int sh_pcm_mul(const sh_buf* in, size_t in_off, size_t nbytes, int width, double
  * (i*slope/numsamples + offset)); i = sample index in the range, numsamples = nbytes/width, truncation */
 int sh_pcm_fade(const sh_buf* in, size_t in_off, size_t nbytes, int width, int fadeout, double slope, double offset,
                 sh_buf* out, size_t out_off);
+/* Sample.modulate_amp: out[i] = int(in[i] * mod[i mod nmod]) (float64 product, truncation toward zero); mod_f64 is
+ * a device buffer of nmod float64 factors, cycled.  A product outside the sample range is SH_ERR_OVERFLOW
+ * (upstream: OverflowError from the array store). */
+int sh_pcm_modulate(const sh_buf* in, size_t nbytes, int width, const sh_buf* mod_f64, size_t nmod, sh_buf* out);
+/* samples as float64: out[i] = in[i] / divisor (Sample.get_frames_as_floats uses 2^(bits-1); modulate_amp with a
+ * waveform modulator uses its largest absolute value) */
+int sh_pcm_to_f64(const sh_buf* in, size_t nsamples, int width, double divisor, sh_buf* out_f64);
 /* Sample.bias -> audioop.bias: wrapping add */
 int sh_pcm_bias(const sh_buf* in, size_t nbytes, int width, int bias, sh_buf* out);
 /* Sample.reverse -> audioop.reverse: sample order reversed (out must not alias in) */

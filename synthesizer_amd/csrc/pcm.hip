@@ -185,6 +185,11 @@ struct RatecvArgs {
     int      shift;             // 32 - 8*width (integer PCM)
 };
 
+// how a kernel forms one output sample
+enum { RS_INT_F64 = 0,          // integer PCM through the float64 expression (any width, any rate)
+       RS_FLOAT = 1,            // float32 PCM through the float64 expression
+       RS_INT_SMALL = 2 };      // 8/16-bit PCM with reduced outrate < 65536: exact 32-bit integer arithmetic
+
 __device__ __forceinline__ void ratecv_index(const RatecvArgs& A, uint64_t m, uint64_t& j, uint32_t& d) {
     const uint64_t M = m * (uint64_t)A.inr;
     uint64_t q;
@@ -214,8 +219,39 @@ __device__ __forceinline__ double ratecv_value(double prev, double cur, double d
     return fma(r, inv_outr, q);
 }
 
+// 8/16-bit PCM, reduced outrate < 65536.  audioop computes trunc(fl(N / outr)) >> s with N = (prev*d + cur*(outr-d)) << s
+// (s = 32 - bits): N is an exact float64 integer (< 2^48), a non-integer N/outr is at least 1/outr > 2^-16 away
+// from an integer while its float64 rounding error is below 2^-21, so the truncation equals integer division, and
+// trunc(.) >> s == floor(M / outr) with M = prev*d + cur*(outr-d) (|M| <= 2^(bits-1)*outr < 2^31; for M < 0 the
+// inner truncation loses less than 2^-s < 1/outr, which the floor of the arithmetic shift restores).  floor(M/outr)
+// is formed as an unsigned division of u = M + 2^(bits-1)*outr (0 <= u < 2^32): trunc(fma(u, 1/outr, 1/(2 outr))) in
+// float64 -- (u + 1/2)/outr is at least 1/(2 outr) > 2^-17 away from every integer and the evaluation error is below
+// 2^-20, so no correction step is needed.  Bit-exactness against audioop is what tests/test_gpu_pcm.py asserts on
+// both paths.
+template <typename T>
+__device__ __forceinline__ T ratecv_small_int(T prev, T cur, uint32_t d, uint32_t outr, double inv_outr) {
+    constexpr int HALF = 1 << (8 * (int)sizeof(T) - 1);
+    const int M = (int)prev * (int)d + (int)cur * (int)(outr - d);
+    const uint32_t u = (uint32_t)M + (uint32_t)HALF * outr;
+    const uint32_t q = (uint32_t)fma((double)u, inv_outr, 0.5 * inv_outr);
+    return (T)((int)q - HALF);
+}
+
+template <typename T, int MODE>
+__device__ __forceinline__ T ratecv_sample(T prev, T cur, uint32_t d, const RatecvArgs& A) {
+    if (MODE == RS_INT_SMALL) {
+        if constexpr (sizeof(T) <= 2) return ratecv_small_int<T>(prev, cur, d, A.outr, A.inv_outr);
+        else return (T)0;
+    }
+    const double dd = (double)d, od = (double)(A.outr - d), outr = (double)A.outr;
+    if (MODE == RS_FLOAT) return (T)ratecv_value((double)prev, (double)cur, dd, od, outr, A.inv_outr);
+    const int ci = (int)((unsigned)(int)cur << A.shift);                               // GETSAMPLE32
+    const int pi = (int)((unsigned)(int)prev << A.shift);
+    return (T)((int)ratecv_value((double)pi, (double)ci, dd, od, outr, A.inv_outr) >> A.shift);   // SETSAMPLE32
+}
+
 // One thread = one output frame x VEC channels, moved as one vector (VEC*sizeof(T) bytes).
-template <typename T, int VEC, bool IS_FLOAT>
+template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(256) void k_resample(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A) {
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
     const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -238,31 +274,20 @@ __global__ __launch_bounds__(256) void k_resample(const T* __restrict__ in, T* _
 #pragma unroll
         for (int c = 0; c < VEC; ++c) prev[c] = (T)0;
     }
-    const double dd = (double)d, od = (double)(A.outr - d), outr = (double)A.outr;
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) {
-        if (IS_FLOAT) {
-            res[c] = (T)ratecv_value((double)prev[c], (double)cur[c], dd, od, outr, A.inv_outr);
-        } else {
-            const int ci = (int)((unsigned)(int)cur[c] << A.shift);                    // GETSAMPLE32
-            const int pi = (int)((unsigned)(int)prev[c] << A.shift);
-            const int cur_o = (int)ratecv_value((double)pi, (double)ci, dd, od, outr, A.inv_outr);
-            res[c] = (T)(cur_o >> A.shift);                                            // SETSAMPLE32
-        }
-    }
+    for (int c = 0; c < VEC; ++c) res[c] = ratecv_sample<T, MODE>(prev[c], cur[c], d, A);
     const size_t out_at = (size_t)m * A.nch + (size_t)cg * VEC;
     if (VEC == 1) out[out_at] = res[0]; else *reinterpret_cast<vec_t*>(out + out_at) = res;
 }
 
 // Few channels (nch == VEC): one thread = FR consecutive output frames x all channels, so that the store
 // is one 8..16-byte vector even for mono 16-bit PCM (a 2-byte store per lane reaches ~1/4 of the bandwidth).
-template <typename T, int VEC, int FR, bool IS_FLOAT>
+template <typename T, int VEC, int FR, int MODE>
 __global__ __launch_bounds__(256) void k_resample_frames(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A, uint64_t out_frames) {
     typedef T vec_t __attribute__((ext_vector_type(VEC * FR)));
     const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t m0 = u * FR;
     if (m0 >= out_frames) return;
-    const double outr = (double)A.outr;
     vec_t res;
     // position of frame m0 in input frames: q + r/outr (exact), then (step_q, step_r) per output frame
     uint64_t q;
@@ -284,19 +309,183 @@ __global__ __launch_bounds__(256) void k_resample_frames(const T* __restrict__ i
             q += A.step_q;
             if (r >= A.outr) { r -= A.outr; q += 1; }
         }
-        const double dd = (double)d, od = (double)(A.outr - d);
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
             const T cur = in[j * VEC + c];
             const T prev = (j && d) ? in[(j - 1) * VEC + c] : (T)0;
-            if (IS_FLOAT) {
-                res[f * VEC + c] = (T)ratecv_value((double)prev, (double)cur, dd, od, outr, A.inv_outr);
-            } else {
-                const int ci = (int)((unsigned)(int)cur << A.shift);
-                const int pi = (int)((unsigned)(int)prev << A.shift);
-                res[f * VEC + c] = (T)((int)ratecv_value((double)pi, (double)ci, dd, od, outr, A.inv_outr) >> A.shift);
-            }
+            res[f * VEC + c] = ratecv_sample<T, MODE>(prev, cur, d, A);
         }
+    }
+    if (m0 + FR <= out_frames) {
+        *reinterpret_cast<vec_t*>(out + m0 * VEC) = res;
+    } else {
+        for (int f = 0; f < FR && m0 + f < out_frames; ++f)
+            for (int c = 0; c < VEC; ++c) out[(m0 + f) * VEC + c] = res[f * VEC + c];
+    }
+}
+
+// Mono / stereo: the input span of a workgroup is staged in LDS with aligned 16-byte loads (coalesced, every
+// input byte fetched once), and each thread interpolates FR consecutive output frames from LDS -- instead of
+// 2*FR narrow gathers per thread.  Used when the span fits the LDS budget (ratios up to ~10:1).
+constexpr uint32_t RS_LDS_BYTES = 48 * 1024;
+
+template <typename T, int VEC, int FR, int MODE>
+__global__ __launch_bounds__(256) void k_resample_lds(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A,
+                                                      uint64_t in_frames, uint64_t out_frames) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* lds = reinterpret_cast<T*>(smem);
+    typedef T vec_t __attribute__((ext_vector_type(VEC * FR)));
+    typedef T ld_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr uint32_t EPV = 16 / sizeof(T);                      // elements per 16-byte vector
+    const uint64_t m_first = (uint64_t)blockIdx.x * (256 * FR);
+    if (m_first >= out_frames) return;
+    uint64_t m_last = m_first + 256 * FR - 1;
+    if (m_last > out_frames - 1) m_last = out_frames - 1;
+    // input frames this workgroup reads: [j(m_first) - 1, j(m_last)]   (uniform)
+    uint64_t jf, jl;
+    uint32_t df, dl;
+    ratecv_index(A, m_first, jf, df);
+    ratecv_index(A, m_last, jl, dl);
+    const uint64_t lo_frame = jf ? jf - 1 : 0;
+    const uint64_t lo_elem = (lo_frame * VEC) & ~(uint64_t)(EPV - 1);            // 16-byte aligned start
+    const uint64_t hi_elem = (jl + 1) * VEC;                                      // exclusive
+    const uint64_t total_elems = in_frames * VEC;
+    const uint32_t nvec = (uint32_t)((hi_elem - lo_elem + EPV - 1) / EPV);
+    for (uint32_t v = threadIdx.x; v < nvec; v += 256) {
+        const uint64_t e = lo_elem + (uint64_t)v * EPV;
+        if (e + EPV <= total_elems) {
+            reinterpret_cast<ld_t*>(lds)[v] = *reinterpret_cast<const ld_t*>(in + e);
+        } else {
+            for (uint32_t k = 0; k < EPV; ++k) lds[v * EPV + k] = (e + k < total_elems) ? in[e + k] : (T)0;
+        }
+    }
+    __syncthreads();
+    const uint64_t m0 = m_first + (uint64_t)threadIdx.x * FR;
+    if (m0 >= out_frames) return;
+    uint64_t q;
+    uint32_t r;
+    {
+        uint64_t j0;
+        uint32_t d0;
+        ratecv_index(A, m0, j0, d0);
+        r = d0 ? A.outr - d0 : 0u;
+        q = j0 - (r != 0);
+    }
+    const uint64_t frames_after = out_frames - 1 - m0;
+    vec_t res;
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+        const uint64_t j = q + (r != 0);
+        const uint32_t d = r ? A.outr - r : 0u;
+        if ((uint64_t)f < frames_after) {
+            r += A.step_r;
+            q += A.step_q;
+            if (r >= A.outr) { r -= A.outr; q += 1; }
+        }
+        const uint32_t at = (uint32_t)(j * VEC - lo_elem);                        // LDS element index of frame j
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const T cur = lds[at + c];
+            const T prev = (j && d) ? lds[at - VEC + c] : (T)0;
+            res[f * VEC + c] = ratecv_sample<T, MODE>(prev, cur, d, A);
+        }
+    }
+    if (m0 + FR <= out_frames) {
+        *reinterpret_cast<vec_t*>(out + m0 * VEC) = res;
+    } else {
+        for (int f = 0; f < FR && m0 + f < out_frames; ++f)
+            for (int c = 0; c < VEC; ++c) out[(m0 + f) * VEC + c] = res[f * VEC + c];
+    }
+}
+
+// 8/16-bit PCM, few channels, reduced rates below 65536 (the common Sample.resample case: 16-bit mono/stereo
+// between 44.1k/48k/96k).  The generic kernels above are VALU-issue-bound there (~55 instructions per output
+// sample at 2-4 bytes of traffic each), so this one strips the arithmetic to ~20 full-rate instructions:
+//  * the workgroup's input span goes through LDS (aligned 16-byte loads), positions are 32-bit LDS-relative;
+//  * output m sits at input position q + r/outr; with a = x[q], b = x[q+1] the reference's expression is
+//    M = a*(outr-r) + b*r for every r (r == 0 gives cur = x[q], weight outr), so there is no prev/cur select;
+//  * u = M + HALF*outr = (b-a)*r + (a+HALF)*outr in 24-bit multiplies (mod 2^32; 0 <= u < 2^32);
+//  * floor(u/outr) = trunc(fma(u, 1/outr, 1/(2 outr))) in float64, exact without a correction step.  See
+//    ratecv_small_int for why the floor equals audioop's float64 expression.
+template <typename T, int VEC, int FR>
+__global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A,
+                                                        uint64_t in_frames, uint64_t out_frames, uint32_t span_vecs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* lds = reinterpret_cast<T*>(smem);
+    typedef T vec_t __attribute__((ext_vector_type(VEC * FR)));
+    typedef T ld_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr uint32_t EPV = 16 / sizeof(T);
+    constexpr int HALF = 1 << (8 * (int)sizeof(T) - 1);
+    const uint64_t m_first = (uint64_t)blockIdx.x * (256 * FR);
+    if (m_first >= out_frames) return;
+    // position of the workgroup's first output frame: q0 + r0/outr   (uniform)
+    uint64_t q0;
+    uint32_t r0;
+    {
+        uint64_t jf;
+        uint32_t df;
+        ratecv_index(A, m_first, jf, df);
+        r0 = df ? A.outr - df : 0u;
+        q0 = jf - (r0 != 0);
+    }
+    const uint64_t lo_elem = (q0 * VEC) & ~(uint64_t)(EPV - 1);                  // 16-byte aligned start of the span
+    const uint64_t total_elems = in_frames * VEC;
+    for (uint32_t v = threadIdx.x; v < span_vecs; v += 256) {
+        const uint64_t e = lo_elem + (uint64_t)v * EPV;
+        if (e + EPV <= total_elems) {
+            reinterpret_cast<ld_t*>(lds)[v] = *reinterpret_cast<const ld_t*>(in + e);
+        } else {
+            for (uint32_t k = 0; k < EPV; ++k) lds[v * EPV + k] = (e + k < total_elems) ? in[e + k] : (T)0;
+        }
+    }
+    __syncthreads();
+    const uint64_t m0 = m_first + (uint64_t)threadIdx.x * FR;
+    if (m0 >= out_frames) return;
+    // this thread's first frame: (q0, r0) advanced by threadIdx.x*FR output frames (host guarantees < 2^31)
+    uint32_t r, qe_elem;
+    {
+        const uint32_t tot = r0 + __umul24(threadIdx.x * FR, A.inr);
+        const uint32_t dq = (uint32_t)fma((double)tot, A.inv_outr, 0.5 * A.inv_outr);   // floor(tot/outr), exact as below
+        r = tot - dq * A.outr;
+        qe_elem = (uint32_t)(q0 * VEC - lo_elem) + dq * VEC;                     // LDS element index of frame q
+    }
+    const uint32_t step_elem = A.step_q * VEC;
+    const double half_inv = 0.5 * A.inv_outr;
+    constexpr bool PAIR_IN_DWORD = 2 * VEC * sizeof(T) <= 4;
+    constexpr uint32_t MASK = (1u << (8 * sizeof(T))) - 1u;
+    constexpr uint32_t FLIP = sizeof(T) == 2 ? 0x80008000u : 0x80808080u;
+    vec_t res;
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+        uint32_t pair = 0;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            // ua = a + HALF, ub = b + HALF as unsigned bit patterns (x + HALF == x ^ HALF on the sample width)
+            uint32_t ua, ub;
+            if (PAIR_IN_DWORD) {
+                // frames q and q+1 together are <= 4 bytes at a 1- or 2-byte aligned address: two aligned dwords and a
+                // funnel shift (a misaligned ds_read_b32 is several times slower than the extra three instructions)
+                if (c == 0) {
+                    const uint32_t byte_off = qe_elem * (uint32_t)sizeof(T);
+                    const uint32_t* l32 = reinterpret_cast<const uint32_t*>(smem) + (byte_off >> 2);
+                    pair = __builtin_amdgcn_alignbit(l32[1], l32[0], (byte_off & 3u) * 8u) ^ FLIP;
+                }
+                ua = (pair >> (8 * sizeof(T) * c)) & MASK;
+                ub = (pair >> (8 * sizeof(T) * (VEC + c))) & MASK;
+            } else {
+                ua = ((uint32_t)lds[qe_elem + c] & MASK) ^ (uint32_t)HALF;
+                ub = ((uint32_t)lds[qe_elem + VEC + c] & MASK) ^ (uint32_t)HALF;
+            }
+            const uint32_t u = (uint32_t)__mul24((int)ub - (int)ua, (int)r) + __umul24(ua, A.outr);
+            // (u + 1/2)/outr is at least 1/(2 outr) > 2^-17 away from every integer and the float64 evaluation is off by
+            // less than 2^-20, so the truncation is floor(u/outr) exactly: 3 instructions, no correction step
+            const uint32_t q = (uint32_t)fma((double)u, A.inv_outr, half_inv);
+            res[f * VEC + c] = (T)(q ^ (uint32_t)HALF);
+        }
+        r += A.step_r;
+        const bool wrap = r >= A.outr;
+        r -= wrap ? A.outr : 0u;
+        qe_elem += step_elem + (wrap ? (uint32_t)VEC : 0u);
     }
     if (m0 + FR <= out_frames) {
         *reinterpret_cast<vec_t*>(out + m0 * VEC) = res;
@@ -492,7 +681,8 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
     A.step_q = A.inr / A.outr;
     A.step_r = A.inr % A.outr;
     A.shift = 32 - 8 * width;
-    (void)in_frames;
+    const bool small = !is_float && width <= 2 && A.outr < 65536u;
+#define SH_I(M, ...) do { if (small) M(__VA_ARGS__, RS_INT_SMALL); else M(__VA_ARGS__, RS_INT_F64); } while (0)
     if (!out_frames) return SH_OK;
     hipStream_t st = sh::state().stream;
     // widest channel vector that divides nch, stays <= 16 bytes and keeps every access aligned
@@ -508,16 +698,45 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
         const int fr = 16 / (nch * width) > 8 ? 8 : 16 / (nch * width);        // 16-byte stores, at most 8 frames per thread
         A.n_out_samples = (uint64_t)out_frames;
         dim3 g2(sh::div_up(sh::div_up(out_frames, fr), 256));
+        // input bytes one workgroup (256*fr output frames) touches; stage them in LDS when they fit
+        const uint64_t span_frames = ((uint64_t)256 * fr * A.inr + A.outr - 1) / A.outr + 3;
+        const uint64_t span_bytes = span_frames * nch * width + 32;
+        if (small && A.inr < 65536u) {
+            // span: frames q0 .. q0 + floor((r0 + (256*fr-1)*inr)/outr) + 1, the alignment slack of the first vector,
+            // and one more vector for the dword-pair reads
+            const uint32_t epv = 16 / width;
+            const uint64_t svecs = (span_frames * nch + epv + epv - 1) / epv + 1;
+            if (svecs * 16 <= RS_LDS_BYTES) {
+                const uint32_t span_vecs = (uint32_t)svecs, lds_bytes = span_vecs * 16;
+#define SH_RM(T, V, F) hipLaunchKernelGGL((k_resample_small<T, V, F>), g2, dim3(256), lds_bytes, st, (const T*)in, (T*)out, A, (uint64_t)in_frames, (uint64_t)out_frames, span_vecs)
+                if (width == 2) { if (nch == 1) SH_RM(short, 1, 8); else if (nch == 2) SH_RM(short, 2, 4); else SH_RM(short, 4, 2); }
+                else { if (nch == 1) SH_RM(signed char, 1, 8); else if (nch == 2) SH_RM(signed char, 2, 8); else SH_RM(signed char, 4, 4); }
+#undef SH_RM
+                SH_CHECK_LAUNCH("k_resample_small");
+                return SH_OK;
+            }
+        }
+        if (nch <= 2 && span_bytes <= RS_LDS_BYTES) {
+            const uint32_t lds_bytes = (uint32_t)((span_bytes + 15) & ~15ull);
+#define SH_RL(T, V, F, FL) hipLaunchKernelGGL((k_resample_lds<T, V, F, FL>), g2, dim3(256), lds_bytes, st, (const T*)in, (T*)out, A, (uint64_t)in_frames, (uint64_t)out_frames)
+            if (is_float) { if (nch == 1) SH_RL(float, 1, 4, RS_FLOAT); else SH_RL(float, 2, 2, RS_FLOAT); }
+            else if (width == 2) { if (nch == 1) SH_I(SH_RL, short, 1, 8); else SH_I(SH_RL, short, 2, 4); }
+            else if (width == 4) { if (nch == 1) SH_RL(int, 1, 4, RS_INT_F64); else SH_RL(int, 2, 2, RS_INT_F64); }
+            else { if (nch == 1) SH_I(SH_RL, signed char, 1, 8); else SH_I(SH_RL, signed char, 2, 8); }
+#undef SH_RL
+            SH_CHECK_LAUNCH("k_resample_lds");
+            return SH_OK;
+        }
 #define SH_RF(T, V, F, FL) hipLaunchKernelGGL((k_resample_frames<T, V, F, FL>), g2, dim3(256), 0, st, (const T*)in, (T*)out, A, (uint64_t)out_frames)
         bool launched = true;
         if (is_float) {
-            if (nch == 1) SH_RF(float, 1, 4, true); else if (nch == 2) SH_RF(float, 2, 2, true); else launched = false;
+            if (nch == 1) SH_RF(float, 1, 4, RS_FLOAT); else if (nch == 2) SH_RF(float, 2, 2, RS_FLOAT); else launched = false;
         } else if (width == 2) {
-            if (nch == 1) SH_RF(short, 1, 8, false); else if (nch == 2) SH_RF(short, 2, 4, false); else SH_RF(short, 4, 2, false);
+            if (nch == 1) SH_I(SH_RF, short, 1, 8); else if (nch == 2) SH_I(SH_RF, short, 2, 4); else SH_I(SH_RF, short, 4, 2);
         } else if (width == 4) {
-            if (nch == 1) SH_RF(int, 1, 4, false); else if (nch == 2) SH_RF(int, 2, 2, false); else launched = false;
+            if (nch == 1) SH_RF(int, 1, 4, RS_INT_F64); else if (nch == 2) SH_RF(int, 2, 2, RS_INT_F64); else launched = false;
         } else {
-            if (nch == 1) SH_RF(signed char, 1, 8, false); else if (nch == 2) SH_RF(signed char, 2, 8, false); else SH_RF(signed char, 4, 4, false);
+            if (nch == 1) SH_I(SH_RF, signed char, 1, 8); else if (nch == 2) SH_I(SH_RF, signed char, 2, 8); else SH_I(SH_RF, signed char, 4, 4);
         }
 #undef SH_RF
         if (launched) {
@@ -529,18 +748,19 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
     dim3 grid(sh::div_up(A.n_out_samples, 256));
 #define SH_RS(T, V, F) hipLaunchKernelGGL((k_resample<T, V, F>), grid, dim3(256), 0, st, (const T*)in, (T*)out, A)
     if (is_float) {
-        if (vec == 4) SH_RS(float, 4, true); else if (vec == 2) SH_RS(float, 2, true); else SH_RS(float, 1, true);
+        if (vec == 4) SH_RS(float, 4, RS_FLOAT); else if (vec == 2) SH_RS(float, 2, RS_FLOAT); else SH_RS(float, 1, RS_FLOAT);
     } else if (width == 2) {
-        if (vec == 8) SH_RS(short, 8, false); else if (vec == 4) SH_RS(short, 4, false);
-        else if (vec == 2) SH_RS(short, 2, false); else SH_RS(short, 1, false);
+        if (vec == 8) SH_I(SH_RS, short, 8); else if (vec == 4) SH_I(SH_RS, short, 4);
+        else if (vec == 2) SH_I(SH_RS, short, 2); else SH_I(SH_RS, short, 1);
     } else if (width == 4) {
-        if (vec == 4) SH_RS(int, 4, false); else if (vec == 2) SH_RS(int, 2, false); else SH_RS(int, 1, false);
+        if (vec == 4) SH_RS(int, 4, RS_INT_F64); else if (vec == 2) SH_RS(int, 2, RS_INT_F64); else SH_RS(int, 1, RS_INT_F64);
     } else {
-        if (vec == 16) SH_RS(signed char, 16, false); else if (vec == 8) SH_RS(signed char, 8, false);
-        else if (vec == 4) SH_RS(signed char, 4, false); else if (vec == 2) SH_RS(signed char, 2, false);
-        else SH_RS(signed char, 1, false);
+        if (vec == 16) SH_I(SH_RS, signed char, 16); else if (vec == 8) SH_I(SH_RS, signed char, 8);
+        else if (vec == 4) SH_I(SH_RS, signed char, 4); else if (vec == 2) SH_I(SH_RS, signed char, 2);
+        else SH_I(SH_RS, signed char, 1);
     }
 #undef SH_RS
+#undef SH_I
     SH_CHECK_LAUNCH("k_resample");
     return SH_OK;
 }

@@ -44,6 +44,31 @@ __global__ __launch_bounds__(256) void k_fade(const T* in, T* out, size_t n, dou
     out[i] = (T)(long long)trunc((double)in[i] * f);
 }
 
+// out[i] = int(in[i] * mod[i mod nmod])          (Sample.modulate_amp: Python float product, int() truncation;
+// a product outside the sample range raises upstream -> flag)
+template <typename T>
+__global__ __launch_bounds__(256) void k_modulate(const T* __restrict__ in, T* __restrict__ out, size_t n,
+                                                  const double* __restrict__ mod, size_t nmod, int* flag) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t k = i < nmod ? i : (i < 0xFFFFFFFFull && nmod < 0xFFFFFFFFull ? (size_t)((uint32_t)i % (uint32_t)nmod) : i % nmod);
+    constexpr double HI = (double)((1ll << (8 * sizeof(T) - 1)) - 1), LO = -(double)(1ll << (8 * sizeof(T) - 1));
+    double t = trunc((double)in[i] * mod[k]);
+    if (!(t >= LO && t <= HI)) {
+        *flag = 1;
+        t = t > HI ? HI : LO;
+    }
+    out[i] = (T)(long long)t;
+}
+
+// out[i] = in[i] / divisor in float64              (Sample.get_frames_as_floats; waveform modulators)
+template <typename T>
+__global__ __launch_bounds__(256) void k_to_f64(const T* __restrict__ in, double* __restrict__ out, size_t n, double divisor) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (double)in[i] / divisor;
+}
+
 // out[i] = in[i] + bias, wrapping                (audioop.bias)
 template <typename T>
 __global__ __launch_bounds__(256) void k_bias(const T* in, T* out, size_t n, int bias) {
@@ -229,6 +254,48 @@ int sh_pcm_fade(const sh_buf* in, size_t in_off, size_t nbytes, int width, int f
                            (T*)((char*)out->ptr + out_off), n, slope, (double)nbytes / (double)width, offset, fadeout);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_fade");
+    });
+}
+
+int sh_pcm_modulate(const sh_buf* in, size_t nbytes, int width, const sh_buf* mod_f64, size_t nmod, sh_buf* out) {
+    SH_REQUIRE_INIT();
+    int rc = check_io(in, 0, nbytes, out, 0, nbytes, "sh_pcm_modulate");
+    if (rc) return rc;
+    if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_modulate: not a whole number of samples");
+    if (!nbytes) return SH_OK;
+    if (!mod_f64 || !nmod || mod_f64->bytes / 8 < nmod) return sh::set_error(SH_ERR_INVALID, "sh_pcm_modulate: modulator buffer empty or smaller than nmod");
+    const size_t n = nbytes / width;
+    sh::State& S = sh::state();
+    rc = dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        hipLaunchKernelGGL(k_modulate<T>, dim3(sh::div_up(n, 256)), dim3(256), 0, S.stream, (const T*)in->ptr, (T*)out->ptr, n,
+                           (const double*)mod_f64->ptr, nmod, S.flag);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_modulate");
+    });
+    if (rc) return rc;
+    SH_HIP(hipMemcpyAsync(S.flag_host, S.flag, sizeof(int), hipMemcpyDeviceToHost, S.stream));
+    SH_HIP(hipStreamSynchronize(S.stream));
+    if (S.flag_host[0]) {
+        SH_HIP(hipMemsetAsync(S.flag, 0, sizeof(int), S.stream));
+        return sh::set_error(SH_ERR_OVERFLOW, "signed integer out of range for sample width %d", width);
+    }
+    return SH_OK;
+}
+
+int sh_pcm_to_f64(const sh_buf* in, size_t nsamples, int width, double divisor, sh_buf* out_f64) {
+    SH_REQUIRE_INIT();
+    if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_pcm_to_f64: width %d not in {1,2,4}", width);
+    int rc = check_io(in, 0, nsamples * width, out_f64, 0, nsamples * 8, "sh_pcm_to_f64");
+    if (rc) return rc;
+    if (!(divisor != 0.0)) return sh::set_error(SH_ERR_INVALID, "sh_pcm_to_f64: divisor is zero");
+    if (!nsamples) return SH_OK;
+    hipStream_t st = sh::state().stream;
+    return dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        hipLaunchKernelGGL(k_to_f64<T>, dim3(sh::div_up(nsamples, 256)), dim3(256), 0, st, (const T*)in->ptr, (double*)out_f64->ptr, nsamples, divisor);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_to_f64");
     });
 }
 

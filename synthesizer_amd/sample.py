@@ -13,7 +13,9 @@ implementation of the arithmetic in this package.
 Also here (the elementwise operations upstream delegates to audioop):
 amplify / amplify_max / invert (``audioop.mul``), bias, reverse, mono / left / right (``tomono``),
 stereo / pan (``tostereo``), normalize / make_16bit / make_32bit (``lin2lin``), peak / rms, fadein / fadeout.
-Not provided: echo, envelope, modulate_amp, split / join / clip, level meter objects, 24-bit samples.
+Editing operations composed from those on device-resident PCM: clip / split / join / add_silence / delay,
+speed (``ratecv``), at_volume, echo, envelope (ADSR), modulate_amp (sample- or oscillator-driven).
+Not provided: level meter objects, 24-bit samples on the GPU path.
 """
 from __future__ import annotations
 
@@ -234,10 +236,185 @@ class Sample:
             out.setparams((self.__nchannels, self.__samplewidth, self.__samplerate, 0, "NONE", "not compressed"))
             out.writeframes(self._host())
 
+    # -- editing: slices and concatenations of device-resident PCM -------------------------------------
+    def __assemble(self, parts: Sequence[tuple]) -> None:
+        """frames = concatenation of parts; a part is (sample, first_byte, nbytes) or (None, 0, nbytes) for silence."""
+        total = sum(p[2] for p in parts)
+        dst = N.DeviceBuffer(total)
+        L = N.lib()
+        at = 0
+        for src, first, nbytes in parts:
+            if nbytes:
+                if src is None:
+                    dst.zero(at, nbytes)
+                else:
+                    N.check(L.sh_buf_copy(dst.handle, at, src._device().handle, first, nbytes))
+            at += nbytes
+        self._set_device(dst, total)
+
     def add_silence(self, seconds: float, at_start: bool = False) -> "Sample":
+        """Add silence at the end (or at the start)."""
         self._check_writable()
-        pad = b"\0" * self.frame_idx(seconds)
-        self._set_host(pad + self._host() if at_start else self._host() + pad)
+        pad = self.frame_idx(seconds)
+        if pad:
+            me = (self, 0, self.__nbytes)
+            keep = self.__dev          # keep the source alive while it is being copied
+            self.__assemble([(None, 0, pad), me] if at_start else [me, (None, 0, pad)])
+            del keep
+        return self
+
+    def clip(self, start_seconds: float, end_seconds: float) -> "Sample":
+        """Keep only the given time range."""
+        self._check_writable()
+        assert end_seconds >= start_seconds
+        start, end = self.frame_idx(start_seconds), self.frame_idx(end_seconds)
+        if start != 0 or end != self.__nbytes:
+            start, end, _ = slice(start, end).indices(self.__nbytes)      # byte-string slicing rules, as upstream
+            keep = self.__dev
+            self.__assemble([(self, start, max(0, end - start))])
+            del keep
+        return self
+
+    def split(self, seconds: float) -> "Sample":
+        """Keep the first part and return the chopped-off rest as a new sample."""
+        self._check_writable()
+        end = self.frame_idx(seconds)
+        rest = Sample(name=self.name, samplerate=self.__samplerate, nchannels=self.__nchannels, samplewidth=self.__samplewidth)
+        if end != self.__nbytes:
+            end = slice(end, None).indices(self.__nbytes)[0]               # byte-string slicing rules, as upstream
+            rest.__assemble([(self, end, self.__nbytes - end)])
+            keep = self.__dev
+            self.__assemble([(self, 0, end)])
+            del keep
+        return rest
+
+    def join(self, other: "Sample") -> "Sample":
+        """Append another sample to this one."""
+        self._check_writable()
+        assert self.samplewidth == other.samplewidth
+        assert self.samplerate == other.samplerate
+        assert self.nchannels == other.nchannels
+        if other.__nbytes:
+            keep = self.__dev
+            self.__assemble([(self, 0, self.__nbytes), (other, 0, other.__nbytes)])
+            del keep
+        return self
+
+    def delay(self, seconds: float, keep_length: bool = False) -> "Sample":
+        """Delay the sample (insert silence at the start); a negative delay skips a bit from the start instead."""
+        self._check_writable()
+        if seconds > 0:
+            if keep_length:
+                num_frames = len(self)
+                self.add_silence(seconds, at_start=True)
+                self.clip(0, num_frames / self.samplerate)
+            else:
+                self.add_silence(seconds, at_start=True)
+        elif seconds < 0:
+            seconds = -seconds
+            if keep_length:
+                self.add_silence(seconds)
+            self.clip(seconds, self.duration)
+        return self
+
+    def speed(self, speed: float) -> "Sample":
+        """Change the playback speed (and the pitch) without changing the sample rate: frames are interpolated with
+        ``audioop.ratecv(frames, width, nchannels, int(samplerate*speed), samplerate, None)``."""
+        self._check_writable()
+        assert speed > 0
+        if speed == 1.0:
+            return self
+        if speed > 10.0 or speed < 0.1:
+            raise ValueError("speed must be between 0.1 and 10")
+        rate = self.__samplerate
+        self.__samplerate = int(rate * speed)
+        self.resample(rate)
+        return self
+
+    def at_volume(self, volume: float) -> "Sample":
+        """A copy of the sample at the given volume 0..1 (works on locked samples: the original is untouched)."""
+        cpy = self.copy()
+        cpy.amplify(volume)
+        return cpy
+
+    def echo(self, length: float, amount: int, delay: float, decay: float) -> "Sample":
+        """Add `amount` echos of the last `length` seconds, `delay` seconds apart, each `decay` times the previous
+        volume.  Echos too quiet for the sample width are skipped."""
+        self._check_writable()
+        self._check_gpu_width("echo")
+        if amount > 0:
+            length = max(0, self.duration - length)
+            echo = self.copy()
+            echo.clip(length, self.duration)
+            echo_amp = decay
+            for _ in range(amount):
+                if echo_amp < 1.0 / (2 ** (8 * self.__samplewidth - 1)):
+                    break       # an echo nobody can hear
+                length += delay
+                echo = echo.copy().amplify(echo_amp)
+                self.mix_at(length, echo)
+                echo_amp *= decay
+        return self
+
+    def envelope(self, attack: float, decay: float, sustainlevel: float, release: float) -> "Sample":
+        """Apply an ADSR volume envelope; attack, decay and release in seconds, sustainlevel a factor."""
+        self._check_writable()
+        assert attack >= 0 and decay >= 0 and release >= 0
+        assert 0 <= sustainlevel <= 1
+        D = self.split(attack)          # self is now the attack part
+        S = D.split(decay)
+        if sustainlevel < 1:
+            S.amplify(sustainlevel)
+        R = S.split(S.duration - release)
+        if attack > 0:
+            self.fadein(attack)
+        if decay > 0:
+            D.fadeout(decay, sustainlevel)
+        if release > 0:
+            R.fadeout(release)
+        self.join(D).join(S).join(R)
+        return self
+
+    def modulate_amp(self, modulation_source) -> "Sample":
+        """Amplitude modulation: every sample becomes int(sample * factor).  The factors come from an oscillator
+        (its block stream from the start), from another Sample or a sequence of numbers (cycled, scaled so that its
+        largest absolute value is 1.0), or from any iterable of floats."""
+        self._check_writable()
+        self._check_gpu_width("modulate_amp")
+        n = self.__nbytes // self.__samplewidth
+        if not n:
+            return self
+        L = N.lib()
+        from .oscillators import Oscillator
+        if isinstance(modulation_source, Sample):
+            modulation_source._check_gpu_width("modulate_amp")
+            nmod = modulation_source.__nbytes // modulation_source.__samplewidth
+            if not nmod:
+                raise ValueError("modulation sample is empty")
+            biggest = modulation_source.peak()
+            mod = N.DeviceBuffer(nmod * 8)
+            N.check(L.sh_pcm_to_f64(modulation_source._device().handle, nmod, modulation_source.__samplewidth, float(biggest), mod.handle))
+        elif isinstance(modulation_source, Oscillator):
+            nmod = n
+            mod = modulation_source._render_f64_device(0, n)
+        else:
+            if isinstance(modulation_source, (list, tuple, array.array, np.ndarray)):
+                values = np.asarray(modulation_source, dtype=np.float64)
+                if not len(values):
+                    raise ValueError("modulation sequence is empty")
+                biggest = max(values.max(), abs(values.min()))
+                values = values / biggest
+            else:
+                import itertools
+                values = np.fromiter(itertools.islice(iter(modulation_source), n), dtype=np.float64)
+                if len(values) < n:
+                    raise ValueError("modulation iterator ran out after %d of %d samples" % (len(values), n))
+            nmod = len(values)
+            mod = N.DeviceBuffer(nmod * 8)
+            mod.upload(values)
+        dst = N.DeviceBuffer(self.__nbytes)
+        N.check(L.sh_pcm_modulate(self._device().handle, self.__nbytes, self.__samplewidth, mod.handle, nmod, dst.handle))
+        self._set_device(dst, self.__nbytes)
         return self
 
     # -- the hot path ----------------------------------------------------------------------------

@@ -124,6 +124,24 @@ def test_resample_live_audioop(gpu, rates, nch):
             assert len(want) == P.ratecv_out_frames(frames, i, o) * width * nch
 
 
+@pytest.mark.parametrize("rates", [(65521, 65535), (65535, 65521), (40000, 65535), (65535, 2), (2, 65535), (65536, 65537),
+                                   (65537, 65536), (44100, 48000)])
+def test_resample_integer_path_extremes(gpu, rates):
+    """8/16-bit PCM with a reduced outrate below 65536 takes the exact 32-bit integer path; extreme sample values and
+    the largest admissible rates against live audioop (the 65536/65537 pairs take the float64 path)."""
+    i, o = rates
+    rng = np.random.default_rng(i * 7 + o)
+    for width in (2, 1):
+        lo, hi = -(1 << (8 * width - 1)), (1 << (8 * width - 1)) - 1
+        dt = {1: np.int8, 2: np.int16}[width]
+        for nch in (1, 2, 3, 4):
+            frames = 30011 if max(i, o) / min(i, o) < 100 else 40
+            x = rng.choice(np.array([lo, hi, -1, 0, 1, lo + 1, hi - 1], dtype=dt), size=frames * nch)
+            s = _sample(x, width, i, nch).resample(o)
+            want = audioop.ratecv(x.tobytes(), width, nch, i, o, None)[0]
+            assert bytes(s.view_frame_data()) == want, (width, nch)
+
+
 def test_resample_edge_cases(gpu):
     from synthesizer_amd.sample import Sample
     e = Sample(samplerate=48000, nchannels=2, samplewidth=2)

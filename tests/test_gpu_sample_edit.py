@@ -1,0 +1,150 @@
+"""GPU parity, SURVEY.md section 8(f) item 2 (continued): the editing operations of Sample -- clip / split / join /
+add_silence / delay, speed, at_volume, echo, envelope, modulate_amp -- against oracle/sample_oracle.py, which
+restates upstream's methods over bytes slicing and the live ``audioop`` module.  Bit-exact."""
+import numpy as np
+import pytest
+
+from oracle.sample_oracle import RefSample
+
+pytestmark = pytest.mark.gpu
+DT = {1: np.int8, 2: np.int16, 4: np.int32}
+
+
+def _rand(rng, width, n, scale=1.0):
+    info = np.iinfo(DT[width])
+    x = (rng.integers(info.min, info.max + 1, n, dtype=np.int64) * scale).astype(DT[width])
+    return x
+
+
+def _pair(x, width, rate, nch):
+    from synthesizer_amd.sample import Sample
+    return Sample.from_raw_frames(x.tobytes(), width, rate, nch), RefSample(x.tobytes(), width, rate, nch)
+
+
+def _same(s, r):
+    assert (s.samplewidth, s.samplerate, s.nchannels) == (r.samplewidth, r.samplerate, r.nchannels)
+    assert bytes(s.view_frame_data()) == r.frames
+
+
+@pytest.mark.parametrize("width,nch", [(2, 1), (2, 2), (1, 2), (4, 1)])
+def test_clip_split_join_silence_delay(gpu, width, nch):
+    rng = np.random.default_rng(width * 10 + nch)
+    rate = 8000
+    x = _rand(rng, width, 8000 * nch)             # 1 s
+    s, r = _pair(x, width, rate, nch)
+    _same(s.clip(0.1, 0.9), r.clip(0.1, 0.9))
+    rest_s, rest_r = s.split(0.5), r.split(0.5)
+    _same(s, r)
+    _same(rest_s, rest_r)
+    _same(s.add_silence(0.0125), r.add_silence(0.0125))
+    _same(s.add_silence(0.02, at_start=True), r.add_silence(0.02, at_start=True))
+    _same(s.join(rest_s), r.join(rest_r))
+    _same(s.delay(0.03), r.delay(0.03))
+    _same(s.delay(0.05, keep_length=True), r.delay(0.05, keep_length=True))
+    _same(s.delay(-0.04), r.delay(-0.04))
+    _same(s.delay(-0.02, keep_length=True), r.delay(-0.02, keep_length=True))
+    # split beyond the end and at zero; clip to nothing
+    e_s, e_r = s.split(10.0), r.split(10.0)
+    _same(e_s, e_r)
+    assert len(e_s) == 0
+    z_s, z_r = s.copy().split(0.0), r.copy().split(0.0)
+    _same(z_s, z_r)
+    _same(s.copy().clip(0.2, 0.2), r.copy().clip(0.2, 0.2))
+    # joining an empty sample changes nothing
+    _same(s.join(e_s), r.join(e_r))
+
+
+@pytest.mark.parametrize("width,nch", [(2, 1), (2, 2), (1, 1), (4, 2)])
+@pytest.mark.parametrize("speed", [0.5, 0.7937, 1.0, 1.25992, 2.0, 9.5])
+def test_speed(gpu, width, nch, speed):
+    rng = np.random.default_rng(int(speed * 1000) + width)
+    x = _rand(rng, width, 20011 * nch)
+    s, r = _pair(x, width, 44100, nch)
+    _same(s.speed(speed), r.speed(speed))
+    with pytest.raises(ValueError):
+        s.speed(11.0)
+    with pytest.raises(ValueError):
+        s.speed(0.05)
+
+
+def test_at_volume_leaves_original(gpu):
+    rng = np.random.default_rng(5)
+    x = _rand(rng, 2, 5000)
+    s, r = _pair(x, 2, 22050, 1)
+    s.lock()
+    _same(s.at_volume(0.3), r.at_volume(0.3))
+    _same(s, r)
+    with pytest.raises(RuntimeError):
+        s.amplify(0.3)
+
+
+@pytest.mark.parametrize("width,nch", [(2, 1), (2, 2), (1, 1), (4, 1)])
+def test_echo(gpu, width, nch):
+    rng = np.random.default_rng(width + nch)
+    x = _rand(rng, width, 16000 * nch, scale=0.4)      # 2 s at 8 kHz
+    for length, amount, delay, decay in ((0.5, 4, 0.3, 0.6), (1.0, 3, 0.05, 0.5), (0.2, 0, 0.1, 0.5),
+                                         (5.0, 2, 0.7, 0.9), (0.3, 40, 0.01, 0.5), (0.25, 3, 0.125, 1.2)):
+        s, r = _pair(x, width, 8000, nch)
+        _same(s.echo(length, amount, delay, decay), r.echo(length, amount, delay, decay))
+
+
+@pytest.mark.parametrize("width,nch", [(2, 1), (2, 2), (1, 1), (4, 1)])
+def test_envelope(gpu, width, nch):
+    rng = np.random.default_rng(width * 3 + nch)
+    x = _rand(rng, width, 8000 * nch)
+    for a, d, sl, rel in ((0.1, 0.2, 0.5, 0.3), (0.0, 0.1, 0.8, 0.1), (0.05, 0.0, 1.0, 0.0), (0.3, 0.3, 0.0, 0.3),
+                          (0.01, 0.02, 0.25, 0.9), (0.4, 0.4, 0.5, 0.4)):
+        s, r = _pair(x, width, 8000, nch)
+        _same(s.envelope(a, d, sl, rel), r.envelope(a, d, sl, rel))
+
+
+@pytest.mark.parametrize("width", [2, 1, 4])
+def test_modulate_amp_sample_and_sequences(gpu, width):
+    rng = np.random.default_rng(width)
+    x = _rand(rng, width, 30011)
+    # another sample as the modulator: cycled, scaled to a peak of 1.0 (includes the most negative value)
+    m = _rand(rng, 2, 777)
+    m[3] = -32768
+    s, r = _pair(x, width, 8000, 1)
+    ms, mr = _pair(m, 2, 8000, 1)
+    _same(s.modulate_amp(ms), r.modulate_amp(mr))
+    # a modulator longer than the sample
+    m2 = _rand(rng, 1, 50000)
+    s, r = _pair(x, width, 8000, 1)
+    ms, mr = _pair(m2, 1, 8000, 1)
+    _same(s.modulate_amp(ms), r.modulate_amp(mr))
+    # a list of numbers (normalised and cycled) and a plain iterator of factors (used as they are)
+    seq = [0.5, 2.0, -1.0, 0.25, 0.0]
+    s, r = _pair(x, width, 8000, 1)
+    _same(s.modulate_amp(seq), r.modulate_amp(list(seq)))
+    fac = rng.uniform(-1, 1, len(x)).tolist()
+    s, r = _pair(x, width, 8000, 1)
+    _same(s.modulate_amp(iter(fac)), r.modulate_amp(iter(fac)))
+    # empty sample: nothing happens
+    s, r = _pair(x[:0], width, 8000, 1)
+    _same(s.modulate_amp(seq), r)
+
+
+def test_modulate_amp_oscillator_and_overflow(gpu):
+    import itertools
+    from oracle import synth_oracle as O
+    from synthesizer_amd.oscillators import Sine
+    rng = np.random.default_rng(9)
+    x = _rand(rng, 2, 12000)
+    s, r = _pair(x, 2, 8000, 1)
+    osc = Sine(3.0, amplitude=0.8, bias=0.1, samplerate=8000)
+    ref_osc = O.Sine(3.0, amplitude=0.8, bias=0.1, samplerate=8000)
+    s.modulate_amp(osc)
+    r.modulate_amp(itertools.chain.from_iterable(ref_osc.blocks()))
+    got = np.frombuffer(bytes(s.view_frame_data()), dtype=np.int16).astype(np.int64)
+    want = np.frombuffer(r.frames, dtype=np.int16).astype(np.int64)
+    # the modulator is a float oscillator (device sin vs libm sin agree to ~1 ulp): a product within 1e-9 of an
+    # integer may truncate either way
+    assert np.abs(got - want).max() <= 1
+    assert (got != want).mean() < 1e-4
+    # a factor that pushes a sample out of range raises, as the array store does upstream
+    s, r = _pair(np.array([30000, -30000], dtype=np.int16), 2, 8000, 1)
+    with pytest.raises(OverflowError):
+        s.modulate_amp(iter([1.5, 1.5]))
+    with pytest.raises(OverflowError):
+        r.modulate_amp(iter([1.5, 1.5]))
