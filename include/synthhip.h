@@ -51,7 +51,10 @@ typedef enum sh_status {
 } sh_status;
 
 typedef enum sh_kind {     /* oscillators.py class names */
-    SH_SINE = 0, SH_SAWTOOTH = 1, SH_SQUARE = 2, SH_PULSE = 3, SH_HARMONICS = 4, SH_TRIANGLE = 5
+    SH_SINE = 0, SH_SAWTOOTH = 1, SH_SQUARE = 2, SH_PULSE = 3, SH_HARMONICS = 4, SH_TRIANGLE = 5,
+    SH_LINEAR = 6,         /* Linear: the sample IS the accumulated value of the phase table (level += increment until
+                            * it leaves (min, max); the host ends the table with a constant piece there) */
+    SH_NOISE = 7           /* WhiteNoise: sample-and-hold uniform noise from a counter-based generator, below */
 } sh_kind;
 
 typedef enum sh_fm_mode {
@@ -112,6 +115,11 @@ typedef struct sh_voice {
     double   lfo_a, lfo_d, lfo_amp, lfo_bias, lfo_K, lfo_C0;
     sh_envelope env;
     float    gain_l, gain_r;   /* stereo bus gains (bank only) */
+    /* SH_NOISE: sample n holds value number h = n / noise_hold; u = (splitmix64(noise_seed + h * 0x9E3779B97F4A7C15) >> 11)
+     * * 2^-53 in [0, 1); value = (-amplitude + (2*amplitude)*u) + bias   (random.uniform(-a, a) + bias) */
+    uint64_t noise_seed;
+    uint32_t noise_hold;       /* samples per held value, >= 1: int(samplerate / frequency) */
+    uint32_t reserved0;
 } sh_voice;
 
 typedef struct sh_devinfo {
@@ -184,7 +192,8 @@ int sh_osc_render(sh_bank* bank, uint32_t voice,
 /* ---- filters over rendered oscillator blocks: MixingFilter (a+b),
  *      AmpModulationFilter (a*b), ClipFilter (max(min(a, p1), p0)), AbsFilter (|a|), copy / constant fill.
  *      a, b, out_f64: float64 device buffers; out_f32 (+ element offset) / out_host: optional float32 copies */
-typedef enum sh_ew_op { SH_EW_ADD = 0, SH_EW_MUL = 1, SH_EW_CLIP = 2, SH_EW_ABS = 3, SH_EW_COPY = 4, SH_EW_FILL = 5 } sh_ew_op;
+typedef enum sh_ew_op { SH_EW_ADD = 0, SH_EW_MUL = 1, SH_EW_CLIP = 2, SH_EW_ABS = 3, SH_EW_COPY = 4, SH_EW_FILL = 5,
+                        SH_EW_AXPY = 6 /* a + b*p0 (product rounded first): EchoFilter */ } sh_ew_op;
 int sh_ew_f64(int op, const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, size_t n, double p0, double p1,
               sh_buf* out_f64, size_t out64_off, sh_buf* out_f32, size_t out32_off, float* out_host);
 

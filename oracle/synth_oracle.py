@@ -546,3 +546,98 @@ class DelayFilter(Oscillator):
             if not block:
                 return
             yield block
+
+
+class Linear(Oscillator):
+    """upstream: oscillators.py class Linear [RECALL]: the level is emitted, then incremented for as long as it lies
+    strictly between min_value and max_value."""
+
+    def __init__(self, startlevel: float, increment: float = 0.0, min_value: float = -1.0, max_value: float = 1.0,
+                 samplerate: int = 0) -> None:
+        super().__init__(samplerate)
+        self._value, self._increment, self._min, self._max = startlevel, increment, min_value, max_value
+
+    def blocks(self):
+        value, increment, minv, maxv = self._value, self._increment, self._min, self._max
+        while True:
+            block = []
+            for _ in range(norm_osc_blocksize):
+                block.append(value)
+                if minv < value < maxv:
+                    value += increment
+            yield block
+
+
+_M64 = (1 << 64) - 1
+
+
+def splitmix64(x: int) -> int:
+    """Steele, Lea & Flood's SplitMix64 output function (public domain reference: xoshiro.di.unimi.it/splitmix64.c)."""
+    z = x & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+class WhiteNoise(Oscillator):
+    """upstream: oscillators.py class WhiteNoise [RECALL]: ``random.uniform(-amplitude, amplitude) + bias`` drawn once per
+    int(samplerate/frequency) samples and held.  Upstream draws from the global Mersenne Twister (not reproducible, and
+    sequential); this build defines the draw as a counter-based generator instead -- value h uses
+    u = (splitmix64(seed + h*0x9E3779B97F4A7C15) >> 11) * 2**-53 -- which is what this class restates.
+    random.uniform(a, b) is a + (b-a)*random()."""
+
+    def __init__(self, frequency: float, amplitude: float = 1.0, bias: float = 0.0, samplerate: int = 0, seed: int = 0) -> None:
+        super().__init__(samplerate)
+        self.frequency, self.amplitude, self.bias, self.seed = frequency, amplitude, bias, seed
+
+    def blocks(self):
+        cycles = int(self.samplerate / self.frequency)
+        if cycles < 1:
+            raise ValueError("whitenoise frequency cannot be bigger than the sample rate")
+        a, b = -self.amplitude, self.amplitude
+        n = 0
+        while True:
+            block = []
+            for _ in range(norm_osc_blocksize):
+                h = n // cycles
+                u = (splitmix64(self.seed + h * 0x9E3779B97F4A7C15) >> 11) * 2.0 ** -53
+                block.append((a + (b - a) * u) + self.bias)
+                n += 1
+            yield block
+
+
+class EchoFilter(Oscillator):
+    """upstream: oscillators.py class EchoFilter [RECALL]: the source plays alone for int(samplerate*after) samples; from
+    there on `amount` copies of the remaining stream (itertools.tee) are mixed in, copy i delayed by
+    int(samplerate*echo_delay) zeros (echo_delay accumulates `delay`) and scaled by the running product of `decay`."""
+
+    def __init__(self, source: Oscillator, after: float, amount: int, delay: float, decay: float) -> None:
+        super().__init__(source.samplerate)
+        if decay < 0 or decay > 1:
+            raise ValueError("decay should be 0-1")
+        self._source, self._after, self._amount, self._delay, self._decay = source, after, amount, delay, decay
+        self.echo_duration = after + amount * delay
+
+    def _samples(self):
+        src = itertools.chain.from_iterable(self._source.blocks())
+        for _ in range(int(self.samplerate * self._after)):
+            yield next(src)
+        copies = itertools.tee(src, max(0, self._amount) + 1)
+        streams = [copies[0]]
+        amp = self._decay
+        echo_delay = self._delay
+        for echo in copies[1:]:
+            zeros = [0.0] * int(self.samplerate * echo_delay)
+            streams.append(itertools.chain(zeros, (lambda e, a: (v * a for v in e))(echo, amp)))
+            echo_delay += self._delay
+            amp *= self._decay
+        for values in zip(*streams):
+            yield sum(values)
+
+    def blocks(self):
+        samples = self._samples()
+        while True:
+            block = list(itertools.islice(samples, norm_osc_blocksize))
+            if not block:
+                return
+            yield block

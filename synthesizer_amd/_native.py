@@ -17,8 +17,8 @@ LIB_PATH = Path(os.environ.get("SYNTHHIP_LIB", HERE / "libsynthhip.so"))
 
 SH_OK = 0
 SH_ERR_INVALID, SH_ERR_HIP, SH_ERR_NOMEM, SH_ERR_NOTINIT, SH_ERR_OVERFLOW, SH_ERR_RCCL, SH_ERR_LENGTH = -1, -2, -3, -4, -5, -6, -7
-SH_SINE, SH_SAWTOOTH, SH_SQUARE, SH_PULSE, SH_HARMONICS, SH_TRIANGLE = range(6)
-SH_EW_ADD, SH_EW_MUL, SH_EW_CLIP, SH_EW_ABS, SH_EW_COPY, SH_EW_FILL = range(6)
+SH_SINE, SH_SAWTOOTH, SH_SQUARE, SH_PULSE, SH_HARMONICS, SH_TRIANGLE, SH_LINEAR, SH_NOISE = range(8)
+SH_EW_ADD, SH_EW_MUL, SH_EW_CLIP, SH_EW_ABS, SH_EW_COPY, SH_EW_FILL, SH_EW_AXPY = range(7)
 SH_FM_NONE, SH_FM_SINE, SH_FM_BUFFER = range(3)
 SH_DIST_ID_BYTES = 128
 
@@ -49,11 +49,12 @@ VOICE_DTYPE = np.dtype([
     ("time_seg_offset", "<u4"), ("time_seg_count", "<u4"),
     ("lfo_a", "<f8"), ("lfo_d", "<f8"), ("lfo_amp", "<f8"), ("lfo_bias", "<f8"), ("lfo_K", "<f8"), ("lfo_C0", "<f8"),
     ("env", ENVELOPE_DTYPE),
-    ("gain_l", "<f4"), ("gain_r", "<f4")], align=True)
+    ("gain_l", "<f4"), ("gain_r", "<f4"),
+    ("noise_seed", "<u8"), ("noise_hold", "<u4"), ("reserved0", "<u4")], align=True)
 
 # sizes the C side must agree with (checked against the library's view in tests via sh_bank_create)
 assert SEGMENT_DTYPE.itemsize == 24 and PARTIAL_DTYPE.itemsize == 16 and ENVELOPE_DTYPE.itemsize == 80
-assert VOICE_DTYPE.itemsize == 224, VOICE_DTYPE.itemsize
+assert VOICE_DTYPE.itemsize == 240, VOICE_DTYPE.itemsize
 
 
 class DevInfo(C.Structure):

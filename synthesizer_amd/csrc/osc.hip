@@ -402,6 +402,26 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
 #pragma unroll
             for (int j = 0; j < FPL; ++j) x[j] = shm::triangle_value(th[j], 4.0 * r.amplitude, r.bias);
             break;
+        case SH_LINEAR:
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = th[j];
+            break;
+        case SH_NOISE: {
+            const uint64_t seed = vfull->noise_seed;
+            const uint32_t hold = vfull->noise_hold;
+            const double a2 = r.amplitude * 2.0;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                const uint64_t n = start + i[j];
+                const uint64_t h = n <= 0xFFFFFFFFull ? (uint64_t)((uint32_t)n / hold) : n / hold;
+                uint64_t z = seed + h * 0x9E3779B97F4A7C15ull;                  // splitmix64 of the held-value counter
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                z ^= z >> 31;
+                const double u = (double)(z >> 11) * 0x1.0p-53;
+                x[j] = (-r.amplitude + a2 * u) + r.bias;
+            }
+        } break;
         case SH_PULSE: {
             const double pw = r.rec->pulsewidth;
 #pragma unroll
@@ -765,6 +785,7 @@ __global__ __launch_bounds__(256) void k_ew_f64(int op, const double* a, const d
     case SH_EW_CLIP: { double t = a[i] < p1 ? a[i] : p1; v = t > p0 ? t : p0; } break;    // max(min(v, maximum), minimum)
     case SH_EW_ABS: v = fabs(a[i]); break;
     case SH_EW_COPY: v = a[i]; break;
+    case SH_EW_AXPY: { const double e = b[i] * p0; v = a[i] + e; } break;
     default: v = p0; break;
     }
     if (out64) out64[i] = v;
@@ -906,8 +927,12 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     if (!segs || nsegs == 0) return sh::set_error(SH_ERR_INVALID, "sh_bank_create: no phase tables");
     for (uint32_t i = 0; i < nvoices; ++i) {
         const sh_voice& v = voices[i];
-        if (v.kind < SH_SINE || v.kind > SH_TRIANGLE)
+        if (v.kind < SH_SINE || v.kind > SH_NOISE)
             return sh::set_error(SH_ERR_INVALID, "voice %u: unknown kind %d", i, v.kind);
+        if (v.kind == SH_NOISE && v.noise_hold == 0)
+            return sh::set_error(SH_ERR_INVALID, "voice %u: noise_hold must be >= 1", i);
+        if ((v.kind == SH_NOISE || v.kind == SH_LINEAR) && v.fm_mode != SH_FM_NONE)
+            return sh::set_error(SH_ERR_INVALID, "voice %u: kind %d has no FM form", i, v.kind);
         if (v.fm_mode < SH_FM_NONE || v.fm_mode > SH_FM_BUFFER)
             return sh::set_error(SH_ERR_INVALID, "voice %u: unknown fm_mode %d", i, v.fm_mode);
         uint32_t off = v.fm_mode ? v.time_seg_offset : v.seg_offset;
@@ -1223,8 +1248,8 @@ int sh_bus_finalize(const sh_buf* bus_f64, size_t nvalues, sh_buf* bus_f32) {
 int sh_ew_f64(int op, const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, size_t n, double p0, double p1,
               sh_buf* out_f64, size_t out64_off, sh_buf* out_f32, size_t out32_off, float* out_host) {
     SH_REQUIRE_INIT();
-    if (op < SH_EW_ADD || op > SH_EW_FILL) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: unknown op %d", op);
-    const bool need_a = op != SH_EW_FILL, need_b = op == SH_EW_ADD || op == SH_EW_MUL;
+    if (op < SH_EW_ADD || op > SH_EW_AXPY) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: unknown op %d", op);
+    const bool need_a = op != SH_EW_FILL, need_b = op == SH_EW_ADD || op == SH_EW_MUL || op == SH_EW_AXPY;
     if (need_a && (!a || a_off > a->bytes / 8 || n > a->bytes / 8 - a_off)) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: operand a too small");
     if (need_b && (!b || b_off > b->bytes / 8 || n > b->bytes / 8 - b_off)) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: operand b too small");
     if (out_f64 && (out64_off > out_f64->bytes / 8 || n > out_f64->bytes / 8 - out64_off)) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: out_f64 too small");

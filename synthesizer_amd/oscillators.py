@@ -31,7 +31,8 @@ from . import _native as N
 from .phasetable import PhaseTable
 
 __all__ = ["Oscillator", "Sine", "Triangle", "Sawtooth", "Square", "Pulse", "Harmonics", "SquareH", "SawtoothH",
-           "EnvelopeFilter", "MixingFilter", "AmpModulationFilter", "ClipFilter", "AbsFilter", "NullFilter", "DelayFilter"]
+           "Linear", "WhiteNoise", "EnvelopeFilter", "MixingFilter", "AmpModulationFilter", "ClipFilter", "AbsFilter",
+           "NullFilter", "DelayFilter", "EchoFilter"]
 
 _SUPERBLOCK = 128          # blocks rendered per kernel launch behind blocks()
 _DENSE_MAX_K = 4096        # Harmonics: use the Clenshaw (dense) form when max k <= min(this, 8*len+64)
@@ -144,6 +145,8 @@ class VoiceSpec:
     env: Optional[EnvelopeSpec] = None
     needs_pwm: bool = False
     flip: bool = False                                  # SawtoothH mirrors the wave around the bias
+    noise_seed: int = 0                                 # WhiteNoise
+    noise_hold: int = 0
 
 
 def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float, float]]] = None):
@@ -207,6 +210,8 @@ def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float
             v["harm_count"] = len(s.harm_sparse)
             v["harm_dense"] = 0
         v["flip"] = 1 if s.flip else 0
+        v["noise_seed"] = s.noise_seed & 0xFFFFFFFFFFFFFFFF
+        v["noise_hold"] = s.noise_hold
         if s.env is not None:
             e = v["env"]
             e["n_attack_end"], e["n_decay_end"] = s.env.n_attack_end, s.env.n_decay_end
@@ -457,6 +462,71 @@ class Pulse(_Carrier):
                          pulsewidth=float(self.pulsewidth), needs_pwm=self.pwm is not None, **fields)
 
 
+class _StoppedTable(PhaseTable):
+    """A running sum that stops changing at sample `stop`: the pieces of `base` before it, then a constant piece."""
+
+    def __init__(self, base: PhaseTable, stop: int) -> None:      # noqa: super().__init__ not called on purpose
+        self.t0, self.inc = base.t0, base.inc
+        self.segments = [seg for seg in base.segments if seg[0] < stop] + [(stop, base.value(stop), 0.0)]
+        self._starts = [seg[0] for seg in self.segments]
+
+
+class Linear(Oscillator):
+    """Linear ramp; a constant if the increment is 0 (upstream: oscillators.py class Linear).  The level grows by
+    `increment` per sample (accumulated in float64, like upstream's running sum) for as long as it lies strictly
+    between min_value and max_value, then stays where it is."""
+
+    def __init__(self, startlevel: float, increment: float = 0.0, min_value: float = -1.0, max_value: float = 1.0,
+                 samplerate: int = 0) -> None:
+        super().__init__(samplerate)
+        self._value = startlevel
+        self._increment = increment
+        self._min = min_value
+        self._max = max_value
+
+    def _make_spec(self) -> VoiceSpec:
+        v, inc, lo, hi = float(self._value), float(self._increment), float(self._min), float(self._max)
+        table = _table(v, inc)
+        stop = None
+        if not lo < v < hi:
+            stop = 0
+        elif inc > 0.0:
+            try:
+                stop = table.first_index_ge(hi)
+            except OverflowError:
+                stop = None                      # the sum saturates below max_value
+        elif inc < 0.0:
+            try:
+                stop = _table(-v, -inc).first_index_ge(-lo)        # float addition is symmetric under negation
+            except OverflowError:
+                stop = None
+        if stop is not None and stop < (1 << 62):
+            table = _StoppedTable(table, stop)
+        return VoiceSpec(kind=N.SH_LINEAR, amplitude=1.0, bias=0.0, fm_mode=N.SH_FM_NONE, carrier=table)
+
+
+class WhiteNoise(Oscillator):
+    """White noise: a new uniform random value in [-amplitude, amplitude) + bias every int(samplerate/frequency)
+    samples, held in between (upstream: oscillators.py class WhiteNoise, which draws from Python's global Mersenne
+    Twister).  Here the values come from a counter-based generator -- splitmix64 of (seed + value index) -- so that any
+    sample range can be rendered in parallel and reproducibly; `seed` is this build's addition."""
+
+    def __init__(self, frequency: float, amplitude: float = 1.0, bias: float = 0.0, samplerate: int = 0,
+                 seed: int = 0) -> None:
+        super().__init__(samplerate)
+        self.frequency = frequency
+        self.amplitude = amplitude
+        self.bias = bias
+        self.seed = seed
+
+    def _make_spec(self) -> VoiceSpec:
+        cycles = int(self.samplerate / self.frequency)
+        if cycles < 1:
+            raise ValueError("whitenoise frequency cannot be bigger than the sample rate")
+        return VoiceSpec(kind=N.SH_NOISE, amplitude=float(self.amplitude), bias=float(self.bias), fm_mode=N.SH_FM_NONE,
+                         carrier=_table(0.0, 0.0), noise_seed=int(self.seed), noise_hold=cycles)
+
+
 class Harmonics(_Carrier):
     """Additive sine series sum_k a_k sin(k*t) (upstream: oscillators.py class Harmonics)."""
     KIND = N.SH_HARMONICS
@@ -526,8 +596,8 @@ class EnvelopeFilter(Oscillator):
         assert attack >= 0 and decay >= 0 and sustain >= 0 and release >= 0
         assert 0 <= sustain_level <= 1
         super().__init__(source.samplerate)
-        if not isinstance(source, _Carrier):
-            raise NotImplementedError("EnvelopeFilter is fused into Sine/Sawtooth/Square/Pulse/Harmonics sources only")
+        if not isinstance(source, (_Carrier, Linear, WhiteNoise)):
+            raise NotImplementedError("EnvelopeFilter is fused into waveform sources only (not into other filters)")
         self._source = source
         self._attack = attack
         self._decay = decay
@@ -688,3 +758,48 @@ class DelayFilter(_Filter):
             N.sync()
             src.free()
         return out
+
+
+class EchoFilter(_Filter):
+    """Mixes `amount` echos of the source into itself, starting `after` seconds in: echo i (1-based) is the source
+    from that point on, delayed by int(samplerate * (delay + ... + delay)) samples (i terms, accumulated) and scaled
+    by decay**i (a running product); per sample the values are summed left to right
+    (upstream: oscillators.py class EchoFilter)."""
+
+    def __init__(self, source: Oscillator, after: float, amount: int, delay: float, decay: float) -> None:
+        super().__init__([source])
+        if decay < 0 or decay > 1:
+            raise ValueError("decay should be 0-1")
+        self._after = after
+        self._amount = amount
+        self._delay = delay
+        self._decay = decay
+        self.echo_duration = self._after + self._amount * self._delay
+
+    def _taps(self) -> List[Tuple[int, float]]:
+        """(first sample index the echo sounds at - its source index offset, amplitude) per echo."""
+        taps = []
+        amp = self._decay
+        echo_delay = self._delay
+        for _ in range(max(0, self._amount)):
+            taps.append((int(self.samplerate * echo_delay), amp))
+            echo_delay += self._delay
+            amp *= self._decay
+        return taps
+
+    def _f64(self, start: int, n: int) -> N.DeviceBuffer:
+        src = self._sources[0]
+        acc = src._render_f64_device(start, n)
+        after = int(self.samplerate * self._after)
+        L = N.lib()
+        for shift, amp in self._taps():
+            first = max(start, after + shift)             # the echo is silent before `after` + its delay
+            count = start + n - first
+            if count <= 0:
+                continue
+            echo = src._render_f64_device(first - shift, count)
+            N.check(L.sh_ew_f64(N.SH_EW_AXPY, acc.handle, first - start, echo.handle, 0, count, float(amp), 0.0,
+                                acc.handle, first - start, None, 0, None))
+            N.sync()
+            echo.free()
+        return acc

@@ -43,15 +43,16 @@ def test_struct_layouts_match_the_header(tmp_path):
     from synthesizer_amd import _native as N
     src = tmp_path / "sz.c"
     src.write_text('#include "%s"\n#include <stdio.h>\n#include <stddef.h>\n'
-                   'int main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(sh_segment), sizeof(sh_partial),'
+                   'int main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(sh_segment), sizeof(sh_partial),'
                    'sizeof(sh_envelope), sizeof(sh_voice), offsetof(sh_voice, env), offsetof(sh_voice, gain_l),'
-                   'offsetof(sh_voice, frequency), sizeof(sh_devinfo));return 0;}\n' % HEADER)
+                   'offsetof(sh_voice, frequency), sizeof(sh_devinfo), offsetof(sh_voice, noise_seed), offsetof(sh_voice, noise_hold));return 0;}\n' % HEADER)
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", str(src), "-o", str(exe)], check=True)      # the header is plain C
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     V = N.VOICE_DTYPE
     want = [N.SEGMENT_DTYPE.itemsize, N.PARTIAL_DTYPE.itemsize, N.ENVELOPE_DTYPE.itemsize, V.itemsize,
-            V.fields["env"][1], V.fields["gain_l"][1], V.fields["frequency"][1], ctypes.sizeof(N.DevInfo)]
+            V.fields["env"][1], V.fields["gain_l"][1], V.fields["frequency"][1], ctypes.sizeof(N.DevInfo),
+            V.fields["noise_seed"][1], V.fields["noise_hold"][1]]
     assert got == want
 
 

@@ -373,3 +373,88 @@ def test_randomised_voices_vs_c_oracle(gpu):
             worst = max(worst, e)
             assert e <= RMS_TOL, (case, kind, e)
     assert worst < 1e-7
+
+
+@pytest.mark.parametrize("args", [(0.0, 0.3, -1.0, 1.0), (0.5, -0.4, -1.0, 1.0), (0.0, 1e-5, -1.0, 1.0), (0.25, 0.0, -1.0, 1.0),
+                                  (0.9, -3.3e-6, 0.0, 1.0), (2.0, 0.1, -1.0, 1.0), (-0.5, 1.0 / 48000, -1.0, 0.25),
+                                  (1e-3, 1e-9, -1.0, 1.0), (0.0, 0.1, -1.0, 1e30)])
+def test_linear_is_bit_exact(gpu, args):
+    """Linear.  The level is a float64 running sum; the phase table reproduces it exactly, so the
+    float32 output equals the oracle's sequential loop bit for bit -- also deep into the stream and past the stop."""
+    g, o = _pair("Linear", *args, samplerate=SR)
+    n = 250000
+    want = np.array(o.take(n), dtype=np.float64)
+    got = g.render(n, start=0)
+    assert np.array_equal(got, want.astype(np.float32)), int(np.sum(got != want.astype(np.float32)))
+    assert np.array_equal(g.render(777, start=199000), want[199000:199777].astype(np.float32))
+    # as a modulator (float64 path) and inside a bank with an envelope
+    from synthesizer_amd import oscillators as G
+    am_g = G.AmpModulationFilter(G.Sine(100.0, samplerate=SR), g)
+    am_o = O.AmpModulationFilter(O.Sine(100.0, samplerate=SR), O.Linear(*args, samplerate=SR))
+    ref = np.array(am_o.take(5000))
+    assert rms(am_g.render(5000), ref) <= RMS_TOL * max(1.0, float(np.abs(ref).max()))      # float32 output: relative
+
+
+def test_white_noise_counter_based(gpu):
+    """WhiteNoise with a counter-based generator: bit-exact against the oracle's restatement,
+    random access equals streaming, different seeds differ, the values are uniform over [-a, a) + bias."""
+    from synthesizer_amd import oscillators as G
+    for freq, amp, bias, sr, seed in ((48000.0, 1.0, 0.0, 48000, 0), (4410.0, 0.5, 0.1, 44100, 3), (1000.0, 0.25, -0.5, 48000, 2 ** 63 + 5),
+                                      (7.0, 1.0, 0.0, 8000, 12345)):
+        g = G.WhiteNoise(freq, amp, bias, samplerate=sr, seed=seed)
+        o = O.WhiteNoise(freq, amp, bias, samplerate=sr, seed=seed)
+        n = 30000
+        want = np.array(o.take(n), dtype=np.float64)
+        got = g.render(n, start=0)
+        assert np.array_equal(got, want.astype(np.float32))
+        assert np.array_equal(g.render(1234, start=20000), got[20000:21234])
+        hold = int(sr / freq)
+        assert np.all(got[:hold] == got[0])
+        assert want.min() >= -amp + bias and want.max() < amp + bias
+    a = G.WhiteNoise(48000.0, samplerate=48000, seed=1).render(200000)
+    b = G.WhiteNoise(48000.0, samplerate=48000, seed=2).render(200000)
+    assert not np.array_equal(a, b)
+    assert abs(float(a.mean())) < 0.01 and abs(float(a.astype(np.float64).var()) - 1.0 / 3.0) < 0.01
+    hist = np.histogram(a, bins=16, range=(-1, 1))[0]
+    assert hist.min() > 0.9 * len(a) / 16
+    # far into the stream (sample index above 2^32): the 64-bit counter path
+    g = G.WhiteNoise(12000.0, samplerate=48000, seed=9)
+    far = (1 << 33) + 12345
+    want = []
+    for k in range(64):
+        h = (far + k) // 4
+        u = (O.splitmix64(9 + h * 0x9E3779B97F4A7C15) >> 11) * 2.0 ** -53
+        want.append((-1.0 + 2.0 * u) + 0.0)
+    assert np.array_equal(g.render(64, start=far), np.array(want).astype(np.float32))
+    with pytest.raises(ValueError):
+        G.WhiteNoise(50000.0, samplerate=48000).render(10)
+    # noise voices in a bank, with an envelope
+    from synthesizer_amd.mixer import VoiceBank
+    env_g = G.EnvelopeFilter(G.WhiteNoise(6000.0, 0.5, samplerate=SR, seed=4), 0.01, 0.01, 0.02, 0.5, 0.02)
+    env_o = O.EnvelopeFilter(O.WhiteNoise(6000.0, 0.5, samplerate=SR, seed=4), 0.01, 0.01, 0.02, 0.5, 0.02)
+    bus = VoiceBank([env_g], gains=[(1.0, 0.5)]).render(4000)
+    ref = np.array(env_o.take(4000))
+    assert rms(bus[:, 0], ref) <= RMS_TOL and rms(bus[:, 1], ref * 0.5) <= RMS_TOL
+
+
+def test_echo_filter(gpu):
+    """EchoFilter."""
+    from synthesizer_amd import oscillators as G
+
+    def build(M, after, amount, delay, decay):
+        src = M.EnvelopeFilter(M.Sine(440.0, 0.6, samplerate=SR), 0.005, 0.01, 0.01, 0.5, 0.02)
+        return M.EchoFilter(src, after, amount, delay, decay)
+
+    for after, amount, delay, decay in ((0.01, 3, 0.02, 0.5), (0.0, 5, 0.003, 0.9), (0.05, 1, 0.0, 1.0), (0.02, 0, 0.1, 0.5),
+                                        (0.0301, 4, 0.0107, 0.33)):
+        g, o = build(G, after, amount, delay, decay), build(O, after, amount, delay, decay)
+        n = 9000
+        got = g.render(n)
+        want = np.array(o.take(n))
+        assert rms(got, want) <= RMS_TOL, (after, amount, delay, decay)
+        assert np.max(np.abs(got - want)) < 3e-7
+        # random access: the same samples up to float64 rounding of the source (its evaluation depends on the launch start)
+        assert np.max(np.abs(g.render(700, start=3000) - got[3000:3700])) < 1e-7
+        assert g.echo_duration == o.echo_duration
+    with pytest.raises(ValueError):
+        G.EchoFilter(G.Sine(1.0), 0.1, 2, 0.1, 1.5)

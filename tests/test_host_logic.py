@@ -153,3 +153,30 @@ def test_note_tables():
     assert S.major_chord_keys("C", 4) == (40, 44, 47) and S.major_chord_keys("G", 4) == (47, 51, 54)
     with pytest.raises(ValueError):
         S.WaveSynth(samplewidth=3)
+
+
+@pytest.mark.parametrize("args", [(0.0, 0.3, -1.0, 1.0), (0.5, -0.4, -1.0, 1.0), (0.0, 1e-5, -1.0, 1.0), (0.25, 0.0, -1.0, 1.0),
+                                  (0.9, -3.3e-6, 0.0, 1.0), (2.0, 0.1, -1.0, 1.0), (-1.0, 0.1, -1.0, 1.0), (1e-3, 1e-9, -1.0, 1.0)])
+def test_linear_table_replays_the_running_sum(args):
+    """Linear: the (stopped) phase table gives the oracle's level at every sample, exactly."""
+    from oracle import synth_oracle as O
+    from synthesizer_amd.oscillators import Linear
+    spec = Linear(*args, samplerate=48000).spec()
+    n = 400000
+    want = O.Linear(*args, samplerate=48000).take(n)
+    tab = spec.carrier
+    for k in list(range(0, 64)) + list(range(64, n, 997)) + [n - 1]:
+        assert tab.value(k) == want[k], k
+    assert tab.segments[0][0] == 0
+    if want[-1] == want[-2]:                       # stopped: the table ends with a constant piece
+        assert tab.segments[-1][2] == 0.0
+
+
+def test_white_noise_spec():
+    from synthesizer_amd.oscillators import WhiteNoise, EnvelopeFilter
+    s = WhiteNoise(4410.0, 0.5, 0.1, samplerate=44100, seed=-1).spec()
+    assert (s.kind, s.noise_hold, s.amplitude, s.bias) == (N.SH_NOISE, 10, 0.5, 0.1)
+    v = G.pack_voices([EnvelopeFilter(WhiteNoise(100.0, samplerate=8000, seed=2 ** 64 + 7), 0.1, 0.1, 0.1, 0.5, 0.1).spec()])[0]
+    assert int(v["noise_seed"][0]) == 7 and int(v["noise_hold"][0]) == 80 and v["env"]["enabled"][0] == 1
+    with pytest.raises(ValueError):
+        WhiteNoise(10000.0, samplerate=8000).spec()

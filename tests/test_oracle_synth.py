@@ -75,3 +75,26 @@ def test_quantise_rule():
     assert O.quantise([1.0], 1) == [127] and O.quantise([-1.0], 4) == [-(2 ** 31 - 1)]
     with pytest.raises(OverflowError):
         O.quantise([1.0001])
+
+
+def test_splitmix64_known_answers_and_noise():
+    """The counter-based generator behind WhiteNoise: SplitMix64's published first outputs for seed 0."""
+    assert O.splitmix64(0x9E3779B97F4A7C15) == 0xE220A8397B1DCDAF
+    assert O.splitmix64((2 * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)) == 0x6E789E6AA1B965F4
+    x = O.WhiteNoise(4410.0, 0.5, 0.1, samplerate=44100, seed=3).take(2000)
+    assert all(x[i] == x[i - i % 10] for i in range(2000))            # held for int(44100/4410) = 10 samples
+    assert len(set(x)) == 200 and -0.4 <= min(x) and max(x) < 0.6
+    assert x == O.WhiteNoise(4410.0, 0.5, 0.1, samplerate=44100, seed=3).take(2000)
+    assert x != O.WhiteNoise(4410.0, 0.5, 0.1, samplerate=44100, seed=4).take(2000)
+
+
+def test_linear_and_echo_known_answers():
+    assert O.Linear(0.0, 0.25, -1, 1).take(7) == [0.0, 0.25, 0.5, 0.75, 1.0, 1.0, 1.0]
+    assert O.Linear(0.5, -0.5, -1, 1).take(6) == [0.5, 0.0, -0.5, -1.0, -1.0, -1.0]
+    assert O.Linear(3.0, 0.5, -1, 1).take(3) == [3.0, 3.0, 3.0]
+    assert O.Linear(0.25, 0.0).take(3) == [0.25, 0.25, 0.25]
+    # a constant source: plays alone for 3 samples, then echos at +2 and +4 samples at 0.5 and 0.25
+    e = O.EchoFilter(O.Linear(1.0, 0.0, samplerate=10), 0.3, 2, 0.2, 0.5)
+    assert e.take(10) == [1.0, 1.0, 1.0, 1.0, 1.0, 1.5, 1.5, 1.75, 1.75, 1.75]
+    assert e.echo_duration == 0.3 + 2 * 0.2
+    assert O.EchoFilter(O.Linear(0.0, 1.0, -1e9, 1e9, samplerate=10), 0.0, 1, 0.1, 1.0).take(5) == [0.0, 1.0, 3.0, 5.0, 7.0]
