@@ -238,9 +238,10 @@ def main() -> int:
     value = voice_samples / wall / 1e6
     kern_s = ev_ms / 1e3 / K         # average duration of one block (k_locate + k_bank_render [+ reduce/finalize])
     fused_bytes = 8.0 * F            # algorithmic: one float32 stereo frame written per output frame
-    # float64 VALU instructions per voice-sample of k_bank_render on this workload, from rocprofv3
-    # (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 / voice-samples * 64; profiles/r01_pmc_bank_render.md)
-    harm_lane_ops = 34.2
+    # float64 VALU lane-operations per voice-sample of k_bank_render on this workload, from rocprofv3:
+    # (SQ_INSTS_VALU_FMA_F64 + MUL_F64 + ADD_F64) * 64 / voice-samples per launch = 23.42 M * 64 / 49.152 M
+    # (profiles/r01_summary.md, "SQ instruction mix"; all VALU: 39.3 per voice-sample)
+    harm_lane_ops = 30.5
     out = {
         "metric": "Msamples/sec mixed to stereo bus, 1024-voice additive @48kHz",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -311,12 +312,15 @@ def main() -> int:
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if world > 1:
         barrier()
         dist.shutdown()
         td.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # C stdio of the loaded libraries (RCCL's banner) goes out first
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)      # last, so that nothing a library prints on teardown follows it
     return 0
 
 

@@ -8,6 +8,7 @@
 #include "common.hpp"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <stdio.h>
 #include <string.h>
 
 namespace {
@@ -91,6 +92,7 @@ int sh_dist_init(int rank, int world, const void* id128) {
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     SH_RCCL(r.CommInitRank(&r.comm, world, id, rank));
+    fflush(stdout);      // RCCL prints a version banner through stdio: push it out now, not at exit after the caller's output
     r.rank = rank;
     r.world = world;
     SH_HIP(hipMalloc((void**)&r.token, sizeof(double)));

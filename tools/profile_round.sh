@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for one round on the GPU box:  tools/profile_round.sh r01
+# (run through gpurun from the repo root; afterwards, here: python tools/summarize_profiles.py gpurun_out/prof_r01 r01)
+# Kernel durations and counters are separate runs: --pmc is never combined with a runtime / sys trace.
+set -u
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+D=gpurun_out/prof_$TAG
+rm -rf "$D"; mkdir -p "$D"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o stats -- \
+    python bench.py --steps 100 --warmup 5 --cpu-frames 0 > gpurun_out/prof_${TAG}_bench.json 2> gpurun_out/prof_${TAG}_stats.err
+SHORT="python bench.py --steps 10 --warmup 2 --cpu-frames 0"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$D" -o fetch -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$D" -o write -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_WAVES SQ_WAVE_CYCLES \
+    --output-format csv -d "$D" -o sq1 -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES \
+    --output-format csv -d "$D" -o sq2 -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
+rm -f "$D"/*_kernel_trace.csv "$D"/*_domain_stats.csv          # large; the stats and counter tables are what is summarised
+ls -la "$D"
