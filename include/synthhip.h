@@ -265,6 +265,16 @@ int sh_resample(const sh_buf* in, size_t in_frames, int nchannels, int width, in
                 int inrate, int outrate, sh_buf* out, size_t* out_frames);
 int sh_resample_host(const void* in, size_t in_frames, int nchannels, int width, int is_float,
                      int inrate, int outrate, void* out, size_t* out_frames);
+/* Sharding Sample.resample by output-frame range (no collective, a halo of one input frame).
+ * sh_resample_span: the input frames [*in_first, *in_first + *in_count) that output frames [out_first, out_first +
+ * out_n) of a stream of in_total_frames read (*in_first rounded down to a multiple of 16).  Host-only arithmetic.
+ * sh_resample_range: resample that output range from a buffer holding input frames [in_first, in_first + in_held)
+ * into out[0 .. out_n); out_first and in_first must be multiples of 16 frames.  Concatenating the ranges of a
+ * partition gives sh_resample's result bit for bit. */
+int sh_resample_span(size_t in_total_frames, int inrate, int outrate, size_t out_first, size_t out_n,
+                     size_t* in_first, size_t* in_count);
+int sh_resample_range(const sh_buf* in, size_t in_first, size_t in_held, int nchannels, int width, int is_float,
+                      int inrate, int outrate, size_t out_first, size_t out_n, sh_buf* out);
 
 /* ---- multi-GPU: voice-sharded banks, partial buses summed by RCCL over xGMI ------------ */
 #define SH_DIST_ID_BYTES 128

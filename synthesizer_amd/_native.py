@@ -111,6 +111,8 @@ _SIGNATURES = {
     "sh_pcm_stats": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
     "sh_resample_out_frames": (C.c_size_t, [C.c_size_t, C.c_int, C.c_int]),
     "sh_resample": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_size_t)]),
+    "sh_resample_span": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "sh_resample_range": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, _P]),
     "sh_resample_host": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_size_t)]),
     "sh_dist_unique_id": (C.c_int, [_P]),
     "sh_dist_init": (C.c_int, [C.c_int, C.c_int, _P]),

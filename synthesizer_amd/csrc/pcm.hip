@@ -178,6 +178,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __res
 // arithmetic to the reference's state machine, evaluated in closed form.
 struct RatecvArgs {
     uint64_t n_out_samples;     // out_frames * nch
+    uint64_t m_base;            // output frame index of the launch's first frame (range launches; else 0)
     uint32_t nch;
     uint32_t inr, outr;
     uint32_t step_q, step_r;    // inr / outr and inr % outr: output frame m+1 starts (step_q, step_r) after frame m
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256) void k_resample(const T* __restrict__ in, T* _
     if (groups == 1) { m = u; cg = 0; }
     else if (u < 0xFFFFFFFFull) { uint32_t u32 = (uint32_t)u; uint32_t m32 = u32 / groups; m = m32; cg = u32 - m32 * groups; }
     else { m = u / groups; cg = (uint32_t)(u - m * groups); }
+    m += A.m_base;
     uint64_t j;
     uint32_t d;
     ratecv_index(A, m, j, d);
@@ -286,7 +288,7 @@ template <typename T, int VEC, int FR, int MODE>
 __global__ __launch_bounds__(256) void k_resample_frames(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A, uint64_t out_frames) {
     typedef T vec_t __attribute__((ext_vector_type(VEC * FR)));
     const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t m0 = u * FR;
+    const uint64_t m0 = A.m_base + u * FR;
     if (m0 >= out_frames) return;
     vec_t res;
     // position of frame m0 in input frames: q + r/outr (exact), then (step_q, step_r) per output frame
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256) void k_resample_lds(const T* __restrict__ in, 
     typedef T vec_t __attribute__((ext_vector_type(VEC * FR)));
     typedef T ld_t __attribute__((ext_vector_type(16 / sizeof(T))));
     constexpr uint32_t EPV = 16 / sizeof(T);                      // elements per 16-byte vector
-    const uint64_t m_first = (uint64_t)blockIdx.x * (256 * FR);
+    const uint64_t m_first = A.m_base + (uint64_t)blockIdx.x * (256 * FR);
     if (m_first >= out_frames) return;
     uint64_t m_last = m_first + 256 * FR - 1;
     if (m_last > out_frames - 1) m_last = out_frames - 1;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in
     typedef T ld_t __attribute__((ext_vector_type(16 / sizeof(T))));
     constexpr uint32_t EPV = 16 / sizeof(T);
     constexpr int HALF = 1 << (8 * (int)sizeof(T) - 1);
-    const uint64_t m_first = (uint64_t)blockIdx.x * (256 * FR);
+    const uint64_t m_first = A.m_base + (uint64_t)blockIdx.x * (256 * FR);
     if (m_first >= out_frames) return;
     // position of the workgroup's first output frame: q0 + r0/outr   (uniform)
     uint64_t q0;
@@ -670,8 +672,12 @@ size_t sh_resample_out_frames(size_t in_frames, int inrate, int outrate) {
     return (size_t)(t / inr) + 1;
 }
 
+// in / out are the addresses input frame 0 / output frame 0 would have (range launches pass pointers shifted back by
+// the frames they do not hold: never dereferenced outside [held input), [m_base, m_end)).  in_frames = end of the
+// held input, m_base / m_end = output frame range.
 static int resample_dev(const void* in, size_t in_frames, int nch, int width, int is_float, int inrate, int outrate,
-                        void* out, size_t out_frames) {
+                        void* out, size_t m_base, size_t m_end) {
+    const size_t out_frames = m_end - m_base;        // frames this launch writes
     uint64_t g = gcd_u64((uint64_t)inrate, (uint64_t)outrate);
     RatecvArgs A;
     A.nch = (uint32_t)nch;
@@ -681,6 +687,7 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
     A.step_q = A.inr / A.outr;
     A.step_r = A.inr % A.outr;
     A.shift = 32 - 8 * width;
+    A.m_base = (uint64_t)m_base;
     const bool small = !is_float && width <= 2 && A.outr < 65536u;
 #define SH_I(M, ...) do { if (small) M(__VA_ARGS__, RS_INT_SMALL); else M(__VA_ARGS__, RS_INT_F64); } while (0)
     if (!out_frames) return SH_OK;
@@ -708,7 +715,7 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
             const uint64_t svecs = (span_frames * nch + epv + epv - 1) / epv + 1;
             if (svecs * 16 <= RS_LDS_BYTES) {
                 const uint32_t span_vecs = (uint32_t)svecs, lds_bytes = span_vecs * 16;
-#define SH_RM(T, V, F) hipLaunchKernelGGL((k_resample_small<T, V, F>), g2, dim3(256), lds_bytes, st, (const T*)in, (T*)out, A, (uint64_t)in_frames, (uint64_t)out_frames, span_vecs)
+#define SH_RM(T, V, F) hipLaunchKernelGGL((k_resample_small<T, V, F>), g2, dim3(256), lds_bytes, st, (const T*)in, (T*)out, A, (uint64_t)in_frames, (uint64_t)m_end, span_vecs)
                 if (width == 2) { if (nch == 1) SH_RM(short, 1, 8); else if (nch == 2) SH_RM(short, 2, 4); else SH_RM(short, 4, 2); }
                 else { if (nch == 1) SH_RM(signed char, 1, 8); else if (nch == 2) SH_RM(signed char, 2, 8); else SH_RM(signed char, 4, 4); }
 #undef SH_RM
@@ -718,7 +725,7 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
         }
         if (nch <= 2 && span_bytes <= RS_LDS_BYTES) {
             const uint32_t lds_bytes = (uint32_t)((span_bytes + 15) & ~15ull);
-#define SH_RL(T, V, F, FL) hipLaunchKernelGGL((k_resample_lds<T, V, F, FL>), g2, dim3(256), lds_bytes, st, (const T*)in, (T*)out, A, (uint64_t)in_frames, (uint64_t)out_frames)
+#define SH_RL(T, V, F, FL) hipLaunchKernelGGL((k_resample_lds<T, V, F, FL>), g2, dim3(256), lds_bytes, st, (const T*)in, (T*)out, A, (uint64_t)in_frames, (uint64_t)m_end)
             if (is_float) { if (nch == 1) SH_RL(float, 1, 4, RS_FLOAT); else SH_RL(float, 2, 2, RS_FLOAT); }
             else if (width == 2) { if (nch == 1) SH_I(SH_RL, short, 1, 8); else SH_I(SH_RL, short, 2, 4); }
             else if (width == 4) { if (nch == 1) SH_RL(int, 1, 4, RS_INT_F64); else SH_RL(int, 2, 2, RS_INT_F64); }
@@ -727,7 +734,7 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
             SH_CHECK_LAUNCH("k_resample_lds");
             return SH_OK;
         }
-#define SH_RF(T, V, F, FL) hipLaunchKernelGGL((k_resample_frames<T, V, F, FL>), g2, dim3(256), 0, st, (const T*)in, (T*)out, A, (uint64_t)out_frames)
+#define SH_RF(T, V, F, FL) hipLaunchKernelGGL((k_resample_frames<T, V, F, FL>), g2, dim3(256), 0, st, (const T*)in, (T*)out, A, (uint64_t)m_end)
         bool launched = true;
         if (is_float) {
             if (nch == 1) SH_RF(float, 1, 4, RS_FLOAT); else if (nch == 2) SH_RF(float, 2, 2, RS_FLOAT); else launched = false;
@@ -783,7 +790,53 @@ int sh_resample(const sh_buf* in, size_t in_frames, int nchannels, int width, in
     if (in->bytes / ((size_t)width * nchannels) < in_frames) return sh::set_error(SH_ERR_INVALID, "sh_resample: input buffer smaller than in_frames");
     if (out->bytes / ((size_t)width * nchannels) < nout) return sh::set_error(SH_ERR_INVALID, "sh_resample: output buffer too small (%zu frames needed)", nout);
     if (out_frames) *out_frames = nout;
-    return resample_dev(in->ptr, in_frames, nchannels, width, is_float, inrate, outrate, out->ptr, nout);
+    return resample_dev(in->ptr, in_frames, nchannels, width, is_float, inrate, outrate, out->ptr, 0, nout);
+}
+
+int sh_resample_span(size_t in_total_frames, int inrate, int outrate, size_t out_first, size_t out_n,
+                     size_t* in_first, size_t* in_count) {
+    if (!in_first || !in_count) return sh::set_error(SH_ERR_INVALID, "sh_resample_span: NULL argument");
+    if (inrate <= 0 || outrate <= 0) return sh::set_error(SH_ERR_INVALID, "resample: sampling rate not > 0");
+    const size_t nout = sh_resample_out_frames(in_total_frames, inrate, outrate);
+    if (out_first > nout || out_n > nout - out_first) return sh::set_error(SH_ERR_INVALID, "sh_resample_span: output range outside the %zu output frames", nout);
+    *in_first = 0;
+    *in_count = 0;
+    if (!out_n) return SH_OK;
+    const uint64_t g = gcd_u64((uint64_t)inrate, (uint64_t)outrate);
+    const unsigned __int128 inr = (uint64_t)inrate / g, outr = (uint64_t)outrate / g;
+    // output frame m interpolates input frames j-1 and j, j = ceil(m*inr/outr)
+    const uint64_t j_lo = (uint64_t)(((unsigned __int128)out_first * inr + outr - 1) / outr);
+    const uint64_t j_hi = (uint64_t)(((unsigned __int128)(out_first + out_n - 1) * inr + outr - 1) / outr);
+    uint64_t first = j_lo ? j_lo - 1 : 0;
+    first &= ~(uint64_t)15;                          // 16 frames of any layout are a multiple of 16 bytes: vector loads stay aligned
+    *in_first = (size_t)first;
+    *in_count = (size_t)(j_hi - first + 1);
+    return SH_OK;
+}
+
+int sh_resample_range(const sh_buf* in, size_t in_first, size_t in_held, int nchannels, int width, int is_float,
+                      int inrate, int outrate, size_t out_first, size_t out_n, sh_buf* out) {
+    SH_REQUIRE_INIT();
+    if (!in || !out) return sh::set_error(SH_ERR_INVALID, "sh_resample_range: NULL argument");
+    int rc = resample_check(nchannels, width, is_float, inrate, outrate);
+    if (rc) return rc;
+    if ((out_first | in_first) & 15) return sh::set_error(SH_ERR_INVALID, "sh_resample_range: ranges must start at a multiple of 16 frames");
+    const size_t fb = (size_t)width * nchannels;
+    if (in->bytes / fb < in_held) return sh::set_error(SH_ERR_INVALID, "sh_resample_range: input buffer smaller than in_held frames");
+    if (out->bytes / fb < out_n) return sh::set_error(SH_ERR_INVALID, "sh_resample_range: output buffer too small (%zu frames needed)", out_n);
+    if (!out_n) return SH_OK;
+    // the input frames the range reads (exact rational index arithmetic, as in sh_resample_span)
+    const uint64_t g = gcd_u64((uint64_t)inrate, (uint64_t)outrate);
+    const unsigned __int128 inr = (uint64_t)inrate / g, outr = (uint64_t)outrate / g;
+    const uint64_t j_lo = (uint64_t)(((unsigned __int128)out_first * inr + outr - 1) / outr);
+    const uint64_t j_hi = (uint64_t)(((unsigned __int128)(out_first + out_n - 1) * inr + outr - 1) / outr);
+    const uint64_t need_lo = j_lo ? j_lo - 1 : 0;
+    if (in_first > need_lo || j_hi >= (uint64_t)in_first + in_held)
+        return sh::set_error(SH_ERR_INVALID, "sh_resample_range: output frames [%zu,+%zu) read input frames [%llu,%llu], buffer holds [%zu,+%zu)",
+                             out_first, out_n, (unsigned long long)need_lo, (unsigned long long)j_hi, in_first, in_held);
+    const char* in0 = (const char*)in->ptr - in_first * fb;        // where input frame 0 would be
+    char* out0 = (char*)out->ptr - out_first * fb;                  // where output frame 0 would be
+    return resample_dev(in0, in_first + in_held, nchannels, width, is_float, inrate, outrate, out0, out_first, out_first + out_n);
 }
 
 int sh_resample_host(const void* in, size_t in_frames, int nchannels, int width, int is_float,
@@ -803,7 +856,7 @@ int sh_resample_host(const void* in, size_t in_frames, int nchannels, int width,
     char* s = (char*)sh::state().scratch;
     hipStream_t st = sh::state().stream;
     SH_HIP(hipMemcpyAsync(s, in, in_bytes, hipMemcpyHostToDevice, st));
-    rc = resample_dev(s, in_frames, nchannels, width, is_float, inrate, outrate, s + in_pad, nout);
+    rc = resample_dev(s, in_frames, nchannels, width, is_float, inrate, outrate, s + in_pad, 0, nout);
     if (rc) return rc;
     SH_HIP(hipMemcpyAsync(out, s + in_pad, out_bytes, hipMemcpyDeviceToHost, st));
     SH_HIP(hipStreamSynchronize(st));

@@ -23,7 +23,8 @@ import numpy as np
 
 from . import _native as N
 
-__all__ = ["shard_range", "shard_sizes", "init_from_env", "init", "shutdown", "DistVoiceBank"]
+__all__ = ["shard_range", "shard_sizes", "init_from_env", "init", "shutdown", "DistVoiceBank",
+           "resample_ranges", "resample_span", "resample_shard"]
 
 
 def shard_sizes(nvoices: int, world: int) -> list:
@@ -203,3 +204,61 @@ class DistVoiceBank:
         if self.rank != root and self.world > 1:
             return None
         return buf.download(np.float32, nframes * 2).reshape(nframes, 2)
+
+
+# -- Sample.resample sharded by output-frame range (SURVEY section 8(e): no collective) ---------------------------
+
+_RANGE_ALIGN = 256          # output ranges start at multiples of this many frames (the library needs 16)
+
+
+def resample_ranges(out_frames: int, world: int) -> list:
+    """[(first, count)] per rank: contiguous output-frame ranges, starts aligned to 256 frames, sizes within one
+    alignment unit of each other; trailing ranks may be empty for tiny outputs."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    units = -(-out_frames // _RANGE_ALIGN)
+    sizes = shard_sizes(units, world)
+    out, first = [], 0
+    for u in sizes:
+        start = min(first * _RANGE_ALIGN, out_frames)
+        end = min((first + u) * _RANGE_ALIGN, out_frames)
+        out.append((start, end - start))
+        first += u
+    return out
+
+
+def resample_span(in_frames: int, inrate: int, outrate: int, out_first: int, out_n: int) -> Tuple[int, int]:
+    """(first, count) of the input frames an output range reads (host arithmetic in the library; needs no GPU)."""
+    a, b = C.c_size_t(), C.c_size_t()
+    N.check(N.lib().sh_resample_span(in_frames, inrate, outrate, out_first, out_n, C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
+
+
+def resample_shard(frames, samplewidth: int, nchannels: int, inrate: int, outrate: int, rank: int, world: int,
+                   is_float: bool = False) -> Tuple[int, bytes]:
+    """This rank's part of ``audioop.ratecv(frames, width, nchannels, inrate, outrate, None)[0]``.
+
+    ``frames`` is the whole input (bytes-like) as every rank sees it on the host (a file, shared memory); only the
+    span this rank's output range reads -- its share plus a halo of one input frame -- is uploaded.  Returns
+    (first output frame, PCM bytes); the ranks' byte strings concatenated in rank order are the full result, bit for
+    bit, and no rank talks to another."""
+    fb = samplewidth * nchannels
+    view = memoryview(frames).cast("B")
+    if len(view) % fb:
+        raise ValueError("frames data is not a whole number of frames")
+    in_frames = len(view) // fb
+    L = N.lib()
+    nout = L.sh_resample_out_frames(in_frames, inrate, outrate)
+    first, count = resample_ranges(nout, world)[rank]
+    if count == 0:
+        return first, b""
+    in_first, in_count = resample_span(in_frames, inrate, outrate, first, count)
+    src = N.DeviceBuffer(in_count * fb)
+    src.upload(np.frombuffer(view[in_first * fb:(in_first + in_count) * fb], dtype=np.uint8))
+    dst = N.DeviceBuffer(count * fb)
+    N.check(L.sh_resample_range(src.handle, in_first, in_count, nchannels, samplewidth, 1 if is_float else 0,
+                                inrate, outrate, first, count, dst.handle))
+    out = dst.download_bytes(count * fb)
+    src.free()
+    dst.free()
+    return first, out

@@ -89,3 +89,33 @@ def test_tcp_rendezvous_broadcast():
     assert q.get(timeout=60) == payload
     p.join(timeout=30)
     del os.environ["SYNTHHIP_RDZV_PORT"]
+
+
+def test_resample_ranges_and_spans_cover_exactly():
+    """Output-range sharding of Sample.resample: the ranges partition the output; every range's input span holds
+    exactly the frames its outputs interpolate (index arithmetic of the oracle), starts on the 16-frame grid and
+    overlaps its neighbour by the halo only."""
+    import math
+    from oracle import pcm_oracle as P
+    from synthesizer_amd import dist
+    for in_frames, inrate, outrate in ((50021, 96000, 44100), (50021, 44100, 48000), (1000, 8000, 8001), (777, 3, 7),
+                                       (5, 48000, 44100), (123457, 48000, 16000)):
+        nout = P.ratecv_out_frames(in_frames, inrate, outrate)
+        for world in (1, 2, 3, 8):
+            ranges = dist.resample_ranges(nout, world)
+            assert len(ranges) == world and ranges[0][0] == 0
+            assert sum(c for _, c in ranges) == nout
+            for (f0, c0), (f1, _c1) in zip(ranges, ranges[1:]):
+                assert f0 + c0 == f1 and (f1 % 256 == 0 or f1 == nout)
+            g = math.gcd(inrate, outrate)
+            inr, outr = inrate // g, outrate // g
+            for first, count in ranges:
+                if not count:
+                    continue
+                lo, n = dist.resample_span(in_frames, inrate, outrate, first, count)
+                j_first = -(-first * inr // outr)
+                j_last = -(-(first + count - 1) * inr // outr)
+                assert lo % 16 == 0 and lo <= max(0, j_first - 1) < lo + 16
+                assert lo + n - 1 == j_last and lo + n <= in_frames
+    with pytest.raises(ValueError):
+        dist.resample_span(1000, 48000, 44100, 900, 100)       # beyond the 919 output frames

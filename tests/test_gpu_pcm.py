@@ -231,3 +231,40 @@ def test_resample_large_vs_c_oracle(gpu):
     pcm = rng.integers(-32768, 32768, 48000 * 60 * 2, dtype=np.int64).astype(np.int16)
     s = _sample(pcm, 2, 48000, 2).resample(44100)
     assert bytes(s.view_frame_data()) == audioop.ratecv(pcm.tobytes(), 2, 2, 48000, 44100, None)[0]
+
+
+@pytest.mark.parametrize("layout", [(2, 1), (2, 2), (2, 8), (4, 2), (1, 4), (2, 3)])
+@pytest.mark.parametrize("rates", [(96000, 44100), (44100, 48000), (8000, 8001), (1000003, 999983), (48000, 16000)])
+def test_resample_sharded_by_output_range(gpu, layout, rates):
+    """Sample.resample shards by output-frame range with a one-frame halo and no collective.  Every rank's
+    range, computed from only the input span it reads, concatenates to audioop.ratecv of the whole input."""
+    from synthesizer_amd import dist
+    width, nch = layout
+    i, o = rates
+    rng = np.random.default_rng(width * 100 + nch)
+    frames = 50021
+    x = _rand(rng, width, frames * nch)
+    want = audioop.ratecv(x.tobytes(), width, nch, i, o, None)[0]
+    for world in (1, 2, 3, 8):
+        parts = [dist.resample_shard(x.tobytes(), width, nch, i, o, r, world) for r in range(world)]
+        at = 0
+        for first, pcm in parts:
+            assert first * width * nch == at or not pcm
+            at += len(pcm)
+        assert b"".join(p for _, p in parts) == want, world
+    # a range that does not hold the frames it reads, or starts off the 16-frame grid, is refused
+    from synthesizer_amd import _native as N
+    src, dst = N.DeviceBuffer(64 * width * nch), N.DeviceBuffer(64 * width * nch)
+    with pytest.raises(ValueError):
+        N.check(N.lib().sh_resample_range(src.handle, 0, 8, nch, width, 0, i, o, 16, 32, dst.handle))
+    with pytest.raises(ValueError):
+        N.check(N.lib().sh_resample_range(src.handle, 0, 64, nch, width, 0, i, o, 8, 8, dst.handle))
+
+
+def test_resample_sharded_float32(gpu):
+    from synthesizer_amd import dist
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (40000, 8)).astype(np.float32)
+    want = P.ratecv_f32(x, 96000, 44100)
+    got = b"".join(dist.resample_shard(x.tobytes(), 4, 8, 96000, 44100, r, 4, is_float=True)[1] for r in range(4))
+    assert np.array_equal(np.frombuffer(got, dtype=np.float32).reshape(-1, 8), want)
