@@ -1136,7 +1136,7 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
         variant = e ? atoi(e) : 0;
     }
     int var = variant;
-    if (var == 0) var = b->nvoices >= 64 ? 826 : (b->nvoices >= 8 ? 421 : 211);
+    if (var == 0) var = b->nvoices >= 128 ? 844 : (b->nvoices >= 64 ? 826 : (b->nvoices >= 8 ? 421 : 211));
     const int W = var / 100, F = (var / 10) % 10;
     // enough workgroups to cover the 256 CUs several times over: split the voices into groups when the
     // frame range alone gives too few tiles (SYNTHHIP_GROUPS overrides)
@@ -1185,6 +1185,10 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     case 411: SH_LAUNCH_RENDER(4, 1, 1); break;
     case 418: SH_LAUNCH_RENDER(4, 1, 8); break;
     case 441: SH_LAUNCH_RENDER(4, 4, 1); break;
+    case 844: SH_LAUNCH_RENDER(8, 4, 4); break;
+    case 843: SH_LAUNCH_RENDER(8, 4, 3); break;
+    case 1642: SH_LAUNCH_RENDER(16, 4, 2); break;
+    case 444: SH_LAUNCH_RENDER(4, 4, 4); break;
     case 211: SH_LAUNCH_RENDER(2, 1, 1); break;
     case 221: SH_LAUNCH_RENDER(2, 2, 1); break;
     default: return sh::set_error(SH_ERR_INVALID, "sh_bank_render: unknown SYNTHHIP_VARIANT %d", var);
