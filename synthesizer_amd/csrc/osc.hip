@@ -513,7 +513,7 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
 // waves on 4 consecutive tiles; each wave walks the voices of its group (so the 8 KB sin/cos table in LDS
 // is filled once per block, not once per voice) and stores one coalesced row segment per voice.
 template <int FPL>
-__global__ __launch_bounds__(256, 6) void k_generate(BankPtrs B, const shm::sc_pair* __restrict__ trig_g, uint32_t first,
+__global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, const shm::sc_pair* __restrict__ trig_g, uint32_t first,
                                                   uint32_t nvoices, uint32_t voices_per_group,
                                                   const VoiceLaunch* __restrict__ launch,
                                                   const VoiceFM* __restrict__ launch_fm,
@@ -1096,7 +1096,9 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
     if (rc) return rc;
     rc = acquire_records(b, start, nframes);
     if (rc) return rc;
-    const int fpl = nframes >= 2048 ? 2 : 1;
+    // frames per lane: 4 for long rows (one sin/cos lookup + three rotations per voice, as in k_bank_render), else 2 / 1
+    static const int fpl_env = getenv("SYNTHHIP_GEN_FPL") ? atoi(getenv("SYNTHHIP_GEN_FPL")) : 0;
+    const int fpl = fpl_env ? fpl_env : (nframes >= 8192 ? 4 : (nframes >= 2048 ? 2 : 1));
     const uint32_t tile_groups = sh::div_up(nframes, 256 * fpl);
     // voices per block: as many as keeps >= ~4096 blocks in flight (and gridDim.y <= 65535)
     uint32_t vpg = 1;
@@ -1104,14 +1106,12 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
     while ((b->nvoices + vpg - 1) / vpg > 65535) vpg *= 2;
     const uint32_t groups = (b->nvoices + vpg - 1) / vpg;
     float* o = (float*)voices_out->ptr;
-    if (fpl == 2)
-        hipLaunchKernelGGL(k_generate<2>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,
-                           ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes,
-                           (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride);
-    else
-        hipLaunchKernelGGL(k_generate<1>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,
-                           ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes,
-                           (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride);
+#define SH_GEN(F_) hipLaunchKernelGGL(k_generate<F_>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,            \
+                                      ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, \
+                                      (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride)
+    if (fpl == 4) SH_GEN(4); else if (fpl == 2) SH_GEN(2); else if (fpl == 1) SH_GEN(1);
+    else return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: SYNTHHIP_GEN_FPL must be 1, 2 or 4");
+#undef SH_GEN
     SH_CHECK_LAUNCH("k_generate");
     return SH_OK;
 }
