@@ -151,6 +151,40 @@ __global__ __launch_bounds__(256) void k_absmax_sumsq(const T* __restrict__ in, 
     constexpr int V = 16 / sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(V)));
     const size_t nvec = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) ? n / V : 0;
+    if constexpr (sizeof(T) == 2) {
+        // 16-bit: packed arithmetic, two samples per instruction.  |x| = max(x, 0 - x) as int16 pairs, read as
+        // uint16 (so |-32768| = 32768 comes out right); running maximum as uint16 pairs; a pair's squares summed
+        // by the dot-product instruction (<= 2^31, fits uint32) and added to the 64-bit total.
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+        u2 mx2 = {0, 0};
+#define SH_PAIR(X_, A_, B_)                                                            \
+            {                                                                            \
+                const s2 v = __builtin_shufflevector(X_, X_, A_, B_);                    \
+                const s2 neg = (s2){0, 0} - v;                                           \
+                const u2 au = __builtin_bit_cast(u2, __builtin_elementwise_max(v, neg)); \
+                mx2 = __builtin_elementwise_max(mx2, au);                                \
+                sq += (unsigned long long)__builtin_amdgcn_udot2(au, au, 0u, false);     \
+            }
+        const size_t step = (size_t)gridDim.x * 256;
+        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * step < nvec; i += 4 * step) {               // four 16-byte loads in flight per lane
+            const vec_t x0 = reinterpret_cast<const vec_t*>(in)[i];
+            const vec_t x1 = reinterpret_cast<const vec_t*>(in)[i + step];
+            const vec_t x2 = reinterpret_cast<const vec_t*>(in)[i + 2 * step];
+            const vec_t x3 = reinterpret_cast<const vec_t*>(in)[i + 3 * step];
+            SH_PAIR(x0, 0, 1) SH_PAIR(x0, 2, 3) SH_PAIR(x0, 4, 5) SH_PAIR(x0, 6, 7)
+            SH_PAIR(x1, 0, 1) SH_PAIR(x1, 2, 3) SH_PAIR(x1, 4, 5) SH_PAIR(x1, 6, 7)
+            SH_PAIR(x2, 0, 1) SH_PAIR(x2, 2, 3) SH_PAIR(x2, 4, 5) SH_PAIR(x2, 6, 7)
+            SH_PAIR(x3, 0, 1) SH_PAIR(x3, 2, 3) SH_PAIR(x3, 4, 5) SH_PAIR(x3, 6, 7)
+        }
+        for (; i < nvec; i += step) {
+            const vec_t x = reinterpret_cast<const vec_t*>(in)[i];
+            SH_PAIR(x, 0, 1) SH_PAIR(x, 2, 3) SH_PAIR(x, 4, 5) SH_PAIR(x, 6, 7)
+        }
+#undef SH_PAIR
+        mx = mx2[0] > mx2[1] ? mx2[0] : mx2[1];
+    } else {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
         const vec_t x = reinterpret_cast<const vec_t*>(in)[i];
 #pragma unroll
@@ -160,6 +194,7 @@ __global__ __launch_bounds__(256) void k_absmax_sumsq(const T* __restrict__ in, 
             mx = a > mx ? a : mx;
             sq += (unsigned long long)(v * v);
         }
+    }
     }
     for (size_t i = nvec * V + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const long long v = (long long)in[i];
