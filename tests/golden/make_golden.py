@@ -7,6 +7,10 @@ Two families, with different standing:
   produced by calling the real module in this container.  These PIN the integer PCM rows.
   Header of every file: oracle = CPython 3.10.12 audioop; upstream delegation recalled, not citable
   (reference tree not mounted, /root/reference/README.md:1-2).
+* ``audioop_ops.npz`` -- the same for the elementwise calls behind Sample.amplify / bias / reverse / mono / stereo /
+  make_16bit / peak / rms (``mul``, ``bias``, ``reverse``, ``tomono``, ``tostereo``, ``lin2lin``, ``max``, ``rms``) and for
+  the editing methods composed from them (echo, envelope, speed, modulate_amp; oracle/sample_oracle.py over the
+  live module).
 * ``osc_*.npy`` -- outputs of oracle/synth_oracle.py, i.e. of this repository's own restatement of the
   oscillator formulas.  They guard the oracle against accidental edits; they are NOT reference
   outputs (parity unpinned for these rows).
@@ -73,6 +77,39 @@ def audioop_ratecv_vectors():
     np.savez_compressed(OUT / "audioop_ratecv.npz", **out)
 
 
+def audioop_ops_vectors():
+    from oracle.sample_oracle import RefSample
+    rng = np.random.default_rng(777)
+    out = {}
+    for width, dt in ((1, np.int8), (2, np.int16), (4, np.int32)):
+        info = np.iinfo(dt)
+        x = rng.integers(info.min, info.max + 1, 1024, dtype=np.int64).astype(dt)
+        x[:8] = [info.max, info.min, info.min + 1, info.max - 1, 0, -1, 3, -3]
+        raw = x.tobytes()
+        out["x%d" % width] = x
+        out["mul%d_1p5" % width] = np.frombuffer(audioop.mul(raw, width, 1.5), dtype=dt)
+        out["mul%d_m0p333" % width] = np.frombuffer(audioop.mul(raw, width, -0.333), dtype=dt)
+        out["bias%d_1000" % width] = np.frombuffer(audioop.bias(raw, width, 1000), dtype=dt)
+        out["reverse%d" % width] = np.frombuffer(audioop.reverse(raw, width), dtype=dt)
+        out["tomono%d" % width] = np.frombuffer(audioop.tomono(raw, width, 0.75, 0.5), dtype=dt)
+        out["tostereo%d" % width] = np.frombuffer(audioop.tostereo(raw, width, 0.3, 1.2), dtype=dt)
+        out["max_rms%d" % width] = np.array([audioop.max(raw, width), audioop.rms(raw, width)], dtype=np.int64)
+        for nw, ndt in ((1, np.int8), (2, np.int16), (4, np.int32)):
+            if nw != width:
+                out["lin2lin%d_%d" % (width, nw)] = np.frombuffer(audioop.lin2lin(raw, width, nw), dtype=ndt)
+    # editing methods (upstream compositions over the live module), 16-bit stereo 0.25 s at 8 kHz
+    y = (rng.integers(-32768, 32768, 4000, dtype=np.int64) * 0.4).astype(np.int16)
+    out["edit_in"] = y
+    out["edit_echo"] = np.frombuffer(RefSample(y.tobytes(), 2, 8000, 2).echo(0.1, 3, 0.05, 0.6).frames, dtype=np.int16)
+    out["edit_envelope"] = np.frombuffer(RefSample(y.tobytes(), 2, 8000, 2).envelope(0.05, 0.05, 0.5, 0.08).frames, dtype=np.int16)
+    out["edit_speed_1p26"] = np.frombuffer(RefSample(y.tobytes(), 2, 8000, 2).speed(1.26).frames, dtype=np.int16)
+    m = rng.integers(-32768, 32768, 333, dtype=np.int64).astype(np.int16)
+    out["edit_mod"] = m
+    out["edit_modulate"] = np.frombuffer(RefSample(y.tobytes(), 2, 8000, 2).modulate_amp(RefSample(m.tobytes(), 2, 8000, 1)).frames,
+                                         dtype=np.int16)
+    np.savez_compressed(OUT / "audioop_ops.npz", **out)
+
+
 def osc_vectors():
     sine = np.array(O.Sine(440, samplerate=44100).take(44100))
     np.save(OUT / "osc_sine440_44k1.npy", sine.astype(np.float64)[np.r_[0:4096, 40004:44100]].copy())
@@ -91,6 +128,7 @@ def osc_vectors():
 if __name__ == "__main__":
     audioop_add_vectors()
     audioop_ratecv_vectors()
+    audioop_ops_vectors()
     osc_vectors()
     for p in sorted(OUT.glob("*.np*")):
         print(p.name, p.stat().st_size)

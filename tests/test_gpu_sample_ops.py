@@ -129,3 +129,24 @@ def test_fades(gpu):
     s = _sample(x, 2, 8000, 2).fadeout(5.0)
     assert _bytes(s) == P.fade(x.tobytes(), 2, True, 1.0, 0.0)
     assert s.get_frame_array()[-1] == 0 or abs(s.get_frame_array()[-1]) <= 1
+
+
+def test_elementwise_and_editing_golden(gpu):
+    """The committed golden vectors (live audioop outputs, tests/golden/audioop_ops.npz) through the GPU path."""
+    g = np.load("tests/golden/audioop_ops.npz")
+    for width in (1, 2, 4):
+        x = g["x%d" % width]
+        assert _bytes(_sample(x, width, 8000, 1).amplify(1.5)) == g["mul%d_1p5" % width].tobytes()
+        assert _bytes(_sample(x, width, 8000, 1).amplify(-0.333)) == g["mul%d_m0p333" % width].tobytes()
+        assert _bytes(_sample(x, width, 8000, 1).bias(1000)) == g["bias%d_1000" % width].tobytes()
+        assert _bytes(_sample(x, width, 8000, 1).reverse()) == g["reverse%d" % width].tobytes()
+        assert _bytes(_sample(x, width, 8000, 2).mono(0.75, 0.5)) == g["tomono%d" % width].tobytes()
+        assert _bytes(_sample(x, width, 8000, 1).stereo(0.3, 1.2)) == g["tostereo%d" % width].tobytes()
+        s = _sample(x, width, 8000, 1)
+        peak, rms = g["max_rms%d" % width].tolist()
+        assert s.peak() == peak and abs(s.rms() - rms) <= (1 if width == 4 else 0)
+    y = g["edit_in"]
+    assert _bytes(_sample(y, 2, 8000, 2).echo(0.1, 3, 0.05, 0.6)) == g["edit_echo"].tobytes()
+    assert _bytes(_sample(y, 2, 8000, 2).envelope(0.05, 0.05, 0.5, 0.08)) == g["edit_envelope"].tobytes()
+    assert _bytes(_sample(y, 2, 8000, 2).speed(1.26)) == g["edit_speed_1p26"].tobytes()
+    assert _bytes(_sample(y, 2, 8000, 2).modulate_amp(_sample(g["edit_mod"], 2, 8000, 1))) == g["edit_modulate"].tobytes()

@@ -96,3 +96,21 @@ def test_elementwise_ops_match_audioop(width):
             assert P.lin2lin(frames, width, nw) == audioop.lin2lin(frames, width, nw)
         assert P.amax(frames, width) == audioop.max(frames, width)
         assert P.rms(frames, width) == audioop.rms(frames, width)
+
+
+def test_elementwise_ops_golden():
+    """oracle restatements of audioop.mul / bias / reverse / tomono / tostereo / lin2lin / max / rms against the committed
+    outputs of the live module (tests/golden/audioop_ops.npz)."""
+    g = np.load("tests/golden/audioop_ops.npz")
+    for width in (1, 2, 4):
+        raw = g["x%d" % width].tobytes()
+        assert P.mul(raw, width, 1.5) == g["mul%d_1p5" % width].tobytes()
+        assert P.mul(raw, width, -0.333) == g["mul%d_m0p333" % width].tobytes()
+        assert P.bias(raw, width, 1000) == g["bias%d_1000" % width].tobytes()
+        assert P.reverse(raw, width) == g["reverse%d" % width].tobytes()
+        assert P.tomono(raw, width, 0.75, 0.5) == g["tomono%d" % width].tobytes()
+        assert P.tostereo(raw, width, 0.3, 1.2) == g["tostereo%d" % width].tobytes()
+        assert [P.amax(raw, width), P.rms(raw, width)] == g["max_rms%d" % width].tolist()
+        for nw in (1, 2, 4):
+            if nw != width:
+                assert P.lin2lin(raw, width, nw) == g["lin2lin%d_%d" % (width, nw)].tobytes()
