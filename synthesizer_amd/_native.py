@@ -86,6 +86,7 @@ _SIGNATURES = {
     "sh_timer_stop": (C.c_int, [C.POINTER(C.c_float)]),
     "sh_bank_create": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(_P)]),
     "sh_bank_destroy": (C.c_int, [_P]),
+    "sh_bank_launch_stats": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sh_bank_nvoices": (C.c_uint32, [_P]),
     "sh_osc_render": (C.c_int, [_P, C.c_uint32, _P, _P, C.c_uint64, C.c_uint32, _P, _P, C.c_size_t, _P]),
     "sh_ew_f64": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_double, C.c_double, _P, C.c_size_t, _P, C.c_size_t, _P]),

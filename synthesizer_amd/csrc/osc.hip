@@ -32,6 +32,8 @@ struct BankPtrs {
     const double*     coefs;
     const sh_partial* partials;
     uint32_t*         hint;       // per voice: table piece of the last prepared launch (streaming: same or next piece)
+    const double2*    seg_rot;    // per table piece: (cos, sin)(64*dt), computed once on the host at bank creation
+    const double2*    lfo_rot;    // per voice: (cos, sin)(64*lfo_d)
 };
 
 // Pointers to data that no thread of the running kernel writes are cast to the constant address space:
@@ -91,8 +93,37 @@ struct alignas(16) VoiceFM {      // only read for FM voices
 };
 static_assert(sizeof(VoiceFM) == 80, "VoiceFM layout");
 
+// The common voice of an additive bank in steady state -- polynomial Harmonics, no FM, amplitude and (constant)
+// envelope gain folded into the bus gains, the whole launch on one table piece -- needs only this much per launch.
+// The render kernel walks these records in a loop of its own, with none of the general code's flag tests.
+struct alignas(64) FastRec {
+    double t_base, dt;            // t(i) = fma(i, dt, t_base) for every frame i of the launch
+    double gain_l, gain_r;        // amplitude * envelope gain * bus gain
+    double rot_c, rot_s;          // cos / sin of 64*dt
+    double poly[16];              // sum_k a_k sin(k t) = sin(t) * P(cos t)
+    double pad[2];
+};
+static_assert(sizeof(FastRec) == 192, "FastRec layout");
+
+// One set of per-launch data (double-buffered in the bank).  Voices are classified per chunk of 64 consecutive
+// voices: the fast voices of chunk c get a FastRec, compacted at fast[64c ..], the others are listed by index in
+// gen_idx[64c ..] (both in ascending voice order: the summation order is fixed), silent voices appear in neither.
+struct LaunchSet {
+    VoiceLaunch* launch;
+    VoiceFM*     fm;
+    FastRec*     fast;
+    uint32_t*    gen_idx;
+    uint32_t*    counts;          // per chunk: [2c] = fast voices, [2c+1] = general voices
+};
+
+struct PrepInfo {                 // what prepare_voice found, for the classification
+    bool   fast, silent;
+    double t_base, dt, gain_l, gain_r, rot_c, rot_s;
+    const double* harm;
+};
+
 __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first, uint32_t vi, uint64_t start, uint32_t nframes,
-                                              VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm) {
+                                              VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm, PrepInfo& info) {
     // Fields are stored straight to the record (no local struct: a 368-byte private array would give
     // every wave of the render kernel a scratch allocation).
     const sh_voice& v = B.voices[first + vi];
@@ -194,8 +225,8 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     }
     o->g0u = g0u;
     o->slu = slu;
-    double rc, rs;
-    shm::sincos_f64(64.0 * dt, rs, rc);
+    const double2 rot = B.seg_rot[off + lo];
+    const double rc = rot.x, rs = rot.y;
     o->rot_c = rc;
     o->rot_s = rs;
     if (flags & FL_POLY) {
@@ -216,6 +247,15 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     o->gain_l = gain_l;
     o->gain_r = gain_r;
     o->flags = flags;
+    info.silent = (flags & FL_SILENT) != 0;
+    info.fast = (flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) && rem >= (uint64_t)nframes;
+    info.t_base = t_base;
+    info.dt = dt;
+    info.gain_l = gain_l;
+    info.gain_r = gain_r;
+    info.rot_c = rc;
+    info.rot_s = rs;
+    info.harm = harm;
     if (fm) {
         VoiceFM* __restrict__ f = out_fm + vi;
         f->frequency = v.frequency;
@@ -226,17 +266,52 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         f->lfo_K = v.lfo_K;
         f->lfo_C0 = v.lfo_C0;
         f->lfo_bias = v.lfo_bias;
-        double lrc, lrs;
-        shm::sincos_f64(64.0 * v.lfo_d, lrs, lrc);
-        f->lfo_rot_c = lrc;
-        f->lfo_rot_s = lrs;
+        const double2 lrot = B.lfo_rot[first + vi];
+        f->lfo_rot_c = lrot.x;
+        f->lfo_rot_s = lrot.y;
     }
 }
 
 __global__ void k_prepare(BankPtrs B, uint32_t first, uint32_t nvoices, uint64_t start, uint32_t nframes,
                           VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm) {
     uint32_t vi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (vi < nvoices) prepare_voice(B, first, vi, start, nframes, out, out_fm);
+    PrepInfo info;
+    if (vi < nvoices) prepare_voice(B, first, vi, start, nframes, out, out_fm, info);
+}
+
+// One wavefront resolves the launch records of one chunk of 64 consecutive voices (lane = voice) and classifies them
+// (see LaunchSet); positions in the chunk's compacted lists come from wave ballots -- no inter-thread memory traffic,
+// no barrier, chunks are independent of each other.
+__device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet& S, uint32_t c, uint32_t nvoices,
+                                              uint64_t start, uint32_t nframes) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t vi = c * 64 + lane;
+    PrepInfo info;
+    info.fast = false;
+    info.silent = true;
+    if (vi < nvoices) prepare_voice(B, 0u, vi, start, nframes, S.launch, S.fm, info);
+    const bool is_fast = vi < nvoices && info.fast;
+    const bool is_gen = vi < nvoices && !info.fast && !info.silent;
+    const uint64_t mf = __ballot(is_fast), mg = __ballot(is_gen);
+    const uint64_t below = (1ull << lane) - 1ull;
+    if (is_fast) {
+        FastRec* __restrict__ f = S.fast + c * 64 + (uint32_t)__popcll(mf & below);
+        f->t_base = info.t_base; f->dt = info.dt;
+        f->gain_l = info.gain_l; f->gain_r = info.gain_r;
+        f->rot_c = info.rot_c; f->rot_s = info.rot_s;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) f->poly[u] = info.harm[u];
+        f->pad[0] = 0.0; f->pad[1] = 0.0;
+    }
+    if (is_gen) S.gen_idx[c * 64 + (uint32_t)__popcll(mg & below)] = vi;
+    if (lane == 0) {
+        S.counts[2 * c] = (uint32_t)__popcll(mf);
+        S.counts[2 * c + 1] = (uint32_t)__popcll(mg);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_prepare_chunks(BankPtrs B, LaunchSet S, uint32_t nvoices, uint64_t start, uint32_t nframes) {
+    prepare_chunk(B, S, blockIdx.x, nvoices, start, nframes);
 }
 
 struct VoiceRegs {                // the hot part of the launch record as plain scalars (SGPRs)
@@ -279,7 +354,8 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
                                             const double* __restrict__ fm_cumsum, const double* __restrict__ pwm,
                                             TrigTab trig, double (&x)[FPL]) {
     double th[FPL];
-    bool linear = false;          // th[j] = th[0] + 64*j*dt exactly (all frames on the launch's first table piece, no FM)
+    bool linear = false;          // th[j] = th[0] + 64*j*dt exactly (all frames of the tile on one table piece, no FM)
+    double rot_c = r.rot_c, rot_s = r.rot_s;      // (cos, sin)(64*dt) of that piece
     // ---- phase: the reference's accumulated t at each frame ----
     if (tile_last < r.remain) {
         linear = (r.flags & FL_FM) == 0;
@@ -300,6 +376,12 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
             const double tb = q->nx_t0[k & 3], dk = q->nx_dt[k & 3], off = (double)k_start;
 #pragma unroll
             for (int j = 0; j < FPL; ++j) th[j] = fma(di[j] - off, dk, tb);
+            if ((r.flags & FL_FM) == 0) {                     // still one piece per tile: the rotation shortcut applies
+                const double2 SH_CONST_AS* rt = as_const(B.seg_rot) + vfull->seg_offset + q->seg + 1 + k;
+                rot_c = rt->x;
+                rot_s = rt->y;
+                linear = true;
+            }
         } else {
             const bool fm = (r.flags & FL_FM) != 0;
             const sh_segment SH_CONST_AS* tab = as_const(B.segs) + (fm ? vfull->time_seg_offset : vfull->seg_offset);
@@ -362,8 +444,8 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
             shm::sincos_tab(th[0], trig, sn[0], cs[0]);
 #pragma unroll
             for (int j = 1; j < FPL; ++j) {               // rotate by 64*dt: 4 float64 ops instead of 17
-                sn[j] = fma(sn[j - 1], r.rot_c, cs[j - 1] * r.rot_s);
-                cs[j] = fma(cs[j - 1], r.rot_c, -(sn[j - 1] * r.rot_s));
+                sn[j] = fma(sn[j - 1], rot_c, cs[j - 1] * rot_s);
+                cs[j] = fma(cs[j - 1], rot_c, -(sn[j - 1] * rot_s));
             }
         } else {
             shm::sincos_tab_n<FPL>(th, trig, sn, cs);
@@ -568,23 +650,25 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
 // partial (L, R) per lane; LDS-staged sum across the waves; one store per frame.  With one group the block
 // writes the final bus; with several it writes a float64 partial bus per group and k_bus_combine folds
 // them in group order -- either way voices are summed in a fixed order (reproducible run to run).
-template <int WAVES, int FPL, int MINW, bool PREFETCH = false>
+template <int WAVES, int FPL, int MINW>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                   uint32_t nvoices, uint32_t voices_per_group,
-                                                                  const VoiceLaunch* __restrict__ launch,
-                                                                  const VoiceFM* __restrict__ launch_fm,
+                                                                  LaunchSet cur, LaunchSet next,
                                                                   uint64_t start, uint32_t nframes,
                                                                   float2* __restrict__ bus32,
                                                                   double2* __restrict__ bus64,
-                                                                  double2* __restrict__ parts,
-                                                                  VoiceLaunch* __restrict__ next_launch,
-                                                                  VoiceFM* __restrict__ next_fm) {
+                                                                  double2* __restrict__ parts) {
     // Sequential streaming is the common call pattern: the first workgroup also resolves the launch records
-    // of the block that is expected next (start + nframes) into the other record set, so that launch needs
-    // no k_prepare of its own (a 7 us kernel + a launch boundary per block otherwise).
-    if (next_launch && blockIdx.x == 0 && blockIdx.y == 0) {
-        for (uint32_t vi = threadIdx.x; vi < nvoices; vi += WAVES * 64)
-            prepare_voice(B, 0u, vi, start + nframes, nframes, next_launch, next_fm);
+    // of the block that is expected next (start + nframes, same launch shape) into the other record set, so
+    // that launch needs no prepare kernel of its own (a 7 us kernel + a launch boundary per block otherwise).
+    // The chunks of 64 voices are spread over the first workgroups (one wavefront each, on different CUs): a single
+    // workgroup doing all of it competes with three rendering workgroups for its CU and ends up as the launch's tail.
+    if (next.launch) {
+        const uint32_t nchunks = (nvoices + 63) / 64, nblocks = gridDim.x * gridDim.y;
+        const uint32_t bid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (threadIdx.x < 64) {
+            for (uint32_t c = bid; c < nchunks; c += nblocks) prepare_chunk(B, next, c, nvoices, start + nframes, nframes);
+        }
     }
     __shared__ double red[WAVES][2][64 * FPL];
     __shared__ shm::sc_pair trig[shm::TRIG_N];
@@ -595,9 +679,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     const uint32_t tile0 = blockIdx.x * (64 * FPL);
     uint32_t tile_last = tile0 + 64 * FPL - 1;
     if (tile_last > nframes - 1) tile_last = nframes - 1;
-    const uint32_t v0 = blockIdx.y * voices_per_group;
-    uint32_t v1 = v0 + voices_per_group;
-    if (v1 > nvoices) v1 = nvoices;
+    // this group's voices: chunks [c0, c1) of 64 voices (voices_per_group is a multiple of 64 unless there is one group)
+    const uint32_t c0 = (blockIdx.y * voices_per_group) / 64;
+    uint32_t c1 = ((blockIdx.y + 1) * voices_per_group + 63) / 64;
+    const uint32_t nchunks = (nvoices + 63) / 64;
+    if (c1 > nchunks) c1 = nchunks;
     uint32_t i[FPL];
     double di[FPL], accl[FPL], accr[FPL];
 #pragma unroll
@@ -608,26 +694,60 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         accl[j] = 0.0;
         accr[j] = 0.0;
     }
-    const VoiceLaunch SH_CONST_AS* rp = as_const(launch) + v0 + wave;
-    for (uint32_t vi = v0 + wave; vi < v1; vi += WAVES, rp += WAVES) {
-        const VoiceRegs r = load_record(rp);
-        if (r.flags & FL_SILENT) continue;       // the note was released before this block: contributes exact zeros
-        // touch the hot cache lines of this wave's NEXT record (one dword per 64-byte line, 4 lines) so that
-        // its loads hit the scalar cache: gfx950 has no scalar prefetch instruction.  The values are only
-        // kept alive until the end of the iteration.
-        uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
-        if (PREFETCH && vi + WAVES < v1) {
-            const uint32_t SH_CONST_AS* nx = reinterpret_cast<const uint32_t SH_CONST_AS*>(rp + WAVES);
-            pf0 = nx[0]; pf1 = nx[16]; pf2 = nx[32]; pf3 = nx[48];
-        }
-        double x[FPL];
-        voice_block<FPL, true>(r, launch_fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
+    // ---- fast voices: one table lookup, FPL-1 rotations, the Horner chains, two accumulations per frame ----
+    // Wave w takes every WAVES-th list entry; the offset carries over from chunk to chunk so that the waves'
+    // shares of the whole group differ by at most one voice.
+    uint32_t first = wave;                                    // position in the current chunk's list this wave starts at
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t nfast = as_const(cur.counts)[2 * c];
+        const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64 + first;
+        uint32_t p = first;
+        for (; p < nfast; p += WAVES, q += WAVES) {
+            const double t_base = q->t_base, dt = q->dt, gl = q->gain_l, gr = q->gain_r, rc = q->rot_c, rs = q->rot_s;
+            double poly[16];
 #pragma unroll
-        for (int j = 0; j < FPL; ++j) {
-            accl[j] = fma(r.gain_l, x[j], accl[j]);
-            accr[j] = fma(r.gain_r, x[j], accr[j]);
+            for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+            double sn[FPL], cs[FPL], pv[FPL];
+            shm::sincos_tab(fma(di[0], dt, t_base), trig, sn[0], cs[0]);
+#pragma unroll
+            for (int j = 1; j < FPL; ++j) {               // frame j is 64 samples after frame j-1: rotate by 64*dt
+                sn[j] = fma(sn[j - 1], rc, cs[j - 1] * rs);
+                cs[j] = fma(cs[j - 1], rc, -(sn[j - 1] * rs));
+            }
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) pv[j] = fma(poly[0], cs[j], poly[1]);
+#pragma unroll
+            for (int u = 2; u < 16; ++u) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) pv[j] = fma(pv[j], cs[j], poly[u]);
+            }
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                const double x = pv[j] * sn[j];
+                accl[j] = fma(gl, x, accl[j]);
+                accr[j] = fma(gr, x, accr[j]);
+            }
         }
-        if (PREFETCH) asm volatile("" :: "s"(pf0), "s"(pf1), "s"(pf2), "s"(pf3));
+        first = p - nfast;                                    // 0 .. WAVES-1: where the stride lands in the next list
+    }
+    // ---- every other sounding voice: the general code (the stride simply continues, so the extra voices go to the
+    // waves that got one fast voice fewer) ----
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t ngen = as_const(cur.counts)[2 * c + 1];
+        const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
+        uint32_t p = first;
+        for (; p < ngen; p += WAVES) {
+            const uint32_t vi = idx[p];
+            const VoiceRegs r = load_record(as_const(cur.launch) + vi);
+            double x[FPL];
+            voice_block<FPL, true>(r, cur.fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                accl[j] = fma(r.gain_l, x[j], accl[j]);
+                accr[j] = fma(r.gain_r, x[j], accr[j]);
+            }
+        }
+        first = p - ngen;
     }
 #pragma unroll
     for (int j = 0; j < FPL; ++j) {
@@ -877,17 +997,33 @@ struct sh_bank {
     // other for the block that is expected next (start + nframes)
     VoiceLaunch* d_launch_buf[2] = {nullptr, nullptr};
     VoiceFM*    d_launch_fm_buf[2] = {nullptr, nullptr};
+    FastRec*    d_fast_buf[2] = {nullptr, nullptr};
+    uint32_t*   d_gen_idx_buf[2] = {nullptr, nullptr};
+    uint32_t*   d_counts_buf[2] = {nullptr, nullptr};      // 2 * nvoices entries: room for one voice per group
     uint32_t*   d_hint = nullptr;
+    double2*    d_seg_rot = nullptr;       // (cos, sin)(64*dt) per table piece
+    double2*    d_lfo_rot = nullptr;       // (cos, sin)(64*lfo_d) per voice
     VoiceLaunch* d_launch = nullptr;       // the set the next kernel reads
     VoiceFM*    d_launch_fm = nullptr;
     int         cur = 0;
     bool        spec_valid = false;
     uint64_t    spec_start = 0;
     uint32_t    spec_nframes = 0;
+    uint32_t    last_groups = 0;          // voice groups of the last sh_bank_render launch (sh_bank_launch_stats)
     float2*     d_gains = nullptr;
     uint32_t    nsegs = 0, ncoefs = 0, npartials = 0;
     std::vector<sh_voice> h_voices;    // for validation of per-call arguments
 };
+
+static LaunchSet launch_set(const sh_bank* b, int k) {
+    LaunchSet s;
+    s.launch = b->d_launch_buf[k];
+    s.fm = b->d_launch_fm_buf[k];
+    s.fast = b->d_fast_buf[k];
+    s.gen_idx = b->d_gen_idx_buf[k];
+    s.counts = b->d_counts_buf[k];
+    return s;
+}
 
 static BankPtrs ptrs(const sh_bank* b) {
     BankPtrs p;
@@ -896,6 +1032,8 @@ static BankPtrs ptrs(const sh_bank* b) {
     p.coefs = b->d_coefs;
     p.partials = b->d_partials;
     p.hint = b->d_hint;
+    p.seg_rot = b->d_seg_rot;
+    p.lfo_rot = b->d_lfo_rot;
     return p;
 }
 
@@ -965,11 +1103,21 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     if (!rc) rc = upload_array(&b->d_coefs, coefs, ncoefs, st);
     if (!rc) rc = upload_array(&b->d_partials, partials, npartials, st);
     if (!rc) rc = upload_array(&b->d_gains, gains.data(), nvoices, st);
+    // rotations by 64 samples: constant per table piece / per voice, so they are computed here once (libm) instead of
+    // in every launch's prepare step
+    std::vector<double2> seg_rot(nsegs), lfo_rot(nvoices);
+    for (uint32_t i = 0; i < nsegs; ++i) seg_rot[i] = make_double2(cos(64.0 * segs[i].dt), sin(64.0 * segs[i].dt));
+    for (uint32_t i = 0; i < nvoices; ++i) lfo_rot[i] = make_double2(cos(64.0 * voices[i].lfo_d), sin(64.0 * voices[i].lfo_d));
+    if (!rc) rc = upload_array(&b->d_seg_rot, seg_rot.data(), nsegs, st);
+    if (!rc) rc = upload_array(&b->d_lfo_rot, lfo_rot.data(), nvoices, st);
     if (!rc) {
         hipError_t e = hipSuccess;
         for (int k = 0; k < 2 && e == hipSuccess; ++k) {
             e = hipMalloc((void**)&b->d_launch_buf[k], sizeof(VoiceLaunch) * nvoices);
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_launch_fm_buf[k], sizeof(VoiceFM) * nvoices);
+            if (e == hipSuccess) e = hipMalloc((void**)&b->d_fast_buf[k], sizeof(FastRec) * nvoices);
+            if (e == hipSuccess) e = hipMalloc((void**)&b->d_gen_idx_buf[k], sizeof(uint32_t) * nvoices);
+            if (e == hipSuccess) e = hipMalloc((void**)&b->d_counts_buf[k], sizeof(uint32_t) * 2 * nvoices);
         }
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_hint, sizeof(uint32_t) * nvoices);
         if (e == hipSuccess) e = hipMemsetAsync(b->d_hint, 0, sizeof(uint32_t) * nvoices, st);
@@ -1000,15 +1148,36 @@ int sh_bank_destroy(sh_bank* b) {
         for (int k = 0; k < 2; ++k) {
             if (b->d_launch_buf[k]) hipFree(b->d_launch_buf[k]);
             if (b->d_launch_fm_buf[k]) hipFree(b->d_launch_fm_buf[k]);
+            if (b->d_fast_buf[k]) hipFree(b->d_fast_buf[k]);
+            if (b->d_gen_idx_buf[k]) hipFree(b->d_gen_idx_buf[k]);
+            if (b->d_counts_buf[k]) hipFree(b->d_counts_buf[k]);
         }
         if (b->d_gains) hipFree(b->d_gains);
         if (b->d_hint) hipFree(b->d_hint);
+        if (b->d_seg_rot) hipFree(b->d_seg_rot);
+        if (b->d_lfo_rot) hipFree(b->d_lfo_rot);
     }
     delete b;
     return SH_OK;
 }
 
 uint32_t sh_bank_nvoices(const sh_bank* b) { return b ? b->nvoices : 0; }
+
+int sh_bank_launch_stats(sh_bank* b, uint32_t* nfast, uint32_t* ngeneral) {
+    SH_REQUIRE_INIT();
+    if (!b) return sh::set_error(SH_ERR_INVALID, "sh_bank_launch_stats: NULL bank");
+    if (!b->last_groups) return sh::set_error(SH_ERR_INVALID, "sh_bank_launch_stats: no sh_bank_render call yet");
+    const uint32_t nchunks = (b->nvoices + 63) / 64;
+    std::vector<uint32_t> c(2 * (size_t)nchunks);
+    hipStream_t st = sh::state().stream;
+    SH_HIP(hipMemcpyAsync(c.data(), b->d_counts_buf[b->cur], c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SH_HIP(hipStreamSynchronize(st));
+    uint32_t f = 0, g = 0;
+    for (uint32_t k = 0; k < nchunks; ++k) { f += c[2 * k]; g += c[2 * k + 1]; }
+    if (nfast) *nfast = f;
+    if (ngeneral) *ngeneral = g;
+    return SH_OK;
+}
 
 static const shm::sc_pair* trig_table() { return (const shm::sc_pair*)sh::state().trig; }
 
@@ -1028,9 +1197,9 @@ static int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes) {
     if (b->spec_valid && b->spec_start == start && b->spec_nframes == nframes) {
         b->cur ^= 1;
     } else {
-        hipLaunchKernelGGL(k_prepare, dim3(sh::div_up(b->nvoices, 64)), dim3(64), 0, st,
-                           ptrs(b), 0u, b->nvoices, start, nframes, b->d_launch_buf[b->cur], b->d_launch_fm_buf[b->cur]);
-        SH_CHECK_LAUNCH("k_prepare");
+        hipLaunchKernelGGL(k_prepare_chunks, dim3(sh::div_up(b->nvoices, 64)), dim3(64), 0, st, ptrs(b), launch_set(b, b->cur),
+                           b->nvoices, start, nframes);
+        SH_CHECK_LAUNCH("k_prepare_chunks");
     }
     b->spec_valid = false;
     b->d_launch = b->d_launch_buf[b->cur];
@@ -1124,8 +1293,6 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     if (bus_f64 && bus_f64->bytes < (size_t)nframes * 16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f64 too small");
     int rc = bank_check_plain(b, "sh_bank_render");
     if (rc) return rc;
-    rc = acquire_records(b, start, nframes);
-    if (rc) return rc;
     float2* o32 = bus_f32 ? (float2*)bus_f32->ptr : nullptr;
     double2* o64 = bus_f64 ? (double2*)bus_f64->ptr : nullptr;
     hipStream_t st = sh::state().stream;
@@ -1148,46 +1315,40 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
         if (forced < 0) { const char* e = getenv("SYNTHHIP_GROUPS"); forced = e ? atoi(e) : 0; }
         if (forced > 0) groups = (uint32_t)forced;
     }
-    const uint32_t vpg = (b->nvoices + groups - 1) / groups;
+    uint32_t vpg = (b->nvoices + groups - 1) / groups;
+    if (groups > 1) vpg = (vpg + 63) & ~63u;                // groups are made of whole 64-voice chunks (the lists' unit)
+    groups = (b->nvoices + vpg - 1) / vpg;                  // no empty trailing groups
+    rc = acquire_records(b, start, nframes);
+    if (rc) return rc;
     double2* parts = nullptr;
     if (groups > 1) {
         rc = sh::ensure_scratch((size_t)groups * nframes * sizeof(double2));
         if (rc) return rc;
         parts = (double2*)sh::state().scratch;
     }
-    VoiceLaunch* nl = speculation_enabled() ? b->d_launch_buf[b->cur ^ 1] : nullptr;
-    VoiceFM* nf = speculation_enabled() ? b->d_launch_fm_buf[b->cur ^ 1] : nullptr;
+    b->last_groups = groups;
+    const LaunchSet cur = launch_set(b, b->cur);
+    LaunchSet next = launch_set(b, b->cur ^ 1);
+    if (!speculation_enabled()) next.launch = nullptr;
 #define SH_LAUNCH_RENDER(W_, F_, M_)                                                                          \
     hipLaunchKernelGGL((k_bank_render<W_, F_, M_>), dim3(tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),       \
-                       trig_table(), b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, o32, o64, parts, nl, nf)
+                       trig_table(), b->nvoices, vpg, cur, next, start, nframes, o32, o64, parts)
     switch (var) {
     case 1621: SH_LAUNCH_RENDER(16, 2, 1); break;
-    case 1611: SH_LAUNCH_RENDER(16, 1, 1); break;
-    case 821: SH_LAUNCH_RENDER(8, 2, 1); break;
-    case 822: SH_LAUNCH_RENDER(8, 2, 2); break;
-    case 826: SH_LAUNCH_RENDER(8, 2, 6); break;
-    case 827:                                          // 826 + scalar-cache prefetch of the next record
-        hipLaunchKernelGGL((k_bank_render<8, 2, 6, true>), dim3(tiles, groups), dim3(8 * 64), 0, st, ptrs(b),
-                           trig_table(), b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, o32, o64, parts, nl, nf);
-        break;
-    case 427:
-        hipLaunchKernelGGL((k_bank_render<4, 2, 6, true>), dim3(tiles, groups), dim3(4 * 64), 0, st, ptrs(b),
-                           trig_table(), b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, o32, o64, parts, nl, nf);
-        break;
-    case 828: SH_LAUNCH_RENDER(8, 2, 8); break;
-    case 426: SH_LAUNCH_RENDER(4, 2, 6); break;
-    case 428: SH_LAUNCH_RENDER(4, 2, 8); break;
-    case 811: SH_LAUNCH_RENDER(8, 1, 1); break;
-    case 814: SH_LAUNCH_RENDER(8, 1, 4); break;
-    case 841: SH_LAUNCH_RENDER(8, 4, 1); break;
-    case 421: SH_LAUNCH_RENDER(4, 2, 1); break;
-    case 424: SH_LAUNCH_RENDER(4, 2, 4); break;
-    case 411: SH_LAUNCH_RENDER(4, 1, 1); break;
-    case 418: SH_LAUNCH_RENDER(4, 1, 8); break;
-    case 441: SH_LAUNCH_RENDER(4, 4, 1); break;
-    case 844: SH_LAUNCH_RENDER(8, 4, 4); break;
-    case 843: SH_LAUNCH_RENDER(8, 4, 3); break;
     case 1642: SH_LAUNCH_RENDER(16, 4, 2); break;
+    case 821: SH_LAUNCH_RENDER(8, 2, 1); break;
+    case 826: SH_LAUNCH_RENDER(8, 2, 6); break;
+    case 828: SH_LAUNCH_RENDER(8, 2, 8); break;
+    case 811: SH_LAUNCH_RENDER(8, 1, 1); break;
+    case 841: SH_LAUNCH_RENDER(8, 4, 1); break;
+    case 844: SH_LAUNCH_RENDER(8, 4, 4); break;
+    case 846: SH_LAUNCH_RENDER(8, 4, 6); break;
+    case 882: SH_LAUNCH_RENDER(8, 8, 2); break;
+    case 884: SH_LAUNCH_RENDER(8, 8, 4); break;
+    case 421: SH_LAUNCH_RENDER(4, 2, 1); break;
+    case 426: SH_LAUNCH_RENDER(4, 2, 6); break;
+    case 411: SH_LAUNCH_RENDER(4, 1, 1); break;
+    case 441: SH_LAUNCH_RENDER(4, 4, 1); break;
     case 444: SH_LAUNCH_RENDER(4, 4, 4); break;
     case 211: SH_LAUNCH_RENDER(2, 1, 1); break;
     case 221: SH_LAUNCH_RENDER(2, 2, 1); break;
@@ -1200,7 +1361,7 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
                            (const double2*)parts, groups, nframes, o32, o64);
         SH_CHECK_LAUNCH("k_bus_combine");
     }
-    if (nl) {
+    if (next.launch) {
         b->spec_valid = true;
         b->spec_start = start + nframes;
         b->spec_nframes = nframes;

@@ -1,0 +1,143 @@
+// Microbenchmark: the inner loop of k_bank_render reduced to its common case (polynomial Harmonics voice, folded
+// gains, tile on one table piece), in isolation -- how fast can one (wave, voice) iteration go on gfx950 when the
+// general kernel's flag tests, cold paths and register pressure are taken away?  Variants:
+//   MODE 0: record (184 B) through scalar loads, like the production kernel
+//   MODE 1: same, next record's loads issued before this voice's arithmetic (software prefetch into SGPRs)
+//   MODE 2: no record loads at all (coefficients loop-invariant): the pure arithmetic floor
+// build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I synthesizer_amd/csrc tools/ubench_fastloop.hip -o tools/ubench_fastloop.bin
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "devmath.hpp"
+
+struct alignas(64) FastRec {
+    double t_base, dt, gl, gr, rot_c, rot_s;
+    double poly[16];
+    double pad[2];
+};
+static_assert(sizeof(FastRec) == 192, "FastRec");
+
+#define AS4 __attribute__((address_space(4)))
+
+template <int FPL, int MODE, int WAVES, int MINW, int EXTRA = 0>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k(const FastRec* __restrict__ recs, const shm::sc_pair* __restrict__ trig_g,
+                                                      uint32_t nvoices, uint32_t vpg, uint32_t nframes, double2* __restrict__ parts) {
+    __shared__ double red[WAVES][2][64 * FPL];
+    __shared__ shm::sc_pair trig[shm::TRIG_N];
+    __shared__ double extra[EXTRA ? EXTRA : 1];           // occupancy limiter
+    if (EXTRA && nframes == 0xFFFFFFFFu) extra[threadIdx.x] = 1.0;
+    for (uint32_t k2 = threadIdx.x; k2 < shm::TRIG_N; k2 += WAVES * 64) trig[k2] = trig_g[k2];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile0 = blockIdx.x * (64 * FPL);
+    const uint32_t v0 = blockIdx.y * vpg;
+    uint32_t v1 = v0 + vpg;
+    if (v1 > nvoices) v1 = nvoices;
+    double di0 = (double)(tile0 + lane);
+    double accl[FPL], accr[FPL];
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) { accl[j] = 0.0; accr[j] = 0.0; }
+    const FastRec AS4* rp = (const FastRec AS4*)(recs + v0 + wave);
+    for (uint32_t vi = v0 + wave; vi < v1; vi += WAVES, rp += WAVES) {
+        const FastRec AS4* q = MODE == 2 ? (const FastRec AS4*)recs : rp;
+        const double t_base = q->t_base, dt = q->dt, gl = q->gl, gr = q->gr, rc = q->rot_c, rs = q->rot_s;
+        double poly[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+        double sn[FPL], cs[FPL], pv[FPL];
+        shm::sincos_tab(fma(di0, dt, t_base), trig, sn[0], cs[0]);
+#pragma unroll
+        for (int j = 1; j < FPL; ++j) {
+            sn[j] = fma(sn[j - 1], rc, cs[j - 1] * rs);
+            cs[j] = fma(cs[j - 1], rc, -(sn[j - 1] * rs));
+        }
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) pv[j] = fma(poly[0], cs[j], poly[1]);
+#pragma unroll
+        for (int u = 2; u < 16; ++u) {
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) pv[j] = fma(pv[j], cs[j], poly[u]);
+        }
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const double x = pv[j] * sn[j];
+            accl[j] = fma(gl, x, accl[j]);
+            accr[j] = fma(gr, x, accr[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        red[wave][0][j * 64 + lane] = accl[j];
+        red[wave][1][j * 64 + lane] = accr[j];
+    }
+    __syncthreads();
+    if (wave < FPL) {
+        const uint32_t f = wave * 64 + lane;
+        const uint32_t raw = tile0 + f;
+        if (raw < nframes) {
+            double l = red[0][0][f], r = red[0][1][f];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) { l += red[w][0][f]; r += red[w][1][f]; }
+            parts[(size_t)blockIdx.y * nframes + raw] = make_double2(l, r);
+        }
+    }
+}
+
+template <int FPL, int MODE, int WAVES, int MINW, int EXTRA = 0>
+void run(const char* name, const FastRec* d_recs, const shm::sc_pair* d_trig, double2* d_parts, uint32_t nvoices, uint32_t nframes, uint32_t groups) {
+    const uint32_t tiles = (nframes + 64 * FPL - 1) / (64 * FPL);
+    const uint32_t vpg = (nvoices + groups - 1) / groups;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        for (int it = 0; it < 20; ++it)
+            hipLaunchKernelGGL((k<FPL, MODE, WAVES, MINW, EXTRA>), dim3(tiles, groups), dim3(WAVES * 64), 0, 0, d_recs, d_trig, nvoices, vpg, nframes, d_parts);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms / 20 < best) best = ms / 20;
+    }
+    const double per_vs = (17.0 + 4.0 * (FPL - 1)) / FPL + 1.0 / FPL + 16.0 + 3.0;      // float64 ops per voice-sample
+    const double fl = (double)nvoices * nframes * per_vs / (best * 1e-3) / 1e12;
+    printf("%-34s groups %2u: %.1f us, %.0f G voice-samples/s, %.1f T f64 lane-ops/s (%.0f%% of 39.3)\n", name, groups, best * 1e3,
+           (double)nvoices * nframes / (best * 1e-3) / 1e9, fl, fl / 39.3 * 100);
+}
+
+int main() {
+    const uint32_t nvoices = 1024, nframes = 48000;
+    std::vector<FastRec> recs(nvoices);
+    srand(1);
+    for (auto& r : recs) {
+        r.t_base = (rand() % 1000) * 0.01;
+        r.dt = 0.01 + (rand() % 1000) * 1e-4;
+        r.gl = 0.01; r.gr = 0.02;
+        r.rot_c = cos(64 * r.dt); r.rot_s = sin(64 * r.dt);
+        for (int u = 0; u < 16; ++u) r.poly[u] = (rand() % 2000 - 1000) * 1e-3;
+    }
+    std::vector<shm::sc_pair> trig(shm::TRIG_N);
+    for (int k2 = 0; k2 < shm::TRIG_N; ++k2) { trig[k2].s = sin(2 * M_PI * k2 / shm::TRIG_N); trig[k2].c = cos(2 * M_PI * k2 / shm::TRIG_N); }
+    FastRec* d_recs; shm::sc_pair* d_trig; double2* d_parts;
+    hipMalloc(&d_recs, sizeof(FastRec) * nvoices);
+    hipMalloc(&d_trig, sizeof(shm::sc_pair) * shm::TRIG_N);
+    hipMalloc(&d_parts, sizeof(double2) * nframes * 64);
+    hipMemcpy(d_recs, recs.data(), sizeof(FastRec) * nvoices, hipMemcpyHostToDevice);
+    hipMemcpy(d_trig, trig.data(), sizeof(shm::sc_pair) * shm::TRIG_N, hipMemcpyHostToDevice);
+    for (uint32_t groups : {8u}) {
+        run<4, 0, 8, 4>("FPL4 s_load rec, 8w min4", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+        run<4, 0, 8, 6>("FPL4 s_load rec, 8w min6", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+        run<4, 0, 8, 8>("FPL4 s_load rec, 8w min8", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+        run<4, 2, 8, 6>("FPL4 no loads,   8w min6", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+        run<2, 0, 8, 6>("FPL2 s_load rec, 8w min6", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+        run<2, 2, 8, 6>("FPL2 no loads,   8w min6", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+        run<8, 0, 8, 4>("FPL8 s_load rec, 8w min4", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+        run<4, 0, 4, 6>("FPL4 s_load rec, 4w min6", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+        run<4, 0, 8, 4, 5120>("FPL4 8w, LDS 80K: 2 blocks/CU", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+        run<4, 0, 8, 4, 1536>("FPL4 8w, LDS 52K: 3 blocks/CU", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+    }
+    return 0;
+}
