@@ -214,3 +214,42 @@ def test_bank_with_released_voices(gpu):
     mat = bank.generate(2000, start=int(0.3 * SR))
     for i in range(n_v):
         assert np.array_equal(mat[i], make(G)[i].render(2000, start=int(0.3 * SR)))
+
+
+def test_lean_loop_classification_and_parity(gpu):
+    """The render kernel sends steady voices (polynomial Harmonics, constant envelope gain, one phase-table piece per
+    launch) through its lean loop and the rest through the general code; the split changes per block.  Streaming
+    block by block (launch records of block s+1 prepared inside block s's kernel) must agree with the materialise +
+    mix path, which knows no lean loop, and with the C oracle -- through attack/decay (nothing is lean), the first
+    sustain blocks (many voices cross a piece end) and later ones (almost all lean), for a bank with several voice
+    groups and a ragged last chunk."""
+    import ctypes as C
+    from oracle import c_oracle as CO
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    n_v, block = 333, 12000
+    adsr = {"attack": 0.01, "decay": 0.05, "sustain": 5.0, "sustain_level": 0.6, "release": 0.2}
+    gv, gains = additive_voices(G, n_v, SR, seed=3, adsr=adsr)
+    ov, _ = additive_voices(O, n_v, SR, seed=3, adsr=adsr)
+    bank = VoiceBank(gv, gains=gains)
+    check = VoiceBank(additive_voices(G, n_v, SR, seed=3, adsr=adsr)[0], gains=gains)
+    want = CO.mix_bus(np.stack([CO.render(v, 4 * block) for v in ov]), gains)
+    stats = []
+    for s in range(12):
+        got = bank.render(block, start=s * block)
+        a, b = C.c_uint32(), C.c_uint32()
+        N.check(N.lib().sh_bank_launch_stats(bank._bank.handle, C.byref(a), C.byref(b)))
+        stats.append((a.value, b.value))
+        assert a.value + b.value == n_v                      # nobody is silent yet
+        two = check.render_two_step(block, start=s * block)
+        assert np.max(np.abs(got - two)) < 2e-7, s
+        if s < 4:
+            assert rms(got, want[s * block:(s + 1) * block]) <= RMS_TOL, s
+            assert np.max(np.abs(got - want[s * block:(s + 1) * block])) < 5e-7, s
+    assert stats[0][0] == 0                                   # attack and decay lie inside block 0: no constant gain
+    assert stats[-1][0] > 0.8 * n_v                           # later almost everything is lean
+    assert any(0 < f < n_v for f, _ in stats[1:])             # and in between the two loops share the work
+    # random access (no speculation) gives the same block
+    again = bank.render(block, start=7 * block)
+    assert np.array_equal(again, VoiceBank(additive_voices(G, n_v, SR, seed=3, adsr=adsr)[0], gains=gains).render(block, start=7 * block))
