@@ -94,16 +94,23 @@ struct alignas(16) VoiceFM {      // only read for FM voices
 static_assert(sizeof(VoiceFM) == 80, "VoiceFM layout");
 
 // The common voice of an additive bank in steady state -- polynomial Harmonics, no FM, amplitude and (constant)
-// envelope gain folded into the bus gains, the whole launch on one table piece -- needs only this much per launch.
+// envelope gain folded into the bus gains, the launch on one table piece or crossing one piece end -- needs only
+// this much per launch.
 // The render kernel walks these records in a loop of its own, with none of the general code's flag tests.
 struct alignas(64) FastRec {
-    double t_base, dt;            // t(i) = fma(i, dt, t_base) for every frame i of the launch
+    double t_base, dt;            // frames i < remain: t(i) = fma(i, dt, t_base)
     double gain_l, gain_r;        // amplitude * envelope gain * bus gain
     double rot_c, rot_s;          // cos / sin of 64*dt
     double poly[16];              // sum_k a_k sin(k t) = sin(t) * P(cos t)
-    double pad[2];
+    // the launch may cross ONE end of a phase-table piece (a binade of the running sum), at frame `remain`:
+    double t0_b, dt_b;            // frames i >= remain: t(i) = fma(i - remain, dt_b, t0_b)
+    double rot_c_b, rot_s_b;      // cos / sin of 64*dt_b
+    double off_b;                 // (double)remain
+    uint32_t remain;              // 0xFFFFFFFF: no crossing in this launch
+    uint32_t pad0;
+    double pad[3];
 };
-static_assert(sizeof(FastRec) == 192, "FastRec layout");
+static_assert(sizeof(FastRec) == 256, "FastRec layout");
 
 // One set of per-launch data (double-buffered in the bank).  Voices are classified per chunk of 64 consecutive
 // voices: the fast voices of chunk c get a FastRec, compacted at fast[64c ..], the others are listed by index in
@@ -119,6 +126,8 @@ struct LaunchSet {
 struct PrepInfo {                 // what prepare_voice found, for the classification
     bool   fast, silent;
     double t_base, dt, gain_l, gain_r, rot_c, rot_s;
+    double t0_b, dt_b, rot_c_b, rot_s_b;
+    uint32_t remain;
     const double* harm;
 };
 
@@ -248,7 +257,18 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     o->gain_r = gain_r;
     o->flags = flags;
     info.silent = (flags & FL_SILENT) != 0;
-    info.fast = (flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) && rem >= (uint64_t)nframes;
+    // lean: the launch lies on the current table piece, or on it and the next one
+    const bool one_piece = rem >= (uint64_t)nframes;
+    const bool two_pieces = !one_piece && lo + 1 < cnt && ((lo + 2 < cnt) ? (tab[lo + 2].n0 - start >= (uint64_t)nframes) : true);
+    info.fast = (flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) && (one_piece || two_pieces);
+    info.remain = one_piece ? 0xFFFFFFFFu : (uint32_t)rem;
+    info.t0_b = one_piece ? t_base : tab[lo + 1].t0;
+    info.dt_b = one_piece ? dt : tab[lo + 1].dt;
+    {
+        const double2 rb = B.seg_rot[off + (one_piece ? lo : lo + 1)];
+        info.rot_c_b = rb.x;
+        info.rot_s_b = rb.y;
+    }
     info.t_base = t_base;
     info.dt = dt;
     info.gain_l = gain_l;
@@ -301,7 +321,11 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         f->rot_c = info.rot_c; f->rot_s = info.rot_s;
 #pragma unroll
         for (int u = 0; u < 16; ++u) f->poly[u] = info.harm[u];
-        f->pad[0] = 0.0; f->pad[1] = 0.0;
+        f->t0_b = info.t0_b; f->dt_b = info.dt_b;
+        f->rot_c_b = info.rot_c_b; f->rot_s_b = info.rot_s_b;
+        f->off_b = (double)info.remain;
+        f->remain = info.remain;
+        f->pad0 = 0;
     }
     if (is_gen) S.gen_idx[c * 64 + (uint32_t)__popcll(mg & below)] = vi;
     if (lane == 0) {
@@ -650,7 +674,8 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
 // partial (L, R) per lane; LDS-staged sum across the waves; one store per frame.  With one group the block
 // writes the final bus; with several it writes a float64 partial bus per group and k_bus_combine folds
 // them in group order -- either way voices are summed in a fixed order (reproducible run to run).
-template <int WAVES, int FPL, int MINW>
+// LISTS = false: the bank has no voice that could ever take the lean loop (e.g. all FM): walk the voice table directly.
+template <int WAVES, int FPL, int MINW, bool LISTS = true>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                   uint32_t nvoices, uint32_t voices_per_group,
                                                                   LaunchSet cur, LaunchSet next,
@@ -694,6 +719,23 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         accl[j] = 0.0;
         accr[j] = 0.0;
     }
+    if constexpr (!LISTS) {
+        const uint32_t v0 = blockIdx.y * voices_per_group;
+        uint32_t v1 = v0 + voices_per_group;
+        if (v1 > nvoices) v1 = nvoices;
+        const VoiceLaunch SH_CONST_AS* rp = as_const(cur.launch) + v0 + wave;
+        for (uint32_t vi = v0 + wave; vi < v1; vi += WAVES, rp += WAVES) {
+            const VoiceRegs r = load_record(rp);
+            if (r.flags & FL_SILENT) continue;       // the note was released before this block: contributes exact zeros
+            double x[FPL];
+            voice_block<FPL, true>(r, cur.fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                accl[j] = fma(r.gain_l, x[j], accl[j]);
+                accr[j] = fma(r.gain_r, x[j], accr[j]);
+            }
+        }
+    } else {
     // ---- fast voices: one table lookup, FPL-1 rotations, the Horner chains, two accumulations per frame ----
     // Wave w takes every WAVES-th list entry; the offset carries over from chunk to chunk so that the waves'
     // shares of the whole group differ by at most one voice.
@@ -703,16 +745,44 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64 + first;
         uint32_t p = first;
         for (; p < nfast; p += WAVES, q += WAVES) {
-            const double t_base = q->t_base, dt = q->dt, gl = q->gain_l, gr = q->gain_r, rc = q->rot_c, rs = q->rot_s;
+            // the whole record in ONE batch of scalar loads: the empty asm makes every field live here, so the compiler
+            // cannot sink the loads of the second piece's fields behind the tests below (it did: three dependent
+            // round trips per voice instead of one)
+            const double gl = q->gain_l, gr = q->gain_r;
+            const uint32_t remain = q->remain;
+            const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
+            const double tb = q->t0_b, db = q->dt_b, rcb = q->rot_c_b, rsb = q->rot_s_b, ob = q->off_b;
             double poly[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+            asm volatile("" :: "s"(gl), "s"(gr), "s"(remain), "s"(ta), "s"(da), "s"(rca), "s"(rsa), "s"(tb), "s"(db), "s"(rcb),
+                         "s"(rsb), "s"(ob), "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
+                         "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
+                         "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
             double sn[FPL], cs[FPL], pv[FPL];
-            shm::sincos_tab(fma(di[0], dt, t_base), trig, sn[0], cs[0]);
+            if (remain == 0xFFFFFFFFu) {                  // no piece end inside the launch: nothing to decide
+                shm::sincos_tab(fma(di[0], da, ta), trig, sn[0], cs[0]);
 #pragma unroll
-            for (int j = 1; j < FPL; ++j) {               // frame j is 64 samples after frame j-1: rotate by 64*dt
-                sn[j] = fma(sn[j - 1], rc, cs[j - 1] * rs);
-                cs[j] = fma(cs[j - 1], rc, -(sn[j - 1] * rs));
+                for (int j = 1; j < FPL; ++j) {           // frame j is 64 samples after frame j-1: rotate by 64*dt
+                    sn[j] = fma(sn[j - 1], rca, cs[j - 1] * rsa);
+                    cs[j] = fma(cs[j - 1], rca, -(sn[j - 1] * rsa));
+                }
+            } else if (tile0 >= remain || tile_last < remain) {       // the tile lies on one of the two pieces (uniform)
+                const bool on_b = tile0 >= remain;
+                const double t_base = on_b ? tb : ta, dt = on_b ? db : da;
+                const double rc = on_b ? rcb : rca, rs = on_b ? rsb : rsa;
+                const double off = on_b ? ob : 0.0;
+                shm::sincos_tab(fma(di[0] - off, dt, t_base), trig, sn[0], cs[0]);
+#pragma unroll
+                for (int j = 1; j < FPL; ++j) {
+                    sn[j] = fma(sn[j - 1], rc, cs[j - 1] * rs);
+                    cs[j] = fma(cs[j - 1], rc, -(sn[j - 1] * rs));
+                }
+            } else {                                      // the one tile per crossing that straddles the piece end
+                double th[FPL];
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) th[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+                shm::sincos_tab_n<FPL>(th, trig, sn, cs);
             }
 #pragma unroll
             for (int j = 0; j < FPL; ++j) pv[j] = fma(poly[0], cs[j], poly[1]);
@@ -736,8 +806,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         const uint32_t ngen = as_const(cur.counts)[2 * c + 1];
         const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
         uint32_t p = first;
+        uint32_t vi_next = p < ngen ? idx[p] : 0u;
         for (; p < ngen; p += WAVES) {
-            const uint32_t vi = idx[p];
+            const uint32_t vi = vi_next;
+            vi_next = p + WAVES < ngen ? idx[p + WAVES] : 0u;       // in flight with this voice's record: one round trip less
             const VoiceRegs r = load_record(as_const(cur.launch) + vi);
             double x[FPL];
             voice_block<FPL, true>(r, cur.fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
@@ -748,6 +820,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             }
         }
         first = p - ngen;
+    }
     }
 #pragma unroll
     for (int j = 0; j < FPL; ++j) {
@@ -1009,6 +1082,7 @@ struct sh_bank {
     bool        spec_valid = false;
     uint64_t    spec_start = 0;
     uint32_t    spec_nframes = 0;
+    uint32_t    lean_candidates = 0;      // voices that can take the lean loop in some launch (static properties)
     uint32_t    last_groups = 0;          // voice groups of the last sh_bank_render launch (sh_bank_launch_stats)
     float2*     d_gains = nullptr;
     uint32_t    nsegs = 0, ncoefs = 0, npartials = 0;
@@ -1096,6 +1170,9 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     b->ncoefs = ncoefs;
     b->npartials = npartials;
     b->h_voices.assign(voices, voices + nvoices);
+    for (uint32_t i = 0; i < nvoices; ++i)
+        if (voices[i].kind == SH_HARMONICS && voices[i].harm_dense == 2 && voices[i].fm_mode == SH_FM_NONE && voices[i].bias == 0.0 && !voices[i].flip)
+            b->lean_candidates += 1;
     std::vector<float2> gains(nvoices);
     for (uint32_t i = 0; i < nvoices; ++i) gains[i] = make_float2(voices[i].gain_l, voices[i].gain_r);
     int rc = upload_array(&b->d_voices, voices, nvoices, st);
@@ -1303,7 +1380,7 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
         variant = e ? atoi(e) : 0;
     }
     int var = variant;
-    if (var == 0) var = b->nvoices >= 128 ? 844 : (b->nvoices >= 64 ? 826 : (b->nvoices >= 8 ? 421 : 211));
+    if (var == 0) var = b->nvoices >= 128 ? (2 * b->lean_candidates >= b->nvoices ? 444 : 844) : (b->nvoices >= 64 ? 826 : (b->nvoices >= 8 ? 421 : 211));
     const int W = var / 100, F = (var / 10) % 10;
     // enough workgroups to cover the 256 CUs several times over: split the voices into groups when the
     // frame range alone gives too few tiles (SYNTHHIP_GROUPS overrides)
@@ -1330,9 +1407,14 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     const LaunchSet cur = launch_set(b, b->cur);
     LaunchSet next = launch_set(b, b->cur ^ 1);
     if (!speculation_enabled()) next.launch = nullptr;
-#define SH_LAUNCH_RENDER(W_, F_, M_)                                                                          \
-    hipLaunchKernelGGL((k_bank_render<W_, F_, M_>), dim3(tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),       \
-                       trig_table(), b->nvoices, vpg, cur, next, start, nframes, o32, o64, parts)
+    const bool lists = b->lean_candidates != 0;
+#define SH_LAUNCH_RENDER(W_, F_, M_)                                                                                \
+    do {                                                                                                            \
+        if (lists) hipLaunchKernelGGL((k_bank_render<W_, F_, M_, true>), dim3(tiles, groups), dim3(W_ * 64), 0, st, \
+                                      ptrs(b), trig_table(), b->nvoices, vpg, cur, next, start, nframes, o32, o64, parts); \
+        else hipLaunchKernelGGL((k_bank_render<W_, F_, M_, false>), dim3(tiles, groups), dim3(W_ * 64), 0, st,      \
+                                ptrs(b), trig_table(), b->nvoices, vpg, cur, next, start, nframes, o32, o64, parts); \
+    } while (0)
     switch (var) {
     case 1621: SH_LAUNCH_RENDER(16, 2, 1); break;
     case 1642: SH_LAUNCH_RENDER(16, 4, 2); break;

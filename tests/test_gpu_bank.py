@@ -221,8 +221,8 @@ def test_lean_loop_classification_and_parity(gpu):
     launch) through its lean loop and the rest through the general code; the split changes per block.  Streaming
     block by block (launch records of block s+1 prepared inside block s's kernel) must agree with the materialise +
     mix path, which knows no lean loop, and with the C oracle -- through attack/decay (nothing is lean), the first
-    sustain blocks (many voices cross a piece end) and later ones (almost all lean), for a bank with several voice
-    groups and a ragged last chunk."""
+    sustain blocks (many voices cross a phase-table piece end inside the block: the lean loop's two-piece and
+    straddling-tile paths) and later ones, for a bank with several voice groups and a ragged last chunk."""
     import ctypes as C
     from oracle import c_oracle as CO
     from synthesizer_amd import _native as N
@@ -249,7 +249,6 @@ def test_lean_loop_classification_and_parity(gpu):
             assert np.max(np.abs(got - want[s * block:(s + 1) * block])) < 5e-7, s
     assert stats[0][0] == 0                                   # attack and decay lie inside block 0: no constant gain
     assert stats[-1][0] > 0.8 * n_v                           # later almost everything is lean
-    assert any(0 < f < n_v for f, _ in stats[1:])             # and in between the two loops share the work
     # random access (no speculation) gives the same block
     again = bank.render(block, start=7 * block)
     assert np.array_equal(again, VoiceBank(additive_voices(G, n_v, SR, seed=3, adsr=adsr)[0], gains=gains).render(block, start=7 * block))

@@ -127,6 +127,19 @@ int main() {
     hipMalloc(&d_parts, sizeof(double2) * nframes * 64);
     hipMemcpy(d_recs, recs.data(), sizeof(FastRec) * nvoices, hipMemcpyHostToDevice);
     hipMemcpy(d_trig, trig.data(), sizeof(shm::sc_pair) * shm::TRIG_N, hipMemcpyHostToDevice);
+    // sustained load: does the clock hold?  2000 launches back to back
+    {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const uint32_t tiles = (nframes + 255) / 256, vpg = 128;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            for (int it = 0; it < 2000; ++it)
+                hipLaunchKernelGGL((k<4, 0, 8, 4, 5120>), dim3(tiles, 8), dim3(512), 0, 0, d_recs, d_trig, nvoices, vpg, nframes, d_parts);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("sustained 2000 launches: %.1f us per launch\n", ms / 2000 * 1e3);
+        }
+    }
     for (uint32_t groups : {8u}) {
         run<4, 0, 8, 4>("FPL4 s_load rec, 8w min4", d_recs, d_trig, d_parts, nvoices, nframes, groups);
         run<4, 0, 8, 6>("FPL4 s_load rec, 8w min6", d_recs, d_trig, d_parts, nvoices, nframes, groups);
