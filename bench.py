@@ -239,9 +239,9 @@ def main() -> int:
     kern_s = ev_ms / 1e3 / K         # average duration of one block (k_locate + k_bank_render [+ reduce/finalize])
     fused_bytes = 8.0 * F            # algorithmic: one float32 stereo frame written per output frame
     # float64 VALU lane-operations per voice-sample of k_bank_render on this workload, from rocprofv3:
-    # (SQ_INSTS_VALU_FMA_F64 + MUL_F64 + ADD_F64) * 64 / voice-samples per launch = 20.65 M * 64 / 49.152 M
-    # (profiles/r01_summary.md, "SQ instruction mix"; all VALU: 37.6 per voice-sample, prepare step included)
-    harm_lane_ops = 26.9
+    # (SQ_INSTS_VALU_FMA_F64 + MUL_F64 + ADD_F64) * 64 / voice-samples per launch = 20.34 M * 64 / 49.152 M
+    # (profiles/r01_summary.md, "SQ instruction mix"; all VALU: 33.0 per voice-sample, prepare step included)
+    harm_lane_ops = 26.5
     out = {
         "metric": "Msamples/sec mixed to stereo bus, 1024-voice additive @48kHz",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": Wm,
