@@ -11,13 +11,17 @@
 // -ffp-contract=off so that a*b+c is fused only where fma() is written.
 //
 // Kernels
-//   k_prepare       one thread per voice: resolve everything that depends on `start` (phase-table piece,
-//                   envelope lines) into a 160-byte launch record
-//   k_generate      grid (frame tiles, voices): voice-major float32 PCM in HBM (4 B per voice-sample)
-//   k_bank_render   fused generate-and-mix: block = 64 frames x W waves, each wave walks a strided
-//                   subset of the voices with the voice record in SGPRs, float64 partial (L, R)
-//                   per lane, LDS-staged sum across the W waves, one float2 store per frame
-//   k_mix_bus_f32   HBM-bound mixer over materialised voices (4N+8 B per frame)
+//   k_prepare_chunks  one wavefront per 64 voices: resolve everything that depends on `start` (phase-table piece,
+//                     envelope lines) into a 416-byte launch record per voice, and classify the voices for the render
+//                     kernel (lean FastRec list / general index list per chunk).  In a stream the same code runs
+//                     inside the previous block's render kernel (its first workgroups), not as a kernel of its own
+//   k_prepare         the same records for a single voice (sh_osc_render)
+//   k_generate        grid (frame tiles, voice groups): voice-major float32 PCM in HBM (4 B per voice-sample)
+//   k_bank_render     fused generate-and-mix: block = W waves on one tile of 64*FPL frames; a wave walks its share of the
+//                     lean list (record in SGPRs, one table lookup + rotations + Horner per voice) and of the general
+//                     list (voice_block); float64 partial (L, R) per lane, LDS-staged sum across the waves
+//   k_bus_combine     folds the voice groups' partial buses in group order, rounds to float32
+//   k_mix_bus_f32     HBM-bound mixer over materialised voices (4N+8 B per frame)
 #include "common.hpp"
 #include "devmath.hpp"
 #include <new>
@@ -683,9 +687,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                                                                   float2* __restrict__ bus32,
                                                                   double2* __restrict__ bus64,
                                                                   double2* __restrict__ parts) {
-    // Sequential streaming is the common call pattern: the first workgroup also resolves the launch records
-    // of the block that is expected next (start + nframes, same launch shape) into the other record set, so
-    // that launch needs no prepare kernel of its own (a 7 us kernel + a launch boundary per block otherwise).
+    // Sequential streaming is the common call pattern: this launch also resolves the launch records of the
+    // block that is expected next (start + nframes) into the other record set, so that launch needs no prepare
+    // kernel of its own (a 15 us kernel + a launch boundary per block otherwise).
     // The chunks of 64 voices are spread over the first workgroups (one wavefront each, on different CUs): a single
     // workgroup doing all of it competes with three rendering workgroups for its CU and ends up as the launch's tail.
     if (next.launch) {
