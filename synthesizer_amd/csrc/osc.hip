@@ -111,10 +111,13 @@ struct alignas(64) FastRec {
     double rot_c_b, rot_s_b;      // cos / sin of 64*dt_b
     double off_b;                 // (double)remain
     uint32_t remain;              // 0xFFFFFFFF: no crossing in this launch
-    uint32_t pad0;
+    uint32_t kind;                // LEAN_HARM: the fields as described; LEAN_FM: Sine carrier with a closed-form Sine LFO --
+                                  // t is the accumulated TIME table, poly[0..10] = frequency, phase0, f_inc, lfo_a_rel, lfo_d,
+                                  // lfo_K, lfo_C0, lfo_bias, lfo_rot_c, lfo_rot_s, (double)start (see VoiceFM)
     double pad[3];
 };
 static_assert(sizeof(FastRec) == 256, "FastRec layout");
+constexpr uint32_t LEAN_HARM = 0, LEAN_FM = 1;
 
 // One set of per-launch data (double-buffered in the bank).  Voices are classified per chunk of 64 consecutive
 // voices: the fast voices of chunk c get a FastRec, compacted at fast[64c ..], the others are listed by index in
@@ -132,6 +135,8 @@ struct PrepInfo {                 // what prepare_voice found, for the classific
     double t_base, dt, gain_l, gain_r, rot_c, rot_s;
     double t0_b, dt_b, rot_c_b, rot_s_b;
     uint32_t remain;
+    uint32_t kind;                // LEAN_HARM / LEAN_FM
+    double   fmv[11];             // LEAN_FM: the values that go to FastRec::poly[0..10]
     const double* harm;
 };
 
@@ -260,11 +265,20 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     o->gain_l = gain_l;
     o->gain_r = gain_r;
     o->flags = flags;
+    // a Sine carrier with a closed-form Sine LFO can take the lean loop too (its record folds amplitude and envelope
+    // into the gains like FL_FOLDED does; the general code is not told: its Sine path applies the amplitude itself)
+    const bool lean_fm = v.kind == SH_SINE && v.fm_mode == SH_FM_SINE && v.bias == 0.0 && (flags & FL_ENV_UNIFORM) && slu == 0.0 &&
+                         !(flags & FL_SILENT);
+    info.kind = lean_fm ? LEAN_FM : LEAN_HARM;
+    if (lean_fm) {
+        gain_l = (v.amplitude * g0u) * gain_l;
+        gain_r = (v.amplitude * g0u) * gain_r;
+    }
     info.silent = (flags & FL_SILENT) != 0;
     // lean: the launch lies on the current table piece, or on it and the next one
     const bool one_piece = rem >= (uint64_t)nframes;
     const bool two_pieces = !one_piece && lo + 1 < cnt && ((lo + 2 < cnt) ? (tab[lo + 2].n0 - start >= (uint64_t)nframes) : true);
-    info.fast = (flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) && (one_piece || two_pieces);
+    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm) && (one_piece || two_pieces);
     info.remain = one_piece ? 0xFFFFFFFFu : (uint32_t)rem;
     info.t0_b = one_piece ? t_base : tab[lo + 1].t0;
     info.dt_b = one_piece ? dt : tab[lo + 1].dt;
@@ -293,6 +307,10 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         const double2 lrot = B.lfo_rot[first + vi];
         f->lfo_rot_c = lrot.x;
         f->lfo_rot_s = lrot.y;
+        info.fmv[0] = v.frequency; info.fmv[1] = v.fm_phase0; info.fmv[2] = v.frequency * v.fm_inc;
+        info.fmv[3] = fma((double)start - 0.5, v.lfo_d, v.lfo_a);
+        info.fmv[4] = v.lfo_d; info.fmv[5] = v.lfo_K; info.fmv[6] = v.lfo_C0; info.fmv[7] = v.lfo_bias;
+        info.fmv[8] = lrot.x; info.fmv[9] = lrot.y; info.fmv[10] = (double)start;
     }
 }
 
@@ -323,13 +341,18 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         f->t_base = info.t_base; f->dt = info.dt;
         f->gain_l = info.gain_l; f->gain_r = info.gain_r;
         f->rot_c = info.rot_c; f->rot_s = info.rot_s;
+        if (info.kind == LEAN_FM) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) f->poly[u] = info.harm[u];
+            for (int u = 0; u < 16; ++u) f->poly[u] = u < 11 ? info.fmv[u] : 0.0;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f->poly[u] = info.harm[u];
+        }
         f->t0_b = info.t0_b; f->dt_b = info.dt_b;
         f->rot_c_b = info.rot_c_b; f->rot_s_b = info.rot_s_b;
         f->off_b = (double)info.remain;
         f->remain = info.remain;
-        f->pad0 = 0;
+        f->kind = info.kind;
     }
     if (is_gen) S.gen_idx[c * 64 + (uint32_t)__popcll(mg & below)] = vi;
     if (lane == 0) {
@@ -678,8 +701,11 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
 // partial (L, R) per lane; LDS-staged sum across the waves; one store per frame.  With one group the block
 // writes the final bus; with several it writes a float64 partial bus per group and k_bus_combine folds
 // them in group order -- either way voices are summed in a fixed order (reproducible run to run).
-// LISTS = false: the bank has no voice that could ever take the lean loop (e.g. all FM): walk the voice table directly.
-template <int WAVES, int FPL, int MINW, bool LISTS = true>
+// MODE (a static property of the bank): RENDER_DIRECT -- no voice could ever take the lean loop: walk the voice table
+// directly; RENDER_LEAN_HARM -- lean loop for polynomial Harmonics only; RENDER_LEAN_ALL -- also for FM Sine voices (kept
+// out of the Harmonics-only kernel: the extra branch and code cost its loop 5 %).
+enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2 };
+template <int WAVES, int FPL, int MINW, int MODE>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                   uint32_t nvoices, uint32_t voices_per_group,
                                                                   LaunchSet cur, LaunchSet next,
@@ -723,7 +749,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         accl[j] = 0.0;
         accr[j] = 0.0;
     }
-    if constexpr (!LISTS) {
+    if constexpr (MODE == RENDER_DIRECT) {
         const uint32_t v0 = blockIdx.y * voices_per_group;
         uint32_t v1 = v0 + voices_per_group;
         if (v1 > nvoices) v1 = nvoices;
@@ -753,16 +779,51 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             // cannot sink the loads of the second piece's fields behind the tests below (it did: three dependent
             // round trips per voice instead of one)
             const double gl = q->gain_l, gr = q->gain_r;
-            const uint32_t remain = q->remain;
+            const uint32_t remain = q->remain, kind = q->kind;
             const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
             const double tb = q->t0_b, db = q->dt_b, rcb = q->rot_c_b, rsb = q->rot_s_b, ob = q->off_b;
             double poly[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
-            asm volatile("" :: "s"(gl), "s"(gr), "s"(remain), "s"(ta), "s"(da), "s"(rca), "s"(rsa), "s"(tb), "s"(db), "s"(rcb),
+            asm volatile("" :: "s"(gl), "s"(gr), "s"(remain), "s"(kind), "s"(ta), "s"(da), "s"(rca), "s"(rsa), "s"(tb), "s"(db), "s"(rcb),
                          "s"(rsb), "s"(ob), "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
                          "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
                          "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
+            if (MODE == RENDER_LEAN_ALL && kind == LEAN_FM) {
+                // Sine carrier, closed-form Sine LFO (the arithmetic of voice_block's FM path): T = accumulated time
+                double T[FPL];
+                if (remain == 0xFFFFFFFFu || tile_last < remain) {
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) T[j] = fma(di[j], da, ta);
+                } else if (tile0 >= remain) {
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) T[j] = fma(di[j] - ob, db, tb);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) T[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+                }
+                const double frequency = poly[0], phase0 = poly[1], f_inc = poly[2], lfo_a_rel = poly[3], lfo_d = poly[4];
+                const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], lrc = poly[8], lrs = poly[9], startd = poly[10];
+                double ls, lc, th[FPL], sn[FPL], cs[FPL];
+                shm::sincos_tab(fma(di[0], lfo_d, lfo_a_rel), trig, ls, lc);
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    if (j > 0) {                          // the LFO angle of the next frame is one rotation by 64*lfo_d away
+                        const double ns = fma(ls, lrc, lc * lrs), nc = fma(lc, lrc, -(ls * lrs));
+                        ls = ns;
+                        lc = nc;
+                    }
+                    const double Ln = fma(lfo_K, lfo_C0 - lc, lfo_bias * (startd + di[j]));
+                    th[j] = frequency * T[j] + fma(f_inc, Ln, phase0);
+                }
+                shm::sincos_tab_n<FPL>(th, trig, sn, cs);
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    accl[j] = fma(gl, sn[j], accl[j]);
+                    accr[j] = fma(gr, sn[j], accr[j]);
+                }
+                continue;
+            }
             double sn[FPL], cs[FPL], pv[FPL];
             if (remain == 0xFFFFFFFFu) {                  // no piece end inside the launch: nothing to decide
                 shm::sincos_tab(fma(di[0], da, ta), trig, sn[0], cs[0]);
@@ -1087,6 +1148,7 @@ struct sh_bank {
     uint64_t    spec_start = 0;
     uint32_t    spec_nframes = 0;
     uint32_t    lean_candidates = 0;      // voices that can take the lean loop in some launch (static properties)
+    uint32_t    lean_fm_candidates = 0;   // ... of them FM Sine voices
     uint32_t    last_groups = 0;          // voice groups of the last sh_bank_render launch (sh_bank_launch_stats)
     float2*     d_gains = nullptr;
     uint32_t    nsegs = 0, ncoefs = 0, npartials = 0;
@@ -1175,8 +1237,12 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     b->npartials = npartials;
     b->h_voices.assign(voices, voices + nvoices);
     for (uint32_t i = 0; i < nvoices; ++i)
-        if (voices[i].kind == SH_HARMONICS && voices[i].harm_dense == 2 && voices[i].fm_mode == SH_FM_NONE && voices[i].bias == 0.0 && !voices[i].flip)
+        if (voices[i].bias == 0.0 && !voices[i].flip &&
+            ((voices[i].kind == SH_HARMONICS && voices[i].harm_dense == 2 && voices[i].fm_mode == SH_FM_NONE) ||
+             (voices[i].kind == SH_SINE && voices[i].fm_mode == SH_FM_SINE))) {
             b->lean_candidates += 1;
+            if (voices[i].kind == SH_SINE) b->lean_fm_candidates += 1;
+        }
     std::vector<float2> gains(nvoices);
     for (uint32_t i = 0; i < nvoices; ++i) gains[i] = make_float2(voices[i].gain_l, voices[i].gain_r);
     int rc = upload_array(&b->d_voices, voices, nvoices, st);
@@ -1411,28 +1477,23 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     const LaunchSet cur = launch_set(b, b->cur);
     LaunchSet next = launch_set(b, b->cur ^ 1);
     if (!speculation_enabled()) next.launch = nullptr;
-    const bool lists = b->lean_candidates != 0;
-#define SH_LAUNCH_RENDER(W_, F_, M_)                                                                                \
-    do {                                                                                                            \
-        if (lists) hipLaunchKernelGGL((k_bank_render<W_, F_, M_, true>), dim3(tiles, groups), dim3(W_ * 64), 0, st, \
-                                      ptrs(b), trig_table(), b->nvoices, vpg, cur, next, start, nframes, o32, o64, parts); \
-        else hipLaunchKernelGGL((k_bank_render<W_, F_, M_, false>), dim3(tiles, groups), dim3(W_ * 64), 0, st,      \
-                                ptrs(b), trig_table(), b->nvoices, vpg, cur, next, start, nframes, o32, o64, parts); \
+    const int mode = b->lean_candidates == 0 ? RENDER_DIRECT : (b->lean_fm_candidates ? RENDER_LEAN_ALL : RENDER_LEAN_HARM);
+#define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
+    hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),    \
+                       trig_table(), b->nvoices, vpg, cur, next, start, nframes, o32, o64, parts)
+#define SH_LAUNCH_RENDER(W_, F_, M_)                                                 \
+    do {                                                                             \
+        if (mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM);  \
+        else if (mode == RENDER_LEAN_ALL) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_ALL); \
+        else SH_LAUNCH_MODE(W_, F_, M_, RENDER_DIRECT);                              \
     } while (0)
     switch (var) {
     case 1621: SH_LAUNCH_RENDER(16, 2, 1); break;
-    case 1642: SH_LAUNCH_RENDER(16, 4, 2); break;
-    case 821: SH_LAUNCH_RENDER(8, 2, 1); break;
     case 826: SH_LAUNCH_RENDER(8, 2, 6); break;
     case 828: SH_LAUNCH_RENDER(8, 2, 8); break;
-    case 811: SH_LAUNCH_RENDER(8, 1, 1); break;
     case 841: SH_LAUNCH_RENDER(8, 4, 1); break;
     case 844: SH_LAUNCH_RENDER(8, 4, 4); break;
-    case 846: SH_LAUNCH_RENDER(8, 4, 6); break;
-    case 882: SH_LAUNCH_RENDER(8, 8, 2); break;
-    case 884: SH_LAUNCH_RENDER(8, 8, 4); break;
     case 421: SH_LAUNCH_RENDER(4, 2, 1); break;
-    case 426: SH_LAUNCH_RENDER(4, 2, 6); break;
     case 411: SH_LAUNCH_RENDER(4, 1, 1); break;
     case 441: SH_LAUNCH_RENDER(4, 4, 1); break;
     case 444: SH_LAUNCH_RENDER(4, 4, 4); break;
@@ -1441,6 +1502,7 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     default: return sh::set_error(SH_ERR_INVALID, "sh_bank_render: unknown SYNTHHIP_VARIANT %d", var);
     }
 #undef SH_LAUNCH_RENDER
+#undef SH_LAUNCH_MODE
     SH_CHECK_LAUNCH("k_bank_render");
     if (groups > 1) {
         hipLaunchKernelGGL(k_bus_combine, dim3(sh::div_up(nframes, 256)), dim3(256), 0, st,

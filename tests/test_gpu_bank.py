@@ -252,3 +252,66 @@ def test_lean_loop_classification_and_parity(gpu):
     # random access (no speculation) gives the same block
     again = bank.render(block, start=7 * block)
     assert np.array_equal(again, VoiceBank(additive_voices(G, n_v, SR, seed=3, adsr=adsr)[0], gains=gains).render(block, start=7 * block))
+
+
+def test_lean_loop_fm_and_mixed_bank(gpu):
+    """FM Sine voices with a plain Sine LFO take the lean loop too (a second record kind); a bank that mixes them with
+    additive voices, enveloped FM, and kinds that never go lean (Pulse, biased Sine, Clenshaw Harmonics) is summed by
+    both loops in one launch.  Against the C oracle over blocks that include the time table's piece ends (1 s, 2 s, 4 s
+    of accumulated time at 48 kHz: frames 48000, 96000, 192000)."""
+    import ctypes as C
+    from oracle import c_oracle as CO
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    rng = np.random.default_rng(5)
+    nv = 90
+    f = rng.uniform(60, 3000, nv)
+    fm = rng.uniform(0.5, 8, nv)
+    depth = rng.uniform(0, 0.05, nv)
+    gains = [(float(np.float32(a)), float(np.float32(b))) for a, b in rng.uniform(0, 1, (nv, 2)) / np.sqrt(nv)]
+
+    def make(M):
+        out = []
+        for k in range(nv):
+            lfo = M.Sine(float(fm[k]), float(depth[k]), phase=0.3, samplerate=SR)
+            kind = k % 6
+            if kind == 0:
+                v = M.Sine(float(f[k]), 0.7, phase=0.1, fm_lfo=lfo, samplerate=SR)                       # lean FM
+            elif kind == 1:
+                v = M.EnvelopeFilter(M.Sine(float(f[k]), 0.5, fm_lfo=lfo, samplerate=SR), 0.01, 0.02, 9.0, 0.5, 0.1)   # lean FM after decay
+            elif kind == 2:
+                v = M.EnvelopeFilter(M.Harmonics(float(f[k]), [(j, 1.0 / j) for j in range(1, 9)], 0.5, samplerate=SR),
+                                     0.01, 0.02, 9.0, 0.6, 0.1)                                           # lean Harmonics
+            elif kind == 3:
+                v = M.Sine(float(f[k]), 0.5, bias=0.1, fm_lfo=lfo, samplerate=SR)                        # biased: general
+            elif kind == 4:
+                v = M.Pulse(float(f[k]), 0.4, pulsewidth=0.3, samplerate=SR)                              # general
+            else:
+                v = M.Harmonics(float(f[k]), [(1, 1.0), (33, 0.2)], 0.5, samplerate=SR)                   # Clenshaw: general
+            out.append(v)
+        return out
+
+    bank = VoiceBank(make(G), gains=gains)
+    ov = make(O)
+    block = 9000
+    want_all = CO.mix_bus(np.stack([CO.render(v, 190000 + block) for v in ov]), gains)
+    for start in (0, 2 * block, 47000, 95000, 190000):
+        want = want_all[start:start + block]
+        got = bank.render(block, start=start)
+        a, b = C.c_uint32(), C.c_uint32()
+        N.check(N.lib().sh_bank_launch_stats(bank._bank.handle, C.byref(a), C.byref(b)))
+        assert a.value + b.value == nv
+        if start:
+            assert a.value == nv // 2, (start, a.value)           # kinds 0, 1, 2: half of the bank
+        else:
+            assert a.value == 0       # the first frames: the accumulated time runs through many binades, attack / decay
+        assert rms(got, want) <= RMS_TOL, start
+        assert np.max(np.abs(got - want)) < 5e-7, start
+    # the whole FM config goes lean
+    gv, g2 = fm_voices(G, 256, SR, seed=1)
+    fmbank = VoiceBank(gv, gains=g2)
+    fmbank.render(4000, start=12345)
+    a, b = C.c_uint32(), C.c_uint32()
+    N.check(N.lib().sh_bank_launch_stats(fmbank._bank.handle, C.byref(a), C.byref(b)))
+    assert (a.value, b.value) == (256, 0)
