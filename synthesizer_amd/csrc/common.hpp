@@ -14,6 +14,17 @@ struct sh_buf {
 
 namespace sh {
 
+// A bank render with several voice groups leaves float64 partial buses that still have to be folded into the caller's
+// bus.  In a stream of renders that fold is done by the NEXT render kernel's first workgroups (no kernel of its own, no
+// launch boundary); any other API call folds it first (SH_REQUIRE_INIT -> flush_pending).
+struct PendingCombine {
+    bool     active = false;
+    const void* parts = nullptr;     // double2[groups][nframes]
+    uint32_t groups = 0, nframes = 0, tile_frames = 0;
+    void*    o32 = nullptr;          // float2[nframes] or NULL
+    void*    o64 = nullptr;          // double2[nframes] or NULL
+};
+
 struct State {
     bool        initialized = false;
     int         device = -1;
@@ -26,18 +37,33 @@ struct State {
     int*        flag = nullptr;        // device int: overflow flag for quantise
     int*        flag_host = nullptr;   // pinned host mirror
     void*       trig = nullptr;        // device: 512 x (sin, cos) of k*2pi/512, float64 (devmath.hpp sincos_tab)
+    // partial buses of bank renders, double-buffered: one may still await its fold while the next launch fills the other
+    void*       parts_buf[2] = {nullptr, nullptr};
+    size_t      parts_bytes[2] = {0, 0};
+    int         parts_cur = 0;
+    PendingCombine pending;
 };
 
 State& state();
 int  set_error(int code, const char* fmt, ...);
 int  hip_error(hipError_t e, const char* what);
 int  ensure_scratch(size_t bytes);
+int  flush_pending();                  // fold a pending bank-render combine now (osc.hip)
 int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out);   // float64 bus -> float32 (osc.hip)
 
-#define SH_REQUIRE_INIT()                                                              \
+#define SH_REQUIRE_INIT_KEEP_PENDING()                                                 \
     do {                                                                               \
         if (!sh::state().initialized)                                                  \
             return sh::set_error(SH_ERR_NOTINIT, "sh_init() has not been called");     \
+    } while (0)
+
+#define SH_REQUIRE_INIT()                                                              \
+    do {                                                                               \
+        SH_REQUIRE_INIT_KEEP_PENDING();                                                \
+        if (sh::state().pending.active) {                                              \
+            int rc_pending__ = sh::flush_pending();                                    \
+            if (rc_pending__) return rc_pending__;                                     \
+        }                                                                              \
     } while (0)
 
 #define SH_HIP(call)                                                                   \

@@ -98,7 +98,10 @@ int sh_shutdown(void) {
     sh::State& s = state();
     if (!s.initialized) return SH_OK;
     hipStreamSynchronize(s.stream);
+    if (s.pending.active) sh::flush_pending();
+    hipStreamSynchronize(s.stream);
     if (s.scratch) hipFree(s.scratch);
+    for (int k = 0; k < 2; ++k) if (s.parts_buf[k]) hipFree(s.parts_buf[k]);
     if (s.flag) hipFree(s.flag);
     if (s.trig) hipFree(s.trig);
     if (s.flag_host) hipHostFree(s.flag_host);

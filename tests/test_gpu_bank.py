@@ -315,3 +315,43 @@ def test_lean_loop_fm_and_mixed_bank(gpu):
     a, b = C.c_uint32(), C.c_uint32()
     N.check(N.lib().sh_bank_launch_stats(fmbank._bank.handle, C.byref(a), C.byref(b)))
     assert (a.value, b.value) == (256, 0)
+
+
+def test_streaming_defers_the_fold_of_partial_buses(gpu):
+    """With several voice groups a render leaves partial buses; in a stream of renders the next launch folds them
+    (no kernel in between), any other API call folds them first.  Blocks rendered back to back into different buffers,
+    into one reused buffer, with a change of block length in between, and a float64 bus, all read back afterwards,
+    equal the same blocks rendered one at a time."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    nv, block = 512, 6000
+    gv, gains = additive_voices(G, nv, SR, seed=9)
+    bank = VoiceBank(gv, gains=gains)
+    ref = VoiceBank(additive_voices(G, nv, SR, seed=9)[0], gains=gains)
+    single = [ref.render(block, start=s * block) for s in range(6)]          # each followed by a download: folded at once
+    bufs = [N.DeviceBuffer(block * 8) for _ in range(6)]
+    for s in range(6):
+        bank.render_device(block, s * block, bus_f32=bufs[s])                   # nothing between the launches
+    got = [b.download(np.float32, block * 2).reshape(block, 2) for b in bufs]
+    for s in range(6):
+        assert np.array_equal(got[s], single[s]), s
+    # one buffer reused: after the stream it holds the last block
+    one = N.DeviceBuffer(block * 8)
+    for s in range(6):
+        bank.render_device(block, s * block, bus_f32=one)
+    assert np.array_equal(one.download(np.float32, block * 2).reshape(block, 2), single[5])
+    # a different block length in the middle of a stream (other launch shape: folded by a kernel), then float64 buses
+    short = N.DeviceBuffer(1000 * 8)
+    bank.render_device(block, 0, bus_f32=bufs[0])
+    bank.render_device(1000, block, bus_f32=short)
+    bank.render_device(block, 2 * block, bus_f32=bufs[2])
+    assert np.array_equal(bufs[0].download(np.float32, block * 2).reshape(block, 2), single[0])
+    assert np.array_equal(short.download(np.float32, 2000).reshape(1000, 2), ref.render(1000, start=block))
+    assert np.array_equal(bufs[2].download(np.float32, block * 2).reshape(block, 2), single[2])
+    d64 = [N.DeviceBuffer(block * 16) for _ in range(3)]
+    for s in range(3):
+        bank.render_device(block, s * block, bus_f32=None, bus_f64=d64[s])
+    for s in range(3):
+        v = d64[s].download(np.float64, block * 2).reshape(block, 2)
+        assert np.array_equal(v.astype(np.float32), single[s]), s
