@@ -5,6 +5,7 @@
 // shuffle (DPP) reductions + one integer atomic per workgroup for max / sum of squares.
 // Built with -ffp-contract=off: audioop forms val1*lfactor + val2*rfactor with separate roundings.
 #include "common.hpp"
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -211,8 +212,35 @@ __global__ __launch_bounds__(256) void k_absmax_sumsq(const T* __restrict__ in, 
         unsigned long long t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
         unsigned m = s_max[0];
         for (int w = 1; w < 4; ++w) m = s_max[w] > m ? s_max[w] : m;
-        atomicMax(&acc[0], (unsigned long long)m);
-        atomicAdd(&acc[1], t);
+        // per-workgroup results, folded by k_stats_fold: thousands of atomics on two addresses serialise (10 ns each,
+        // 40 % of this kernel's time at 4096 workgroups)
+        acc[2 * blockIdx.x] = (unsigned long long)m;
+        acc[2 * blockIdx.x + 1] = t;
+    }
+}
+
+// one workgroup: out[0] = max, out[1] = sum over the per-workgroup pairs (integer: exact, order-independent)
+__global__ __launch_bounds__(256) void k_stats_fold(const unsigned long long* __restrict__ part, unsigned nblocks,
+                                                    unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long s_sum[4];
+    __shared__ unsigned s_max[4];
+    unsigned mx = 0;
+    unsigned long long sq = 0;
+    for (unsigned b = threadIdx.x; b < nblocks; b += 256) {
+        const unsigned m = (unsigned)part[2 * b];
+        mx = m > mx ? m : mx;
+        sq += part[2 * b + 1];
+    }
+    mx = wave_max_u32(mx);
+    sq = wave_sum_u64(sq);
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_sum[wave] = sq; s_max[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = s_max[0];
+        for (int w = 1; w < 4; ++w) m = s_max[w] > m ? s_max[w] : m;
+        out[0] = (unsigned long long)m;
+        out[1] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
     }
 }
 
@@ -434,20 +462,23 @@ int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, 
     if (sum_squares) *sum_squares = 0.0;
     if (!nbytes) return SH_OK;
     const size_t n = nbytes / width;
-    const unsigned blocks = n / 2048 < 4096 ? (unsigned)(n / 2048 + 1) : 4096u;
-    int rc = sh::ensure_scratch(16 + (size_t)blocks * 8);
+    static const unsigned max_blocks = getenv("SYNTHHIP_STATS_BLOCKS") ? (unsigned)atoi(getenv("SYNTHHIP_STATS_BLOCKS")) : 4096u;
+    const unsigned blocks = n / 2048 < max_blocks ? (unsigned)(n / 2048 + 1) : max_blocks;
+    int rc = sh::ensure_scratch(16 + (size_t)blocks * 24);
     if (rc) return rc;
     hipStream_t st = sh::state().stream;
-    unsigned long long* acc = (unsigned long long*)sh::state().scratch;
-    double* part = (double*)(acc + 2);
-    SH_HIP(hipMemsetAsync(acc, 0, 16, st));
+    unsigned long long* acc = (unsigned long long*)sh::state().scratch;          // [0..1]: result; then per-workgroup pairs
+    unsigned long long* pairs = acc + 2;
+    double* part = (double*)(pairs + 2 * (size_t)blocks);
     rc = dispatch_width(width, [&](auto tag) {
         typedef decltype(tag) T;
-        hipLaunchKernelGGL(k_absmax_sumsq<T>, dim3(blocks), dim3(256), 0, st, (const T*)in->ptr, n, acc);
+        hipLaunchKernelGGL(k_absmax_sumsq<T>, dim3(blocks), dim3(256), 0, st, (const T*)in->ptr, n, pairs);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_absmax_sumsq");
     });
     if (rc) return rc;
+    hipLaunchKernelGGL(k_stats_fold, dim3(1), dim3(256), 0, st, (const unsigned long long*)pairs, blocks, acc);
+    SH_CHECK_LAUNCH("k_stats_fold");
     if (width == 4) {
         hipLaunchKernelGGL(k_sumsq_f64, dim3(blocks), dim3(256), 0, st, (const int*)in->ptr, n, part);
         SH_CHECK_LAUNCH("k_sumsq_f64");
