@@ -114,7 +114,9 @@ struct alignas(64) FastRec {
     uint32_t kind;                // LEAN_HARM: the fields as described; LEAN_FM: Sine carrier with a closed-form Sine LFO --
                                   // t is the accumulated TIME table, poly[0..10] = frequency, phase0, f_inc, lfo_a_rel, lfo_d,
                                   // lfo_K, lfo_C0, lfo_bias, lfo_rot_c, lfo_rot_s, (double)start (see VoiceFM)
-    double pad[3];
+    double amplitude, g0u;        // unfolded, for k_generate_lists: the voice's own sample is ((x * amplitude) + 0) * g0u
+    uint32_t vi;                  // the voice
+    uint32_t pad1;
 };
 static_assert(sizeof(FastRec) == 256, "FastRec layout");
 constexpr uint32_t LEAN_HARM = 0, LEAN_FM = 1;
@@ -127,7 +129,7 @@ struct LaunchSet {
     VoiceFM*     fm;
     FastRec*     fast;
     uint32_t*    gen_idx;
-    uint32_t*    counts;          // per chunk: [2c] = fast voices, [2c+1] = general voices
+    uint32_t*    counts;          // per chunk: [4c] = lean voices, [4c+1] = general voices, [4c+2] = silent voices
 };
 
 struct PrepInfo {                 // what prepare_voice found, for the classification
@@ -136,6 +138,7 @@ struct PrepInfo {                 // what prepare_voice found, for the classific
     double t0_b, dt_b, rot_c_b, rot_s_b;
     uint32_t remain;
     uint32_t kind;                // LEAN_HARM / LEAN_FM
+    double   amplitude, g0u;
     double   fmv[11];             // LEAN_FM: the values that go to FastRec::poly[0..10]
     const double* harm;
 };
@@ -270,6 +273,8 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     const bool lean_fm = v.kind == SH_SINE && v.fm_mode == SH_FM_SINE && v.bias == 0.0 && (flags & FL_ENV_UNIFORM) && slu == 0.0 &&
                          !(flags & FL_SILENT);
     info.kind = lean_fm ? LEAN_FM : LEAN_HARM;
+    info.amplitude = v.amplitude;
+    info.g0u = g0u;
     if (lean_fm) {
         gain_l = (v.amplitude * g0u) * gain_l;
         gain_r = (v.amplitude * g0u) * gain_r;
@@ -353,11 +358,22 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         f->off_b = (double)info.remain;
         f->remain = info.remain;
         f->kind = info.kind;
+        f->amplitude = info.amplitude;
+        f->g0u = info.g0u;
+        f->vi = vi;
+        f->pad1 = 0;
     }
     if (is_gen) S.gen_idx[c * 64 + (uint32_t)__popcll(mg & below)] = vi;
+    // silent voices: listed from the END of the chunk's index slots (the render kernel never looks there; k_generate_lists
+    // zero-fills their rows)
+    const bool is_silent = vi < nvoices && info.silent;
+    const uint64_t ms = __ballot(is_silent);
+    if (is_silent) S.gen_idx[c * 64 + 63 - (uint32_t)__popcll(ms & below)] = vi;
     if (lane == 0) {
-        S.counts[2 * c] = (uint32_t)__popcll(mf);
-        S.counts[2 * c + 1] = (uint32_t)__popcll(mg);
+        S.counts[4 * c] = (uint32_t)__popcll(mf);
+        S.counts[4 * c + 1] = (uint32_t)__popcll(mg);
+        S.counts[4 * c + 2] = (uint32_t)__popcll(ms);
+        S.counts[4 * c + 3] = 0;
     }
 }
 
@@ -696,6 +712,133 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
     }
 }
 
+// Whole-bank materialisation through the launch's voice lists (see LaunchSet): grid = (groups of 4 tiles, 64-voice chunks);
+// a wave owns one tile and walks the chunk's lean records with the loop of k_bank_render (the sample is rounded and
+// stored instead of accumulated), then the general list through voice_block, then zero-fills the rows of silent voices.
+// The lean arithmetic repeats the general code's order -- ((x * amplitude) + 0) * g0u -- so a row equals what
+// sh_osc_render gives for that voice, bit for bit.
+template <int FPL>
+__global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
+                                                                         uint32_t nvoices, LaunchSet cur, uint64_t start, uint32_t n,
+                                                                         float* __restrict__ out32, size_t stride) {
+    __shared__ shm::sc_pair trig[shm::TRIG_N];
+    for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile0 = (blockIdx.x * 4 + wave) * (64 * FPL);
+    if (tile0 >= n) return;
+    uint32_t tile_last = tile0 + 64 * FPL - 1;
+    if (tile_last > n - 1) tile_last = n - 1;
+    uint32_t i[FPL];
+    double di[FPL];
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        uint32_t raw = tile0 + j * 64 + lane;
+        i[j] = raw < n ? raw : n - 1;
+        di[j] = (double)i[j];
+    }
+    const uint32_t c = blockIdx.y;
+    const uint32_t SH_CONST_AS* cnt = as_const(cur.counts) + 4 * c;
+    const uint32_t nfast = cnt[0], ngen = cnt[1], nsilent = cnt[2];
+    const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64;
+    for (uint32_t p = 0; p < nfast; ++p, ++q) {
+        const uint32_t remain = q->remain, kind = q->kind, vi = q->vi;
+        const double amp = q->amplitude, g0u = q->g0u;
+        const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
+        const double tb = q->t0_b, db = q->dt_b, rcb = q->rot_c_b, rsb = q->rot_s_b, ob = q->off_b;
+        double poly[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+        asm volatile("" :: "s"(amp), "s"(g0u), "s"(remain), "s"(kind), "s"(vi), "s"(ta), "s"(da), "s"(rca), "s"(rsa), "s"(tb), "s"(db),
+                     "s"(rcb), "s"(rsb), "s"(ob), "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
+                     "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
+                     "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
+        double x[FPL];
+        if (kind == LEAN_FM) {
+            double T[FPL];
+            if (remain == 0xFFFFFFFFu || tile_last < remain) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) T[j] = fma(di[j], da, ta);
+            } else if (tile0 >= remain) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) T[j] = fma(di[j] - ob, db, tb);
+            } else {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) T[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+            }
+            double ls, lc, th[FPL], sn[FPL], cs[FPL];
+            shm::sincos_tab(fma(di[0], poly[4], poly[3]), trig, ls, lc);
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                if (j > 0) {
+                    const double ns = fma(ls, poly[8], lc * poly[9]), nc = fma(lc, poly[8], -(ls * poly[9]));
+                    ls = ns;
+                    lc = nc;
+                }
+                const double Ln = fma(poly[5], poly[6] - lc, poly[7] * (poly[10] + di[j]));
+                th[j] = poly[0] * T[j] + fma(poly[2], Ln, poly[1]);
+            }
+            shm::sincos_tab_n<FPL>(th, trig, sn, cs);
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = sn[j];
+        } else {
+            double sn[FPL], cs[FPL], pv[FPL];
+            if (remain == 0xFFFFFFFFu || tile0 >= remain || tile_last < remain) {
+                const bool on_b = remain != 0xFFFFFFFFu && tile0 >= remain;
+                const double t_base = on_b ? tb : ta, dt = on_b ? db : da;
+                const double rc = on_b ? rcb : rca, rs = on_b ? rsb : rsa;
+                const double off = on_b ? ob : 0.0;
+                shm::sincos_tab(fma(di[0] - off, dt, t_base), trig, sn[0], cs[0]);
+#pragma unroll
+                for (int j = 1; j < FPL; ++j) {
+                    sn[j] = fma(sn[j - 1], rc, cs[j - 1] * rs);
+                    cs[j] = fma(cs[j - 1], rc, -(sn[j - 1] * rs));
+                }
+            } else {
+                double th[FPL];
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) th[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+                shm::sincos_tab_n<FPL>(th, trig, sn, cs);
+            }
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) pv[j] = fma(poly[0], cs[j], poly[1]);
+#pragma unroll
+            for (int u = 2; u < 16; ++u) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) pv[j] = fma(pv[j], cs[j], poly[u]);
+            }
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = pv[j] * sn[j];
+        }
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const uint32_t raw = tile0 + j * 64 + lane;
+            if (raw < n) out32[(size_t)vi * stride + raw] = (float)((x[j] * amp + 0.0) * g0u);
+        }
+    }
+    const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
+    for (uint32_t p = 0; p < ngen; ++p) {
+        const uint32_t vi = idx[p];
+        const VoiceRegs r = load_record(as_const(cur.launch) + vi);
+        double x[FPL];
+        voice_block<FPL, false>(r, cur.fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const uint32_t raw = tile0 + j * 64 + lane;
+            if (raw < n) out32[(size_t)vi * stride + raw] = (float)x[j];
+        }
+    }
+    for (uint32_t p = 0; p < nsilent; ++p) {
+        const uint32_t vi = idx[63 - p];
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const uint32_t raw = tile0 + j * 64 + lane;
+            if (raw < n) out32[(size_t)vi * stride + raw] = 0.0f;
+        }
+    }
+}
+
 // fused generate-and-mix.  grid = (frame tiles, voice groups); block = WAVES waves on ONE tile of 64*FPL
 // frames; wave w walks voices v0+w, v0+w+WAVES, ... of its group with the voice record in SGPRs; float64
 // partial (L, R) per lane; LDS-staged sum across the waves; one store per frame.  With one group the block
@@ -791,7 +934,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // shares of the whole group differ by at most one voice.
     uint32_t first = wave;                                    // position in the current chunk's list this wave starts at
     for (uint32_t c = c0; c < c1; ++c) {
-        const uint32_t nfast = as_const(cur.counts)[2 * c];
+        const uint32_t nfast = as_const(cur.counts)[4 * c];
         const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64 + first;
         uint32_t p = first;
         for (; p < nfast; p += WAVES, q += WAVES) {
@@ -888,7 +1031,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // ---- every other sounding voice: the general code (the stride simply continues, so the extra voices go to the
     // waves that got one fast voice fewer) ----
     for (uint32_t c = c0; c < c1; ++c) {
-        const uint32_t ngen = as_const(cur.counts)[2 * c + 1];
+        const uint32_t ngen = as_const(cur.counts)[4 * c + 1];
         const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
         uint32_t p = first;
         uint32_t vi_next = p < ngen ? idx[p] : 0u;
@@ -1157,7 +1300,7 @@ struct sh_bank {
     VoiceFM*    d_launch_fm_buf[2] = {nullptr, nullptr};
     FastRec*    d_fast_buf[2] = {nullptr, nullptr};
     uint32_t*   d_gen_idx_buf[2] = {nullptr, nullptr};
-    uint32_t*   d_counts_buf[2] = {nullptr, nullptr};      // 2 * nvoices entries: room for one voice per group
+    uint32_t*   d_counts_buf[2] = {nullptr, nullptr};      // 4 per 64-voice chunk: lean, general, silent, -
     uint32_t*   d_hint = nullptr;
     double2*    d_seg_rot = nullptr;       // (cos, sin)(64*dt) per table piece
     double2*    d_lfo_rot = nullptr;       // (cos, sin)(64*lfo_d) per voice
@@ -1294,7 +1437,7 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_launch_fm_buf[k], sizeof(VoiceFM) * nvoices);
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_fast_buf[k], sizeof(FastRec) * nvoices);
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_gen_idx_buf[k], sizeof(uint32_t) * nvoices);
-            if (e == hipSuccess) e = hipMalloc((void**)&b->d_counts_buf[k], sizeof(uint32_t) * 2 * nvoices);
+            if (e == hipSuccess) e = hipMalloc((void**)&b->d_counts_buf[k], sizeof(uint32_t) * 4 * ((nvoices + 63) / 64));
         }
         if (e == hipSuccess) e = hipMalloc((void**)&b->d_hint, sizeof(uint32_t) * nvoices);
         if (e == hipSuccess) e = hipMemsetAsync(b->d_hint, 0, sizeof(uint32_t) * nvoices, st);
@@ -1345,12 +1488,12 @@ int sh_bank_launch_stats(sh_bank* b, uint32_t* nfast, uint32_t* ngeneral) {
     if (!b) return sh::set_error(SH_ERR_INVALID, "sh_bank_launch_stats: NULL bank");
     if (!b->last_groups) return sh::set_error(SH_ERR_INVALID, "sh_bank_launch_stats: no sh_bank_render call yet");
     const uint32_t nchunks = (b->nvoices + 63) / 64;
-    std::vector<uint32_t> c(2 * (size_t)nchunks);
+    std::vector<uint32_t> c(4 * (size_t)nchunks);
     hipStream_t st = sh::state().stream;
     SH_HIP(hipMemcpyAsync(c.data(), b->d_counts_buf[b->cur], c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SH_HIP(hipStreamSynchronize(st));
     uint32_t f = 0, g = 0;
-    for (uint32_t k = 0; k < nchunks; ++k) { f += c[2 * k]; g += c[2 * k + 1]; }
+    for (uint32_t k = 0; k < nchunks; ++k) { f += c[4 * k]; g += c[4 * k + 1]; }
     if (nfast) *nfast = f;
     if (ngeneral) *ngeneral = g;
     return SH_OK;
@@ -1455,7 +1598,11 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
 #define SH_GEN(F_) hipLaunchKernelGGL(k_generate<F_>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,            \
                                       ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, \
                                       (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride)
-    if (fpl == 4) SH_GEN(4); else if (fpl == 2) SH_GEN(2); else if (fpl == 1) SH_GEN(1);
+    if (fpl == 4 && b->lean_candidates != 0) {
+        // long rows of a bank with lean candidates: one workgroup column per 64-voice chunk, walking the launch's lists
+        hipLaunchKernelGGL(k_generate_lists<4>, dim3(tile_groups, sh::div_up(b->nvoices, 64)), dim3(256), 0, sh::state().stream,
+                           ptrs(b), trig_table(), b->nvoices, launch_set(b, b->cur), start, nframes, o, stride);
+    } else if (fpl == 4) SH_GEN(4); else if (fpl == 2) SH_GEN(2); else if (fpl == 1) SH_GEN(1);
     else return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: SYNTHHIP_GEN_FPL must be 1, 2 or 4");
 #undef SH_GEN
     SH_CHECK_LAUNCH("k_generate");
