@@ -137,6 +137,16 @@ def pcm_rows(N):
     nbytes = (2 * nv + 2) * nsamples
     rows["mix_chain_i16_1024v_10s_stereo"] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
                                               "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    # Sample.from_osc_block: float32 -> int16 with the overflow check (the call returns after reading the flag back)
+    nq = 300_000_000
+    for _ in range(2):
+        N.check(L.sh_quantize_f32(src.handle, 0, nq, 32767.0, 2, dst.handle, 0))
+    N.timer_start()
+    for _ in range(5):
+        N.check(L.sh_quantize_f32(src.handle, 0, nq, 32767.0, 2, dst.handle, 0))
+    ms = N.timer_stop() / 5
+    rows["quantize_f32_to_i16_1200MB"] = {"ms": ms, "bytes": 6 * nq, "GBps": 6 * nq / (ms / 1e3) / 1e9,
+                                          "frac_hbm": 6 * nq / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
     # Sample.mix: saturating add of two 900 MB int16 buffers (3 bytes moved per byte of output)
     n = 900_000_000
     N.timer_start()
