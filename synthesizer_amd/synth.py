@@ -11,7 +11,8 @@ from __future__ import annotations
 from typing import List, Optional, Sequence, Tuple
 
 from . import params
-from .oscillators import (Harmonics, Oscillator, Pulse, Sawtooth, SawtoothH, Sine, Square, SquareH, Triangle)
+from .oscillators import (Harmonics, Linear, Oscillator, Pulse, Sawtooth, SawtoothH, Sine, Square, SquareH, Triangle,
+                          WhiteNoise)
 from .sample import Sample
 
 __all__ = ["WaveSynth", "key_num", "key_freq", "note_freq", "octave_notes", "major_chords", "major_chord_keys"]
@@ -103,6 +104,15 @@ class WaveSynth:
         return Harmonics(frequency, harmonics, amplitude, phase, bias, fm_lfo=fm_lfo, samplerate=self.samplerate)
 
     # -- Samples -----------------------------------------------------------------------------------
+    def white_noise_gen(self, frequency, amplitude=0.9999, bias=0.0, seed: int = 0) -> Oscillator:
+        """White noise, a new value every samplerate/frequency samples (`seed`: this build's counter-based generator)."""
+        self._check(frequency, amplitude, bias)
+        return WhiteNoise(frequency, amplitude, bias, samplerate=self.samplerate, seed=seed)
+
+    def linear_gen(self, startlevel, increment=0.0, min_value=-1.0, max_value=1.0) -> Oscillator:
+        """Linear ramp (a constant if increment is 0), staying within the given bounds."""
+        return Linear(startlevel, increment, min_value, max_value, samplerate=self.samplerate)
+
     def sine(self, frequency, duration, amplitude=0.9999, phase=0.0, bias=0.0, fm_lfo=None) -> Sample:
         return self.to_sample(self.sine_gen(frequency, amplitude, phase, bias, fm_lfo), duration)
 
@@ -126,3 +136,10 @@ class WaveSynth:
 
     def harmonics(self, frequency, duration, harmonics, amplitude=0.5, phase=0.0, bias=0.0, fm_lfo=None) -> Sample:
         return self.to_sample(self.harmonics_gen(frequency, harmonics, amplitude, phase, bias, fm_lfo), duration)
+
+
+    def white_noise(self, frequency, duration, amplitude=0.9999, bias=0.0, seed: int = 0) -> Sample:
+        return self.to_sample(self.white_noise_gen(frequency, amplitude, bias, seed), duration)
+
+    def linear(self, duration, startlevel, increment=0.0, min_value=-1.0, max_value=1.0) -> Sample:
+        return self.to_sample(self.linear_gen(startlevel, increment, min_value, max_value), duration)

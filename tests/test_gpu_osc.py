@@ -314,6 +314,8 @@ def test_wavesynth_facade(gpu):
         "sawtooth_h": (ws.sawtooth_h(220, dur, 6, amplitude=0.3), O.SawtoothH(220, 6, 0.3, samplerate=22050)),
         "harmonics": (ws.harmonics(220, dur, [(1, 1.0), (2, 0.5)], amplitude=0.4), O.Harmonics(220, [(1, 1.0), (2, 0.5)], 0.4, samplerate=22050)),
         "fm": (ws.sine(440, dur, fm_lfo=ws.sine_gen(5, 0.05)), O.Sine(440, 0.9999, fm_lfo=O.Sine(5, 0.05, samplerate=22050), samplerate=22050)),
+        "white_noise": (ws.white_noise(2205, dur, amplitude=0.5, seed=11), O.WhiteNoise(2205, 0.5, samplerate=22050, seed=11)),
+        "linear": (ws.linear(dur, -0.5, 1e-4, -1.0, 0.25), O.Linear(-0.5, 1e-4, -1.0, 0.25, samplerate=22050)),
     }
     for name, (sample, osc) in cases.items():
         assert sample.samplerate == 22050 and sample.nchannels == 1 and sample.samplewidth == 2 and len(sample) == n, name
