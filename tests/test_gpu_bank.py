@@ -355,3 +355,65 @@ def test_streaming_defers_the_fold_of_partial_buses(gpu):
     for s in range(3):
         v = d64[s].download(np.float64, block * 2).reshape(block, 2)
         assert np.array_equal(v.astype(np.float32), single[s]), s
+
+
+def test_fuzz_fused_vs_two_step_vs_oracle(gpu):
+    """Random mixed banks, random starts and block lengths (piece ends of the phase tables inside the block, ragged tiles,
+    ragged chunks, notes that end, sample indices beyond 2^32): the fused render (lean + general loops, deferred fold),
+    the materialise + mix path (lists incl. silent rows) and the C oracle agree."""
+    from oracle import c_oracle as CO
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    rng = np.random.default_rng(2024)
+    for case in range(14):
+        nv = int(rng.choice([1, 7, 63, 64, 65, 130, 257, 400]))
+        f = rng.uniform(40, 4000, nv)
+        kinds = rng.integers(0, 7, nv)
+        sustain = rng.uniform(0.02, 1.5, nv)
+        gains = [(float(np.float32(a)), float(np.float32(b))) for a, b in rng.uniform(0, 1, (nv, 2)) / np.sqrt(nv)]
+        seeds = rng.uniform(0, 1, (nv, 3))
+
+        def make(M):
+            out = []
+            for k in range(nv):
+                lfo = M.Sine(0.5 + 7 * float(seeds[k, 0]), 0.04 * float(seeds[k, 1]), phase=float(seeds[k, 2]), samplerate=SR)
+                kd = int(kinds[k])
+                if kd == 0:
+                    v = M.Harmonics(float(f[k]), [(j, 1.0 / j) for j in range(1, 13)], 0.5, phase=float(seeds[k, 2]), samplerate=SR)
+                elif kd == 1:
+                    v = M.EnvelopeFilter(M.Harmonics(float(f[k]), [(1, 1.0), (3, 0.3), (5, 0.2)], 0.6, samplerate=SR),
+                                         0.01, 0.03, float(sustain[k]), 0.55, 0.05)
+                elif kd == 2:
+                    v = M.Sine(float(f[k]), 0.7, fm_lfo=lfo, samplerate=SR)
+                elif kd == 3:
+                    v = M.EnvelopeFilter(M.Sine(float(f[k]), 0.6, fm_lfo=lfo, samplerate=SR), 0.005, 0.02, float(sustain[k]), 0.4, 0.1)
+                elif kd == 4:
+                    v = M.Sawtooth(float(f[k]), 0.4, phase=float(seeds[k, 0]), samplerate=SR)
+                elif kd == 5:
+                    v = M.Harmonics(float(f[k]), [(1, 1.0), (2, 0.5)], 0.5, bias=0.05, samplerate=SR)
+                else:
+                    v = M.Square(float(f[k]), 0.3, samplerate=SR)
+                out.append(v)
+            return out
+
+        bank = VoiceBank(make(G), gains=gains)
+        total = int(rng.choice([3000, 9000, 20000, 40000]))
+        ov = make(O)
+        want = CO.mix_bus(np.stack([CO.render(v, total) for v in ov]), gains)
+        pos = 0
+        while pos < total:
+            n = int(min(total - pos, rng.choice([1, 63, 256, 257, 1000, 4096, 12345])))
+            got = bank.render(n, start=pos)
+            assert rms(got, want[pos:pos + n]) <= RMS_TOL, (case, pos, n)
+            assert np.max(np.abs(got - want[pos:pos + n])) < 5e-7, (case, pos, n)
+            two = bank.render_two_step(n, start=pos)
+            assert np.max(np.abs(got - two)) < 1e-6, (case, pos, n)      # two-step: float32 voices, float32 accumulation
+            pos += n
+        # far into the stream (no oracle there: the sequential restatement cannot get to 2^33): fused == two-step
+        far = (1 << 33) + int(rng.integers(0, 1 << 20))
+        for n in (777, 9000):
+            a = bank.render(n, start=far)
+            b = bank.render_two_step(n, start=far)
+            assert np.max(np.abs(a - b)) < 1e-6, (case, far, n)
+            far += n
