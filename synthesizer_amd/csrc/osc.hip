@@ -102,22 +102,26 @@ static_assert(sizeof(VoiceFM) == 80, "VoiceFM layout");
 // this much per launch.
 // The render kernel walks these records in a loop of its own, with none of the general code's flag tests.
 struct alignas(64) FastRec {
+    // ---- the first 192 bytes are all a launch without a piece crossing needs: three s_load_dwordx16 ----
     double t_base, dt;            // frames i < remain: t(i) = fma(i, dt, t_base)
     double gain_l, gain_r;        // amplitude * envelope gain * bus gain
     double rot_c, rot_s;          // cos / sin of 64*dt
     double poly[16];              // sum_k a_k sin(k t) = sin(t) * P(cos t)
-    // the launch may cross ONE end of a phase-table piece (a binade of the running sum), at frame `remain`:
-    double t0_b, dt_b;            // frames i >= remain: t(i) = fma(i - remain, dt_b, t0_b)
-    double rot_c_b, rot_s_b;      // cos / sin of 64*dt_b
-    double off_b;                 // (double)remain
     uint32_t remain;              // 0xFFFFFFFF: no crossing in this launch
     uint32_t kind;                // LEAN_HARM: the fields as described; LEAN_FM: Sine carrier with a closed-form Sine LFO --
                                   // t is the accumulated TIME table, poly[0..10] = frequency, phase0, f_inc, lfo_a_rel, lfo_d,
                                   // lfo_K, lfo_C0, lfo_bias, lfo_rot_c, lfo_rot_s, (double)start (see VoiceFM)
-    double amplitude, g0u;        // unfolded, for k_generate_lists: the voice's own sample is ((x * amplitude) + 0) * g0u
+    double off_b;                 // (double)remain
+    // ---- read only when the launch crosses ONE end of a phase-table piece (a binade of the running sum), at `remain` ----
+    double t0_b, dt_b;            // frames i >= remain: t(i) = fma(i - remain, dt_b, t0_b)
+    double rot_c_b, rot_s_b;      // cos / sin of 64*dt_b
+    // ---- k_generate_lists ----
+    double amplitude, g0u;        // unfolded: the voice's own sample is ((x * amplitude) + 0) * g0u
     uint32_t vi;                  // the voice
     uint32_t pad1;
+    double pad2;
 };
+static_assert(offsetof(FastRec, t0_b) == 192, "FastRec: common part is 192 bytes");
 static_assert(sizeof(FastRec) == 256, "FastRec layout");
 constexpr uint32_t LEAN_HARM = 0, LEAN_FM = 1;
 
@@ -362,6 +366,7 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         f->g0u = info.g0u;
         f->vi = vi;
         f->pad1 = 0;
+        f->pad2 = 0.0;
     }
     if (is_gen) S.gen_idx[c * 64 + (uint32_t)__popcll(mg & below)] = vi;
     // silent voices: listed from the END of the chunk's index slots (the render kernel never looks there; k_generate_lists
@@ -938,18 +943,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64 + first;
         uint32_t p = first;
         for (; p < nfast; p += WAVES, q += WAVES) {
-            // the whole record in ONE batch of scalar loads: the empty asm makes every field live here, so the compiler
-            // cannot sink the loads of the second piece's fields behind the tests below (it did: three dependent
-            // round trips per voice instead of one)
+            // the common 192 bytes in ONE batch of scalar loads: the empty asm makes these fields live here, so the
+            // compiler cannot sink their loads behind the tests below (it did: three dependent round trips per voice).
+            // The second piece's fields are NOT in the list: their loads stay inside the rare crossing branches.
             const double gl = q->gain_l, gr = q->gain_r;
             const uint32_t remain = q->remain, kind = q->kind;
             const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
-            const double tb = q->t0_b, db = q->dt_b, rcb = q->rot_c_b, rsb = q->rot_s_b, ob = q->off_b;
             double poly[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
-            asm volatile("" :: "s"(gl), "s"(gr), "s"(remain), "s"(kind), "s"(ta), "s"(da), "s"(rca), "s"(rsa), "s"(tb), "s"(db), "s"(rcb),
-                         "s"(rsb), "s"(ob), "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
+            asm volatile("" :: "s"(gl), "s"(gr), "s"(remain), "s"(kind), "s"(ta), "s"(da), "s"(rca), "s"(rsa),
+                         "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
                          "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
                          "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
             if (MODE == RENDER_LEAN_ALL && kind == LEAN_FM) {
@@ -958,12 +962,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                 if (remain == 0xFFFFFFFFu || tile_last < remain) {
 #pragma unroll
                     for (int j = 0; j < FPL; ++j) T[j] = fma(di[j], da, ta);
-                } else if (tile0 >= remain) {
-#pragma unroll
-                    for (int j = 0; j < FPL; ++j) T[j] = fma(di[j] - ob, db, tb);
                 } else {
+                    const double tb = q->t0_b, db = q->dt_b, ob = q->off_b;
+                    if (tile0 >= remain) {
 #pragma unroll
-                    for (int j = 0; j < FPL; ++j) T[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+                        for (int j = 0; j < FPL; ++j) T[j] = fma(di[j] - ob, db, tb);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < FPL; ++j) T[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+                    }
                 }
                 const double frequency = poly[0], phase0 = poly[1], f_inc = poly[2], lfo_a_rel = poly[3], lfo_d = poly[4];
                 const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], lrc = poly[8], lrs = poly[9], startd = poly[10];
@@ -996,6 +1003,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                     cs[j] = fma(cs[j - 1], rca, -(sn[j - 1] * rsa));
                 }
             } else if (tile0 >= remain || tile_last < remain) {       // the tile lies on one of the two pieces (uniform)
+                const double tb = q->t0_b, db = q->dt_b, rcb = q->rot_c_b, rsb = q->rot_s_b, ob = q->off_b;
                 const bool on_b = tile0 >= remain;
                 const double t_base = on_b ? tb : ta, dt = on_b ? db : da;
                 const double rc = on_b ? rcb : rca, rs = on_b ? rsb : rsa;
@@ -1007,6 +1015,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                     cs[j] = fma(cs[j - 1], rc, -(sn[j - 1] * rs));
                 }
             } else {                                      // the one tile per crossing that straddles the piece end
+                const double tb = q->t0_b, db = q->dt_b, ob = q->off_b;
                 double th[FPL];
 #pragma unroll
                 for (int j = 0; j < FPL; ++j) th[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
