@@ -844,6 +844,35 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
     }
 }
 
+// One voice through the general code, accumulated into the lane's partial bus.  With more than four frames per lane
+// (the lean loop likes eight: one table lookup serves them all) the general code still runs four at a time, so that its
+// register needs stay those of the four-frame kernel.
+template <int FPL>
+__device__ __forceinline__ void general_voice(const VoiceRegs& r, const VoiceFM* __restrict__ fmrec, const BankPtrs& B,
+                                              const sh_voice* __restrict__ vfull, uint64_t start, uint32_t tile0, uint32_t nframes,
+                                              const uint32_t (&i)[FPL], const double (&di)[FPL], TrigTab trig,
+                                              double (&accl)[FPL], double (&accr)[FPL]) {
+    constexpr int GF = FPL > 4 ? 4 : FPL;
+    static_assert(FPL % GF == 0, "frames per lane: 1, 2, 4 or a multiple of 4");
+#pragma unroll
+    for (int h = 0; h < FPL / GF; ++h) {
+        const uint32_t first = tile0 + (uint32_t)h * 64 * GF;
+        if (h > 0 && first >= nframes) break;                 // uniform: this part of the tile lies beyond the launch
+        uint32_t last = first + 64 * GF - 1;
+        if (last > nframes - 1) last = nframes - 1;
+        uint32_t ih[GF];
+        double dh[GF], x[GF];
+#pragma unroll
+        for (int j = 0; j < GF; ++j) { ih[j] = i[h * GF + j]; dh[j] = di[h * GF + j]; }
+        voice_block<GF, true>(r, fmrec, B, vfull, start, last, ih, dh, nullptr, nullptr, trig, x);
+#pragma unroll
+        for (int j = 0; j < GF; ++j) {
+            accl[h * GF + j] = fma(r.gain_l, x[j], accl[h * GF + j]);
+            accr[h * GF + j] = fma(r.gain_r, x[j], accr[h * GF + j]);
+        }
+    }
+}
+
 // fused generate-and-mix.  grid = (frame tiles, voice groups); block = WAVES waves on ONE tile of 64*FPL
 // frames; wave w walks voices v0+w, v0+w+WAVES, ... of its group with the voice record in SGPRs; float64
 // partial (L, R) per lane; LDS-staged sum across the waves; one store per frame.  With one group the block
@@ -925,13 +954,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         for (uint32_t vi = v0 + wave; vi < v1; vi += WAVES, rp += WAVES) {
             const VoiceRegs r = load_record(rp);
             if (r.flags & FL_SILENT) continue;       // the note was released before this block: contributes exact zeros
-            double x[FPL];
-            voice_block<FPL, true>(r, cur.fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
-#pragma unroll
-            for (int j = 0; j < FPL; ++j) {
-                accl[j] = fma(r.gain_l, x[j], accl[j]);
-                accr[j] = fma(r.gain_r, x[j], accr[j]);
-            }
+            general_voice<FPL>(r, cur.fm + vi, B, B.voices + vi, start, tile0, nframes, i, di, trig, accl, accr);
         }
     } else {
     // ---- fast voices: one table lookup, FPL-1 rotations, the Horner chains, two accumulations per frame ----
@@ -1048,13 +1071,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             const uint32_t vi = vi_next;
             vi_next = p + WAVES < ngen ? idx[p + WAVES] : 0u;       // in flight with this voice's record: one round trip less
             const VoiceRegs r = load_record(as_const(cur.launch) + vi);
-            double x[FPL];
-            voice_block<FPL, true>(r, cur.fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
-#pragma unroll
-            for (int j = 0; j < FPL; ++j) {
-                accl[j] = fma(r.gain_l, x[j], accl[j]);
-                accr[j] = fma(r.gain_r, x[j], accr[j]);
-            }
+            general_voice<FPL>(r, cur.fm + vi, B, B.voices + vi, start, tile0, nframes, i, di, trig, accl, accr);
         }
         first = p - ngen;
     }
@@ -1065,9 +1082,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         red[wave][1][j * 64 + lane] = accr[j];
     }
     __syncthreads();
-    // waves 0..FPL-1 each finish 64 frames
-    if (wave < FPL) {
-        const uint32_t f = wave * 64 + lane;
+    // each wave finishes 64-frame rows of the tile: rows wave, wave + WAVES, ...
+    for (uint32_t row = wave; row < (uint32_t)FPL; row += WAVES) {
+        const uint32_t f = row * 64 + lane;
         const uint32_t raw = tile0 + f;
         if (raw < nframes) {
             double l = red[0][0][f], rr = red[0][1][f];

@@ -150,6 +150,12 @@ int main() {
         run<8, 0, 8, 4>("FPL8 s_load rec, 8w min4", d_recs, d_trig, d_parts, nvoices, nframes, groups);
         run<4, 0, 4, 6>("FPL4 s_load rec, 4w min6", d_recs, d_trig, d_parts, nvoices, nframes, groups);
         run<4, 0, 8, 4, 5120>("FPL4 8w, LDS 80K: 2 blocks/CU", d_recs, d_trig, d_parts, nvoices, nframes, groups);
+        run<4, 0, 4, 4>("FPL4 4w min4 (production shape)", d_recs, d_trig, d_parts, nvoices, nframes, 8);
+        run<8, 0, 4, 4>("FPL8 4w min4 groups 16", d_recs, d_trig, d_parts, nvoices, nframes, 16);
+        run<8, 0, 4, 2>("FPL8 4w min2 groups 16", d_recs, d_trig, d_parts, nvoices, nframes, 16);
+        run<8, 0, 4, 4>("FPL8 4w min4 groups 8", d_recs, d_trig, d_parts, nvoices, nframes, 8);
+        run<6, 0, 4, 4>("FPL6 4w min4 groups 8", d_recs, d_trig, d_parts, nvoices, nframes, 8);
+        run<6, 0, 4, 4>("FPL6 4w min4 groups 16", d_recs, d_trig, d_parts, nvoices, nframes, 16);
         run<4, 0, 8, 4, 1536>("FPL4 8w, LDS 52K: 3 blocks/CU", d_recs, d_trig, d_parts, nvoices, nframes, groups);
     }
     return 0;
