@@ -1612,8 +1612,7 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
     rc = acquire_records(b, start, nframes);
     if (rc) return rc;
     // frames per lane: 4 for long rows (one sin/cos lookup + three rotations per voice, as in k_bank_render), else 2 / 1
-    static const int fpl_env = getenv("SYNTHHIP_GEN_FPL") ? atoi(getenv("SYNTHHIP_GEN_FPL")) : 0;
-    const int fpl = fpl_env ? fpl_env : (nframes >= 8192 ? 4 : (nframes >= 2048 ? 2 : 1));
+    const int fpl = nframes >= 8192 ? 4 : (nframes >= 2048 ? 2 : 1);
     const uint32_t tile_groups = sh::div_up(nframes, 256 * fpl);
     // voices per block: as many as keeps >= ~4096 blocks in flight (and gridDim.y <= 65535)
     uint32_t vpg = 1;
@@ -1628,8 +1627,7 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
         // long rows of a bank with lean candidates: one workgroup column per 64-voice chunk, walking the launch's lists
         hipLaunchKernelGGL(k_generate_lists<4>, dim3(tile_groups, sh::div_up(b->nvoices, 64)), dim3(256), 0, sh::state().stream,
                            ptrs(b), trig_table(), b->nvoices, launch_set(b, b->cur), start, nframes, o, stride);
-    } else if (fpl == 4) SH_GEN(4); else if (fpl == 2) SH_GEN(2); else if (fpl == 1) SH_GEN(1);
-    else return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: SYNTHHIP_GEN_FPL must be 1, 2 or 4");
+    } else if (fpl == 4) SH_GEN(4); else if (fpl == 2) SH_GEN(2); else SH_GEN(1);
 #undef SH_GEN
     SH_CHECK_LAUNCH("k_generate");
     return SH_OK;

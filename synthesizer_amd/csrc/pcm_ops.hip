@@ -462,8 +462,7 @@ int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, 
     if (sum_squares) *sum_squares = 0.0;
     if (!nbytes) return SH_OK;
     const size_t n = nbytes / width;
-    static const unsigned max_blocks = getenv("SYNTHHIP_STATS_BLOCKS") ? (unsigned)atoi(getenv("SYNTHHIP_STATS_BLOCKS")) : 4096u;
-    const unsigned blocks = n / 2048 < max_blocks ? (unsigned)(n / 2048 + 1) : max_blocks;
+    const unsigned blocks = n / 2048 < 4096 ? (unsigned)(n / 2048 + 1) : 4096u;
     int rc = sh::ensure_scratch(16 + (size_t)blocks * 24);
     if (rc) return rc;
     hipStream_t st = sh::state().stream;
