@@ -10,6 +10,7 @@ struct sh_buf {
     void*  ptr;
     size_t bytes;
     bool   owner;      // false for views created by sh_buf_view (they alias a parent allocation)
+    size_t cap = 0;    // bytes actually allocated (size class of the buffer pool); 0 for views
 };
 
 namespace sh {
@@ -48,6 +49,9 @@ State& state();
 int  set_error(int code, const char* fmt, ...);
 int  hip_error(hipError_t e, const char* what);
 int  ensure_scratch(size_t bytes);
+int  pool_alloc(size_t bytes, void** ptr, size_t* cap);   // device buffer pool (runtime.hip)
+void pool_free(void* ptr, size_t cap);
+void pool_trim();
 int  flush_pending();                  // fold a pending bank-render combine now (osc.hip)
 int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out);   // float64 bus -> float32 (osc.hip)
 

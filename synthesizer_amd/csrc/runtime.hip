@@ -5,6 +5,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <unordered_map>
 
 namespace sh {
 
@@ -26,6 +27,68 @@ int set_error(int code, const char* fmt, ...) {
 int hip_error(hipError_t e, const char* what) {
     int code = (e == hipErrorOutOfMemory) ? SH_ERR_NOMEM : SH_ERR_HIP;
     return set_error(code, "%s: %s", what, hipGetErrorString(e));
+}
+
+// ---- device buffer pool ------------------------------------------------------------
+// hipFree synchronises the device and hipMalloc takes tens of microseconds: a chain of Sample operations (each
+// producing a new buffer and dropping the old one) would stall the stream at every step.  Freed buffers are kept,
+// by size class (eight classes per power of two: at most 12.5 % slack), and handed out again.  Reuse is safe without
+// synchronisation because everything the library enqueues goes through one stream, in order: work that still reads a
+// freed buffer precedes whatever the next owner enqueues.  (The communication stream only touches buffers that
+// DistVoiceBank keeps for its lifetime.)
+namespace {
+struct Pool {
+    std::unordered_map<size_t, std::vector<void*>> free_;
+    size_t cached = 0;
+    static constexpr size_t LIMIT = size_t(16) << 30;      // bytes kept at most
+};
+Pool g_pool;
+
+size_t size_class(size_t bytes) {
+    if (bytes <= 256) return 256;
+    size_t p = 256;
+    while (p < bytes) p <<= 1;                              // 2^k >= bytes > 2^(k-1)
+    const size_t step = p >> 4;                             // eight classes in (2^(k-1), 2^k]
+    return (bytes + step - 1) / step * step;
+}
+}  // namespace
+
+int pool_alloc(size_t bytes, void** ptr, size_t* cap) {
+    const size_t c = size_class(bytes);
+    auto it = g_pool.free_.find(c);
+    if (it != g_pool.free_.end() && !it->second.empty()) {
+        *ptr = it->second.back();
+        it->second.pop_back();
+        g_pool.cached -= c;
+        *cap = c;
+        return SH_OK;
+    }
+    hipError_t e = hipMalloc(ptr, c);
+    if (e == hipErrorOutOfMemory && g_pool.cached) {        // give the cache back and try once more
+        pool_trim();
+        e = hipMalloc(ptr, c);
+    }
+    if (e != hipSuccess) return hip_error(e, "hipMalloc");
+    *cap = c;
+    return SH_OK;
+}
+
+void pool_free(void* ptr, size_t cap) {
+    if (g_pool.cached + cap > Pool::LIMIT) {
+        hipStreamSynchronize(state().stream);
+        hipFree(ptr);
+        return;
+    }
+    g_pool.free_[cap].push_back(ptr);
+    g_pool.cached += cap;
+}
+
+void pool_trim() {
+    if (state().stream) hipStreamSynchronize(state().stream);
+    for (auto& kv : g_pool.free_)
+        for (void* p : kv.second) hipFree(p);
+    g_pool.free_.clear();
+    g_pool.cached = 0;
 }
 
 int ensure_scratch(size_t bytes) {
@@ -100,6 +163,7 @@ int sh_shutdown(void) {
     hipStreamSynchronize(s.stream);
     if (s.pending.active) sh::flush_pending();
     hipStreamSynchronize(s.stream);
+    sh::pool_trim();
     if (s.scratch) hipFree(s.scratch);
     for (int k = 0; k < 2; ++k) if (s.parts_buf[k]) hipFree(s.parts_buf[k]);
     if (s.flag) hipFree(s.flag);
@@ -146,10 +210,10 @@ int sh_buf_alloc(size_t bytes, sh_buf** out) {
     b->bytes = bytes;
     b->owner = true;
     if (bytes) {
-        hipError_t e = hipMalloc(&b->ptr, bytes);
-        if (e != hipSuccess) {
+        int rc = sh::pool_alloc(bytes, &b->ptr, &b->cap);
+        if (rc) {
             delete b;
-            return sh::hip_error(e, "hipMalloc");
+            return rc;
         }
     }
     *out = b;
@@ -176,8 +240,9 @@ int sh_buf_free(sh_buf* b) {
         return SH_OK;
     }
     if (b->ptr && state().initialized) {
-        hipStreamSynchronize(state().stream);
-        hipFree(b->ptr);
+        // a render may still owe this buffer the fold of its partial buses: enqueue it before the memory changes hands
+        if (state().pending.active) sh::flush_pending();
+        sh::pool_free(b->ptr, b->cap);
     }
     delete b;
     return SH_OK;

@@ -205,7 +205,13 @@ class Sample:
     def copy(self) -> "Sample":
         cpy = Sample(name=self.name, samplerate=self.__samplerate, nchannels=self.__nchannels,
                      samplewidth=self.__samplewidth)
-        cpy._set_host(self._host())
+        if self.__dev is not None and self.__frames is None:        # resident in HBM only: copy it there
+            buf = N.DeviceBuffer(self.__nbytes)
+            if self.__nbytes:
+                N.check(N.lib().sh_buf_copy(buf.handle, 0, self.__dev.handle, 0, self.__nbytes))
+            cpy._set_device(buf, self.__nbytes)
+        else:
+            cpy._set_host(self._host())
         cpy.filename = self.filename
         return cpy
 

@@ -418,3 +418,32 @@ def test_fuzz_fused_vs_two_step_vs_oracle(gpu):
             b = bank.render_two_step(n, start=far)
             assert np.max(np.abs(a - b)) < 1e-6, (case, far, n)
             far += n
+
+
+def test_buffer_pool_and_free_with_a_pending_fold(gpu):
+    """Device buffers come from a pool (freed ones are handed out again without a device synchronisation); a buffer that
+    is freed while a render still owes it the fold of its partial buses gets the fold first."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    gv, gains = additive_voices(G, 512, SR, seed=4)
+    bank = VoiceBank(gv, gains=gains)
+    ref = bank.render(6000, start=0)
+    for _ in range(3):
+        tmp = N.DeviceBuffer(6000 * 8)
+        bank.render_device(6000, 0, bus_f32=tmp)
+        tmp.free()                                    # nothing was called in between: the fold is still pending
+        again = N.DeviceBuffer(6000 * 8)              # very likely the same memory, handed out again
+        bank.render_device(6000, 0, bus_f32=again)
+        assert np.array_equal(again.download(np.float32, 12000).reshape(6000, 2), ref)
+        again.free()
+    # sizes are the requested ones whatever the size class; contents of a recycled buffer are the new owner's
+    for nbytes in (1, 255, 257, 4097, 1000003):
+        a = N.DeviceBuffer(nbytes)
+        assert a.nbytes == nbytes and N.lib().sh_buf_size(a.handle) == nbytes
+        a.upload(np.full(nbytes, 7, dtype=np.uint8))
+        a.free()
+        b = N.DeviceBuffer(nbytes)
+        b.zero()
+        assert not b.download(np.uint8, nbytes).any()
+        b.free()
