@@ -89,8 +89,7 @@ class VoiceBank:
         bus = self.render_device(nframes, start)
         pcm = N.DeviceBuffer(nframes * 4)
         N.check(N.lib().sh_quantize_clip_f32(bus.handle, nframes * 2, float(scale), pcm.handle))
-        N.sync()
-        bus.free()
+        bus.free()                      # back to the pool: reuse is ordered behind the kernel by the stream
         s._set_device(pcm, nframes * 4)
         return s
 
@@ -173,7 +172,6 @@ def mix_samples(samples: Sequence[Sample], name: str = "mix") -> Sample:
                 N.check(L.sh_buf_copy(chunks.handle, i * stride * 2, s._device().handle, 0, n))
         dst = N.DeviceBuffer(nbytes)
         N.check(L.sh_mix_chain_i16(chunks.handle, len(samples), stride, nsamples, dst.handle))
-        N.sync()
         chunks.free()
         out._set_device(dst, nbytes)
         return out

@@ -310,12 +310,11 @@ class Oscillator:
             out_host.ctypes.data if out_host is not None else None,
             out_f32.handle if out_f32 is not None else None, out_off,
             out_f64.handle if out_f64 is not None else None))
-        if fm_buf is not None or pwm_buf is not None:
-            N.sync()
-            if fm_buf is not None:
-                fm_buf.free()
-            if pwm_buf is not None:
-                pwm_buf.free()
+        # the modulator buffers go back to the pool; whoever gets them next is ordered behind this kernel by the stream
+        if fm_buf is not None:
+            fm_buf.free()
+        if pwm_buf is not None:
+            pwm_buf.free()
 
     def _render_f64_device(self, start: int, n: int) -> N.DeviceBuffer:
         """This oscillator's samples as float64 in HBM (it is someone's modulator)."""
@@ -651,7 +650,6 @@ class _Filter(Oscillator):
                                   out_f64.handle if out_f64 is not None else None, 0,
                                   out_f32.handle if out_f32 is not None else None, out_off,
                                   out_host.ctypes.data if out_host is not None else None))
-        N.sync()
         buf.free()
 
     @staticmethod
@@ -674,7 +672,6 @@ class MixingFilter(_Filter):
         for src in self._sources[1:]:
             other = src._render_f64_device(start, n)
             self._ew(N.SH_EW_ADD, acc, other, n)
-            N.sync()
             other.free()
         return acc
 
@@ -689,7 +686,6 @@ class AmpModulationFilter(_Filter):
         acc = self._sources[0]._render_f64_device(start, n)
         mod = self._sources[1]._render_f64_device(start, n)
         self._ew(N.SH_EW_MUL, acc, mod, n)
-        N.sync()
         mod.free()
         return acc
 
@@ -755,7 +751,6 @@ class DelayFilter(_Filter):
         if n > nzero:
             src = self._sources[0]._render_f64_device(start + nzero - d, n - nzero)
             N.check(L.sh_ew_f64(N.SH_EW_COPY, src.handle, 0, None, 0, n - nzero, 0.0, 0.0, out.handle, nzero, None, 0, None))
-            N.sync()
             src.free()
         return out
 
@@ -800,6 +795,5 @@ class EchoFilter(_Filter):
             echo = src._render_f64_device(first - shift, count)
             N.check(L.sh_ew_f64(N.SH_EW_AXPY, acc.handle, first - start, echo.handle, 0, count, float(amp), 0.0,
                                 acc.handle, first - start, None, 0, None))
-            N.sync()
             echo.free()
         return acc
