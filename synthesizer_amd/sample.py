@@ -350,8 +350,9 @@ class Sample:
         self._check_gpu_width("echo")
         if amount > 0:
             length = max(0, self.duration - length)
-            echo = self.copy()
-            echo.clip(length, self.duration)
+            echo = Sample(name=self.name, samplerate=self.__samplerate, nchannels=self.__nchannels, samplewidth=self.__samplewidth)
+            first = slice(self.frame_idx(length), None).indices(self.__nbytes)[0]      # frames[frame_idx(length):], as upstream
+            echo.__assemble([(self, first, self.__nbytes - first)])
             echo_amp = decay
             for _ in range(amount):
                 if echo_amp < 1.0 / (2 ** (8 * self.__samplewidth - 1)):

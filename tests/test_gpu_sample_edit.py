@@ -148,3 +148,82 @@ def test_modulate_amp_oscillator_and_overflow(gpu):
         s.modulate_amp(iter([1.5, 1.5]))
     with pytest.raises(OverflowError):
         r.modulate_amp(iter([1.5, 1.5]))
+
+
+def test_fuzz_random_chains_of_sample_operations(gpu):
+    """Random chains of Sample operations (arithmetic, editing, resampling, channel conversions) on random PCM, against
+    the same chain on RefSample / the live audioop -- bit-exact after every step."""
+    import audioop
+    import os
+    from synthesizer_amd.sample import Sample
+
+    class Ref(RefSample):
+        def bias(self, b):
+            self.frames = audioop.bias(self.frames, self.samplewidth, b)
+            return self
+
+        def reverse(self):
+            self.frames = audioop.reverse(self.frames, self.samplewidth)
+            return self
+
+        def mono(self, lf=1.0, rf=1.0):
+            if self.nchannels == 2:
+                self.frames = audioop.tomono(self.frames, self.samplewidth, lf, rf)
+                self.nchannels = 1
+            return self
+
+        def stereo(self, lf=1.0, rf=1.0):
+            if self.nchannels == 1:
+                self.frames = audioop.tostereo(self.frames, self.samplewidth, lf, rf)
+                self.nchannels = 2
+            return self
+
+    rng = np.random.default_rng(int(os.environ.get("SYNTHHIP_FUZZ_SEED", "77")))
+    for case in range(12):
+        width = int(rng.choice([1, 2, 2, 4]))
+        nch = int(rng.choice([1, 2]))
+        rate = int(rng.choice([8000, 11025, 22050]))
+        frames = int(rng.integers(200, 6000))
+        x = _rand(rng, width, frames * nch, scale=0.3)
+        s = Sample.from_raw_frames(x.tobytes(), width, rate, nch)
+        r = Ref(x.tobytes(), width, rate, nch)
+        for step in range(8):
+            op = int(rng.integers(0, 13))
+            dur = r.duration
+            if op == 0:
+                f = float(rng.uniform(-1.2, 1.2)); s.amplify(f); r.amplify(f)
+            elif op == 1:
+                b = int(rng.integers(-50, 50)); s.bias(b); r.bias(b)
+            elif op == 2:
+                s.reverse(); r.reverse()
+            elif op == 3:
+                t = float(rng.uniform(0, dur)); v = float(rng.uniform(0, 0.5)); s.fadeout(t, v); r.fadeout(t, v)
+            elif op == 4:
+                t = float(rng.uniform(0, dur)); v = float(rng.uniform(0, 0.5)); s.fadein(t, v); r.fadein(t, v)
+            elif op == 5:
+                y = _rand(rng, width, int(rng.integers(1, 3000)) * r.nchannels, scale=0.3)
+                at = float(rng.uniform(0, dur * 1.2))
+                s.mix_at(at, Sample.from_raw_frames(y.tobytes(), width, r.samplerate, r.nchannels))
+                r.mix_at(at, Ref(y.tobytes(), width, r.samplerate, r.nchannels))
+            elif op == 6:
+                a = float(rng.uniform(0, dur)); b = float(rng.uniform(a, dur)); s.clip(a, b); r.clip(a, b)
+            elif op == 7:
+                t = float(rng.uniform(-0.2, 0.2) * max(dur, 0.01)); k = bool(rng.integers(0, 2)); s.delay(t, k); r.delay(t, k)
+            elif op == 8 and len(r) > 10:
+                sp = float(rng.choice([0.5, 0.8, 1.25, 2.0])); s.speed(sp); r.speed(sp)
+            elif op == 9 and len(r) > 10:
+                nr = int(rng.choice([8000, 11025, 16000, 22050, 44100])); s.resample(nr); r.resample(nr)
+            elif op == 10:
+                lf, rf = float(rng.uniform(0, 1)), float(rng.uniform(0, 1))
+                if r.nchannels == 2:
+                    s.mono(lf, rf); r.mono(lf, rf)
+                else:
+                    s.stereo(lf, rf); r.stereo(lf, rf)
+            elif op == 11 and dur > 0:
+                a = (float(rng.uniform(0, dur * 0.8)), int(rng.integers(0, 4)), float(rng.uniform(0.001, 0.05)), float(rng.uniform(0.2, 0.9)))
+                s.echo(*a); r.echo(*a)
+            elif op == 12 and dur > 0.05:
+                a = (dur * 0.1, dur * 0.2, float(rng.uniform(0, 1)), dur * 0.3)
+                s.envelope(*a); r.envelope(*a)
+            assert (s.samplewidth, s.samplerate, s.nchannels) == (r.samplewidth, r.samplerate, r.nchannels), (case, step, op)
+            assert bytes(s.view_frame_data()) == r.frames, (case, step, op, width, nch, len(r))
