@@ -208,7 +208,7 @@ def test_fuzz_random_chains_of_sample_operations(gpu):
             elif op == 6:
                 a = float(rng.uniform(0, dur)); b = float(rng.uniform(a, dur)); s.clip(a, b); r.clip(a, b)
             elif op == 7:
-                t = float(rng.uniform(-0.2, 0.2) * max(dur, 0.01)); k = bool(rng.integers(0, 2)); s.delay(t, k); r.delay(t, k)
+                t = float(rng.uniform(-0.2, 0.2) * dur); k = bool(rng.integers(0, 2)); s.delay(t, k); r.delay(t, k)
             elif op == 8 and len(r) > 10:
                 sp = float(rng.choice([0.5, 0.8, 1.25, 2.0])); s.speed(sp); r.speed(sp)
             elif op == 9 and len(r) > 10:
