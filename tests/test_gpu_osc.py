@@ -332,7 +332,8 @@ def test_randomised_voices_vs_c_oracle(gpu):
     """Seeded sweep over kinds x FM x envelope x parameters, 30 000 samples each, against the C oracle."""
     from oracle import c_oracle as CO
     from synthesizer_amd import oscillators as G
-    rng = np.random.default_rng(777)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SYNTHHIP_FUZZ_SEED", "777")))
     kinds = ["Sine", "Sawtooth", "Square", "Pulse", "Harmonics"]
     n = 30000
     worst = 0.0
