@@ -109,19 +109,19 @@ int sh_dist_shutdown(void) {
     Rccl& r = R();
     if (r.comm) {
         if (sh::state().initialized) {
-            hipStreamSynchronize(sh::state().stream);
-            if (sh::state().comm_stream) hipStreamSynchronize(sh::state().comm_stream);
+            (void)hipStreamSynchronize(sh::state().stream);
+            if (sh::state().comm_stream) (void)hipStreamSynchronize(sh::state().comm_stream);
         }
         r.CommDestroy(r.comm);
         r.comm = nullptr;
         for (int k = 0; k < Rccl::SLOTS; ++k) {
-            if (r.ev_rendered[k]) { hipEventDestroy(r.ev_rendered[k]); r.ev_rendered[k] = nullptr; }
-            if (r.ev_done[k]) { hipEventDestroy(r.ev_done[k]); r.ev_done[k] = nullptr; }
+            if (r.ev_rendered[k]) { (void)hipEventDestroy(r.ev_rendered[k]); r.ev_rendered[k] = nullptr; }
+            if (r.ev_done[k]) { (void)hipEventDestroy(r.ev_done[k]); r.ev_done[k] = nullptr; }
         }
-        if (sh::state().comm_stream) { hipStreamDestroy(sh::state().comm_stream); sh::state().comm_stream = nullptr; }
+        if (sh::state().comm_stream) { (void)hipStreamDestroy(sh::state().comm_stream); sh::state().comm_stream = nullptr; }
     }
     if (r.token) {
-        hipFree(r.token);
+        (void)hipFree(r.token);
         r.token = nullptr;
     }
     r.rank = -1;

@@ -1486,22 +1486,22 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
 int sh_bank_destroy(sh_bank* b) {
     if (!b) return SH_OK;
     if (sh::state().initialized) {
-        hipStreamSynchronize(sh::state().stream);
-        if (b->d_voices) hipFree(b->d_voices);
-        if (b->d_segs) hipFree(b->d_segs);
-        if (b->d_coefs) hipFree(b->d_coefs);
-        if (b->d_partials) hipFree(b->d_partials);
+        (void)hipStreamSynchronize(sh::state().stream);
+        if (b->d_voices) (void)hipFree(b->d_voices);
+        if (b->d_segs) (void)hipFree(b->d_segs);
+        if (b->d_coefs) (void)hipFree(b->d_coefs);
+        if (b->d_partials) (void)hipFree(b->d_partials);
         for (int k = 0; k < 2; ++k) {
-            if (b->d_launch_buf[k]) hipFree(b->d_launch_buf[k]);
-            if (b->d_launch_fm_buf[k]) hipFree(b->d_launch_fm_buf[k]);
-            if (b->d_fast_buf[k]) hipFree(b->d_fast_buf[k]);
-            if (b->d_gen_idx_buf[k]) hipFree(b->d_gen_idx_buf[k]);
-            if (b->d_counts_buf[k]) hipFree(b->d_counts_buf[k]);
+            if (b->d_launch_buf[k]) (void)hipFree(b->d_launch_buf[k]);
+            if (b->d_launch_fm_buf[k]) (void)hipFree(b->d_launch_fm_buf[k]);
+            if (b->d_fast_buf[k]) (void)hipFree(b->d_fast_buf[k]);
+            if (b->d_gen_idx_buf[k]) (void)hipFree(b->d_gen_idx_buf[k]);
+            if (b->d_counts_buf[k]) (void)hipFree(b->d_counts_buf[k]);
         }
-        if (b->d_gains) hipFree(b->d_gains);
-        if (b->d_hint) hipFree(b->d_hint);
-        if (b->d_seg_rot) hipFree(b->d_seg_rot);
-        if (b->d_lfo_rot) hipFree(b->d_lfo_rot);
+        if (b->d_gains) (void)hipFree(b->d_gains);
+        if (b->d_hint) (void)hipFree(b->d_hint);
+        if (b->d_seg_rot) (void)hipFree(b->d_seg_rot);
+        if (b->d_lfo_rot) (void)hipFree(b->d_lfo_rot);
     }
     delete b;
     return SH_OK;

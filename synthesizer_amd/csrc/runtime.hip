@@ -75,8 +75,8 @@ int pool_alloc(size_t bytes, void** ptr, size_t* cap) {
 
 void pool_free(void* ptr, size_t cap) {
     if (g_pool.cached + cap > Pool::LIMIT) {
-        hipStreamSynchronize(state().stream);
-        hipFree(ptr);
+        (void)hipStreamSynchronize(state().stream);
+        (void)hipFree(ptr);
         return;
     }
     g_pool.free_[cap].push_back(ptr);
@@ -84,9 +84,9 @@ void pool_free(void* ptr, size_t cap) {
 }
 
 void pool_trim() {
-    if (state().stream) hipStreamSynchronize(state().stream);
+    if (state().stream) (void)hipStreamSynchronize(state().stream);
     for (auto& kv : g_pool.free_)
-        for (void* p : kv.second) hipFree(p);
+        for (void* p : kv.second) (void)hipFree(p);
     g_pool.free_.clear();
     g_pool.cached = 0;
 }
@@ -160,18 +160,18 @@ int sh_init(int device) {
 int sh_shutdown(void) {
     sh::State& s = state();
     if (!s.initialized) return SH_OK;
-    hipStreamSynchronize(s.stream);
+    (void)hipStreamSynchronize(s.stream);
     if (s.pending.active) sh::flush_pending();
-    hipStreamSynchronize(s.stream);
+    (void)hipStreamSynchronize(s.stream);
     sh::pool_trim();
-    if (s.scratch) hipFree(s.scratch);
-    for (int k = 0; k < 2; ++k) if (s.parts_buf[k]) hipFree(s.parts_buf[k]);
-    if (s.flag) hipFree(s.flag);
-    if (s.trig) hipFree(s.trig);
-    if (s.flag_host) hipHostFree(s.flag_host);
-    hipEventDestroy(s.ev_start);
-    hipEventDestroy(s.ev_stop);
-    hipStreamDestroy(s.stream);
+    if (s.scratch) (void)hipFree(s.scratch);
+    for (int k = 0; k < 2; ++k) if (s.parts_buf[k]) (void)hipFree(s.parts_buf[k]);
+    if (s.flag) (void)hipFree(s.flag);
+    if (s.trig) (void)hipFree(s.trig);
+    if (s.flag_host) (void)hipHostFree(s.flag_host);
+    (void)hipEventDestroy(s.ev_start);
+    (void)hipEventDestroy(s.ev_stop);
+    (void)hipStreamDestroy(s.stream);
     s = sh::State();
     return SH_OK;
 }
