@@ -12,7 +12,7 @@
 //
 // Kernels
 //   k_prepare_chunks  one wavefront per 64 voices: resolve everything that depends on `start` (phase-table piece,
-//                     envelope lines) into a 416-byte launch record per voice, and classify the voices for the render
+//                     envelope lines) into a 384-byte launch record per voice, and classify the voices for the render
 //                     kernel (lean FastRec list / general index list per chunk).  In a stream the same code runs
 //                     inside the previous block's render kernel (its first workgroups), not as a kernel of its own
 //   k_prepare         the same records for a single voice (sh_osc_render)
@@ -60,6 +60,7 @@ __device__ __forceinline__ const T SH_CONST_AS* as_const(const T* p) {
 constexpr uint32_t FL_KIND = 0x7, FL_FM_SHIFT = 4, FL_FM = 0x30, FL_DENSE = 0x40, FL_ENV_UNIFORM = 0x80,
                    FL_POLY = 0x100, FL_FOLDED = 0x200, FL_FLIP = 0x400, FL_SILENT = 0x800;
 constexpr uint32_t NO_TAIL = 0xFFFFFFFFu;
+constexpr int NXP = 12;                             // following phase-table pieces a launch record lists
 
 struct alignas(16) VoiceLaunch {
     // ---- hot part (96 bytes) ----
@@ -73,7 +74,7 @@ struct alignas(16) VoiceLaunch {
     uint32_t harm_cnt;
     uint32_t seg;                 // piece index (slow path resumes the walk here)
     uint32_t tail_i;              // launch-relative index of the post-release extra sample, or NO_TAIL
-    uint32_t pad0;
+    uint32_t nx_count;            // following table pieces listed in nx_end
     double   poly[16];            // FL_POLY: the 16 polynomial coefficients, copied here so that the record
                                   // and the coefficients arrive in ONE batch of scalar loads
     double   rot_c, rot_s;        // cos / sin of 64*dt: a lane's second frame is 64 samples after its first, so its
@@ -83,12 +84,12 @@ struct alignas(16) VoiceLaunch {
     double   g0[4], slope[4];     // gain(i) = fma(i, slope[p], g0[p]) on piece p; 0 after release
     double   tail_amp;
     double   pulsewidth;
-    // the NEXT four table pieces: frames i in [nx_start(k), nx_end[k]) have t = fma(i - nx_start(k), nx_dt[k], nx_t0[k]),
-    // nx_start(0) = remain, nx_start(k) = nx_end[k-1]; unused entries have nx_end = 0
-    uint32_t nx_end[4];
-    double   nx_t0[4], nx_dt[4];
+    // the table pieces that follow inside the launch (the first second of a note runs through a dozen binades of the
+    // phase sum): piece k (table index seg+1+k) holds the frames [nx_start(k), nx_end[k]), nx_start(0) = remain,
+    // nx_start(k) = nx_end[k-1]; there t = fma(i - nx_start(k), dt, t0) with the piece's (t0, dt) from the table
+    uint32_t nx_end[NXP];
 };
-static_assert(sizeof(VoiceLaunch) == 416, "VoiceLaunch layout");
+static_assert(sizeof(VoiceLaunch) == 384, "VoiceLaunch layout");
 
 struct alignas(16) VoiceFM {      // only read for FM voices
     double frequency, phase0, f_inc;      // theta = frequency*T + fma(f_inc, L, phase0)
@@ -176,21 +177,22 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     o->dt = dt;
     o->remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
     o->seg = lo;
-    o->pad0 = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t pi = lo + 1 + k;                       // table piece that follows
-        uint32_t end = 0;
-        double t0 = t_base, d0 = dt;
-        if (pi < cnt && tab[pi].n0 - start <= 0xFFFFFFFFull) {
-            t0 = tab[pi].t0;
-            d0 = tab[pi].dt;
-            const uint64_t e = (pi + 1 < cnt) ? (tab[pi + 1].n0 - start) : 0xFFFFFFFFull;
-            end = e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
+    {
+        uint32_t count = 0;
+        uint64_t piece_start = rem;                           // launch-relative first frame of the next piece
+#pragma unroll 1
+        for (int k = 0; k < NXP; ++k) {
+            const uint32_t pi = lo + 1 + k;
+            uint32_t end = 0xFFFFFFFFu;
+            if (count == (uint32_t)k && pi < cnt && piece_start < (uint64_t)nframes) {      // still inside the launch
+                const uint64_t e = (pi + 1 < cnt) ? (tab[pi + 1].n0 - start) : 0xFFFFFFFFull;
+                end = e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
+                piece_start = e;
+                count = (uint32_t)k + 1;
+            }
+            o->nx_end[k] = end;
         }
-        o->nx_end[k] = end;
-        o->nx_t0[k] = t0;
-        o->nx_dt[k] = d0;
+        o->nx_count = count;
     }
     uint32_t flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
                      (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u) | (v.flip ? FL_FLIP : 0u);
@@ -439,13 +441,21 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
         // (scalar binary search), then per lane only for the lanes past that piece's end.
         const VoiceLaunch SH_CONST_AS* q = r.rec;
         const uint32_t tile_first = tile_last & ~(uint32_t)(64 * FPL - 1);
-        const uint32_t e0 = q->nx_end[0], e1 = q->nx_end[1], e2 = q->nx_end[2], e3 = q->nx_end[3];
-        // k = index of the following piece that holds the tile's first frame (uniform)
-        const uint32_t k = (tile_first >= e0) + (tile_first >= e1) + (tile_first >= e2) + (tile_first >= e3);
-        const uint32_t k_end = k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : k == 3 ? e3 : 0u;
-        const uint32_t k_start = k == 0 ? r.remain : k == 1 ? e0 : k == 2 ? e1 : e2;
-        if (tile_first >= r.remain && k < 4 && tile_last < k_end) {
-            const double tb = q->nx_t0[k & 3], dk = q->nx_dt[k & 3], off = (double)k_start;
+        // k = index of the following piece that holds the tile's first frame (uniform): the number of listed piece
+        // ends at or before it
+        uint32_t k = 0;
+#pragma unroll
+        for (int u = 0; u < NXP; ++u) k += tile_first >= q->nx_end[u];
+        const uint32_t nx_count = q->nx_count;
+        const bool fm_t = (r.flags & FL_FM) != 0;
+        uint32_t k_end = 0, k_start = 0;
+        if (k < nx_count) {
+            k_end = q->nx_end[k];
+            k_start = k ? q->nx_end[k - 1] : r.remain;
+        }
+        if (tile_first >= r.remain && k < nx_count && tile_last < k_end) {
+            const sh_segment SH_CONST_AS* pc = as_const(B.segs) + (fm_t ? vfull->time_seg_offset : vfull->seg_offset) + q->seg + 1 + k;
+            const double tb = pc->t0, dk = pc->dt, off = (double)k_start;
 #pragma unroll
             for (int j = 0; j < FPL; ++j) th[j] = fma(di[j] - off, dk, tb);
             if ((r.flags & FL_FM) == 0) {                     // still one piece per tile: the rotation shortcut applies
@@ -720,8 +730,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
 // Whole-bank materialisation through the launch's voice lists (see LaunchSet): grid = (groups of 4 tiles, 64-voice chunks);
 // a wave owns one tile and walks the chunk's lean records with the loop of k_bank_render (the sample is rounded and
 // stored instead of accumulated), then the general list through voice_block, then zero-fills the rows of silent voices.
-// The lean arithmetic repeats the general code's order -- ((x * amplitude) + 0) * g0u -- so a row equals what
-// sh_osc_render gives for that voice, bit for bit.
+// The lean arithmetic repeats the general code's order -- ((x * amplitude) + 0) * g0u.
 template <int FPL>
 __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                          uint32_t nvoices, LaunchSet cur, uint64_t start, uint32_t n,

@@ -38,11 +38,12 @@ def test_config2_additive_64_voices_adsr(gpu):
     # two-step (materialise, then HBM-bound mix) agrees with the fused kernel
     two = bank.render_two_step(n)
     assert rms(two, want) <= RMS_TOL
-    # per-voice materialisation equals the single-oscillator path
+    # per-voice materialisation agrees with the single-oscillator path
     mat = bank.generate(n)
     assert mat.shape == (64, n)
     for i in (0, 17, 63):
-        assert np.array_equal(mat[i], gv[i].render(n, start=0))
+        one = gv[i].render(n, start=0)       # another launch shape (frames per lane): the float64 values may differ in
+        assert np.max(np.abs(mat[i] - one)) < 1.5e-7 and np.mean(mat[i] != one) < 0.01      # the last bit before rounding
     # frames past the release: voices are silent, bus is exactly zero
     late = bank.render(256, start=SR * 2)
     assert not late.any()
@@ -213,7 +214,8 @@ def test_bank_with_released_voices(gpu):
     assert not bank.render(1000, start=int(0.65 * SR)).any()
     mat = bank.generate(2000, start=int(0.3 * SR))
     for i in range(n_v):
-        assert np.array_equal(mat[i], make(G)[i].render(2000, start=int(0.3 * SR)))
+        one = make(G)[i].render(2000, start=int(0.3 * SR))
+        assert np.max(np.abs(mat[i] - one)) < 1.5e-7 and np.mean(mat[i] != one) < 0.01
 
 
 def test_lean_loop_classification_and_parity(gpu):
