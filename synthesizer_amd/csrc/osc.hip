@@ -124,7 +124,8 @@ struct alignas(64) FastRec {
 };
 static_assert(offsetof(FastRec, t0_b) == 192, "FastRec: common part is 192 bytes");
 static_assert(sizeof(FastRec) == 256, "FastRec layout");
-constexpr uint32_t LEAN_HARM = 0, LEAN_FM = 1;
+constexpr uint32_t LEAN_HARM = 0, LEAN_FM = 1,                 // ... and the plain waveforms without FM (t in turns, Sine: radians);
+                   LEAN_SINE = 2, LEAN_SAW = 3, LEAN_SQUARE = 4, LEAN_TRIANGLE = 5, LEAN_PULSE = 6;    // Pulse: poly[0] = pulsewidth
 
 // One set of per-launch data (double-buffered in the bank).  Voices are classified per chunk of 64 consecutive
 // voices: the fast voices of chunk c get a FastRec, compacted at fast[64c ..], the others are listed by index in
@@ -143,7 +144,7 @@ struct PrepInfo {                 // what prepare_voice found, for the classific
     double t0_b, dt_b, rot_c_b, rot_s_b;
     uint32_t remain;
     uint32_t kind;                // LEAN_HARM / LEAN_FM
-    double   amplitude, g0u;
+    double   amplitude, g0u, pulsewidth;
     double   fmv[11];             // LEAN_FM: the values that go to FastRec::poly[0..10]
     const double* harm;
 };
@@ -274,14 +275,21 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     o->gain_l = gain_l;
     o->gain_r = gain_r;
     o->flags = flags;
-    // a Sine carrier with a closed-form Sine LFO can take the lean loop too (its record folds amplitude and envelope
-    // into the gains like FL_FOLDED does; the general code is not told: its Sine path applies the amplitude itself)
-    const bool lean_fm = v.kind == SH_SINE && v.fm_mode == SH_FM_SINE && v.bias == 0.0 && (flags & FL_ENV_UNIFORM) && slu == 0.0 &&
-                         !(flags & FL_SILENT);
-    info.kind = lean_fm ? LEAN_FM : LEAN_HARM;
+    // Other voices that can take the lean loop: a Sine carrier with a closed-form Sine LFO, and the plain waveforms without
+    // FM.  Their record folds amplitude and envelope into the gains like FL_FOLDED does (the general code is not told: its
+    // paths apply the amplitude themselves).
+    const bool lean_env = v.bias == 0.0 && !v.flip && (flags & FL_ENV_UNIFORM) && slu == 0.0 && !(flags & FL_SILENT);
+    const bool lean_fm = lean_env && v.kind == SH_SINE && v.fm_mode == SH_FM_SINE;
+    const bool lean_plain = lean_env && v.fm_mode == SH_FM_NONE &&
+                            (v.kind == SH_SINE || v.kind == SH_SAWTOOTH || v.kind == SH_SQUARE || v.kind == SH_TRIANGLE || v.kind == SH_PULSE);
+    info.kind = lean_fm ? LEAN_FM
+              : !lean_plain ? LEAN_HARM
+              : v.kind == SH_SINE ? LEAN_SINE : v.kind == SH_SAWTOOTH ? LEAN_SAW : v.kind == SH_SQUARE ? LEAN_SQUARE
+              : v.kind == SH_TRIANGLE ? LEAN_TRIANGLE : LEAN_PULSE;
     info.amplitude = v.amplitude;
     info.g0u = g0u;
-    if (lean_fm) {
+    info.pulsewidth = v.pulsewidth;
+    if (lean_fm || lean_plain) {
         gain_l = (v.amplitude * g0u) * gain_l;
         gain_r = (v.amplitude * g0u) * gain_r;
     }
@@ -289,7 +297,7 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     // lean: the launch lies on the current table piece, or on it and the next one
     const bool one_piece = rem >= (uint64_t)nframes;
     const bool two_pieces = !one_piece && lo + 1 < cnt && ((lo + 2 < cnt) ? (tab[lo + 2].n0 - start >= (uint64_t)nframes) : true);
-    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm) && (one_piece || two_pieces);
+    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm || lean_plain) && (one_piece || two_pieces);
     info.remain = one_piece ? 0xFFFFFFFFu : (uint32_t)rem;
     info.t0_b = one_piece ? t_base : tab[lo + 1].t0;
     info.dt_b = one_piece ? dt : tab[lo + 1].dt;
@@ -355,6 +363,9 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         if (info.kind == LEAN_FM) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) f->poly[u] = u < 11 ? info.fmv[u] : 0.0;
+        } else if (info.kind != LEAN_HARM) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f->poly[u] = u == 0 ? info.pulsewidth : 0.0;
         } else {
 #pragma unroll
             for (int u = 0; u < 16; ++u) f->poly[u] = info.harm[u];
@@ -796,6 +807,24 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
             shm::sincos_tab_n<FPL>(th, trig, sn, cs);
 #pragma unroll
             for (int j = 0; j < FPL; ++j) x[j] = sn[j];
+        } else if (kind >= LEAN_SAW) {                       // Sawtooth / Square / Triangle / Pulse at unit amplitude
+            double th[FPL];
+            if (remain == 0xFFFFFFFFu || tile_last < remain) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) th[j] = fma(di[j], da, ta);
+            } else if (tile0 >= remain) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) th[j] = fma(di[j] - ob, db, tb);
+            } else {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) th[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+            }
+#pragma unroll
+            for (int j = 0; j < FPL; ++j)
+                x[j] = kind == LEAN_SAW ? shm::saw_value(th[j], 2.0, 0.0)
+                     : kind == LEAN_SQUARE ? shm::square_value(th[j], 1.0, 0.0)
+                     : kind == LEAN_TRIANGLE ? shm::triangle_value(th[j], 4.0, 0.0)
+                     : shm::pulse_value(th[j], poly[0], 1.0, 0.0);
         } else {
             double sn[FPL], cs[FPL], pv[FPL];
             if (remain == 0xFFFFFFFFu || tile0 >= remain || tile_last < remain) {
@@ -823,7 +852,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
                 for (int j = 0; j < FPL; ++j) pv[j] = fma(pv[j], cs[j], poly[u]);
             }
 #pragma unroll
-            for (int j = 0; j < FPL; ++j) x[j] = pv[j] * sn[j];
+            for (int j = 0; j < FPL; ++j) x[j] = kind == LEAN_SINE ? sn[j] : pv[j] * sn[j];
         }
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
@@ -1026,6 +1055,42 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                 }
                 continue;
             }
+            if (MODE == RENDER_LEAN_ALL && kind >= LEAN_SAW) {
+                // Sawtooth / Square / Triangle / Pulse at unit amplitude (the amplitude lives in the gains): t in turns
+                double th[FPL], x[FPL];
+                if (remain == 0xFFFFFFFFu || tile_last < remain) {
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) th[j] = fma(di[j], da, ta);
+                } else {
+                    const double tb = q->t0_b, db = q->dt_b, ob = q->off_b;
+                    if (tile0 >= remain) {
+#pragma unroll
+                        for (int j = 0; j < FPL; ++j) th[j] = fma(di[j] - ob, db, tb);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < FPL; ++j) th[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+                    }
+                }
+                if (kind == LEAN_SAW) {
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) x[j] = shm::saw_value(th[j], 2.0, 0.0);
+                } else if (kind == LEAN_SQUARE) {
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) x[j] = shm::square_value(th[j], 1.0, 0.0);
+                } else if (kind == LEAN_TRIANGLE) {
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) x[j] = shm::triangle_value(th[j], 4.0, 0.0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) x[j] = shm::pulse_value(th[j], poly[0], 1.0, 0.0);
+                }
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    accl[j] = fma(gl, x[j], accl[j]);
+                    accr[j] = fma(gr, x[j], accr[j]);
+                }
+                continue;
+            }
             double sn[FPL], cs[FPL], pv[FPL];
             if (remain == 0xFFFFFFFFu) {                  // no piece end inside the launch: nothing to decide
                 shm::sincos_tab(fma(di[0], da, ta), trig, sn[0], cs[0]);
@@ -1052,6 +1117,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
 #pragma unroll
                 for (int j = 0; j < FPL; ++j) th[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
                 shm::sincos_tab_n<FPL>(th, trig, sn, cs);
+            }
+            if (MODE == RENDER_LEAN_ALL && kind == LEAN_SINE) {       // a plain Sine: sin(t) is the sample
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    accl[j] = fma(gl, sn[j], accl[j]);
+                    accr[j] = fma(gr, sn[j], accr[j]);
+                }
+                continue;
             }
 #pragma unroll
             for (int j = 0; j < FPL; ++j) pv[j] = fma(poly[0], cs[j], poly[1]);
@@ -1346,7 +1419,7 @@ struct sh_bank {
     uint64_t    spec_start = 0;
     uint32_t    spec_nframes = 0;
     uint32_t    lean_candidates = 0;      // voices that can take the lean loop in some launch (static properties)
-    uint32_t    lean_fm_candidates = 0;   // ... of them FM Sine voices
+    uint32_t    lean_fm_candidates = 0;   // ... of them other than polynomial Harmonics (FM Sine, plain waveforms)
     uint32_t    last_groups = 0;          // voice groups of the last sh_bank_render launch (sh_bank_launch_stats)
     float2*     d_gains = nullptr;
     uint32_t    nsegs = 0, ncoefs = 0, npartials = 0;
@@ -1447,9 +1520,11 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     for (uint32_t i = 0; i < nvoices; ++i)
         if (voices[i].bias == 0.0 && !voices[i].flip &&
             ((voices[i].kind == SH_HARMONICS && voices[i].harm_dense == 2 && voices[i].fm_mode == SH_FM_NONE) ||
-             (voices[i].kind == SH_SINE && voices[i].fm_mode == SH_FM_SINE))) {
+             (voices[i].kind == SH_SINE && voices[i].fm_mode == SH_FM_SINE) ||
+             (voices[i].fm_mode == SH_FM_NONE && (voices[i].kind == SH_SINE || voices[i].kind == SH_SAWTOOTH || voices[i].kind == SH_SQUARE ||
+                                                  voices[i].kind == SH_TRIANGLE || voices[i].kind == SH_PULSE)))) {
             b->lean_candidates += 1;
-            if (voices[i].kind == SH_SINE) b->lean_fm_candidates += 1;
+            if (voices[i].kind != SH_HARMONICS) b->lean_fm_candidates += 1;       // needs the kernel with all record kinds
         }
     std::vector<float2> gains(nvoices);
     for (uint32_t i = 0; i < nvoices; ++i) gains[i] = make_float2(voices[i].gain_l, voices[i].gain_r);

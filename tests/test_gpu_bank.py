@@ -258,7 +258,7 @@ def test_lean_loop_classification_and_parity(gpu):
 
 def test_lean_loop_fm_and_mixed_bank(gpu):
     """FM Sine voices with a plain Sine LFO take the lean loop too (a second record kind); a bank that mixes them with
-    additive voices, enveloped FM, and kinds that never go lean (Pulse, biased Sine, Clenshaw Harmonics) is summed by
+    additive voices, enveloped FM, plain Pulse voices, and voices that never go lean (biased Sine, Clenshaw Harmonics) is summed by
     both loops in one launch.  Against the C oracle over blocks that include the time table's piece ends (1 s, 2 s, 4 s
     of accumulated time at 48 kHz: frames 48000, 96000, 192000)."""
     import ctypes as C
@@ -288,7 +288,7 @@ def test_lean_loop_fm_and_mixed_bank(gpu):
             elif kind == 3:
                 v = M.Sine(float(f[k]), 0.5, bias=0.1, fm_lfo=lfo, samplerate=SR)                        # biased: general
             elif kind == 4:
-                v = M.Pulse(float(f[k]), 0.4, pulsewidth=0.3, samplerate=SR)                              # general
+                v = M.Pulse(float(f[k]), 0.4, pulsewidth=0.3, samplerate=SR)                              # lean (plain waveform)
             else:
                 v = M.Harmonics(float(f[k]), [(1, 1.0), (33, 0.2)], 0.5, samplerate=SR)                   # Clenshaw: general
             out.append(v)
@@ -305,7 +305,7 @@ def test_lean_loop_fm_and_mixed_bank(gpu):
         N.check(N.lib().sh_bank_launch_stats(bank._bank.handle, C.byref(a), C.byref(b)))
         assert a.value + b.value == nv
         if start:
-            assert a.value == nv // 2, (start, a.value)           # kinds 0, 1, 2: half of the bank
+            assert a.value == 4 * (nv // 6), (start, a.value)     # kinds 0, 1, 2 and the Pulse voices (4)
         else:
             assert a.value == 0       # the first frames: the accumulated time runs through many binades, attack / decay
         assert rms(got, want) <= RMS_TOL, start
