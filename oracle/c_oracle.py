@@ -19,7 +19,7 @@ from . import synth_oracle as O
 HERE = Path(__file__).resolve().parent
 _lib = None
 _D = C.POINTER(C.c_double)
-_KIND = {O.Sine: 0, O.Sawtooth: 1, O.Square: 2, O.Pulse: 3, O.Harmonics: 4}
+_KIND = {O.Sine: 0, O.Sawtooth: 1, O.Square: 2, O.Pulse: 3, O.Harmonics: 4, O.Triangle: 5}
 
 
 def lib() -> C.CDLL:

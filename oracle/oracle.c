@@ -18,7 +18,7 @@
 #include <stddef.h>
 #include <string.h>
 
-enum { K_SINE = 0, K_SAW = 1, K_SQUARE = 2, K_PULSE = 3, K_HARM = 4 };
+enum { K_SINE = 0, K_SAW = 1, K_SQUARE = 2, K_PULSE = 3, K_HARM = 4, K_TRIANGLE = 5 };
 
 /* Python float modulo by 1.0 */
 static double pymod1(double t) {
@@ -37,6 +37,7 @@ static double wave(int kind, double t, double amp, double bias, double pw, const
         return (odd ? -amp : amp) + bias;
     }
     case K_PULSE: return ((pymod1(t) < pw) ? amp : -amp) + bias;
+    case K_TRIANGLE: return 4.0 * amp * (fabs(pymod1(t + 0.75) - 0.5) - 0.25) + bias;   /* (t+0.75) % 1.0: Python float modulo */
     default: {
         double h = 0.0;
         for (int k = 0; k < nh; ++k) h += sin(t * hk[k]) * ha[k];

@@ -372,7 +372,7 @@ def test_fuzz_fused_vs_two_step_vs_oracle(gpu):
     for case in range(14):
         nv = int(rng.choice([1, 7, 63, 64, 65, 130, 257, 400]))
         f = rng.uniform(40, 4000, nv)
-        kinds = rng.integers(0, 7, nv)
+        kinds = rng.integers(0, 10, nv)
         sustain = rng.uniform(0.02, 1.5, nv)
         gains = [(float(np.float32(a)), float(np.float32(b))) for a, b in rng.uniform(0, 1, (nv, 2)) / np.sqrt(nv)]
         seeds = rng.uniform(0, 1, (nv, 3))
@@ -395,8 +395,15 @@ def test_fuzz_fused_vs_two_step_vs_oracle(gpu):
                     v = M.Sawtooth(float(f[k]), 0.4, phase=float(seeds[k, 0]), samplerate=SR)
                 elif kd == 5:
                     v = M.Harmonics(float(f[k]), [(1, 1.0), (2, 0.5)], 0.5, bias=0.05, samplerate=SR)
-                else:
+                elif kd == 6:
                     v = M.Square(float(f[k]), 0.3, samplerate=SR)
+                elif kd == 7:
+                    v = M.EnvelopeFilter(M.Triangle(float(f[k]), 0.4, phase=float(seeds[k, 1]), samplerate=SR),
+                                         0.0, 0.01, float(sustain[k]), 0.8, 0.02)
+                elif kd == 8:
+                    v = M.Pulse(float(f[k]), 0.35, pulsewidth=0.05 + 0.9 * float(seeds[k, 0]), samplerate=SR)
+                else:
+                    v = M.Sine(float(f[k]), 0.5, phase=float(seeds[k, 2]), samplerate=SR)
                 out.append(v)
             return out
 

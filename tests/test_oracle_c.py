@@ -25,6 +25,9 @@ SR = 48000
     lambda: O.EnvelopeFilter(O.Sine(440.0, samplerate=SR), 0.01, 0.05, 0.1, 0.6, 0.05),
     lambda: O.EnvelopeFilter(O.Sawtooth(300.0, samplerate=SR), 0.0, 0.02, 0.0, 0.3, 0.02),
     lambda: O.EnvelopeFilter(O.Pulse(100.0, samplerate=SR), 0.02, 0.0, 0.01, 1.0, 0.0),
+    lambda: O.Triangle(441.0, 0.6, phase=-0.4, bias=0.05, samplerate=SR),
+    lambda: O.Triangle(-250.0, 0.5, phase=0.3, samplerate=SR),
+    lambda: O.Triangle(300.0, fm_lfo=O.Sine(2.0, 0.05, samplerate=SR), samplerate=SR),
 ])
 def test_c_oscillators_equal_python_oracle(make):
     n = 12000
