@@ -55,9 +55,22 @@ def cpu_baseline(frames: int):
     blocks = [v.take(frames) for v in voices]
     O.mix_bus(blocks, gains)
     dt = time.perf_counter() - t0
-    return {"value": VOICES_PER_GPU * frames / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "1024 voices x %d frames (%.3f s of audio), pure-Python oracle generators + float bus sum, "
-                      "%.1f s wall" % (frames, frames / SR, dt)}
+    out = {"value": VOICES_PER_GPU * frames / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": "1024 voices x %d frames (%.3f s of audio), pure-Python oracle generators + float bus sum, "
+                     "%.1f s wall" % (frames, frames / SR, dt)}
+    # the same sample through the C restatement of the oracle (oracle/oracle.c, one core): what a compiled single-threaded
+    # CPU implementation of this arithmetic does -- a fairer yardstick than the interpreter
+    try:
+        import numpy as np
+        from oracle import c_oracle as CO
+        CO.render(voices[0], 16)                     # build / load the shared object outside the timed region
+        t0 = time.perf_counter()
+        CO.mix_bus(np.stack([CO.render(v, frames) for v in voices]), gains)
+        dtc = time.perf_counter() - t0
+        out["c_port"] = {"value": VOICES_PER_GPU * frames / dtc / 1e6, "unit": "Msamples/s", "cores": 1, "wall_s": dtc}
+    except Exception as e:                           # no C compiler on the box: the Python number stands alone
+        out["c_port"] = {"error": str(e)}
+    return out
 
 
 def measured_traffic():
