@@ -172,7 +172,8 @@ def pcm_rows(N):
     for name, call, moved in (
             ("pcm_mul_i16_900MB", lambda: L.sh_pcm_mul(chunks.handle, 0, n, 2, 0.7071, src.handle, 0), 2 * n),
             ("pcm_tomono_i16_900MB", lambda: L.sh_pcm_tomono(chunks.handle, n // 4, 2, 0.5, 0.5, src.handle), n + n // 2),
-            ("pcm_stats_i16_900MB", lambda: L.sh_pcm_stats(chunks.handle, n, 2, ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_double())), n)):
+            ("pcm_stats_i16_900MB", lambda: L.sh_pcm_stats(chunks.handle, n, 2, ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_double())), n),
+            ("pcm_stats_stereo_i16_900MB", lambda: L.sh_pcm_stats_stereo(chunks.handle, n // 4, 2, (ctypes.c_uint32 * 2)(), (ctypes.c_double * 2)()), n)):
         N.check(call())
         N.sync()
         N.timer_start()

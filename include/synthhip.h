@@ -267,6 +267,10 @@ int sh_pcm_lin2lin(const sh_buf* in, size_t nsamples, int width, int new_width, 
 /* audioop.max (maximum absolute sample) and the sum of squares audioop.rms takes the root of
  * (exact for widths 1 and 2; width 4 is summed in float64 in a fixed tree order) */
 int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, double* sum_squares);
+/* The same for interleaved stereo, per channel in one pass: [0] = left, [1] = right.  Replaces the
+ * audioop.tomono(frames, w, 1, 0) / (.., 0, 1) + audioop.max / audioop.rms sequence of Sample.level_db_peak /
+ * level_db_rms and LevelMeter.update (upstream synthplayer/sample.py, [RECALL], tree not mounted). */
+int sh_pcm_stats_stereo(const sh_buf* in, size_t nframes, int width, uint32_t max_abs[2], double sum_squares[2]);
 
 /* ---- Sample.resample -> audioop.ratecv(frames, width, nchannels, inrate, outrate, None) */
 size_t sh_resample_out_frames(size_t in_frames, int inrate, int outrate);

@@ -1,6 +1,7 @@
 """
 CPU ORACLE for the editing operations of ``Sample``: clip / split / join /
-add_silence / delay, speed, at_volume, echo, envelope, modulate_amp.
+add_silence / delay, speed, at_volume, echo, envelope, modulate_amp, and of the level metering
+(``level_db_peak`` / ``level_db_rms`` and the stateful ``LevelMeter``).
 
 THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle/synth_oracle.py): only tests/ may import it.
 
@@ -18,6 +19,7 @@ from __future__ import annotations
 import array
 import audioop
 import itertools
+import math
 from typing import Iterable, Optional, Sequence, Union
 
 _TYPECODE = {1: "b", 2: "h", 4: "i"}
@@ -46,6 +48,37 @@ class RefSample:
 
     def copy(self) -> "RefSample":
         return RefSample(self.frames, self.samplewidth, self.samplerate, self.nchannels)
+
+    # -- level metering ----------------------------------------------------------------------------
+    def _db_level(self, rms_mode: bool):
+        maxvalue = 2 ** (8 * self.samplewidth - 1)
+        measure = audioop.rms if rms_mode else audioop.max
+        if self.nchannels == 1:
+            left = right = (measure(self.frames, self.samplewidth) + 1) / maxvalue
+        else:
+            left_frames = audioop.tomono(self.frames, self.samplewidth, 1, 0)
+            right_frames = audioop.tomono(self.frames, self.samplewidth, 0, 1)
+            left = (measure(left_frames, self.samplewidth) + 1) / maxvalue
+            right = (measure(right_frames, self.samplewidth) + 1) / maxvalue
+        return max(20.0 * math.log(left, 10), -60.0), max(20.0 * math.log(right, 10), -60.0)
+
+    @property
+    def level_db_peak(self):
+        return self._db_level(False)
+
+    @property
+    def level_db_rms(self):
+        return self._db_level(True)
+
+    @property
+    def level_db_peak_mono(self) -> float:
+        maxvalue = 2 ** (8 * self.samplewidth - 1)
+        return max(20.0 * math.log((audioop.max(self.frames, self.samplewidth) + 1) / maxvalue, 10), -60.0)
+
+    @property
+    def level_db_rms_mono(self) -> float:
+        maxvalue = 2 ** (8 * self.samplewidth - 1)
+        return max(20.0 * math.log((audioop.rms(self.frames, self.samplewidth) + 1) / maxvalue, 10), -60.0)
 
     # -- arithmetic (audioop) ------------------------------------------------------------------------
     def amplify(self, factor: float) -> "RefSample":
@@ -231,3 +264,29 @@ class RefSample:
             frames[i] = int(frames[i] * next(actual_modulator))
         self.frames = frames.tobytes()
         return self
+
+
+class RefLevelMeter:
+    """Upstream ``LevelMeter`` ([RECALL]): level / held peak per channel, hold 0.4 s, fall 30 dB per second."""
+
+    def __init__(self, rms_mode: bool = False, lowest: float = -60.0) -> None:
+        self._rms = rms_mode
+        self._lowest = lowest
+        self.peak_left = self.peak_right = lowest
+        self._hold_left = self._hold_right = 0.0
+        self._time = 0.0
+
+    def update(self, sample: RefSample):
+        left, right = sample.level_db_rms if self._rms else sample.level_db_peak
+        left, right = max(left, self._lowest), max(right, self._lowest)
+        now = self._time + sample.duration
+        if now - self._hold_left > 0.4:
+            self.peak_left -= sample.duration * 30.0
+        if left >= self.peak_left:
+            self.peak_left, self._hold_left = left, now
+        if now - self._hold_right > 0.4:
+            self.peak_right -= sample.duration * 30.0
+        if right >= self.peak_right:
+            self.peak_right, self._hold_right = right, now
+        self._time = now
+        return left, self.peak_left, right, self.peak_right

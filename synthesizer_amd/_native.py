@@ -110,6 +110,7 @@ _SIGNATURES = {
     "sh_pcm_tostereo": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_double, C.c_double, _P]),
     "sh_pcm_lin2lin": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, _P]),
     "sh_pcm_stats": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
+    "sh_pcm_stats_stereo": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
     "sh_resample_out_frames": (C.c_size_t, [C.c_size_t, C.c_int, C.c_int]),
     "sh_resample": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_size_t)]),
     "sh_resample_span": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

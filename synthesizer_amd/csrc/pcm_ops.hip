@@ -6,6 +6,7 @@
 // Built with -ffp-contract=off: audioop forms val1*lfactor + val2*rfactor with separate roundings.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -241,6 +242,139 @@ __global__ __launch_bounds__(256) void k_stats_fold(const unsigned long long* __
         for (int w = 1; w < 4; ++w) m = s_max[w] > m ? s_max[w] : m;
         out[0] = (unsigned long long)m;
         out[1] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    }
+}
+
+// Interleaved stereo, both channels in one pass (Sample.level_db_peak / level_db_rms: upstream takes
+// audioop.tomono(frames, w, 1, 0) and (.., 0, 1), two copies, and runs audioop.max / rms over each -- four passes and
+// two temporaries; here: one read).  A 16-byte vector holds whole frames, so even elements are left, odd right.
+// part[4b..4b+3] = max|L|, max|R|, sum L^2, sum R^2; for width 4 the sums are float64 bit patterns.
+template <typename T>
+__global__ __launch_bounds__(256) void k_stats_stereo(const T* __restrict__ in, size_t nframes, unsigned long long* __restrict__ part) {
+    __shared__ unsigned long long s_sum[4][2];
+    __shared__ unsigned s_max[4][2];
+    typedef typename std::conditional<sizeof(T) == 4, double, unsigned long long>::type acc_t;
+    unsigned mxl = 0, mxr = 0;
+    acc_t sql = 0, sqr = 0;
+    constexpr int V = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const size_t n = nframes * 2;
+    const size_t nvec = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) ? n / V : 0;
+    const size_t step = (size_t)gridDim.x * 256;
+    if constexpr (sizeof(T) == 2) {
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+        u2 mx2 = {0, 0};
+#define SH_FRAME(X_, A_, B_)                                                             \
+            {                                                                            \
+                const s2 v = __builtin_shufflevector(X_, X_, A_, B_);                    \
+                const s2 neg = (s2){0, 0} - v;                                           \
+                const u2 au = __builtin_bit_cast(u2, __builtin_elementwise_max(v, neg)); \
+                mx2 = __builtin_elementwise_max(mx2, au);                                \
+                sql += (unsigned long long)__umul24(au[0], au[0]);                       \
+                sqr += (unsigned long long)__umul24(au[1], au[1]);                       \
+            }
+        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + step < nvec; i += 2 * step) {
+            const vec_t x0 = reinterpret_cast<const vec_t*>(in)[i];
+            const vec_t x1 = reinterpret_cast<const vec_t*>(in)[i + step];
+            SH_FRAME(x0, 0, 1) SH_FRAME(x0, 2, 3) SH_FRAME(x0, 4, 5) SH_FRAME(x0, 6, 7)
+            SH_FRAME(x1, 0, 1) SH_FRAME(x1, 2, 3) SH_FRAME(x1, 4, 5) SH_FRAME(x1, 6, 7)
+        }
+        for (; i < nvec; i += step) {
+            const vec_t x = reinterpret_cast<const vec_t*>(in)[i];
+            SH_FRAME(x, 0, 1) SH_FRAME(x, 2, 3) SH_FRAME(x, 4, 5) SH_FRAME(x, 6, 7)
+        }
+#undef SH_FRAME
+        mxl = mx2[0];
+        mxr = mx2[1];
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += step) {
+            const vec_t x = reinterpret_cast<const vec_t*>(in)[i];
+#pragma unroll
+            for (int c = 0; c < V; c += 2) {
+                const long long l = (long long)x[c], r = (long long)x[c + 1];
+                const unsigned al = (unsigned)(l < 0 ? -l : l), ar = (unsigned)(r < 0 ? -r : r);
+                mxl = al > mxl ? al : mxl;
+                mxr = ar > mxr ? ar : mxr;
+                if constexpr (sizeof(T) == 4) { sql += (double)l * (double)l; sqr += (double)r * (double)r; }
+                else { sql += (unsigned long long)(l * l); sqr += (unsigned long long)(r * r); }
+            }
+        }
+    }
+    for (size_t f = nvec * V / 2 + (size_t)blockIdx.x * 256 + threadIdx.x; f < nframes; f += step) {
+        const long long l = (long long)in[2 * f], r = (long long)in[2 * f + 1];
+        const unsigned al = (unsigned)(l < 0 ? -l : l), ar = (unsigned)(r < 0 ? -r : r);
+        mxl = al > mxl ? al : mxl;
+        mxr = ar > mxr ? ar : mxr;
+        if constexpr (sizeof(T) == 4) { sql += (double)l * (double)l; sqr += (double)r * (double)r; }
+        else { sql += (unsigned long long)(l * l); sqr += (unsigned long long)(r * r); }
+    }
+    mxl = wave_max_u32(mxl);
+    mxr = wave_max_u32(mxr);
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sql += __shfl_down(sql, o, 64); sqr += __shfl_down(sqr, o, 64); }
+    } else {
+        sql = wave_sum_u64(sql);
+        sqr = wave_sum_u64(sqr);
+    }
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_sum[wave][0] = __builtin_bit_cast(unsigned long long, sql);
+        s_sum[wave][1] = __builtin_bit_cast(unsigned long long, sqr);
+        s_max[wave][0] = mxl;
+        s_max[wave][1] = mxr;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned c = threadIdx.x;
+        unsigned m = s_max[0][c];
+        for (int w = 1; w < 4; ++w) m = s_max[w][c] > m ? s_max[w][c] : m;
+        acc_t t = __builtin_bit_cast(acc_t, s_sum[0][c]);
+        for (int w = 1; w < 4; ++w) t += __builtin_bit_cast(acc_t, s_sum[w][c]);
+        part[4 * (size_t)blockIdx.x + c] = (unsigned long long)m;
+        part[4 * (size_t)blockIdx.x + 2 + c] = __builtin_bit_cast(unsigned long long, t);
+    }
+}
+
+// one workgroup: out[0..3] = max L, max R, sum L^2, sum R^2 over the per-workgroup quadruples (F64: sums are float64,
+// added in a fixed order: thread t takes workgroups t, t+256, ...; then the 64-lane tree; then the four waves)
+template <bool F64>
+__global__ __launch_bounds__(256) void k_stats_fold_stereo(const unsigned long long* __restrict__ part, unsigned nblocks,
+                                                           unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long s_sum[4][2];
+    __shared__ unsigned s_max[4][2];
+    typedef typename std::conditional<F64, double, unsigned long long>::type acc_t;
+    unsigned mxl = 0, mxr = 0;
+    acc_t sql = 0, sqr = 0;
+    for (unsigned b = threadIdx.x; b < nblocks; b += 256) {
+        const unsigned ml = (unsigned)part[4 * b], mr = (unsigned)part[4 * b + 1];
+        mxl = ml > mxl ? ml : mxl;
+        mxr = mr > mxr ? mr : mxr;
+        sql += __builtin_bit_cast(acc_t, part[4 * b + 2]);
+        sqr += __builtin_bit_cast(acc_t, part[4 * b + 3]);
+    }
+    mxl = wave_max_u32(mxl);
+    mxr = wave_max_u32(mxr);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sql += __shfl_down(sql, o, 64); sqr += __shfl_down(sqr, o, 64); }
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_sum[wave][0] = __builtin_bit_cast(unsigned long long, sql);
+        s_sum[wave][1] = __builtin_bit_cast(unsigned long long, sqr);
+        s_max[wave][0] = mxl;
+        s_max[wave][1] = mxr;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned c = threadIdx.x;
+        unsigned m = s_max[0][c];
+        for (int w = 1; w < 4; ++w) m = s_max[w][c] > m ? s_max[w][c] : m;
+        acc_t t = __builtin_bit_cast(acc_t, s_sum[0][c]);
+        for (int w = 1; w < 4; ++w) t += __builtin_bit_cast(acc_t, s_sum[w][c]);
+        out[c] = (unsigned long long)m;
+        out[2 + c] = __builtin_bit_cast(unsigned long long, t);
     }
 }
 
@@ -499,6 +633,39 @@ int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, 
         } else {
             *sum_squares = (double)host_acc[1];
         }
+    }
+    return SH_OK;
+}
+
+int sh_pcm_stats_stereo(const sh_buf* in, size_t nframes, int width, uint32_t max_abs[2], double sum_squares[2]) {
+    SH_REQUIRE_INIT();
+    if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats_stereo: width %d not in {1,2,4}", width);
+    if (!in || nframes > in->bytes / (2 * (size_t)width)) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats_stereo: range outside buffer");
+    if (max_abs) max_abs[0] = max_abs[1] = 0;
+    if (sum_squares) sum_squares[0] = sum_squares[1] = 0.0;
+    if (!nframes) return SH_OK;
+    const unsigned blocks = nframes / 1024 < 4096 ? (unsigned)(nframes / 1024 + 1) : 4096u;
+    int rc = sh::ensure_scratch(32 + (size_t)blocks * 32);
+    if (rc) return rc;
+    hipStream_t st = sh::state().stream;
+    unsigned long long* acc = (unsigned long long*)sh::state().scratch;          // [0..3]: result; then per-workgroup quadruples
+    unsigned long long* quads = acc + 4;
+    rc = dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        hipLaunchKernelGGL(k_stats_stereo<T>, dim3(blocks), dim3(256), 0, st, (const T*)in->ptr, nframes, quads);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_stats_stereo");
+    });
+    if (rc) return rc;
+    if (width == 4) hipLaunchKernelGGL(k_stats_fold_stereo<true>, dim3(1), dim3(256), 0, st, (const unsigned long long*)quads, blocks, acc);
+    else hipLaunchKernelGGL(k_stats_fold_stereo<false>, dim3(1), dim3(256), 0, st, (const unsigned long long*)quads, blocks, acc);
+    SH_CHECK_LAUNCH("k_stats_fold_stereo");
+    unsigned long long host_acc[4];
+    SH_HIP(hipMemcpyAsync(host_acc, acc, 32, hipMemcpyDeviceToHost, st));
+    SH_HIP(hipStreamSynchronize(st));
+    for (int c = 0; c < 2; ++c) {
+        if (max_abs) max_abs[c] = (uint32_t)host_acc[c];
+        if (sum_squares) sum_squares[c] = width == 4 ? __builtin_bit_cast(double, host_acc[2 + c]) : (double)host_acc[2 + c];
     }
     return SH_OK;
 }

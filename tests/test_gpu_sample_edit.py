@@ -1,6 +1,8 @@
 """GPU parity, SURVEY.md section 8(f) item 2 (continued): the editing operations of Sample -- clip / split / join /
 add_silence / delay, speed, at_volume, echo, envelope, modulate_amp -- against oracle/sample_oracle.py, which
 restates upstream's methods over bytes slicing and the live ``audioop`` module.  Bit-exact."""
+import math
+
 import numpy as np
 import pytest
 
@@ -227,3 +229,68 @@ def test_fuzz_random_chains_of_sample_operations(gpu):
                 s.envelope(*a); r.envelope(*a)
             assert (s.samplewidth, s.samplerate, s.nchannels) == (r.samplewidth, r.samplerate, r.nchannels), (case, step, op)
             assert bytes(s.view_frame_data()) == r.frames, (case, step, op, width, nch, len(r))
+
+
+@pytest.mark.parametrize("width", [1, 2, 4])
+@pytest.mark.parametrize("nch", [1, 2])
+def test_level_db_matches_audioop(gpu, width, nch):
+    """level_db_peak / level_db_rms: the per-channel maxima and root mean squares come from one device pass over the
+    interleaved PCM; upstream takes them from audioop.tomono copies.  Same floats, exactly (integer statistics; the
+    width-4 sum of squares is float64 in a different order, so the truncated RMS may differ by one unit there)."""
+    rng = np.random.default_rng(width * 7 + nch)
+    for n, scale in ((1, 1.0), (7, 1.0), (1000, 0.01), (50021, 0.5), (262144 + 3, 1.0)):
+        x = _rand(rng, width, n * nch, scale)
+        if nch == 2:
+            x[1::2] = (x[1::2] * 0.25).astype(DT[width])          # channels at different levels
+        s, r = _pair(x, width, 8000, nch)
+        assert s.level_db_peak == r.level_db_peak
+        assert s.level_db_peak_mono == r.level_db_peak_mono
+        if width < 4:
+            assert s.level_db_rms == r.level_db_rms
+            assert s.level_db_rms_mono == r.level_db_rms_mono
+        else:
+            assert np.allclose(s.level_db_rms, r.level_db_rms, rtol=0, atol=1e-6)
+            assert abs(s.level_db_rms_mono - r.level_db_rms_mono) < 1e-6
+    # extremes: silence bottoms out at -60 (8-bit: one count of 128 = -42 dB); full-scale negative is above 0 dB by one count
+    z, rz = _pair(np.zeros(64 * nch, DT[width]), width, 8000, nch)
+    assert z.level_db_peak == rz.level_db_peak == ((-60.0, -60.0) if width > 1 else (20.0 * math.log(1 / 128, 10),) * 2)
+    lo = np.full(64 * nch, np.iinfo(DT[width]).min, DT[width])
+    s, r = _pair(lo, width, 8000, nch)
+    assert s.level_db_peak == r.level_db_peak and s.level_db_peak[0] > 0.0
+    if width < 4:
+        assert s.level_db_rms == r.level_db_rms
+    e, re_ = _pair(np.zeros(0, DT[width]), width, 8000, nch)
+    assert e.level_db_peak == re_.level_db_peak and e.level_db_rms == re_.level_db_rms
+
+
+def test_level_db_unaligned_device_views(gpu):
+    """Stereo statistics of a sample whose device storage does not start on a 16-byte boundary (after clip)."""
+    rng = np.random.default_rng(99)
+    x = _rand(rng, 2, 2 * 30011)
+    s, r = _pair(x, 2, 8000, 2)
+    s.to_device()
+    _same(s.clip(0.000125, 3.5), r.clip(0.000125, 3.5))          # drops one frame: 4-byte offset
+    assert s.level_db_peak == r.level_db_peak and s.level_db_rms == r.level_db_rms
+
+
+def test_level_meter_tracks_like_upstream(gpu):
+    """LevelMeter over a run of chunks with rising and falling level: same (level, peak) sequence as the oracle's
+    restatement over audioop, for both modes -- the hold (0.4 s) and fall (30 dB/s) logic is host arithmetic."""
+    from oracle.sample_oracle import RefLevelMeter
+    from synthesizer_amd.sample import LevelMeter
+    rng = np.random.default_rng(5)
+    rate, chunk = 8000, 800                                       # 0.1 s chunks
+    for rms_mode in (False, True):
+        meter, ref = LevelMeter(rms_mode=rms_mode), RefLevelMeter(rms_mode=rms_mode)
+        for k in range(30):
+            level = (0.9, 0.5, 0.02, 0.001, 0.0, 0.3)[k % 6] * (1.0 if k < 12 else 0.1)
+            x = _rand(rng, 2, 2 * chunk, level)
+            x[1::2] = (x[1::2] * 0.5).astype(np.int16)
+            s, r = _pair(x, 2, rate, 2)
+            assert meter.update(s) == ref.update(r)
+        assert meter.peak_left >= meter.level_left and meter.peak_right >= meter.level_right
+        meter.reset()
+        assert (meter.peak_left, meter.level_right) == (-60.0, -60.0)
+    with pytest.raises(ValueError):
+        from synthesizer_amd.sample import Sample
+        Sample.from_raw_frames(bytes(12), 2, rate, 3).level_db_peak
