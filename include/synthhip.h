@@ -255,6 +255,10 @@ int sh_pcm_modulate(const sh_buf* in, size_t nbytes, int width, const sh_buf* mo
 /* samples as float64: out[i] = in[i] / divisor (Sample.get_frames_as_floats uses 2^(bits-1); modulate_amp with a
  * waveform modulator uses its largest absolute value) */
 int sh_pcm_to_f64(const sh_buf* in, size_t nsamples, int width, double divisor, sh_buf* out_f64);
+/* Sample.pan(lfo=...) (upstream synthplayer/sample.py, [RECALL]): out frame i = (int(l*(1-p)/2), int(r*(1+p)/2)),
+ * p = pan_f64[i] (one float64 per frame, device resident: an oscillator rendered in place, or uploaded values);
+ * nchannels 1 (l = r = the mono sample) or 2; out is stereo.  SH_ERR_OVERFLOW where Python would raise. */
+int sh_pcm_pan_lfo(const sh_buf* in, size_t nframes, int width, int nchannels, const sh_buf* pan_f64, sh_buf* out);
 /* Sample.bias -> audioop.bias: wrapping add */
 int sh_pcm_bias(const sh_buf* in, size_t nbytes, int width, int bias, sh_buf* out);
 /* Sample.reverse -> audioop.reverse: sample order reversed (out must not alias in) */

@@ -1,6 +1,6 @@
 """
 CPU ORACLE for the editing operations of ``Sample``: clip / split / join /
-add_silence / delay, speed, at_volume, echo, envelope, modulate_amp, and of the level metering
+add_silence / delay, speed, at_volume, echo, envelope, modulate_amp, pan with an LFO, and of the level metering
 (``level_db_peak`` / ``level_db_rms`` and the stateful ``LevelMeter``).
 
 THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle/synth_oracle.py): only tests/ may import it.
@@ -249,6 +249,38 @@ class RefSample:
         if release > 0:
             R.fadeout(release)
         self.join(D).join(S).join(R)
+        return self
+
+    def pan(self, panning: float = 0.0, lfo: Optional[Iterable[float]] = None) -> "RefSample":
+        if lfo is None:
+            lf, rf = (1 - panning) / 2, (1 + panning) / 2
+            w = self.samplewidth
+            if self.nchannels == 2:           # Sample.stereo on a stereo source: channels scaled apart, then recombined
+                left = audioop.mul(audioop.tomono(self.frames, w, 1, 0), w, lf)
+                right = audioop.mul(audioop.tomono(self.frames, w, 0, 1), w, rf)
+                self.frames = audioop.add(audioop.tostereo(left, w, 1, 0), audioop.tostereo(right, w, 0, 1), w)
+            else:
+                self.frames = audioop.tostereo(self.frames, w, lf, rf)
+            self.nchannels = 2
+            return self
+        lfo = iter(lfo)
+        if self.nchannels == 2:
+            right = array.array(_TYPECODE[self.samplewidth], audioop.tomono(self.frames, self.samplewidth, 0, 1))
+            left = array.array(_TYPECODE[self.samplewidth], audioop.tomono(self.frames, self.samplewidth, 1, 0))
+            stereo = self.get_frame_array()
+            for i in range(len(right)):
+                panning = next(lfo)
+                stereo[i * 2] = int(left[i] * (1 - panning) / 2)
+                stereo[i * 2 + 1] = int(right[i] * (1 + panning) / 2)
+        else:
+            mono = self.get_frame_array()
+            stereo = mono + mono
+            for i, sample in enumerate(mono):
+                panning = next(lfo)
+                stereo[i * 2] = int(sample * (1 - panning) / 2)
+                stereo[i * 2 + 1] = int(sample * (1 + panning) / 2)
+            self.nchannels = 2
+        self.frames = stereo.tobytes()
         return self
 
     def modulate_amp(self, modulation_source: Union["RefSample", Sequence[float], Iterable[float]]) -> "RefSample":

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "sh_pcm_fade": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, _P, C.c_size_t]),
     "sh_pcm_modulate": (C.c_int, [_P, C.c_size_t, C.c_int, _P, C.c_size_t, _P]),
     "sh_pcm_to_f64": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_double, _P]),
+    "sh_pcm_pan_lfo": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, _P, _P]),
     "sh_pcm_bias": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, _P]),
     "sh_pcm_reverse": (C.c_int, [_P, C.c_size_t, C.c_int, _P]),
     "sh_pcm_tomono": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_double, C.c_double, _P]),

@@ -63,6 +63,25 @@ __global__ __launch_bounds__(256) void k_modulate(const T* __restrict__ in, T* _
     out[i] = (T)(long long)t;
 }
 
+// Sample.pan(lfo=...): frame i becomes (int(l * (1 - p) / 2), int(r * (1 + p) / 2)) with p = pan[i]; a mono source
+// feeds both sides.  float64 like the Python expression (the halving is exact); a value outside the sample range
+// raises upstream (array assignment) -> flag.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void k_pan_lfo(const T* __restrict__ in, T* __restrict__ out, size_t nframes,
+                                                 const double* __restrict__ pan, int* flag) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nframes) return;
+    constexpr double HI = (double)((1ll << (8 * sizeof(T) - 1)) - 1), LO = -(double)(1ll << (8 * sizeof(T) - 1));
+    const double p = pan[i];
+    const double l = (double)in[i * NCH], r = (double)in[i * NCH + NCH - 1];
+    double tl = trunc(l * (1.0 - p) / 2.0), tr = trunc(r * (1.0 + p) / 2.0);
+    if (!(tl >= LO && tl <= HI)) { *flag = 1; tl = tl > HI ? HI : LO; }
+    if (!(tr >= LO && tr <= HI)) { *flag = 1; tr = tr > HI ? HI : LO; }
+    typedef T pair_t __attribute__((ext_vector_type(2)));
+    pair_t o = {(T)(long long)tl, (T)(long long)tr};
+    reinterpret_cast<pair_t*>(out)[i] = o;
+}
+
 // out[i] = in[i] / divisor in float64              (Sample.get_frames_as_floats; waveform modulators)
 template <typename T>
 __global__ __launch_bounds__(256) void k_to_f64(const T* __restrict__ in, double* __restrict__ out, size_t n, double divisor) {
@@ -469,6 +488,36 @@ int sh_pcm_modulate(const sh_buf* in, size_t nbytes, int width, const sh_buf* mo
                            (const double*)mod_f64->ptr, nmod, S.flag);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_modulate");
+    });
+    if (rc) return rc;
+    SH_HIP(hipMemcpyAsync(S.flag_host, S.flag, sizeof(int), hipMemcpyDeviceToHost, S.stream));
+    SH_HIP(hipStreamSynchronize(S.stream));
+    if (S.flag_host[0]) {
+        SH_HIP(hipMemsetAsync(S.flag, 0, sizeof(int), S.stream));
+        return sh::set_error(SH_ERR_OVERFLOW, "signed integer out of range for sample width %d", width);
+    }
+    return SH_OK;
+}
+
+int sh_pcm_pan_lfo(const sh_buf* in, size_t nframes, int width, int nchannels, const sh_buf* pan_f64, sh_buf* out) {
+    SH_REQUIRE_INIT();
+    if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_pcm_pan_lfo: width %d not in {1,2,4}", width);
+    if (nchannels != 1 && nchannels != 2) return sh::set_error(SH_ERR_INVALID, "sh_pcm_pan_lfo: %d channels (1 or 2)", nchannels);
+    int rc = check_io(in, 0, nframes * width * nchannels, out, 0, nframes * width * 2, "sh_pcm_pan_lfo");
+    if (rc) return rc;
+    if (!nframes) return SH_OK;
+    if (!pan_f64 || pan_f64->bytes / 8 < nframes) return sh::set_error(SH_ERR_INVALID, "sh_pcm_pan_lfo: fewer pan values than frames");
+    sh::State& S = sh::state();
+    rc = dispatch_width(width, [&](auto tag) {
+        typedef decltype(tag) T;
+        if (nchannels == 1)
+            hipLaunchKernelGGL((k_pan_lfo<T, 1>), dim3(sh::div_up(nframes, 256)), dim3(256), 0, S.stream, (const T*)in->ptr, (T*)out->ptr, nframes,
+                               (const double*)pan_f64->ptr, S.flag);
+        else
+            hipLaunchKernelGGL((k_pan_lfo<T, 2>), dim3(sh::div_up(nframes, 256)), dim3(256), 0, S.stream, (const T*)in->ptr, (T*)out->ptr, nframes,
+                               (const double*)pan_f64->ptr, S.flag);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_pan_lfo");
     });
     if (rc) return rc;
     SH_HIP(hipMemcpyAsync(S.flag_host, S.flag, sizeof(int), hipMemcpyDeviceToHost, S.stream));

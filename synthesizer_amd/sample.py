@@ -618,13 +618,36 @@ class Sample:
         return self
 
     def pan(self, panning: float = 0.0, lfo=None) -> "Sample":
-        """Linear stereo panning, -1.0 (left) .. 1.0 (right); the sample becomes stereo."""
-        if lfo is not None:
-            raise NotImplementedError("pan with an lfo is outside the GPU path")
-        assert -1.0 <= panning <= 1.0
-        left_volume = (1.0 - panning) / 2.0
-        right_volume = (1.0 + panning) / 2.0
-        return self.mono().stereo(left_volume, right_volume)
+        """Linear stereo panning, -1.0 (left) .. 1.0 (right); the sample becomes stereo.  With an ``lfo`` (an
+        oscillator, or any iterable of floats: one value per frame) the position follows it instead: the left side of
+        frame i becomes int(l * (1 - p) / 2), the right side int(r * (1 + p) / 2)."""
+        if lfo is None:
+            assert -1.0 <= panning <= 1.0
+            left_volume = (1.0 - panning) / 2.0
+            right_volume = (1.0 + panning) / 2.0
+            return self.stereo(left_volume, right_volume)     # a stereo source keeps its channels apart, like the lfo form
+        self._check_writable()
+        self._check_gpu_width("pan")
+        if self.__nchannels not in (1, 2):
+            raise ValueError("pan needs a mono or stereo sample")
+        n = len(self)
+        from .oscillators import Oscillator
+        if isinstance(lfo, Oscillator):
+            mod = lfo._render_f64_device(0, n) if n else N.DeviceBuffer(0)
+        else:
+            import itertools
+            values = np.fromiter(itertools.islice(iter(lfo), n), dtype=np.float64)
+            if len(values) < n:
+                raise ValueError("pan lfo ran out after %d of %d frames" % (len(values), n))
+            mod = N.DeviceBuffer(n * 8)
+            if n:
+                mod.upload(values)
+        nbytes = n * 2 * self.__samplewidth
+        dst = N.DeviceBuffer(nbytes)
+        N.check(N.lib().sh_pcm_pan_lfo(self._device().handle, n, self.__samplewidth, self.__nchannels, mod.handle, dst.handle))
+        self.__nchannels = 2
+        self._set_device(dst, nbytes)
+        return self
 
     def __lin2lin(self, new_width: int) -> None:
         n = self.__nbytes // self.__samplewidth

@@ -294,3 +294,38 @@ def test_level_meter_tracks_like_upstream(gpu):
     with pytest.raises(ValueError):
         from synthesizer_amd.sample import Sample
         Sample.from_raw_frames(bytes(12), 2, rate, 3).level_db_peak
+
+
+@pytest.mark.parametrize("width", [1, 2, 4])
+@pytest.mark.parametrize("nch", [1, 2])
+def test_pan_with_lfo(gpu, width, nch):
+    """Sample.pan(lfo=...): per-frame position from an iterable or an oscillator; both channels of a stereo source are
+    kept apart.  Bit-exact against the oracle's per-sample Python loop; plain pan() on the same sources as well."""
+    import itertools
+    from oracle import synth_oracle as O
+    from synthesizer_amd import oscillators as G
+    rng = np.random.default_rng(width + 10 * nch)
+    n = 3001
+    x = _rand(rng, width, n * nch)
+    for p in (-1.0, -0.3, 0.0, 0.5, 1.0):
+        s, r = _pair(x, width, 8000, nch)
+        _same(s.pan(p), r.pan(p))
+    pos = rng.uniform(-1, 1, n)
+    pos[:4] = (-1.0, 1.0, 0.0, 0.999999)
+    s, r = _pair(x, width, 8000, nch)
+    _same(s.pan(lfo=iter(pos.tolist())), r.pan(lfo=iter(pos.tolist())))
+    assert s.nchannels == 2 and len(s) == n
+    s, r = _pair(x, width, 8000, nch)
+    lfo = G.Sine(3.0, amplitude=0.8, samplerate=8000)
+    ref_lfo = O.Sine(3.0, amplitude=0.8, samplerate=8000)
+    _same(s.pan(lfo=lfo), r.pan(lfo=itertools.chain.from_iterable(ref_lfo.blocks())))
+    # positions outside [-1, 1] can leave the sample range: Python raises, so does the device path
+    s, r = _pair(np.full(8 * nch, np.iinfo(DT[width]).max, DT[width]), width, 8000, nch)
+    with pytest.raises(OverflowError):
+        r.pan(lfo=iter([-1.5] * 8))
+    with pytest.raises(OverflowError):
+        s.pan(lfo=iter([-1.5] * 8))
+    with pytest.raises(ValueError):
+        _pair(x, width, 8000, nch)[0].pan(lfo=iter([0.0] * 5))     # ran out
+    e, re_ = _pair(np.zeros(0, DT[width]), width, 8000, nch)
+    _same(e.pan(lfo=iter([])), re_.pan(lfo=iter([])))
