@@ -150,6 +150,28 @@ def pcm_rows(N):
     nbytes = (2 * nv + 2) * nsamples
     rows["mix_chain_i16_1024v_10s_stereo"] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
                                               "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    # the same fold through the pointer table (RealTimeMixer / mix_samples: every source read where it lives)
+    bufs = (ctypes.c_void_p * nv)(*[chunks.handle] * nv)
+    offs = (ctypes.c_size_t * nv)(*[v * nsamples for v in range(nv)])
+    lens = (ctypes.c_uint32 * nv)(*[nsamples] * nv)
+    for _ in range(2):
+        N.check(L.sh_mix_chain_gather_i16(bufs, offs, lens, nv, nsamples, mixed.handle, 0))
+    N.sync()
+    N.timer_start()
+    for _ in range(5):
+        N.check(L.sh_mix_chain_gather_i16(bufs, offs, lens, nv, nsamples, mixed.handle, 0))
+    ms = N.timer_stop() / 5
+    rows["mix_chain_gather_i16_1024v_10s_stereo"] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
+                                                     "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    # one real-time turn: 64 sources x 4096-byte chunk (latency-bound: table upload + one small kernel)
+    small = 2048
+    for _ in range(3):
+        N.check(L.sh_mix_chain_gather_i16(bufs, offs, lens, 64, small, mixed.handle, 0))
+    N.sync()
+    N.timer_start()
+    for _ in range(200):
+        N.check(L.sh_mix_chain_gather_i16(bufs, offs, lens, 64, small, mixed.handle, 0))
+    rows["mixer_turn_64src_4KB_chunk"] = {"ms": N.timer_stop() / 200}
     # Sample.from_osc_block: float32 -> int16 with the overflow check (the call returns after reading the flag back)
     nq = 300_000_000
     for _ in range(2):

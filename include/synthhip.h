@@ -226,6 +226,14 @@ int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32
 /* integer: the reference mixer's fold, mixed = add(add(c0, c1), c2) ... in voice order,
  * saturating at every step (playback.py mixer loop -> audioop.add).  chunks[v*stride + i] int16. */
 int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint32_t nsamples, sh_buf* out);
+/* The same fold with every chunk read where its sample lives (no staging copy): source v contributes
+ * srcs[v][sample_offsets[v] .. +nsamples_each[v]) and silence after that, up to nsamples; the result goes to
+ * out[out_sample_off ..).  This is one turn of the real-time mixer's chunk loop (upstream synthplayer/playback.py
+ * RealTimeMixer.chunks, [RECALL]: next(chunk) of every active sample, short chunks padded with silence, then
+ * mixed = audioop.add(mixed, chunk, 2) in the order the samples were added).  An in-place source (out among srcs)
+ * is not allowed. */
+int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
+                            uint32_t nsamples, sh_buf* out, size_t out_sample_off);
 
 /* ---- Sample.from_osc_block: int(scale*v), truncation toward zero; SH_ERR_OVERFLOW if out of range */
 int sh_quantize_f32(const sh_buf* in_f32, size_t in_off, size_t n, double scale, int width,

@@ -158,6 +158,25 @@ class RefSample:
         self.samplerate = samplerate
         return self
 
+    def chunked_frame_data(self, chunksize: int, repeat: bool = False):
+        if repeat:
+            bdata = self.frames
+            if len(bdata) < chunksize:
+                bdata = bdata * math.ceil(chunksize / len(bdata))
+            length = len(bdata)
+            bdata += bdata[:chunksize]
+            mdata = memoryview(bdata)
+            i = 0
+            while True:
+                yield mdata[i: i + chunksize]
+                i = (i + chunksize) % length
+        else:
+            mdata = memoryview(self.frames)
+            i = 0
+            while i < len(mdata):
+                yield mdata[i: i + chunksize]
+                i += chunksize
+
     # -- editing --------------------------------------------------------------------------------------
     def add_silence(self, seconds: float, at_start: bool = False) -> "RefSample":
         required_extra = self.frame_idx(seconds)
@@ -322,3 +341,50 @@ class RefLevelMeter:
             self.peak_right, self._hold_right = right, now
         self._time = now
         return left, self.peak_left, right, self.peak_right
+
+
+class RefRealTimeMixer:
+    """Upstream ``playback.py`` ``RealTimeMixer`` ([RECALL]), reduced to its arithmetic: every turn takes the next
+    chunk of every active sample in the order they were added, pads a short one with silence, and folds them with
+    ``audioop.add``; a sample whose chunks ran out is dropped; nothing playing = silence."""
+
+    def __init__(self, chunksize: int, samplewidth: int = 2) -> None:
+        self.chunksize = chunksize
+        self.samplewidth = samplewidth
+        self.active = {}
+        self.counter = 0
+
+    @staticmethod
+    def _with_delay(chunks, chunk_delay, chunksize):
+        for _ in range(chunk_delay):
+            yield None                                    # not started yet: contributes nothing this turn
+        yield from chunks
+
+    def add_sample(self, sample: RefSample, repeat: bool = False, chunk_delay: int = 0) -> int:
+        self.counter += 1
+        self.active[self.counter] = self._with_delay(sample.chunked_frame_data(self.chunksize, repeat), chunk_delay, self.chunksize)
+        return self.counter
+
+    def remove_sample(self, sid: int) -> None:
+        self.active.pop(sid, None)
+
+    def chunks(self):
+        silence = b"\0" * self.chunksize
+        while True:
+            to_mix = []
+            for sid, gen in list(self.active.items()):
+                try:
+                    chunk = next(gen)
+                except StopIteration:
+                    del self.active[sid]
+                    continue
+                if chunk is None or len(chunk) == 0:
+                    continue
+                if len(chunk) < self.chunksize:
+                    chunk = bytes(chunk) + silence[: self.chunksize - len(chunk)]
+                to_mix.append(bytes(chunk))
+            to_mix = to_mix or [silence]
+            mixed = to_mix[0]
+            for other in to_mix[1:]:
+                mixed = audioop.add(mixed, other, self.samplewidth)
+            yield mixed

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "sh_bank_render": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, _P]),
     "sh_mix_bus_f32": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P, _P]),
     "sh_mix_chain_i16": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P]),
+    "sh_mix_chain_gather_i16": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, _P, C.c_size_t]),
     "sh_quantize_f32": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_double, C.c_int, _P, C.c_size_t]),
     "sh_quantize_f64": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_double, C.c_int, _P, C.c_size_t]),
     "sh_quantize_clip_f32": (C.c_int, [_P, C.c_size_t, C.c_double, _P]),

@@ -172,6 +172,90 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __res
     }
 }
 
+// The same fold over chunks that live where their samples live: a table of (pointer, samples available) per
+// source instead of one padded array -- the real-time mixer's loop without the staging copy (every active sample is
+// read in place at its play position; past its end it counts as silence, which the fold skips: x + 0 saturates to x).
+struct ChainSrc {
+    const short* p;
+    uint32_t n;
+    uint32_t pad;
+};
+
+__device__ __forceinline__ short8v chain_load8(const short* p, uint32_t n, uint32_t s0) {
+    short8v x = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (s0 + 8 <= n && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        x = *reinterpret_cast<const short8v*>(p + s0);
+    } else if (s0 < n) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (s0 + j < n) x[j] = p[s0 + j];
+    }
+    return x;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather(const ChainSrc* __restrict__ tab, uint32_t nsrc, uint32_t nsamples,
+                                                                 short* __restrict__ out) {
+    constexpr int S = 8;
+    __shared__ int red[WAVES][3][S][64];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t s0 = (blockIdx.x * 64 + lane) * S;
+    const uint32_t per = (nsrc + WAVES - 1) / WAVES;
+    const uint32_t v0 = wave * per;
+    uint32_t v1 = v0 + per;
+    if (v1 > nsrc) v1 = nsrc;
+    int a[S], L[S], U[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) { a[j] = 0; L[j] = -CH_BIG; U[j] = CH_BIG; }
+#define SH_FOLD(X_)                                                   \
+    _Pragma("unroll") for (int j = 0; j < S; ++j) {                   \
+        const int s_ = (X_)[j];                                        \
+        a[j] += s_;                                                    \
+        L[j] = clampi(L[j] + s_, -32768, 32767);                       \
+        U[j] = clampi(U[j] + s_, -32768, 32767);                       \
+    }
+    if (s0 < nsamples) {
+        uint32_t v = v0;
+        for (; v + 3 < v1; v += 4) {                      // four sources in flight
+            const ChainSrc c0 = tab[v], c1 = tab[v + 1], c2 = tab[v + 2], c3 = tab[v + 3];
+            const short8v x0 = chain_load8(c0.p, c0.n, s0);
+            const short8v x1 = chain_load8(c1.p, c1.n, s0);
+            const short8v x2 = chain_load8(c2.p, c2.n, s0);
+            const short8v x3 = chain_load8(c3.p, c3.n, s0);
+            SH_FOLD(x0) SH_FOLD(x1) SH_FOLD(x2) SH_FOLD(x3)
+        }
+        for (; v < v1; ++v) {
+            const ChainSrc c0 = tab[v];
+            const short8v x0 = chain_load8(c0.p, c0.n, s0);
+            SH_FOLD(x0)
+        }
+    }
+#undef SH_FOLD
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        red[wave][0][j][lane] = a[j];
+        red[wave][1][j][lane] = L[j];
+        red[wave][2][j][lane] = U[j];
+    }
+    __syncthreads();
+    if (wave == 0 && s0 < nsamples) {
+        short8v r;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            int x = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) x = clampi(x + red[w][0][j][lane], red[w][1][j][lane], red[w][2][j][lane]);
+            r[j] = (short)x;
+        }
+        if (s0 + S - 1 < nsamples && ((reinterpret_cast<uintptr_t>(out + s0) & 15) == 0)) {
+            *reinterpret_cast<short8v*>(out + s0) = r;
+        } else {
+            for (uint32_t j = 0; j < S && s0 + j < nsamples; ++j) out[s0 + j] = r[j];
+        }
+    }
+}
+
 // ---- audioop.ratecv / float32 resample ----------------------------------------------------------
 // One thread per output sample (frame m, channel c).  Output m interpolates input frames j-1 and j,
 // j = ceil(m*inrate/outrate), d = j*outrate - m*inrate (rates gcd-reduced): identical index
@@ -661,6 +745,44 @@ int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint
     if (nvoices >= 64) hipLaunchKernelGGL(k_mix_chain_i16<8>, grid, dim3(8 * 64), 0, st, (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
     else hipLaunchKernelGGL(k_mix_chain_i16<2>, grid, dim3(2 * 64), 0, st, (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
     SH_CHECK_LAUNCH("k_mix_chain_i16");
+    return SH_OK;
+}
+
+int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
+                            uint32_t nsamples, sh_buf* out, size_t out_sample_off) {
+    SH_REQUIRE_INIT();
+    if (!out || (nsrc && (!srcs || !sample_offsets || !nsamples_each))) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: NULL argument");
+    if (nsrc > 32768) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: at most 32768 sources");
+    if (out_sample_off > out->bytes / 2 || nsamples > out->bytes / 2 - out_sample_off)
+        return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: output range outside buffer");
+    if (!nsamples) return SH_OK;
+    std::vector<ChainSrc> tab;
+    tab.reserve(nsrc);
+    for (uint32_t v = 0; v < nsrc; ++v) {
+        if (!nsamples_each[v]) continue;                  // silence: the fold's identity
+        if (!srcs[v] || sample_offsets[v] > srcs[v]->bytes / 2 || nsamples_each[v] > srcs[v]->bytes / 2 - sample_offsets[v])
+            return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: source %u range outside its buffer", v);
+        ChainSrc c;
+        c.p = (const short*)srcs[v]->ptr + sample_offsets[v];
+        c.n = nsamples_each[v] < nsamples ? nsamples_each[v] : nsamples;
+        c.pad = 0;
+        tab.push_back(c);
+    }
+    hipStream_t st = sh::state().stream;
+    short* op = (short*)out->ptr + out_sample_off;
+    if (tab.empty()) {
+        SH_HIP(hipMemsetAsync(op, 0, (size_t)nsamples * 2, st));
+        return SH_OK;
+    }
+    int rc = sh::ensure_scratch(tab.size() * sizeof(ChainSrc));
+    if (rc) return rc;
+    // the table goes through the stream (pageable source: staged before the call returns, ordered after earlier kernels)
+    SH_HIP(hipMemcpyAsync(sh::state().scratch, tab.data(), tab.size() * sizeof(ChainSrc), hipMemcpyHostToDevice, st));
+    const uint32_t n = (uint32_t)tab.size();
+    dim3 grid(sh::div_up(nsamples, 512));
+    if (n >= 64) hipLaunchKernelGGL(k_mix_chain_gather<8>, grid, dim3(8 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
+    else hipLaunchKernelGGL(k_mix_chain_gather<2>, grid, dim3(2 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
+    SH_CHECK_LAUNCH("k_mix_chain_gather");
     return SH_OK;
 }
 

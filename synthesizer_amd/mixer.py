@@ -10,12 +10,17 @@ Two shapes of the same operation:
 * ``mix_samples``: the reference's real-time mixer rule over integer PCM chunks (upstream
   playback.py mixer loop: ``mixed = audioop.add(mixed, chunk, width)`` for every active voice, in
   order) -- an order-dependent chain of saturating adds, reproduced bit-exactly.
+* ``RealTimeMixer``: that loop itself, chunk by chunk: samples are added while it runs, may repeat or start a few
+  chunks late, and every ``next(chunks())`` folds the current chunk of every active sample, read in place in HBM
+  (``sh_mix_chain_gather_i16``: a pointer table instead of a staging copy), into one chunk of output.
 
 ``pan`` follows the linear law used throughout: gain_l = (1 - pan) / 2, gain_r = (1 + pan) / 2.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+import ctypes as C
+import threading
+from typing import Callable, Dict, Generator, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -23,7 +28,7 @@ from . import _native as N
 from .oscillators import Oscillator, pack_voices
 from .sample import Sample
 
-__all__ = ["VoiceBank", "mix_samples", "pan_gains"]
+__all__ = ["VoiceBank", "RealTimeMixer", "mix_samples", "pan_gains"]
 
 
 def pan_gains(pan: float) -> Tuple[float, float]:
@@ -147,6 +152,15 @@ def mix_bus(voices: np.ndarray, gains: Sequence[Tuple[float, float]]) -> np.ndar
     return out
 
 
+def _gather_i16(sources: Sequence[Tuple[N.DeviceBuffer, int, int]], nsamples: int, out: N.DeviceBuffer, out_sample_off: int = 0) -> None:
+    """out[out_sample_off : +nsamples] = ordered saturating fold of (buffer, first sample, samples available) sources."""
+    n = len(sources)
+    bufs = (C.c_void_p * max(n, 1))(*[b.handle for b, _o, _n in sources])
+    offs = (C.c_size_t * max(n, 1))(*[o for _b, o, _n in sources])
+    lens = (C.c_uint32 * max(n, 1))(*[min(k, 0xFFFFFFFF) for _b, _o, k in sources])
+    N.check(N.lib().sh_mix_chain_gather_i16(bufs, offs, lens, n, nsamples, out.handle, out_sample_off))
+
+
 def mix_samples(samples: Sequence[Sample], name: str = "mix") -> Sample:
     """The real-time mixer's fold over whole samples: pad every voice with silence to the longest,
     then ``mixed = add(mixed, voice)`` in the given order, saturating at every step."""
@@ -163,16 +177,8 @@ def mix_samples(samples: Sequence[Sample], name: str = "mix") -> Sample:
     L = N.lib()
     if width == 2:
         nsamples = nbytes // 2
-        stride = (nsamples + 7) // 8 * 8                  # 16-byte aligned rows
-        chunks = N.DeviceBuffer(len(samples) * stride * 2)
-        chunks.zero()
-        for i, s in enumerate(samples):
-            n = len(s) * width * s.nchannels
-            if n:
-                N.check(L.sh_buf_copy(chunks.handle, i * stride * 2, s._device().handle, 0, n))
         dst = N.DeviceBuffer(nbytes)
-        N.check(L.sh_mix_chain_i16(chunks.handle, len(samples), stride, nsamples, dst.handle))
-        chunks.free()
+        _gather_i16([(s._device(), 0, len(s) * s.nchannels) for s in samples], nsamples, dst)
         out._set_device(dst, nbytes)
         return out
     # other widths: the literal chain of pairwise saturating adds
@@ -187,3 +193,118 @@ def mix_samples(samples: Sequence[Sample], name: str = "mix") -> Sample:
             N.check(L.sh_pcm_add(acc.handle, 0, s._device().handle, 0, n, width, acc.handle, 0))
     out._set_device(acc, nbytes)
     return out
+
+
+class _MixSource:
+    """One playing sample: its PCM in HBM (a repeating one carries one extra chunk of its own start behind its end,
+    so every chunk is one contiguous range), the play position, and how many silent chunks come first."""
+
+    def __init__(self, name: str, buf: N.DeviceBuffer, nbytes: int, loop_bytes: int, delay: int) -> None:
+        self.name = name
+        self.buf = buf
+        self.nbytes = nbytes            # one-shot: length; repeating: length of the looped data (before the extra chunk)
+        self.loop_bytes = loop_bytes    # 0 = one-shot
+        self.pos = 0
+        self.delay = delay
+
+
+class RealTimeMixer:
+    """Real-time sample mixer: samples play from the moment they are added; every turn of ``chunks()`` yields
+    ``chunksize`` bytes, the saturating sum -- in the order the samples were added -- of the current chunk of every
+    active sample.  A sample that ran out is dropped (``all_played_callback`` fires when the last one goes); with
+    nothing playing the mixer yields silence.  Samples must be in the mixer's format (16-bit by default: the fold
+    kernel is the int16 one).  Mirrors upstream ``synthplayer/playback.py`` ``RealTimeMixer`` ([RECALL], tree not
+    mounted): ``add_sample`` / ``remove_sample`` / ``clear_sources`` / ``chunks``.
+
+    The PCM stays in HBM: ``add_sample`` uploads (or reuses the resident buffer of) the sample once, a chunk turn is
+    one kernel over a pointer table plus ``chunksize`` bytes back to the host.  ``chunks_device()`` yields the device
+    buffer instead, for a consumer that keeps going on the GPU (level metering, resampling)."""
+
+    def __init__(self, chunksize: int, all_played_callback: Optional[Callable[[], None]] = None, samplewidth: int = 2) -> None:
+        if samplewidth != 2:
+            raise NotImplementedError("the mixer folds 16-bit chunks")
+        if chunksize <= 0 or chunksize % 2:
+            raise ValueError("chunksize must be a positive whole number of samples")
+        self.chunksize = chunksize
+        self.all_played_callback = all_played_callback or (lambda: None)
+        self.add_lock = threading.Lock()
+        self.chunks_mixed = 0
+        self.active_samples: Dict[int, _MixSource] = {}
+        self.sample_counter = 0
+        self._out = [N.DeviceBuffer(chunksize), N.DeviceBuffer(chunksize)]      # the consumer may still hold the last one
+
+    def add_sample(self, sample: Sample, repeat: bool = False, chunk_delay: int = 0, sid: Optional[int] = None) -> int:
+        """Start playing a sample; returns its id.  ``repeat`` loops it forever, ``chunk_delay`` holds it back."""
+        if sample.samplewidth != 2:
+            raise ValueError("sample width must be 2")
+        nbytes = len(sample) * sample.samplewidth * sample.nchannels
+        if repeat and nbytes:
+            # upstream: data repeated up to at least one chunk, then one more chunk of its start appended
+            reps = -(-self.chunksize // nbytes) if nbytes < self.chunksize else 1
+            loop = nbytes * reps
+            buf = N.DeviceBuffer(loop + self.chunksize)
+            src = sample._device()
+            for r in range(reps):
+                N.check(N.lib().sh_buf_copy(buf.handle, r * nbytes, src.handle, 0, nbytes))
+            N.check(N.lib().sh_buf_copy(buf.handle, loop, buf.handle, 0, self.chunksize))
+            source = _MixSource(sample.name, buf, loop, loop, chunk_delay)
+        else:
+            source = _MixSource(sample.name, sample._device(), nbytes, 0, chunk_delay)     # Sample never writes a buffer in place
+        with self.add_lock:
+            self.sample_counter += 1
+            sid = sid or self.sample_counter
+            self.active_samples[sid] = source
+            return sid
+
+    def remove_sample(self, sid_or_name: Union[int, str]) -> None:
+        with self.add_lock:
+            if isinstance(sid_or_name, int):
+                self.active_samples.pop(sid_or_name, None)
+            else:
+                for sid in [i for i, src in self.active_samples.items() if src.name == sid_or_name]:
+                    del self.active_samples[sid]
+
+    def clear_sources(self) -> None:
+        with self.add_lock:
+            self.active_samples.clear()
+        self.all_played_callback()
+
+    def _turn(self) -> N.DeviceBuffer:
+        with self.add_lock:
+            active = list(self.active_samples.items())
+        sources = []
+        finished = []
+        for sid, src in active:
+            if src.delay > 0:
+                src.delay -= 1
+                continue
+            if src.loop_bytes:
+                sources.append((src.buf, src.pos // 2, self.chunksize // 2))
+                src.pos = (src.pos + self.chunksize) % src.loop_bytes
+            elif src.pos < src.nbytes:
+                n = min(self.chunksize, src.nbytes - src.pos)
+                sources.append((src.buf, src.pos // 2, n // 2))
+                src.pos += self.chunksize
+            else:
+                finished.append(sid)
+        if finished:
+            with self.add_lock:
+                for sid in finished:
+                    self.active_samples.pop(sid, None)
+                empty = not self.active_samples
+            if empty:
+                self.all_played_callback()
+        out = self._out[self.chunks_mixed & 1]
+        _gather_i16(sources, self.chunksize // 2, out)
+        self.chunks_mixed += 1
+        return out
+
+    def chunks_device(self) -> Generator[N.DeviceBuffer, None, None]:
+        """Endless stream of mixed chunks left in HBM (valid until the turn after the next)."""
+        while True:
+            yield self._turn()
+
+    def chunks(self) -> Generator[memoryview, None, None]:
+        """Endless stream of mixed chunks, ``chunksize`` bytes each."""
+        while True:
+            yield memoryview(self._turn().download_bytes(self.chunksize))

@@ -218,6 +218,28 @@ class Sample:
         cpy.filename = self.filename
         return cpy
 
+    def chunked_frame_data(self, chunksize: int, repeat: bool = False, stopcondition=lambda: False):
+        """Generator over the frame bytes in chunks of ``chunksize`` bytes (the last one of a one-shot sample may be
+        shorter); with ``repeat`` the data wraps around forever and every chunk is full."""
+        frames = self._host()
+        if repeat:
+            if not frames:
+                return
+            if len(frames) < chunksize:
+                frames = frames * math.ceil(chunksize / len(frames))
+            length = len(frames)
+            mdata = memoryview(frames + frames[:chunksize])
+            i = 0
+            while not stopcondition():
+                yield mdata[i: i + chunksize]
+                i = (i + chunksize) % length
+        else:
+            mdata = memoryview(frames)
+            i = 0
+            while i < len(mdata) and not stopcondition():
+                yield mdata[i: i + chunksize]
+                i += chunksize
+
     def lock(self) -> "Sample":
         self.__locked = True
         return self

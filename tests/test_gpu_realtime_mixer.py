@@ -1,0 +1,108 @@
+"""GPU parity, SURVEY.md section 8(a) row a11 -- the real-time mixer's chunk loop: RealTimeMixer.chunks() against the
+oracle's restatement over ``audioop.add`` (oracle/sample_oracle.py RefRealTimeMixer), byte for byte, chunk for chunk,
+with samples of ragged lengths, repeating samples, delayed starts, samples added and removed while it runs, and
+levels that saturate (so the order of the fold matters)."""
+import numpy as np
+import pytest
+
+from oracle.sample_oracle import RefRealTimeMixer, RefSample
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(x, rate=8000, nch=1, name=""):
+    from synthesizer_amd.sample import Sample
+    s = Sample.from_raw_frames(x.tobytes(), 2, rate, nch)
+    s.name = name
+    return s, RefSample(x.tobytes(), 2, rate, nch)
+
+
+def _rand(rng, n, scale=1.0):
+    return (rng.integers(-32768, 32768, n) * scale).astype(np.int16)
+
+
+@pytest.mark.parametrize("chunksize", [512, 4096, 1000])
+def test_chunk_stream_matches_audioop_fold(gpu, chunksize):
+    from synthesizer_amd.mixer import RealTimeMixer
+    rng = np.random.default_rng(chunksize)
+    mixer, ref = RealTimeMixer(chunksize), RefRealTimeMixer(chunksize)
+    played = []
+    mixer.all_played_callback = lambda: played.append(mixer.chunks_mixed)
+    specs = [(3000, 1.0, False, 0), (9001, 0.9, False, 2), (257, 1.0, True, 0), (20000, 0.7, False, 1), (5, 1.0, True, 3),
+             (chunksize // 2, 1.0, False, 0), (chunksize // 2 * 3, 1.0, True, 0), (0, 1.0, False, 0)]
+    for n, scale, repeat, delay in specs:                       # n int16 samples each, loud: the sum saturates
+        s, r = _pair(_rand(rng, n, scale))
+        assert mixer.add_sample(s, repeat=repeat, chunk_delay=delay) == ref.add_sample(r, repeat=repeat, chunk_delay=delay)
+    got, want = mixer.chunks(), ref.chunks()
+    for turn in range(12):
+        a, b = bytes(next(got)), next(want)
+        assert len(a) == chunksize and a == b, "turn %d" % turn
+        if turn == 4:                                           # a late joiner and a removal while running
+            s, r = _pair(_rand(rng, 7000))
+            sid = mixer.add_sample(s)
+            assert sid == ref.add_sample(r)
+            mixer.remove_sample(3)
+            ref.remove_sample(3)
+    assert mixer.chunks_mixed == 12
+    # only the repeating samples are left; drop them: silence from then on, and the callback fires
+    for sid in list(mixer.active_samples):
+        mixer.remove_sample(sid)
+        ref.remove_sample(sid)
+    assert bytes(next(got)) == next(want) == bytes(chunksize)
+    mixer.clear_sources()
+    assert played
+
+
+def test_many_sources_and_device_chunks(gpu):
+    """200 quiet sources (the 8-wave fold) + the device-resident stream feeding the level meter."""
+    from synthesizer_amd.mixer import RealTimeMixer
+    from synthesizer_amd.sample import LevelMeter, Sample
+    from oracle.sample_oracle import RefLevelMeter
+    rng = np.random.default_rng(77)
+    chunksize = 8192
+    mixer, ref = RealTimeMixer(chunksize), RefRealTimeMixer(chunksize)
+    for k in range(200):
+        s, r = _pair(_rand(rng, int(rng.integers(1, 30000)), 0.02 if k % 10 else 1.0))
+        mixer.add_sample(s, repeat=k % 7 == 0, chunk_delay=k % 3)
+        ref.add_sample(r, repeat=k % 7 == 0, chunk_delay=k % 3)
+    meter, ref_meter = LevelMeter(), RefLevelMeter()
+    want = ref.chunks()
+    for turn, dev in zip(range(10), mixer.chunks_device()):
+        chunk = Sample(samplerate=8000, nchannels=2, samplewidth=2)
+        chunk._set_device(dev, chunksize)
+        b = next(want)
+        assert meter.update(chunk) == ref_meter.update(RefSample(b, 2, 8000, 2))
+        assert dev.download_bytes(chunksize) == b, "turn %d" % turn
+
+
+def test_mix_samples_reads_sources_in_place(gpu):
+    """mix_samples over ragged, device-resident samples (no staging copy) equals the chain of audioop.add."""
+    import audioop
+    from synthesizer_amd.mixer import mix_samples
+    rng = np.random.default_rng(3)
+    xs = [_rand(rng, n) for n in (10001 * 2, 8 * 2, 4097 * 2, 1 * 2, 10001 * 2)]
+    samples = [_pair(x, nch=2)[0].to_device() for x in xs]
+    longest = max(len(x) for x in xs) * 2
+    mixed = bytes(longest)
+    for x in xs:
+        mixed = audioop.add(mixed, x.tobytes() + bytes(longest - 2 * len(x)), 2)
+    out = mix_samples(samples)
+    assert bytes(out.view_frame_data()) == mixed
+    # a source that does not start on a 16-byte boundary: a clipped sample (view into its parent buffer, if it is one)
+    s, r = _pair(xs[0], nch=2)
+    s.to_device().clip(0.000125, 1.0)
+    r.clip(0.000125, 1.0)
+    out = mix_samples([s, samples[2]])
+    want = audioop.add(r.frames + bytes(max(0, len(xs[2]) * 2 - len(r.frames))), xs[2].tobytes() + bytes(max(0, len(r.frames) - len(xs[2]) * 2)), 2)
+    assert bytes(out.view_frame_data()) == want
+
+
+def test_mixer_argument_checks(gpu):
+    from synthesizer_amd.mixer import RealTimeMixer
+    from synthesizer_amd.sample import Sample
+    with pytest.raises(ValueError):
+        RealTimeMixer(0)
+    with pytest.raises(NotImplementedError):
+        RealTimeMixer(512, samplewidth=4)
+    with pytest.raises(ValueError):
+        RealTimeMixer(512).add_sample(Sample.from_raw_frames(bytes(16), 4, 8000, 1))
