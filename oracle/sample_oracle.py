@@ -270,6 +270,17 @@ class RefSample:
         self.join(D).join(S).join(R)
         return self
 
+    def stereo_mix(self, other: "RefSample", other_channel: str, other_mix_factor: float = 1.0, mix_at: float = 0.0,
+                   other_seconds: Optional[float] = None) -> "RefSample":
+        w = self.samplewidth
+        if self.nchannels == 1:
+            self.frames = audioop.tostereo(self.frames, w, *((0, 1) if other_channel == "L" else (1, 0)))
+            self.nchannels = 2
+        other = other.copy()
+        other.frames = audioop.tostereo(other.frames, w, *((other_mix_factor, 0) if other_channel == "L" else (0, other_mix_factor)))
+        other.nchannels = 2
+        return self.mix_at(mix_at, other, other_seconds)
+
     def pan(self, panning: float = 0.0, lfo: Optional[Iterable[float]] = None) -> "RefSample":
         if lfo is None:
             lf, rf = (1 - panning) / 2, (1 + panning) / 2

@@ -639,6 +639,27 @@ class Sample:
         self.__nchannels = 2
         return self
 
+    def stereo_mix(self, other: "Sample", other_channel: str, other_mix_factor: float = 1.0, mix_at: float = 0.0,
+                   other_seconds: Optional[float] = None) -> "Sample":
+        """Mix a mono sample into the left ("L") or right ("R") channel of this one, scaled by ``other_mix_factor``,
+        starting at ``mix_at`` seconds.  A mono self first becomes the opposite channel of a stereo sample."""
+        self._check_writable()
+        assert other.nchannels == 1
+        assert other.samplerate == self.__samplerate
+        assert other.samplewidth == self.__samplewidth
+        assert other_channel in ("L", "R")
+        if self.__nchannels == 1:
+            if other_channel == "L":
+                self.stereo(left_factor=0, right_factor=1)
+            else:
+                self.stereo(left_factor=1, right_factor=0)
+        other = other.copy()
+        if other_channel == "L":
+            other.stereo(left_factor=other_mix_factor, right_factor=0)
+        else:
+            other.stereo(left_factor=0, right_factor=other_mix_factor)
+        return self.mix_at(mix_at, other, other_seconds)
+
     def pan(self, panning: float = 0.0, lfo=None) -> "Sample":
         """Linear stereo panning, -1.0 (left) .. 1.0 (right); the sample becomes stereo.  With an ``lfo`` (an
         oscillator, or any iterable of floats: one value per frame) the position follows it instead: the left side of

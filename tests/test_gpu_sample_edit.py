@@ -329,3 +329,18 @@ def test_pan_with_lfo(gpu, width, nch):
         _pair(x, width, 8000, nch)[0].pan(lfo=iter([0.0] * 5))     # ran out
     e, re_ = _pair(np.zeros(0, DT[width]), width, 8000, nch)
     _same(e.pan(lfo=iter([])), re_.pan(lfo=iter([])))
+
+
+@pytest.mark.parametrize("width", [1, 2, 4])
+def test_stereo_mix(gpu, width):
+    """Sample.stereo_mix: a mono sample into the left or right channel of a mono or stereo one, scaled, at an offset."""
+    rng = np.random.default_rng(width)
+    base_m, base_s, other = _rand(rng, width, 4000), _rand(rng, width, 2 * 4000), _rand(rng, width, 2500)
+    for base, nch in ((base_m, 1), (base_s, 2)):
+        for channel, factor, at, secs in (("L", 1.0, 0.0, None), ("R", 0.5, 0.1, None), ("L", 2.0, 0.4, 0.2), ("R", -1.0, 0.0, 0.05)):
+            s, r = _pair(base, width, 8000, nch)
+            o, ro = _pair(other, width, 8000, 1)
+            _same(s.stereo_mix(o, channel, factor, at, secs), r.stereo_mix(ro, channel, factor, at, secs))
+            _same(o, ro)                                             # the mixed-in sample is left alone
+    with pytest.raises(AssertionError):
+        _pair(base_m, width, 8000, 1)[0].stereo_mix(_pair(base_s, width, 8000, 2)[0], "L")
