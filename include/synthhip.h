@@ -24,9 +24,11 @@
  *     the ABI; sh_last_error() returns a thread-local message for the last failure.
  *   - the caller owns all host memory; the library owns device memory behind sh_buf /
  *     sh_bank handles.  No callbacks.  Plain pointers and sizes only.
- *   - one HIP stream per process (created by sh_init); calls are not thread-safe
- *     against each other.  Kernel launches are asynchronous; functions that copy to
- *     host memory, and sh_sync(), synchronise.
+ *   - one HIP stream per process (created by sh_init).  Calls may come from any thread:
+ *     each entry point runs under one process-wide lock (the real-time mixer is fed from
+ *     one thread and drained from another), so calls serialise -- in the order the lock is
+ *     won, which is also their order on the stream.  Kernel launches are asynchronous;
+ *     functions that copy to host memory, and sh_sync(), synchronise (holding the lock).
  *   - "frame" = one sample period (all channels); PCM is interleaved, little endian.
  */
 #ifndef SYNTHHIP_H

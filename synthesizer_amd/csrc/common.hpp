@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
 #include <string>
 #include "../../include/synthhip.h"
 
@@ -46,6 +47,11 @@ struct State {
 };
 
 State& state();
+// Every extern "C" entry point holds this for its whole body: one stream, one scratch buffer, one pool and one pending
+// fold are shared by all callers, and the real-time mixer is driven from two threads (one adds samples, one pulls
+// chunks).  Recursive: entry points call each other.
+std::recursive_mutex& api_mutex();
+#define SH_API_LOCK() std::lock_guard<std::recursive_mutex> sh_api_lock__(sh::api_mutex())
 int  set_error(int code, const char* fmt, ...);
 int  hip_error(hipError_t e, const char* what);
 int  ensure_scratch(size_t bytes);
@@ -56,14 +62,17 @@ int  flush_pending();                  // fold a pending bank-render combine now
 int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out);   // float64 bus -> float32 (osc.hip)
 
 #define SH_REQUIRE_INIT_KEEP_PENDING()                                                 \
+    SH_API_LOCK();                                                                     \
     do {                                                                               \
         if (!sh::state().initialized)                                                  \
             return sh::set_error(SH_ERR_NOTINIT, "sh_init() has not been called");     \
     } while (0)
 
 #define SH_REQUIRE_INIT()                                                              \
+    SH_API_LOCK();                                                                     \
     do {                                                                               \
-        SH_REQUIRE_INIT_KEEP_PENDING();                                                \
+        if (!sh::state().initialized)                                                  \
+            return sh::set_error(SH_ERR_NOTINIT, "sh_init() has not been called");     \
         if (sh::state().pending.active) {                                              \
             int rc_pending__ = sh::flush_pending();                                    \
             if (rc_pending__) return rc_pending__;                                     \

@@ -106,6 +106,7 @@ int sh_dist_init(int rank, int world, const void* id128) {
 }
 
 int sh_dist_shutdown(void) {
+    SH_API_LOCK();
     Rccl& r = R();
     if (r.comm) {
         if (sh::state().initialized) {

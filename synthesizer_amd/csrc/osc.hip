@@ -1569,6 +1569,7 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
 
 int sh_bank_destroy(sh_bank* b) {
     if (!b) return SH_OK;
+    SH_API_LOCK();
     if (sh::state().initialized) {
         (void)hipStreamSynchronize(sh::state().stream);
         if (b->d_voices) (void)hipFree(b->d_voices);

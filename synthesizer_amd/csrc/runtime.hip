@@ -16,6 +16,11 @@ State& state() {
     return s;
 }
 
+std::recursive_mutex& api_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
 int set_error(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -125,6 +130,7 @@ int sh_device_count(void) {
 int sh_is_initialized(void) { return state().initialized ? 1 : 0; }
 
 int sh_init(int device) {
+    SH_API_LOCK();
     sh::State& s = state();
     if (s.initialized) {
         if (s.device == device) return SH_OK;
@@ -158,6 +164,7 @@ int sh_init(int device) {
 }
 
 int sh_shutdown(void) {
+    SH_API_LOCK();
     sh::State& s = state();
     if (!s.initialized) return SH_OK;
     (void)hipStreamSynchronize(s.stream);
@@ -235,6 +242,7 @@ int sh_buf_view(sh_buf* parent, size_t offset, size_t bytes, sh_buf** out) {
 
 int sh_buf_free(sh_buf* b) {
     if (!b) return SH_OK;
+    SH_API_LOCK();
     if (!b->owner) {
         delete b;
         return SH_OK;

@@ -106,3 +106,50 @@ def test_mixer_argument_checks(gpu):
         RealTimeMixer(512, samplewidth=4)
     with pytest.raises(ValueError):
         RealTimeMixer(512).add_sample(Sample.from_raw_frames(bytes(16), 4, 8000, 1))
+
+
+def test_two_threads_share_the_library(gpu):
+    """The way upstream drives the mixer: one thread pulls chunks, another adds samples and does its own Sample work
+    meanwhile.  Every ctypes call drops the GIL, so the native calls really interleave; results on both sides must
+    still be exact.  (Samples of silence are added at arbitrary moments: they cannot change the mix, whenever they
+    land, so the chunk stream stays comparable with the oracle's.)"""
+    import audioop
+    import threading
+    from synthesizer_amd.mixer import RealTimeMixer
+    from synthesizer_amd.sample import Sample
+    rng = np.random.default_rng(2024)
+    chunksize, turns = 2048, 300
+    mixer, ref = RealTimeMixer(chunksize), RefRealTimeMixer(chunksize)
+    for k in range(40):
+        s, r = _pair(_rand(rng, int(rng.integers(1000, 200000)), 0.3))
+        mixer.add_sample(s, repeat=k % 4 == 0)
+        ref.add_sample(r, repeat=k % 4 == 0)
+    want_chunks = [c for _, c in zip(range(turns), ref.chunks())]
+    got_chunks, errors = [], []
+
+    def drain():
+        try:
+            for _, c in zip(range(turns), mixer.chunks()):
+                got_chunks.append(bytes(c))
+        except Exception as e:                                   # pragma: no cover
+            errors.append(e)
+
+    t = threading.Thread(target=drain)
+    x = _rand(rng, 2 * 30000)
+    y = _rand(rng, 2 * 30000)
+    want_add = audioop.add(x.tobytes(), y.tobytes(), 2)
+    want_rate = audioop.ratecv(x.tobytes(), 2, 2, 8000, 11025, None)[0]
+    want_peak = audioop.max(x.tobytes(), 2)
+    t.start()
+    rounds = 0
+    while t.is_alive() or rounds < 5:
+        a = Sample.from_raw_frames(x.tobytes(), 2, 8000, 2)
+        b = Sample.from_raw_frames(y.tobytes(), 2, 8000, 2)
+        assert a.peak() == want_peak
+        assert bytes(a.copy().mix(b).view_frame_data()) == want_add
+        assert bytes(a.resample(11025).view_frame_data()) == want_rate
+        mixer.add_sample(Sample.from_raw_frames(bytes(2 * int(rng.integers(1, 5000))), 2, 8000, 1), repeat=bool(rounds & 1))
+        rounds += 1
+    t.join()
+    assert not errors
+    assert got_chunks == want_chunks
