@@ -99,75 +99,139 @@ constexpr int CH_BIG = 1 << 28;
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-template <int WAVES>
+// Per-lane fold state for 8 samples: the sums in int32, the two clamp bounds as packed int16 pairs.  Once a range
+// holds one voice the bounds are inside the int16 range for good (L = U = "no bound" only before), and
+// bound' = clamp(bound + s, -32768, 32767) is exactly the packed saturating add: one instruction per two samples;
+// the sum takes one dot-product instruction per sample ((s_lo, s_hi) . (1, 0) + a), no unpacking.
+typedef short short2v __attribute__((ext_vector_type(2)));
+struct ChainFold {
+    int a[8];
+    short2v L[4], U[4];
+    bool any;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { L[q] = (short2v){-32768, -32768}; U[q] = (short2v){32767, 32767}; }
+        any = false;
+    }
+    // first voice of the range: the sum starts, the bounds become the int16 range (set by init)
+    __device__ __forceinline__ void first(const short8v x) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = x[j];
+        any = true;
+    }
+    __device__ __forceinline__ void add(const short8v x) {
+#define SH_PAIR(Q_)                                                                              \
+        {                                                                                        \
+            const short2v s2 = __builtin_shufflevector(x, x, 2 * Q_, 2 * Q_ + 1);                \
+            L[Q_] = __builtin_elementwise_add_sat(L[Q_], s2);                                    \
+            U[Q_] = __builtin_elementwise_add_sat(U[Q_], s2);                                    \
+            a[2 * Q_] = __builtin_amdgcn_sdot2(s2, (short2v){1, 0}, a[2 * Q_], false);           \
+            a[2 * Q_ + 1] = __builtin_amdgcn_sdot2(s2, (short2v){0, 1}, a[2 * Q_ + 1], false);   \
+        }
+        SH_PAIR(0) SH_PAIR(1) SH_PAIR(2) SH_PAIR(3)
+#undef SH_PAIR
+    }
+    __device__ __forceinline__ int lo(int j) const { return any ? (int)L[j >> 1][j & 1] : -CH_BIG; }
+    __device__ __forceinline__ int hi(int j) const { return any ? (int)U[j >> 1][j & 1] : CH_BIG; }
+};
+
+// WAVES waves = (WAVES / COLS) voice ranges x COLS adjacent 1 KB columns: a workgroup visits COLS KB of a row at a time.
+template <int WAVES, int COLS>
 __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __restrict__ chunks, uint32_t nvoices,
                                                               size_t stride, uint32_t nsamples,
                                                               short* __restrict__ out) {
     constexpr int S = 8;                                  // samples per lane: one 16-byte load per voice row
+    constexpr int VG = WAVES / COLS;
     __shared__ int red[WAVES][3][S][64];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t s0 = (blockIdx.x * 64 + lane) * S;
-    const uint32_t per = (nvoices + WAVES - 1) / WAVES;
-    const uint32_t v0 = wave * per;
+    const uint32_t col = wave % COLS, vg = wave / COLS;
+    const uint32_t s0 = ((blockIdx.x * COLS + col) * 64 + lane) * S;
+    const uint32_t per = (nvoices + VG - 1) / VG;
+    const uint32_t v0 = vg * per;
     uint32_t v1 = v0 + per;
     if (v1 > nvoices) v1 = nvoices;
-    int a[S], L[S], U[S];
-#pragma unroll
-    for (int j = 0; j < S; ++j) { a[j] = 0; L[j] = -CH_BIG; U[j] = CH_BIG; }
+    ChainFold f;
+    f.init();
     const bool vec = (s0 + S - 1 < nsamples) && ((stride & (S - 1)) == 0);
-#define SH_FOLD(X_)                                                   \
-    _Pragma("unroll") for (int j = 0; j < S; ++j) {                   \
-        const int s_ = (X_)[j];                                        \
-        a[j] += s_;                                                    \
-        L[j] = clampi(L[j] + s_, -32768, 32767);                       \
-        U[j] = clampi(U[j] + s_, -32768, 32767);                       \
-    }
-    if (s0 < nsamples) {
+    if (s0 < nsamples && v0 < v1) {
         if (vec) {
             uint32_t v = v0;
+            f.first(*reinterpret_cast<const short8v*>(chunks + (size_t)v * stride + s0));
+            ++v;
             for (; v + 3 < v1; v += 4) {                  // four voice rows in flight
                 const short8v x0 = *reinterpret_cast<const short8v*>(chunks + (size_t)v * stride + s0);
                 const short8v x1 = *reinterpret_cast<const short8v*>(chunks + (size_t)(v + 1) * stride + s0);
                 const short8v x2 = *reinterpret_cast<const short8v*>(chunks + (size_t)(v + 2) * stride + s0);
                 const short8v x3 = *reinterpret_cast<const short8v*>(chunks + (size_t)(v + 3) * stride + s0);
-                SH_FOLD(x0) SH_FOLD(x1) SH_FOLD(x2) SH_FOLD(x3)
+                f.add(x0); f.add(x1); f.add(x2); f.add(x3);
             }
-            for (; v < v1; ++v) {
-                const short8v x0 = *reinterpret_cast<const short8v*>(chunks + (size_t)v * stride + s0);
-                SH_FOLD(x0)
-            }
+            for (; v < v1; ++v) f.add(*reinterpret_cast<const short8v*>(chunks + (size_t)v * stride + s0));
         } else {
             for (uint32_t v = v0; v < v1; ++v) {
                 const short* row = chunks + (size_t)v * stride + s0;
                 short8v x;
 #pragma unroll
                 for (int j = 0; j < S; ++j) x[j] = (s0 + j < nsamples) ? row[j] : (short)0;
-                SH_FOLD(x)
+                if (v == v0) f.first(x); else f.add(x);
             }
         }
     }
-#undef SH_FOLD
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-        red[wave][0][j][lane] = a[j];
-        red[wave][1][j][lane] = L[j];
-        red[wave][2][j][lane] = U[j];
+        red[wave][0][j][lane] = f.a[j];
+        red[wave][1][j][lane] = f.lo(j);
+        red[wave][2][j][lane] = f.hi(j);
     }
     __syncthreads();
-    if (wave == 0 && s0 < nsamples) {
+    if (vg == 0 && s0 < nsamples) {
         short8v r;
 #pragma unroll
         for (int j = 0; j < S; ++j) {
             int x = 0;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) x = clampi(x + red[w][0][j][lane], red[w][1][j][lane], red[w][2][j][lane]);
+            for (int g = 0; g < VG; ++g) {
+                const int w = g * COLS + col;
+                x = clampi(x + red[w][0][j][lane], red[w][1][j][lane], red[w][2][j][lane]);
+            }
             r[j] = (short)x;
         }
         if (s0 + S - 1 < nsamples && ((reinterpret_cast<uintptr_t>(out + s0) & 15) == 0)) {
             *reinterpret_cast<short8v*>(out + s0) = r;
         } else {
             for (uint32_t j = 0; j < S && s0 + j < nsamples; ++j) out[s0 + j] = r[j];
+        }
+    }
+}
+
+// Long buffers: enough columns to fill the chip without splitting the voices, so a lane simply runs the reference's
+// loop -- mixed = add_sat(mixed, row) down all the rows, packed int16 -- and a workgroup walks WAVES KB of every row.
+// No fold state, no LDS; INFLIGHT independent row loads per lane.
+template <int WAVES, int INFLIGHT>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_direct(const short* __restrict__ chunks, uint32_t nvoices, size_t stride,
+                                                                 uint32_t nsamples, short* __restrict__ out) {
+    const uint32_t s0 = (blockIdx.x * (WAVES * 64) + threadIdx.x) * 8;
+    if (s0 >= nsamples) return;
+    const short* col = chunks + s0;
+    if (s0 + 8 <= nsamples) {
+        short8v acc = *reinterpret_cast<const short8v*>(col);
+        uint32_t v = 1;
+        for (; v + INFLIGHT <= nvoices; v += INFLIGHT) {
+            short8v x[INFLIGHT];
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) x[k] = *reinterpret_cast<const short8v*>(col + (size_t)(v + k) * stride);
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) acc = __builtin_elementwise_add_sat(acc, x[k]);
+        }
+        for (; v < nvoices; ++v) acc = __builtin_elementwise_add_sat(acc, *reinterpret_cast<const short8v*>(col + (size_t)v * stride));
+        *reinterpret_cast<short8v*>(out + s0) = acc;
+    } else {
+        for (uint32_t j = 0; s0 + j < nsamples; ++j) {
+            short acc = col[j];
+            for (uint32_t v = 1; v < nvoices; ++v) acc = __builtin_elementwise_add_sat(acc, col[(size_t)v * stride + j]);
+            out[s0 + j] = acc;
         }
     }
 }
@@ -205,38 +269,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather(const ChainSrc*
     const uint32_t v0 = wave * per;
     uint32_t v1 = v0 + per;
     if (v1 > nsrc) v1 = nsrc;
-    int a[S], L[S], U[S];
-#pragma unroll
-    for (int j = 0; j < S; ++j) { a[j] = 0; L[j] = -CH_BIG; U[j] = CH_BIG; }
-#define SH_FOLD(X_)                                                   \
-    _Pragma("unroll") for (int j = 0; j < S; ++j) {                   \
-        const int s_ = (X_)[j];                                        \
-        a[j] += s_;                                                    \
-        L[j] = clampi(L[j] + s_, -32768, 32767);                       \
-        U[j] = clampi(U[j] + s_, -32768, 32767);                       \
-    }
-    if (s0 < nsamples) {
+    ChainFold f;
+    f.init();
+    if (s0 < nsamples && v0 < v1) {
         uint32_t v = v0;
+        {
+            const ChainSrc c0 = tab[v];
+            f.first(chain_load8(c0.p, c0.n, s0));         // a source past its end contributes zeros: still a voice of the fold
+            ++v;
+        }
         for (; v + 3 < v1; v += 4) {                      // four sources in flight
             const ChainSrc c0 = tab[v], c1 = tab[v + 1], c2 = tab[v + 2], c3 = tab[v + 3];
             const short8v x0 = chain_load8(c0.p, c0.n, s0);
             const short8v x1 = chain_load8(c1.p, c1.n, s0);
             const short8v x2 = chain_load8(c2.p, c2.n, s0);
             const short8v x3 = chain_load8(c3.p, c3.n, s0);
-            SH_FOLD(x0) SH_FOLD(x1) SH_FOLD(x2) SH_FOLD(x3)
+            f.add(x0); f.add(x1); f.add(x2); f.add(x3);
         }
         for (; v < v1; ++v) {
             const ChainSrc c0 = tab[v];
-            const short8v x0 = chain_load8(c0.p, c0.n, s0);
-            SH_FOLD(x0)
+            f.add(chain_load8(c0.p, c0.n, s0));
         }
     }
-#undef SH_FOLD
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-        red[wave][0][j][lane] = a[j];
-        red[wave][1][j][lane] = L[j];
-        red[wave][2][j][lane] = U[j];
+        red[wave][0][j][lane] = f.a[j];
+        red[wave][1][j][lane] = f.lo(j);
+        red[wave][2][j][lane] = f.hi(j);
     }
     __syncthreads();
     if (wave == 0 && s0 < nsamples) {
@@ -253,6 +312,55 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather(const ChainSrc*
         } else {
             for (uint32_t j = 0; j < S && s0 + j < nsamples; ++j) out[s0 + j] = r[j];
         }
+    }
+}
+
+// the direct loop over the pointer table (long samples: mix_samples of whole tracks)
+template <int WAVES, int INFLIGHT>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather_direct(const ChainSrc* __restrict__ tab, uint32_t nsrc, uint32_t nsamples,
+                                                                        short* __restrict__ out) {
+    const uint32_t s0 = (blockIdx.x * (WAVES * 64) + threadIdx.x) * 8;
+    const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(s0 - (threadIdx.x & 63) * 8);
+    if (s0 >= nsamples) return;
+    short8v acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t v = 0;
+    if (nsrc >= INFLIGHT) {
+        ChainSrc c[INFLIGHT], nx[INFLIGHT];               // table entries one batch ahead: their scalar loads overlap the row loads
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) c[k] = tab[k];
+        for (; v + INFLIGHT <= nsrc; v += INFLIGHT) {
+            const bool more = v + 2 * INFLIGHT <= nsrc;
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < INFLIGHT; ++k) nx[k] = tab[v + INFLIGHT + k];
+            }
+            short8v x[INFLIGHT];
+            bool whole = true;                            // wave-uniform: every source of the batch covers this wave's 1 KB, aligned
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) whole = whole && wave_s0 + 512 <= c[k].n && (reinterpret_cast<uintptr_t>(c[k].p) & 15) == 0;
+            if (whole) {
+#pragma unroll
+                for (int k = 0; k < INFLIGHT; ++k) x[k] = *reinterpret_cast<const short8v*>(c[k].p + s0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < INFLIGHT; ++k) x[k] = chain_load8(c[k].p, c[k].n, s0);
+            }
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) acc = __builtin_elementwise_add_sat(acc, x[k]);
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < INFLIGHT; ++k) c[k] = nx[k];
+            }
+        }
+    }
+    for (; v < nsrc; ++v) {
+        const ChainSrc c = tab[v];
+        acc = __builtin_elementwise_add_sat(acc, chain_load8(c.p, c.n, s0));
+    }
+    if (s0 + 8 <= nsamples && ((reinterpret_cast<uintptr_t>(out + s0) & 15) == 0)) {
+        *reinterpret_cast<short8v*>(out + s0) = acc;
+    } else {
+        for (uint32_t j = 0; j < 8 && s0 + j < nsamples; ++j) out[s0 + j] = acc[j];
     }
 }
 
@@ -736,14 +844,26 @@ int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint
     SH_REQUIRE_INIT();
     if (!chunks || !out || nvoices == 0) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: NULL argument");
     if (nvoices > 32768) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: at most 32768 voices");
+    if (nsamples > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: at most 2^32 - 65536 samples per call");
     if (!nsamples) return SH_OK;
     if (stride < nsamples || chunks->bytes / 2 < (size_t)(nvoices - 1) * stride + nsamples)
         return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: chunk buffer too small");
     if (out->bytes / 2 < nsamples) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_i16: output too small");
-    dim3 grid(sh::div_up(nsamples, 512));
     hipStream_t st = sh::state().stream;
-    if (nvoices >= 64) hipLaunchKernelGGL(k_mix_chain_i16<8>, grid, dim3(8 * 64), 0, st, (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
-    else hipLaunchKernelGGL(k_mix_chain_i16<2>, grid, dim3(2 * 64), 0, st, (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
+    // shape by the number of 1 KB columns (= waves when the voices are not split): plenty -> the direct loop
+    // (6.4-6.5 TB/s at 1875 columns, where the split kernel's waves of one workgroup fetch the same column of eight
+    // distant rows: 5.8); fewer -> split the voices over the waves of a workgroup for parallelism
+    const uint32_t columns = (uint32_t)sh::div_up(nsamples, 512);
+    const bool aligned = (stride & 7) == 0 && ((uintptr_t)chunks->ptr & 15) == 0 && ((uintptr_t)out->ptr & 15) == 0;
+#define SH_CHAIN(W_, C_) hipLaunchKernelGGL((k_mix_chain_i16<W_, C_>), dim3(sh::div_up(nsamples, 512 * C_)), dim3(W_ * 64), 0, st, \
+                                            (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr)
+    if (columns >= 1536 && aligned)
+        hipLaunchKernelGGL((k_mix_chain_direct<8, 4>), dim3(sh::div_up(nsamples, 512 * 8)), dim3(8 * 64), 0, st,
+                           (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
+    else if (nvoices < 64) SH_CHAIN(2, 1);
+    else if (columns >= 512) SH_CHAIN(8, 2);
+    else SH_CHAIN(8, 1);
+#undef SH_CHAIN
     SH_CHECK_LAUNCH("k_mix_chain_i16");
     return SH_OK;
 }
@@ -753,6 +873,7 @@ int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offs
     SH_REQUIRE_INIT();
     if (!out || (nsrc && (!srcs || !sample_offsets || !nsamples_each))) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: NULL argument");
     if (nsrc > 32768) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: at most 32768 sources");
+    if (nsamples > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: at most 2^32 - 65536 samples per call");
     if (out_sample_off > out->bytes / 2 || nsamples > out->bytes / 2 - out_sample_off)
         return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: output range outside buffer");
     if (!nsamples) return SH_OK;
@@ -780,7 +901,10 @@ int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offs
     SH_HIP(hipMemcpyAsync(sh::state().scratch, tab.data(), tab.size() * sizeof(ChainSrc), hipMemcpyHostToDevice, st));
     const uint32_t n = (uint32_t)tab.size();
     dim3 grid(sh::div_up(nsamples, 512));
-    if (n >= 64) hipLaunchKernelGGL(k_mix_chain_gather<8>, grid, dim3(8 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
+    if (sh::div_up(nsamples, 512) >= 1536)
+        hipLaunchKernelGGL((k_mix_chain_gather_direct<8, 4>), dim3(sh::div_up(nsamples, 512 * 8)), dim3(8 * 64), 0, st,
+                           (const ChainSrc*)sh::state().scratch, n, nsamples, op);
+    else if (n >= 64) hipLaunchKernelGGL(k_mix_chain_gather<8>, grid, dim3(8 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
     else hipLaunchKernelGGL(k_mix_chain_gather<2>, grid, dim3(2 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
     SH_CHECK_LAUNCH("k_mix_chain_gather");
     return SH_OK;

@@ -153,3 +153,46 @@ def test_two_threads_share_the_library(gpu):
     t.join()
     assert not errors
     assert got_chunks == want_chunks
+
+
+def _audioop_fold(rows, nsamples):
+    import audioop
+    mixed = bytes(2 * nsamples)
+    for x in rows:
+        mixed = audioop.add(mixed, x.tobytes() + bytes(2 * (nsamples - len(x))), 2)
+    return mixed
+
+
+@pytest.mark.parametrize("nsamples", [262144 + 40, 786432 + 8 + 3, 1200000])
+def test_long_buffers_every_kernel_shape(gpu, nsamples):
+    """The fold picks its kernel by buffer length (voices split over waves / two columns per workgroup / the direct
+    loop): the three shapes, through both entry points (padded array, pointer table), loud voices so that the order of
+    the saturating adds shows, ragged ends and a source off the 16-byte grid."""
+    import ctypes as C
+    from synthesizer_amd import _native as N
+    from synthesizer_amd.mixer import mix_samples
+    rng = np.random.default_rng(nsamples)
+    nv = 9
+    rows = [_rand(rng, nsamples, 0.6) for _ in range(nv)]
+    want = _audioop_fold(rows, nsamples)
+    # padded array
+    stride = (nsamples + 7) // 8 * 8
+    chunks = N.DeviceBuffer(nv * stride * 2)
+    chunks.zero()
+    for v, x in enumerate(rows):
+        chunks.upload(x, v * stride * 2)
+    out = N.DeviceBuffer(nsamples * 2)
+    N.check(N.lib().sh_mix_chain_i16(chunks.handle, nv, stride, nsamples, out.handle))
+    assert out.download_bytes(nsamples * 2) == want
+    # pointer table, ragged: sources shorter than the output, one empty, one starting 2 bytes into its buffer
+    lens = [nsamples, nsamples - 5, 1000, 0, nsamples // 2 + 1, nsamples, 8, nsamples - 1, nsamples]
+    ragged = [x[:n] for x, n in zip(rows, lens)]
+    want = _audioop_fold(ragged, nsamples)
+    samples = [_pair(x)[0].to_device() for x in ragged]
+    assert bytes(mix_samples(samples).view_frame_data()) == want
+    shifted = N.DeviceBuffer.from_array(np.concatenate([np.zeros(1, np.int16), ragged[0]]))
+    bufs = (C.c_void_p * 2)(shifted.handle, samples[1]._device().handle)
+    offs = (C.c_size_t * 2)(1, 0)
+    cnt = (C.c_uint32 * 2)(len(ragged[0]), len(ragged[1]))
+    N.check(N.lib().sh_mix_chain_gather_i16(bufs, offs, cnt, 2, nsamples, out.handle, 0))
+    assert out.download_bytes(nsamples * 2) == _audioop_fold(ragged[:2], nsamples)

@@ -1,0 +1,97 @@
+// Microbenchmark: what HBM bandwidth can a plain streaming kernel reach on this MI355X?  The HBM-bound rows of
+// bench.py (mixer bus, saturating mix, resample, elementwise PCM) sit at 66-78 % of the 8 TB/s data-sheet figure; this
+// is the yardstick they should be read against: read-only reduction, copy, and write-only fill over 2 GiB, 16-byte
+// accesses, with 1 / 2 / 4 / 8 independent loads in flight per lane and grid sizes from "one wave per SIMD" upward.
+// build: hipcc --offload-arch=gfx950 -O3 tools/ubench_hbm.hip -o tools/ubench_hbm.bin
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+template <int INFLIGHT>
+__global__ __launch_bounds__(256) void k_read(const u4* __restrict__ in, size_t nvec, unsigned* __restrict__ out) {
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u4 acc = {0, 0, 0, 0};
+    for (; i + (INFLIGHT - 1) * step < nvec; i += INFLIGHT * step) {
+        u4 x[INFLIGHT];
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) x[k] = __builtin_nontemporal_load(in + i + k * step);
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) acc ^= x[k];
+    }
+    for (; i < nvec; i += step) acc ^= in[i];
+    const unsigned r = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+    if (r == 0x12345678u) out[0] = r;                  // practically never: keeps the loads alive
+}
+
+template <int INFLIGHT>
+__global__ __launch_bounds__(256) void k_copy(const u4* __restrict__ in, u4* __restrict__ out, size_t nvec) {
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (INFLIGHT - 1) * step < nvec; i += INFLIGHT * step) {
+        u4 x[INFLIGHT];
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) x[k] = __builtin_nontemporal_load(in + i + k * step);
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) __builtin_nontemporal_store(x[k], out + i + k * step);
+    }
+    for (; i < nvec; i += step) out[i] = in[i];
+}
+
+__global__ __launch_bounds__(256) void k_fill(u4* __restrict__ out, size_t nvec, unsigned v) {
+    const size_t step = (size_t)gridDim.x * 256;
+    const u4 x = {v, v, v, v};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += step) __builtin_nontemporal_store(x, out + i);
+}
+
+// one thread per vector, no loop (the shape of the elementwise PCM kernels)
+__global__ __launch_bounds__(256) void k_copy_flat(const u4* __restrict__ in, u4* __restrict__ out, size_t nvec) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nvec) out[i] = in[i];
+}
+
+template <typename F>
+static double time_ms(F&& launch) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    launch();
+    hipDeviceSynchronize();
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        for (int it = 0; it < 5; ++it) launch();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms / 5 < best) best = ms / 5;
+    }
+    return best;
+}
+
+int main() {
+    const size_t bytes = (size_t)2 << 30, nvec = bytes / 16;
+    u4 *a, *b; unsigned* flag;
+    hipMalloc(&a, bytes); hipMalloc(&b, bytes); hipMalloc(&flag, 4);
+    hipMemset(a, 1, bytes); hipMemset(b, 2, bytes);
+    for (unsigned blocks : {1024u, 2048u, 4096u, 8192u, 16384u}) {
+#define ROW(NAME, MOVED, ...) { double ms = time_ms([&] { __VA_ARGS__; }); \
+        printf("%-26s blocks %6u: %.3f ms  %.2f TB/s  (%.0f%% of 8)\n", NAME, blocks, ms, (MOVED) / ms / 1e9, (MOVED) / ms / 1e9 / 8 * 100); }
+        ROW("read  1 in flight", (double)bytes, hipLaunchKernelGGL(k_read<1>, dim3(blocks), dim3(256), 0, 0, a, nvec, flag))
+        ROW("read  4 in flight", (double)bytes, hipLaunchKernelGGL(k_read<4>, dim3(blocks), dim3(256), 0, 0, a, nvec, flag))
+        ROW("read  8 in flight", (double)bytes, hipLaunchKernelGGL(k_read<8>, dim3(blocks), dim3(256), 0, 0, a, nvec, flag))
+        ROW("copy  1 in flight", 2.0 * bytes, hipLaunchKernelGGL(k_copy<1>, dim3(blocks), dim3(256), 0, 0, a, b, nvec))
+        ROW("copy  4 in flight", 2.0 * bytes, hipLaunchKernelGGL(k_copy<4>, dim3(blocks), dim3(256), 0, 0, a, b, nvec))
+        ROW("fill", (double)bytes, hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, 0, b, nvec, 7u))
+    }
+    {
+        unsigned blocks = (unsigned)(nvec / 256);
+        ROW("copy  one vector per lane", 2.0 * bytes, hipLaunchKernelGGL(k_copy_flat, dim3(blocks), dim3(256), 0, 0, a, b, nvec))
+    }
+    {
+        unsigned blocks = 0;
+        ROW("hipMemcpyAsync D2D", 2.0 * bytes, hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0))
+    }
+    return 0;
+}
