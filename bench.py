@@ -338,9 +338,9 @@ def main() -> int:
         out["two_step"] = {
             "frames_per_launch": F2, "voices": nv,
             "value": nv * F2 / ((gen_ms + mix_ms) / 1e3) / 1e6, "unit": "Msamples/s",
-            "roofline_mix": {"kernel": "k_mix_bus_f32<8>", "bound": "hbm", "achieved": mix_bytes / (mix_ms / 1e3) / 1e9,
+            "roofline_mix": {"kernel": "k_mix_bus_direct<8,4>", "bound": "hbm", "achieved": mix_bytes / (mix_ms / 1e3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mix_bytes / (mix_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": traffic_of("k_mix_bus_f32"), "avg_launch_ms": mix_ms, "bytes_per_frame": 4 * nv + 8,
+                             "traffic": traffic_of("k_mix_bus"), "avg_launch_ms": mix_ms, "bytes_per_frame": 4 * nv + 8,
                              "algorithmic_bytes": mix_bytes},
             "roofline_generate": {"kernel": "k_generate", "bound": "hbm", "achieved": gen_bytes / (gen_ms / 1e3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gen_bytes / (gen_ms / 1e3) / 1e9 / HBM_PEAK_GBS,

@@ -1284,6 +1284,54 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_bus_f32(const float* __restr
     }
 }
 
+// Long buffers (the frame range alone fills the chip): no voice split -- a lane walks all the rows for its 4 frames,
+// a workgroup covers WAVES KB of every row it visits, no LDS.  (Same lesson as the integer fold, DESIGN.md section 4
+// item 15: eight waves fetching one 1 KB column of eight distant rows cost 10 % of the bandwidth.)
+template <int WAVES, int INFLIGHT>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_bus_direct(const float* __restrict__ voices, uint32_t nvoices, size_t stride,
+                                                               uint32_t nframes, const float2* __restrict__ gains,
+                                                               float2* __restrict__ out) {
+    const uint32_t f0 = (blockIdx.x * (WAVES * 64) + threadIdx.x) * 4;
+    if (f0 + 3 >= nframes) {
+        for (uint32_t j = 0; f0 + j < nframes; ++j) {
+            float l = 0.f, r = 0.f;
+            for (uint32_t v = 0; v < nvoices; ++v) {
+                const float x = voices[(size_t)v * stride + f0 + j];
+                const float2 g = gains[v];
+                l = fmaf(g.x, x, l);
+                r = fmaf(g.y, x, r);
+            }
+            out[f0 + j] = make_float2(l, r);
+        }
+        return;
+    }
+    float l0 = 0, l1 = 0, l2 = 0, l3 = 0, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    const float* col = voices + f0;
+    uint32_t v = 0;
+    for (; v + INFLIGHT <= nvoices; v += INFLIGHT) {
+        float4 x[INFLIGHT];
+        float2 gg[INFLIGHT];
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) x[k] = *reinterpret_cast<const float4*>(col + (size_t)(v + k) * stride);
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) gg[k] = gains[v + k];
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) {
+            l0 = fmaf(gg[k].x, x[k].x, l0); l1 = fmaf(gg[k].x, x[k].y, l1); l2 = fmaf(gg[k].x, x[k].z, l2); l3 = fmaf(gg[k].x, x[k].w, l3);
+            r0 = fmaf(gg[k].y, x[k].x, r0); r1 = fmaf(gg[k].y, x[k].y, r1); r2 = fmaf(gg[k].y, x[k].z, r2); r3 = fmaf(gg[k].y, x[k].w, r3);
+        }
+    }
+    for (; v < nvoices; ++v) {
+        const float4 x = *reinterpret_cast<const float4*>(col + (size_t)v * stride);
+        const float2 g = gains[v];
+        l0 = fmaf(g.x, x.x, l0); l1 = fmaf(g.x, x.y, l1); l2 = fmaf(g.x, x.z, l2); l3 = fmaf(g.x, x.w, l3);
+        r0 = fmaf(g.y, x.x, r0); r1 = fmaf(g.y, x.y, r1); r2 = fmaf(g.y, x.z, r2); r3 = fmaf(g.y, x.w, r3);
+    }
+    float2* o = out + f0;
+    reinterpret_cast<float4*>(o)[0] = make_float4(l0, r0, l1, r1);
+    reinterpret_cast<float4*>(o)[1] = make_float4(l2, r2, l3, r3);
+}
+
 __global__ void k_bus_sum(const float2* __restrict__ parts, uint32_t ngroups, size_t group_stride,
                           uint32_t nframes, float2* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1852,6 +1900,12 @@ int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32
     int rc = sh::ensure_scratch(part_bytes);
     if (rc) return rc;
     hipStream_t st = sh::state().stream;
+    if (tiles >= 1536 && (stride & 3) == 0 && ((uintptr_t)voices->ptr & 15) == 0 && ((uintptr_t)bus_f32->ptr & 15) == 0) {
+        hipLaunchKernelGGL((k_mix_bus_direct<8, 4>), dim3(sh::div_up(nframes, 256 * 8)), dim3(8 * 64), 0, st,
+                           (const float*)voices->ptr, nvoices, stride, nframes, (const float2*)gains_lr->ptr, (float2*)bus_f32->ptr);
+        SH_CHECK_LAUNCH("k_mix_bus_direct");
+        return SH_OK;
+    }
     float2* parts = (float2*)sh::state().scratch;
     float2* dst = groups > 1 ? parts : (float2*)bus_f32->ptr;
     hipLaunchKernelGGL(k_mix_bus_f32<W>, dim3(tiles, groups), dim3(W * 64), 0, st,

@@ -91,10 +91,11 @@ def test_bank_properties_at_full_size(gpu):
 
 
 def test_mix_bus_kernel_shapes(gpu):
-    """sh_mix_bus_f32 over materialised voices: ragged sizes, voice-group split, gains."""
+    """sh_mix_bus_f32 over materialised voices: ragged sizes, voice-group split, the direct kernel, gains."""
     from synthesizer_amd.mixer import mix_bus
     rng = np.random.default_rng(5)
-    for nv, nf in ((1, 1), (3, 7), (8, 255), (33, 1000), (64, 4099), (1024, 3000), (257, 1024)):
+    # the last two sizes are long enough (>= 1536 tiles of 256 frames) for the direct, unsplit kernel; one of them ragged
+    for nv, nf in ((1, 1), (3, 7), (8, 255), (33, 1000), (64, 4099), (1024, 3000), (257, 1024), (9, 393216), (5, 500003)):
         v = rng.uniform(-1, 1, (nv, nf)).astype(np.float32)
         g = rng.uniform(0, 1, (nv, 2)).astype(np.float32)
         got = mix_bus(v, g)
