@@ -163,7 +163,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return v;
 }
 
-template <typename T>
+template <typename T, int INFLIGHT>
 __global__ __launch_bounds__(256) void k_absmax_sumsq(const T* __restrict__ in, size_t n, unsigned long long* __restrict__ acc) {
     __shared__ unsigned long long s_sum[4];
     __shared__ unsigned s_max[4];
@@ -187,21 +187,25 @@ __global__ __launch_bounds__(256) void k_absmax_sumsq(const T* __restrict__ in, 
                 mx2 = __builtin_elementwise_max(mx2, au);                                \
                 sq += (unsigned long long)__builtin_amdgcn_udot2(au, au, 0u, false);     \
             }
-        const size_t step = (size_t)gridDim.x * 256;
-        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-        for (; i + 3 * step < nvec; i += 4 * step) {               // four 16-byte loads in flight per lane
-            const vec_t x0 = reinterpret_cast<const vec_t*>(in)[i];
-            const vec_t x1 = reinterpret_cast<const vec_t*>(in)[i + step];
-            const vec_t x2 = reinterpret_cast<const vec_t*>(in)[i + 2 * step];
-            const vec_t x3 = reinterpret_cast<const vec_t*>(in)[i + 3 * step];
-            SH_PAIR(x0, 0, 1) SH_PAIR(x0, 2, 3) SH_PAIR(x0, 4, 5) SH_PAIR(x0, 6, 7)
-            SH_PAIR(x1, 0, 1) SH_PAIR(x1, 2, 3) SH_PAIR(x1, 4, 5) SH_PAIR(x1, 6, 7)
-            SH_PAIR(x2, 0, 1) SH_PAIR(x2, 2, 3) SH_PAIR(x2, 4, 5) SH_PAIR(x2, 6, 7)
-            SH_PAIR(x3, 0, 1) SH_PAIR(x3, 2, 3) SH_PAIR(x3, 4, 5) SH_PAIR(x3, 6, 7)
+        // a workgroup reads INFLIGHT * 4 KB contiguous per turn (the loads in flight are neighbours, not a grid apart:
+        // the whole chip then sweeps one window of memory at a time, which the DRAM pages like)
+        const size_t step = (size_t)gridDim.x * 256 * INFLIGHT;
+        size_t i = (size_t)blockIdx.x * 256 * INFLIGHT + threadIdx.x;
+        for (; i + (INFLIGHT - 1) * 256 < nvec; i += step) {
+            vec_t x[INFLIGHT];
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) x[k] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(in) + i + k * 256);
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) { SH_PAIR(x[k], 0, 1) SH_PAIR(x[k], 2, 3) SH_PAIR(x[k], 4, 5) SH_PAIR(x[k], 6, 7) }
         }
-        for (; i < nvec; i += step) {
-            const vec_t x = reinterpret_cast<const vec_t*>(in)[i];
-            SH_PAIR(x, 0, 1) SH_PAIR(x, 2, 3) SH_PAIR(x, 4, 5) SH_PAIR(x, 6, 7)
+        if (i < nvec) {                                            // the last, partial turn of this workgroup
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) {
+                if (i + k * 256 < nvec) {
+                    const vec_t x = reinterpret_cast<const vec_t*>(in)[i + k * 256];
+                    SH_PAIR(x, 0, 1) SH_PAIR(x, 2, 3) SH_PAIR(x, 4, 5) SH_PAIR(x, 6, 7)
+                }
+            }
         }
 #undef SH_PAIR
         mx = mx2[0] > mx2[1] ? mx2[0] : mx2[1];
@@ -293,16 +297,24 @@ __global__ __launch_bounds__(256) void k_stats_stereo(const T* __restrict__ in, 
                 sql += (unsigned long long)__umul24(au[0], au[0]);                       \
                 sqr += (unsigned long long)__umul24(au[1], au[1]);                       \
             }
-        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-        for (; i + step < nvec; i += 2 * step) {
-            const vec_t x0 = reinterpret_cast<const vec_t*>(in)[i];
-            const vec_t x1 = reinterpret_cast<const vec_t*>(in)[i + step];
-            SH_FRAME(x0, 0, 1) SH_FRAME(x0, 2, 3) SH_FRAME(x0, 4, 5) SH_FRAME(x0, 6, 7)
-            SH_FRAME(x1, 0, 1) SH_FRAME(x1, 2, 3) SH_FRAME(x1, 4, 5) SH_FRAME(x1, 6, 7)
+        constexpr int INFLIGHT = 4;                                 // neighbouring loads, as in k_absmax_sumsq
+        const size_t bstep = step * INFLIGHT;
+        size_t i = (size_t)blockIdx.x * 256 * INFLIGHT + threadIdx.x;
+        for (; i + (INFLIGHT - 1) * 256 < nvec; i += bstep) {
+            vec_t x[INFLIGHT];
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) x[k] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(in) + i + k * 256);
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) { SH_FRAME(x[k], 0, 1) SH_FRAME(x[k], 2, 3) SH_FRAME(x[k], 4, 5) SH_FRAME(x[k], 6, 7) }
         }
-        for (; i < nvec; i += step) {
-            const vec_t x = reinterpret_cast<const vec_t*>(in)[i];
-            SH_FRAME(x, 0, 1) SH_FRAME(x, 2, 3) SH_FRAME(x, 4, 5) SH_FRAME(x, 6, 7)
+        if (i < nvec) {
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) {
+                if (i + k * 256 < nvec) {
+                    const vec_t x = reinterpret_cast<const vec_t*>(in)[i + k * 256];
+                    SH_FRAME(x, 0, 1) SH_FRAME(x, 2, 3) SH_FRAME(x, 4, 5) SH_FRAME(x, 6, 7)
+                }
+            }
         }
 #undef SH_FRAME
         mxl = mx2[0];
@@ -645,7 +657,9 @@ int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, 
     if (sum_squares) *sum_squares = 0.0;
     if (!nbytes) return SH_OK;
     const size_t n = nbytes / width;
-    const unsigned blocks = n / 2048 < 4096 ? (unsigned)(n / 2048 + 1) : 4096u;
+    // 512 workgroups x 4 neighbouring 16-byte loads in flight per lane: 6.0 TB/s on 900 MB; 4096 workgroups with the four
+    // loads a grid apart read the same data at 4.2-4.8
+    const unsigned blocks = n / 8192 < 512 ? (unsigned)(n / 8192 + 1) : 512u;
     int rc = sh::ensure_scratch(16 + (size_t)blocks * 24);
     if (rc) return rc;
     hipStream_t st = sh::state().stream;
@@ -654,7 +668,7 @@ int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, 
     double* part = (double*)(pairs + 2 * (size_t)blocks);
     rc = dispatch_width(width, [&](auto tag) {
         typedef decltype(tag) T;
-        hipLaunchKernelGGL(k_absmax_sumsq<T>, dim3(blocks), dim3(256), 0, st, (const T*)in->ptr, n, pairs);
+        hipLaunchKernelGGL((k_absmax_sumsq<T, 4>), dim3(blocks), dim3(256), 0, st, (const T*)in->ptr, n, pairs);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_absmax_sumsq");
     });
@@ -693,7 +707,7 @@ int sh_pcm_stats_stereo(const sh_buf* in, size_t nframes, int width, uint32_t ma
     if (max_abs) max_abs[0] = max_abs[1] = 0;
     if (sum_squares) sum_squares[0] = sum_squares[1] = 0.0;
     if (!nframes) return SH_OK;
-    const unsigned blocks = nframes / 1024 < 4096 ? (unsigned)(nframes / 1024 + 1) : 4096u;
+    const unsigned blocks = nframes / 4096 < 512 ? (unsigned)(nframes / 4096 + 1) : 512u;
     int rc = sh::ensure_scratch(32 + (size_t)blocks * 32);
     if (rc) return rc;
     hipStream_t st = sh::state().stream;

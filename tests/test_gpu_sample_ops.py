@@ -150,3 +150,25 @@ def test_elementwise_and_editing_golden(gpu):
     assert _bytes(_sample(y, 2, 8000, 2).envelope(0.05, 0.05, 0.5, 0.08)) == g["edit_envelope"].tobytes()
     assert _bytes(_sample(y, 2, 8000, 2).speed(1.26)) == g["edit_speed_1p26"].tobytes()
     assert _bytes(_sample(y, 2, 8000, 2).modulate_amp(_sample(g["edit_mod"], 2, 8000, 1))) == g["edit_modulate"].tobytes()
+
+
+def test_stats_long_ragged_buffers(gpu):
+    """peak / sum of squares over buffers long enough for several turns of the 512-workgroup sweep, lengths that end
+    inside a turn, inside a vector and on an odd sample; mono and per-channel entry points; exact."""
+    import ctypes as C
+    from synthesizer_amd import _native as N
+    rng = np.random.default_rng(11)
+    for n in (512 * 8192 * 2 + 1024 * 8 * 3 + 5, 512 * 8192 + 8, 4_500_001 * 2):
+        x = rng.integers(-32768, 32768, n).astype(np.int16)
+        x[n - 1] = -32768                                          # the maximum sits in the ragged tail
+        buf = N.DeviceBuffer.from_array(x)
+        mx, sq = C.c_uint32(), C.c_double()
+        N.check(N.lib().sh_pcm_stats(buf.handle, n * 2, 2, C.byref(mx), C.byref(sq)))
+        x64 = x.astype(np.int64)
+        assert mx.value == 32768 and int(sq.value) == int((x64 * x64).sum())
+        if n % 2 == 0:
+            mx2, sq2 = (C.c_uint32 * 2)(), (C.c_double * 2)()
+            N.check(N.lib().sh_pcm_stats_stereo(buf.handle, n // 2, 2, mx2, sq2))
+            for c in range(2):
+                ch = x64[c::2]
+                assert mx2[c] == int(np.abs(ch).max()) and int(sq2[c]) == int((ch * ch).sum())
