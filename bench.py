@@ -302,7 +302,7 @@ def main() -> int:
         "realtime_factor": F * K / wall / SR,
         "device": info["name"] or "AMD Instinct MI355X", "arch": info["arch"],
         "roofline": {
-            "kernel": "k_bank_render<4,4,4>", "bound": "hbm",
+            "kernel": "k_bank_render<4,4,4,1>", "bound": "hbm",
             "achieved": fused_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": fused_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("k_bank_render"),
             "traffic_source": traffic_src,
