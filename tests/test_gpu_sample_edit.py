@@ -190,7 +190,7 @@ def test_fuzz_random_chains_of_sample_operations(gpu):
         s = Sample.from_raw_frames(x.tobytes(), width, rate, nch)
         r = Ref(x.tobytes(), width, rate, nch)
         for step in range(8):
-            op = int(rng.integers(0, 13))
+            op = int(rng.integers(0, 17))
             dur = r.duration
             if op == 0:
                 f = float(rng.uniform(-1.2, 1.2)); s.amplify(f); r.amplify(f)
@@ -227,6 +227,19 @@ def test_fuzz_random_chains_of_sample_operations(gpu):
             elif op == 12 and dur > 0.05:
                 a = (dur * 0.1, dur * 0.2, float(rng.uniform(0, 1)), dur * 0.3)
                 s.envelope(*a); r.envelope(*a)
+            elif op == 13:
+                pn = float(rng.uniform(-1, 1)); s.pan(pn); r.pan(pn)
+            elif op == 14 and len(r) > 0:
+                pos = rng.uniform(-1, 1, len(r)).tolist(); s.pan(lfo=iter(pos)); r.pan(lfo=iter(pos))
+            elif op == 15:
+                y = _rand(rng, width, int(rng.integers(1, 3000)), scale=0.3)
+                a = (str(rng.choice(["L", "R"])), float(rng.uniform(0, 1.5)), float(rng.uniform(0, dur)))
+                s.stereo_mix(Sample.from_raw_frames(y.tobytes(), width, r.samplerate, 1), *a)
+                r.stereo_mix(Ref(y.tobytes(), width, r.samplerate, 1), *a)
+            elif op == 16 and r.nchannels <= 2:
+                assert s.level_db_peak == r.level_db_peak and s.level_db_peak_mono == r.level_db_peak_mono
+                if width < 4:
+                    assert s.level_db_rms == r.level_db_rms
             assert (s.samplewidth, s.samplerate, s.nchannels) == (r.samplewidth, r.samplerate, r.nchannels), (case, step, op)
             assert bytes(s.view_frame_data()) == r.frames, (case, step, op, width, nch, len(r))
 
