@@ -213,12 +213,15 @@ int sh_scan_f64(const sh_buf* x, uint32_t n, double carry_in, sh_buf* out, doubl
 int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voices_out, size_t stride);
 /* fused generate-and-mix: bus_f32[i] = (sum_v gl_v x_v[i], sum_v gr_v x_v[i]), float32 x2 interleaved.
  * bus_f64 (optional) receives the float64 partial bus (frames x 2) used for the multi-GPU reduce.
- * Work is enqueued on the library's stream like every other call.  One detail matters to code that reads the bus
- * buffers with its OWN kernels through sh_buf_devptr: with several voice groups the last step of a render (folding the
- * groups' partial buses into the bus) is enqueued by the NEXT call into the library -- the next sh_bank_render of the
- * stream does it inside its kernel, any other call (sh_sync, sh_buf_download, ...) runs it first -- so such code must
- * call sh_sync() (or any other entry point) before touching the buffers.  Everything inside the library sees
- * completed buses. */
+ * Work is enqueued like every other call.  One detail matters to code that reads the bus buffers with its OWN
+ * kernels through sh_buf_devptr: consecutive renders of a bank (same block length, the next block each time) form a
+ * run that is pipelined -- they alternate between two HIP streams so that one launch fills the tail of the other, and
+ * with several voice groups the last step of a render (folding the groups' partial buses into the bus) is done inside
+ * the render kernel two launches later.  Any other call into the library (sh_sync, sh_buf_download, sh_buf_free, ...;
+ * not sh_buf_alloc) ends the run first: it joins the streams and folds what is outstanding -- so such code must call
+ * sh_sync() (or any other entry point) before touching the buffers.  Everything inside the library sees completed
+ * buses.  To keep a run going while consuming its output, render into a ring of bus buffers and read a buffer only
+ * after the run has been ended. */
 int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64);
 
 /* ---- mixer sum bus over materialised voices ------------------------------------------ */

@@ -923,7 +923,7 @@ enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2 };
 template <int WAVES, int FPL, int MINW, int MODE>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                   uint32_t nvoices, uint32_t voices_per_group,
-                                                                  LaunchSet cur, LaunchSet next,
+                                                                  LaunchSet cur, LaunchSet next, uint64_t next_start,
                                                                   uint64_t start, uint32_t nframes,
                                                                   float2* __restrict__ bus32,
                                                                   double2* __restrict__ bus64,
@@ -948,8 +948,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             if (prev_bus64) prev_bus64[raw] = acc;
         }
     }
-    // Sequential streaming is the common call pattern: this launch also resolves the launch records of the
-    // block that is expected next (start + nframes) into the other record set, so that launch needs no prepare
+    // Sequential streaming is the common call pattern: this launch also resolves the launch records of the block
+    // expected two launches on (next_start = start + 2 * nframes: the launch in between runs beside this one on the
+    // other stream and got its records from this one's predecessor) into a free record set, so that launch needs no prepare
     // kernel of its own (a 15 us kernel + a launch boundary per block otherwise).
     // The chunks of 64 voices are spread over the first workgroups (one wavefront each, on different CUs): a single
     // workgroup doing all of it competes with three rendering workgroups for its CU and ends up as the launch's tail.
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         const uint32_t nchunks = (nvoices + 63) / 64, nblocks = gridDim.x * gridDim.y;
         const uint32_t bid = blockIdx.y * gridDim.x + blockIdx.x;
         if (threadIdx.x < 64) {
-            for (uint32_t c = bid; c < nchunks; c += nblocks) prepare_chunk(B, next, c, nvoices, start + nframes, nframes);
+            for (uint32_t c = bid; c < nchunks; c += nblocks) prepare_chunk(B, next, c, nvoices, next_start, nframes);
         }
     }
     __shared__ double red[WAVES][2][64 * FPL];
@@ -1450,22 +1451,23 @@ struct sh_bank {
     sh_segment* d_segs = nullptr;
     double*     d_coefs = nullptr;
     sh_partial* d_partials = nullptr;
-    // launch records, double-buffered: while a render kernel reads one set, its first workgroup fills the
-    // other for the block that is expected next (start + nframes)
-    VoiceLaunch* d_launch_buf[2] = {nullptr, nullptr};
-    VoiceFM*    d_launch_fm_buf[2] = {nullptr, nullptr};
-    FastRec*    d_fast_buf[2] = {nullptr, nullptr};
-    uint32_t*   d_gen_idx_buf[2] = {nullptr, nullptr};
-    uint32_t*   d_counts_buf[2] = {nullptr, nullptr};      // 4 per 64-voice chunk: lean, general, silent, -
+    // launch records, four sets: launch n reads one while its first workgroups resolve the records of the block expected
+    // two launches later (start + 2 * nframes) into another; launch n-1, on the other stream, holds two more
+    static constexpr int NSETS = 4;
+    VoiceLaunch* d_launch_buf[NSETS] = {};
+    VoiceFM*    d_launch_fm_buf[NSETS] = {};
+    FastRec*    d_fast_buf[NSETS] = {};
+    uint32_t*   d_gen_idx_buf[NSETS] = {};
+    uint32_t*   d_counts_buf[NSETS] = {};      // 4 per 64-voice chunk: lean, general, silent, -
     uint32_t*   d_hint = nullptr;
     double2*    d_seg_rot = nullptr;       // (cos, sin)(64*dt) per table piece
     double2*    d_lfo_rot = nullptr;       // (cos, sin)(64*lfo_d) per voice
     VoiceLaunch* d_launch = nullptr;       // the set the next kernel reads
     VoiceFM*    d_launch_fm = nullptr;
-    int         cur = 0;
-    bool        spec_valid = false;
-    uint64_t    spec_start = 0;
-    uint32_t    spec_nframes = 0;
+    int         cur = 0;                   // the set the last launch read
+    int         last_target = -1;          // the set the last render launch is filling (-1: none)
+    struct Spec { bool valid = false; uint64_t start = 0; uint32_t nframes = 0; } spec[NSETS];   // what each set holds (or will)
+    void        void_specs() { for (auto& q : spec) q.valid = false; last_target = -1; }
     uint32_t    lean_candidates = 0;      // voices that can take the lean loop in some launch (static properties)
     uint32_t    lean_fm_candidates = 0;   // ... of them other than polynomial Harmonics (FM Sine, plain waveforms)
     uint32_t    last_groups = 0;          // voice groups of the last sh_bank_render launch (sh_bank_launch_stats)
@@ -1507,12 +1509,21 @@ static int upload_array(T** dst, const T* src, size_t count, hipStream_t st) {
 
 namespace sh {
 int flush_pending() {
-    PendingCombine& pc = state().pending;
-    if (!pc.active) return SH_OK;
-    pc.active = false;
-    hipLaunchKernelGGL(k_bus_combine, dim3(div_up(pc.nframes, 256)), dim3(256), 0, state().stream,
-                       (const double2*)pc.parts, pc.groups, pc.nframes, (float2*)pc.o32, (double2*)pc.o64);
-    SH_CHECK_LAUNCH("k_bus_combine");
+    State& S = state();
+    S.run_bank = nullptr;                                 // the run of renders ends here: the next one starts on `stream`
+    S.run_count = 0;
+    if (S.aux_busy) {
+        S.aux_busy = false;
+        SH_HIP(hipStreamWaitEvent(S.stream, S.ev_aux, 0));
+    }
+    const int n = S.npending;
+    S.npending = 0;
+    for (int k = 0; k < n; ++k) {                         // oldest first: a bus used for two blocks ends up holding the later one
+        const PendingCombine& pc = S.pending[k];
+        hipLaunchKernelGGL(k_bus_combine, dim3(div_up(pc.nframes, 256)), dim3(256), 0, S.stream,
+                           (const double2*)pc.parts, pc.groups, pc.nframes, (float2*)pc.o32, (double2*)pc.o64);
+        SH_CHECK_LAUNCH("k_bus_combine");
+    }
     return SH_OK;
 }
 
@@ -1590,7 +1601,7 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     if (!rc) rc = upload_array(&b->d_lfo_rot, lfo_rot.data(), nvoices, st);
     if (!rc) {
         hipError_t e = hipSuccess;
-        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        for (int k = 0; k < sh_bank::NSETS && e == hipSuccess; ++k) {
             e = hipMalloc((void**)&b->d_launch_buf[k], sizeof(VoiceLaunch) * nvoices);
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_launch_fm_buf[k], sizeof(VoiceFM) * nvoices);
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_fast_buf[k], sizeof(FastRec) * nvoices);
@@ -1619,12 +1630,13 @@ int sh_bank_destroy(sh_bank* b) {
     if (!b) return SH_OK;
     SH_API_LOCK();
     if (sh::state().initialized) {
+        if (sh::has_pending()) (void)sh::flush_pending();
         (void)hipStreamSynchronize(sh::state().stream);
         if (b->d_voices) (void)hipFree(b->d_voices);
         if (b->d_segs) (void)hipFree(b->d_segs);
         if (b->d_coefs) (void)hipFree(b->d_coefs);
         if (b->d_partials) (void)hipFree(b->d_partials);
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < sh_bank::NSETS; ++k) {
             if (b->d_launch_buf[k]) (void)hipFree(b->d_launch_buf[k]);
             if (b->d_launch_fm_buf[k]) (void)hipFree(b->d_launch_fm_buf[k]);
             if (b->d_fast_buf[k]) (void)hipFree(b->d_fast_buf[k]);
@@ -1662,7 +1674,7 @@ static const shm::sc_pair* trig_table() { return (const shm::sc_pair*)sh::state(
 
 static int prepare(sh_bank* b, uint32_t first, uint32_t count, uint64_t start, uint32_t nframes) {
     // single-voice path (sh_osc_render): records go to slot 0 of the current set; any speculation is void
-    b->spec_valid = false;
+    b->void_specs();
     hipLaunchKernelGGL(k_prepare, dim3(sh::div_up(count, 64)), dim3(64), 0, sh::state().stream,
                        ptrs(b), first, count, start, nframes, b->d_launch, b->d_launch_fm);
     SH_CHECK_LAUNCH("k_prepare");
@@ -1671,24 +1683,47 @@ static int prepare(sh_bank* b, uint32_t first, uint32_t count, uint64_t start, u
 
 // Whole-bank launches: use the records the previous render kernel prepared if the caller asks for the block
 // that was predicted (sequential streaming), else run k_prepare.
-static int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes) {
-    hipStream_t st = sh::state().stream;
-    if (b->spec_valid && b->spec_start == start && b->spec_nframes == nframes) {
-        b->cur ^= 1;
-    } else {
-        hipLaunchKernelGGL(k_prepare_chunks, dim3(sh::div_up(b->nvoices, 64)), dim3(64), 0, st, ptrs(b), launch_set(b, b->cur),
-                           b->nvoices, start, nframes);
-        SH_CHECK_LAUNCH("k_prepare_chunks");
+// `launch_stream`: the stream the consuming kernel goes to.  `in_run`: the previous render launch of this bank may still
+// be executing on the other stream -- its set (b->cur) and the set it is filling (b->last_target) must not be touched.
+static int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t launch_stream, bool in_run) {
+    sh::State& S = sh::state();
+    for (int k = 0; k < sh_bank::NSETS; ++k) {
+        if (b->spec[k].valid && b->spec[k].start == start && b->spec[k].nframes == nframes) {
+            b->spec[k].valid = false;                    // consumed: the set is this launch's from here on
+            b->cur = k;
+            b->d_launch = b->d_launch_buf[k];
+            b->d_launch_fm = b->d_launch_fm_buf[k];
+            return SH_OK;
+        }
     }
-    b->spec_valid = false;
-    b->d_launch = b->d_launch_buf[b->cur];
-    b->d_launch_fm = b->d_launch_fm_buf[b->cur];
+    int k = -1;
+    for (int c = 0; c < sh_bank::NSETS && k < 0; ++c)   // a free set, preferably one that holds no resolved block
+        if (!(in_run && (c == b->cur || c == b->last_target)) && !b->spec[c].valid) k = c;
+    for (int c = 0; c < sh_bank::NSETS && k < 0; ++c)
+        if (!(in_run && (c == b->cur || c == b->last_target))) k = c;
+    b->spec[k].valid = false;
+    hipLaunchKernelGGL(k_prepare_chunks, dim3(sh::div_up(b->nvoices, 64)), dim3(64), 0, S.stream, ptrs(b), launch_set(b, k),
+                       b->nvoices, start, nframes);
+    SH_CHECK_LAUNCH("k_prepare_chunks");
+    if (launch_stream != S.stream) {
+        SH_HIP(hipEventRecord(S.ev_prep, S.stream));
+        SH_HIP(hipStreamWaitEvent(launch_stream, S.ev_prep, 0));
+    }
+    b->cur = k;
+    b->d_launch = b->d_launch_buf[k];
+    b->d_launch_fm = b->d_launch_fm_buf[k];
     return SH_OK;
 }
 
 static bool speculation_enabled() {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("SYNTHHIP_NO_SPECULATION"); enabled = (e && e[0] == '1') ? 0 : 1; }
+    return enabled != 0;
+}
+
+static bool overlap_enabled() {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("SYNTHHIP_NO_OVERLAP"); enabled = (e && e[0] == '1') ? 0 : 1; }
     return enabled != 0;
 }
 
@@ -1742,7 +1777,7 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
         return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: output buffer too small");
     int rc = bank_check_plain(b, "sh_bank_generate");
     if (rc) return rc;
-    rc = acquire_records(b, start, nframes);
+    rc = acquire_records(b, start, nframes, sh::state().stream, false);
     if (rc) return rc;
     // frames per lane: 4 for long rows (one sin/cos lookup + three rotations per voice, as in k_bank_render), else 2 / 1
     const int fpl = nframes >= 8192 ? 4 : (nframes >= 2048 ? 2 : 1);
@@ -1780,7 +1815,7 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     if (rc) return rc;
     float2* o32 = bus_f32 ? (float2*)bus_f32->ptr : nullptr;
     double2* o64 = bus_f64 ? (double2*)bus_f64->ptr : nullptr;
-    hipStream_t st = sh::state().stream;
+    sh::State& S = sh::state();
     // variant = WAVES*100 + FPL*10 + MINW (SYNTHHIP_VARIANT overrides the tuned default)
     static int variant = -1;
     if (variant < 0) {
@@ -1803,24 +1838,39 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     uint32_t vpg = (b->nvoices + groups - 1) / groups;
     if (groups > 1) vpg = (vpg + 63) & ~63u;                // groups are made of whole 64-voice chunks (the lists' unit)
     groups = (b->nvoices + vpg - 1) / vpg;                  // no empty trailing groups
-    rc = acquire_records(b, start, nframes);
-    if (rc) return rc;
-    // the previous render's partial buses: this launch folds them if it has the same shape, else a kernel does it now
-    sh::State& S = sh::state();
-    sh::PendingCombine prev = S.pending;
-    const bool take_over = prev.active && groups > 1 && prev.groups == groups && prev.nframes == nframes &&
-                           prev.tile_frames == (uint32_t)(64 * F);
-    if (prev.active && !take_over) {
+    // Does this launch continue the run of renders (same bank and shape, the next block)?  Then it alternates streams with
+    // its predecessor and folds the partial buses of the launch before that; else what is outstanding is folded now and a
+    // new run starts on `stream`.
+    const bool cont = groups > 1 && S.run_bank == (const void*)b && S.run_nframes == nframes && S.run_groups == groups &&
+                      S.run_tile == (uint32_t)(64 * F) && S.run_next_start == start;
+    if (!cont) {
         rc = sh::flush_pending();
         if (rc) return rc;
+        if (groups > 1) {
+            S.run_bank = b;
+            S.run_nframes = nframes;
+            S.run_groups = groups;
+            S.run_tile = (uint32_t)(64 * F);
+            SH_HIP(hipEventRecord(S.ev_join, S.stream));    // everything enqueued so far: stream2's first launch waits for it
+        }
     }
+    const uint32_t n = groups > 1 ? S.run_count : 0;
+    const bool two_streams = groups > 1 && speculation_enabled() && overlap_enabled();
+    const bool use_aux = two_streams && (n & 1);
+    hipStream_t st = use_aux ? S.stream2 : S.stream;
+    if (use_aux && n == 1) SH_HIP(hipStreamWaitEvent(S.stream2, S.ev_join, 0));
+    const int prev_cur = b->cur;
+    rc = acquire_records(b, start, nframes, st, cont);
+    if (rc) return rc;
+    // partial buses: ring slot n % 4 (last read by the fold in launch n - 2, which is this stream's previous launch)
     double2* parts = nullptr;
     if (groups > 1) {
-        const int k = S.parts_cur ^ 1;                  // not the buffer a pending fold still reads
+        const int k = (int)(n & 3);
         const size_t need = (size_t)groups * nframes * sizeof(double2);
         if (S.parts_bytes[k] < need) {
             if (S.parts_buf[k]) {
-                SH_HIP(hipStreamSynchronize(st));
+                SH_HIP(hipStreamSynchronize(S.stream));
+                SH_HIP(hipStreamSynchronize(S.stream2));
                 SH_HIP(hipFree(S.parts_buf[k]));
                 S.parts_buf[k] = nullptr;
                 S.parts_bytes[k] = 0;
@@ -1829,19 +1879,31 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
             S.parts_bytes[k] = need;
         }
         parts = (double2*)S.parts_buf[k];
-        S.parts_cur = k;
     }
+    // the fold this launch takes over: the older of two outstanding ones (launch n - 2's)
+    const bool take_over = S.npending == 2;
+    const sh::PendingCombine prev = take_over ? S.pending[0] : sh::PendingCombine();
     const double2* pv_parts = take_over ? (const double2*)prev.parts : nullptr;
     float2* pv32 = take_over ? (float2*)prev.o32 : nullptr;
     double2* pv64 = take_over ? (double2*)prev.o64 : nullptr;
     b->last_groups = groups;
     const LaunchSet cur = launch_set(b, b->cur);
-    LaunchSet next = launch_set(b, b->cur ^ 1);
-    if (!speculation_enabled()) next.launch = nullptr;
+    // the records of the block two launches on go to a set that is neither this launch's, nor its predecessor's (perhaps
+    // still executing), nor the one holding the block in between
+    const uint64_t next_start = start + 2 * (uint64_t)nframes;
+    int target = -1;
+    if (speculation_enabled()) {
+        for (int c = 0; c < sh_bank::NSETS && target < 0; ++c) {
+            const bool holds_between = b->spec[c].valid && b->spec[c].start == start + nframes && b->spec[c].nframes == nframes;
+            if (c != b->cur && !(cont && (c == prev_cur || c == b->last_target)) && !holds_between) target = c;
+        }
+    }
+    LaunchSet next = launch_set(b, target < 0 ? 0 : target);
+    if (target < 0) next.launch = nullptr;
     const int mode = b->lean_candidates == 0 ? RENDER_DIRECT : (b->lean_fm_candidates ? RENDER_LEAN_ALL : RENDER_LEAN_HARM);
 #define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
     hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),    \
-                       trig_table(), b->nvoices, vpg, cur, next, start, nframes, o32, o64, parts, pv_parts, pv32, pv64)
+                       trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64)
 #define SH_LAUNCH_RENDER(W_, F_, M_)                                                 \
     do {                                                                             \
         if (mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM);  \
@@ -1865,17 +1927,29 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
 #undef SH_LAUNCH_RENDER
 #undef SH_LAUNCH_MODE
     SH_CHECK_LAUNCH("k_bank_render");
-    S.pending.active = groups > 1;                      // folded by the next render of the same shape, or by the next API call
-    S.pending.parts = parts;
-    S.pending.groups = groups;
-    S.pending.nframes = nframes;
-    S.pending.tile_frames = (uint32_t)(64 * F);
-    S.pending.o32 = o32;
-    S.pending.o64 = o64;
-    if (next.launch) {
-        b->spec_valid = true;
-        b->spec_start = start + nframes;
-        b->spec_nframes = nframes;
+    if (use_aux) {
+        SH_HIP(hipEventRecord(S.ev_aux, S.stream2));
+        S.aux_busy = true;
+    }
+    if (take_over) {                                        // folded by this launch
+        S.pending[0] = S.pending[1];
+        S.npending = 1;
+    }
+    if (groups > 1) {                                       // this launch's partial buses: folded two launches on, or by the next other API call
+        sh::PendingCombine& pc = S.pending[S.npending++];
+        pc.parts = parts;
+        pc.groups = groups;
+        pc.nframes = nframes;
+        pc.o32 = o32;
+        pc.o64 = o64;
+        S.run_count = n + 1;
+        S.run_next_start = start + nframes;
+    }
+    b->last_target = target;
+    if (target >= 0) {
+        b->spec[target].valid = true;
+        b->spec[target].start = next_start;
+        b->spec[target].nframes = nframes;
     }
     return SH_OK;
 }

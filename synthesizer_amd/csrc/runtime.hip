@@ -39,7 +39,8 @@ int hip_error(hipError_t e, const char* what) {
 // producing a new buffer and dropping the old one) would stall the stream at every step.  Freed buffers are kept,
 // by size class (eight classes per power of two: at most 12.5 % slack), and handed out again.  Reuse is safe without
 // synchronisation because everything the library enqueues goes through one stream, in order: work that still reads a
-// freed buffer precedes whatever the next owner enqueues.  (The communication stream only touches buffers that
+// freed buffer precedes whatever the next owner enqueues.  (The second render stream is joined into that order before a
+// buffer changes hands: sh_buf_free ends the run of renders first.  The communication stream only touches buffers that
 // DistVoiceBank keeps for its lifetime.)
 namespace {
 struct Pool {
@@ -141,6 +142,10 @@ int sh_init(int device) {
     if (device < 0 || device >= n) return sh::set_error(SH_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
     SH_HIP(hipSetDevice(device));
     SH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    SH_HIP(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+    SH_HIP(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
+    SH_HIP(hipEventCreateWithFlags(&s.ev_aux, hipEventDisableTiming));
+    SH_HIP(hipEventCreateWithFlags(&s.ev_prep, hipEventDisableTiming));
     SH_HIP(hipEventCreate(&s.ev_start));
     SH_HIP(hipEventCreate(&s.ev_stop));
     SH_HIP(hipMalloc((void**)&s.flag, sizeof(int) * 16));
@@ -168,11 +173,16 @@ int sh_shutdown(void) {
     sh::State& s = state();
     if (!s.initialized) return SH_OK;
     (void)hipStreamSynchronize(s.stream);
-    if (s.pending.active) sh::flush_pending();
+    if (sh::has_pending()) sh::flush_pending();
     (void)hipStreamSynchronize(s.stream);
+    (void)hipStreamSynchronize(s.stream2);
     sh::pool_trim();
     if (s.scratch) (void)hipFree(s.scratch);
-    for (int k = 0; k < 2; ++k) if (s.parts_buf[k]) (void)hipFree(s.parts_buf[k]);
+    for (int k = 0; k < 4; ++k) if (s.parts_buf[k]) (void)hipFree(s.parts_buf[k]);
+    (void)hipEventDestroy(s.ev_join);
+    (void)hipEventDestroy(s.ev_aux);
+    (void)hipEventDestroy(s.ev_prep);
+    (void)hipStreamDestroy(s.stream2);
     if (s.flag) (void)hipFree(s.flag);
     if (s.trig) (void)hipFree(s.trig);
     if (s.flag_host) (void)hipHostFree(s.flag_host);
@@ -209,7 +219,7 @@ int sh_sync(void) {
 // ---- buffers -----------------------------------------------------------------------
 
 int sh_buf_alloc(size_t bytes, sh_buf** out) {
-    SH_REQUIRE_INIT();
+    SH_REQUIRE_INIT_KEEP_PENDING();          // touches no stream: a run of renders goes on (the memory's last owner flushed when freeing it)
     if (!out) return sh::set_error(SH_ERR_INVALID, "out is NULL");
     sh_buf* b = new (std::nothrow) sh_buf;
     if (!b) return sh::set_error(SH_ERR_NOMEM, "host allocation failed");
@@ -228,7 +238,7 @@ int sh_buf_alloc(size_t bytes, sh_buf** out) {
 }
 
 int sh_buf_view(sh_buf* parent, size_t offset, size_t bytes, sh_buf** out) {
-    SH_REQUIRE_INIT();
+    SH_REQUIRE_INIT_KEEP_PENDING();
     if (!parent || !out) return sh::set_error(SH_ERR_INVALID, "sh_buf_view: NULL argument");
     if (offset > parent->bytes || bytes > parent->bytes - offset) return sh::set_error(SH_ERR_INVALID, "sh_buf_view: range outside the parent buffer");
     sh_buf* b = new (std::nothrow) sh_buf;
@@ -249,7 +259,7 @@ int sh_buf_free(sh_buf* b) {
     }
     if (b->ptr && state().initialized) {
         // a render may still owe this buffer the fold of its partial buses: enqueue it before the memory changes hands
-        if (state().pending.active) sh::flush_pending();
+        if (sh::has_pending()) sh::flush_pending();
         sh::pool_free(b->ptr, b->cap);
     }
     delete b;

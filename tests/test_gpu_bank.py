@@ -457,3 +457,83 @@ def test_buffer_pool_and_free_with_a_pending_fold(gpu):
         b.zero()
         assert not b.download(np.uint8, nbytes).any()
         b.free()
+
+
+def test_two_stream_render_pipeline(gpu):
+    """Back-to-back renders alternate between two streams; launch n takes its records from launch n-2 and folds launch
+    n-2's partial buses.  Long runs, runs that break (a jump in the start position, another bank in between, another
+    block length, an unrelated API call, a bus freed while its fold is outstanding, a generate call), notes that end
+    inside the run -- every block must equal the same block rendered alone (each followed by a download)."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    rng = np.random.default_rng(31)
+    nv, block = 640, 5000
+    mk = lambda seed: additive_voices(G, nv, SR, seed=seed, adsr={"sustain": 0.3})      # notes end after ~0.6 s = block 6
+    (va, ga), (vb, gb) = mk(1), mk(2)
+    bank_a, bank_b = VoiceBank(va, gains=ga), VoiceBank(vb, gains=gb)
+    ref_a, ref_b = VoiceBank(mk(1)[0], gains=ga), VoiceBank(mk(2)[0], gains=gb)
+    nblocks = 23
+    alone_a = [ref_a.render(block, start=s * block) for s in range(nblocks)]
+    alone_b = [ref_b.render(block, start=s * block) for s in range(nblocks)]
+
+    def read(buf, n=block):
+        return buf.download(np.float32, n * 2).reshape(n, 2)
+
+    # 1. one long run, rotating buses
+    bufs = [N.DeviceBuffer(block * 8) for _ in range(nblocks)]
+    for s in range(nblocks):
+        bank_a.render_device(block, s * block, bus_f32=bufs[s])
+    for s in range(nblocks):
+        assert np.array_equal(read(bufs[s]), alone_a[s]), s
+    # 2. runs broken in every way, checked against the block-at-a-time results
+    plan = []
+    s = 0
+    while len(plan) < 60:
+        kind = int(rng.integers(0, 8))
+        run = int(rng.integers(1, 6))
+        s = int(rng.integers(0, nblocks - run))
+        plan += [("a", s + k) for k in range(run)]
+        if kind == 0:
+            plan.append(("b", int(rng.integers(0, nblocks))))
+        elif kind == 1:
+            plan.append(("sync", 0))
+        elif kind == 2:
+            plan.append(("short", int(rng.integers(0, nblocks - 1))))
+        elif kind == 3:
+            plan.append(("free", int(rng.integers(0, nblocks))))
+        elif kind == 4:
+            plan.append(("generate", int(rng.integers(0, nblocks))))
+        elif kind == 5:
+            plan += [("b", k) for k in range(3)]
+    outs = []
+    for what, s in plan:
+        if what in ("a", "b"):
+            buf = N.DeviceBuffer(block * 8)
+            (bank_a if what == "a" else bank_b).render_device(block, s * block, bus_f32=buf)
+            outs.append((what, s, buf))
+        elif what == "sync":
+            N.sync()
+        elif what == "short":
+            buf = N.DeviceBuffer(777 * 8)
+            bank_a.render_device(777, s * block, bus_f32=buf)
+            outs.append(("short", s, buf))
+        elif what == "free":
+            buf = N.DeviceBuffer(block * 8)
+            bank_a.render_device(block, s * block, bus_f32=buf)
+            buf.free()                                           # its fold is still outstanding: must be folded (or dropped) safely
+        elif what == "generate":
+            v = N.DeviceBuffer(nv * 1024 * 4)
+            bank_a.generate_device(1024, s * block, out=v)
+            v.free()
+    for what, s, buf in outs:
+        if what == "short":
+            assert np.array_equal(read(buf, 777), ref_a.render(777, start=s * block)), (what, s)
+        else:
+            assert np.array_equal(read(buf), (alone_a if what == "a" else alone_b)[s]), (what, s)
+    # 3. one bus for a whole run: it holds the last block afterwards; the float64 bus likewise
+    one, one64 = N.DeviceBuffer(block * 8), N.DeviceBuffer(block * 16)
+    for s in range(9):
+        bank_b.render_device(block, s * block, bus_f32=one, bus_f64=one64)
+    assert np.array_equal(read(one), alone_b[8])
+    assert np.array_equal(one64.download(np.float64, block * 2).reshape(block, 2).astype(np.float32), alone_b[8])

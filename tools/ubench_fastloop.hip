@@ -124,7 +124,7 @@ int main() {
     FastRec* d_recs; shm::sc_pair* d_trig; double2* d_parts;
     hipMalloc(&d_recs, sizeof(FastRec) * nvoices);
     hipMalloc(&d_trig, sizeof(shm::sc_pair) * shm::TRIG_N);
-    hipMalloc(&d_parts, sizeof(double2) * nframes * 64);
+    hipMalloc(&d_parts, sizeof(double2) * nframes * 64 * 2);
     hipMemcpy(d_recs, recs.data(), sizeof(FastRec) * nvoices, hipMemcpyHostToDevice);
     hipMemcpy(d_trig, trig.data(), sizeof(shm::sc_pair) * shm::TRIG_N, hipMemcpyHostToDevice);
     // sustained load: does the clock hold?  2000 launches back to back
@@ -138,6 +138,26 @@ int main() {
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             printf("sustained 2000 launches: %.1f us per launch\n", ms / 2000 * 1e3);
+        }
+    }
+    // the same launches alternating between two streams: how much of a launch is tail + launch gap that a second,
+    // independent launch could fill?  (production launches depend on their predecessor: records, partial buses)
+    {
+        hipStream_t s2[2]; hipStreamCreate(&s2[0]); hipStreamCreate(&s2[1]);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const uint32_t tiles = (nframes + 255) / 256, vpg = 128;
+        for (int nstreams = 1; nstreams <= 2; ++nstreams) {
+            for (int rep = 0; rep < 3; ++rep) {
+                hipDeviceSynchronize();
+                hipEventRecord(e0, s2[0]);
+                for (int it = 0; it < 2000; ++it)
+                    hipLaunchKernelGGL((k<4, 0, 4, 4>), dim3(tiles, 8), dim3(256), 0, s2[it % nstreams], d_recs, d_trig, nvoices, vpg, nframes,
+                                       d_parts + (size_t)(it % nstreams) * nframes * 8);
+                hipDeviceSynchronize();
+                hipEventRecord(e1, s2[0]); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("production shape, %d stream(s), 2000 launches: %.1f us per launch\n", nstreams, ms / 2000 * 1e3);
+            }
         }
     }
     for (uint32_t groups : {8u}) {
