@@ -311,6 +311,11 @@ def main() -> int:
                      "peak": FP64_PEAK_GOPS, "frac": VOICES_PER_GPU * F * harm_lane_ops / kern_s / 1e9 / FP64_PEAK_GOPS,
                      "ops_per_voice_sample": harm_lane_ops},
             "avg_launch_ms": kern_s * 1e3,
+            "launches_in_flight": 1 if os.environ.get("SYNTHHIP_NO_OVERLAP") == "1" else 2,
+            "timing_note": "avg_launch_ms = HIP events over the timed region / launches (time per launch of the stream of "
+                           "launches); consecutive launches overlap pairwise on two streams, so one kernel's own start-to-end "
+                           "duration (rocprofv3 kernel trace) is about twice that -- profiles/r01_summary.md sets both against "
+                           "the serialised run (SYNTHHIP_NO_OVERLAP=1), where they coincide",
         },
     }
 

@@ -32,6 +32,43 @@ for r in csv.DictReader(open(src / "stats_kernel_stats.csv")):
                                                            float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
 
 
+serial = src / "serial_kernel_stats.csv"
+if serial.exists():
+    shutil.copy(serial, out / ("%s_kernel_stats_serial.csv" % tag))
+    lines += ["", "### k_bank_render: duration of a kernel vs time per launch", "",
+              "The default run pipelines consecutive `k_bank_render` launches over two HIP streams (DESIGN.md section 4 item 16): "
+              "two kernels are in flight at any time, so the start-to-end duration of ONE kernel in the table above is about "
+              "twice the time the stream of launches needs per launch -- the figure `bench.py` reports from HIP events over the "
+              "timed region (`roofline.avg_launch_ms`) and the one that throughput follows.  With the launches serialised on one "
+              "stream (`SYNTHHIP_NO_OVERLAP=1`, same command with `--no-pcm-rows --no-two-step`) the kernel-trace average IS the "
+              "time per launch and agrees with that run's HIP-event figure:", "",
+              "| run | kernel-trace avg us (k_bank_render) | calls | bench.py HIP events, us per launch | Msamples/s |", "|---|---|---|---|---|"]
+    import json as _json
+
+    def bench_line(path):
+        try:
+            last = [l for l in path.read_text().splitlines() if l.startswith("{")][-1]
+            return _json.loads(last)
+        except Exception:
+            return None
+
+    def render_row(csv_path):
+        for r in csv.DictReader(open(csv_path)):
+            if "k_bank_render" in r["Name"]:
+                return float(r["AverageNs"]) / 1e3, r["Calls"]
+        return float("nan"), "?"
+    for label, csv_path, bpath in (("two streams (default)", src / "stats_kernel_stats.csv", src.parent / ("%s_bench.json" % src.name)),
+                                   ("one stream (SYNTHHIP_NO_OVERLAP=1)", serial, src.parent / ("%s_bench_serial.json" % src.name))):
+        avg, calls = render_row(csv_path)
+        b = bench_line(bpath)
+        lines.append("| %s | %.1f | %s | %s | %s |" % (label, avg, calls,
+                                                     ("%.1f" % (b["roofline"]["avg_launch_ms"] * 1e3)) if b else "?",
+                                                     ("%.0f" % b["value"]) if b else "?"))
+    sb = bench_line(src.parent / ("%s_bench_serial.json" % src.name))
+    if sb:
+        (out / ("%s_bench_serial_under_rocprof.json" % tag)).write_text(_json.dumps(sb) + "\n")
+
+
 def counters(fname):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
