@@ -124,7 +124,7 @@ int main() {
     FastRec* d_recs; shm::sc_pair* d_trig; double2* d_parts;
     hipMalloc(&d_recs, sizeof(FastRec) * nvoices);
     hipMalloc(&d_trig, sizeof(shm::sc_pair) * shm::TRIG_N);
-    hipMalloc(&d_parts, sizeof(double2) * nframes * 64 * 2);
+    hipMalloc(&d_parts, sizeof(double2) * nframes * 64 * 4);
     hipMemcpy(d_recs, recs.data(), sizeof(FastRec) * nvoices, hipMemcpyHostToDevice);
     hipMemcpy(d_trig, trig.data(), sizeof(shm::sc_pair) * shm::TRIG_N, hipMemcpyHostToDevice);
     // sustained load: does the clock hold?  2000 launches back to back
@@ -143,10 +143,10 @@ int main() {
     // the same launches alternating between two streams: how much of a launch is tail + launch gap that a second,
     // independent launch could fill?  (production launches depend on their predecessor: records, partial buses)
     {
-        hipStream_t s2[2]; hipStreamCreate(&s2[0]); hipStreamCreate(&s2[1]);
+        hipStream_t s2[4]; for (int q = 0; q < 4; ++q) hipStreamCreate(&s2[q]);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         const uint32_t tiles = (nframes + 255) / 256, vpg = 128;
-        for (int nstreams = 1; nstreams <= 2; ++nstreams) {
+        for (int nstreams = 1; nstreams <= 4; ++nstreams) {
             for (int rep = 0; rep < 3; ++rep) {
                 hipDeviceSynchronize();
                 hipEventRecord(e0, s2[0]);
