@@ -1699,8 +1699,13 @@ static int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStre
     int k = -1;
     for (int c = 0; c < sh_bank::NSETS && k < 0; ++c)   // a free set, preferably one that holds no resolved block
         if (!(in_run && (c == b->cur || c == b->last_target)) && !b->spec[c].valid) k = c;
-    for (int c = 0; c < sh_bank::NSETS && k < 0; ++c)
-        if (!(in_run && (c == b->cur || c == b->last_target))) k = c;
+    if (k < 0) {
+        // every other set holds a resolved block (not reachable with the call patterns that keep a run alive; kept safe
+        // anyway): an older launch on stream2 may still be filling the one taken here, so order the prepare after it
+        if (in_run && S.aux_busy) SH_HIP(hipStreamWaitEvent(S.stream, S.ev_aux, 0));
+        for (int c = 0; c < sh_bank::NSETS && k < 0; ++c)
+            if (!(in_run && (c == b->cur || c == b->last_target))) k = c;
+    }
     b->spec[k].valid = false;
     hipLaunchKernelGGL(k_prepare_chunks, dim3(sh::div_up(b->nvoices, 64)), dim3(64), 0, S.stream, ptrs(b), launch_set(b, k),
                        b->nvoices, start, nframes);
