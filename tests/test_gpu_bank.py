@@ -537,3 +537,49 @@ def test_two_stream_render_pipeline(gpu):
         bank_b.render_device(block, s * block, bus_f32=one, bus_f64=one64)
     assert np.array_equal(read(one), alone_b[8])
     assert np.array_equal(one64.download(np.float64, block * 2).reshape(block, 2).astype(np.float32), alone_b[8])
+
+
+def test_render_run_with_another_thread_calling_in(gpu):
+    """A run of pipelined renders in one thread while another thread keeps calling unrelated entry points: each of those
+    calls ends the run wherever it happens to land (joins the streams, folds what is outstanding) and the next render
+    starts a new one.  Both sides' results must be exact whatever the interleaving."""
+    import audioop
+    import threading
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    from synthesizer_amd.sample import Sample
+    nv, block, nblocks = 512, 4000, 40
+    voices, gains = additive_voices(G, nv, SR, seed=4)
+    bank = VoiceBank(voices, gains=gains)
+    ref = VoiceBank(additive_voices(G, nv, SR, seed=4)[0], gains=gains)
+    alone = [ref.render(block, start=s * block) for s in range(nblocks)]
+    bufs = [N.DeviceBuffer(block * 8) for _ in range(nblocks)]
+    errors, done = [], threading.Event()
+
+    def render():
+        try:
+            for rep in range(3):
+                for s in range(nblocks):
+                    bank.render_device(block, s * block, bus_f32=bufs[s])
+        except Exception as e:                                   # pragma: no cover
+            errors.append(e)
+        done.set()
+
+    rng = np.random.default_rng(8)
+    x = rng.integers(-20000, 20000, 2 * 20000).astype(np.int16)
+    y = rng.integers(-20000, 20000, 2 * 20000).astype(np.int16)
+    want_add, want_peak = audioop.add(x.tobytes(), y.tobytes(), 2), audioop.max(x.tobytes(), 2)
+    t = threading.Thread(target=render)
+    t.start()
+    rounds = 0
+    while not done.is_set() or rounds < 3:
+        a = Sample.from_raw_frames(x.tobytes(), 2, 8000, 2)
+        assert a.peak() == want_peak
+        assert bytes(a.mix(Sample.from_raw_frames(y.tobytes(), 2, 8000, 2)).view_frame_data()) == want_add
+        rounds += 1
+    t.join()
+    assert not errors
+    for s in range(nblocks):
+        got = bufs[s].download(np.float32, block * 2).reshape(block, 2)
+        assert np.array_equal(got, alone[s]), s
