@@ -217,7 +217,7 @@ def main() -> int:
     ap.add_argument("--cpu-frames", type=int, default=12288, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-pcm-rows", action="store_true", help="skip the resample / integer-mix rows")
     ap.add_argument("--no-two-step", action="store_true")
-    ap.add_argument("--reduce-batch", type=int, default=4, help="blocks per RCCL reduce when --gpus > 1")
+    ap.add_argument("--reduce-batch", type=int, default=8, help="blocks per RCCL reduce when --gpus > 1 (also the length of a run of pipelined renders)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
