@@ -319,6 +319,22 @@ def main() -> int:
         },
     }
 
+    # ---- the same stream of blocks delivered as int16 PCM (what a player consumes): quantised by the fold itself ----
+    if world == 1:
+        ring = [N.DeviceBuffer(F * 4) for _ in range(4)]
+        for s in range(Wm):
+            bank.local.render_pcm_device(F, s * F, pcm=ring[s & 3])
+        N.sync()
+        N.timer_start()
+        for s in range(K):
+            bank.local.render_pcm_device(F, (Wm + s) * F, pcm=ring[s & 3])
+        pcm_ms = N.timer_stop() / K
+        out["int16_stream"] = {"ms_per_step": pcm_ms, "value": VOICES_PER_GPU * F / (pcm_ms / 1e3) / 1e6, "unit": "Msamples/s",
+                               "note": "sh_bank_render_pcm into a ring of 4 buffers: saturated int16 stereo straight from the "
+                                       "partial-bus fold, launches pipelined like the headline's"}
+        for b_ in ring:
+            b_.free()
+
     # ---- two-step path on rank 0's shard: materialise (generate) + HBM-bound mix ----
     if not args.no_two_step:
         nv = bank.local.nvoices

@@ -223,6 +223,12 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
  * buses.  To keep a run going while consuming its output, render into a ring of bus buffers and read a buffer only
  * after the run has been ended. */
 int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64);
+/* The same render delivered as saturated int16 stereo PCM (frames x 2, interleaved): sample = trunc(scale * bus) of the
+ * float32 bus, clamped to the int16 range -- exactly what sh_quantize_clip_f32 makes of sh_bank_render's bus_f32 -- but
+ * produced by the fold of the partial buses itself, so a stream of PCM blocks (what a player consumes: upstream's
+ * synth -> Sample.from_osc_block -> mixer route) stays on the two-stream pipeline described above instead of ending
+ * the run with a quantise kernel after every block.  The same rule about reading the buffer applies. */
+int sh_bank_render_pcm(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* pcm_i16);
 
 /* ---- mixer sum bus over materialised voices ------------------------------------------ */
 /* float32: bus[i] = sum_v gains[v] * voices[v*stride+i]; gains = device buffer of nvoices x (l, r) floats */

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "sh_scan_f64": (C.c_int, [_P, C.c_uint32, C.c_double, _P, C.POINTER(C.c_double)]),
     "sh_bank_generate": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t]),
     "sh_bank_render": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, _P]),
+    "sh_bank_render_pcm": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_double, _P]),
     "sh_mix_bus_f32": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P, _P]),
     "sh_mix_chain_i16": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P]),
     "sh_mix_chain_gather_i16": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, _P, C.c_size_t]),

@@ -28,6 +28,8 @@ struct PendingCombine {
     uint32_t groups = 0, nframes = 0;
     void*    o32 = nullptr;          // float2[nframes] or NULL
     void*    o64 = nullptr;          // double2[nframes] or NULL
+    void*    o16 = nullptr;          // int16 stereo PCM (one dword per frame) or NULL
+    double   scale = 0.0;            // ... quantised as trunc(scale * float32(bus)), saturating
 };
 
 struct State {

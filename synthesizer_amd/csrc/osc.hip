@@ -919,6 +919,15 @@ __device__ __forceinline__ void general_voice(const VoiceRegs& r, const VoiceFM*
 // MODE (a static property of the bank): RENDER_DIRECT -- no voice could ever take the lean loop: walk the voice table
 // directly; RENDER_LEAN_HARM -- lean loop for polynomial Harmonics only; RENDER_LEAN_ALL -- also for FM Sine voices (kept
 // out of the Harmonics-only kernel: the extra branch and code cost its loop 5 %).
+// One stereo frame of the float64 bus as saturated int16 PCM: what sh_quantize_clip_f32 makes of the float32 bus
+// (rounded to float32 first, float64 product with the scale, truncation toward zero, clamp; NaN -> 0), packed (L | R << 16).
+__device__ __forceinline__ uint32_t pcm16_frame(double l, double r, double scale) {
+    double tl = trunc(scale * (double)(float)l), tr = trunc(scale * (double)(float)r);
+    tl = tl != tl ? 0.0 : (tl > 32767.0 ? 32767.0 : (tl < -32768.0 ? -32768.0 : tl));
+    tr = tr != tr ? 0.0 : (tr > 32767.0 ? 32767.0 : (tr < -32768.0 ? -32768.0 : tr));
+    return ((uint32_t)(int)tl & 0xFFFFu) | ((uint32_t)(int)tr << 16);
+}
+
 enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2 };
 template <int WAVES, int FPL, int MINW, int MODE>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
@@ -930,7 +939,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                                                                   double2* __restrict__ parts,
                                                                   const double2* __restrict__ prev_parts,
                                                                   float2* __restrict__ prev_bus32,
-                                                                  double2* __restrict__ prev_bus64) {
+                                                                  double2* __restrict__ prev_bus64,
+                                                                  uint32_t* __restrict__ pcm16, double pcm_scale,
+                                                                  uint32_t* __restrict__ prev_pcm16, double prev_pcm_scale) {
     // The previous launch of the stream (same shape) left its voice groups' partial buses unfolded: the workgroups of
     // group 0 fold their tile of it now, in group order, before their own work -- instead of a 5 us kernel between
     // every two render launches.
@@ -946,6 +957,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             }
             if (prev_bus32) prev_bus32[raw] = make_float2((float)acc.x, (float)acc.y);
             if (prev_bus64) prev_bus64[raw] = acc;
+            if (prev_pcm16) prev_pcm16[raw] = pcm16_frame(acc.x, acc.y, prev_pcm_scale);
         }
     }
     // Sequential streaming is the common call pattern: this launch also resolves the launch records of the block
@@ -1181,13 +1193,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             } else {
                 if (bus32) bus32[raw] = make_float2((float)l, (float)rr);
                 if (bus64) bus64[raw] = make_double2(l, rr);
+                if (pcm16) pcm16[raw] = pcm16_frame(l, rr, pcm_scale);
             }
         }
     }
 }
 
 __global__ __launch_bounds__(256) void k_bus_combine(const double2* __restrict__ parts, uint32_t ngroups, uint32_t nframes,
-                                                     float2* __restrict__ bus32, double2* __restrict__ bus64) {
+                                                     float2* __restrict__ bus32, double2* __restrict__ bus64,
+                                                     uint32_t* __restrict__ pcm16, double pcm_scale) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nframes) return;
     double2 s = parts[i];
@@ -1198,6 +1212,7 @@ __global__ __launch_bounds__(256) void k_bus_combine(const double2* __restrict__
     }
     if (bus32) bus32[i] = make_float2((float)s.x, (float)s.y);
     if (bus64) bus64[i] = s;
+    if (pcm16) pcm16[i] = pcm16_frame(s.x, s.y, pcm_scale);
 }
 
 // ---- mixer over materialised float32 voices ------------------------------------------
@@ -1521,7 +1536,8 @@ int flush_pending() {
     for (int k = 0; k < n; ++k) {                         // oldest first: a bus used for two blocks ends up holding the later one
         const PendingCombine& pc = S.pending[k];
         hipLaunchKernelGGL(k_bus_combine, dim3(div_up(pc.nframes, 256)), dim3(256), 0, S.stream,
-                           (const double2*)pc.parts, pc.groups, pc.nframes, (float2*)pc.o32, (double2*)pc.o64);
+                           (const double2*)pc.parts, pc.groups, pc.nframes, (float2*)pc.o32, (double2*)pc.o64,
+                           (uint32_t*)pc.o16, pc.scale);
         SH_CHECK_LAUNCH("k_bus_combine");
     }
     return SH_OK;
@@ -1806,20 +1822,26 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
     return SH_OK;
 }
 
-int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64) {
+}  // extern "C"
+
+// the render behind sh_bank_render (float32 / float64 bus) and sh_bank_render_pcm (int16 PCM straight from the fold)
+static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64, sh_buf* pcm_i16, double pcm_scale) {
     SH_REQUIRE_INIT_KEEP_PENDING();          // a pending fold of the previous render is taken over by this launch (below)
-    if (!b || nframes == 0 || (!bus_f32 && !bus_f64)) {
+    const bool no_out = !bus_f32 && !bus_f64 && !pcm_i16;
+    if (!b || nframes == 0 || no_out) {
         int rcp = sh::flush_pending();
         if (rcp) return rcp;
     }
-    if (!b || (!bus_f32 && !bus_f64)) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: NULL argument");
+    if (!b || no_out) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: NULL argument");
     if (nframes == 0) return SH_OK;
     if (bus_f32 && bus_f32->bytes < (size_t)nframes * 8) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f32 too small");
     if (bus_f64 && bus_f64->bytes < (size_t)nframes * 16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f64 too small");
+    if (pcm_i16 && pcm_i16->bytes < (size_t)nframes * 4) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_pcm: PCM buffer too small");
     int rc = bank_check_plain(b, "sh_bank_render");
     if (rc) return rc;
     float2* o32 = bus_f32 ? (float2*)bus_f32->ptr : nullptr;
     double2* o64 = bus_f64 ? (double2*)bus_f64->ptr : nullptr;
+    uint32_t* o16 = pcm_i16 ? (uint32_t*)pcm_i16->ptr : nullptr;
     sh::State& S = sh::state();
     // variant = WAVES*100 + FPL*10 + MINW (SYNTHHIP_VARIANT overrides the tuned default)
     static int variant = -1;
@@ -1891,6 +1913,8 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     const double2* pv_parts = take_over ? (const double2*)prev.parts : nullptr;
     float2* pv32 = take_over ? (float2*)prev.o32 : nullptr;
     double2* pv64 = take_over ? (double2*)prev.o64 : nullptr;
+    uint32_t* pv16 = take_over ? (uint32_t*)prev.o16 : nullptr;
+    const double pv_scale = take_over ? prev.scale : 0.0;
     b->last_groups = groups;
     const LaunchSet cur = launch_set(b, b->cur);
     // the records of the block two launches on go to a set that is neither this launch's, nor its predecessor's (perhaps
@@ -1908,7 +1932,8 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
     const int mode = b->lean_candidates == 0 ? RENDER_DIRECT : (b->lean_fm_candidates ? RENDER_LEAN_ALL : RENDER_LEAN_HARM);
 #define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
     hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),    \
-                       trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64)
+                       trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64, \
+                       o16, pcm_scale, pv16, pv_scale)
 #define SH_LAUNCH_RENDER(W_, F_, M_)                                                 \
     do {                                                                             \
         if (mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM);  \
@@ -1947,6 +1972,8 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
         pc.nframes = nframes;
         pc.o32 = o32;
         pc.o64 = o64;
+        pc.o16 = o16;
+        pc.scale = pcm_scale;
         S.run_count = n + 1;
         S.run_next_start = start + nframes;
     }
@@ -1957,6 +1984,17 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
         b->spec[target].nframes = nframes;
     }
     return SH_OK;
+}
+
+extern "C" {
+
+int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64) {
+    return bank_render(b, start, nframes, bus_f32, bus_f64, nullptr, 0.0);
+}
+
+int sh_bank_render_pcm(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* pcm_i16) {
+    if (!pcm_i16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_pcm: NULL PCM buffer");
+    return bank_render(b, start, nframes, nullptr, nullptr, pcm_i16, scale);
 }
 
 int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32_t nframes,

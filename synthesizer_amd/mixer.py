@@ -86,16 +86,22 @@ class VoiceBank:
         buf.free()
         return out
 
+    def render_pcm_device(self, nframes: int, start: int = 0, scale: float = 32767.0,
+                          pcm: Optional[N.DeviceBuffer] = None) -> N.DeviceBuffer:
+        """Fused generate-and-mix delivered as saturated int16 stereo PCM (nframes x 2) in a device buffer: the fold of
+        the voice groups' partial buses quantises as it goes, so consecutive blocks stay pipelined (no quantise kernel
+        between them).  The buffer is complete once any other library call (or ``_native.sync()``) has been made."""
+        if pcm is None:
+            pcm = N.DeviceBuffer(nframes * 4)
+        N.check(N.lib().sh_bank_render_pcm(self._bank.handle, start, nframes, float(scale), pcm.handle))
+        return pcm
+
     def render_sample(self, nframes: int, start: int = 0, scale: float = 32767.0) -> Sample:
         """Stereo bus quantised to an int16 Sample (saturating: a bus can exceed full scale)."""
         s = Sample(samplerate=self.samplerate, nchannels=2, samplewidth=2)
         if nframes == 0:
             return s
-        bus = self.render_device(nframes, start)
-        pcm = N.DeviceBuffer(nframes * 4)
-        N.check(N.lib().sh_quantize_clip_f32(bus.handle, nframes * 2, float(scale), pcm.handle))
-        bus.free()                      # back to the pool: reuse is ordered behind the kernel by the stream
-        s._set_device(pcm, nframes * 4)
+        s._set_device(self.render_pcm_device(nframes, start, scale), nframes * 4)
         return s
 
     # -- two-step (reference-shaped) path -----------------------------------------------------------

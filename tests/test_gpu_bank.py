@@ -583,3 +583,48 @@ def test_render_run_with_another_thread_calling_in(gpu):
     for s in range(nblocks):
         got = bufs[s].download(np.float32, block * 2).reshape(block, 2)
         assert np.array_equal(got, alone[s]), s
+
+
+def test_pcm_blocks_straight_from_the_fold(gpu):
+    """sh_bank_render_pcm: int16 stereo PCM produced by the fold of the partial buses (in the render kernel two launches
+    on, or by the combine kernel when the run ends) equals quantising the float32 bus of the same block with
+    sh_quantize_clip_f32 -- for a run of blocks into a ring of buffers, for a loud bank that saturates, for a small bank
+    (one voice group: the kernel's own epilogue writes the PCM), and mixed with float renders in one run."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    L = N.lib()
+    block = 4800
+    for nv, loud in ((640, 1.0), (640, 40.0), (5, 1.0)):
+        voices, gains = additive_voices(G, nv, SR, seed=nv)
+        gains = [(gl * loud, gr * loud) for gl, gr in gains]
+        bank = VoiceBank(voices, gains=gains)
+        ref = VoiceBank(additive_voices(G, nv, SR, seed=nv)[0], gains=gains)
+        want = []
+        for s in range(9):
+            bus = ref.render_device(block, s * block)
+            pcm = N.DeviceBuffer(block * 4)
+            N.check(L.sh_quantize_clip_f32(bus.handle, block * 2, 32767.0, pcm.handle))
+            want.append(pcm.download_bytes(block * 4))
+        if loud > 1:
+            assert any(np.abs(np.frombuffer(w, np.int16)).max() == 32767 for w in want)      # it does saturate
+        ring = [N.DeviceBuffer(block * 4) for _ in range(9)]
+        for s in range(9):
+            bank.render_pcm_device(block, s * block, pcm=ring[s])                            # nothing in between: one run
+        for s in range(9):
+            assert ring[s].download_bytes(block * 4) == want[s], (nv, loud, s)
+        # float and PCM outputs alternating within one run, other scale
+        f32 = N.DeviceBuffer(block * 8)
+        p16 = N.DeviceBuffer(block * 4)
+        bank.render_device(block, 0, bus_f32=f32)
+        bank.render_pcm_device(block, block, scale=1000.0, pcm=p16)
+        bank.render_device(block, 2 * block, bus_f32=f32)
+        half = N.DeviceBuffer(block * 4)
+        bus = ref.render_device(block, block)                  # (keep the buffer object alive across the call)
+        N.check(L.sh_quantize_clip_f32(bus.handle, block * 2, 1000.0, half.handle))
+        assert p16.download_bytes(block * 4) == half.download_bytes(block * 4)
+        assert np.array_equal(f32.download(np.float32, block * 2), ref.render(block, 2 * block).reshape(-1))
+        smp = bank.render_sample(block, 3 * block)
+        assert bytes(smp.view_frame_data()) == want[3] and smp.nchannels == 2 and smp.samplewidth == 2
+    with pytest.raises(ValueError):
+        bank.render_pcm_device(block, 0, pcm=N.DeviceBuffer(16))
