@@ -2,8 +2,8 @@
 oracle/synth_oracle.py / oracle/pcm_oracle.py, in C, for sizes Python cannot finish in seconds.
 
 TEST INFRASTRUCTURE, NOT PRODUCT CODE.  ``render(osc, n)`` takes an *oracle* oscillator object
-(synth_oracle.Sine / Sawtooth / Square / Pulse / Harmonics, optionally FM'd by a plain Sine, optionally
-inside an EnvelopeFilter) and returns its first n samples as float64.
+(synth_oracle.Sine / Sawtooth / Square / Triangle / Pulse / Harmonics, optionally FM'd by a plain Sine; Linear;
+WhiteNoise; any of them optionally inside an EnvelopeFilter) and returns its first n samples as float64.
 """
 from __future__ import annotations
 
@@ -43,6 +43,21 @@ def render(osc, n: int) -> np.ndarray:
     env = None
     if isinstance(osc, O.EnvelopeFilter):
         env, osc = osc, osc._source
+    if isinstance(osc, (O.Linear, O.WhiteNoise)):
+        out = np.empty(n, dtype=np.float64)
+        if isinstance(osc, O.Linear):
+            lib().or_linear(C.c_double(osc._value), C.c_double(osc._increment), C.c_double(osc._min), C.c_double(osc._max),
+                            C.c_size_t(n), _dp(out))
+        else:
+            cycles = int(osc.samplerate / osc.frequency)
+            if cycles < 1:
+                raise ValueError("whitenoise frequency cannot be bigger than the sample rate")
+            lib().or_white_noise(C.c_uint64(cycles), C.c_double(osc.amplitude), C.c_double(osc.bias),
+                                 C.c_uint64(osc.seed & ((1 << 64) - 1)), C.c_size_t(n), _dp(out))
+        if env is not None:
+            lib().or_envelope(C.c_double(env._attack), C.c_double(env._decay), C.c_double(env._sustain), C.c_double(env._sustain_level),
+                              C.c_double(env._release), C.c_int(osc.samplerate), C.c_size_t(n), _dp(out))
+        return out
     kind = _KIND[type(osc)]
     radians = kind in (0, 4)
     sr = osc.samplerate

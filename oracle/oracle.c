@@ -72,6 +72,32 @@ void or_osc_fm_sine(int kind, double frequency, double phase0, double inc, doubl
     }
 }
 
+/* Linear: the level is emitted, then incremented while it lies strictly between min and max (synth_oracle.Linear) */
+void or_linear(double start, double increment, double minv, double maxv, size_t n, double* out) {
+    double value = start;
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = value;
+        if (minv < value && value < maxv) value += increment;
+    }
+}
+
+/* WhiteNoise as this build defines it (synth_oracle.WhiteNoise): sample n holds draw h = n / cycles,
+ * u = (splitmix64(seed + h * 0x9E3779B97F4A7C15) >> 11) * 2^-53, value = (a + (b - a) * u) + bias, a = -amplitude, b = amplitude */
+static uint64_t splitmix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void or_white_noise(uint64_t cycles, double amplitude, double bias, uint64_t seed, size_t n, double* out) {
+    const double a = -amplitude, b = amplitude;
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t h = (uint64_t)i / cycles;
+        const double u = (double)(splitmix64(seed + h * 0x9E3779B97F4A7C15ull) >> 11) * 0x1.0p-53;
+        out[i] = (a + (b - a) * u) + bias;
+    }
+}
+
 /* EnvelopeFilter applied in place to n samples of a stream that started at sample 0 */
 void or_envelope(double attack, double decay, double sustain, double sustain_level, double release,
                  int samplerate, size_t n, double* x) {

@@ -461,3 +461,20 @@ def test_echo_filter(gpu):
         assert g.echo_duration == o.echo_duration
     with pytest.raises(ValueError):
         G.EchoFilter(G.Sine(1.0), 0.1, 2, 0.1, 1.5)
+
+
+def test_linear_and_noise_at_full_size_vs_c_oracle(gpu):
+    """100 s of WhiteNoise and Linear at 48 kHz (4.8 M samples) against the C restatement of the oracle
+    (oracle/oracle.c: or_white_noise / or_linear, themselves checked against the Python oracle in tests/test_oracle_c.py)."""
+    from oracle import c_oracle as CO
+    from synthesizer_amd import oscillators as G
+    n = 4_800_000
+    for args in ((6000.0, 0.7, 0.05, 7), (48000.0, 1.0, 0.0, 2 ** 64 - 3), (3.0, 0.5, -0.2, 1)):
+        freq, amp, bias, seed = args
+        want = CO.render(O.WhiteNoise(freq, amp, bias, samplerate=SR, seed=seed), n).astype(np.float32)
+        got = G.WhiteNoise(freq, amp, bias, samplerate=SR, seed=seed).render(n)
+        assert np.array_equal(got, want), args
+    for args in ((-1.0 + 1e-9, 4.1e-7, -1.0, 1.0), (0.5, -3.0e-7, -0.75, 1.0), (0.0, 1e-12, -1.0, 1.0)):
+        want = CO.render(O.Linear(*args, samplerate=SR), n).astype(np.float32)
+        got = G.Linear(*args, samplerate=SR).render(n)
+        assert np.array_equal(got, want), args

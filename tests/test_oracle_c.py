@@ -28,6 +28,12 @@ SR = 48000
     lambda: O.Triangle(441.0, 0.6, phase=-0.4, bias=0.05, samplerate=SR),
     lambda: O.Triangle(-250.0, 0.5, phase=0.3, samplerate=SR),
     lambda: O.Triangle(300.0, fm_lfo=O.Sine(2.0, 0.05, samplerate=SR), samplerate=SR),
+    lambda: O.Linear(-0.5, 0.00013, samplerate=SR),
+    lambda: O.Linear(0.9, 0.001, min_value=-2.0, max_value=1.0, samplerate=SR),
+    lambda: O.Linear(0.2, -0.0007, samplerate=SR),
+    lambda: O.WhiteNoise(4000.0, 0.8, bias=0.1, samplerate=SR, seed=12345),
+    lambda: O.WhiteNoise(48000.0, 1.0, samplerate=SR, seed=(1 << 63) + 7),
+    lambda: O.EnvelopeFilter(O.WhiteNoise(1000.0, samplerate=SR, seed=3), 0.01, 0.02, 0.05, 0.5, 0.05),
 ])
 def test_c_oscillators_equal_python_oracle(make):
     n = 12000
