@@ -58,6 +58,17 @@ def test_single_rank_rccl_reduce(gpu):
         N.sync()
         for s in (3 * nslots + 1, 3 * nslots, 3 * nslots - 1, 2 * 3):           # blocks whose slots have not been reused
             assert np.array_equal(got_blocks[s].download(np.float32, 2000).reshape(1000, 2), bank.local.render(1000, s * 1000)), s
+        # the same with a bank large enough for several voice groups: the renders of a slot then form one run of the
+        # two-stream pipeline (partial buses folded two launches on) which the slot's reduce has to end first
+        big_v, big_g = additive_voices(G, 640, 48000, seed=6)
+        big = dist.DistVoiceBank(big_v, big_g, 0, 1, batch=5)
+        big.world, big.batch = 2, 5
+        alone = dist.DistVoiceBank(additive_voices(G, 640, 48000, seed=6)[0], big_g, 0, 1).local
+        blocks = [big.render_device(3000, s * 3000) for s in range(5 * nslots + 3)]
+        big.flush()
+        N.sync()
+        for s in range(5 * nslots + 2, 5 * nslots + 2 - 5 * (nslots - 1), -1):    # blocks whose slots have not been reused
+            assert np.array_equal(blocks[s].download(np.float32, 6000).reshape(3000, 2), alone.render(3000, s * 3000)), s
     finally:
         dist.shutdown()
     assert L.sh_dist_world() == 0
