@@ -140,8 +140,8 @@ def lib() -> C.CDLL:
     """Load libsynthhip.so (CDLL: the GIL is released around every call)."""
     global _lib
     if _lib is None:
-        if not LIB_PATH.exists() and "SYNTHHIP_LIB" not in os.environ:
-            try:                                    # in-tree build (hipcc cross-compiles gfx950 in seconds)
+        if "SYNTHHIP_LIB" not in os.environ:
+            try:                                    # in-tree build when missing or stale (embedded source hash != the tree's)
                 from . import build as _build
                 _build.build(verbose=False)
             except Exception as exc:
@@ -194,6 +194,15 @@ def ensure_init(device: Optional[int] = None) -> None:
         raise SynthHipError(SH_ERR_NOTINIT, "no HIP device visible; this package has no CPU fallback")
     check(L.sh_init(device))
     _initialized = True
+
+
+def shutdown() -> None:
+    """sh_shutdown (which tears the RCCL state down first) and forget the initialisation, so that the next call
+    re-initialises instead of failing with SH_ERR_NOTINIT."""
+    global _initialized
+    if _lib is not None:
+        check(_lib.sh_shutdown())
+    _initialized = False
 
 
 def device_info() -> dict:

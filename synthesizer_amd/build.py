@@ -7,7 +7,9 @@ repository snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
 """
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import subprocess
 import sys
 from pathlib import Path
@@ -29,18 +31,32 @@ FLAGS = [
 ]
 
 
-def needs_build() -> bool:
+def source_hash() -> str:
+    """SHA-256 (16 hex digits) over the sources, headers and compiler flags the library is built from."""
+    h = hashlib.sha256()
+    for f in [CSRC / s for s in SOURCES] + [(CSRC / x).resolve() for x in HEADERS]:
+        h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def built_hash() -> str:
+    """The hash embedded in libsynthhip.so (sh_version(): "... src:<hash>"), read from the file without loading it."""
     if not LIB.exists():
-        return True
-    t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [(CSRC / h).resolve() for h in HEADERS] + [Path(__file__)]
-    return any(d.stat().st_mtime > t for d in deps)
+        return ""
+    m = re.search(rb"synthhip [0-9.]+ \(gfx950\) src:([0-9a-f]{16})", LIB.read_bytes())
+    return m.group(1).decode() if m else ""
+
+
+def needs_build() -> bool:
+    """Stale = the library's embedded source hash differs from the tree's (mtimes of a shipped .so mean nothing)."""
+    return built_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + [str(CSRC / s) for s in SOURCES] + ["-o", str(LIB), "-ldl"]
+    cmd = [HIPCC] + FLAGS + ['-DSH_SOURCE_HASH="%s"' % source_hash()] + [str(CSRC / s) for s in SOURCES] + ["-o", str(LIB), "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -435,6 +435,9 @@ int dispatch_width(int width, F&& f) {
     return sh::set_error(SH_ERR_INVALID, "sample width %d not in {1,2,4}", width);
 }
 
+inline bool valid_width(int width) { return width == 1 || width == 2 || width == 4; }
+int bad_width(const char* who, int width) { return sh::set_error(SH_ERR_INVALID, "%s: sample width %d not in {1,2,4}", who, width); }
+
 int check_io(const sh_buf* in, size_t in_off, size_t in_bytes, const sh_buf* out, size_t out_off, size_t out_bytes, const char* who) {
     if (!in || !out) return sh::set_error(SH_ERR_INVALID, "%s: NULL buffer", who);
     if (in_off > in->bytes || in_bytes > in->bytes - in_off) return sh::set_error(SH_ERR_INVALID, "%s: input range outside buffer", who);
@@ -448,6 +451,7 @@ extern "C" {
 
 int sh_pcm_mul(const sh_buf* in, size_t in_off, size_t nbytes, int width, double factor, sh_buf* out, size_t out_off) {
     SH_REQUIRE_INIT();
+    if (!valid_width(width)) return bad_width("sh_pcm_mul", width);
     int rc = check_io(in, in_off, nbytes, out, out_off, nbytes, "sh_pcm_mul");
     if (rc) return rc;
     if (nbytes % width || (in_off | out_off) % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_mul: not a whole number of frames");
@@ -470,6 +474,7 @@ int sh_pcm_mul(const sh_buf* in, size_t in_off, size_t nbytes, int width, double
 int sh_pcm_fade(const sh_buf* in, size_t in_off, size_t nbytes, int width, int fadeout, double slope, double offset,
                 sh_buf* out, size_t out_off) {
     SH_REQUIRE_INIT();
+    if (!valid_width(width)) return bad_width("sh_pcm_fade", width);
     int rc = check_io(in, in_off, nbytes, out, out_off, nbytes, "sh_pcm_fade");
     if (rc) return rc;
     if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_fade: not a whole number of samples");
@@ -487,6 +492,7 @@ int sh_pcm_fade(const sh_buf* in, size_t in_off, size_t nbytes, int width, int f
 
 int sh_pcm_modulate(const sh_buf* in, size_t nbytes, int width, const sh_buf* mod_f64, size_t nmod, sh_buf* out) {
     SH_REQUIRE_INIT();
+    if (!valid_width(width)) return bad_width("sh_pcm_modulate", width);
     int rc = check_io(in, 0, nbytes, out, 0, nbytes, "sh_pcm_modulate");
     if (rc) return rc;
     if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_modulate: not a whole number of samples");
@@ -559,6 +565,7 @@ int sh_pcm_to_f64(const sh_buf* in, size_t nsamples, int width, double divisor, 
 
 int sh_pcm_bias(const sh_buf* in, size_t nbytes, int width, int bias, sh_buf* out) {
     SH_REQUIRE_INIT();
+    if (!valid_width(width)) return bad_width("sh_pcm_bias", width);
     int rc = check_io(in, 0, nbytes, out, 0, nbytes, "sh_pcm_bias");
     if (rc) return rc;
     if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_bias: not a whole number of frames");
@@ -575,6 +582,7 @@ int sh_pcm_bias(const sh_buf* in, size_t nbytes, int width, int bias, sh_buf* ou
 
 int sh_pcm_reverse(const sh_buf* in, size_t nbytes, int width, sh_buf* out) {
     SH_REQUIRE_INIT();
+    if (!valid_width(width)) return bad_width("sh_pcm_reverse", width);
     int rc = check_io(in, 0, nbytes, out, 0, nbytes, "sh_pcm_reverse");
     if (rc) return rc;
     if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_reverse: not a whole number of frames");
@@ -592,6 +600,7 @@ int sh_pcm_reverse(const sh_buf* in, size_t nbytes, int width, sh_buf* out) {
 
 int sh_pcm_tomono(const sh_buf* in, size_t nframes, int width, double lfactor, double rfactor, sh_buf* out) {
     SH_REQUIRE_INIT();
+    if (!valid_width(width)) return bad_width("sh_pcm_tomono", width);
     int rc = check_io(in, 0, nframes * 2 * width, out, 0, nframes * width, "sh_pcm_tomono");
     if (rc) return rc;
     if (!nframes) return SH_OK;
@@ -610,6 +619,7 @@ int sh_pcm_tomono(const sh_buf* in, size_t nframes, int width, double lfactor, d
 
 int sh_pcm_tostereo(const sh_buf* in, size_t nframes, int width, double lfactor, double rfactor, sh_buf* out) {
     SH_REQUIRE_INIT();
+    if (!valid_width(width)) return bad_width("sh_pcm_tostereo", width);
     int rc = check_io(in, 0, nframes * width, out, 0, nframes * 2 * width, "sh_pcm_tostereo");
     if (rc) return rc;
     if (!nframes) return SH_OK;
@@ -651,6 +661,7 @@ int sh_pcm_lin2lin(const sh_buf* in, size_t nsamples, int width, int new_width, 
 
 int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, double* sum_squares) {
     SH_REQUIRE_INIT();
+    if (!valid_width(width)) return bad_width("sh_pcm_stats", width);
     if (!in || nbytes > in->bytes) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats: range outside buffer");
     if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats: not a whole number of frames");
     if (max_abs) *max_abs = 0;

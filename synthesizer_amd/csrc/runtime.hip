@@ -120,7 +120,12 @@ extern "C" {
 
 const char* sh_last_error(void) { return sh::g_err; }
 
-const char* sh_version(void) { return "synthhip 0.1 (gfx950)"; }
+#ifndef SH_SOURCE_HASH
+#define SH_SOURCE_HASH "unknown"
+#endif
+// "src:<hash>" = SHA-256 (first 16 hex digits) of csrc/ + include/synthhip.h + the compiler flags, embedded by
+// synthesizer_amd/build.py: a library whose hash differs from the tree's is stale and gets rebuilt.
+const char* sh_version(void) { return "synthhip 0.2 (gfx950) src:" SH_SOURCE_HASH; }
 
 int sh_device_count(void) {
     int n = 0;
@@ -172,6 +177,7 @@ int sh_shutdown(void) {
     SH_API_LOCK();
     sh::State& s = state();
     if (!s.initialized) return SH_OK;
+    (void)sh_dist_shutdown();          // communicator, slot events and the communication stream go first (they belong to this device context)
     (void)hipStreamSynchronize(s.stream);
     if (sh::has_pending()) sh::flush_pending();
     (void)hipStreamSynchronize(s.stream);

@@ -12,8 +12,10 @@ evaluates once per oscillator (increment, start phase, envelope slopes), turns t
 reference carries per sample into exact tables (phasetable.py) and packs everything into the
 ``sh_voice`` record the kernels read.
 
-Beyond the reference API each oscillator has ``render(nframes, start=None) -> numpy float32`` (bulk,
-no Python-level per-sample work) and can be put in a ``mixer.VoiceBank``.
+Beyond the reference API each oscillator has ``render(nframes, start=None) -> numpy float32`` (bulk, the
+float32 PCM storage format) and ``render_f64`` (the float64 values ``blocks()`` yields and the quantiser
+consumes: float32 is a storage format only, never an intermediate on the way to integer PCM), and can be
+put in a ``mixer.VoiceBank``.
 """
 from __future__ import annotations
 
@@ -338,6 +340,23 @@ class Oscillator:
         self._pos = start + nframes
         return out
 
+    def render_f64(self, nframes: int, start: Optional[int] = None) -> np.ndarray:
+        """Samples [start, start+nframes) as float64 -- the values the reference's generator yields (Python floats),
+        before any rounding to the float32 storage format (truncated at the end of a finite stream)."""
+        if start is None:
+            start = self._pos
+        limit = self.length
+        if limit is not None:
+            nframes = max(0, min(nframes, limit - start))
+        if nframes == 0:
+            self._pos = start
+            return np.empty(0, dtype=np.float64)
+        buf = self._render_f64_device(start, nframes)
+        out = buf.download(np.float64, nframes)
+        buf.free()
+        self._pos = start + nframes
+        return out
+
     def render_to(self, buf: N.DeviceBuffer, offset: int, nframes: int, start: int) -> None:
         """Samples into an existing float32 device buffer at element ``offset`` (no host copy)."""
         if nframes:
@@ -354,7 +373,7 @@ class Oscillator:
                 want = min(want, limit - pos)
                 if want <= 0:
                     return
-            chunk = self.render(want, start=pos)
+            chunk = self.render_f64(want, start=pos)       # float64, like upstream's Python floats
             pos += len(chunk)
             values = chunk.tolist()
             for i in range(0, len(values), bs):

@@ -145,6 +145,27 @@ class Sample:
         s._set_device(dst, n * width)
         return s
 
+    @classmethod
+    def from_osc_device(cls, block_f64: N.DeviceBuffer, n: int, samplerate: int,
+                        amplitude_scale: Optional[float] = None, samplewidth: int = 0, free_block: bool = True) -> "Sample":
+        """from_osc_block for a float64 block that already lives in HBM (an oscillator's ``_render_f64_device``): the
+        quantiser reads the float64 samples the reference would have yielded, nothing is rounded to float32 on the way."""
+        width = samplewidth or params.norm_samplewidth
+        if width not in (1, 2, 4):
+            raise NotImplementedError("from_osc_block: sample width %d" % width)
+        if amplitude_scale is None:
+            amplitude_scale = 2 ** (8 * width - 1) - 1
+        s = cls(samplerate=samplerate, nchannels=1, samplewidth=width)
+        if n:
+            dst = N.DeviceBuffer(n * width)
+            try:
+                N.check(N.lib().sh_quantize_f64(block_f64.handle, 0, n, float(amplitude_scale), width, dst.handle, 0))
+            finally:
+                if free_block:
+                    block_f64.free()
+            s._set_device(dst, n * width)
+        return s
+
     # -- accessors -------------------------------------------------------------------------------
     @property
     def samplewidth(self) -> int:

@@ -4,7 +4,8 @@ mounted, so names/signatures are as recalled): ``sine()``, ``square()``, ``squar
 ``sawtooth()``, ``sawtooth_h()``, ``pulse()``, ``harmonics()`` return a ``Sample`` of ``duration`` seconds,
 the ``*_gen`` forms return the oscillator, plus the equal-temperament note tables.  It is a thin caller of
 the oscillators and of ``Sample.from_osc_block`` -- no arithmetic of its own: the block is rendered on
-the GPU, quantised on the GPU (``int(scale*v)``, scale = 2**(8*width-1)-1) and stays in HBM.
+the GPU in float64 (the reference's arithmetic), quantised on the GPU from that float64 block
+(``int(scale*v)``, scale = 2**(8*width-1)-1) and stays in HBM.
 """
 from __future__ import annotations
 
@@ -66,8 +67,14 @@ class WaveSynth:
     def to_sample(self, osc: Oscillator, duration: float) -> Sample:
         """``duration`` seconds of the oscillator, quantised to this synth's sample width."""
         n = int(self.samplerate * duration)
-        block = osc.render(n, start=0)
-        return Sample.from_osc_block(block, self.samplerate, samplewidth=self.samplewidth)
+        limit = osc.length
+        if limit is not None:
+            n = min(n, limit)
+        if n <= 0:
+            return Sample(samplerate=self.samplerate, nchannels=1, samplewidth=self.samplewidth)
+        # float64 block in HBM -> int(scale * v) on the device: the float32 storage format is never an intermediate
+        block = osc._render_f64_device(0, n)
+        return Sample.from_osc_device(block, n, self.samplerate, samplewidth=self.samplewidth)
 
     # -- oscillator factories (upstream: the *_gen methods) ------------------------------------------
     def sine_gen(self, frequency, amplitude=0.9999, phase=0.0, bias=0.0, fm_lfo=None) -> Oscillator:

@@ -198,6 +198,7 @@ def test_late_window_phase_precision(gpu):
 
 
 def test_blocks_protocol(gpu):
+    """blocks() yields float64 (upstream: lists of Python floats), not float32-rounded values."""
     from synthesizer_amd import oscillators as G, params
     g = G.Sawtooth(100, samplerate=SR)
     o = O.Sawtooth(100, samplerate=SR)
@@ -206,8 +207,20 @@ def test_blocks_protocol(gpu):
         b, w = next(gb), next(ob)
         assert isinstance(b, list) and len(b) == params.norm_osc_blocksize == len(w)
         assert isinstance(b[0], float)
-        assert rms(b, w) <= RMS_TOL
+        assert np.max(np.abs(np.array(b) - np.array(w))) <= 1e-12
     assert len(next(iter(g))) == params.norm_osc_blocksize
+    # transcendental kinds: float64 all the way (a float32-rounded block would sit at ~3e-8)
+    for name, args in (("Sine", (440.0, 0.8)), ("Harmonics", (220.0, [(1, 1.0), (2, 0.5), (5, 0.2)], 0.4)), ("Triangle", (330.0,))):
+        gg, oo = _pair(name, *args, samplerate=SR)
+        gb, ob = gg.blocks(), oo.blocks()
+        for _ in range(130):                         # crosses the 128-block superblock of one kernel launch
+            b, w = next(gb), next(ob)
+        assert np.max(np.abs(np.array(b) - np.array(w))) <= 1e-12, name
+    # Square / Pulse / Linear: equal
+    gg, oo = _pair("Square", 1000.0, 0.7, samplerate=SR)
+    assert next(gg.blocks()) == next(oo.blocks())
+    got = G.Sine(440.0, samplerate=SR).render_f64(1000, start=5)
+    assert got.dtype == np.float64 and np.max(np.abs(got - np.array(O.Sine(440.0, samplerate=SR).take(1005))[5:])) <= 1e-12
 
 
 def test_quantise_bit_exact_and_overflow(gpu):
@@ -299,7 +312,7 @@ def test_filters(gpu):
 
 
 def test_wavesynth_facade(gpu):
-    """WaveSynth methods = oscillator + Sample.from_osc_block, bit-exact int16."""
+    """WaveSynth methods = oscillator (float64 block) + Sample.from_osc_block: bit-exact int16."""
     from synthesizer_amd.synth import WaveSynth
     ws = WaveSynth(samplerate=22050, samplewidth=2)
     dur = 0.25
@@ -321,11 +334,22 @@ def test_wavesynth_facade(gpu):
         assert sample.samplerate == 22050 and sample.nchannels == 1 and sample.samplewidth == 2 and len(sample) == n, name
         got = np.array(sample.get_frame_array())
         want = np.array(O.quantise(osc.take(n)))
-        # the float32 block differs from the float64 oracle by <= 1e-7, so a sample sitting within that of an
-        # integer boundary may land one step away; everything else is identical
-        assert np.max(np.abs(got - want)) <= 1, name
-        assert np.mean(got != want) < 0.02, name
-    assert WaveSynth(samplewidth=4).sine(100, 0.01).samplewidth == 4
+        # float64 block -> int(scale * v): the reference's own route, no float32 on the way
+        assert np.array_equal(got, want), (name, int(np.sum(got != want)))
+    # 32-bit samples: every one of the 31 magnitude bits comes from the float64 block
+    ws4 = WaveSynth(samplerate=22050, samplewidth=4)
+    for name, sample, osc in (("sine32", ws4.sine(440, dur), O.Sine(440, 0.9999, samplerate=22050)),
+                              ("harm32", ws4.harmonics(220, dur, [(1, 1.0), (3, 0.3)], amplitude=0.4),
+                               O.Harmonics(220, [(1, 1.0), (3, 0.3)], 0.4, samplerate=22050)),
+                              ("saw32", ws4.sawtooth(330, dur), O.Sawtooth(330, 0.75, samplerate=22050))):
+        got = np.array(sample.get_frame_array(), dtype=np.int64)
+        want = np.array(O.quantise(osc.take(n), 4), dtype=np.int64)
+        assert sample.samplewidth == 4
+        # scale 2^31-1 magnifies the ~2e-16 difference between the table-driven sin and libm's to ~1e-6 of an LSB:
+        # a sample within that of an integer may land on the other side
+        assert np.max(np.abs(got - want)) <= 1 and np.mean(got != want) < 1e-4, (name, int(np.sum(got != want)))
+    assert np.array_equal(np.array(ws4.square(440, dur, amplitude=0.5).get_frame_array()),
+                          np.array(O.quantise(O.Square(440, 0.5, samplerate=22050).take(n), 4)))
 
 
 def test_randomised_voices_vs_c_oracle(gpu):
