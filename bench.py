@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the oscillator-bank + mixer hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -9,20 +9,30 @@ Workload (BASELINE.json metric): 1024 additive voices PE
 Harmonics oscillator with 16 partials a_k = 1/k under an ADSR envelope, f log-uniform in [55, 3520] Hz,
 random phase/pan, seed 0 -- mixed to one float32 stereo bus at 48 kHz.  One step = one block of 48 000
 frames (1 s of audio) rendered by the fused generate-and-mix kernel; steps render consecutive blocks and
-the envelope spans the whole run (no silent voices).  With N > 1 the voice table (N x 1024 voices, weak
-scaling; configs[3] at N = 8) is sharded across ranks and the float64 partial buses are summed to rank 0
-by RCCL every step.
+the envelope's sustain spans the whole run (no silent voices).  With N > 1 the voice table is sharded
+across ranks and the float64 partial buses are summed to rank 0 by RCCL: `--scaling weak` (default)
+N x 1024 voices (configs[3] at N = 8), `--scaling strong` 8192 voices whatever N.
+
+Timing: W untimed warm-up steps, then PASSES of exactly K steps, each pass bracketed by barrier +
+device synchronisation on both sides and clocked on every rank (maximum over ranks).  Passes repeat
+(consecutive blocks of the same stream) until the timed passes add up to >= --min-seconds (0.25 s): one
+pass of the driver's K = 20 lasts under a millisecond, less than the GPU's clock governor needs to
+leave its idle state (the first ~50 ms of a run are up to 25 % slower), so a single pass measures the
+governor, not the kernel.  `value` / `ms_per_step` are those of the MEDIAN pass (`passes` lists count,
+median, min, first); a step stays one block.
 
 value = voice-samples mixed per second over all ranks / 1e6 ("Msamples/s"), inputs (the voice table)
-resident in HBM before the timed region.  The same run also times (a) the reference-shaped two-step
-path (voices materialised as float32 PCM in HBM, then the HBM-bound mixer kernel) and (b) the CPU
-oracle (pure-Python generators, 1 core) on a bounded sample -- reported beside, never as `value`.
+resident in HBM before the timed region.  The same run also times the other BASELINE configs
+(`configs`), the reference-shaped two-step path (voices materialised as float32 PCM in HBM, then the
+HBM-bound mixer kernel), the PCM rows (resample = configs[4], integer mixer chain, audioop.add ...) and
+the CPU oracle (pure-Python generators) on a bounded sample -- reported beside, never as `value`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -32,32 +42,54 @@ sys.path.insert(0, str(ROOT))
 
 SR = 48000
 VOICES_PER_GPU = 1024
+STRONG_VOICES = 8192           # BASELINE configs[3]
 PARTIALS = 16
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-FP64_PEAK_GOPS = 256 * 4 * 16 * 2.4   # float64 FMA lanes/s (78.6 TFLOP/s spec / 2), in G lane-ops/s
+FP64_PEAK_TOPS = 256 * 4 * 16 * 2.4 / 1e3   # float64 VALU issue peak: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s
+                                            # (an FMA, a MUL and an ADD each take one lane-op slot; 78.6 TFLOP/s spec = 2 x this)
+ADSR_BENCH = {"sustain": 1.0e6}             # attack 0.01, decay 0.05, release 0.2 as SURVEY 8(d); the sustain spans any run
 
 
-def build_voices(n_total: int, seconds_total: float):
+def gloo_broadcast(payload, rank: int, world: int, nbytes: int) -> bytes:
+    """The rendezvous channel bench.py hands to synthesizer_amd.dist.init under torchrun: 128 opaque bytes from rank 0
+    over the (gloo) process group that the launcher plumbing already has.  torch never enters the product package."""
+    import torch
+    import torch.distributed as td
+    t = torch.zeros(nbytes, dtype=torch.uint8)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+    td.broadcast(t, src=0)
+    return bytes(t.numpy().tobytes())
+
+
+def build_voices(n_total: int):
     from synthesizer_amd import oscillators as G
     from synthesizer_amd import workloads as W
-    # envelope spans the whole run: attack 0.01, decay 0.05, release 0.2, sustain fills the rest
-    return W.additive_voices(G, n_total, SR, seed=0, partials=PARTIALS,
-                             adsr={"sustain": max(0.0, seconds_total - 0.26)})
+    return W.additive_voices(G, n_total, SR, seed=0, partials=PARTIALS, adsr=ADSR_BENCH)
 
 
-def cpu_baseline(frames: int):
+def _cpu_shard(args):
+    lo, hi, frames = args
+    from oracle import synth_oracle as O
+    from synthesizer_amd import workloads as W
+    voices, gains = W.additive_voices(O, VOICES_PER_GPU, SR, seed=0, partials=PARTIALS, adsr=ADSR_BENCH)
+    return O.mix_bus([v.take(frames) for v in voices[lo:hi]], gains[lo:hi])
+
+
+def cpu_baseline(frames: int, all_cores: bool = True):
     """The oracle (pure-Python generator restatement of the reference path) on ONE core, timed on a
     bounded sample of the same workload: all 1024 voices x `frames` frames, mixed to the stereo bus."""
     from oracle import synth_oracle as O
     from synthesizer_amd import workloads as W
-    voices, gains = W.additive_voices(O, VOICES_PER_GPU, SR, seed=0, partials=PARTIALS)
+    voices, gains = W.additive_voices(O, VOICES_PER_GPU, SR, seed=0, partials=PARTIALS, adsr=ADSR_BENCH)
     t0 = time.perf_counter()
     blocks = [v.take(frames) for v in voices]
     O.mix_bus(blocks, gains)
     dt = time.perf_counter() - t0
     out = {"value": VOICES_PER_GPU * frames / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-           "sample": "1024 voices x %d frames (%.3f s of audio), pure-Python oracle generators + float bus sum, "
-                     "%.1f s wall" % (frames, frames / SR, dt)}
+           "sample": "1024 voices (the bench's: Harmonics x16 + ADSR attack 0.01 / decay 0.05 / sustain spanning the run, level 0.6) "
+                     "x the first %d frames (%.3f s of audio: attack, decay and the start of the sustain), pure-Python oracle "
+                     "generators + float bus sum, %.1f s wall" % (frames, frames / SR, dt)}
     # the same sample through the C restatement of the oracle (oracle/oracle.c, one core): what a compiled single-threaded
     # CPU implementation of this arithmetic does -- a fairer yardstick than the interpreter
     try:
@@ -70,21 +102,72 @@ def cpu_baseline(frames: int):
         out["c_port"] = {"value": VOICES_PER_GPU * frames / dtc / 1e6, "unit": "Msamples/s", "cores": 1, "wall_s": dtc}
     except Exception as e:                           # no C compiler on the box: the Python number stands alone
         out["c_port"] = {"error": str(e)}
+    # BASELINE.md's optional leg: the same pure-Python sample over all host cores (one process per core, voices split evenly)
+    if all_cores:
+        try:
+            import multiprocessing as mp
+            ncores = os.cpu_count() or 1
+            nproc = max(1, min(ncores, 64))
+            bounds = [(VOICES_PER_GPU * i // nproc, VOICES_PER_GPU * (i + 1) // nproc, frames) for i in range(nproc)]
+            with mp.get_context("spawn").Pool(nproc) as pool:
+                pool.map(_cpu_shard, [(0, 1, 16)] * nproc)           # start the workers and import the oracle outside the timed region
+                t0 = time.perf_counter()
+                parts = pool.map(_cpu_shard, bounds)
+                dta = time.perf_counter() - t0
+            del parts
+            out["all_cores"] = {"value": VOICES_PER_GPU * frames / dta / 1e6, "unit": "Msamples/s", "cores": nproc,
+                                "host_cpu_count": ncores, "wall_s": dta,
+                                "note": "multiprocessing over voices, one process per core; the partial buses' final sum is not timed"}
+        except Exception as e:
+            out["all_cores"] = {"error": str(e)}
     return out
 
 
-def measured_traffic():
-    """HBM bytes per dispatch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, profiles/rNN_traffic.json written by tools/summarize_profiles.py); None when absent."""
-    best = None
-    for p in sorted((ROOT / "profiles").glob("r*_traffic.json")):
-        best = p
-    if best is None:
-        return {}, None
-    try:
-        return json.loads(best.read_text()), best.name
-    except Exception:
-        return {}, None
+def committed_profile():
+    """The newest committed rocprofv3 summary: HBM bytes per dispatch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) and
+    the SQ instruction counters per dispatch (profiles/rNN_traffic.json, profiles/rNN_counters.json, both written by
+    tools/summarize_profiles.py), with the hash of the kernel sources they were measured on."""
+    out = {"traffic": {}, "counters": {}, "source": None, "source_hash": None}
+    tr = sorted((ROOT / "profiles").glob("r*_traffic.json"))
+    if tr:
+        try:
+            out["traffic"] = json.loads(tr[-1].read_text())
+            out["source"] = tr[-1].name
+        except Exception:
+            pass
+    cn = sorted((ROOT / "profiles").glob("r*_counters.json"))
+    if cn:
+        try:
+            c = json.loads(cn[-1].read_text())
+            out["source_hash"] = c.get("_meta", {}).get("source_hash")
+            out["counters"] = {k: v for k, v in c.items() if not k.startswith("_")}
+            out["counters_source"] = cn[-1].name
+        except Exception:
+            pass
+    return out
+
+
+def _by_prefix(table, prefix):
+    for k, v in table.items():
+        if k.startswith(prefix):
+            return v
+    return None
+
+
+def steady(N, call, min_seconds=0.05, reps=5, max_loops=400):
+    """Average time (ms, HIP events on the library stream) of `call` once the clocks are up: loops of `reps` calls until
+    the loops add up to min_seconds; the median loop counts."""
+    call()
+    N.sync()
+    loops, total = [], 0.0
+    while (total < min_seconds or len(loops) < 3) and len(loops) < max_loops:
+        N.timer_start()
+        for _ in range(reps):
+            call()
+        ms = N.timer_stop()
+        loops.append(ms / reps)
+        total += ms / 1e3
+    return statistics.median(loops)
 
 
 def pcm_rows(N):
@@ -93,6 +176,13 @@ def pcm_rows(N):
     import numpy as np
     L = N.lib()
     rows = {}
+
+    def row(name, call, nbytes, **extra):
+        ms = steady(N, lambda: N.check(call()), min_seconds=0.02, reps=3)
+        rows[name] = dict({"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
+                           "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}, **extra)
+        return ms
+
     # configs[4]: 8-channel, 10-minute float32 PCM, 96 kHz -> 44.1 kHz (1.84 GB in, 0.85 GB out)
     nch, in_frames = 8, 96000 * 600
     nout = L.sh_resample_out_frames(in_frames, 96000, 44100)
@@ -104,34 +194,17 @@ def pcm_rows(N):
     for width, is_float, name in ((4, 1, "resample_f32_8ch_600s_96k_to_44k1"), (2, 0, "resample_i16_8ch_1200s_96k_to_44k1")):
         frames = in_frames if is_float else in_frames * 2       # same byte count as the float case
         nout_w = L.sh_resample_out_frames(frames, 96000, 44100)
-        for _ in range(2):
-            N.check(L.sh_resample(src.handle, frames, nch, width, is_float, 96000, 44100, dst.handle, None))
-        N.sync()
-        reps = 5
-        N.timer_start()
-        for _ in range(reps):
-            N.check(L.sh_resample(src.handle, frames, nch, width, is_float, 96000, 44100, dst.handle, None))
-        ms = N.timer_stop() / reps
-        nbytes = (frames + nout_w) * nch * width
-        rows[name] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9, "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                      "out_Mframes_per_s": nout_w / (ms / 1e3) / 1e6}
+        ms = row(name, lambda: L.sh_resample(src.handle, frames, nch, width, is_float, 96000, 44100, dst.handle, None),
+                 (frames + nout_w) * nch * width)
+        rows[name]["out_Mframes_per_s"] = nout_w / (ms / 1e3) / 1e6
     # 16-bit mono / stereo, the shapes Sample.resample sees in practice (WaveSynth output, loaded WAVs): 900 MB in
-    for name, nch, inr, outr in (("resample_i16_mono_44k1_to_48k_900MB", 1, 44100, 48000),
-                                 ("resample_i16_stereo_44k1_to_48k_900MB", 2, 44100, 48000),
-                                 ("resample_i16_stereo_96k_to_44k1_900MB", 2, 96000, 44100)):
-        frames = 450_000_000 // nch
+    for name, nch_, inr, outr in (("resample_i16_mono_44k1_to_48k_900MB", 1, 44100, 48000),
+                                  ("resample_i16_stereo_44k1_to_48k_900MB", 2, 44100, 48000),
+                                  ("resample_i16_stereo_96k_to_44k1_900MB", 2, 96000, 44100)):
+        frames = 450_000_000 // nch_
         nout_m = L.sh_resample_out_frames(frames, inr, outr)
-        big = N.DeviceBuffer(nout_m * 2 * nch)
-        for _ in range(2):
-            N.check(L.sh_resample(src.handle, frames, nch, 2, 0, inr, outr, big.handle, None))
-        N.sync()
-        N.timer_start()
-        for _ in range(5):
-            N.check(L.sh_resample(src.handle, frames, nch, 2, 0, inr, outr, big.handle, None))
-        ms = N.timer_stop() / 5
-        nbytes = (frames + nout_m) * 2 * nch
-        rows[name] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
-                      "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+        big = N.DeviceBuffer(nout_m * 2 * nch_)
+        row(name, lambda: L.sh_resample(src.handle, frames, nch_, 2, 0, inr, outr, big.handle, None), (frames + nout_m) * 2 * nch_)
         big.free()
     # mixer chain: 1024 int16 voices x 10 s stereo (saturating fold in voice order), 2N+2 bytes per sample
     nv, nsamples = 1024, 48000 * 2 * 10
@@ -140,71 +213,74 @@ def pcm_rows(N):
     for off in range(0, chunks.nbytes, pcm.nbytes):
         chunks.upload(pcm[:min(len(pcm), (chunks.nbytes - off) // 2)], off)
     mixed = N.DeviceBuffer(nsamples * 2)
-    for _ in range(2):
-        N.check(L.sh_mix_chain_i16(chunks.handle, nv, nsamples, nsamples, mixed.handle))
-    N.sync()
-    N.timer_start()
-    for _ in range(5):
-        N.check(L.sh_mix_chain_i16(chunks.handle, nv, nsamples, nsamples, mixed.handle))
-    ms = N.timer_stop() / 5
     nbytes = (2 * nv + 2) * nsamples
-    rows["mix_chain_i16_1024v_10s_stereo"] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
-                                              "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    row("mix_chain_i16_1024v_10s_stereo", lambda: L.sh_mix_chain_i16(chunks.handle, nv, nsamples, nsamples, mixed.handle), nbytes)
     # the same fold through the pointer table (RealTimeMixer / mix_samples: every source read where it lives)
     bufs = (ctypes.c_void_p * nv)(*[chunks.handle] * nv)
     offs = (ctypes.c_size_t * nv)(*[v * nsamples for v in range(nv)])
     lens = (ctypes.c_uint32 * nv)(*[nsamples] * nv)
-    for _ in range(2):
-        N.check(L.sh_mix_chain_gather_i16(bufs, offs, lens, nv, nsamples, mixed.handle, 0))
-    N.sync()
-    N.timer_start()
-    for _ in range(5):
-        N.check(L.sh_mix_chain_gather_i16(bufs, offs, lens, nv, nsamples, mixed.handle, 0))
-    ms = N.timer_stop() / 5
-    rows["mix_chain_gather_i16_1024v_10s_stereo"] = {"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
-                                                     "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    row("mix_chain_gather_i16_1024v_10s_stereo", lambda: L.sh_mix_chain_gather_i16(bufs, offs, lens, nv, nsamples, mixed.handle, 0), nbytes)
     # one real-time turn: 64 sources x 4096-byte chunk (latency-bound: table upload + one small kernel)
     small = 2048
-    for _ in range(3):
-        N.check(L.sh_mix_chain_gather_i16(bufs, offs, lens, 64, small, mixed.handle, 0))
-    N.sync()
-    N.timer_start()
-    for _ in range(200):
-        N.check(L.sh_mix_chain_gather_i16(bufs, offs, lens, 64, small, mixed.handle, 0))
-    rows["mixer_turn_64src_4KB_chunk"] = {"ms": N.timer_stop() / 200}
+    rows["mixer_turn_64src_4KB_chunk"] = {"ms": steady(N, lambda: N.check(L.sh_mix_chain_gather_i16(bufs, offs, lens, 64, small, mixed.handle, 0)),
+                                                        min_seconds=0.01, reps=50)}
     # Sample.from_osc_block: float32 -> int16 with the overflow check (the call returns after reading the flag back)
     nq = 300_000_000
-    for _ in range(2):
-        N.check(L.sh_quantize_f32(src.handle, 0, nq, 32767.0, 2, dst.handle, 0))
-    N.timer_start()
-    for _ in range(5):
-        N.check(L.sh_quantize_f32(src.handle, 0, nq, 32767.0, 2, dst.handle, 0))
-    ms = N.timer_stop() / 5
-    rows["quantize_f32_to_i16_1200MB"] = {"ms": ms, "bytes": 6 * nq, "GBps": 6 * nq / (ms / 1e3) / 1e9,
-                                          "frac_hbm": 6 * nq / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    row("quantize_f32_to_i16_1200MB", lambda: L.sh_quantize_f32(src.handle, 0, nq, 32767.0, 2, dst.handle, 0), 6 * nq)
+    nq64 = 150_000_000
+    row("quantize_f64_to_i16_1200MB", lambda: L.sh_quantize_f64(src.handle, 0, nq64, 32767.0, 2, dst.handle, 0), 10 * nq64,
+        note="the float32 buffer read as float64 bit patterns: tiny magnitudes, same traffic")
     # Sample.mix: saturating add of two 900 MB int16 buffers (3 bytes moved per byte of output)
     n = 900_000_000
-    N.timer_start()
-    for _ in range(5):
-        N.check(L.sh_pcm_add(chunks.handle, 0, chunks.handle, n, n, 2, src.handle, 0))
-    ms = N.timer_stop() / 5
-    rows["pcm_add_i16_900MB"] = {"ms": ms, "bytes": 3 * n, "GBps": 3 * n / (ms / 1e3) / 1e9, "frac_hbm": 3 * n / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    row("pcm_add_i16_900MB", lambda: L.sh_pcm_add(chunks.handle, 0, chunks.handle, n, n, 2, src.handle, 0), 3 * n)
     # Sample.amplify (audioop.mul), Sample.mono (audioop.tomono), peak/rms
-    n = 900_000_000
-    for name, call, moved in (
-            ("pcm_mul_i16_900MB", lambda: L.sh_pcm_mul(chunks.handle, 0, n, 2, 0.7071, src.handle, 0), 2 * n),
-            ("pcm_tomono_i16_900MB", lambda: L.sh_pcm_tomono(chunks.handle, n // 4, 2, 0.5, 0.5, src.handle), n + n // 2),
-            ("pcm_stats_i16_900MB", lambda: L.sh_pcm_stats(chunks.handle, n, 2, ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_double())), n),
-            ("pcm_stats_stereo_i16_900MB", lambda: L.sh_pcm_stats_stereo(chunks.handle, n // 4, 2, (ctypes.c_uint32 * 2)(), (ctypes.c_double * 2)()), n)):
-        N.check(call())
-        N.sync()
-        N.timer_start()
-        for _ in range(5):
-            N.check(call())
-        ms = N.timer_stop() / 5
-        rows[name] = {"ms": ms, "bytes": moved, "GBps": moved / (ms / 1e3) / 1e9, "frac_hbm": moved / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}
+    row("pcm_mul_i16_900MB", lambda: L.sh_pcm_mul(chunks.handle, 0, n, 2, 0.7071, src.handle, 0), 2 * n)
+    row("pcm_tomono_i16_900MB", lambda: L.sh_pcm_tomono(chunks.handle, n // 4, 2, 0.5, 0.5, src.handle), n + n // 2)
+    row("pcm_stats_i16_900MB", lambda: L.sh_pcm_stats(chunks.handle, n, 2, ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_double())), n)
+    row("pcm_stats_stereo_i16_900MB", lambda: L.sh_pcm_stats_stereo(chunks.handle, n // 4, 2, (ctypes.c_uint32 * 2)(), (ctypes.c_double * 2)()), n)
     for b in (src, dst, chunks, mixed):
         b.free()
+    return rows
+
+
+def config_rows(N):
+    """The BASELINE configs other than the headline, each on its own steady-state loop (one MI355X)."""
+    import numpy as np
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd import workloads as W
+    from synthesizer_amd.mixer import VoiceBank
+    rows = {}
+    # configs[0]: single 440 Hz Sine, 1 s @ 44.1 kHz mono, delivered to a host array (the call includes the D2H copy)
+    osc = G.Sine(440, samplerate=44100)
+    osc.render(44100)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        osc.render(44100, start=0)
+    dt = (time.perf_counter() - t0) / 200
+    rows["config1_sine_440Hz_1s_44k1_mono_to_host"] = {"ms": dt * 1e3, "Msamples_per_s": 44100 / dt / 1e6,
+                                                        "note": "Oscillator.render -> numpy float32 on the host, wall clock, PCIe copy included"}
+
+    def bank_row(name, voices, gains, note):
+        bank = VoiceBank(voices, gains=gains)
+        ring = [N.DeviceBuffer(SR * 8) for _ in range(4)]
+        pos = [0]
+
+        def step():
+            bank.render_device(SR, pos[0] * SR, bus_f32=ring[pos[0] & 3])
+            pos[0] += 1
+        for _ in range(8):
+            step()
+        ms = steady(N, step, min_seconds=0.1, reps=20)
+        rows[name] = {"voices": len(voices), "ms_per_1s_block": ms, "Msamples_per_s": len(voices) * SR / (ms / 1e3) / 1e6,
+                      "realtime_factor": 1e3 / ms, "note": note}
+        for b in ring:
+            b.free()
+    v, g = W.additive_voices(G, 64, SR, seed=0, partials=PARTIALS, adsr=ADSR_BENCH)
+    bank_row("config2_additive_64v_adsr_48k_stereo", v, g, "64 Harmonics x16 voices + ADSR -> float32 stereo bus; launch-bound (64 voices do not fill 256 CUs)")
+    v, g = W.fm_voices(G, 1024, SR, seed=1)
+    bank_row("config3_fm_1024v_48k_stereo", v, g, "1024 Sine carriers, each with a Sine fm_lfo (closed-form running sum), -> float32 stereo bus")
+    rows["config4_8192v_8gpu"] = {"note": "python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 [--scaling strong]; not measurable on a 1-GPU box"}
+    rows["config5_resample_8ch_600s_96k_to_44k1"] = {"note": "pcm_rows.resample_f32_8ch_600s_96k_to_44k1"}
     return rows
 
 
@@ -214,9 +290,15 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=SR, help="frames per step (block size)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 1024 voices per GPU; strong: 8192 voices in total (BASELINE configs[3]) whatever --gpus")
+    ap.add_argument("--min-seconds", type=float, default=0.25, help="passes of K steps repeat until they add up to this much timed work")
+    ap.add_argument("--max-passes", type=int, default=4000)
     ap.add_argument("--cpu-frames", type=int, default=12288, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu-all-cores", action="store_true")
     ap.add_argument("--no-pcm-rows", action="store_true", help="skip the resample / integer-mix rows")
     ap.add_argument("--no-two-step", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the rows of the other BASELINE configs")
     ap.add_argument("--reduce-batch", type=int, default=8, help="blocks per RCCL reduce when --gpus > 1 (also the length of a run of pipelined renders)")
     args = ap.parse_args()
 
@@ -230,21 +312,23 @@ def main() -> int:
     td = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
         import torch.distributed as td      # plumbing only: barrier + max over ranks + id broadcast
         td.init_process_group("gloo", rank=rank, world_size=world)
 
     from synthesizer_amd import _native as N
+    from synthesizer_amd import build as B
     from synthesizer_amd import dist
     N.ensure_init(local_rank)
     info = N.device_info()
     if world > 1:
-        dist.init(rank, world)
+        dist.init(rank, world, broadcast=gloo_broadcast)
 
     K, Wm, F = args.steps, args.warmup, args.frames
-    total_voices = VOICES_PER_GPU * world
-    seconds_total = (K + Wm) * F / SR
-    voices, gains = build_voices(total_voices, seconds_total)
+    total_voices = STRONG_VOICES if args.scaling == "strong" else VOICES_PER_GPU * world
+    voices, gains = build_voices(total_voices)
     bank = dist.DistVoiceBank(voices, gains, rank, world, batch=args.reduce_batch)
+    local_voices = bank.hi - bank.lo
     L = N.lib()
 
     def barrier():
@@ -252,83 +336,160 @@ def main() -> int:
         if td is not None:
             td.barrier()
 
+    def allmax(*vals):
+        if td is None:
+            return vals
+        t = torch.tensor(list(vals), dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return tuple(float(x) for x in t)
+
     # ---- fused path (headline) ----
     for s in range(Wm):
         bank.render_device(F, s * F)
     bank.flush()
     barrier()
-    t0 = time.perf_counter()
-    N.timer_start()
-    for s in range(K):
-        bank.render_device(F, (Wm + s) * F)
-    bank.flush()
-    host_enqueue = time.perf_counter() - t0      # host time to enqueue all K steps (launches are asynchronous)
-    ev_ms = N.timer_stop()           # HIP events on the library stream (also synchronises it)
-    barrier()
-    wall = time.perf_counter() - t0
-    if td is not None:
-        import torch
-        t = torch.tensor([wall, ev_ms], dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        wall, ev_ms = float(t[0]), float(t[1])
+    passes = []               # (wall s, HIP-event ms) of each pass of K steps, max over ranks
+    step0, timed = Wm, 0.0
+    host_enqueue = 0.0
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        N.timer_start()
+        for s in range(K):
+            bank.render_device(F, (step0 + s) * F)
+        bank.flush()
+        host_enqueue = time.perf_counter() - t0      # host time to enqueue all K steps (launches are asynchronous)
+        ev_ms = N.timer_stop()                       # HIP events on the library stream (also synchronises it)
+        barrier()
+        wall = time.perf_counter() - t0
+        wall, ev_ms = allmax(wall, ev_ms)
+        passes.append((wall, ev_ms))
+        step0 += K
+        timed += wall
+        if (timed >= args.min_seconds and len(passes) >= 3) or len(passes) >= args.max_passes:
+            break
+    walls = sorted(p[0] for p in passes)
+    wall = statistics.median(walls)
+    ev_ms = statistics.median(sorted(p[1] for p in passes))
 
-    traffic, traffic_src = measured_traffic()
-
-    def traffic_of(prefix):
-        for k, v in traffic.items():
-            if k.startswith(prefix):
-                return v["hbm_bytes"]
-        return None
+    prof = committed_profile()
+    src_hash = B.source_hash()
+    prof_stale = prof["source_hash"] is not None and prof["source_hash"] != src_hash
 
     voice_samples = float(total_voices) * F * K
     value = voice_samples / wall / 1e6
-    kern_s = ev_ms / 1e3 / K         # average duration of one block (k_locate + k_bank_render [+ reduce/finalize])
+    kern_s = ev_ms / 1e3 / K         # time per block of the stream of launches: HIP events over the median pass / K
     fused_bytes = 8.0 * F            # algorithmic: one float32 stereo frame written per output frame
-    # float64 VALU lane-operations per voice-sample of k_bank_render on this workload, from rocprofv3:
-    # (SQ_INSTS_VALU_FMA_F64 + MUL_F64 + ADD_F64) * 64 / voice-samples per launch = 20.34 M * 64 / 49.152 M
-    # (profiles/r01_summary.md, "SQ instruction mix"; all VALU: 33.0 per voice-sample, prepare step included)
-    harm_lane_ops = 26.5
+    # float64 VALU lane-operations per voice-sample of the render kernel on this workload, from the committed rocprofv3
+    # counters: (SQ_INSTS_VALU_FMA_F64 + MUL_F64 + ADD_F64) wave-instructions x 64 lanes / voice-samples per dispatch
+    render_counters = _by_prefix(prof["counters"], "k_bank_render")
+    if render_counters and all(k in render_counters for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")):
+        fma, mul, add = (render_counters[k] for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"))
+        per_launch = float(VOICES_PER_GPU * SR)      # the profiled dispatches: 1024 voices x 48 000 frames each (tools/profile_round.sh)
+        lane_ops = (fma + mul + add) * 64.0 / per_launch
+        flops_per_vs = (2.0 * fma + mul + add) * 64.0 / per_launch
+        ops_source = prof.get("counters_source")
+    else:
+        lane_ops, flops_per_vs = 25.97, 25.97 + 16448494 * 64.0 / (VOICES_PER_GPU * SR)     # profiles/r01_summary.md
+        ops_source = "profiles/r01_summary.md (literal: no rNN_counters.json committed)"
+    valu_achieved = local_voices * F * lane_ops / kern_s / 1e12
+    traffic = _by_prefix(prof["traffic"], "k_bank_render")
+    traffic_bytes = traffic["hbm_bytes"] if traffic else None
     out = {
         "metric": "Msamples/sec mixed to stereo bus, 1024-voice additive @48kHz",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": Wm,
-        "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%d-voice additive (Harmonics x%d partials + ADSR) -> float32 stereo bus, 48 kHz, "
                                "fused generate-and-mix, block %d frames" % (total_voices, PARTIALS, F),
-                   "voices_per_gpu": VOICES_PER_GPU, "frames_per_step": F, "samplerate": SR,
-                   "parallelism": ("voice-shard x%d, pipelined RCCL reduce of float64 partial buses every %d blocks" % (world, bank.batch)) if world > 1 else "single GPU"},
+                   "voices_total": total_voices, "voices_this_rank": local_voices, "frames_per_step": F, "samplerate": SR,
+                   "adsr": "attack 0.01 s, decay 0.05 s, sustain level 0.6 held for the whole run (SURVEY 8(d)'s 0.5 s sustain would leave "
+                           "every block after the first silent), release 0.2 s",
+                   "parallelism": ("voice-shard x%d (%s scaling), pipelined RCCL reduce of float64 partial buses every %d blocks"
+                                   % (world, args.scaling, bank.batch)) if world > 1 else "single GPU"},
+        "passes": {"count": len(passes), "steps_per_pass": K, "timed_region_s": timed,
+                   "median_ms_per_step": wall * 1e3 / K, "min_ms_per_step": walls[0] * 1e3 / K, "max_ms_per_step": walls[-1] * 1e3 / K,
+                   "first_pass_ms_per_step": passes[0][0] * 1e3 / K,
+                   "value_of_min_pass": voice_samples / walls[0] / 1e6,
+                   "note": "every pass = exactly K consecutive blocks between barrier + device sync on both sides, max over ranks; "
+                           "value / ms_per_step are the median pass's; the first passes run while the clock governor ramps up"},
         "frames_per_s": F * K / wall,
         "host_enqueue_ms_per_step": host_enqueue * 1e3 / K,
         "realtime_factor": F * K / wall / SR,
         "device": info["name"] or "AMD Instinct MI355X", "arch": info["arch"],
+        "library": L.sh_version().decode(),
         "roofline": {
-            "kernel": "k_bank_render<4,4,4,1>", "bound": "hbm",
-            "achieved": fused_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": fused_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("k_bank_render"),
-            "traffic_source": traffic_src,
-            "note": "fused kernel writes 8 B per output frame: VALU(float64)-bound by construction, see valu",
-            "valu": {"unit": "G f64 lane-ops/s", "achieved": VOICES_PER_GPU * F * harm_lane_ops / kern_s / 1e9,
-                     "peak": FP64_PEAK_GOPS, "frac": VOICES_PER_GPU * F * harm_lane_ops / kern_s / 1e9 / FP64_PEAK_GOPS,
-                     "ops_per_voice_sample": harm_lane_ops},
+            "kernel": "k_bank_render<4,4,4,1>", "bound": "valu_f64",
+            "achieved": valu_achieved, "peak": FP64_PEAK_TOPS, "unit": "T f64 lane-ops/s", "frac": valu_achieved / FP64_PEAK_TOPS,
+            "ops_per_voice_sample": lane_ops, "ops_source": ops_source,
+            "flops": {"achieved_TFLOPs": local_voices * F * flops_per_vs / kern_s / 1e12, "peak_TFLOPs": 2 * FP64_PEAK_TOPS,
+                      "frac": local_voices * F * flops_per_vs / kern_s / 1e12 / (2 * FP64_PEAK_TOPS),
+                      "note": "the same work counted in FLOPs (FMA = 2) against the 78.6 TFLOP/s vector figure: lower, because "
+                              "MUL and ADD fill an issue slot with one FLOP"},
+            "traffic": traffic_bytes, "traffic_source": prof["source"],
             "avg_launch_ms": kern_s * 1e3,
             "launches_in_flight": 1 if os.environ.get("SYNTHHIP_NO_OVERLAP") == "1" else 2,
-            "timing_note": "avg_launch_ms = HIP events over the timed region / launches (time per launch of the stream of "
-                           "launches); consecutive launches overlap pairwise on two streams, so one kernel's own start-to-end "
-                           "duration (rocprofv3 kernel trace) is about twice that -- profiles/r01_summary.md sets both against "
-                           "the serialised run (SYNTHHIP_NO_OVERLAP=1), where they coincide",
+            "why": "the fused kernel writes 8 B per output frame and reads only the voice table: HBM is idle by construction "
+                   "(SURVEY 8(d) regime ii); what binds is float64 VALU issue (one lane-op slot per FMA / MUL / ADD)",
+            "hbm": {"bound": "hbm", "achieved": fused_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": fused_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": fused_bytes,
+                    "traffic": traffic_bytes,
+                    "traffic_over_algorithmic": (traffic_bytes / fused_bytes) if traffic_bytes else None,
+                    "note": "measured traffic is the float64 partial buses of the voice groups (16 B x frames x groups written, "
+                            "then read by the fold two launches on) next to the 8 B per frame of the float32 bus"},
+            "profile_stale": prof_stale,
+            "profile_note": ("profiles/ counters were measured on kernel sources %s, this library is %s: traffic / ops per voice-sample "
+                             "may have drifted" % (prof["source_hash"], src_hash)) if prof_stale else
+                            ("profiles/ counters and this library share source hash %s" % src_hash if prof["source_hash"] else
+                             "profiles/ carries no source hash (pre-round-2 summary)"),
+            "timing_note": "avg_launch_ms = HIP events over the median pass / K (time per launch of the stream of launches); "
+                           "consecutive launches overlap pairwise on two streams, so one kernel's own start-to-end duration "
+                           "(rocprofv3 kernel trace) is about twice that -- profiles/ sets both against the serialised run "
+                           "(SYNTHHIP_NO_OVERLAP=1), where they coincide",
         },
     }
+
+    # ---- multi-GPU: what each rank spends on rendering and what the exchange adds ----
+    if world > 1:
+        ring = [N.DeviceBuffer(F * 16) for _ in range(4)]
+        pos = [step0]
+
+        def local_step():
+            bank.local.render_device(F, pos[0] * F, bus_f32=None, bus_f64=ring[pos[0] & 3])
+            pos[0] += 1
+        render_ms = steady(N, local_step, min_seconds=0.1, reps=K)
+        nval = bank.batch * F * 2
+        msg = N.DeviceBuffer(nval * 8)
+        msg.zero()
+        barrier()
+        N.timer_start()
+        for _ in range(20):
+            N.check(L.sh_dist_reduce_bus(msg.handle, nval, 0))
+        reduce_ms = N.timer_stop() / 20
+        barrier()
+        t = torch.tensor([render_ms, reduce_ms], dtype=torch.float64)
+        gathered = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        td.all_gather(gathered, t)
+        out["per_rank"] = {"render_us_per_step": [float(g[0]) * 1e3 for g in gathered],
+                           "blocking_reduce_us_per_call": [float(g[1]) * 1e3 for g in gathered],
+                           "reduce_message_bytes": nval * 8, "blocks_per_reduce": bank.batch,
+                           "step_us_with_exchange": wall * 1e6 / K,
+                           "exposed_exchange_us_per_step": wall * 1e6 / K - max(float(g[0]) for g in gathered) * 1e3,
+                           "note": "render: this rank's shard alone, no collective; blocking reduce: ncclReduce of one batch message "
+                                   "back to back on the main stream (the pipelined path hides it behind the next renders)"}
+        for b_ in ring:
+            b_.free()
+        msg.free()
 
     # ---- the same stream of blocks delivered as int16 PCM (what a player consumes): quantised by the fold itself ----
     if world == 1:
         ring = [N.DeviceBuffer(F * 4) for _ in range(4)]
-        for s in range(Wm):
-            bank.local.render_pcm_device(F, s * F, pcm=ring[s & 3])
-        N.sync()
-        N.timer_start()
-        for s in range(K):
-            bank.local.render_pcm_device(F, (Wm + s) * F, pcm=ring[s & 3])
-        pcm_ms = N.timer_stop() / K
+        pos = [step0]
+
+        def pcm_step():
+            bank.local.render_pcm_device(F, pos[0] * F, pcm=ring[pos[0] & 3])
+            pos[0] += 1
+        pcm_ms = steady(N, pcm_step, min_seconds=0.1, reps=K)
         out["int16_stream"] = {"ms_per_step": pcm_ms, "value": VOICES_PER_GPU * F / (pcm_ms / 1e3) / 1e6, "unit": "Msamples/s",
                                "note": "sh_bank_render_pcm into a ring of 4 buffers: saturated int16 stereo straight from the "
                                        "partial-bus fold, launches pipelined like the headline's"}
@@ -341,35 +502,29 @@ def main() -> int:
         F2 = F * 10 if nv * F * 10 * 4 <= (8 << 30) else F     # 10 s blocks: 1.97 GB of voices, far past the 256 MB L3
         vbuf = N.DeviceBuffer(nv * F2 * 4)
         bus = N.DeviceBuffer(F2 * 8)
-        reps = max(3, min(20, K // 5))
-        for _ in range(2):
-            bank.local.generate_device(F2, Wm * F, out=vbuf)
-            bank.local.mix_device(vbuf, F2, bus_f32=bus)
-        N.sync()
-        N.timer_start()
-        for r in range(reps):
-            bank.local.generate_device(F2, Wm * F, out=vbuf)
-        gen_ms = N.timer_stop() / reps
-        N.timer_start()
-        for r in range(reps):
-            bank.local.mix_device(vbuf, F2, bus_f32=bus)
-        mix_ms = N.timer_stop() / reps
+        gen_ms = steady(N, lambda: bank.local.generate_device(F2, Wm * F, out=vbuf), min_seconds=0.03, reps=3)
+        mix_ms = steady(N, lambda: bank.local.mix_device(vbuf, F2, bus_f32=bus), min_seconds=0.03, reps=3)
         mix_bytes = (4.0 * nv + 8.0) * F2
         gen_bytes = 4.0 * nv * F2
+        tm, tg = _by_prefix(prof["traffic"], "k_mix_bus"), _by_prefix(prof["traffic"], "k_generate")
         out["two_step"] = {
             "frames_per_launch": F2, "voices": nv,
             "value": nv * F2 / ((gen_ms + mix_ms) / 1e3) / 1e6, "unit": "Msamples/s",
             "roofline_mix": {"kernel": "k_mix_bus_direct<8,4>", "bound": "hbm", "achieved": mix_bytes / (mix_ms / 1e3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mix_bytes / (mix_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": traffic_of("k_mix_bus"), "avg_launch_ms": mix_ms, "bytes_per_frame": 4 * nv + 8,
+                             "traffic": tm["hbm_bytes"] if tm else None, "avg_launch_ms": mix_ms, "bytes_per_frame": 4 * nv + 8,
                              "algorithmic_bytes": mix_bytes},
-            "roofline_generate": {"kernel": "k_generate", "bound": "hbm", "achieved": gen_bytes / (gen_ms / 1e3) / 1e9,
+            "roofline_generate": {"kernel": "k_generate_lists<4>", "bound": "hbm", "achieved": gen_bytes / (gen_ms / 1e3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gen_bytes / (gen_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": traffic_of("k_generate"), "avg_launch_ms": gen_ms, "bytes_per_voice_sample": 4,
+                                  "traffic": tg["hbm_bytes"] if tg else None, "avg_launch_ms": gen_ms, "bytes_per_voice_sample": 4,
                                   "algorithmic_bytes": gen_bytes},
         }
         vbuf.free()
         bus.free()
+
+    # ---- the other BASELINE configs (rank 0, N = 1) ----
+    if rank == 0 and world == 1 and not args.no_configs:
+        out["configs"] = config_rows(N)
 
     # ---- the integer / float PCM rows (rank 0): Sample.resample (configs[4]) and the mixer chain ----
     if rank == 0 and not args.no_pcm_rows:
@@ -377,7 +532,7 @@ def main() -> int:
 
     # ---- CPU baseline (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and args.cpu_frames > 0:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_frames, all_cores=not args.no_cpu_all_cores)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     if world > 1:
         barrier()

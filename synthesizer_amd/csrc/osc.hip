@@ -1907,10 +1907,14 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         }
         parts = (double2*)S.parts_buf[k];
     }
+    // Timing diagnostics only (wrong audio!): SYNTHHIP_DEBUG bit 0 drops the in-kernel prepare of the block two launches on
+    // once the run is warm (the stale record sets are reused), bit 1 drops the in-kernel fold of the partial buses.
+    static int debug = -1;
+    if (debug < 0) { const char* e = getenv("SYNTHHIP_DEBUG"); debug = e ? atoi(e) : 0; }
     // the fold this launch takes over: the older of two outstanding ones (launch n - 2's)
     const bool take_over = S.npending == 2;
     const sh::PendingCombine prev = take_over ? S.pending[0] : sh::PendingCombine();
-    const double2* pv_parts = take_over ? (const double2*)prev.parts : nullptr;
+    const double2* pv_parts = (take_over && !(debug & 2)) ? (const double2*)prev.parts : nullptr;
     float2* pv32 = take_over ? (float2*)prev.o32 : nullptr;
     double2* pv64 = take_over ? (double2*)prev.o64 : nullptr;
     uint32_t* pv16 = take_over ? (uint32_t*)prev.o16 : nullptr;
@@ -1929,6 +1933,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     }
     LaunchSet next = launch_set(b, target < 0 ? 0 : target);
     if (target < 0) next.launch = nullptr;
+    if ((debug & 1) && n >= 8) next.launch = nullptr;
     const int mode = b->lean_candidates == 0 ? RENDER_DIRECT : (b->lean_fm_candidates ? RENDER_LEAN_ALL : RENDER_LEAN_HARM);
 #define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
     hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),    \

@@ -7,9 +7,11 @@ same frame range and the partial buses are summed by RCCL over xGMI (``ncclReduc
 0) -- the only collective on the path.  The reference is single-process: this is new work asked for
 by BASELINE.json, not a translation of anything upstream.
 
-Rendezvous: rank 0 creates the ``ncclUniqueId`` and broadcasts its 128 bytes through whatever
-channel the launcher provides -- ``torch.distributed`` when the process group is up (bench.py under
-torchrun), else a tiny TCP exchange on MASTER_ADDR:MASTER_PORT+1.
+Rendezvous: rank 0 creates the ``ncclUniqueId`` and broadcasts its 128 bytes -- by default through a
+tiny TCP exchange on MASTER_ADDR:MASTER_PORT+1 (no dependency beyond the standard library); a launcher
+that already has a channel passes its own ``broadcast(payload, rank, world, nbytes) -> bytes`` callable to
+``init`` (bench.py under torchrun hands over its gloo process group that way).  Nothing here imports
+PyTorch.
 """
 from __future__ import annotations
 
@@ -79,32 +81,12 @@ def _tcp_broadcast(payload: Optional[bytes], rank: int, world: int, nbytes: int)
     return data
 
 
-def _torch_broadcast(payload: Optional[bytes], rank: int, world: int, nbytes: int) -> bytes:
-    import torch
-    import torch.distributed as td
-    t = torch.zeros(nbytes, dtype=torch.uint8)
-    if rank == 0:
-        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
-    if td.get_backend() == "nccl":
-        t = t.cuda()
-    td.broadcast(t, src=0)
-    return bytes(t.cpu().numpy().tobytes())
-
-
 def init(rank: int, world: int, broadcast: Optional[Callable[[Optional[bytes], int, int, int], bytes]] = None) -> None:
     """Create the RCCL communicator on this process's GPU (sh_init must select the right device first)."""
     N.ensure_init()
     L = N.lib()
     if broadcast is None:
         broadcast = _tcp_broadcast
-        try:
-            import sys
-            if "torch" in sys.modules:
-                import torch.distributed as td
-                if td.is_available() and td.is_initialized():
-                    broadcast = _torch_broadcast
-        except Exception:
-            pass
     payload = None
     if rank == 0:
         buf = (C.c_char * N.SH_DIST_ID_BYTES)()
@@ -130,16 +112,52 @@ def shutdown() -> None:
     N.check(N.lib().sh_dist_shutdown())
 
 
+class _HipBackend:
+    """What DistVoiceBank's slot ring needs from the device side: libsynthhip (RCCL on the communication stream)."""
+
+    def __init__(self, voices: Sequence, gains: Sequence[Tuple[float, float]]) -> None:
+        from .mixer import VoiceBank
+        self.local = VoiceBank(list(voices), gains=list(gains))
+
+    def nslots(self) -> int:
+        return N.lib().sh_dist_slots()
+
+    def alloc(self, nbytes: int):
+        return N.DeviceBuffer(nbytes)
+
+    def view(self, buf, offset: int, nbytes: int):
+        return buf.view(offset, nbytes)
+
+    def render(self, nframes: int, start: int, bus_f32, bus_f64) -> None:
+        self.local.render_device(nframes, start, bus_f32=bus_f32, bus_f64=bus_f64)
+
+    def wait_slot(self, slot: int) -> None:
+        N.check(N.lib().sh_dist_wait_slot(slot))
+
+    def reduce_async(self, bus_f64, nvalues: int, root: int, bus_f32, slot: int) -> None:
+        N.check(N.lib().sh_dist_reduce_bus_async(bus_f64.handle, nvalues, root, bus_f32.handle, slot))
+
+    def sync(self) -> None:
+        N.sync()
+
+    def download(self, buf, nvalues: int) -> np.ndarray:
+        return buf.download(np.float32, nvalues)
+
+
 class DistVoiceBank:
     """This rank's shard of a voice table + the reduce of the partial buses.
 
     With several ranks the exchange is pipelined and batched: blocks are rendered into a ring of slots, each
     slot holding ``batch`` consecutive blocks; when a slot is full one ``ncclReduce`` (and, on root, the
     rounding to float32) is enqueued for it on the communication stream, overlapping the render of the
-    following blocks.  ``flush()`` sends a partly filled slot; ``_native.sync()`` waits for everything."""
+    following blocks.  ``flush()`` sends a partly filled slot; ``sync()`` waits for everything.
 
-    def __init__(self, voices: Sequence, gains: Sequence[Tuple[float, float]], rank: int, world: int, batch: int = 1) -> None:
-        from .mixer import VoiceBank
+    ``backend`` (tests): an object with _HipBackend's methods that renders / reduces some other way -- the world-2
+    gloo test on CPU drives this very ring (slot rotation, batching, back-pressure, flush) with the oracle as the
+    renderer and gloo as the collective."""
+
+    def __init__(self, voices: Sequence, gains: Sequence[Tuple[float, float]], rank: int, world: int, batch: int = 1,
+                 backend=None) -> None:
         self.rank, self.world = rank, world
         self.batch = max(1, int(batch)) if world > 1 else 1
         self.total_voices = len(voices)
@@ -147,7 +165,8 @@ class DistVoiceBank:
         self.lo, self.hi = lo, hi
         if hi <= lo:
             raise ValueError("rank %d owns no voices (%d voices over %d ranks)" % (rank, len(voices), world))
-        self.local = VoiceBank(list(voices[lo:hi]), gains=list(gains[lo:hi]))
+        self.backend = backend if backend is not None else _HipBackend(voices[lo:hi], gains[lo:hi])
+        self.local = getattr(self.backend, "local", None)
         self._bus64 = []          # per slot: float64 partial buses of `batch` blocks
         self._bus32 = []          # per slot: float32 results (meaningful on root)
         self._views = []          # per slot, per block: (float64 view, float32 view)
@@ -159,11 +178,12 @@ class DistVoiceBank:
     def _buffers(self, nframes: int) -> None:
         if nframes != self._cap:
             self.flush()
-            N.sync()
-            nslots = N.lib().sh_dist_slots() if self.world > 1 else 1
-            self._bus64 = [N.DeviceBuffer(self.batch * nframes * 16) for _ in range(nslots)]
-            self._bus32 = [N.DeviceBuffer(self.batch * nframes * 8) for _ in range(nslots)]
-            self._views = [[(b64.view(j * nframes * 16, nframes * 16), b32.view(j * nframes * 8, nframes * 8))
+            self.backend.sync()
+            B = self.backend
+            nslots = B.nslots() if self.world > 1 else 1
+            self._bus64 = [B.alloc(self.batch * nframes * 16) for _ in range(nslots)]
+            self._bus32 = [B.alloc(self.batch * nframes * 8) for _ in range(nslots)]
+            self._views = [[(B.view(b64, j * nframes * 16, nframes * 16), B.view(b32, j * nframes * 8, nframes * 8))
                             for j in range(self.batch)] for b64, b32 in zip(self._bus64, self._bus32)]
             self._cap = nframes
             self._slot = 0
@@ -174,24 +194,28 @@ class DistVoiceBank:
         if self.world > 1 and self._fill:
             k = self._slot
             n = self._fill * self._cap * 2
-            N.check(N.lib().sh_dist_reduce_bus_async(self._bus64[k].handle, n, self._root, self._bus32[k].handle, k))
+            self.backend.reduce_async(self._bus64[k], n, self._root, self._bus32[k], k)
             self._slot = (k + 1) % len(self._bus64)
             self._fill = 0
 
-    def render_device(self, nframes: int, start: int = 0, root: int = 0) -> N.DeviceBuffer:
+    def sync(self) -> None:
+        self.backend.sync()
+
+    def render_device(self, nframes: int, start: int = 0, root: int = 0):
         """Render the shard's block; returns the float32 bus buffer of this block (meaningful on root once the
-        slot's reduce has run: after ``flush()`` + ``_native.sync()``)."""
+        slot's reduce has run: after ``flush()`` + ``sync()``)."""
         self._buffers(nframes)
         if self.world == 1:                      # nothing to exchange: the kernel rounds to float32 itself
-            self.local.render_device(nframes, start, bus_f32=self._bus32[0])
+            self.backend.render(nframes, start, self._bus32[0], None)
             return self._bus32[0]
-        L = N.lib()
+        if self._fill and root != self._root:
+            self.flush()                         # a slot is reduced to ONE root
         self._root = root
         k, j = self._slot, self._fill
         if j == 0:
-            N.check(L.sh_dist_wait_slot(k))      # the reduce that last used this slot must have finished
+            self.backend.wait_slot(k)            # the reduce that last used this slot must have finished
         v64, v32 = self._views[k][j]
-        self.local.render_device(nframes, start, bus_f32=None, bus_f64=v64)
+        self.backend.render(nframes, start, None, v64)
         self._fill += 1
         if self._fill == self.batch:
             self.flush()
@@ -200,10 +224,10 @@ class DistVoiceBank:
     def render(self, nframes: int, start: int = 0, root: int = 0) -> Optional[np.ndarray]:
         buf = self.render_device(nframes, start, root)
         self.flush()
-        N.sync()
+        self.backend.sync()
         if self.rank != root and self.world > 1:
             return None
-        return buf.download(np.float32, nframes * 2).reshape(nframes, 2)
+        return self.backend.download(buf, nframes * 2).reshape(nframes, 2)
 
 
 # -- Sample.resample sharded by output-frame range (no collective) ---------------------------

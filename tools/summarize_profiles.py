@@ -123,6 +123,18 @@ for k in sorted(set(f) | set(w)):
                   "read_bytes_corrected_x2": fa * 1024 * 2, "write_bytes": wa * 1024,
                   "hbm_bytes": fa * 1024 * 2 + wa * 1024}
 (out / ("%s_traffic.json" % tag)).write_text(json.dumps(traffic, indent=1) + "\n")
+# machine-readable SQ counters per dispatch (averages), read by bench.py for the float64 lane-ops per voice-sample;
+# _meta.source_hash = hash of the kernel sources the profiled library was built from (tools/profile_round.sh records it)
+allc = {}
+for fname in ("sq1_counter_collection.csv", "sq2_counter_collection.csv"):
+    agg, _m = counters(fname)
+    for k, cs in agg.items():
+        if k.startswith("k_"):
+            allc.setdefault(k, {}).update({cn: sum(v) / len(v) for cn, v in cs.items()})
+hash_file = src / "source_hash.txt"
+allc["_meta"] = {"source_hash": hash_file.read_text().strip() if hash_file.exists() else None,
+                 "dispatch": "bench.py default workload: 1024 voices x 48000 frames per k_bank_render dispatch"}
+(out / ("%s_counters.json" % tag)).write_text(json.dumps(allc, indent=1) + "\n")
 bench = src.parent / ("%s_bench.json" % src.name)
 if bench.exists():
     last = [l for l in bench.read_text().splitlines() if l.startswith("{")]
