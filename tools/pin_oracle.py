@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""Pin the oscillator / Sample oracle against the REAL synthplayer package -- the moment it is importable.
+
+    python tools/pin_oracle.py [--regen] [--quick] [--json PATH]
+
+The tree mounted at /root/reference holds a two-line relocation notice (README.md:1-2), so today this script
+finds nothing to diff against and exits 3 ("reference absent"); `parity: unpinned` stays in oracle/synth_oracle.py's
+header and in DESIGN.md.  In a build container where `import synthplayer` works (a clone of the CodeBerg repository
+or the PyPI sdist mounted at /root/reference, or installed) it
+
+  1. diffs every class of oracle/synth_oracle.py against the class of the same name in synthplayer.oscillators over
+     a seed grid -- kinds x {plain, fm_lfo, pwm_lfo} x phases x three sample rates, the first blocks AND the blocks
+     around sample 2**20 (late enough for the accumulated `t += increment` to have drifted from n*increment) -- and
+     demands EQUAL float64 samples (the oracle claims to restate the arithmetic, not to approximate it);
+  2. diffs oracle/sample_oracle.RefSample method by method against synthplayer.sample.Sample on random PCM
+     (bytes must be equal), and the quantiser oracle.quantise against Sample.from_osc_block;
+  3. diffs the module constants the oracle copied from synthplayer.params;
+  4. with --regen, rewrites tests/golden/osc_*.np* FROM THE REAL PACKAGE (with a header array saying so), which turns
+     the "guards the oracle against accidental edits" files into reference-pinned vectors.
+
+Exit codes: 0 everything equal (oracle pinned), 1 differences found (listed), 3 reference absent.
+The reference never travels to the GPU box: this runs in the build container only, and only its OUTPUTS (the golden
+vectors) are committed.  SURVEY.md Appendix B lists the nine questions this settles; DESIGN.md section 9 lists the
+assumption the oracle currently makes for each.
+"""
+from __future__ import annotations
+
+import argparse
+import itertools
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def find_reference():
+    """synthplayer as installed, or from a tree mounted at /root/reference (this container only)."""
+    try:
+        import synthplayer                                   # noqa: F401
+        return "installed"
+    except ImportError:
+        pass
+    ref = Path("/root/reference")
+    for cand in (ref, ref / "synthesizer", ref / "src"):
+        if (cand / "synthplayer" / "oscillators.py").exists():
+            sys.path.insert(0, str(cand))
+            try:
+                import synthplayer                           # noqa: F401
+                return str(cand)
+            except ImportError:
+                sys.path.pop(0)
+    return None
+
+
+def take(osc, n, skip=0):
+    """n samples of a blocks() generator after skipping `skip` (both sides: lists of Python floats)."""
+    gen = osc.blocks()
+    out = []
+    seen = 0
+    while len(out) < n:
+        try:
+            b = next(gen)
+        except StopIteration:
+            break
+        if seen + len(b) <= skip:
+            seen += len(b)
+            continue
+        lo = max(0, skip - seen)
+        out.extend(b[lo:])
+        seen += len(b)
+    return out[:n]
+
+
+def oscillator_cases(quick: bool):
+    """(name, constructor(module) -> oscillator) over the seed grid."""
+    rates = (44100, 48000, 22050) if not quick else (48000,)
+    phases = (0.0, 0.3, -0.25) if not quick else (0.3,)
+    cases = []
+    for sr, ph in itertools.product(rates, phases):
+        for kind in ("Sine", "Triangle", "Square", "Sawtooth"):
+            for f in (440.0, 1000.0, 55.5):
+                cases.append(("%s f=%g sr=%d ph=%g" % (kind, f, sr, ph),
+                              lambda m, kind=kind, f=f, sr=sr, ph=ph: getattr(m, kind)(f, 0.8, ph, 0.1, samplerate=sr)))
+                cases.append(("%s f=%g sr=%d ph=%g fm" % (kind, f, sr, ph),
+                              lambda m, kind=kind, f=f, sr=sr, ph=ph: getattr(m, kind)(f, 0.8, ph, 0.0, fm_lfo=m.Sine(5.0, 0.05, samplerate=sr), samplerate=sr)))
+        cases.append(("Pulse sr=%d ph=%g" % (sr, ph), lambda m, sr=sr, ph=ph: m.Pulse(441.0, 0.7, ph, 0.25, 0.05, samplerate=sr)))
+        cases.append(("Pulse pwm sr=%d ph=%g" % (sr, ph),
+                      lambda m, sr=sr, ph=ph: m.Pulse(441.0, 0.7, ph, 0.25, 0.0, pwm_lfo=m.Sine(2.0, 0.2, bias=0.4, samplerate=sr), samplerate=sr)))
+        cases.append(("Pulse fm+pwm sr=%d" % sr,
+                      lambda m, sr=sr, ph=ph: m.Pulse(441.0, 0.7, ph, 0.25, 0.0, fm_lfo=m.Triangle(3.0, 0.1, samplerate=sr),
+                                                      pwm_lfo=m.Sine(2.0, 0.2, bias=0.4, samplerate=sr), samplerate=sr)))
+        harm = [(k, 1.0 / k) for k in range(1, 17)]
+        cases.append(("Harmonics x16 sr=%d ph=%g" % (sr, ph), lambda m, sr=sr, ph=ph: m.Harmonics(220.0, harm, 0.5, ph, samplerate=sr)))
+        cases.append(("Harmonics sparse fm sr=%d" % sr,
+                      lambda m, sr=sr, ph=ph: m.Harmonics(220.0, [(1, 1.0), (2.5, 0.3), (7, 0.1)], 0.5, ph, fm_lfo=m.Sine(4.0, 0.02, samplerate=sr), samplerate=sr)))
+        cases.append(("SquareH sr=%d" % sr, lambda m, sr=sr, ph=ph: m.SquareH(220.0, 9, 0.8, ph, samplerate=sr)))
+        cases.append(("SawtoothH sr=%d" % sr, lambda m, sr=sr, ph=ph: m.SawtoothH(220.0, 9, 0.8, ph, samplerate=sr)))
+    sr = 48000
+    cases += [
+        ("Linear up", lambda m: m.Linear(-0.5, 1e-4, -1.0, 0.25, samplerate=sr)),
+        ("Linear const", lambda m: m.Linear(0.3, samplerate=sr)),
+        ("Envelope ADSR", lambda m: m.EnvelopeFilter(m.Sine(440.0, samplerate=sr), 0.01, 0.02, 0.03, 0.6, 0.02)),
+        ("Envelope stop_at_end", lambda m: m.EnvelopeFilter(m.Square(440.0, samplerate=sr), 0.005, 0.0, 0.01, 0.5, 0.01, stop_at_end=True)),
+        ("Envelope no release", lambda m: m.EnvelopeFilter(m.Sawtooth(440.0, samplerate=sr), 0.0, 0.01, 0.02, 0.7, 0.0)),
+        ("MixingFilter", lambda m: m.MixingFilter(m.Sine(440.0, 0.4, samplerate=sr), m.Square(220.0, 0.3, samplerate=sr), m.Triangle(110.0, 0.2, samplerate=sr))),
+        ("AmpModulationFilter", lambda m: m.AmpModulationFilter(m.Sine(440.0, samplerate=sr), m.Sine(3.0, 0.5, bias=0.5, samplerate=sr))),
+        ("ClipFilter", lambda m: m.ClipFilter(m.Sine(440.0, samplerate=sr), -0.3, 0.6)),
+        ("AbsFilter", lambda m: m.AbsFilter(m.Sawtooth(440.0, samplerate=sr))),
+        ("NullFilter", lambda m: m.NullFilter(m.Sine(440.0, samplerate=sr))),
+        ("DelayFilter +", lambda m: m.DelayFilter(m.Sine(440.0, samplerate=sr), 0.01)),
+        ("DelayFilter -", lambda m: m.DelayFilter(m.Sine(440.0, samplerate=sr), -0.01)),
+        ("EchoFilter", lambda m: m.EchoFilter(m.EnvelopeFilter(m.Sine(440.0, samplerate=sr), 0.01, 0.01, 0.02, 0.6, 0.01, stop_at_end=True), 0.02, 3, 0.015, 0.6)),
+    ]
+    return cases
+
+
+def diff_oscillators(ref, O, quick, report):
+    import numpy as np
+    n = 2048
+    late = (1 << 20) - 1024                     # a window that straddles sample 2**20
+    for name, make in oscillator_cases(quick):
+        try:
+            a, b = make(ref), make(O)
+        except Exception as e:                  # a class or keyword the real package does not have: that IS a finding
+            report.append({"case": name, "error": "constructor: %r" % (e,)})
+            continue
+        windows = [(0, n)]
+        if not quick and ("fm" not in name or "Sine f=440" in name) and "Envelope" not in name and "Echo" not in name:
+            windows.append((late, n))
+        for skip, cnt in windows:
+            try:
+                x, y = np.array(take(a, cnt, skip), dtype=np.float64), np.array(take(b, cnt, skip), dtype=np.float64)
+            except Exception as e:
+                report.append({"case": name, "window": skip, "error": "blocks(): %r" % (e,)})
+                continue
+            if x.shape != y.shape:
+                report.append({"case": name, "window": skip, "len_ref": int(x.size), "len_oracle": int(y.size)})
+            elif not np.array_equal(x, y):
+                d = np.abs(x - y)
+                report.append({"case": name, "window": skip, "differing": int(np.sum(x != y)), "max_abs": float(d.max()),
+                               "first": int(np.argmax(x != y))})
+
+
+def diff_samples(refS, RefSample, O, report):
+    import numpy as np
+    rng = np.random.default_rng(2024)
+
+    def pair(width, nch, nframes, rate=22050):
+        info = {1: np.int8, 2: np.int16, 4: np.int32}[width]
+        ii = np.iinfo(info)
+        raw = (rng.integers(ii.min, ii.max + 1, nframes * nch, dtype=np.int64) * 0.4).astype(info).tobytes()
+        return refS.from_raw_frames(raw, width, rate, nch), RefSample(raw, width, rate, nch)
+
+    def frames_of(s):
+        return bytes(s.view_frame_data()) if hasattr(s, "view_frame_data") else s.frames
+
+    ops = [
+        ("amplify 0.5", lambda s: s.amplify(0.5)), ("amplify 1.7", lambda s: s.amplify(1.7)),
+        ("fadeout", lambda s: s.fadeout(0.05, 0.1)), ("fadein", lambda s: s.fadein(0.05, 0.2)),
+        ("resample 48000", lambda s: s.resample(48000)), ("resample 8000", lambda s: s.resample(8000)),
+        ("add_silence", lambda s: s.add_silence(0.01)), ("add_silence start", lambda s: s.add_silence(0.01, True)),
+        ("clip", lambda s: s.clip(0.01, 0.05)), ("delay", lambda s: s.delay(0.02)), ("delay keep", lambda s: s.delay(0.02, True)),
+        ("delay negative", lambda s: s.delay(-0.02)), ("speed 1.26", lambda s: s.speed(1.26)), ("at_volume", lambda s: s.at_volume(0.7)),
+        ("echo", lambda s: s.echo(0.1, 3, 0.05, 0.6)), ("envelope", lambda s: s.envelope(0.02, 0.02, 0.5, 0.03)),
+    ]
+    for width, nch in ((2, 1), (2, 2), (4, 2), (1, 1)):
+        for name, op in ops:
+            a, b = pair(width, nch, 4000)
+            try:
+                op(a), op(b)
+                if frames_of(a) != frames_of(b):
+                    report.append({"case": "Sample.%s w%d ch%d" % (name, width, nch), "bytes_differ": True,
+                                   "len_ref": len(frames_of(a)), "len_oracle": len(frames_of(b))})
+            except Exception as e:
+                report.append({"case": "Sample.%s w%d ch%d" % (name, width, nch), "error": repr(e)})
+    for other_at in (None, 0.03):
+        a, b = pair(2, 2, 4000)
+        c, d = pair(2, 2, 2500)
+        if other_at is None:
+            a.mix(c), b.mix(d)
+        else:
+            a.mix_at(other_at, c), b.mix_at(other_at, d)
+        if frames_of(a) != frames_of(b):
+            report.append({"case": "Sample.mix at=%r" % (other_at,), "bytes_differ": True})
+    # the quantiser
+    block = [0.9999 * __import__("math").sin(0.01 * i) for i in range(3000)] + [1.0, -1.0, 0.0, 1234.0 / 32767.0]
+    for width in (2, 4):
+        want = list(refS.from_osc_block(block, 22050, samplewidth=width).get_frame_array())
+        if want != list(O.quantise(block, width)):
+            report.append({"case": "from_osc_block width %d" % width, "differs": True})
+
+
+def diff_params(refP, O, report):
+    for name in ("norm_samplerate", "norm_nchannels", "norm_samplewidth", "norm_osc_blocksize"):
+        if getattr(refP, name, None) != getattr(O, name):
+            report.append({"case": "params.%s" % name, "ref": getattr(refP, name, None), "oracle": getattr(O, name)})
+
+
+def regenerate_golden(ref):
+    """tests/golden/osc_*.np*, same keys as tests/golden/make_golden.py::osc_vectors, from the real package."""
+    import numpy as np
+    out_dir = ROOT / "tests" / "golden"
+    sine = np.array(take(ref.Sine(440, samplerate=44100), 44100), dtype=np.float64)
+    np.save(out_dir / "osc_sine440_44k1.npy", sine[np.r_[0:4096, 40004:44100]].copy())
+    sr = 48000
+    out = {"_source": np.array("synthplayer (the real package), written by tools/pin_oracle.py --regen")}
+    out["saw"] = np.array(take(ref.Sawtooth(1000, 0.8, phase=0.1, bias=0.05, samplerate=sr), 2048))
+    out["square"] = np.array(take(ref.Square(1000, samplerate=sr), 2048))
+    out["pulse"] = np.array(take(ref.Pulse(441, pulsewidth=0.25, samplerate=sr), 2048))
+    out["harm"] = np.array(take(ref.Harmonics(220, [(k, 1.0 / k) for k in range(1, 17)], 0.5, samplerate=sr), 2048))
+    out["fm_sine"] = np.array(take(ref.Sine(440, fm_lfo=ref.Sine(5, 0.03, samplerate=sr), samplerate=sr), 2048))
+    out["adsr"] = np.array(take(ref.EnvelopeFilter(ref.Sine(440, samplerate=sr), 0.01, 0.01, 0.01, 0.6, 0.01), 2048))
+    from synthplayer.sample import Sample
+    out["quant"] = np.array(Sample.from_osc_block(list(out["harm"] * 0.5), sr).get_frame_array(), dtype=np.int16)
+    np.savez_compressed(out_dir / "osc_misc.npz", **out)
+    return ["osc_sine440_44k1.npy", "osc_misc.npz"]
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--regen", action="store_true", help="rewrite tests/golden/osc_*.np* from the real package")
+    ap.add_argument("--quick", action="store_true", help="one sample rate / phase, no late windows")
+    ap.add_argument("--json", default=None, help="write the outcome here as JSON")
+    args = ap.parse_args()
+    where = find_reference()
+    outcome = {"reference": where, "status": None, "differences": []}
+    if where is None:
+        outcome["status"] = "reference absent"
+        msg = ("reference absent: synthplayer is not importable and /root/reference holds no synthplayer/oscillators.py "
+               "(README.md:1-2 only) -- oracle parity stays UNPINNED")
+        print(msg)
+        if args.json:
+            Path(args.json).write_text(json.dumps(outcome, indent=1) + "\n")
+        return 3
+    from oracle import synth_oracle as O
+    from oracle.sample_oracle import RefSample
+    import synthplayer.oscillators as ref_osc
+    import synthplayer.params as ref_params
+    import synthplayer.sample as ref_sample
+    report = outcome["differences"]
+    diff_params(ref_params, O, report)
+    diff_oscillators(ref_osc, O, args.quick, report)
+    diff_samples(ref_sample.Sample, RefSample, O, report)
+    if args.regen:
+        outcome["regenerated"] = regenerate_golden(ref_osc)
+    outcome["status"] = "pinned" if not report else "differences"
+    print("reference: %s; %d difference(s)" % (where, len(report)))
+    for r in report[:200]:
+        print("  ", r)
+    if args.json:
+        Path(args.json).write_text(json.dumps(outcome, indent=1) + "\n")
+    return 0 if not report else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
