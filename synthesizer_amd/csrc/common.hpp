@@ -30,6 +30,7 @@ struct PendingCombine {
     void*    o64 = nullptr;          // double2[nframes] or NULL
     void*    o16 = nullptr;          // int16 stereo PCM (one dword per frame) or NULL
     double   scale = 0.0;            // ... quantised as trunc(scale * float32(bus)), saturating
+    const void* gen_valid = nullptr; // split launch: uint32[groups], which of the general kernel's parts[groups + g] exist
 };
 
 struct State {

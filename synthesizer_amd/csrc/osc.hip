@@ -928,7 +928,57 @@ __device__ __forceinline__ uint32_t pcm16_frame(double l, double r, double scale
     return ((uint32_t)(int)tl & 0xFFFFu) | ((uint32_t)(int)tr << 16);
 }
 
-enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2 };
+// The lean Harmonics arithmetic for FPL frames of one lane, 64 samples apart: frame 0 by table lookup (s0, c0), frame 1 by
+// one rotation (s1, c1), frames j >= 2 by the three-term recurrence x[j] = k2 x[j-1] - x[j-2], k2 = 2cos(64 dt) -- one FMA
+// per value where a rotation takes two FMAs and two MULs -- consumed pair by pair, so that no array of FPL sines ever
+// lives in registers and the accumulators are updated in place on every path.  The one tile per crossing that straddles a
+// phase-table piece end (`straddle`, wave-uniform) cannot step that way: there every pair is looked up afresh from
+// theta(frame), which picks the piece per lane.
+// Rounding errors propagate through the recurrence like U_j(cos(64 dt)), i.e. grow at most linearly in j (FPL <= 8: < 25
+// ulp worst case, ~2 ulp typically); the rounding of k2 itself shifts the step angle by <= 1.1e-16 / |sin(64 dt)| per
+// step: below 1e-9 relative for all but ~1e-6 of voices, orders of magnitude inside the 1e-6 RMS contract in any case.
+template <int FPL, typename Theta>
+__device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1, double c1, double k2, bool straddle, Theta theta,
+                                                 TrigTab trig, const double (&poly)[16], double gl, double gr,
+                                                 double (&accl)[FPL], double (&accr)[FPL]) {
+#pragma unroll
+    for (int h = 0; h < FPL; h += 2) {
+        const bool two = h + 1 < FPL;                 // compile-time after unrolling (FPL = 1: a single frame)
+        double p0 = fma(poly[0], c0, poly[1]), p1 = fma(poly[0], c1, poly[1]);
+#pragma unroll
+        for (int u = 2; u < 16; ++u) {
+            p0 = fma(p0, c0, poly[u]);
+            if (two) p1 = fma(p1, c1, poly[u]);
+        }
+        const double x0 = p0 * s0;
+        accl[h] = fma(gl, x0, accl[h]);
+        accr[h] = fma(gr, x0, accr[h]);
+        if (two) {
+            const double x1 = p1 * s1;
+            accl[h + 1 < FPL ? h + 1 : h] = fma(gl, x1, accl[h + 1 < FPL ? h + 1 : h]);
+            accr[h + 1 < FPL ? h + 1 : h] = fma(gr, x1, accr[h + 1 < FPL ? h + 1 : h]);
+        }
+        if (h + 2 < FPL) {
+            if (straddle) {
+                shm::sincos_tab(theta(h + 2), trig, s0, c0);
+                if (h + 3 < FPL) shm::sincos_tab(theta(h + 3), trig, s1, c1);
+            } else {
+                const double s2 = fma(k2, s1, -s0), c2 = fma(k2, c1, -c0);
+                const double s3 = fma(k2, s2, -s1), c3 = fma(k2, c2, -c1);
+                s0 = s2; c0 = c2; s1 = s3; c1 = c3;
+            }
+        }
+    }
+}
+
+// ... RENDER_LEAN_HARM_ONLY / RENDER_GENERAL_ONLY: the same launch as TWO kernels on one stream (banks whose lean candidates are all
+// polynomial Harmonics, several voice groups).  The lean kernel compiles without the general code and so without its
+// registers, scalar pressure and scratch (108 VGPRs at eight frames per lane where the combined kernel needs 128 + 280 bytes of
+// scratch; 37 instead of 42 us per block); the general kernel walks the general lists with four frames per lane, writes its
+// partial buses behind the lean kernel's (parts[groups + g]) and sets gen_valid[g] -- or, for a group without general voices
+// (the steady state of a note), leaves after one scalar load.  The fold adds the general parts whose flag is set.
+enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2, RENDER_LEAN_HARM_ONLY = 3, RENDER_GENERAL_ONLY = 4 };
+constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY; }
 template <int WAVES, int FPL, int MINW, int MODE>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                   uint32_t nvoices, uint32_t voices_per_group,
@@ -941,11 +991,24 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                                                                   float2* __restrict__ prev_bus32,
                                                                   double2* __restrict__ prev_bus64,
                                                                   uint32_t* __restrict__ pcm16, double pcm_scale,
-                                                                  uint32_t* __restrict__ prev_pcm16, double prev_pcm_scale) {
+                                                                  uint32_t* __restrict__ prev_pcm16, double prev_pcm_scale,
+                                                                  uint32_t* __restrict__ gen_valid,
+                                                                  const uint32_t* __restrict__ prev_gen_valid) {
+    if constexpr (MODE == RENDER_GENERAL_ONLY) {
+        // a group without general voices in this launch: nothing to render, nothing to write (wave-uniform: scalar loads)
+        const uint32_t c0g = (blockIdx.y * voices_per_group) / 64;
+        uint32_t c1g = ((blockIdx.y + 1) * voices_per_group + 63) / 64;
+        const uint32_t nch = (nvoices + 63) / 64;
+        if (c1g > nch) c1g = nch;
+        uint32_t total = 0;
+        for (uint32_t c = c0g; c < c1g; ++c) total += as_const(cur.counts)[4 * c + 1];
+        if (blockIdx.x == 0 && threadIdx.x == 0) gen_valid[blockIdx.y] = total ? 1u : 0u;
+        if (total == 0) return;
+    }
     // The previous launch of the stream (same shape) left its voice groups' partial buses unfolded: the workgroups of
     // group 0 fold their tile of it now, in group order, before their own work -- instead of a 5 us kernel between
     // every two render launches.
-    if (prev_parts && blockIdx.y == 0) {
+    if (MODE != RENDER_GENERAL_ONLY && prev_parts && blockIdx.y == 0) {
         for (uint32_t f = threadIdx.x; f < 64 * FPL; f += WAVES * 64) {
             const uint32_t raw = blockIdx.x * (64 * FPL) + f;
             if (raw >= nframes) continue;
@@ -954,6 +1017,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                 const double2 pp = prev_parts[(size_t)g * nframes + raw];
                 acc.x += pp.x;
                 acc.y += pp.y;
+            }
+            if (prev_gen_valid) {                              // the general kernel's parts of that launch, where it wrote any
+                for (uint32_t g = 0; g < gridDim.y; ++g) {
+                    if (as_const(prev_gen_valid)[g]) {
+                        const double2 pp = prev_parts[(size_t)(gridDim.y + g) * nframes + raw];
+                        acc.x += pp.x;
+                        acc.y += pp.y;
+                    }
+                }
             }
             if (prev_bus32) prev_bus32[raw] = make_float2((float)acc.x, (float)acc.y);
             if (prev_bus64) prev_bus64[raw] = acc;
@@ -966,7 +1038,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // kernel of its own (a 15 us kernel + a launch boundary per block otherwise).
     // The chunks of 64 voices are spread over the first workgroups (one wavefront each, on different CUs): a single
     // workgroup doing all of it competes with three rendering workgroups for its CU and ends up as the launch's tail.
-    if (next.launch) {
+    if (MODE != RENDER_GENERAL_ONLY && next.launch) {
         const uint32_t nchunks = (nvoices + 63) / 64, nblocks = gridDim.x * gridDim.y;
         const uint32_t bid = blockIdx.y * gridDim.x + blockIdx.x;
         if (threadIdx.x < 64) {
@@ -991,12 +1063,21 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     double di[FPL], accl[FPL], accr[FPL];
 #pragma unroll
     for (int j = 0; j < FPL; ++j) {
-        uint32_t raw = tile0 + j * 64 + lane;
-        i[j] = raw < nframes ? raw : nframes - 1;
-        di[j] = (double)i[j];
         accl[j] = 0.0;
         accr[j] = 0.0;
     }
+    // the frames of this lane, launch-relative (clamped into the launch: out-of-range lanes compute a valid sample and do not
+    // store it).  The lean Harmonics loop does not use the arrays -- it works from the lane's first frame alone -- so in that
+    // mode they are only built after it, for the general code: they would cost 3 registers per frame for the whole loop.
+    auto build_frames = [&](uint32_t lane_) {
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            uint32_t raw = tile0 + j * 64 + lane_;
+            i[j] = raw < nframes ? raw : nframes - 1;
+            di[j] = (double)i[j];
+        }
+    };
+    if constexpr (!mode_lean_harm(MODE)) build_frames(lane);
     if constexpr (MODE == RENDER_DIRECT) {
         const uint32_t v0 = blockIdx.y * voices_per_group;
         uint32_t v1 = v0 + voices_per_group;
@@ -1012,6 +1093,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // Wave w takes every WAVES-th list entry; the offset carries over from chunk to chunk so that the waves'
     // shares of the whole group differ by at most one voice.
     uint32_t first = wave;                                    // position in the current chunk's list this wave starts at
+    if constexpr (MODE != RENDER_GENERAL_ONLY) {
     for (uint32_t c = c0; c < c1; ++c) {
         const uint32_t nfast = as_const(cur.counts)[4 * c];
         const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64 + first;
@@ -1030,6 +1112,36 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                          "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
                          "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
                          "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
+            if constexpr (mode_lean_harm(MODE)) {
+                // every record here is a polynomial Harmonics voice: lookup + one rotation + the recurrence.  The piece (first /
+                // second of the launch) is chosen by scalar selects, the rare straddling tile by one uniform flag, and all three
+                // cases run through the same arithmetic below.
+                const uint32_t i0 = tile0 + lane;                     // the lane's first frame (< nframes + 64: harmless)
+                const double di0 = (double)i0;
+                double t_base = ta, dt = da, rc = rca, rs = rsa, off = 0.0, tb = ta, db = da, ob = 0.0;
+                bool straddle = false;
+                if (remain != 0xFFFFFFFFu && tile_last >= remain) {   // not wholly on the first piece
+                    tb = q->t0_b; db = q->dt_b; ob = q->off_b;
+                    const double rcb = q->rot_c_b, rsb = q->rot_s_b;
+                    straddle = tile0 < remain;
+                    if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
+                }
+                auto theta = [&](int j) {                             // per lane: frame j of a straddling tile
+                    const uint32_t ii = i0 + (uint32_t)j * 64u;
+                    const double dd = di0 + (double)(j * 64);
+                    return ii < remain ? fma(dd, da, ta) : fma(dd - ob, db, tb);
+                };
+                double s0, c0, s1, c1;
+                shm::sincos_tab(straddle ? theta(0) : fma(di0 - off, dt, t_base), trig, s0, c0);
+                if (straddle) {
+                    if (FPL > 1) shm::sincos_tab(theta(1), trig, s1, c1); else { s1 = s0; c1 = c0; }
+                } else {
+                    s1 = fma(s0, rc, c0 * rs);
+                    c1 = fma(c0, rc, -(s0 * rs));
+                }
+                lean_harm_frames<FPL>(s0, c0, s1, c1, rc + rc, straddle, theta, trig, poly, gl, gr, accl, accr);
+                continue;
+            }
             if (MODE == RENDER_LEAN_ALL && kind == LEAN_FM) {
                 // Sine carrier, closed-form Sine LFO (the arithmetic of voice_block's FM path): T = accumulated time
                 double T[FPL];
@@ -1155,8 +1267,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         }
         first = p - nfast;                                    // 0 .. WAVES-1: where the stride lands in the next list
     }
+    }
     // ---- every other sounding voice: the general code (the stride simply continues, so the extra voices go to the
     // waves that got one fast voice fewer) ----
+    if constexpr (MODE == RENDER_LEAN_HARM) {
+        uint32_t lane_late = lane;
+        asm volatile("" : "+v"(lane_late));       // defined here, after the loop above: the arrays cannot be built earlier
+        build_frames(lane_late);
+    }
+    if constexpr (MODE != RENDER_LEAN_HARM_ONLY) {
     for (uint32_t c = c0; c < c1; ++c) {
         const uint32_t ngen = as_const(cur.counts)[4 * c + 1];
         const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
@@ -1169,6 +1288,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             general_voice<FPL>(r, cur.fm + vi, B, B.voices + vi, start, tile0, nframes, i, di, trig, accl, accr);
         }
         first = p - ngen;
+    }
     }
     }
 #pragma unroll
@@ -1189,7 +1309,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                 rr += red[w][1][f];
             }
             if (parts) {
-                parts[(size_t)blockIdx.y * nframes + raw] = make_double2(l, rr);
+                const uint32_t slot = MODE == RENDER_GENERAL_ONLY ? gridDim.y + blockIdx.y : blockIdx.y;
+                parts[(size_t)slot * nframes + raw] = make_double2(l, rr);
             } else {
                 if (bus32) bus32[raw] = make_float2((float)l, (float)rr);
                 if (bus64) bus64[raw] = make_double2(l, rr);
@@ -1201,7 +1322,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
 
 __global__ __launch_bounds__(256) void k_bus_combine(const double2* __restrict__ parts, uint32_t ngroups, uint32_t nframes,
                                                      float2* __restrict__ bus32, double2* __restrict__ bus64,
-                                                     uint32_t* __restrict__ pcm16, double pcm_scale) {
+                                                     uint32_t* __restrict__ pcm16, double pcm_scale,
+                                                     const uint32_t* __restrict__ gen_valid) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nframes) return;
     double2 s = parts[i];
@@ -1209,6 +1331,15 @@ __global__ __launch_bounds__(256) void k_bus_combine(const double2* __restrict__
         const double2 p = parts[(size_t)g * nframes + i];
         s.x += p.x;
         s.y += p.y;
+    }
+    if (gen_valid) {                                   // split launch: the general kernel's parts, same order as the in-kernel fold
+        for (uint32_t g = 0; g < ngroups; ++g) {
+            if (gen_valid[g]) {
+                const double2 p = parts[(size_t)(ngroups + g) * nframes + i];
+                s.x += p.x;
+                s.y += p.y;
+            }
+        }
     }
     if (bus32) bus32[i] = make_float2((float)s.x, (float)s.y);
     if (bus64) bus64[i] = s;
@@ -1537,7 +1668,7 @@ int flush_pending() {
         const PendingCombine& pc = S.pending[k];
         hipLaunchKernelGGL(k_bus_combine, dim3(div_up(pc.nframes, 256)), dim3(256), 0, S.stream,
                            (const double2*)pc.parts, pc.groups, pc.nframes, (float2*)pc.o32, (double2*)pc.o64,
-                           (uint32_t*)pc.o16, pc.scale);
+                           (uint32_t*)pc.o16, pc.scale, (const uint32_t*)pc.gen_valid);
         SH_CHECK_LAUNCH("k_bus_combine");
     }
     return SH_OK;
@@ -1850,13 +1981,24 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         variant = e ? atoi(e) : 0;
     }
     int var = variant;
-    if (var == 0) var = b->nvoices >= 128 ? (2 * b->lean_candidates >= b->nvoices ? 444 : 844) : (b->nvoices >= 64 ? 826 : (b->nvoices >= 8 ? 421 : 211));
+    const int mode = b->lean_candidates == 0 ? RENDER_DIRECT : (b->lean_fm_candidates ? RENDER_LEAN_ALL : RENDER_LEAN_HARM);
+    // banks whose lean voices are all polynomial Harmonics take eight frames per lane on long blocks: the recurrence makes
+    // every frame after the second cost two FMAs of trigonometry (one table lookup per eight frames)
+    if (var == 0) var = b->nvoices >= 128 ? (2 * b->lean_candidates >= b->nvoices ? ((mode == RENDER_LEAN_HARM && nframes >= 16384) ? 484 : 444) : 844)
+                                          : (b->nvoices >= 64 ? 826 : (b->nvoices >= 8 ? 421 : 211));
     const int W = var / 100, F = (var / 10) % 10;
-    // enough workgroups to cover the 256 CUs several times over: split the voices into groups when the
-    // frame range alone gives too few tiles (SYNTHHIP_GROUPS overrides)
+    // Voice groups: split the voices when the frame range alone gives too few tiles for 256 CUs -- up to ONE round of
+    // resident workgroups (1024 slots of four waves), not beyond: 752 workgroups that all start at once beat 1504 whose
+    // second round runs half empty (MI355X, 1024 voices x 48 000 frames: 4 groups of 188 tiles 46.7 us, 8 groups 47.2, 16
+    // groups 50.1; eight frames per lane: 8 groups of 94 tiles 36.9, 16 groups 38.9, 4 groups 40.3).  SYNTHHIP_GROUPS overrides.
     const uint32_t tiles = sh::div_up(nframes, 64 * F);
+    const uint32_t slots = 4096u / (uint32_t)W;
     uint32_t groups = 1;
-    while (tiles * groups < 1024 && b->nvoices / (groups * 2) >= (uint32_t)(4 * W)) groups *= 2;
+    if (W == 4) {
+        while (tiles * groups * 2 <= slots && b->nvoices / (groups * 2) >= (uint32_t)(4 * W)) groups *= 2;
+    } else {                                                 // the eight-wave shapes of small / non-lean banks: cover the chip several times over
+        while (tiles * groups < 1024 && b->nvoices / (groups * 2) >= (uint32_t)(4 * W)) groups *= 2;
+    }
     {
         static int forced = -1;
         if (forced < 0) { const char* e = getenv("SYNTHHIP_GROUPS"); forced = e ? atoi(e) : 0; }
@@ -1889,11 +2031,18 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     const int prev_cur = b->cur;
     rc = acquire_records(b, start, nframes, st, cont);
     if (rc) return rc;
+    // lean candidates all polynomial Harmonics + several voice groups: the launch is split into a lean and a general kernel
+    // (see the RENDER_* modes); SYNTHHIP_NO_SPLIT=1 keeps the combined kernel
+    static int no_split = -1;
+    if (no_split < 0) { const char* e = getenv("SYNTHHIP_NO_SPLIT"); no_split = (e && e[0] == '1') ? 1 : 0; }
+    const bool split = mode == RENDER_LEAN_HARM && groups > 1 && !no_split;
     // partial buses: ring slot n % 4 (last read by the fold in launch n - 2, which is this stream's previous launch)
     double2* parts = nullptr;
     if (groups > 1) {
         const int k = (int)(n & 3);
-        const size_t need = (size_t)groups * nframes * sizeof(double2);
+        // split launch: the general kernel's parts follow the lean kernel's, then one flag per group
+        const size_t need = split ? 2 * (size_t)groups * nframes * sizeof(double2) + (size_t)groups * sizeof(uint32_t)
+                                  : (size_t)groups * nframes * sizeof(double2);
         if (S.parts_bytes[k] < need) {
             if (S.parts_buf[k]) {
                 SH_HIP(hipStreamSynchronize(S.stream));
@@ -1907,6 +2056,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         }
         parts = (double2*)S.parts_buf[k];
     }
+    uint32_t* gen_valid = split ? (uint32_t*)(parts + 2 * (size_t)groups * nframes) : nullptr;
     // Timing diagnostics only (wrong audio!): SYNTHHIP_DEBUG bit 0 drops the in-kernel prepare of the block two launches on
     // once the run is warm (the stale record sets are reused), bit 1 drops the in-kernel fold of the partial buses.
     static int debug = -1;
@@ -1919,6 +2069,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     double2* pv64 = take_over ? (double2*)prev.o64 : nullptr;
     uint32_t* pv16 = take_over ? (uint32_t*)prev.o16 : nullptr;
     const double pv_scale = take_over ? prev.scale : 0.0;
+    const uint32_t* pv_gen = (take_over && !(debug & 2)) ? (const uint32_t*)prev.gen_valid : nullptr;
     b->last_groups = groups;
     const LaunchSet cur = launch_set(b, b->cur);
     // the records of the block two launches on go to a set that is neither this launch's, nor its predecessor's (perhaps
@@ -1934,14 +2085,14 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     LaunchSet next = launch_set(b, target < 0 ? 0 : target);
     if (target < 0) next.launch = nullptr;
     if ((debug & 1) && n >= 8) next.launch = nullptr;
-    const int mode = b->lean_candidates == 0 ? RENDER_DIRECT : (b->lean_fm_candidates ? RENDER_LEAN_ALL : RENDER_LEAN_HARM);
 #define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
     hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),    \
                        trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64, \
-                       o16, pcm_scale, pv16, pv_scale)
+                       o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen)
 #define SH_LAUNCH_RENDER(W_, F_, M_)                                                 \
     do {                                                                             \
-        if (mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM);  \
+        if (split) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM_ONLY);                \
+        else if (mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM);  \
         else if (mode == RENDER_LEAN_ALL) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_ALL); \
         else SH_LAUNCH_MODE(W_, F_, M_, RENDER_DIRECT);                              \
     } while (0)
@@ -1955,6 +2106,8 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     case 411: SH_LAUNCH_RENDER(4, 1, 1); break;
     case 441: SH_LAUNCH_RENDER(4, 4, 1); break;
     case 444: SH_LAUNCH_RENDER(4, 4, 4); break;
+    case 484: SH_LAUNCH_RENDER(4, 8, 4); break;
+    case 884: SH_LAUNCH_RENDER(8, 8, 4); break;
     case 211: SH_LAUNCH_RENDER(2, 1, 1); break;
     case 221: SH_LAUNCH_RENDER(2, 2, 1); break;
     default: return sh::set_error(SH_ERR_INVALID, "sh_bank_render: unknown SYNTHHIP_VARIANT %d", var);
@@ -1962,6 +2115,17 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
 #undef SH_LAUNCH_RENDER
 #undef SH_LAUNCH_MODE
     SH_CHECK_LAUNCH("k_bank_render");
+    if (split) {
+        // the general lists of the same launch: four waves x four frames per lane whatever the lean kernel's shape (the parts
+        // are indexed by frame), same voice groups, behind the lean kernel on the same stream
+        LaunchSet none = cur;
+        none.launch = nullptr;
+        hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_ONLY>), dim3(sh::div_up(nframes, 256), groups), dim3(256), 0, st, ptrs(b),
+                           trig_table(), b->nvoices, vpg, cur, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
+                           (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
+                           gen_valid, (const uint32_t*)nullptr);
+        SH_CHECK_LAUNCH("k_bank_render(general lists)");
+    }
     if (use_aux) {
         SH_HIP(hipEventRecord(S.ev_aux, S.stream2));
         S.aux_busy = true;
@@ -1979,6 +2143,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         pc.o64 = o64;
         pc.o16 = o16;
         pc.scale = pcm_scale;
+        pc.gen_valid = gen_valid;
         S.run_count = n + 1;
         S.run_next_start = start + nframes;
     }

@@ -47,6 +47,30 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k(const FastRec* __restrict_
         double poly[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+        if constexpr (MODE == 3) {
+            // frames j >= 2 by the three-term recurrence x[j] = 2cos(64dt) x[j-1] - x[j-2] (one FMA per value instead of a
+            // two-FMA + two-MUL rotation); pad[0] holds 2cos(64dt)
+            const double k2 = q->pad[0];
+            double s0, c0, s1, c1;
+            shm::sincos_tab(fma(di0, dt, t_base), trig, s0, c0);
+            s1 = fma(s0, rc, c0 * rs);
+            c1 = fma(c0, rc, -(s0 * rs));
+#pragma unroll
+            for (int h = 0; h < FPL; h += 2) {
+                double p0 = fma(poly[0], c0, poly[1]), p1 = fma(poly[0], c1, poly[1]);
+#pragma unroll
+                for (int u = 2; u < 16; ++u) { p0 = fma(p0, c0, poly[u]); p1 = fma(p1, c1, poly[u]); }
+                const double x0 = p0 * s0, x1 = p1 * s1;
+                accl[h] = fma(gl, x0, accl[h]); accr[h] = fma(gr, x0, accr[h]);
+                accl[h + 1] = fma(gl, x1, accl[h + 1]); accr[h + 1] = fma(gr, x1, accr[h + 1]);
+                if (h + 2 < FPL) {
+                    const double s2 = fma(k2, s1, -s0), c2 = fma(k2, c1, -c0);
+                    const double s3 = fma(k2, s2, -s1), c3 = fma(k2, c2, -c1);
+                    s0 = s2; c0 = c2; s1 = s3; c1 = c3;
+                }
+            }
+            continue;
+        }
         double sn[FPL], cs[FPL], pv[FPL];
         shm::sincos_tab(fma(di0, dt, t_base), trig, sn[0], cs[0]);
 #pragma unroll
@@ -118,6 +142,7 @@ int main() {
         r.gl = 0.01; r.gr = 0.02;
         r.rot_c = cos(64 * r.dt); r.rot_s = sin(64 * r.dt);
         for (int u = 0; u < 16; ++u) r.poly[u] = (rand() % 2000 - 1000) * 1e-3;
+        r.pad[0] = 2.0 * cos(64 * r.dt);
     }
     std::vector<shm::sc_pair> trig(shm::TRIG_N);
     for (int k2 = 0; k2 < shm::TRIG_N; ++k2) { trig[k2].s = sin(2 * M_PI * k2 / shm::TRIG_N); trig[k2].c = cos(2 * M_PI * k2 / shm::TRIG_N); }
@@ -133,7 +158,7 @@ int main() {
         const uint32_t tiles = (nframes + 255) / 256, vpg = 128;
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
-            for (int it = 0; it < 2000; ++it)
+            for (int it = 0; it < 3000; ++it)
                 hipLaunchKernelGGL((k<4, 0, 8, 4, 5120>), dim3(tiles, 8), dim3(512), 0, 0, d_recs, d_trig, nvoices, vpg, nframes, d_parts);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -161,6 +186,13 @@ int main() {
         }
     }
     for (uint32_t groups : {8u}) {
+        run<4, 3, 4, 4>("FPL4 recurrence 4w min4", d_recs, d_trig, d_parts, nvoices, nframes, 8);
+        run<8, 3, 4, 4>("FPL8 recurrence 4w min4 g16", d_recs, d_trig, d_parts, nvoices, nframes, 16);
+        run<8, 3, 4, 5>("FPL8 recurrence 4w min5 g16", d_recs, d_trig, d_parts, nvoices, nframes, 16);
+        run<8, 3, 8, 4>("FPL8 recurrence 8w min4 g8", d_recs, d_trig, d_parts, nvoices, nframes, 8);
+        run<8, 3, 4, 4>("FPL8 recurrence 4w min4 g8", d_recs, d_trig, d_parts, nvoices, nframes, 8);
+        run<16, 3, 4, 4>("FPL16 recurrence 4w min4 g16", d_recs, d_trig, d_parts, nvoices, nframes, 16);
+        run<16, 3, 4, 3>("FPL16 recurrence 4w min3 g32", d_recs, d_trig, d_parts, nvoices, nframes, 32);
         run<4, 0, 8, 4>("FPL4 s_load rec, 8w min4", d_recs, d_trig, d_parts, nvoices, nframes, groups);
         run<4, 0, 8, 6>("FPL4 s_load rec, 8w min6", d_recs, d_trig, d_parts, nvoices, nframes, groups);
         run<4, 0, 8, 8>("FPL4 s_load rec, 8w min8", d_recs, d_trig, d_parts, nvoices, nframes, groups);
