@@ -1617,6 +1617,19 @@ struct sh_bank {
     uint32_t    lean_candidates = 0;      // voices that can take the lean loop in some launch (static properties)
     uint32_t    lean_fm_candidates = 0;   // ... of them other than polynomial Harmonics (FM Sine, plain waveforms)
     uint32_t    last_groups = 0;          // voice groups of the last sh_bank_render launch (sh_bank_launch_stats)
+    // When can a launch hold NO general voice (so that a split launch needs no general-lists kernel)?  Conservative, from
+    // static properties: every voice is a polynomial-Harmonics lean candidate, every envelope is on its sustain piece for the
+    // whole launch, and no phase-table piece shorter than the launch ends after its start (a launch then crosses at most one
+    // piece end per voice).  short_piece_end[k] = the largest end of any piece shorter than 2^k samples.
+    bool        all_lean_harm = false;
+    uint64_t    env_flat_from = 0, env_flat_until = ~0ull;
+    uint64_t    short_piece_end[34] = {};
+    bool        no_general_voice(uint64_t start, uint32_t nframes) const {
+        if (!all_lean_harm || start < env_flat_from || start + nframes > env_flat_until) return false;
+        int k = 0;
+        while ((1ull << k) < (uint64_t)nframes) ++k;
+        return short_piece_end[k] <= start;
+    }
     float2*     d_gains = nullptr;
     uint32_t    nsegs = 0, ncoefs = 0, npartials = 0;
     std::vector<sh_voice> h_voices;    // for validation of per-call arguments
@@ -1732,6 +1745,23 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             b->lean_candidates += 1;
             if (voices[i].kind != SH_HARMONICS) b->lean_fm_candidates += 1;       // needs the kernel with all record kinds
         }
+    {
+        b->all_lean_harm = b->lean_candidates == nvoices && b->lean_fm_candidates == 0;
+        for (uint32_t i = 0; i < nvoices && b->all_lean_harm; ++i) {
+            const sh_voice& v = voices[i];
+            if (v.env.enabled) {
+                if (v.env.n_decay_end > b->env_flat_from) b->env_flat_from = v.env.n_decay_end;
+                if (v.env.n_attack_end > b->env_flat_from) b->env_flat_from = v.env.n_attack_end;
+                if (v.env.n_sustain_end < b->env_flat_until) b->env_flat_until = v.env.n_sustain_end;
+            }
+            for (uint32_t k = 0; k + 1 < v.seg_count; ++k) {
+                const uint64_t a = segs[v.seg_offset + k].n0, e = segs[v.seg_offset + k + 1].n0;
+                const uint64_t len = e - a;
+                for (int q = 0; q < 34; ++q)
+                    if (len < (1ull << q) && e > b->short_piece_end[q]) b->short_piece_end[q] = e;
+            }
+        }
+    }
     std::vector<float2> gains(nvoices);
     for (uint32_t i = 0; i < nvoices; ++i) gains[i] = make_float2(voices[i].gain_l, voices[i].gain_r);
     int rc = upload_array(&b->d_voices, voices, nvoices, st);
@@ -2056,7 +2086,11 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         }
         parts = (double2*)S.parts_buf[k];
     }
-    uint32_t* gen_valid = split ? (uint32_t*)(parts + 2 * (size_t)groups * nframes) : nullptr;
+    // ... and the general-lists kernel is only launched when the launch CAN hold a general voice
+    static int always_general = -1;
+    if (always_general < 0) { const char* e = getenv("SYNTHHIP_ALWAYS_GENERAL"); always_general = (e && e[0] == '1') ? 1 : 0; }
+    const bool with_general = split && (always_general || !b->no_general_voice(start, nframes));
+    uint32_t* gen_valid = with_general ? (uint32_t*)(parts + 2 * (size_t)groups * nframes) : nullptr;
     // Timing diagnostics only (wrong audio!): SYNTHHIP_DEBUG bit 0 drops the in-kernel prepare of the block two launches on
     // once the run is warm (the stale record sets are reused), bit 1 drops the in-kernel fold of the partial buses.
     static int debug = -1;
@@ -2115,7 +2149,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
 #undef SH_LAUNCH_RENDER
 #undef SH_LAUNCH_MODE
     SH_CHECK_LAUNCH("k_bank_render");
-    if (split) {
+    if (with_general) {
         // the general lists of the same launch: four waves x four frames per lane whatever the lean kernel's shape (the parts
         // are indexed by frame), same voice groups, behind the lean kernel on the same stream
         LaunchSet none = cur;

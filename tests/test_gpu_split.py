@@ -1,0 +1,79 @@
+"""The split launch of sh_bank_render (lean Harmonics kernel with the three-term recurrence at eight frames per lane +
+general-lists kernel, csrc/osc.hip RENDER_LEAN_HARM_ONLY / RENDER_GENERAL_ONLY) against the combined kernel
+(SYNTHHIP_NO_SPLIT=1, four frames per lane by rotations) and against the C oracle -- the same voice tables, blocks
+that lie in the attack (every voice general), blocks whose voices cross a phase-table piece end, the steady state
+(no general voice: the general kernel leaves at once), and a bank in which only SOME voice groups hold general voices."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from synthesizer_amd.workloads import additive_voices
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+SR = 48000
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_split import banks, BLOCKS
+from synthesizer_amd.mixer import VoiceBank
+out = {}
+for name, (voices, gains) in banks().items():
+    bank = VoiceBank(voices, gains=gains)
+    for n, start in BLOCKS:
+        out["%%s_%%d_%%d" %% (name, n, start)] = bank.render(n, start=start)
+np.savez(sys.argv[1], **out)
+"""
+
+BLOCKS = [(48000, 0), (48000, 48000), (20000, 5 * 48000), (48000, 200 * 48000), (16384, 3 * 48000 + 11)]
+
+
+def banks():
+    from synthesizer_amd import oscillators as G
+    v, g = additive_voices(G, 1024, SR, seed=3, adsr={"sustain": 1.0e6})
+    out = {"additive1024": (v, g)}
+    # general voices (a bias keeps a Harmonics voice out of the lean loop) in the first and the last voice group only
+    v2, g2 = additive_voices(G, 640, SR, seed=4, adsr={"sustain": 1.0e6})
+    harm = [(k, 1.0 / k) for k in range(1, 9)]
+    for i in (3, 17, 600, 639):
+        v2[i] = G.Harmonics(100.0 + i, harm, amplitude=0.01, bias=0.001, samplerate=SR)
+    out["mixed640"] = (v2, g2)
+    return out
+
+
+def test_split_launch_equals_combined_kernel_and_oracle(gpu, tmp_path):
+    from oracle import c_oracle as CO
+    from oracle import synth_oracle as O
+    from synthesizer_amd.mixer import VoiceBank
+    # the combined kernel's output, from a process of its own (the switches are read once per process)
+    ref = tmp_path / "nosplit.npz"
+    env = dict(os.environ, SYNTHHIP_NO_SPLIT="1", SYNTHHIP_VARIANT="444")
+    p = subprocess.run([sys.executable, "-c", _CHILD % str(ROOT), str(ref)], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    want = np.load(ref)
+    for name, (voices, gains) in banks().items():
+        bank = VoiceBank(voices, gains=gains)
+        for n, start in BLOCKS:
+            got = bank.render(n, start=start)
+            w = want["%s_%d_%d" % (name, n, start)]
+            scale = max(1e-3, float(np.max(np.abs(w))))
+            # other frames per lane, recurrence instead of rotations, another order of the general voices: float64 noise
+            # before ONE rounding to float32
+            assert np.max(np.abs(got.astype(np.float64) - w)) <= 1.3e-7 * scale, (name, n, start)
+            assert np.mean(got != w) < 2e-3, (name, n, start, float(np.mean(got != w)))
+    # and against the C restatement of the oracle on a window the CPU finishes quickly: 64 of the voices, 1 s
+    from synthesizer_amd import oscillators as G
+    v, g = additive_voices(G, 1024, SR, seed=3, adsr={"sustain": 1.0e6})
+    ov, _ = additive_voices(O, 1024, SR, seed=3, adsr={"sustain": 1.0e6})
+    sub = slice(0, 1024, 16)
+    n = 48000
+    bank = VoiceBank(v[sub] * 4, gains=g[sub] * 4)             # 256 voices: the split path (several voice groups)
+    got = bank.render(n, start=0)
+    rows = np.stack([CO.render(o, n) for o in ov[sub]])
+    bus = np.array(CO.mix_bus(rows, g[sub]), dtype=np.float64) * 4.0
+    assert np.sqrt(np.mean((got - bus) ** 2)) <= 1e-6 / 3

@@ -16,7 +16,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o stats -- \
 # kernel-trace average is the per-launch time and can be set against bench.py's HIP-event figure of the same run
 SYNTHHIP_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o serial -- \
     python bench.py --steps 100 --warmup 5 --cpu-frames 0 --no-pcm-rows --no-two-step --no-configs > gpurun_out/prof_${TAG}_bench_serial.json 2>> gpurun_out/prof_${TAG}_stats.err
-SHORT="python bench.py --steps 10 --warmup 2 --cpu-frames 0 --min-seconds 0 --no-configs"
+# counters: blocks 100 .. 190 of the stream (the steady state the timed passes of a default run sit in)
+SHORT="python bench.py --steps 30 --warmup 100 --cpu-frames 0 --min-seconds 0 --no-configs"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$D" -o fetch -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$D" -o write -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_WAVES SQ_WAVE_CYCLES \
