@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "devmath.hpp"
 #include <new>
+#include <type_traits>
 #include <vector>
 #include <stdlib.h>
 
@@ -399,6 +400,29 @@ __global__ __launch_bounds__(64) void k_prepare_chunks(BankPtrs B, LaunchSet S, 
     prepare_chunk(B, S, blockIdx.x, nvoices, start, nframes);
 }
 
+// Segment s of a long materialisation: the frames [s * seg_frames, ...) of the launch get a record set of their own, laid out
+// one after the other in arrays of nseg * nvoices records (counts: nseg * 4 * nchunks).
+__device__ __forceinline__ LaunchSet segment_set(const LaunchSet& base, uint32_t s, uint32_t nvoices) {
+    const uint32_t nchunks = (nvoices + 63) / 64;
+    LaunchSet r;
+    r.launch = base.launch + (size_t)s * nvoices;
+    r.fm = base.fm + (size_t)s * nvoices;
+    r.fast = base.fast + (size_t)s * nvoices;
+    r.gen_idx = base.gen_idx + (size_t)s * nvoices;
+    r.counts = base.counts + (size_t)s * 4 * nchunks;
+    return r;
+}
+
+// grid = (chunks, segments): the launch records of every segment of a long materialisation in one launch.  (All segments
+// read and write the per-voice piece hint; whatever value a lane finds there is checked before use.)
+__global__ __launch_bounds__(64) void k_prepare_segments(BankPtrs B, LaunchSet base, uint32_t nvoices, uint64_t start, uint32_t nframes,
+                                                         uint32_t seg_frames) {
+    const uint32_t s = blockIdx.y;
+    const uint32_t first = s * seg_frames;
+    const uint32_t n = nframes - first < seg_frames ? nframes - first : seg_frames;
+    prepare_chunk(B, segment_set(base, s, nvoices), blockIdx.x, nvoices, start + first, n);
+}
+
 struct VoiceRegs {                // the hot part of the launch record as plain scalars (SGPRs)
     double   t_base, dt;
     uint32_t remain, flags;
@@ -742,10 +766,15 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
 // a wave owns one tile and walks the chunk's lean records with the loop of k_bank_render (the sample is rounded and
 // stored instead of accumulated), then the general list through voice_block, then zero-fills the rows of silent voices.
 // The lean arithmetic repeats the general code's order -- ((x * amplitude) + 0) * g0u.
-template <int FPL>
+// LEAN = false: only the general and the silent list (the lean records went through k_generate_lean_harm).
+template <int FPL, bool LEAN>
 __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                          uint32_t nvoices, LaunchSet cur, uint64_t start, uint32_t n,
                                                                          float* __restrict__ out32, size_t stride) {
+    if constexpr (!LEAN) {                     // nothing but lean voices in this chunk: leave before the table is staged
+        const uint32_t SH_CONST_AS* cnt0 = as_const(cur.counts) + 4 * blockIdx.y;
+        if (cnt0[1] + cnt0[2] == 0) return;
+    }
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
     __syncthreads();
@@ -765,7 +794,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
     }
     const uint32_t c = blockIdx.y;
     const uint32_t SH_CONST_AS* cnt = as_const(cur.counts) + 4 * c;
-    const uint32_t nfast = cnt[0], ngen = cnt[1], nsilent = cnt[2];
+    const uint32_t nfast = LEAN ? cnt[0] : 0u, ngen = cnt[1], nsilent = cnt[2];
     const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64;
     for (uint32_t p = 0; p < nfast; ++p, ++q) {
         const uint32_t remain = q->remain, kind = q->kind, vi = q->vi;
@@ -879,6 +908,111 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
             const uint32_t raw = tile0 + j * 64 + lane;
             if (raw < n) out32[(size_t)vi * stride + raw] = 0.0f;
         }
+    }
+}
+
+// Materialisation of the lean polynomial-Harmonics records of a launch (banks whose lean candidates are all of that kind):
+// grid = (groups of 4 tiles of 64*FPL frames, 64-voice chunks); a wave owns one tile and walks the chunk's lean records with
+// the arithmetic of the render kernel's lean loop -- one table lookup, one rotation, the three-term recurrence, Horner -- and
+// stores FPL coalesced 256-byte row segments per record: base address of the row in SGPRs, one lane offset for all rows, the
+// frame's 256*j bytes as the instruction's immediate.  No general code in this kernel (k_generate_lists<4, false> follows
+// for the general and silent lists): 4 B written per voice-sample is what should bind it, not the scalar unit.
+// The sample repeats the general code's order, ((x * amplitude) + 0) * g0u, before its one rounding to float32.
+// A long row is cut into segments of seg_frames (a multiple of the tile) with a record set each (k_prepare_segments): a
+// record describes at most two phase-table pieces, and ten seconds of a high voice run through more.
+template <int FPL>
+__global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
+                                                               uint32_t total, uint32_t seg_frames,
+                                                               float* __restrict__ out32_all, size_t stride) {
+    __shared__ shm::sc_pair trig[shm::TRIG_N];
+    for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t abs0 = (blockIdx.x * 4 + wave) * (64 * FPL);       // the tile's first frame in the whole launch
+    if (abs0 >= total) return;
+    const uint32_t seg = abs0 / seg_frames;                            // (uniform) its segment, and everything relative to it
+    const uint32_t seg_first = seg * seg_frames;
+    const uint32_t n = total - seg_first < seg_frames ? total - seg_first : seg_frames;
+    const uint32_t tile0 = abs0 - seg_first;
+    const LaunchSet cur = segment_set(base, seg, nvoices);
+    float* __restrict__ out32 = out32_all + seg_first;
+    uint32_t tile_last = tile0 + 64 * FPL - 1;
+    if (tile_last > n - 1) tile_last = n - 1;
+    const uint32_t c = blockIdx.y;
+    const uint32_t nfast = as_const(cur.counts)[4 * c];
+    const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64;
+    const uint32_t i0 = tile0 + lane;
+    const double di0 = (double)i0;
+    float* __restrict__ col = out32 + i0;                      // + vi * stride per record (uniform), + 64 * j per frame
+    for (uint32_t p = 0; p < nfast; ++p, ++q) {
+        const uint32_t remain = q->remain, vi = q->vi;
+        const double amp = q->amplitude, g0u = q->g0u;
+        const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
+        double poly[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+        asm volatile("" :: "s"(amp), "s"(g0u), "s"(remain), "s"(vi), "s"(ta), "s"(da), "s"(rca), "s"(rsa),
+                     "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
+                     "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
+                     "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
+        double t_base = ta, dt = da, rc = rca, rs = rsa, off = 0.0, tb = ta, db = da, ob = 0.0;
+        bool straddle = false;
+        if (remain != 0xFFFFFFFFu && tile_last >= remain) {   // not wholly on the first piece
+            tb = q->t0_b; db = q->dt_b; ob = q->off_b;
+            const double rcb = q->rot_c_b, rsb = q->rot_s_b;
+            straddle = tile0 < remain;
+            if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
+        }
+        auto theta = [&](int j) {
+            const uint32_t ii = i0 + (uint32_t)j * 64u;
+            const double dd = di0 + (double)(j * 64);
+            return ii < remain ? fma(dd, da, ta) : fma(dd - ob, db, tb);
+        };
+        double s0, c0, s1, c1;
+        shm::sincos_tab(straddle ? theta(0) : fma(di0 - off, dt, t_base), trig, s0, c0);
+        if (straddle) {
+            shm::sincos_tab(theta(1), trig, s1, c1);
+        } else {
+            s1 = fma(s0, rc, c0 * rs);
+            c1 = fma(c0, rc, -(s0 * rs));
+        }
+        const double k2 = rc + rc;
+        float* __restrict__ row = col + (size_t)vi * stride;
+        // amplitude and (constant) envelope gain scale the sine ONCE: the recurrence is linear, so every later frame's sine
+        // arrives scaled and the sample is one product, p * s (differs from the general code's ((x * amplitude) + 0) * g0u
+        // by float64 rounding only)
+        const double ag = amp * g0u;
+        s0 *= ag;
+        s1 *= ag;
+        auto frames = [&](auto full_tile) {
+            constexpr bool FULL = decltype(full_tile)::value;
+#pragma unroll
+            for (int h = 0; h < FPL; h += 2) {
+                double p0 = fma(poly[0], c0, poly[1]), p1 = fma(poly[0], c1, poly[1]);
+#pragma unroll
+                for (int u = 2; u < 16; ++u) {
+                    p0 = fma(p0, c0, poly[u]);
+                    p1 = fma(p1, c1, poly[u]);
+                }
+                // streaming stores: the rows are not read again by this kernel (1.97 GB per launch of the benchmark shape)
+                if (FULL || i0 + (uint32_t)h * 64u < n) __builtin_nontemporal_store((float)(p0 * s0), row + h * 64);
+                if (FULL || i0 + (uint32_t)(h + 1) * 64u < n) __builtin_nontemporal_store((float)(p1 * s1), row + (h + 1) * 64);
+                if (h + 2 < FPL) {
+                    if (straddle) {
+                        shm::sincos_tab(theta(h + 2), trig, s0, c0);
+                        shm::sincos_tab(theta(h + 3), trig, s1, c1);
+                        s0 *= ag;
+                        s1 *= ag;
+                    } else {
+                        const double s2 = fma(k2, s1, -s0), c2 = fma(k2, c1, -c0);
+                        const double s3 = fma(k2, s2, -s1), c3 = fma(k2, c2, -c1);
+                        s0 = s2; c0 = c2; s1 = s3; c1 = c3;
+                    }
+                }
+            }
+        };
+        if (tile0 + 64 * FPL <= n) frames(std::true_type()); else frames(std::false_type());
     }
 }
 
@@ -1606,6 +1740,9 @@ struct sh_bank {
     uint32_t*   d_gen_idx_buf[NSETS] = {};
     uint32_t*   d_counts_buf[NSETS] = {};      // 4 per 64-voice chunk: lean, general, silent, -
     uint32_t*   d_hint = nullptr;
+    // record sets of a segmented materialisation (sh_bank_generate over long rows), gen_segs of them, allocated on demand
+    LaunchSet   gen_set = {};
+    uint32_t    gen_segs = 0;
     double2*    d_seg_rot = nullptr;       // (cos, sin)(64*dt) per table piece
     double2*    d_lfo_rot = nullptr;       // (cos, sin)(64*lfo_d) per voice
     VoiceLaunch* d_launch = nullptr;       // the set the next kernel reads
@@ -1822,6 +1959,11 @@ int sh_bank_destroy(sh_bank* b) {
         }
         if (b->d_gains) (void)hipFree(b->d_gains);
         if (b->d_hint) (void)hipFree(b->d_hint);
+        if (b->gen_set.launch) (void)hipFree(b->gen_set.launch);
+        if (b->gen_set.fm) (void)hipFree(b->gen_set.fm);
+        if (b->gen_set.fast) (void)hipFree(b->gen_set.fast);
+        if (b->gen_set.gen_idx) (void)hipFree(b->gen_set.gen_idx);
+        if (b->gen_set.counts) (void)hipFree(b->gen_set.counts);
         if (b->d_seg_rot) (void)hipFree(b->d_seg_rot);
         if (b->d_lfo_rot) (void)hipFree(b->d_lfo_rot);
     }
@@ -1959,23 +2101,71 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
         return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: output buffer too small");
     int rc = bank_check_plain(b, "sh_bank_generate");
     if (rc) return rc;
-    rc = acquire_records(b, start, nframes, sh::state().stream, false);
-    if (rc) return rc;
     // frames per lane: 4 for long rows (one sin/cos lookup + three rotations per voice, as in k_bank_render), else 2 / 1
     const int fpl = nframes >= 8192 ? 4 : (nframes >= 2048 ? 2 : 1);
+    float* o = (float*)voices_out->ptr;
+    if (fpl == 4 && b->lean_candidates != 0 && b->lean_fm_candidates == 0) {
+        // Long rows, every lean candidate a polynomial Harmonics voice: the lean records by the recurrence kernel at sixteen frames
+        // per lane, then the general and silent lists -- unless the segment provably has none.  Rows longer than a segment get
+        // one record set per segment, all resolved by ONE prepare launch.
+        constexpr int LF = 16;                               // 1024 x 480 000 on MI355X: 16 frames per lane 496 us, 8: 508
+        constexpr uint32_t SEG = 65536;                      // frames per segment (a multiple of the 1024-frame tile)
+        const uint32_t nseg = sh::div_up(nframes, SEG);
+        hipStream_t st = sh::state().stream;
+        const uint32_t nchunks = sh::div_up(b->nvoices, 64);
+        LaunchSet base;
+        if (nseg == 1) {
+            rc = acquire_records(b, start, nframes, st, false);
+            if (rc) return rc;
+            base = launch_set(b, b->cur);
+        } else {
+            if (b->gen_segs < nseg) {
+                SH_HIP(hipStreamSynchronize(st));
+                LaunchSet& g = b->gen_set;
+                if (g.launch) { (void)hipFree(g.launch); (void)hipFree(g.fm); (void)hipFree(g.fast); (void)hipFree(g.gen_idx); (void)hipFree(g.counts); g = LaunchSet(); }
+                b->gen_segs = 0;
+                SH_HIP(hipMalloc((void**)&g.launch, sizeof(VoiceLaunch) * (size_t)nseg * b->nvoices));
+                SH_HIP(hipMalloc((void**)&g.fm, sizeof(VoiceFM) * (size_t)nseg * b->nvoices));
+                SH_HIP(hipMalloc((void**)&g.fast, sizeof(FastRec) * (size_t)nseg * b->nvoices));
+                SH_HIP(hipMalloc((void**)&g.gen_idx, sizeof(uint32_t) * (size_t)nseg * b->nvoices));
+                SH_HIP(hipMalloc((void**)&g.counts, sizeof(uint32_t) * 4 * (size_t)nseg * nchunks));
+                b->gen_segs = nseg;
+            }
+            base = b->gen_set;
+            hipLaunchKernelGGL(k_prepare_segments, dim3(nchunks, nseg), dim3(64), 0, st, ptrs(b), base, b->nvoices, start, nframes, SEG);
+            SH_CHECK_LAUNCH("k_prepare_segments");
+        }
+        hipLaunchKernelGGL(k_generate_lean_harm<LF>, dim3(sh::div_up(nframes, 256 * LF), nchunks), dim3(256), 0, st,
+                           trig_table(), base, b->nvoices, nframes, nseg == 1 ? (nframes + 1023u) / 1024u * 1024u : SEG, o, stride);
+        SH_CHECK_LAUNCH("k_generate_lean_harm");
+        for (uint32_t sg = 0; sg < nseg; ++sg) {
+            const uint32_t first = sg * SEG, n = nframes - first < SEG ? nframes - first : SEG;
+            if (b->no_general_voice(start + first, n)) continue;
+            LaunchSet cur = base;
+            if (nseg > 1) {
+                cur.launch += (size_t)sg * b->nvoices; cur.fm += (size_t)sg * b->nvoices; cur.fast += (size_t)sg * b->nvoices;
+                cur.gen_idx += (size_t)sg * b->nvoices; cur.counts += (size_t)sg * 4 * nchunks;
+            }
+            hipLaunchKernelGGL((k_generate_lists<4, false>), dim3(sh::div_up(n, 1024), nchunks), dim3(256), 0, st,
+                               ptrs(b), trig_table(), b->nvoices, cur, start + first, n, o + first, stride);
+            SH_CHECK_LAUNCH("k_generate_lists");
+        }
+        return SH_OK;
+    }
+    rc = acquire_records(b, start, nframes, sh::state().stream, false);
+    if (rc) return rc;
     const uint32_t tile_groups = sh::div_up(nframes, 256 * fpl);
     // voices per block: as many as keeps >= ~4096 blocks in flight (and gridDim.y <= 65535)
     uint32_t vpg = 1;
     while (vpg < 64 && (uint64_t)tile_groups * ((b->nvoices + 2 * vpg - 1) / (2 * vpg)) >= 4096) vpg *= 2;
     while ((b->nvoices + vpg - 1) / vpg > 65535) vpg *= 2;
     const uint32_t groups = (b->nvoices + vpg - 1) / vpg;
-    float* o = (float*)voices_out->ptr;
 #define SH_GEN(F_) hipLaunchKernelGGL(k_generate<F_>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,            \
                                       ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, \
                                       (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride)
     if (fpl == 4 && b->lean_candidates != 0) {
         // long rows of a bank with lean candidates: one workgroup column per 64-voice chunk, walking the launch's lists
-        hipLaunchKernelGGL(k_generate_lists<4>, dim3(tile_groups, sh::div_up(b->nvoices, 64)), dim3(256), 0, sh::state().stream,
+        hipLaunchKernelGGL((k_generate_lists<4, true>), dim3(tile_groups, sh::div_up(b->nvoices, 64)), dim3(256), 0, sh::state().stream,
                            ptrs(b), trig_table(), b->nvoices, launch_set(b, b->cur), start, nframes, o, stride);
     } else if (fpl == 4) SH_GEN(4); else if (fpl == 2) SH_GEN(2); else SH_GEN(1);
 #undef SH_GEN

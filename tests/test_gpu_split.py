@@ -77,3 +77,28 @@ def test_split_launch_equals_combined_kernel_and_oracle(gpu, tmp_path):
     rows = np.stack([CO.render(o, n) for o in ov[sub]])
     bus = np.array(CO.mix_bus(rows, g[sub]), dtype=np.float64) * 4.0
     assert np.sqrt(np.mean((got - bus) ** 2)) <= 1e-6 / 3
+
+
+def test_segmented_materialisation_of_long_rows(gpu):
+    """sh_bank_generate over rows longer than one 65 536-frame segment: one record set per segment from ONE prepare launch,
+    the lean Harmonics kernel over all of them, the general / silent lists per segment where they can exist."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    nv, n, start = 160, 150_001, 777                     # attack + decay lie in segment 0; the last segment is ragged
+    v, g = additive_voices(G, nv, SR, seed=8, adsr={"sustain": 2.0})     # ... and the release (then silence) in segment 1 / 2
+    bank = VoiceBank(v, gains=g)
+    rows = bank.generate(n, start=start)
+    assert rows.shape == (nv, n)
+    for i in (0, 63, 64, 159):                           # the oscillator on its own (general code, one frame per lane)
+        one = v[i].render(n, start=start)
+        assert np.max(np.abs(rows[i] - one)) < 2e-7 and np.mean(rows[i] != one) < 0.01, i
+    # silent after the release
+    assert not rows[:, int(2.3 * SR):].any()
+    # the same rows from short launches (one record set each)
+    for lo in (0, 40_000, 100_000):
+        part = bank.generate(30_000, start=start + lo)
+        assert np.max(np.abs(part - rows[:, lo:lo + 30_000])) < 2e-7
+    # mixed down: two-step == fused within float32 summation noise
+    two = bank.render_two_step(n, start=start)
+    fused = bank.render(n, start=start)
+    assert np.sqrt(np.mean((two.astype(np.float64) - fused) ** 2)) <= 5e-7
