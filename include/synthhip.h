@@ -56,7 +56,9 @@ typedef enum sh_kind {     /* oscillators.py class names */
     SH_SINE = 0, SH_SAWTOOTH = 1, SH_SQUARE = 2, SH_PULSE = 3, SH_HARMONICS = 4, SH_TRIANGLE = 5,
     SH_LINEAR = 6,         /* Linear: the sample IS the accumulated value of the phase table (level += increment until
                             * it leaves (min, max); the host ends the table with a constant piece there) */
-    SH_NOISE = 7           /* WhiteNoise: sample-and-hold uniform noise from a counter-based generator, below */
+    SH_NOISE = 7,          /* WhiteNoise: sample-and-hold uniform noise from a counter-based generator, below */
+    SH_BUFFER = 8          /* a voice whose float64 samples were rendered elsewhere (MixingFilter, EchoFilter, nested envelopes ...):
+                            * row fm_row[voice] of sh_bank_render_rows' matrix; the fused envelope and the bus gains still apply */
 } sh_kind;
 
 typedef enum sh_fm_mode {
@@ -229,6 +231,22 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
  * synth -> Sample.from_osc_block -> mixer route) stays on the two-stream pipeline described above instead of ending
  * the run with a quantise kernel after every block.  The same rule about reading the buffer applies. */
 int sh_bank_render_pcm(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* pcm_i16);
+
+/* ---- banks whose voices are modulated by arbitrary oscillators (fm_lfo= / pwm_lfo= any Oscillator, upstream oscillators.py)
+ *      or ARE arbitrary oscillator graphs (filters): the modulators / sources are rendered as float64 rows of one matrix
+ *      [row][row_stride] (launch-relative: element i = frame start + i) and the bank's general code reads them.
+ * sh_bank_set_rows: per voice, the row holding L(start + i) = running sum of its fm_lfo (SH_FM_BUFFER voices) or its samples
+ *   (SH_BUFFER voices) in fm_row, the row holding its pulse width per sample in pwm_row (Pulse with a pwm_lfo); -1 = none.
+ * sh_bank_generate_f64: every voice of a bank of closed-form oscillators as float64 rows row0 .. row0 + nvoices - 1 (one launch
+ *   for all the modulators of a bank).
+ * sh_scan_rows_f64: rows row0 .. row0 + nrows - 1 replaced by their exclusive running sums, row r continuing from carry[r]
+ *   (device buffer of nrows doubles, updated to the carry-out: consecutive blocks chain without a host round trip).
+ * sh_bank_render_rows: sh_bank_render with that matrix. */
+int sh_bank_set_rows(sh_bank* b, const int32_t* fm_row, const int32_t* pwm_row);
+int sh_bank_generate_f64(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* rows_out, size_t row0, size_t row_stride);
+int sh_scan_rows_f64(sh_buf* rows, size_t row0, uint32_t nrows, uint32_t n, size_t row_stride, sh_buf* carry);
+int sh_bank_render_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
+                        sh_buf* bus_f32, sh_buf* bus_f64);
 
 /* ---- mixer sum bus over materialised voices ------------------------------------------ */
 /* float32: bus[i] = sum_v gains[v] * voices[v*stride+i]; gains = device buffer of nvoices x (l, r) floats */

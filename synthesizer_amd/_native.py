@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ.get("SYNTHHIP_LIB", HERE / "libsynthhip.so"))
 
 SH_OK = 0
 SH_ERR_INVALID, SH_ERR_HIP, SH_ERR_NOMEM, SH_ERR_NOTINIT, SH_ERR_OVERFLOW, SH_ERR_RCCL, SH_ERR_LENGTH = -1, -2, -3, -4, -5, -6, -7
-SH_SINE, SH_SAWTOOTH, SH_SQUARE, SH_PULSE, SH_HARMONICS, SH_TRIANGLE, SH_LINEAR, SH_NOISE = range(8)
+SH_SINE, SH_SAWTOOTH, SH_SQUARE, SH_PULSE, SH_HARMONICS, SH_TRIANGLE, SH_LINEAR, SH_NOISE, SH_BUFFER = range(9)
 SH_EW_ADD, SH_EW_MUL, SH_EW_CLIP, SH_EW_ABS, SH_EW_COPY, SH_EW_FILL, SH_EW_AXPY = range(7)
 SH_FM_NONE, SH_FM_SINE, SH_FM_BUFFER = range(3)
 SH_DIST_ID_BYTES = 128
@@ -94,6 +94,10 @@ _SIGNATURES = {
     "sh_bank_generate": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t]),
     "sh_bank_render": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, _P]),
     "sh_bank_render_pcm": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_double, _P]),
+    "sh_bank_set_rows": (C.c_int, [_P, _P, _P]),
+    "sh_bank_generate_f64": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t, C.c_size_t]),
+    "sh_scan_rows_f64": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t, _P]),
+    "sh_bank_render_rows": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t, _P, _P]),
     "sh_mix_bus_f32": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P, _P]),
     "sh_mix_chain_i16": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P]),
     "sh_mix_chain_gather_i16": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, _P, C.c_size_t]),

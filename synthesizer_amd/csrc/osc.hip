@@ -39,6 +39,13 @@ struct BankPtrs {
     uint32_t*         hint;       // per voice: table piece of the last prepared launch (streaming: same or next piece)
     const double2*    seg_rot;    // per table piece: (cos, sin)(64*dt), computed once on the host at bank creation
     const double2*    lfo_rot;    // per voice: (cos, sin)(64*lfo_d)
+    // per launch (sh_bank_render_rows): float64 rows [row][row_stride], launch-relative -- the running LFO sum of an
+    // SH_FM_BUFFER voice (fm_row), the pulse width per sample of a Pulse with a pwm_lfo (pwm_row), or the samples themselves of
+    // an SH_BUFFER voice (fm_row); -1 = none.  NULL outside such launches.
+    const double*     rows;
+    size_t            row_stride;
+    const int32_t*    fm_row;
+    const int32_t*    pwm_row;
 };
 
 // Pointers to data that no thread of the running kernel writes are cast to the constant address space:
@@ -58,7 +65,7 @@ __device__ __forceinline__ const T SH_CONST_AS* as_const(const T* p) {
 // wave: the phase-table piece that holds `start`, and the envelope as lines in the launch-relative frame
 // index i = n - start.  The scalar unit (one per CU) is the scarce resource of these kernels, so the
 // record is laid out to cost the hot path one batch of loads and almost no scalar arithmetic.
-constexpr uint32_t FL_KIND = 0x7, FL_FM_SHIFT = 4, FL_FM = 0x30, FL_DENSE = 0x40, FL_ENV_UNIFORM = 0x80,
+constexpr uint32_t FL_KIND = 0xF, FL_FM_SHIFT = 4, FL_FM = 0x30, FL_DENSE = 0x40, FL_ENV_UNIFORM = 0x80,
                    FL_POLY = 0x100, FL_FOLDED = 0x200, FL_FLIP = 0x400, FL_SILENT = 0x800;
 constexpr uint32_t NO_TAIL = 0xFFFFFFFFu;
 constexpr int NXP = 12;                             // following phase-table pieces a launch record lists
@@ -605,6 +612,10 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
 #pragma unroll
             for (int j = 0; j < FPL; ++j) x[j] = th[j];
             break;
+        case SH_BUFFER:                            // the samples were rendered elsewhere (a filter graph): row[i]
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = fm_cumsum ? fm_cumsum[i[j]] : 0.0;
+            break;
         case SH_NOISE: {
             const uint64_t seed = vfull->noise_seed;
             const uint32_t hold = vfull->noise_hold;
@@ -1026,6 +1037,14 @@ __device__ __forceinline__ void general_voice(const VoiceRegs& r, const VoiceFM*
                                               double (&accl)[FPL], double (&accr)[FPL]) {
     constexpr int GF = FPL > 4 ? 4 : FPL;
     static_assert(FPL % GF == 0, "frames per lane: 1, 2, 4 or a multiple of 4");
+    const double* fm_p = nullptr;
+    const double* pwm_p = nullptr;
+    if (B.rows) {                                              // (uniform) this voice's rows of the launch's modulation matrix
+        const uint32_t vidx = (uint32_t)(vfull - B.voices);
+        const int32_t fr = as_const(B.fm_row)[vidx], pr = as_const(B.pwm_row)[vidx];
+        if (fr >= 0) fm_p = B.rows + (size_t)fr * B.row_stride;
+        if (pr >= 0) pwm_p = B.rows + (size_t)pr * B.row_stride;
+    }
 #pragma unroll
     for (int h = 0; h < FPL / GF; ++h) {
         const uint32_t first = tile0 + (uint32_t)h * 64 * GF;
@@ -1036,7 +1055,7 @@ __device__ __forceinline__ void general_voice(const VoiceRegs& r, const VoiceFM*
         double dh[GF], x[GF];
 #pragma unroll
         for (int j = 0; j < GF; ++j) { ih[j] = i[h * GF + j]; dh[j] = di[h * GF + j]; }
-        voice_block<GF, true>(r, fmrec, B, vfull, start, last, ih, dh, nullptr, nullptr, trig, x);
+        voice_block<GF, true>(r, fmrec, B, vfull, start, last, ih, dh, fm_p, pwm_p, trig, x);
 #pragma unroll
         for (int j = 0; j < GF; ++j) {
             accl[h * GF + j] = fma(r.gain_l, x[j], accl[h * GF + j]);
@@ -1721,6 +1740,64 @@ __global__ __launch_bounds__(256) void k_scan_apply(const double* __restrict__ x
     }
 }
 
+// The same scan for many rows at once (the modulators of a bank): blockIdx.y = row; x and out may be the same buffer;
+// carry[row] is read as the row's carry-in and replaced by its carry-out, on the device: consecutive blocks chain without a
+// host round trip.
+__global__ __launch_bounds__(256) void k_scan_rows_tile_sums(const double* __restrict__ x, size_t stride, uint32_t n, uint32_t ntiles,
+                                                             double* __restrict__ sums) {
+    __shared__ double sh[256];
+    const double* xr = x + (size_t)blockIdx.y * stride;
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (base + j < n) s += xr[base + j];
+    double total;
+    block_exclusive_scan_256(s, sh, total);
+    if (threadIdx.x == 0) sums[(size_t)blockIdx.y * (ntiles + 1) + blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_scan_rows_sums(double* __restrict__ sums, uint32_t ntiles, double* __restrict__ carry) {
+    __shared__ double sh[256];
+    __shared__ double run;
+    double* sr = sums + (size_t)blockIdx.x * (ntiles + 1);
+    if (threadIdx.x == 0) run = carry[blockIdx.x];
+    __syncthreads();
+    for (uint32_t base = 0; base < ntiles; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const double v = (i < ntiles) ? sr[i] : 0.0;
+        double total;
+        const double ex = block_exclusive_scan_256(v, sh, total);
+        const double c = run;
+        if (i < ntiles) sr[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) run = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) carry[blockIdx.x] = run;
+}
+
+__global__ __launch_bounds__(256) void k_scan_rows_apply(const double* x, size_t stride, uint32_t n, uint32_t ntiles,
+                                                         const double* __restrict__ sums, double* out) {
+    __shared__ double sh[256];
+    const double* xr = x + (size_t)blockIdx.y * stride;
+    double* outr = out + (size_t)blockIdx.y * stride;
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+    double v[8];
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = (base + j < n) ? xr[base + j] : 0.0;
+        s += v[j];
+    }
+    double total;
+    double ex = block_exclusive_scan_256(s, sh, total) + sums[(size_t)blockIdx.y * (ntiles + 1) + blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (base + j < n) outr[base + j] = ex;
+        ex += v[j];
+    }
+}
+
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------
@@ -1740,6 +1817,13 @@ struct sh_bank {
     uint32_t*   d_gen_idx_buf[NSETS] = {};
     uint32_t*   d_counts_buf[NSETS] = {};      // 4 per 64-voice chunk: lean, general, silent, -
     uint32_t*   d_hint = nullptr;
+    // modulation rows (sh_bank_set_rows / sh_bank_render_rows)
+    int32_t*    d_fm_row = nullptr;
+    int32_t*    d_pwm_row = nullptr;
+    int32_t     fm_row_max = -1;
+    bool        needs_rows = false;        // some voice reads a row: SH_FM_BUFFER, SH_BUFFER, or a pwm row was set
+    const double* launch_rows = nullptr;   // set for the duration of one sh_bank_render_rows call
+    size_t      launch_row_stride = 0;
     // record sets of a segmented materialisation (sh_bank_generate over long rows), gen_segs of them, allocated on demand
     LaunchSet   gen_set = {};
     uint32_t    gen_segs = 0;
@@ -1791,6 +1875,10 @@ static BankPtrs ptrs(const sh_bank* b) {
     p.hint = b->d_hint;
     p.seg_rot = b->d_seg_rot;
     p.lfo_rot = b->d_lfo_rot;
+    p.rows = b->launch_rows;
+    p.row_stride = b->launch_row_stride;
+    p.fm_row = b->d_fm_row;
+    p.pwm_row = b->d_pwm_row;
     return p;
 }
 
@@ -1842,11 +1930,11 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     if (!segs || nsegs == 0) return sh::set_error(SH_ERR_INVALID, "sh_bank_create: no phase tables");
     for (uint32_t i = 0; i < nvoices; ++i) {
         const sh_voice& v = voices[i];
-        if (v.kind < SH_SINE || v.kind > SH_NOISE)
+        if (v.kind < SH_SINE || v.kind > SH_BUFFER)
             return sh::set_error(SH_ERR_INVALID, "voice %u: unknown kind %d", i, v.kind);
         if (v.kind == SH_NOISE && v.noise_hold == 0)
             return sh::set_error(SH_ERR_INVALID, "voice %u: noise_hold must be >= 1", i);
-        if ((v.kind == SH_NOISE || v.kind == SH_LINEAR) && v.fm_mode != SH_FM_NONE)
+        if ((v.kind == SH_NOISE || v.kind == SH_LINEAR || v.kind == SH_BUFFER) && v.fm_mode != SH_FM_NONE)
             return sh::set_error(SH_ERR_INVALID, "voice %u: kind %d has no FM form", i, v.kind);
         if (v.fm_mode < SH_FM_NONE || v.fm_mode > SH_FM_BUFFER)
             return sh::set_error(SH_ERR_INVALID, "voice %u: unknown fm_mode %d", i, v.fm_mode);
@@ -1959,6 +2047,8 @@ int sh_bank_destroy(sh_bank* b) {
         }
         if (b->d_gains) (void)hipFree(b->d_gains);
         if (b->d_hint) (void)hipFree(b->d_hint);
+        if (b->d_fm_row) (void)hipFree(b->d_fm_row);
+        if (b->d_pwm_row) (void)hipFree(b->d_pwm_row);
         if (b->gen_set.launch) (void)hipFree(b->gen_set.launch);
         if (b->gen_set.fm) (void)hipFree(b->gen_set.fm);
         if (b->gen_set.fast) (void)hipFree(b->gen_set.fast);
@@ -2086,9 +2176,11 @@ int sh_osc_render(sh_bank* bank, uint32_t voice, const sh_buf* fm_cumsum, const 
 }
 
 static int bank_check_plain(const sh_bank* b, const char* who) {
+    if (b->launch_rows) return SH_OK;                      // sh_bank_render_rows supplies them
     for (uint32_t i = 0; i < b->nvoices; ++i)
-        if (b->h_voices[i].fm_mode == SH_FM_BUFFER)
-            return sh::set_error(SH_ERR_INVALID, "%s: voice %u needs a modulator buffer (SH_FM_BUFFER); render it with sh_osc_render", who, i);
+        if (b->h_voices[i].fm_mode == SH_FM_BUFFER || b->h_voices[i].kind == SH_BUFFER)
+            return sh::set_error(SH_ERR_INVALID, "%s: voice %u reads a modulation / sample row; render the bank with sh_bank_render_rows", who, i);
+    if (b->needs_rows) return sh::set_error(SH_ERR_INVALID, "%s: the bank has modulation rows (sh_bank_set_rows); render it with sh_bank_render_rows", who);
     return SH_OK;
 }
 
@@ -2391,6 +2483,50 @@ int sh_bank_render_pcm(sh_bank* b, uint64_t start, uint32_t nframes, double scal
     return bank_render(b, start, nframes, nullptr, nullptr, pcm_i16, scale);
 }
 
+int sh_bank_set_rows(sh_bank* b, const int32_t* fm_row, const int32_t* pwm_row) {
+    SH_REQUIRE_INIT();
+    if (!b || !fm_row || !pwm_row) return sh::set_error(SH_ERR_INVALID, "sh_bank_set_rows: NULL argument");
+    for (uint32_t i = 0; i < b->nvoices; ++i) {
+        const sh_voice& v = b->h_voices[i];
+        if ((v.fm_mode == SH_FM_BUFFER || v.kind == SH_BUFFER) && fm_row[i] < 0)
+            return sh::set_error(SH_ERR_INVALID, "sh_bank_set_rows: voice %u (SH_FM_BUFFER / SH_BUFFER) needs a row", i);
+        if (pwm_row[i] >= 0 && v.kind != SH_PULSE) return sh::set_error(SH_ERR_INVALID, "sh_bank_set_rows: voice %u has a pwm row but is no Pulse", i);
+    }
+    hipStream_t st = sh::state().stream;
+    if (!b->d_fm_row) {
+        SH_HIP(hipMalloc((void**)&b->d_fm_row, sizeof(int32_t) * b->nvoices));
+        SH_HIP(hipMalloc((void**)&b->d_pwm_row, sizeof(int32_t) * b->nvoices));
+    }
+    SH_HIP(hipMemcpyAsync(b->d_fm_row, fm_row, sizeof(int32_t) * b->nvoices, hipMemcpyHostToDevice, st));
+    SH_HIP(hipMemcpyAsync(b->d_pwm_row, pwm_row, sizeof(int32_t) * b->nvoices, hipMemcpyHostToDevice, st));
+    SH_HIP(hipStreamSynchronize(st));
+    b->needs_rows = true;
+    b->fm_row_max = -1;
+    for (uint32_t i = 0; i < b->nvoices; ++i) {
+        if (fm_row[i] > b->fm_row_max) b->fm_row_max = fm_row[i];
+        if (pwm_row[i] > b->fm_row_max) b->fm_row_max = pwm_row[i];
+    }
+    return SH_OK;
+}
+
+int sh_bank_render_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
+                        sh_buf* bus_f32, sh_buf* bus_f64) {
+    if (!b || !rows_f64) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_rows: NULL argument");
+    SH_API_LOCK();                                           // held across bank_render (recursive): the rows belong to this call
+    {
+        if (!b->d_fm_row) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_rows: sh_bank_set_rows has not been called");
+        if (row_stride < nframes) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_rows: row_stride < nframes");
+        if (b->fm_row_max >= 0 && rows_f64->bytes / 8 < (size_t)b->fm_row_max * row_stride + nframes)
+            return sh::set_error(SH_ERR_INVALID, "sh_bank_render_rows: rows buffer too small for row %d", b->fm_row_max);
+        b->launch_rows = (const double*)rows_f64->ptr;
+        b->launch_row_stride = row_stride;
+    }
+    int rc = bank_render(b, start, nframes, bus_f32, bus_f64, nullptr, 0.0);
+    b->launch_rows = nullptr;
+    b->launch_row_stride = 0;
+    return rc;
+}
+
 int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32_t nframes,
                    const sh_buf* gains_lr, sh_buf* bus_f32) {
     SH_REQUIRE_INIT();
@@ -2464,6 +2600,54 @@ int sh_ew_f64(int op, const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_o
         SH_HIP(hipMemcpyAsync(out_host, d32, n * 4, hipMemcpyDeviceToHost, st));
         SH_HIP(hipStreamSynchronize(st));
     }
+    return SH_OK;
+}
+
+int sh_scan_rows_f64(sh_buf* rows, size_t row0, uint32_t nrows, uint32_t n, size_t row_stride, sh_buf* carry) {
+    SH_REQUIRE_INIT();
+    if (!rows || !carry) return sh::set_error(SH_ERR_INVALID, "sh_scan_rows_f64: NULL argument");
+    if (!nrows || !n) return SH_OK;
+    if (row_stride < n || rows->bytes / 8 < (row0 + nrows - 1) * row_stride + n) return sh::set_error(SH_ERR_INVALID, "sh_scan_rows_f64: rows buffer too small");
+    if (carry->bytes / 8 < nrows) return sh::set_error(SH_ERR_INVALID, "sh_scan_rows_f64: carry buffer smaller than nrows doubles");
+    if (nrows > 65535) return sh::set_error(SH_ERR_INVALID, "sh_scan_rows_f64: more than 65535 rows");
+    const uint32_t ntiles = sh::div_up(n, SCAN_TILE);
+    int rc = sh::ensure_scratch((size_t)nrows * (ntiles + 1) * 8);
+    if (rc) return rc;
+    double* sums = (double*)sh::state().scratch;
+    double* x = (double*)rows->ptr + row0 * row_stride;
+    hipStream_t st = sh::state().stream;
+    hipLaunchKernelGGL(k_scan_rows_tile_sums, dim3(ntiles, nrows), dim3(256), 0, st, (const double*)x, row_stride, n, ntiles, sums);
+    SH_CHECK_LAUNCH("k_scan_rows_tile_sums");
+    hipLaunchKernelGGL(k_scan_rows_sums, dim3(nrows), dim3(256), 0, st, sums, ntiles, (double*)carry->ptr);
+    SH_CHECK_LAUNCH("k_scan_rows_sums");
+    hipLaunchKernelGGL(k_scan_rows_apply, dim3(ntiles, nrows), dim3(256), 0, st, (const double*)x, row_stride, n, ntiles, (const double*)sums, x);
+    SH_CHECK_LAUNCH("k_scan_rows_apply");
+    return SH_OK;
+}
+
+int sh_bank_generate_f64(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* rows_out, size_t row0, size_t row_stride) {
+    SH_REQUIRE_INIT();
+    if (!b || !rows_out) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_f64: NULL argument");
+    if (nframes == 0) return SH_OK;
+    if (row_stride < nframes || rows_out->bytes / 8 < (row0 + b->nvoices - 1) * row_stride + nframes)
+        return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_f64: rows buffer too small");
+    int rc = bank_check_plain(b, "sh_bank_generate_f64");
+    if (rc) return rc;
+    rc = acquire_records(b, start, nframes, sh::state().stream, false);
+    if (rc) return rc;
+    const int fpl = nframes >= 8192 ? 4 : (nframes >= 2048 ? 2 : 1);
+    const uint32_t tile_groups = sh::div_up(nframes, 256 * fpl);
+    uint32_t vpg = 1;
+    while (vpg < 64 && (uint64_t)tile_groups * ((b->nvoices + 2 * vpg - 1) / (2 * vpg)) >= 4096) vpg *= 2;
+    while ((b->nvoices + vpg - 1) / vpg > 65535) vpg *= 2;
+    const uint32_t groups = (b->nvoices + vpg - 1) / vpg;
+    double* o = (double*)rows_out->ptr + row0 * row_stride;
+#define SH_GEN64(F_) hipLaunchKernelGGL(k_generate<F_>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,          \
+                                        ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, \
+                                        (const double*)nullptr, (const double*)nullptr, (float*)nullptr, o, row_stride)
+    if (fpl == 4) SH_GEN64(4); else if (fpl == 2) SH_GEN64(2); else SH_GEN64(1);
+#undef SH_GEN64
+    SH_CHECK_LAUNCH("k_generate(f64 rows)");
     return SH_OK;
 }
 

@@ -25,7 +25,7 @@ from typing import Callable, Dict, Generator, List, Optional, Sequence, Tuple, U
 import numpy as np
 
 from . import _native as N
-from .oscillators import Oscillator, pack_voices
+from .oscillators import Oscillator, VoiceSpec, _table, pack_voices
 from .sample import Sample
 
 __all__ = ["VoiceBank", "RealTimeMixer", "mix_samples", "pan_gains"]
@@ -33,6 +33,80 @@ __all__ = ["VoiceBank", "RealTimeMixer", "mix_samples", "pan_gains"]
 
 def pan_gains(pan: float) -> Tuple[float, float]:
     return (1.0 - pan) / 2.0, (1.0 + pan) / 2.0
+
+
+class _RowMatrix:
+    """The per-launch float64 rows of a VoiceBank (sh_bank_render_rows): rows 0 .. nfm-1 hold the running sums of the fm_lfo
+    modulators (rendered, then scanned in place by ONE batched launch, the carries staying on the device from block to
+    block), the rows after them pulse widths / rendered voices.  Sources that are single closed-form records are rendered by
+    one launch per group (a bank of modulators, sh_bank_generate_f64); anything else -- a modulator that is itself
+    modulated by an arbitrary oscillator, a filter graph -- renders into its row on its own."""
+
+    def __init__(self, fm_sources: Sequence[Oscillator], other_sources: Sequence[Oscillator], samplerate: int) -> None:
+        self.nfm = len(fm_sources)
+        self.nrows = len(fm_sources) + len(other_sources)
+        self.samplerate = samplerate
+        self.fm_rows: List[int] = []
+        self.other_rows: List[int] = []
+        self._banks: List[Tuple[N.Bank, int]] = []              # (bank of closed-form sources, first row)
+        self._singles: List[Tuple[Oscillator, int]] = []        # (source, row)
+
+        def place(sources, first_row, out_rows):
+            bankable, single = [], []
+            for k, m in enumerate(sources):
+                if m.samplerate != samplerate:
+                    raise ValueError("a modulator must run at the sample rate of its voice")
+                try:
+                    sp = m.spec()
+                    ok = sp.fm_mode != N.SH_FM_BUFFER and not sp.needs_pwm and m.length is None
+                except NotImplementedError:
+                    sp, ok = None, False
+                (bankable if ok else single).append((k, m, sp))
+            rows = [0] * len(sources)
+            r = first_row
+            if bankable:
+                self._banks.append((N.Bank(*pack_voices([sp for _, _, sp in bankable])), r))
+                for k, _m, _sp in bankable:
+                    rows[k] = r
+                    r += 1
+            for k, m, _sp in single:
+                rows[k] = r
+                self._singles.append((m, r))
+                r += 1
+            out_rows.extend(rows)
+
+        place(fm_sources, 0, self.fm_rows)
+        place(other_sources, self.nfm, self.other_rows)
+        self._buf: Optional[N.DeviceBuffer] = None
+        self._stride = 0
+        self._carry: Optional[N.DeviceBuffer] = None
+        if self.nfm:
+            self._carry = N.DeviceBuffer(self.nfm * 8)
+            self._carry.zero()
+        self._pos = 0                                           # the carries hold L(_pos)
+
+    def _render(self, start: int, n: int) -> None:
+        L = N.lib()
+        for bank, row0 in self._banks:
+            N.check(L.sh_bank_generate_f64(bank.handle, start, n, self._buf.handle, row0, self._stride))
+        for m, row in self._singles:
+            m._render_device(start, n, out_f64=self._buf.view(row * self._stride * 8, n * 8))
+        if self.nfm:
+            N.check(L.sh_scan_rows_f64(self._buf.handle, 0, self.nfm, n, self._stride, self._carry.handle))
+            self._pos = start + n
+
+    def fill(self, start: int, n: int) -> Tuple[N.DeviceBuffer, int]:
+        if self._buf is None or n > self._stride:
+            self._stride = max(n, 4096)
+            self._buf = N.DeviceBuffer(self.nrows * self._stride * 8)
+        if self.nfm and start != self._pos:                     # random access into a recurrence: replay the sums up to `start`
+            if start < self._pos:
+                self._carry.zero()
+                self._pos = 0
+            while self._pos < start:
+                self._render(self._pos, min(self._stride, start - self._pos))
+        self._render(start, n)
+        return self._buf, self._stride
 
 
 class VoiceBank:
@@ -56,15 +130,37 @@ class VoiceBank:
         self.samplerate = rates.pop()
         self.nvoices = len(voices)
         self.gains = [(float(l), float(r)) for l, r in gains]
-        specs = [v.spec() for v in voices]
-        for i, s in enumerate(specs):
-            if s.fm_mode == N.SH_FM_BUFFER or s.needs_pwm:
-                raise NotImplementedError(
-                    "voice %d is modulated by a non-Sine oscillator; banks take closed-form modulators only "
-                    "(render such a voice on its own with Oscillator.render)" % i)
+        # Voices that read a ROW of a per-launch float64 matrix: a carrier whose fm_lfo is not a closed-form Sine (the row is
+        # the running sum of the modulator), a Pulse with a pwm_lfo (pulse width per sample), or a voice that is no single
+        # record at all -- a filter graph, an envelope over one -- whose samples are rendered into its row (SH_BUFFER).
+        specs: List[VoiceSpec] = []
+        fm_src: List[Tuple[int, Oscillator]] = []           # (voice, modulator): rows 0 .. nfm-1, scanned in place
+        other_src: List[Tuple[str, int, Oscillator]] = []   # ("pwm" | "voice", voice, source): the rows after them
+        for i, v in enumerate(voices):
+            try:
+                sp = v.spec()
+            except NotImplementedError:
+                sp = VoiceSpec(kind=N.SH_BUFFER, amplitude=1.0, bias=0.0, fm_mode=N.SH_FM_NONE, carrier=_table(0.0, 0.0))
+                other_src.append(("voice", i, v))
+            else:
+                if sp.fm_mode == N.SH_FM_BUFFER:
+                    fm_src.append((i, v._fm_source()))
+                if sp.needs_pwm:
+                    other_src.append(("pwm", i, v._pwm_source()))
+            specs.append(sp)
         self._packed = pack_voices(specs, self.gains)
         self._bank = N.Bank(*self._packed)
         self._gains_dev: Optional[N.DeviceBuffer] = None
+        self._rows: Optional[_RowMatrix] = None
+        if fm_src or other_src:
+            fm_row = np.full(self.nvoices, -1, dtype=np.int32)
+            pwm_row = np.full(self.nvoices, -1, dtype=np.int32)
+            self._rows = _RowMatrix([m for _, m in fm_src], [m for _, _, m in other_src], self.samplerate)
+            for (i, _m), r in zip(fm_src, self._rows.fm_rows):
+                fm_row[i] = r
+            for (what, i, _m), r in zip(other_src, self._rows.other_rows):
+                (pwm_row if what == "pwm" else fm_row)[i] = r
+            N.check(N.lib().sh_bank_set_rows(self._bank.handle, fm_row.ctypes.data, pwm_row.ctypes.data))
 
     # -- fused path ------------------------------------------------------------------------------
     def render_device(self, nframes: int, start: int = 0, bus_f32: Optional[N.DeviceBuffer] = None,
@@ -72,6 +168,12 @@ class VoiceBank:
         """Fused generate-and-mix into device buffers (float32 frames x 2 and/or float64 frames x 2)."""
         if bus_f32 is None and bus_f64 is None:
             bus_f32 = N.DeviceBuffer(nframes * 8)
+        if self._rows is not None and nframes:
+            rows, stride = self._rows.fill(start, nframes)
+            N.check(N.lib().sh_bank_render_rows(self._bank.handle, start, nframes, rows.handle, stride,
+                                                bus_f32.handle if bus_f32 is not None else None,
+                                                bus_f64.handle if bus_f64 is not None else None))
+            return bus_f32 if bus_f32 is not None else bus_f64
         N.check(N.lib().sh_bank_render(self._bank.handle, start, nframes,
                                        bus_f32.handle if bus_f32 is not None else None,
                                        bus_f64.handle if bus_f64 is not None else None))
@@ -93,6 +195,11 @@ class VoiceBank:
         between them).  The buffer is complete once any other library call (or ``_native.sync()``) has been made."""
         if pcm is None:
             pcm = N.DeviceBuffer(nframes * 4)
+        if self._rows is not None:                       # modulation rows: float32 bus first, then the saturating quantiser
+            bus = self.render_device(nframes, start)
+            N.check(N.lib().sh_quantize_clip_f32(bus.handle, nframes * 2, float(scale), pcm.handle))
+            bus.free()
+            return pcm
         N.check(N.lib().sh_bank_render_pcm(self._bank.handle, start, nframes, float(scale), pcm.handle))
         return pcm
 
@@ -109,6 +216,9 @@ class VoiceBank:
                         stride: Optional[int] = None) -> N.DeviceBuffer:
         """Every voice as float32 PCM in HBM, voice-major: out[v*stride + i]."""
         stride = nframes if stride is None else stride
+        if self._rows is not None:
+            raise NotImplementedError("voices modulated by arbitrary oscillators (or rendered from filter graphs) take the fused "
+                                      "render; materialise such a voice with Oscillator.render")
         if out is None:
             out = N.DeviceBuffer(self.nvoices * stride * 4)
         N.check(N.lib().sh_bank_generate(self._bank.handle, start, nframes, out.handle, stride))

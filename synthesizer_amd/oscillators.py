@@ -607,15 +607,16 @@ class SawtoothH(Harmonics):
 
 class EnvelopeFilter(Oscillator):
     """ADSR volume envelope over an oscillator (upstream: oscillators.py class EnvelopeFilter).
-    A, D, S, R in seconds, sustain_level an amplitude factor.  Fused into the source's kernel."""
+    A, D, S, R in seconds, sustain_level an amplitude factor.  Over a waveform source (the usual patch) the envelope is
+    fused into the source's kernel; over anything else -- a filter graph, another envelope -- the source is rendered as a
+    float64 block and multiplied by the gain curve, which is itself rendered by the fused path (the envelope of a constant 1:
+    exactly the reference's accumulated amplitude), one elementwise kernel."""
 
     def __init__(self, source: Oscillator, attack: float, decay: float, sustain: float, sustain_level: float,
                  release: float, stop_at_end: bool = False) -> None:
         assert attack >= 0 and decay >= 0 and sustain >= 0 and release >= 0
         assert 0 <= sustain_level <= 1
         super().__init__(source.samplerate)
-        if not isinstance(source, (_Carrier, Linear, WhiteNoise)):
-            raise NotImplementedError("EnvelopeFilter is fused into waveform sources only (not into other filters)")
         self._source = source
         self._attack = attack
         self._decay = decay
@@ -623,17 +624,53 @@ class EnvelopeFilter(Oscillator):
         self._sustain_level = sustain_level
         self._release = release
         self._stop_at_end = stop_at_end
+        self._fused = isinstance(source, (_Carrier, Linear, WhiteNoise))
+        self._gain: Optional["EnvelopeFilter"] = None
+        if not self._fused:
+            self._gain = EnvelopeFilter(Linear(1.0, samplerate=source.samplerate), attack, decay, sustain, sustain_level, release,
+                                        stop_at_end)
 
     def _fm_source(self):
-        return self._source._fm_source()
+        return self._source._fm_source() if self._fused else None
 
     def _pwm_source(self):
-        return self._source._pwm_source()
+        return self._source._pwm_source() if self._fused else None
 
     def _make_spec(self) -> VoiceSpec:
+        if not self._fused:
+            raise NotImplementedError("an envelope over a filter graph is rendered block by block, it is not a single voice record")
         env = envelope_spec(self._attack, self._decay, self._sustain, self._sustain_level, self._release,
                             self.samplerate, self._stop_at_end)
         return replace(self._source.spec(), env=env)
+
+    @property
+    def length(self) -> Optional[int]:
+        if self._fused:
+            return super().length
+        lens = [x for x in (self._gain.length, self._source.length) if x is not None]
+        return min(lens) if lens else None
+
+    def _render_f64_device(self, start: int, n: int) -> N.DeviceBuffer:
+        if self._fused:
+            return super()._render_f64_device(start, n)
+        limit = self.length
+        if limit is not None and start + n > limit:
+            raise ValueError("stream ended before the requested range")
+        acc = self._source._render_f64_device(start, n)
+        gain = self._gain._render_f64_device(start, n)
+        N.check(N.lib().sh_ew_f64(N.SH_EW_MUL, acc.handle, 0, gain.handle, 0, n, 0.0, 0.0, acc.handle, 0, None, 0, None))
+        gain.free()
+        return acc
+
+    def _render_device(self, start, n, out_host=None, out_f32=None, out_off=0, out_f64=None) -> None:
+        if self._fused:
+            return super()._render_device(start, n, out_host=out_host, out_f32=out_f32, out_off=out_off, out_f64=out_f64)
+        buf = self._render_f64_device(start, n)
+        N.check(N.lib().sh_ew_f64(N.SH_EW_COPY, buf.handle, 0, None, 0, n, 0.0, 0.0,
+                                  out_f64.handle if out_f64 is not None else None, 0,
+                                  out_f32.handle if out_f32 is not None else None, out_off,
+                                  out_host.ctypes.data if out_host is not None else None))
+        buf.free()
 
 
 # ---------------------------------------------------------------------------------------------------

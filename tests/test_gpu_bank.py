@@ -104,11 +104,11 @@ def test_mix_bus_kernel_shapes(gpu):
         assert np.max(np.abs(got - want)) <= 4e-6 * max(1.0, np.sqrt(nv))
 
 
-def test_bank_rejects_buffer_modulators(gpu):
+def test_bank_argument_checks(gpu):
     from synthesizer_amd import oscillators as G
     from synthesizer_amd.mixer import VoiceBank
-    with pytest.raises(NotImplementedError):
-        VoiceBank([G.Sine(440, fm_lfo=G.Square(2, 0.1, samplerate=SR), samplerate=SR)])
+    # (a voice modulated by a non-Sine oscillator is a bank voice like any other: tests/test_gpu_modbank.py)
+    assert VoiceBank([G.Sine(440, fm_lfo=G.Square(2, 0.1, samplerate=SR), samplerate=SR)]).render(64).shape == (64, 2)
     with pytest.raises(ValueError):
         VoiceBank([])
     with pytest.raises(ValueError):

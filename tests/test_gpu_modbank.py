@@ -1,0 +1,116 @@
+"""Voice banks whose voices are modulated by ARBITRARY oscillators (fm_lfo= / pwm_lfo= anything, upstream composes them
+freely) or are oscillator graphs themselves (filters, envelopes over filters, nested envelopes): the modulators / sources
+are rendered as float64 rows of one matrix per launch (one launch per group of closed-form sources), the fm rows scanned
+by one batched launch with the carries kept on the device, and the bank's general code reads its rows
+(sh_bank_set_rows / sh_bank_generate_f64 / sh_scan_rows_f64 / sh_bank_render_rows).  Oracle: oracle/synth_oracle.py."""
+import numpy as np
+import pytest
+
+from oracle import synth_oracle as O
+from tests.helpers import rms
+from synthesizer_amd.workloads import additive_voices
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+RMS_TOL = 1e-6
+
+
+def _voices(m):
+    harm = [(1, 1.0), (2, 0.5), (3, 0.25)]
+    return [
+        m.Sine(440.0, 0.3, fm_lfo=m.Square(3.0, 0.02, samplerate=SR), samplerate=SR),                     # fm row (bank of modulators)
+        m.Pulse(220.0, 0.2, pulsewidth=0.3, pwm_lfo=m.Triangle(2.0, 0.2, bias=0.4, samplerate=SR), samplerate=SR),   # pwm row
+        m.Sine(330.0, 0.25, fm_lfo=m.Sine(5.0, 0.03, samplerate=SR), samplerate=SR),                      # closed form: no row
+        m.Harmonics(110.0, harm, 0.2, samplerate=SR),                                                     # plain
+        m.Sawtooth(150.0, 0.2, fm_lfo=m.Sine(2.0, 0.05, fm_lfo=m.Sine(0.5, 0.5, samplerate=SR), samplerate=SR), samplerate=SR),  # modulator is FM itself
+        m.Pulse(90.0, 0.2, pulsewidth=0.5, fm_lfo=m.Triangle(1.5, 0.04, samplerate=SR),
+                pwm_lfo=m.Sine(0.7, 0.3, bias=0.5, samplerate=SR), samplerate=SR),                        # fm row AND pwm row
+        m.Harmonics(70.0, harm, 0.2, fm_lfo=m.Sawtooth(1.0, 0.03, samplerate=SR), samplerate=SR),         # Harmonics with a buffer LFO
+        m.Square(55.0, 0.15, fm_lfo=m.Sine(3.0, 0.02, fm_lfo=m.Square(0.7, 0.3, samplerate=SR), samplerate=SR), samplerate=SR),  # modulator needs a row itself
+        m.MixingFilter(m.Sine(500.0, 0.1, samplerate=SR), m.Triangle(250.0, 0.1, samplerate=SR)),         # a filter graph as a voice
+        m.EnvelopeFilter(m.MixingFilter(m.Sine(600.0, 0.2, samplerate=SR), m.Square(300.0, 0.1, samplerate=SR)), 0.01, 0.02, 0.03, 0.6, 0.02),
+        m.EnvelopeFilter(m.EnvelopeFilter(m.Sine(700.0, 0.3, samplerate=SR), 0.0, 0.01, 0.05, 0.8, 0.01), 0.02, 0.0, 0.04, 1.0, 0.03),  # nested
+        m.AmpModulationFilter(m.Sawtooth(800.0, 0.2, samplerate=SR), m.Sine(4.0, 0.5, bias=0.5, samplerate=SR)),
+        m.EnvelopeFilter(m.Sine(900.0, 0.2, samplerate=SR), 0.01, 0.01, 0.02, 0.5, 0.02),                 # the usual fused envelope
+    ]
+
+
+def _oracle_bus(ov, gains, n):
+    return np.array(O.mix_bus([v.take(n) for v in ov], gains), dtype=np.float64)
+
+
+def test_bank_with_arbitrary_modulators_and_filter_voices(gpu):
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    gv, ov = _voices(G), _voices(O)
+    rng = np.random.default_rng(5)
+    gains = [(float(np.float32(a)), float(np.float32(b))) for a, b in rng.uniform(0.2, 1.0, (len(gv), 2))]
+    bank = VoiceBank(gv, gains=gains)
+    n = 7000                                           # crosses three 2048-value scan tiles
+    want = _oracle_bus(ov, gains, 2 * n + 100)
+    got = bank.render(n)
+    assert got.shape == (n, 2) and rms(got, want[:n]) <= RMS_TOL
+    assert np.max(np.abs(got - want[:n])) < 5e-7
+    # the next block continues the running sums from the carries kept on the device
+    nxt = bank.render(n, start=n)
+    assert rms(nxt, want[n:2 * n]) <= RMS_TOL
+    # random access: back to an earlier position (replay from 0), a jump ahead, an odd short block
+    again = bank.render(1000, start=2500)
+    assert rms(again, want[2500:3500]) <= RMS_TOL
+    ahead = bank.render(100, start=2 * n)
+    assert rms(ahead, want[2 * n:2 * n + 100]) <= RMS_TOL
+    # int16 PCM of such a bank: the float32 bus through the saturating quantiser
+    pcm = bank.render_sample(2000).get_frames_numpy()
+    ref = np.clip(np.trunc(32767.0 * bank.render(2000).astype(np.float64)), -32768, 32767).astype(np.int16)
+    assert np.array_equal(pcm, ref)
+    with pytest.raises(NotImplementedError):
+        bank.generate(100)
+
+
+def test_large_bank_with_modulated_voices_among_lean_ones(gpu):
+    """192 voices (several voice groups, the split launch): mostly lean additive voices, every eighth voice modulated by a
+    non-Sine oscillator -- the general-lists kernel reads the rows while the lean kernel does the rest."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+
+    def build(m):
+        v, g = additive_voices(m, 192, SR, seed=11, partials=6, adsr={"sustain": 100.0})
+        for i in range(0, 192, 8):
+            f = 100.0 + 7.0 * i
+            if i % 16:
+                v[i] = m.Sine(f, 0.02, fm_lfo=m.Triangle(0.5 + 0.01 * i, 0.03, samplerate=SR), samplerate=SR)
+            else:
+                v[i] = m.Pulse(f, 0.02, pulsewidth=0.4, pwm_lfo=m.Sawtooth(0.3 + 0.01 * i, 0.2, bias=0.5, samplerate=SR), samplerate=SR)
+        return v, g
+    gv, gains = build(G)
+    ov, _ = build(O)
+    bank = VoiceBank(gv, gains=gains)
+    n = 3000
+    want = _oracle_bus(ov, gains, 2 * n)
+    assert rms(bank.render(n), want[:n]) <= RMS_TOL
+    assert rms(bank.render(n, start=n), want[n:]) <= RMS_TOL
+    # long block: eight frames per lane in the lean kernel, rows indexed by frame in the general one
+    big = bank.render(20000)
+    assert rms(big[:2 * n], want) <= RMS_TOL
+
+
+def test_envelope_over_filters_and_nested_envelopes_as_oscillators(gpu):
+    from synthesizer_amd import oscillators as G
+    cases = [
+        lambda m: m.EnvelopeFilter(m.MixingFilter(m.Sine(440.0, 0.4, samplerate=SR), m.Square(220.0, 0.3, samplerate=SR)), 0.01, 0.02, 0.03, 0.6, 0.02),
+        lambda m: m.EnvelopeFilter(m.EnvelopeFilter(m.Sawtooth(330.0, 0.5, samplerate=SR), 0.005, 0.01, 0.05, 0.7, 0.01), 0.02, 0.0, 0.03, 1.0, 0.02),
+        lambda m: m.EnvelopeFilter(m.EchoFilter(m.EnvelopeFilter(m.Sine(500.0, samplerate=SR), 0.0, 0.01, 0.01, 0.5, 0.01, stop_at_end=True), 0.01, 2, 0.02, 0.5),
+                                   0.0, 0.01, 0.01, 0.5, 0.005, stop_at_end=True),      # shorter than its (finite) source
+        lambda m: m.EnvelopeFilter(m.AbsFilter(m.Sine(100.0, samplerate=SR)), 0.0, 0.0, 0.02, 1.0, 0.01, stop_at_end=True),
+    ]
+    for k, make in enumerate(cases):
+        g, o = make(G), make(O)
+        n = 6000
+        want = np.array(o.take(n), dtype=np.float64)
+        got = g.render_f64(n, start=0)
+        assert len(got) == len(want), k
+        assert np.max(np.abs(got - want)) <= 1e-12, k
+        assert g.length == (len(want) if len(want) < n else g.length), k
+        # as someone's modulator and through the blocks() protocol
+        blk_g, blk_o = next(g.blocks()), next(o.blocks())
+        assert np.max(np.abs(np.array(blk_g) - np.array(blk_o))) <= 1e-12, k

@@ -306,9 +306,11 @@ def test_filters(gpu):
     assert np.array_equal(g["mix"].render(1000, start=2500), g["mix"].render(n, start=0)[2500:3500])
     assert np.array_equal(g["delay"].render(300, start=400), g["delay"].render(n, start=0)[400:700])
     assert rms(next(g["clip"].blocks()), next(o["clip"].blocks())) <= RMS_TOL
+    # a filter graph as the voice of a bank: rendered into a row, mixed with the bus gains
     from synthesizer_amd.mixer import VoiceBank
-    with pytest.raises(NotImplementedError):
-        VoiceBank([g["mix"]])
+    bus = VoiceBank([g["mix"]], gains=[(0.5, 0.25)]).render(2000)
+    mixed = np.array(o["mix"].take(2000))
+    assert rms(bus[:, 0], 0.5 * mixed) <= RMS_TOL and rms(bus[:, 1], 0.25 * mixed) <= RMS_TOL
 
 
 def test_wavesynth_facade(gpu):
