@@ -110,4 +110,23 @@ int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* ou
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// ---- 24-bit PCM (audioop width 3) -----------------------------------------------------------------------------------
+// audioop reads a 3-byte sample as GETINT24 (sign-extended) and, wherever it works through GETSAMPLE32 (ratecv, lin2lin) or
+// scales linearly (mul, tomono, tostereo, add, bias), the result for width 3 equals the width-4 operation on value << 8 taken
+// >> 8 (DESIGN.md section 4b spells the argument out per call).  The library therefore unpacks 3-byte samples into int32
+// temporaries (pcm_ops.hip), runs the 32-bit kernels, and packs the result: two extra streaming passes, no new arithmetic.
+int unpack24(const void* in, size_t nsamples, int shift, int32_t* out);    // out[i] = int24(in[3i..]) << shift
+int pack24(const int32_t* in, size_t nsamples, int shift, void* out);      // 3 low bytes of in[i] >> shift
+struct Temp {                       // a pool-backed device temporary wrapped as a (non-owning) sh_buf
+    sh_buf buf{nullptr, 0, false, 0};
+    size_t cap = 0;
+    int  alloc(size_t bytes) {
+        if (!bytes) bytes = 4;
+        int rc = pool_alloc(bytes, &buf.ptr, &cap);
+        buf.bytes = bytes;
+        return rc;
+    }
+    ~Temp() { if (buf.ptr) pool_free(buf.ptr, cap); }       // stream-ordered reuse: see the pool's comment in runtime.hip
+};
+
 }  // namespace sh

@@ -810,6 +810,23 @@ int sh_pcm_add(const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, siz
                sh_buf* out, size_t out_off) {
     SH_REQUIRE_INIT();
     if (!a || !b || !out) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add: NULL argument");
+    if (width == 3) {
+        // audioop.add at width 3: int sum clamped to [-2^23, 2^23 - 1] == the 32-bit saturating add of the samples << 8, >> 8
+        if (nbytes % 3 || (a_off | b_off | out_off) % 3) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add: not a whole number of frames");
+        if (a_off > a->bytes || nbytes > a->bytes - a_off || b_off > b->bytes || nbytes > b->bytes - b_off ||
+            out_off > out->bytes || nbytes > out->bytes - out_off)
+            return sh::set_error(SH_ERR_LENGTH, "sh_pcm_add: range outside buffer (Lengths should be the same)");
+        const size_t n = nbytes / 3;
+        if (!n) return SH_OK;
+        sh::Temp ta, tb;
+        int rc = ta.alloc(n * 4);
+        if (!rc) rc = tb.alloc(n * 4);
+        if (!rc) rc = sh::unpack24((const char*)a->ptr + a_off, n, 8, (int32_t*)ta.buf.ptr);
+        if (!rc) rc = sh::unpack24((const char*)b->ptr + b_off, n, 8, (int32_t*)tb.buf.ptr);
+        if (!rc) rc = pcm_add_dev((const char*)ta.buf.ptr, (const char*)tb.buf.ptr, (char*)ta.buf.ptr, n * 4, 4);
+        if (!rc) rc = sh::pack24((const int32_t*)ta.buf.ptr, n, 8, (char*)out->ptr + out_off);
+        return rc;
+    }
     if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add: width %d not in {1,2,4}", width);
     if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add: not a whole number of frames");
     if (a_off > a->bytes || nbytes > a->bytes - a_off || b_off > b->bytes || nbytes > b->bytes - b_off ||
@@ -822,6 +839,23 @@ int sh_pcm_add(const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, siz
 
 int sh_pcm_add_host(const void* a, const void* b, size_t nbytes, int width, void* out) {
     SH_REQUIRE_INIT();
+    if (width == 3) {                                       // staged in device temporaries, then the device form (24-bit via 32-bit)
+        if (nbytes % 3) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add_host: not a whole number of frames");
+        if (!nbytes) return SH_OK;
+        if (!a || !b || !out) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add_host: NULL argument");
+        sh::Temp da, db;
+        int rc3 = da.alloc(nbytes);
+        if (!rc3) rc3 = db.alloc(nbytes);
+        if (rc3) return rc3;
+        hipStream_t st3 = sh::state().stream;
+        SH_HIP(hipMemcpyAsync(da.buf.ptr, a, nbytes, hipMemcpyHostToDevice, st3));
+        SH_HIP(hipMemcpyAsync(db.buf.ptr, b, nbytes, hipMemcpyHostToDevice, st3));
+        rc3 = sh_pcm_add(&da.buf, 0, &db.buf, 0, nbytes, 3, &da.buf, 0);
+        if (rc3) return rc3;
+        SH_HIP(hipMemcpyAsync(out, da.buf.ptr, nbytes, hipMemcpyDeviceToHost, st3));
+        SH_HIP(hipStreamSynchronize(st3));
+        return SH_OK;
+    }
     if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add_host: width %d not in {1,2,4}", width);
     if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_add_host: not a whole number of frames");
     if (!nbytes) return SH_OK;
@@ -1018,9 +1052,26 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
     return SH_OK;
 }
 
+// audioop.ratecv at width 3 works on GETSAMPLE32 = value << 8 and stores SETSAMPLE32 = result >> 8: the 32-bit path on
+// unpacked samples, packed again.
+static int resample24(const void* in, size_t in_frames_held, size_t in_first, int nch, int inrate, int outrate,
+                      void* out, size_t out_first, size_t out_n) {
+    sh::Temp tin, tout;
+    int rc = tin.alloc(in_frames_held * nch * 4);
+    if (!rc) rc = tout.alloc(out_n * nch * 4);
+    if (!rc) rc = sh::unpack24(in, in_frames_held * nch, 8, (int32_t*)tin.buf.ptr);
+    if (rc) return rc;
+    const size_t fb = (size_t)4 * nch;
+    const char* in0 = (const char*)tin.buf.ptr - in_first * fb;
+    char* out0 = (char*)tout.buf.ptr - out_first * fb;
+    rc = resample_dev(in0, in_first + in_frames_held, nch, 4, 0, inrate, outrate, out0, out_first, out_first + out_n);
+    if (!rc) rc = sh::pack24((const int32_t*)tout.buf.ptr, out_n * nch, 8, out);
+    return rc;
+}
+
 static int resample_check(int nch, int width, int is_float, int inrate, int outrate) {
     if (nch < 1) return sh::set_error(SH_ERR_INVALID, "resample: # of channels should be >= 1");
-    if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "resample: width %d not in {1,2,4}", width);
+    if (width != 1 && width != 2 && width != 3 && width != 4) return sh::set_error(SH_ERR_INVALID, "resample: width %d not in {1,2,3,4}", width);
     if (is_float && width != 4) return sh::set_error(SH_ERR_INVALID, "resample: float PCM must have width 4");
     if (inrate <= 0 || outrate <= 0) return sh::set_error(SH_ERR_INVALID, "resample: sampling rate not > 0");
     return SH_OK;
@@ -1036,6 +1087,7 @@ int sh_resample(const sh_buf* in, size_t in_frames, int nchannels, int width, in
     if (in->bytes / ((size_t)width * nchannels) < in_frames) return sh::set_error(SH_ERR_INVALID, "sh_resample: input buffer smaller than in_frames");
     if (out->bytes / ((size_t)width * nchannels) < nout) return sh::set_error(SH_ERR_INVALID, "sh_resample: output buffer too small (%zu frames needed)", nout);
     if (out_frames) *out_frames = nout;
+    if (width == 3) return nout ? resample24(in->ptr, in_frames, 0, nchannels, inrate, outrate, out->ptr, 0, nout) : (int)SH_OK;
     return resample_dev(in->ptr, in_frames, nchannels, width, is_float, inrate, outrate, out->ptr, 0, nout);
 }
 
@@ -1080,6 +1132,7 @@ int sh_resample_range(const sh_buf* in, size_t in_first, size_t in_held, int nch
     if (in_first > need_lo || j_hi >= (uint64_t)in_first + in_held)
         return sh::set_error(SH_ERR_INVALID, "sh_resample_range: output frames [%zu,+%zu) read input frames [%llu,%llu], buffer holds [%zu,+%zu)",
                              out_first, out_n, (unsigned long long)need_lo, (unsigned long long)j_hi, in_first, in_held);
+    if (width == 3) return resample24(in->ptr, in_held, in_first, nchannels, inrate, outrate, out->ptr, out_first, out_n);
     const char* in0 = (const char*)in->ptr - in_first * fb;        // where input frame 0 would be
     char* out0 = (char*)out->ptr - out_first * fb;                  // where output frame 0 would be
     return resample_dev(in0, in_first + in_held, nchannels, width, is_float, inrate, outrate, out0, out_first, out_first + out_n);
@@ -1102,7 +1155,8 @@ int sh_resample_host(const void* in, size_t in_frames, int nchannels, int width,
     char* s = (char*)sh::state().scratch;
     hipStream_t st = sh::state().stream;
     SH_HIP(hipMemcpyAsync(s, in, in_bytes, hipMemcpyHostToDevice, st));
-    rc = resample_dev(s, in_frames, nchannels, width, is_float, inrate, outrate, s + in_pad, 0, nout);
+    rc = width == 3 ? resample24(s, in_frames, 0, nchannels, inrate, outrate, s + in_pad, 0, nout)
+                    : resample_dev(s, in_frames, nchannels, width, is_float, inrate, outrate, s + in_pad, 0, nout);
     if (rc) return rc;
     SH_HIP(hipMemcpyAsync(out, s + in_pad, out_bytes, hipMemcpyDeviceToHost, st));
     SH_HIP(hipStreamSynchronize(st));

@@ -427,6 +427,50 @@ __global__ __launch_bounds__(256) void k_sumsq_f64(const int* __restrict__ in, s
     if (threadIdx.x == 0) part[blockIdx.x] = s[0];
 }
 
+// 24-bit <-> 32-bit: a thread converts four samples (12 bytes <-> 16 bytes); the 12 bytes are read / written as three
+// dwords when the 3-byte stream starts on a dword boundary, byte by byte otherwise (the tail always is).
+__global__ __launch_bounds__(256) void k_unpack24(const unsigned char* __restrict__ in, size_t n, int shift, int* __restrict__ out, int dwords) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;              // group of four samples
+    if (q * 4 >= n) return;
+    if (dwords && q * 4 + 4 <= n) {
+        const unsigned* w = reinterpret_cast<const unsigned*>(in) + q * 3;
+        const unsigned a = w[0], b = w[1], c = w[2];
+        int4 r;
+        r.x = ((int)(a << 8)) >> 8;
+        r.y = ((int)(((a >> 24) | (b << 8)) << 8)) >> 8;
+        r.z = ((int)(((b >> 16) | (c << 16)) << 8)) >> 8;
+        r.w = ((int)c) >> 8;
+        r.x <<= shift; r.y <<= shift; r.z <<= shift; r.w <<= shift;
+        if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) reinterpret_cast<int4*>(out)[q] = r;
+        else { out[q * 4] = r.x; out[q * 4 + 1] = r.y; out[q * 4 + 2] = r.z; out[q * 4 + 3] = r.w; }
+        return;
+    }
+    for (size_t i = q * 4; i < q * 4 + 4 && i < n; ++i) {
+        const unsigned v = (unsigned)in[3 * i] | ((unsigned)in[3 * i + 1] << 8) | ((unsigned)in[3 * i + 2] << 16);
+        out[i] = (((int)(v << 8)) >> 8) << shift;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack24(const int* __restrict__ in, size_t n, int shift, unsigned char* __restrict__ out, int dwords) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= n) return;
+    if (dwords && q * 4 + 4 <= n) {
+        const unsigned a = (unsigned)(in[q * 4] >> shift) & 0xFFFFFFu, b = (unsigned)(in[q * 4 + 1] >> shift) & 0xFFFFFFu;
+        const unsigned c = (unsigned)(in[q * 4 + 2] >> shift) & 0xFFFFFFu, d = (unsigned)(in[q * 4 + 3] >> shift) & 0xFFFFFFu;
+        unsigned* w = reinterpret_cast<unsigned*>(out) + q * 3;
+        w[0] = a | (b << 24);
+        w[1] = (b >> 8) | (c << 16);
+        w[2] = (c >> 16) | (d << 8);
+        return;
+    }
+    for (size_t i = q * 4; i < q * 4 + 4 && i < n; ++i) {
+        const unsigned v = (unsigned)(in[i] >> shift);
+        out[3 * i] = (unsigned char)v;
+        out[3 * i + 1] = (unsigned char)(v >> 8);
+        out[3 * i + 2] = (unsigned char)(v >> 16);
+    }
+}
+
 template <typename F>
 int dispatch_width(int width, F&& f) {
     if (width == 1) return f((signed char)0);
@@ -435,7 +479,7 @@ int dispatch_width(int width, F&& f) {
     return sh::set_error(SH_ERR_INVALID, "sample width %d not in {1,2,4}", width);
 }
 
-inline bool valid_width(int width) { return width == 1 || width == 2 || width == 4; }
+inline bool valid_width(int width) { return width == 1 || width == 2 || width == 4; }      // (width 3 is diverted to the 32-bit kernels before this test)
 int bad_width(const char* who, int width) { return sh::set_error(SH_ERR_INVALID, "%s: sample width %d not in {1,2,4}", who, width); }
 
 int check_io(const sh_buf* in, size_t in_off, size_t in_bytes, const sh_buf* out, size_t out_off, size_t out_bytes, const char* who) {
@@ -447,10 +491,55 @@ int check_io(const sh_buf* in, size_t in_off, size_t in_bytes, const sh_buf* out
 
 }  // namespace
 
+namespace sh {
+int unpack24(const void* in, size_t nsamples, int shift, int32_t* out) {
+    if (!nsamples) return SH_OK;
+    hipLaunchKernelGGL(k_unpack24, dim3(div_up((nsamples + 3) / 4, 256)), dim3(256), 0, state().stream, (const unsigned char*)in, nsamples, shift,
+                       (int*)out, ((uintptr_t)in & 3) == 0 ? 1 : 0);
+    SH_CHECK_LAUNCH("k_unpack24");
+    return SH_OK;
+}
+int pack24(const int32_t* in, size_t nsamples, int shift, void* out) {
+    if (!nsamples) return SH_OK;
+    hipLaunchKernelGGL(k_pack24, dim3(div_up((nsamples + 3) / 4, 256)), dim3(256), 0, state().stream, (const int*)in, nsamples, shift,
+                       (unsigned char*)out, ((uintptr_t)out & 3) == 0 ? 1 : 0);
+    SH_CHECK_LAUNCH("k_pack24");
+    return SH_OK;
+}
+}  // namespace sh
+
+namespace {
+// width 3 through the 32-bit kernels: `nin` samples unpacked (<< shift_in), op32(temporary in, temporary out), `nout` samples
+// packed (>> shift_out) to out + out_off.  inplace: the 32-bit operation may write where it reads.
+template <typename F>
+int via32(const sh_buf* in, size_t in_off, size_t nin, int shift_in, sh_buf* out, size_t out_off, size_t nout, int shift_out,
+          bool inplace, const char* who, F&& op32) {
+    if (!in || !out) return sh::set_error(SH_ERR_INVALID, "%s: NULL buffer", who);
+    if (in_off > in->bytes || nin * 3 > in->bytes - in_off) return sh::set_error(SH_ERR_INVALID, "%s: input range outside buffer", who);
+    if (out_off > out->bytes || nout * 3 > out->bytes - out_off) return sh::set_error(SH_ERR_INVALID, "%s: output range outside buffer", who);
+    sh::Temp tin, tout;
+    int rc = tin.alloc(nin * 4);
+    if (rc) return rc;
+    if (!inplace) { rc = tout.alloc(nout * 4); if (rc) return rc; }
+    rc = sh::unpack24((const char*)in->ptr + in_off, nin, shift_in, (int32_t*)tin.buf.ptr);
+    if (rc) return rc;
+    sh_buf* o32 = inplace ? &tin.buf : &tout.buf;
+    rc = op32(&tin.buf, o32);
+    if (rc) return rc;
+    return sh::pack24((const int32_t*)o32->ptr, nout, shift_out, (char*)out->ptr + out_off);
+}
+}  // namespace
+
 extern "C" {
 
 int sh_pcm_mul(const sh_buf* in, size_t in_off, size_t nbytes, int width, double factor, sh_buf* out, size_t out_off) {
     SH_REQUIRE_INIT();
+    if (width == 3) {
+        if (nbytes % 3 || (in_off | out_off) % 3) return sh::set_error(SH_ERR_INVALID, "sh_pcm_mul: not a whole number of frames");
+        const size_t n = nbytes / 3;
+        return via32(in, in_off, n, 8, out, out_off, n, 8, true, "sh_pcm_mul",
+                     [&](sh_buf* a, sh_buf* o) { return sh_pcm_mul(a, 0, n * 4, 4, factor, o, 0); });
+    }
     if (!valid_width(width)) return bad_width("sh_pcm_mul", width);
     int rc = check_io(in, in_off, nbytes, out, out_off, nbytes, "sh_pcm_mul");
     if (rc) return rc;
@@ -565,6 +654,12 @@ int sh_pcm_to_f64(const sh_buf* in, size_t nsamples, int width, double divisor, 
 
 int sh_pcm_bias(const sh_buf* in, size_t nbytes, int width, int bias, sh_buf* out) {
     SH_REQUIRE_INIT();
+    if (width == 3) {
+        if (nbytes % 3) return sh::set_error(SH_ERR_INVALID, "sh_pcm_bias: not a whole number of frames");
+        const size_t n = nbytes / 3;
+        const int bias32 = (int)(((unsigned)bias & 0xFFFFFFu) << 8);           // (v + bias) mod 2^24 == ((v << 8) + (bias << 8) mod 2^32) >> 8
+        return via32(in, 0, n, 8, out, 0, n, 8, true, "sh_pcm_bias", [&](sh_buf* a, sh_buf* o) { return sh_pcm_bias(a, n * 4, 4, bias32, o); });
+    }
     if (!valid_width(width)) return bad_width("sh_pcm_bias", width);
     int rc = check_io(in, 0, nbytes, out, 0, nbytes, "sh_pcm_bias");
     if (rc) return rc;
@@ -582,6 +677,11 @@ int sh_pcm_bias(const sh_buf* in, size_t nbytes, int width, int bias, sh_buf* ou
 
 int sh_pcm_reverse(const sh_buf* in, size_t nbytes, int width, sh_buf* out) {
     SH_REQUIRE_INIT();
+    if (width == 3) {
+        if (nbytes % 3) return sh::set_error(SH_ERR_INVALID, "sh_pcm_reverse: not a whole number of frames");
+        const size_t n = nbytes / 3;
+        return via32(in, 0, n, 0, out, 0, n, 0, false, "sh_pcm_reverse", [&](sh_buf* a, sh_buf* o) { return sh_pcm_reverse(a, n * 4, 4, o); });
+    }
     if (!valid_width(width)) return bad_width("sh_pcm_reverse", width);
     int rc = check_io(in, 0, nbytes, out, 0, nbytes, "sh_pcm_reverse");
     if (rc) return rc;
@@ -600,6 +700,9 @@ int sh_pcm_reverse(const sh_buf* in, size_t nbytes, int width, sh_buf* out) {
 
 int sh_pcm_tomono(const sh_buf* in, size_t nframes, int width, double lfactor, double rfactor, sh_buf* out) {
     SH_REQUIRE_INIT();
+    if (width == 3)
+        return via32(in, 0, nframes * 2, 8, out, 0, nframes, 8, false, "sh_pcm_tomono",
+                     [&](sh_buf* a, sh_buf* o) { return sh_pcm_tomono(a, nframes, 4, lfactor, rfactor, o); });
     if (!valid_width(width)) return bad_width("sh_pcm_tomono", width);
     int rc = check_io(in, 0, nframes * 2 * width, out, 0, nframes * width, "sh_pcm_tomono");
     if (rc) return rc;
@@ -619,6 +722,9 @@ int sh_pcm_tomono(const sh_buf* in, size_t nframes, int width, double lfactor, d
 
 int sh_pcm_tostereo(const sh_buf* in, size_t nframes, int width, double lfactor, double rfactor, sh_buf* out) {
     SH_REQUIRE_INIT();
+    if (width == 3)
+        return via32(in, 0, nframes, 8, out, 0, nframes * 2, 8, false, "sh_pcm_tostereo",
+                     [&](sh_buf* a, sh_buf* o) { return sh_pcm_tostereo(a, nframes, 4, lfactor, rfactor, o); });
     if (!valid_width(width)) return bad_width("sh_pcm_tostereo", width);
     int rc = check_io(in, 0, nframes * width, out, 0, nframes * 2 * width, "sh_pcm_tostereo");
     if (rc) return rc;
@@ -638,6 +744,21 @@ int sh_pcm_tostereo(const sh_buf* in, size_t nframes, int width, double lfactor,
 
 int sh_pcm_lin2lin(const sh_buf* in, size_t nsamples, int width, int new_width, sh_buf* out) {
     SH_REQUIRE_INIT();
+    if (width == 3 || new_width == 3) {
+        if (!in || !out) return sh::set_error(SH_ERR_INVALID, "sh_pcm_lin2lin: NULL buffer");
+        if ((width != 1 && width != 2 && width != 3 && width != 4) || (new_width != 1 && new_width != 2 && new_width != 3 && new_width != 4))
+            return sh::set_error(SH_ERR_INVALID, "sh_pcm_lin2lin: widths %d -> %d not in {1,2,3,4}", width, new_width);
+        if (nsamples * (size_t)width > in->bytes || nsamples * (size_t)new_width > out->bytes)
+            return sh::set_error(SH_ERR_INVALID, "sh_pcm_lin2lin: range outside buffer");
+        if (!nsamples) return SH_OK;
+        // GETSAMPLE32 of a 24-bit sample is value << 8; SETSAMPLE32 to 24 bits keeps value >> 8
+        sh::Temp t32;
+        int rc3 = t32.alloc(nsamples * 4);
+        if (rc3) return rc3;
+        rc3 = width == 3 ? sh::unpack24(in->ptr, nsamples, 8, (int32_t*)t32.buf.ptr) : sh_pcm_lin2lin(in, nsamples, width, 4, &t32.buf);
+        if (rc3) return rc3;
+        return new_width == 3 ? sh::pack24((const int32_t*)t32.buf.ptr, nsamples, 8, out->ptr) : sh_pcm_lin2lin(&t32.buf, nsamples, 4, new_width, out);
+    }
     int rc = check_io(in, 0, nsamples * width, out, 0, nsamples * new_width, "sh_pcm_lin2lin");
     if (rc) return rc;
     if (!nsamples) return SH_OK;
@@ -661,6 +782,16 @@ int sh_pcm_lin2lin(const sh_buf* in, size_t nsamples, int width, int new_width, 
 
 int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, double* sum_squares) {
     SH_REQUIRE_INIT();
+    if (width == 3) {                           // raw 24-bit values (audioop.max / rms read GETRAWSAMPLE)
+        if (!in || nbytes > in->bytes || nbytes % 3) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats: range outside buffer / not whole samples");
+        const size_t n = nbytes / 3;
+        sh::Temp t32;
+        int rc3 = t32.alloc(n * 4);
+        if (rc3) return rc3;
+        rc3 = sh::unpack24(in->ptr, n, 0, (int32_t*)t32.buf.ptr);
+        if (rc3) return rc3;
+        return sh_pcm_stats(&t32.buf, n * 4, 4, max_abs, sum_squares);
+    }
     if (!valid_width(width)) return bad_width("sh_pcm_stats", width);
     if (!in || nbytes > in->bytes) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats: range outside buffer");
     if (nbytes % width) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats: not a whole number of frames");
@@ -713,6 +844,15 @@ int sh_pcm_stats(const sh_buf* in, size_t nbytes, int width, uint32_t* max_abs, 
 
 int sh_pcm_stats_stereo(const sh_buf* in, size_t nframes, int width, uint32_t max_abs[2], double sum_squares[2]) {
     SH_REQUIRE_INIT();
+    if (width == 3) {
+        if (!in || nframes > in->bytes / 6) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats_stereo: range outside buffer");
+        sh::Temp t32;
+        int rc3 = t32.alloc(nframes * 8);
+        if (rc3) return rc3;
+        rc3 = sh::unpack24(in->ptr, nframes * 2, 0, (int32_t*)t32.buf.ptr);
+        if (rc3) return rc3;
+        return sh_pcm_stats_stereo(&t32.buf, nframes, 4, max_abs, sum_squares);
+    }
     if (width != 1 && width != 2 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats_stereo: width %d not in {1,2,4}", width);
     if (!in || nframes > in->bytes / (2 * (size_t)width)) return sh::set_error(SH_ERR_INVALID, "sh_pcm_stats_stereo: range outside buffer");
     if (max_abs) max_abs[0] = max_abs[1] = 0;

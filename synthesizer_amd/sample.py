@@ -17,7 +17,8 @@ Editing operations composed from those on device-resident PCM: clip / split / jo
 speed (``ratecv``), at_volume, echo, envelope (ADSR), modulate_amp (sample- or oscillator-driven).
 Level metering: ``level_db_peak`` / ``level_db_rms`` (both channels from ONE pass over the interleaved PCM, where
 upstream makes two ``tomono`` copies and reads each) and the stateful ``LevelMeter``.
-Not provided: 24-bit samples on the GPU path.
+24-bit samples (width 3): everything upstream delegates to audioop; not the per-sample ``array`` operations (fades,
+modulate_amp, pan with an lfo), which have no 24-bit form upstream either.
 """
 from __future__ import annotations
 
@@ -220,6 +221,10 @@ class Sample:
 
     def get_frames_numpy(self) -> np.ndarray:
         """[frames, channels] integer array (copy)."""
+        if self.__samplewidth == 3:                   # 24-bit little endian -> int32
+            b = np.frombuffer(self._host(), dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            return (v - ((v & 0x800000) << 1)).reshape(-1, self.__nchannels)
         return np.frombuffer(self._host(), dtype=_NPTYPE[self.__samplewidth]).reshape(-1, self.__nchannels).copy()
 
     def get_frames_as_floats(self) -> Sequence[float]:
@@ -471,7 +476,15 @@ class Sample:
         return self
 
     # -- the hot path ----------------------------------------------------------------------------
+    # 24-bit samples: every operation upstream hands to audioop (which reads 3-byte samples) runs on the GPU too; the ones
+    # upstream does sample by sample through ``array`` (fades, modulate_amp, pan with an lfo, from_osc_block) have no 24-bit
+    # form there either (no array typecode) and none here
+    _WIDTH3_OK = frozenset(("mix", "mix_at", "amplify", "peak", "rms", "level_db", "bias", "reverse", "mono", "stereo", "normalize",
+                            "make_32bit", "make_16bit", "resample", "echo"))
+
     def _check_gpu_width(self, what: str) -> None:
+        if self.__samplewidth == 3 and what in self._WIDTH3_OK:
+            return
         if self.__samplewidth not in (1, 2, 4):
             raise NotImplementedError("%s: %d-byte samples are not supported on the GPU path" % (what, self.__samplewidth))
 
