@@ -169,6 +169,23 @@ def ratecv_f32(x: np.ndarray, inrate: int, outrate: int) -> np.ndarray:
     return val.astype(np.float32)
 
 
+def ratecv_f32_window(get_frames, inrate: int, outrate: int, m_first: int, m_count: int) -> np.ndarray:
+    """The same closed form for output frames m_first .. m_first + m_count - 1 only, of an input too long to hold twice:
+    get_frames(idx) returns the input frames idx (int64 array) as [len(idx), nchannels] float32.  Used to check the tail
+    of BASELINE config 5 at its full size (57.6 M input frames)."""
+    g = gcd(inrate, outrate)
+    inr = inrate // g
+    outr = outrate // g
+    m = np.arange(m_first, m_first + m_count, dtype=np.int64)
+    j = (m * inr + outr - 1) // outr
+    d = j * outr - m * inr
+    cur = get_frames(j).astype(np.float64)
+    prev = np.where((j > 0)[:, None], get_frames(np.maximum(j - 1, 0)), 0).astype(np.float64)
+    dd = d.astype(np.float64)[:, None]
+    val = (prev * dd + cur * (float(outr) - dd)) / float(outr)
+    return val.astype(np.float32)
+
+
 # ---------------------------------------------------------------------------------------------------
 # the other audioop functions Sample delegates to (SURVEY.md section 8(f) item 2), restated from
 # CPython 3.10 Modules/audioop.c and checked against the live module in tests/test_oracle_pcm.py

@@ -233,6 +233,38 @@ def test_resample_large_vs_c_oracle(gpu):
     assert bytes(s.view_frame_data()) == audioop.ratecv(pcm.tobytes(), 2, 2, 48000, 44100, None)[0]
 
 
+def test_config5_at_full_size_head_middle_and_tail(gpu):
+    """BASELINE configs[4] at its FULL size -- 8 channels x 600 s x 96 kHz float32 (1.84 GB, 14 % below 2^31 bytes) -> 44.1 kHz:
+    windows of 4096 output frames at the head, where the input's byte offset passes 2^30, in the middle and at the very tail
+    (the last output frame reads the last but one input frame) against the oracle's closed form, bit for bit; plus the output
+    frame count and sh_resample_span's claim about the frames the tail reads."""
+    from oracle import pcm_oracle as P
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import dist
+    nch, in_frames, inrate, outrate = 8, 96000 * 600, 96000, 44100
+    tile_frames = 1 << 21                                   # the input is one 64 MB tile of noise repeated: frame f = tile[f % 2^21]
+    tile = np.random.default_rng(55).uniform(-1, 1, (tile_frames, nch)).astype(np.float32)
+    src = N.DeviceBuffer(in_frames * nch * 4)
+    for f0 in range(0, in_frames, tile_frames):
+        n = min(tile_frames, in_frames - f0)
+        src.upload(tile[:n].reshape(-1), f0 * nch * 4)
+    nout = N.lib().sh_resample_out_frames(in_frames, inrate, outrate)
+    assert nout == P.ratecv_out_frames(in_frames, inrate, outrate) == 26_460_000
+    dst = N.DeviceBuffer(nout * nch * 4)
+    N.check(N.lib().sh_resample(src.handle, in_frames, nch, 4, 1, inrate, outrate, dst.handle, None))
+    get = lambda idx: tile[idx % tile_frames]
+    w = 4096
+    for first in (0, ((1 << 30) // (nch * 4)) * outrate // inrate - w // 2, nout // 2 + 7, nout - w):
+        got = dst.download(np.float32, w * nch, first * nch * 4).reshape(w, nch)
+        want = P.ratecv_f32_window(get, inrate, outrate, first, w)
+        assert np.array_equal(got, want), first
+    lo, cnt = dist.resample_span(in_frames, inrate, outrate, nout - w, w)
+    j_hi = -(-(nout - 1) * 320 // 147)                      # the input frame the last output frame interpolates up to
+    assert lo + cnt == j_hi + 1 and in_frames - 2 <= j_hi < in_frames and lo % 16 == 0
+    src.free()
+    dst.free()
+
+
 @pytest.mark.parametrize("layout", [(2, 1), (2, 2), (2, 8), (4, 2), (1, 4), (2, 3)])
 @pytest.mark.parametrize("rates", [(96000, 44100), (44100, 48000), (8000, 8001), (1000003, 999983), (48000, 16000)])
 def test_resample_sharded_by_output_range(gpu, layout, rates):
