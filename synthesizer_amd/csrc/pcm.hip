@@ -985,7 +985,12 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
         int fr = 16 / (nch * width) > 8 ? 8 : 16 / (nch * width);        // 16-byte stores, at most 8 frames per thread
         // 16-bit mono through the LDS kernel: 16 frames (two 16-byte stores) per thread -- the per-thread set-up (position of the
         // first frame, staging loop) is a fifth of the instructions at 8 frames; +4 % (stereo, already at 16 bytes per 4 frames: -5 %)
-        const bool wide = small && width == 2 && nch == 1 && A.inr < 65536u;
+        // (only when the doubled input span still fits the LDS budget of that kernel: the other kernels keep 8 frames)
+        bool wide = false;
+        if (small && width == 2 && nch == 1 && A.inr < 65536u) {
+            const uint64_t sf2 = ((uint64_t)256 * 2 * fr * A.inr + A.outr - 1) / A.outr + 3;
+            wide = ((sf2 * nch + 8 + 7) / 8 + 1) * 16 <= RS_LDS_BYTES;
+        }
         if (wide) fr *= 2;
         A.n_out_samples = (uint64_t)out_frames;
         dim3 g2(sh::div_up(sh::div_up(out_frames, fr), 256));
