@@ -135,6 +135,21 @@ static_assert(sizeof(FastRec) == 256, "FastRec layout");
 constexpr uint32_t LEAN_HARM = 0, LEAN_FM = 1,                 // ... and the plain waveforms without FM (t in turns, Sine: radians);
                    LEAN_SINE = 2, LEAN_SAW = 3, LEAN_SQUARE = 4, LEAN_TRIANGLE = 5, LEAN_PULSE = 6;    // Pulse: poly[0] = pulsewidth
 
+// The accumulated t of a lane's frame j (64 samples apart) on the launch's first or second phase-table piece -- by VALUE
+// members (a lambda capturing by reference kept its closure, and with it every captured scalar, in scratch memory).
+struct LaneTheta {
+    double   di0;                 // the lane's first frame
+    double   t_base, dt, off;     // the tile's piece when it lies on one (uniform): t = fma(i - off, dt, t_base)
+    double   ta, da, tb, db, ob;  // both pieces, for the tile that straddles the end of the first at `remain`
+    uint32_t i0, remain;
+    bool     straddle;
+    __device__ __forceinline__ double operator()(int j) const {
+        const double dd = di0 + (double)(j * 64);
+        if (!straddle) return fma(dd - off, dt, t_base);
+        return i0 + (uint32_t)j * 64u < remain ? fma(dd, da, ta) : fma(dd - ob, db, tb);
+    }
+};
+
 // One set of per-launch data (double-buffered in the bank).  Voices are classified per chunk of 64 consecutive
 // voices: the fast voices of chunk c get a FastRec, compacted at fast[64c ..], the others are listed by index in
 // gen_idx[64c ..] (both in ascending voice order: the summation order is fixed), silent voices appear in neither.
@@ -975,13 +990,9 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
             straddle = tile0 < remain;
             if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
         }
-        auto theta = [&](int j) {
-            const uint32_t ii = i0 + (uint32_t)j * 64u;
-            const double dd = di0 + (double)(j * 64);
-            return ii < remain ? fma(dd, da, ta) : fma(dd - ob, db, tb);
-        };
+        const LaneTheta theta{di0, t_base, dt, off, ta, da, tb, db, ob, i0, remain, straddle};
         double s0, c0, s1, c1;
-        shm::sincos_tab(straddle ? theta(0) : fma(di0 - off, dt, t_base), trig, s0, c0);
+        shm::sincos_tab(theta(0), trig, s0, c0);
         if (straddle) {
             shm::sincos_tab(theta(1), trig, s1, c1);
         } else {
@@ -1130,8 +1141,10 @@ __device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1
 // scratch; 37 instead of 42 us per block); the general kernel walks the general lists with four frames per lane, writes its
 // partial buses behind the lean kernel's (parts[groups + g]) and sets gen_valid[g] -- or, for a group without general voices
 // (the steady state of a note), leaves after one scalar load.  The fold adds the general parts whose flag is set.
-enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2, RENDER_LEAN_HARM_ONLY = 3, RENDER_GENERAL_ONLY = 4 };
+enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2, RENDER_LEAN_HARM_ONLY = 3, RENDER_GENERAL_ONLY = 4, RENDER_LEAN_ALL_ONLY = 5 };
 constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY; }
+constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY; }
+constexpr bool mode_has_lean(int mode) { return mode != RENDER_DIRECT && mode != RENDER_GENERAL_ONLY; }
 template <int WAVES, int FPL, int MINW, int MODE>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                   uint32_t nvoices, uint32_t voices_per_group,
@@ -1222,7 +1235,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // the frames of this lane, launch-relative (clamped into the launch: out-of-range lanes compute a valid sample and do not
     // store it).  The lean Harmonics loop does not use the arrays -- it works from the lane's first frame alone -- so in that
     // mode they are only built after it, for the general code: they would cost 3 registers per frame for the whole loop.
-    auto build_frames = [&](uint32_t lane_) {
+    auto build_frames = [&](uint32_t lane_) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
             uint32_t raw = tile0 + j * 64 + lane_;
@@ -1230,7 +1243,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             di[j] = (double)i[j];
         }
     };
-    if constexpr (!mode_lean_harm(MODE)) build_frames(lane);
+    if constexpr (!mode_has_lean(MODE)) build_frames(lane);        // (the lean loops work from the lane's first frame alone)
     if constexpr (MODE == RENDER_DIRECT) {
         const uint32_t v0 = blockIdx.y * voices_per_group;
         uint32_t v1 = v0 + voices_per_group;
@@ -1265,27 +1278,24 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                          "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
                          "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
                          "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
-            if constexpr (mode_lean_harm(MODE)) {
-                // every record here is a polynomial Harmonics voice: lookup + one rotation + the recurrence.  The piece (first /
-                // second of the launch) is chosen by scalar selects, the rare straddling tile by one uniform flag, and all three
-                // cases run through the same arithmetic below.
-                const uint32_t i0 = tile0 + lane;                     // the lane's first frame (< nframes + 64: harmless)
-                const double di0 = (double)i0;
-                double t_base = ta, dt = da, rc = rca, rs = rsa, off = 0.0, tb = ta, db = da, ob = 0.0;
-                bool straddle = false;
-                if (remain != 0xFFFFFFFFu && tile_last >= remain) {   // not wholly on the first piece
-                    tb = q->t0_b; db = q->dt_b; ob = q->off_b;
-                    const double rcb = q->rot_c_b, rsb = q->rot_s_b;
-                    straddle = tile0 < remain;
-                    if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
-                }
-                auto theta = [&](int j) {                             // per lane: frame j of a straddling tile
-                    const uint32_t ii = i0 + (uint32_t)j * 64u;
-                    const double dd = di0 + (double)(j * 64);
-                    return ii < remain ? fma(dd, da, ta) : fma(dd - ob, db, tb);
-                };
+            // Every lean kind works from the lane's FIRST frame alone (no per-frame index arrays): the piece of the phase table
+            // (first / second of the launch) is chosen by scalar selects, the one tile per crossing that straddles the piece end by
+            // a uniform flag, and the frames follow 64 samples apart.
+            const uint32_t i0 = tile0 + lane;                         // the lane's first frame (< nframes + 64: harmless)
+            const double di0 = (double)i0;
+            double t_base = ta, dt = da, rc = rca, rs = rsa, off = 0.0, tb = ta, db = da, ob = 0.0;
+            bool straddle = false;
+            if (remain != 0xFFFFFFFFu && tile_last >= remain) {       // not wholly on the first piece
+                tb = q->t0_b; db = q->dt_b; ob = q->off_b;
+                const double rcb = q->rot_c_b, rsb = q->rot_s_b;
+                straddle = tile0 < remain;
+                if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
+            }
+            const LaneTheta theta{di0, t_base, dt, off, ta, da, tb, db, ob, i0, remain, straddle};    // the accumulated t at frame j
+            if (mode_lean_harm(MODE) || kind == LEAN_HARM) {
+                // polynomial Harmonics: lookup + one rotation + the three-term recurrence (lean_harm_frames)
                 double s0, c0, s1, c1;
-                shm::sincos_tab(straddle ? theta(0) : fma(di0 - off, dt, t_base), trig, s0, c0);
+                shm::sincos_tab(theta(0), trig, s0, c0);
                 if (straddle) {
                     if (FPL > 1) shm::sincos_tab(theta(1), trig, s1, c1); else { s1 = s0; c1 = c0; }
                 } else {
@@ -1295,127 +1305,74 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                 lean_harm_frames<FPL>(s0, c0, s1, c1, rc + rc, straddle, theta, trig, poly, gl, gr, accl, accr);
                 continue;
             }
-            if (MODE == RENDER_LEAN_ALL && kind == LEAN_FM) {
-                // Sine carrier, closed-form Sine LFO (the arithmetic of voice_block's FM path): T = accumulated time
-                double T[FPL];
-                if (remain == 0xFFFFFFFFu || tile_last < remain) {
-#pragma unroll
-                    for (int j = 0; j < FPL; ++j) T[j] = fma(di[j], da, ta);
+            if constexpr (!mode_lean_harm(MODE)) {
+            if (kind == LEAN_SINE) {
+                // a plain Sine: the same recurrence on the sine alone (the amplitude lives in the gains)
+                double s0, c0, s1, c1;
+                shm::sincos_tab(theta(0), trig, s0, c0);
+                if (straddle) {
+                    if (FPL > 1) shm::sincos_tab(theta(1), trig, s1, c1); else { s1 = s0; c1 = c0; }
                 } else {
-                    const double tb = q->t0_b, db = q->dt_b, ob = q->off_b;
-                    if (tile0 >= remain) {
+                    s1 = fma(s0, rc, c0 * rs);
+                }
+                const double k2 = rc + rc;
 #pragma unroll
-                        for (int j = 0; j < FPL; ++j) T[j] = fma(di[j] - ob, db, tb);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < FPL; ++j) T[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+                for (int j = 0; j < FPL; ++j) {
+                    accl[j] = fma(gl, s0, accl[j]);
+                    accr[j] = fma(gr, s0, accr[j]);
+                    if (j + 1 < FPL) {
+                        double s2;
+                        if (straddle) { if (j + 2 < FPL) shm::sincos_tab(theta(j + 2), trig, s2, c1); else s2 = 0.0; }
+                        else s2 = fma(k2, s1, -s0);
+                        s0 = s1;
+                        s1 = s2;
                     }
                 }
+                continue;
+            }
+            if (kind == LEAN_FM) {
+                // Sine carrier, closed-form Sine LFO (the arithmetic of voice_block's FM path).  theta(j) is the accumulated TIME;
+                // the LFO angle a_rel + i*d is exactly linear in i, and only its COSINE enters L(i) = K (C0 - cos) + bias*(start+i):
+                // one table lookup for the lane's first frame, one rotation for the second, then cos[j] = 2cos(64d) cos[j-1] - cos[j-2].
                 const double frequency = poly[0], phase0 = poly[1], f_inc = poly[2], lfo_a_rel = poly[3], lfo_d = poly[4];
                 const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], lrc = poly[8], lrs = poly[9], startd = poly[10];
-                double ls, lc, th[FPL], sn[FPL], cs[FPL];
-                shm::sincos_tab(fma(di[0], lfo_d, lfo_a_rel), trig, ls, lc);
+                double ls0, lc0;
+                shm::sincos_tab(fma(di0, lfo_d, lfo_a_rel), trig, ls0, lc0);
+                double lc1 = fma(lc0, lrc, -(ls0 * lrs));
+                const double lk2 = lrc + lrc;
 #pragma unroll
-                for (int j = 0; j < FPL; ++j) {
-                    if (j > 0) {                          // the LFO angle of the next frame is one rotation by 64*lfo_d away
-                        const double ns = fma(ls, lrc, lc * lrs), nc = fma(lc, lrc, -(ls * lrs));
-                        ls = ns;
-                        lc = nc;
+                for (int h = 0; h < FPL; h += 4) {            // four carriers at a time: their table reads are in flight together
+                    constexpr int Q = FPL < 4 ? FPL : 4;
+                    double th[Q], sn[Q], cs[Q];
+#pragma unroll
+                    for (int jj = 0; jj < Q; ++jj) {
+                        const int j = h + jj;
+                        const double Ln = fma(lfo_K, lfo_C0 - lc0, lfo_bias * (startd + (di0 + (double)(j * 64))));
+                        th[jj] = frequency * theta(j) + fma(f_inc, Ln, phase0);
+                        const double lc2 = fma(lk2, lc1, -lc0);
+                        lc0 = lc1;
+                        lc1 = lc2;
                     }
-                    const double Ln = fma(lfo_K, lfo_C0 - lc, lfo_bias * (startd + di[j]));
-                    th[j] = frequency * T[j] + fma(f_inc, Ln, phase0);
-                }
-                shm::sincos_tab_n<FPL>(th, trig, sn, cs);
+                    shm::sincos_tab_n<Q>(th, trig, sn, cs);
 #pragma unroll
-                for (int j = 0; j < FPL; ++j) {
-                    accl[j] = fma(gl, sn[j], accl[j]);
-                    accr[j] = fma(gr, sn[j], accr[j]);
-                }
-                continue;
-            }
-            if (MODE == RENDER_LEAN_ALL && kind >= LEAN_SAW) {
-                // Sawtooth / Square / Triangle / Pulse at unit amplitude (the amplitude lives in the gains): t in turns
-                double th[FPL], x[FPL];
-                if (remain == 0xFFFFFFFFu || tile_last < remain) {
-#pragma unroll
-                    for (int j = 0; j < FPL; ++j) th[j] = fma(di[j], da, ta);
-                } else {
-                    const double tb = q->t0_b, db = q->dt_b, ob = q->off_b;
-                    if (tile0 >= remain) {
-#pragma unroll
-                        for (int j = 0; j < FPL; ++j) th[j] = fma(di[j] - ob, db, tb);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < FPL; ++j) th[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+                    for (int jj = 0; jj < Q; ++jj) {
+                        accl[h + jj] = fma(gl, sn[jj], accl[h + jj]);
+                        accr[h + jj] = fma(gr, sn[jj], accr[h + jj]);
                     }
                 }
-                if (kind == LEAN_SAW) {
-#pragma unroll
-                    for (int j = 0; j < FPL; ++j) x[j] = shm::saw_value(th[j], 2.0, 0.0);
-                } else if (kind == LEAN_SQUARE) {
-#pragma unroll
-                    for (int j = 0; j < FPL; ++j) x[j] = shm::square_value(th[j], 1.0, 0.0);
-                } else if (kind == LEAN_TRIANGLE) {
-#pragma unroll
-                    for (int j = 0; j < FPL; ++j) x[j] = shm::triangle_value(th[j], 4.0, 0.0);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < FPL; ++j) x[j] = shm::pulse_value(th[j], poly[0], 1.0, 0.0);
-                }
-#pragma unroll
-                for (int j = 0; j < FPL; ++j) {
-                    accl[j] = fma(gl, x[j], accl[j]);
-                    accr[j] = fma(gr, x[j], accr[j]);
-                }
                 continue;
             }
-            double sn[FPL], cs[FPL], pv[FPL];
-            if (remain == 0xFFFFFFFFu) {                  // no piece end inside the launch: nothing to decide
-                shm::sincos_tab(fma(di[0], da, ta), trig, sn[0], cs[0]);
-#pragma unroll
-                for (int j = 1; j < FPL; ++j) {           // frame j is 64 samples after frame j-1: rotate by 64*dt
-                    sn[j] = fma(sn[j - 1], rca, cs[j - 1] * rsa);
-                    cs[j] = fma(cs[j - 1], rca, -(sn[j - 1] * rsa));
-                }
-            } else if (tile0 >= remain || tile_last < remain) {       // the tile lies on one of the two pieces (uniform)
-                const double tb = q->t0_b, db = q->dt_b, rcb = q->rot_c_b, rsb = q->rot_s_b, ob = q->off_b;
-                const bool on_b = tile0 >= remain;
-                const double t_base = on_b ? tb : ta, dt = on_b ? db : da;
-                const double rc = on_b ? rcb : rca, rs = on_b ? rsb : rsa;
-                const double off = on_b ? ob : 0.0;
-                shm::sincos_tab(fma(di[0] - off, dt, t_base), trig, sn[0], cs[0]);
-#pragma unroll
-                for (int j = 1; j < FPL; ++j) {
-                    sn[j] = fma(sn[j - 1], rc, cs[j - 1] * rs);
-                    cs[j] = fma(cs[j - 1], rc, -(sn[j - 1] * rs));
-                }
-            } else {                                      // the one tile per crossing that straddles the piece end
-                const double tb = q->t0_b, db = q->dt_b, ob = q->off_b;
-                double th[FPL];
-#pragma unroll
-                for (int j = 0; j < FPL; ++j) th[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
-                shm::sincos_tab_n<FPL>(th, trig, sn, cs);
-            }
-            if (MODE == RENDER_LEAN_ALL && kind == LEAN_SINE) {       // a plain Sine: sin(t) is the sample
-#pragma unroll
-                for (int j = 0; j < FPL; ++j) {
-                    accl[j] = fma(gl, sn[j], accl[j]);
-                    accr[j] = fma(gr, sn[j], accr[j]);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int j = 0; j < FPL; ++j) pv[j] = fma(poly[0], cs[j], poly[1]);
-#pragma unroll
-            for (int u = 2; u < 16; ++u) {
-#pragma unroll
-                for (int j = 0; j < FPL; ++j) pv[j] = fma(pv[j], cs[j], poly[u]);
-            }
+            // Sawtooth / Square / Triangle / Pulse at unit amplitude (the amplitude lives in the gains): t in turns, frame by frame
 #pragma unroll
             for (int j = 0; j < FPL; ++j) {
-                const double x = pv[j] * sn[j];
+                const double th = theta(j);
+                const double x = kind == LEAN_SAW ? shm::saw_value(th, 2.0, 0.0)
+                               : kind == LEAN_SQUARE ? shm::square_value(th, 1.0, 0.0)
+                               : kind == LEAN_TRIANGLE ? shm::triangle_value(th, 4.0, 0.0)
+                               : shm::pulse_value(th, poly[0], 1.0, 0.0);
                 accl[j] = fma(gl, x, accl[j]);
                 accr[j] = fma(gr, x, accr[j]);
+            }
             }
         }
         first = p - nfast;                                    // 0 .. WAVES-1: where the stride lands in the next list
@@ -1423,12 +1380,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     }
     // ---- every other sounding voice: the general code (the stride simply continues, so the extra voices go to the
     // waves that got one fast voice fewer) ----
-    if constexpr (MODE == RENDER_LEAN_HARM) {
+    if constexpr (MODE == RENDER_LEAN_HARM || MODE == RENDER_LEAN_ALL) {
         uint32_t lane_late = lane;
         asm volatile("" : "+v"(lane_late));       // defined here, after the loop above: the arrays cannot be built earlier
         build_frames(lane_late);
     }
-    if constexpr (MODE != RENDER_LEAN_HARM_ONLY) {
+    if constexpr (!mode_lean_only(MODE)) {
     for (uint32_t c = c0; c < c1; ++c) {
         const uint32_t ngen = as_const(cur.counts)[4 * c + 1];
         const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
@@ -1839,14 +1796,14 @@ struct sh_bank {
     uint32_t    lean_fm_candidates = 0;   // ... of them other than polynomial Harmonics (FM Sine, plain waveforms)
     uint32_t    last_groups = 0;          // voice groups of the last sh_bank_render launch (sh_bank_launch_stats)
     // When can a launch hold NO general voice (so that a split launch needs no general-lists kernel)?  Conservative, from
-    // static properties: every voice is a polynomial-Harmonics lean candidate, every envelope is on its sustain piece for the
+    // static properties: every voice is a lean candidate, every envelope is on its sustain piece for the
     // whole launch, and no phase-table piece shorter than the launch ends after its start (a launch then crosses at most one
     // piece end per voice).  short_piece_end[k] = the largest end of any piece shorter than 2^k samples.
-    bool        all_lean_harm = false;
+    bool        all_lean = false;          // every voice is a lean candidate (of any lean kind)
     uint64_t    env_flat_from = 0, env_flat_until = ~0ull;
     uint64_t    short_piece_end[34] = {};
     bool        no_general_voice(uint64_t start, uint32_t nframes) const {
-        if (!all_lean_harm || start < env_flat_from || start + nframes > env_flat_until) return false;
+        if (!all_lean || start < env_flat_from || start + nframes > env_flat_until) return false;
         int k = 0;
         while ((1ull << k) < (uint64_t)nframes) ++k;
         return short_piece_end[k] <= start;
@@ -1971,16 +1928,17 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             if (voices[i].kind != SH_HARMONICS) b->lean_fm_candidates += 1;       // needs the kernel with all record kinds
         }
     {
-        b->all_lean_harm = b->lean_candidates == nvoices && b->lean_fm_candidates == 0;
-        for (uint32_t i = 0; i < nvoices && b->all_lean_harm; ++i) {
+        b->all_lean = b->lean_candidates == nvoices;
+        for (uint32_t i = 0; i < nvoices && b->all_lean; ++i) {
             const sh_voice& v = voices[i];
             if (v.env.enabled) {
                 if (v.env.n_decay_end > b->env_flat_from) b->env_flat_from = v.env.n_decay_end;
                 if (v.env.n_attack_end > b->env_flat_from) b->env_flat_from = v.env.n_attack_end;
                 if (v.env.n_sustain_end < b->env_flat_until) b->env_flat_until = v.env.n_sustain_end;
             }
-            for (uint32_t k = 0; k + 1 < v.seg_count; ++k) {
-                const uint64_t a = segs[v.seg_offset + k].n0, e = segs[v.seg_offset + k + 1].n0;
+            const uint32_t toff = v.fm_mode ? v.time_seg_offset : v.seg_offset, tcnt = v.fm_mode ? v.time_seg_count : v.seg_count;
+            for (uint32_t k = 0; k + 1 < tcnt; ++k) {
+                const uint64_t a = segs[toff + k].n0, e = segs[toff + k + 1].n0;
                 const uint64_t len = e - a;
                 for (int q = 0; q < 34; ++q)
                     if (len < (1ull << q) && e > b->short_piece_end[q]) b->short_piece_end[q] = e;
@@ -2294,9 +2252,9 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     }
     int var = variant;
     const int mode = b->lean_candidates == 0 ? RENDER_DIRECT : (b->lean_fm_candidates ? RENDER_LEAN_ALL : RENDER_LEAN_HARM);
-    // banks whose lean voices are all polynomial Harmonics take eight frames per lane on long blocks: the recurrence makes
-    // every frame after the second cost two FMAs of trigonometry (one table lookup per eight frames)
-    if (var == 0) var = b->nvoices >= 128 ? (2 * b->lean_candidates >= b->nvoices ? ((mode == RENDER_LEAN_HARM && nframes >= 16384) ? 484 : 444) : 844)
+    // mostly-lean banks take eight frames per lane on long blocks: the recurrences make every frame after the second cost one or
+    // two FMAs of trigonometry (one table lookup per eight frames)
+    if (var == 0) var = b->nvoices >= 128 ? (2 * b->lean_candidates >= b->nvoices ? (nframes >= 16384 ? 484 : 444) : 844)
                                           : (b->nvoices >= 64 ? 826 : (b->nvoices >= 8 ? 421 : 211));
     const int W = var / 100, F = (var / 10) % 10;
     // Voice groups: split the voices when the frame range alone gives too few tiles for 256 CUs -- up to ONE round of
@@ -2343,11 +2301,11 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     const int prev_cur = b->cur;
     rc = acquire_records(b, start, nframes, st, cont);
     if (rc) return rc;
-    // lean candidates all polynomial Harmonics + several voice groups: the launch is split into a lean and a general kernel
+    // a bank with lean candidates + several voice groups: the launch is split into a lean and a general kernel
     // (see the RENDER_* modes); SYNTHHIP_NO_SPLIT=1 keeps the combined kernel
     static int no_split = -1;
     if (no_split < 0) { const char* e = getenv("SYNTHHIP_NO_SPLIT"); no_split = (e && e[0] == '1') ? 1 : 0; }
-    const bool split = mode == RENDER_LEAN_HARM && groups > 1 && !no_split;
+    const bool split = mode != RENDER_DIRECT && groups > 1 && !no_split;
     // partial buses: ring slot n % 4 (last read by the fold in launch n - 2, which is this stream's previous launch)
     double2* parts = nullptr;
     if (groups > 1) {
@@ -2407,7 +2365,8 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
                        o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen)
 #define SH_LAUNCH_RENDER(W_, F_, M_)                                                 \
     do {                                                                             \
-        if (split) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM_ONLY);                \
+        if (split && mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM_ONLY); \
+        else if (split) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_ALL_ONLY);            \
         else if (mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM);  \
         else if (mode == RENDER_LEAN_ALL) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_ALL); \
         else SH_LAUNCH_MODE(W_, F_, M_, RENDER_DIRECT);                              \
