@@ -47,6 +47,79 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k(const FastRec* __restrict_
         double poly[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+        if constexpr (MODE == 4) {
+            // mixed precision: float64 phase, lookup, rotation and recurrence; the harmonic series by
+            // CLENSHAW IN FLOAT32, two frames per packed instruction (v_pk_fma_f32); accumulation in float64.
+            // q->poly[k] here = a_k (series amplitudes), used as float.
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const double k2 = q->pad[0];
+            float af[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) af[u] = (float)poly[u];
+            double s0, c0, s1, c1;
+            shm::sincos_tab(fma(di0, dt, t_base), trig, s0, c0);
+            s1 = fma(s0, rc, c0 * rs);
+            c1 = fma(c0, rc, -(s0 * rs));
+#pragma unroll
+            for (int h = 0; h < FPL; h += 2) {
+                const v2f c2 = {(float)(c0 + c0), (float)(c1 + c1)};
+                const v2f sv = {(float)s0, (float)s1};
+                v2f b1 = {0.f, 0.f}, b2 = {0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const v2f ak = {af[u], af[u]};
+                    const v2f bn = __builtin_elementwise_fma(c2, b1, ak - b2);
+                    b2 = b1;
+                    b1 = bn;
+                }
+                const v2f x = b1 * sv;
+                accl[h] = fma(gl, (double)x[0], accl[h]); accr[h] = fma(gr, (double)x[0], accr[h]);
+                accl[h + 1] = fma(gl, (double)x[1], accl[h + 1]); accr[h + 1] = fma(gr, (double)x[1], accr[h + 1]);
+                if (h + 2 < FPL) {
+                    const double s2 = fma(k2, s1, -s0), c2d = fma(k2, c1, -c0);
+                    const double s3 = fma(k2, s2, -s1), c3 = fma(k2, c2d, -c1);
+                    s0 = s2; c0 = c2d; s1 = s3; c1 = c3;
+                }
+            }
+            continue;
+        }
+        if constexpr (MODE == 5) {
+            // the same with float32 accumulators (packed), summed to float64 once per voice loop
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const double k2 = q->pad[0];
+            float af[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) af[u] = (float)poly[u];
+            const float glf = (float)gl, grf = (float)gr;
+            double s0, c0, s1, c1;
+            shm::sincos_tab(fma(di0, dt, t_base), trig, s0, c0);
+            s1 = fma(s0, rc, c0 * rs);
+            c1 = fma(c0, rc, -(s0 * rs));
+#pragma unroll
+            for (int h = 0; h < FPL; h += 2) {
+                const v2f c2 = {(float)(c0 + c0), (float)(c1 + c1)};
+                const v2f sv = {(float)s0, (float)s1};
+                v2f b1 = {0.f, 0.f}, b2 = {0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const v2f ak = {af[u], af[u]};
+                    const v2f bn = __builtin_elementwise_fma(c2, b1, ak - b2);
+                    b2 = b1;
+                    b1 = bn;
+                }
+                const v2f x = b1 * sv;
+                v2f al = {(float)accl[h], (float)accl[h + 1]}, ar = {(float)accr[h], (float)accr[h + 1]};
+                al = __builtin_elementwise_fma((v2f){glf, glf}, x, al);
+                ar = __builtin_elementwise_fma((v2f){grf, grf}, x, ar);
+                accl[h] = al[0]; accl[h + 1] = al[1]; accr[h] = ar[0]; accr[h + 1] = ar[1];
+                if (h + 2 < FPL) {
+                    const double s2 = fma(k2, s1, -s0), c2d = fma(k2, c1, -c0);
+                    const double s3 = fma(k2, s2, -s1), c3 = fma(k2, c2d, -c1);
+                    s0 = s2; c0 = c2d; s1 = s3; c1 = c3;
+                }
+            }
+            continue;
+        }
         if constexpr (MODE == 3) {
             // frames j >= 2 by the three-term recurrence x[j] = 2cos(64dt) x[j-1] - x[j-2] (one FMA per value instead of a
             // two-FMA + two-MUL rotation); pad[0] holds 2cos(64dt)
@@ -186,6 +259,10 @@ int main() {
         }
     }
     for (uint32_t groups : {8u}) {
+        run<8, 4, 4, 4>("FPL8 f32 pk Clenshaw, f64 acc, g8", d_recs, d_trig, d_parts, nvoices, nframes, 8);
+        run<8, 4, 4, 5>("FPL8 f32 pk Clenshaw, f64 acc, min5", d_recs, d_trig, d_parts, nvoices, nframes, 8);
+        run<16, 4, 4, 4>("FPL16 f32 pk Clenshaw, f64 acc, g16", d_recs, d_trig, d_parts, nvoices, nframes, 16);
+        run<8, 5, 4, 4>("FPL8 f32 pk Clenshaw, f32 acc (cvt), g8", d_recs, d_trig, d_parts, nvoices, nframes, 8);
         run<4, 3, 4, 4>("FPL4 recurrence 4w min4", d_recs, d_trig, d_parts, nvoices, nframes, 8);
         run<8, 3, 4, 4>("FPL8 recurrence 4w min4 g16", d_recs, d_trig, d_parts, nvoices, nframes, 16);
         run<8, 3, 4, 5>("FPL8 recurrence 4w min5 g16", d_recs, d_trig, d_parts, nvoices, nframes, 16);
