@@ -102,3 +102,35 @@ def test_segmented_materialisation_of_long_rows(gpu):
     two = bank.render_two_step(n, start=start)
     fused = bank.render(n, start=start)
     assert np.sqrt(np.mean((two.astype(np.float64) - fused) ** 2)) <= 5e-7
+
+
+def test_recurrence_at_frequencies_where_the_step_angle_is_degenerate(gpu):
+    """The lean loop steps 64 samples by x[j] = 2cos(d) x[j-1] - x[j-2], d = 64*dt.  Where sin(d) is tiny -- 750 Hz at 48 kHz is
+    d = 2 pi exactly, 375 Hz d = pi, and their neighbours -- 2cos(d) pins the step angle least precisely (error ~1e-16/|sin d|
+    per step).  192 voices right at and around such frequencies (several voice groups: the eight-frames-per-lane lean kernel),
+    16 partials each, against the C oracle: still orders of magnitude inside the contract."""
+    from oracle import c_oracle as CO
+    from oracle import synth_oracle as O
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    harm = [(k, 1.0 / k) for k in range(1, 17)]
+    freqs = []
+    for base in (750.0, 375.0, 1500.0, 93.75, 3000.0, 187.5):
+        for eps in (0.0, 1e-9, -1e-9, 1e-6, -1e-6, 1e-4, 1e-3, -1e-2):
+            freqs.append(base * (1.0 + eps))
+    freqs = (freqs * 4)[:192]
+    rng = np.random.default_rng(2)
+    phases = rng.uniform(0, 1, len(freqs))
+    gains = [(float(np.float32(a)), float(np.float32(b))) for a, b in rng.uniform(0.1, 1.0, (len(freqs), 2))]
+
+    def build(m):
+        return [m.Harmonics(f, harm, amplitude=0.01, phase=float(p), samplerate=SR) for f, p in zip(freqs, phases)]
+    bank = VoiceBank(build(G), gains=gains)
+    ov = build(O)
+    for start, n in ((0, 48000), (48000 * 5, 20000)):           # the first second and a block five seconds into the note
+        got = bank.render(n, start=start)
+        rows = np.stack([CO.render(o, start + n)[start:] for o in ov])
+        want = np.array(CO.mix_bus(rows, gains), dtype=np.float64)
+        err = got.astype(np.float64) - want
+        assert np.sqrt(np.mean(err ** 2)) <= 2e-8, (start, float(np.sqrt(np.mean(err ** 2))))
+        assert np.max(np.abs(err)) <= 2e-7, start
