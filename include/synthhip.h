@@ -217,7 +217,8 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
  * bus_f64 (optional) receives the float64 partial bus (frames x 2) used for the multi-GPU reduce.
  * Work is enqueued like every other call.  One detail matters to code that reads the bus buffers with its OWN
  * kernels through sh_buf_devptr: consecutive renders of a bank (same block length, the next block each time) form a
- * run that is pipelined -- they alternate between two HIP streams so that one launch fills the tail of the other, and
+ * run that is pipelined (every bank has its own: banks rendering turn by turn do not end each other's runs) -- they
+ * alternate between two HIP streams so that one launch fills the tail of the other, and
  * with several voice groups the last step of a render (folding the groups' partial buses into the bus) is done inside
  * the render kernel two launches later.  Any other call into the library (sh_sync, sh_buf_download, sh_buf_free, ...;
  * not sh_buf_alloc) ends the run first: it joins the streams and folds what is outstanding -- so such code must call

@@ -19,7 +19,8 @@ namespace sh {
 // A bank render with several voice groups leaves float64 partial buses that still have to be folded into the caller's
 // bus.  In a stream of renders that fold is done by the first workgroups of the render kernel TWO launches later (no
 // kernel of its own, no launch boundary); any other API call folds what is outstanding first (SH_REQUIRE_INIT ->
-// flush_pending).  Two launches, not one: consecutive renders alternate between two HIP streams so that the tail of one
+// flush_pending).  The run, the folds owed and the ring of partial-bus buffers belong to the BANK (osc.hip, struct sh_bank): banks
+// rendering turn by turn each keep their pipeline; only a render that breaks its own bank's run folds that bank's leftovers.  Two launches, not one: consecutive renders alternate between two HIP streams so that the tail of one
 // launch (its last, partly empty round of workgroups, the launch gap) is filled by the next -- which therefore must not
 // depend on its predecessor: launch n reads the launch records that launch n-2 resolved and folds launch n-2's partial
 // buses (same stream), and shares nothing with launch n-1.
@@ -45,21 +46,15 @@ struct State {
     int*        flag = nullptr;        // device int: overflow flag for quantise
     int*        flag_host = nullptr;   // pinned host mirror
     void*       trig = nullptr;        // device: 512 x (sin, cos) of k*2pi/512, float64 (devmath.hpp sincos_tab)
-    // partial buses of bank renders: launch n writes ring slot n % 4, launch n + 2 (same stream) reads it
-    void*       parts_buf[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t      parts_bytes[4] = {0, 0, 0, 0};
-    PendingCombine pending[2];          // partial buses not yet folded, oldest first
-    int         npending = 0;
+    // Bank renders that still owe the fold of their partial buses (over all banks: each bank keeps its own run of pipelined
+    // launches, its pending folds and its ring of partial-bus buffers -- osc.hip, struct sh_bank)
+    int         pending_total = 0;
     // second render stream and the events that tie it to `stream`
     hipStream_t stream2 = nullptr;
     hipEvent_t  ev_join = nullptr;      // on `stream` when a run of renders starts: stream2's first launch of the run waits for it
     hipEvent_t  ev_aux = nullptr;       // on stream2 after every launch there: `stream` waits for it when the run ends
     hipEvent_t  ev_prep = nullptr;      // on `stream` after a prepare kernel that a stream2 launch needs
     bool        aux_busy = false;       // stream2 holds work `stream` has not waited for
-    // the current run of back-to-back renders: same bank and shape, consecutive blocks
-    const void* run_bank = nullptr;
-    uint64_t    run_next_start = 0;
-    uint32_t    run_nframes = 0, run_groups = 0, run_tile = 0, run_count = 0;
 };
 
 State& state();
@@ -74,8 +69,9 @@ int  ensure_scratch(size_t bytes);
 int  pool_alloc(size_t bytes, void** ptr, size_t* cap);   // device buffer pool (runtime.hip)
 void pool_free(void* ptr, size_t cap);
 void pool_trim();
-int  flush_pending();                  // end the run of renders: join stream2, fold outstanding partial buses now (osc.hip)
-inline bool has_pending() { return state().npending != 0 || state().aux_busy; }
+int  flush_pending();                  // end every bank's run of renders: join stream2, fold all outstanding partial buses now (osc.hip)
+void free_render_buffers();            // the banks' partial-bus rings (sh_shutdown)
+inline bool has_pending() { return state().pending_total != 0 || state().aux_busy; }
 int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out);   // float64 bus -> float32 (osc.hip)
 
 #define SH_REQUIRE_INIT_KEEP_PENDING()                                                 \

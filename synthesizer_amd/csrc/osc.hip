@@ -1774,6 +1774,17 @@ struct sh_bank {
     uint32_t*   d_gen_idx_buf[NSETS] = {};
     uint32_t*   d_counts_buf[NSETS] = {};      // 4 per 64-voice chunk: lean, general, silent, -
     uint32_t*   d_hint = nullptr;
+    // This bank's run of pipelined renders (same shape, consecutive blocks), the folds it still owes, and its ring of
+    // partial-bus buffers: launch n writes ring slot n % 4, launch n + 2 (same stream) folds it.  Per bank, so that two banks
+    // rendering turn by turn (or a bank beside a DistVoiceBank's) each keep their pipeline: only calls that can touch a bus
+    // buffer end the runs (sh::flush_pending).
+    bool        run_active = false;
+    uint64_t    run_next_start = 0;
+    uint32_t    run_nframes = 0, run_groups = 0, run_tile = 0, run_count = 0;
+    sh::PendingCombine pending[2];
+    int         npending = 0;
+    void*       parts_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t      parts_bytes[4] = {0, 0, 0, 0};
     // modulation rows (sh_bank_set_rows / sh_bank_render_rows)
     int32_t*    d_fm_row = nullptr;
     int32_t*    d_pwm_row = nullptr;
@@ -1848,25 +1859,54 @@ static int upload_array(T** dst, const T* src, size_t count, hipStream_t st) {
     return SH_OK;
 }
 
-namespace sh {
-int flush_pending() {
-    State& S = state();
-    S.run_bank = nullptr;                                 // the run of renders ends here: the next one starts on `stream`
-    S.run_count = 0;
-    if (S.aux_busy) {
-        S.aux_busy = false;
-        SH_HIP(hipStreamWaitEvent(S.stream, S.ev_aux, 0));
-    }
-    const int n = S.npending;
-    S.npending = 0;
-    for (int k = 0; k < n; ++k) {                         // oldest first: a bus used for two blocks ends up holding the later one
-        const PendingCombine& pc = S.pending[k];
-        hipLaunchKernelGGL(k_bus_combine, dim3(div_up(pc.nframes, 256)), dim3(256), 0, S.stream,
+static std::vector<sh_bank*>& live_banks() {
+    static std::vector<sh_bank*> v;
+    return v;
+}
+
+// Fold what one bank still owes (oldest first: a bus used for two blocks ends up holding the later one) on the main stream and
+// end its run.  The caller has joined stream2 into the main stream.
+static int fold_bank(sh_bank* b) {
+    sh::State& S = sh::state();
+    b->run_active = false;
+    b->run_count = 0;
+    const int n = b->npending;
+    b->npending = 0;
+    S.pending_total -= n;
+    for (int k = 0; k < n; ++k) {
+        const sh::PendingCombine& pc = b->pending[k];
+        hipLaunchKernelGGL(k_bus_combine, dim3(sh::div_up(pc.nframes, 256)), dim3(256), 0, S.stream,
                            (const double2*)pc.parts, pc.groups, pc.nframes, (float2*)pc.o32, (double2*)pc.o64,
                            (uint32_t*)pc.o16, pc.scale, (const uint32_t*)pc.gen_valid);
         SH_CHECK_LAUNCH("k_bus_combine");
     }
     return SH_OK;
+}
+
+static int join_aux() {
+    sh::State& S = sh::state();
+    if (S.aux_busy) {
+        S.aux_busy = false;
+        SH_HIP(hipStreamWaitEvent(S.stream, S.ev_aux, 0));
+    }
+    return SH_OK;
+}
+
+namespace sh {
+int flush_pending() {
+    int rc = join_aux();
+    if (rc) return rc;
+    for (sh_bank* b : live_banks()) {                     // every bank's run ends here: the next one starts on `stream`
+        rc = fold_bank(b);
+        if (rc) return rc;
+    }
+    return SH_OK;
+}
+
+void free_render_buffers() {
+    for (sh_bank* b : live_banks())
+        for (int k = 0; k < 4; ++k)
+            if (b->parts_buf[k]) { (void)hipFree(b->parts_buf[k]); b->parts_buf[k] = nullptr; b->parts_bytes[k] = 0; }
 }
 
 int bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out) {
@@ -1982,6 +2022,7 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
         sh_bank_destroy(b);
         return rc;
     }
+    live_banks().push_back(b);
     *out = b;
     return SH_OK;
 }
@@ -1992,6 +2033,7 @@ int sh_bank_destroy(sh_bank* b) {
     if (sh::state().initialized) {
         if (sh::has_pending()) (void)sh::flush_pending();
         (void)hipStreamSynchronize(sh::state().stream);
+        for (int k = 0; k < 4; ++k) if (b->parts_buf[k]) (void)hipFree(b->parts_buf[k]);
         if (b->d_voices) (void)hipFree(b->d_voices);
         if (b->d_segs) (void)hipFree(b->d_segs);
         if (b->d_coefs) (void)hipFree(b->d_coefs);
@@ -2014,6 +2056,11 @@ int sh_bank_destroy(sh_bank* b) {
         if (b->gen_set.counts) (void)hipFree(b->gen_set.counts);
         if (b->d_seg_rot) (void)hipFree(b->d_seg_rot);
         if (b->d_lfo_rot) (void)hipFree(b->d_lfo_rot);
+    }
+    {
+        auto& v = live_banks();
+        for (size_t k = 0; k < v.size(); ++k)
+            if (v[k] == b) { v.erase(v.begin() + (long)k); break; }
     }
     delete b;
     return SH_OK;
@@ -2280,20 +2327,37 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // Does this launch continue the run of renders (same bank and shape, the next block)?  Then it alternates streams with
     // its predecessor and folds the partial buses of the launch before that; else what is outstanding is folded now and a
     // new run starts on `stream`.
-    const bool cont = groups > 1 && S.run_bank == (const void*)b && S.run_nframes == nframes && S.run_groups == groups &&
-                      S.run_tile == (uint32_t)(64 * F) && S.run_next_start == start;
-    if (!cont) {
-        rc = sh::flush_pending();
-        if (rc) return rc;
-        if (groups > 1) {
-            S.run_bank = b;
-            S.run_nframes = nframes;
-            S.run_groups = groups;
-            S.run_tile = (uint32_t)(64 * F);
-            SH_HIP(hipEventRecord(S.ev_join, S.stream));    // everything enqueued so far: stream2's first launch waits for it
+    const bool cont = groups > 1 && b->run_active && b->run_nframes == nframes && b->run_groups == groups &&
+                      b->run_tile == (uint32_t)(64 * F) && b->run_next_start == start;
+    // an output buffer another bank still owes a fold to: the order of the two writes must be the callers' -- end every run
+    for (sh_bank* o : live_banks()) {
+        if (o == b) continue;
+        for (int k = 0; k < o->npending; ++k) {
+            const sh::PendingCombine& pc = o->pending[k];
+            if ((o32 && pc.o32 == (void*)o32) || (o64 && pc.o64 == (void*)o64) || (o16 && pc.o16 == (void*)o16) ||
+                (o32 && pc.o16 == (void*)o32) || (o16 && pc.o32 == (void*)o16)) {
+                rc = sh::flush_pending();
+                if (rc) return rc;
+            }
         }
     }
-    const uint32_t n = groups > 1 ? S.run_count : 0;
+    if (!cont) {
+        // this bank's own leftovers are folded now; the other banks' runs go on
+        if (b->npending || b->run_active) {
+            rc = join_aux();
+            if (!rc) rc = fold_bank(b);
+            if (rc) return rc;
+        }
+        if (groups > 1) {
+            b->run_active = true;
+            b->run_nframes = nframes;
+            b->run_groups = groups;
+            b->run_tile = (uint32_t)(64 * F);
+            b->run_count = 0;
+            SH_HIP(hipEventRecord(S.ev_join, S.stream));    // everything enqueued so far: stream2's first launch of the run waits for it
+        }
+    }
+    const uint32_t n = groups > 1 ? b->run_count : 0;
     const bool two_streams = groups > 1 && speculation_enabled() && overlap_enabled();
     const bool use_aux = two_streams && (n & 1);
     hipStream_t st = use_aux ? S.stream2 : S.stream;
@@ -2313,18 +2377,18 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         // split launch: the general kernel's parts follow the lean kernel's, then one flag per group
         const size_t need = split ? 2 * (size_t)groups * nframes * sizeof(double2) + (size_t)groups * sizeof(uint32_t)
                                   : (size_t)groups * nframes * sizeof(double2);
-        if (S.parts_bytes[k] < need) {
-            if (S.parts_buf[k]) {
+        if (b->parts_bytes[k] < need) {
+            if (b->parts_buf[k]) {
                 SH_HIP(hipStreamSynchronize(S.stream));
                 SH_HIP(hipStreamSynchronize(S.stream2));
-                SH_HIP(hipFree(S.parts_buf[k]));
-                S.parts_buf[k] = nullptr;
-                S.parts_bytes[k] = 0;
+                SH_HIP(hipFree(b->parts_buf[k]));
+                b->parts_buf[k] = nullptr;
+                b->parts_bytes[k] = 0;
             }
-            SH_HIP(hipMalloc(&S.parts_buf[k], need));
-            S.parts_bytes[k] = need;
+            SH_HIP(hipMalloc(&b->parts_buf[k], need));
+            b->parts_bytes[k] = need;
         }
-        parts = (double2*)S.parts_buf[k];
+        parts = (double2*)b->parts_buf[k];
     }
     // ... and the general-lists kernel is only launched when the launch CAN hold a general voice
     static int always_general = -1;
@@ -2336,8 +2400,8 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     static int debug = -1;
     if (debug < 0) { const char* e = getenv("SYNTHHIP_DEBUG"); debug = e ? atoi(e) : 0; }
     // the fold this launch takes over: the older of two outstanding ones (launch n - 2's)
-    const bool take_over = S.npending == 2;
-    const sh::PendingCombine prev = take_over ? S.pending[0] : sh::PendingCombine();
+    const bool take_over = b->npending == 2;
+    const sh::PendingCombine prev = take_over ? b->pending[0] : sh::PendingCombine();
     const double2* pv_parts = (take_over && !(debug & 2)) ? (const double2*)prev.parts : nullptr;
     float2* pv32 = take_over ? (float2*)prev.o32 : nullptr;
     double2* pv64 = take_over ? (double2*)prev.o64 : nullptr;
@@ -2406,11 +2470,13 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         S.aux_busy = true;
     }
     if (take_over) {                                        // folded by this launch
-        S.pending[0] = S.pending[1];
-        S.npending = 1;
+        b->pending[0] = b->pending[1];
+        b->npending = 1;
+        S.pending_total -= 1;
     }
     if (groups > 1) {                                       // this launch's partial buses: folded two launches on, or by the next other API call
-        sh::PendingCombine& pc = S.pending[S.npending++];
+        sh::PendingCombine& pc = b->pending[b->npending++];
+        S.pending_total += 1;
         pc.parts = parts;
         pc.groups = groups;
         pc.nframes = nframes;
@@ -2419,8 +2485,8 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         pc.o16 = o16;
         pc.scale = pcm_scale;
         pc.gen_valid = gen_valid;
-        S.run_count = n + 1;
-        S.run_next_start = start + nframes;
+        b->run_count = n + 1;
+        b->run_next_start = start + nframes;
     }
     b->last_target = target;
     if (target >= 0) {

@@ -184,7 +184,7 @@ int sh_shutdown(void) {
     (void)hipStreamSynchronize(s.stream2);
     sh::pool_trim();
     if (s.scratch) (void)hipFree(s.scratch);
-    for (int k = 0; k < 4; ++k) if (s.parts_buf[k]) (void)hipFree(s.parts_buf[k]);
+    sh::free_render_buffers();
     (void)hipEventDestroy(s.ev_join);
     (void)hipEventDestroy(s.ev_aux);
     (void)hipEventDestroy(s.ev_prep);

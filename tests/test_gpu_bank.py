@@ -628,3 +628,50 @@ def test_pcm_blocks_straight_from_the_fold(gpu):
         assert bytes(smp.view_frame_data()) == want[3] and smp.nchannels == 2 and smp.samplewidth == 2
     with pytest.raises(ValueError):
         bank.render_pcm_device(block, 0, pcm=N.DeviceBuffer(16))
+
+
+def test_banks_rendering_turn_by_turn_keep_their_pipelines(gpu):
+    """Each bank owns its run of pipelined renders, its pending folds and its partial-bus ring: three banks rendering turn by
+    turn (a, b, c, a, b, c, ...) stay pipelined -- and every block equals the block rendered alone.  Also: two banks writing
+    the SAME bus buffer in turn (the later write must win), a bank destroyed while the others' runs go on, and
+    sh_bank_launch_stats in the middle."""
+    import ctypes
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    nv, block, nblocks = 384, 6000, 11
+    mk = lambda seed: additive_voices(G, nv, SR, seed=seed, adsr={"sustain": 100.0})
+    banks = [VoiceBank(mk(s)[0], gains=mk(s)[1]) for s in (41, 42, 43)]
+    alone = [[VoiceBank(mk(s)[0], gains=mk(s)[1]).render(block, start=k * block) for k in range(nblocks)] for s in (41, 42, 43)]
+    read = lambda buf: buf.download(np.float32, block * 2).reshape(block, 2)
+    bufs = [[N.DeviceBuffer(block * 8) for _ in range(nblocks)] for _ in banks]
+    for k in range(nblocks):
+        for i, bank in enumerate(banks):
+            bank.render_device(block, k * block, bus_f32=bufs[i][k])
+        if k == 5:
+            nf, ng = ctypes.c_uint32(), ctypes.c_uint32()
+            N.check(N.lib().sh_bank_launch_stats(banks[1]._bank.handle, ctypes.byref(nf), ctypes.byref(ng)))   # ends the runs
+            assert nf.value + ng.value == nv
+    for i in range(3):
+        for k in range(nblocks):
+            assert np.array_equal(read(bufs[i][k]), alone[i][k]), (i, k)
+    # one bus buffer written by two banks in turn: what it holds in the end is the last render into it
+    shared = N.DeviceBuffer(block * 8)
+    for k in range(4):
+        banks[0].render_device(block, k * block, bus_f32=shared)
+        banks[1].render_device(block, k * block, bus_f32=shared)
+    assert np.array_equal(read(shared), alone[1][3])
+    for k in range(4):
+        banks[1].render_device(block, k * block, bus_f32=shared)
+        banks[0].render_device(block, k * block, bus_f32=shared)
+    assert np.array_equal(read(shared), alone[0][3])
+    # a bank goes away in the middle of everybody's runs
+    outs = [N.DeviceBuffer(block * 8) for _ in range(6)]
+    for k in range(3):
+        banks[0].render_device(block, k * block, bus_f32=outs[k])
+        banks[2].render_device(block, k * block, bus_f32=outs[3 + k])
+    banks[2]._bank.free()
+    banks[0].render_device(block, 3 * block, bus_f32=shared)
+    assert np.array_equal(read(shared), alone[0][3])
+    for k in range(3):
+        assert np.array_equal(read(outs[k]), alone[0][k]) and np.array_equal(read(outs[3 + k]), alone[2][k]), k
