@@ -3,7 +3,7 @@ synthesizer_amd -- synthplayer's oscillator-bank + sample-mixing hot path on AMD
 
 Host code is Python and keeps the reference's class API (oscillators, Sample.mix/resample, the mixer
 sum bus); the arithmetic runs in hand-written HIP kernels reached through the C ABI of
-libsynthhip.so (include/synthhip.h).  No PyTorch, no CPU fallback.
+libsynthhip.so (include/synthhip.h).  No ML framework anywhere in the package, no CPU fallback.
 
     from synthesizer_amd.oscillators import Sine, Harmonics, EnvelopeFilter
     from synthesizer_amd.sample import Sample

@@ -10,8 +10,8 @@ by BASELINE.json, not a translation of anything upstream.
 Rendezvous: rank 0 creates the ``ncclUniqueId`` and broadcasts its 128 bytes -- by default through a
 tiny TCP exchange on MASTER_ADDR:MASTER_PORT+1 (no dependency beyond the standard library); a launcher
 that already has a channel passes its own ``broadcast(payload, rank, world, nbytes) -> bytes`` callable to
-``init`` (bench.py under torchrun hands over its gloo process group that way).  Nothing here imports
-PyTorch.
+``init`` (bench.py, started by the distributed launcher, hands over its gloo process group that way).  This package
+imports no ML framework.
 """
 from __future__ import annotations
 
@@ -98,7 +98,7 @@ def init(rank: int, world: int, broadcast: Optional[Callable[[Optional[bytes], i
 
 
 def init_from_env() -> Tuple[int, int]:
-    """RANK / WORLD_SIZE / LOCAL_RANK as set by torchrun; selects GPU LOCAL_RANK."""
+    """RANK / WORLD_SIZE / LOCAL_RANK as the launcher sets them (one process per GPU); selects GPU LOCAL_RANK."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))

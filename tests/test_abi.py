@@ -78,6 +78,13 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert L.sh_resample_out_frames(8, 96000, 44100) == 4 and L.sh_resample_out_frames(0, 3, 7) == 0
 
 
+def test_product_has_no_ml_framework():
+    """north_star: 'no PyTorch'.  Not a mention of it anywhere under synthesizer_amd/ (sources; bench.py owns the launcher plumbing)."""
+    for f in (ROOT / "synthesizer_amd").rglob("*"):
+        if f.suffix in (".py", ".hip", ".hpp", ".h"):
+            assert "torch" not in f.read_text().lower(), f
+
+
 def test_product_never_imports_the_oracle():
     for py in (ROOT / "synthesizer_amd").rglob("*.py"):
         text = py.read_text()
