@@ -56,10 +56,22 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + ['-DSH_SOURCE_HASH="%s"' % source_hash()] + [str(CSRC / s) for s in SOURCES] + ["-o", str(LIB), "-ldl"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    # one builder at a time: the ranks of a multi-GPU job all import the package at once, and a stale library must be compiled
+    # by ONE of them (the others wait on the lock and then find it up to date); the result is moved into place atomically
+    import fcntl
+    with open(HERE / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or needs_build():
+            tmp = LIB.with_suffix(".so.tmp%d" % os.getpid())
+            cmd = [HIPCC] + FLAGS + ['-DSH_SOURCE_HASH="%s"' % source_hash()] + [str(CSRC / s) for s in SOURCES] + ["-o", str(tmp), "-ldl"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, LIB)
+            finally:
+                if tmp.exists():
+                    tmp.unlink()
     return LIB
 
 
