@@ -249,6 +249,44 @@ def test_quantise_bit_exact_and_overflow(gpu):
     assert list(Sample.from_osc_block(np.array([0.5], dtype=np.float32), SR).get_frame_array()) == [16383]
 
 
+def test_quantise_f64_offsets_tails_and_overflow_position(gpu):
+    """sh_quantize_f64 (the WaveSynth.to_sample route): the 8-per-thread kernel, its scalar tail, ranges that start off a
+    16-byte boundary, and an out-of-range value anywhere in the range -> OverflowError."""
+    from synthesizer_amd import _native as N
+    L = N.lib()
+    rng = np.random.default_rng(226)
+    n = 70001
+    vals = rng.uniform(-1.0, 1.0, n)
+    vals[:8] = [1.0, -1.0, 0.0, -0.0, 1234.0 / 32767.0, -1234.0 / 32767.0, 0.9999999999, -0.9999999999]
+    src = N.DeviceBuffer.from_array(vals)
+    dst = N.DeviceBuffer(2 * (n + 16))
+    for in_off, out_off, cnt in ((0, 0, n), (0, 0, 4096), (1, 0, 5000), (0, 3, 5000), (2, 8, 8191), (5, 1, 7), (0, 0, 8), (16, 16, 64)):
+        N.check(L.sh_quantize_f64(src.handle, in_off, cnt, 32767.0, 2, dst.handle, out_off))
+        got = dst.download(np.int16, cnt, 2 * out_off)
+        assert list(got) == O.quantise(vals[in_off:in_off + cnt]), (in_off, out_off, cnt)
+    for pos in (0, 7, 8, 4095, 65535, n - 1):
+        bad = vals.copy()
+        bad[pos] = 1.0001 if pos % 2 else float("nan")
+        b = N.DeviceBuffer.from_array(bad)
+        assert L.sh_quantize_f64(b.handle, 0, n, 32767.0, 2, dst.handle, 0) == N.SH_ERR_OVERFLOW, pos
+    N.check(L.sh_quantize_f64(src.handle, 0, 16, 32767.0, 2, dst.handle, 0))       # the flag does not stick
+    # the float32 entry points through the same cases (vectors of four samples, 8-byte stores)
+    v32 = vals.astype(np.float32)
+    src32 = N.DeviceBuffer.from_array(v32)
+    for in_off, out_off, cnt in ((0, 0, n), (0, 0, 2048), (1, 0, 5000), (0, 3, 5000), (4, 4, 8191), (4, 2, 4099), (5, 1, 7), (0, 0, 3)):
+        N.check(L.sh_quantize_f32(src32.handle, in_off, cnt, 32767.0, 2, dst.handle, out_off))
+        assert list(dst.download(np.int16, cnt, 2 * out_off)) == O.quantise([float(x) for x in v32[in_off:in_off + cnt]]), (in_off, out_off, cnt)
+    loud = (v32 * np.float32(1.7)).astype(np.float32)
+    loud[[3, 600, n - 1]] = [np.float32("nan"), np.float32(5.0), np.float32(-5.0)]
+    b = N.DeviceBuffer.from_array(loud)
+    for cnt in (n, 1027, 2):
+        N.check(L.sh_quantize_clip_f32(b.handle, cnt, 32767.0, dst.handle))
+        p = 32767.0 * loud[:cnt].astype(np.float64)
+        want = np.where(np.isnan(p), 0.0, np.clip(np.trunc(p), -32768.0, 32767.0)).astype(np.int16)
+        assert np.array_equal(dst.download(np.int16, cnt), want), cnt
+    assert L.sh_quantize_f32(b.handle, 0, n, 32767.0, 2, dst.handle, 0) == N.SH_ERR_OVERFLOW
+
+
 def test_triangle_and_band_limited_harmonics(gpu):
     """Triangle, SquareH, SawtoothH."""
     from synthesizer_amd import oscillators as G
