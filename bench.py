@@ -529,7 +529,7 @@ def main() -> int:
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mix_bytes / (mix_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                              "traffic": tm["hbm_bytes"] if tm else None, "avg_launch_ms": mix_ms, "bytes_per_frame": 4 * nv + 8,
                              "algorithmic_bytes": mix_bytes},
-            "roofline_generate": {"kernel": "k_generate_lists<4>", "bound": "hbm", "achieved": gen_bytes / (gen_ms / 1e3) / 1e9,
+            "roofline_generate": {"kernel": "k_generate_lean_harm<16> (+ k_prepare_segments; k_generate_lists<4, false> where a segment holds general or silent voices)", "bound": "hbm", "achieved": gen_bytes / (gen_ms / 1e3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gen_bytes / (gen_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                                   "traffic": tg["hbm_bytes"] if tg else None, "avg_launch_ms": gen_ms, "bytes_per_voice_sample": 4,
                                   "algorithmic_bytes": gen_bytes},
