@@ -1,0 +1,123 @@
+"""Buffers beyond 2^32 bytes and 2^31 samples: the 64-bit index arithmetic of the PCM kernels (audioop.add, audioop.max / rms,
+audioop.ratecv for 16-bit PCM and for the float32 shape of BASELINE configs[4]) at sizes no test with a CPU-side expectation
+of the whole result could hold.  Inputs are one tile of noise repeated with an ODD period (an index that wrapped at 2^32 would
+land on other data), results are checked in windows -- at the head, across the 2^31-sample and 2^32-byte marks, at the tail --
+against CPython's audioop / the oracle's closed form on just the input those windows read."""
+import audioop
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fill(buf, tile: np.ndarray, total_elems: int) -> None:
+    """buf[e] = tile[e % len(tile)] for e < total_elems (uploads of at most one tile)."""
+    n, size = len(tile), tile.itemsize
+    for e0 in range(0, total_elems, n):
+        m = min(n, total_elems - e0)
+        buf.upload(tile[:m], e0 * size)
+
+
+def test_pcm_add_and_stats_beyond_4_gib(gpu):
+    from synthesizer_amd import _native as N
+    L = N.lib()
+    n = (1 << 31) + (1 << 29) + 12345                       # 2.68 G samples of int16: 5.4 GB per operand
+    rng = np.random.default_rng(2026)
+    ta = rng.integers(-32768, 32768, (1 << 24) - 3, dtype=np.int64).astype(np.int16)
+    tb = rng.integers(-32768, 32768, (1 << 24) - 13, dtype=np.int64).astype(np.int16)
+    a, b, o = N.DeviceBuffer(2 * n), N.DeviceBuffer(2 * n), N.DeviceBuffer(2 * n)
+    _fill(a, ta, n)
+    _fill(b, tb, n)
+    N.check(L.sh_pcm_add(a.handle, 0, b.handle, 0, 2 * n, 2, o.handle, 0))
+    w = 1 << 16
+    for first in (0, (1 << 31) - w // 2, (1 << 32) // 2 - w // 2 + 1, (1 << 31) + (1 << 28) + 7, n - w):
+        got = o.download(np.int16, w, 2 * first)
+        idx = np.arange(first, first + w)
+        want = np.frombuffer(audioop.add(ta[idx % len(ta)].tobytes(), tb[idx % len(tb)].tobytes(), 2), dtype=np.int16)
+        assert np.array_equal(got, want), first
+    # in place at an offset past 4 GiB (Sample.mix_at): out = a, both ranges start beyond 2^32 bytes
+    off = (1 << 32) + 2 * 4097
+    cnt = 2 * n - off
+    N.check(L.sh_pcm_add(a.handle, off, b.handle, off, cnt, 2, a.handle, off))
+    first = off // 2
+    for lo in (first, n - w):
+        got = a.download(np.int16, w, 2 * lo)
+        idx = np.arange(lo, lo + w)
+        want = np.frombuffer(audioop.add(ta[idx % len(ta)].tobytes(), tb[idx % len(tb)].tobytes(), 2), dtype=np.int16)
+        assert np.array_equal(got, want), lo
+    assert np.array_equal(a.download(np.int16, w, 2 * (first - w)), ta[np.arange(first - w, first) % len(ta)])   # untouched below
+    # audioop.max and the sum of squares behind audioop.rms over all of b: whole tiles + the ragged rest, exactly
+    mx, ss = N.C.c_uint32(0), N.C.c_double(0.0)
+    N.check(L.sh_pcm_stats(b.handle, 2 * n, 2, N.C.byref(mx), N.C.byref(ss)))
+    reps, rest = divmod(n, len(tb))
+    sq = tb.astype(np.int64) ** 2
+    want_ss = reps * int(sq.sum()) + int(sq[:rest].sum())
+    assert mx.value == int(np.abs(tb.astype(np.int64)).max())
+    assert abs(ss.value - want_ss) <= want_ss * 2e-16 * 4
+    for x in (a, b, o):
+        x.free()
+
+
+def test_resample_int16_mono_beyond_4_gib(gpu):
+    """44.1 kHz -> 48 kHz, 2.2 G frames of 16-bit mono (4.4 GB in, 4.8 GB out).  An output frame m = 160 k sits exactly on
+    input frame 147 k, so audioop.ratecv started on the input from there reproduces the outputs from m on."""
+    from synthesizer_amd import _native as N
+    L = N.lib()
+    inrate, outrate = 44100, 48000
+    in_frames = (1 << 31) + (1 << 26) + 999
+    tile = np.random.default_rng(7).integers(-32768, 32768, (1 << 24) - 5, dtype=np.int64).astype(np.int16)
+    src = N.DeviceBuffer(2 * in_frames)
+    _fill(src, tile, in_frames)
+    nout = L.sh_resample_out_frames(in_frames, inrate, outrate)
+    dst = N.DeviceBuffer(2 * nout)
+    made = N.C.c_size_t(0)
+    N.check(L.sh_resample(src.handle, in_frames, 1, 2, 0, inrate, outrate, dst.handle, N.C.byref(made)))
+    assert made.value == nout
+    w = 8000
+    marks = [0, ((1 << 31) // 160) * 160 - 160 * 20, ((1 << 31) * 160 // 147 // 160) * 160 - 160 * 10, ((nout - w - 200) // 160) * 160]
+    for m in marks:
+        q = m // 160 * 147                                   # the input frame output m coincides with
+        need = w * 147 // 160 + 8
+        idx = np.arange(q, min(q + need, in_frames))
+        want = np.frombuffer(audioop.ratecv(tile[idx % len(tile)].tobytes(), 2, 1, inrate, outrate, None)[0], dtype=np.int16)
+        cnt = min(w, len(want), nout - m)
+        got = dst.download(np.int16, cnt, 2 * m)
+        assert np.array_equal(got, want[:cnt]), m
+    # the very last output frames
+    tail = dst.download(np.int16, 64, 2 * (nout - 64))
+    m = ((nout - 64) // 160) * 160
+    q = m // 160 * 147
+    idx = np.arange(q, in_frames)
+    want = np.frombuffer(audioop.ratecv(tile[idx % len(tile)].tobytes(), 2, 1, inrate, outrate, None)[0], dtype=np.int16)
+    assert len(want) == nout - m and np.array_equal(tail, want[-64:])
+    src.free()
+    dst.free()
+
+
+def test_resample_float32_8ch_beyond_4_gib(gpu):
+    """The shape of BASELINE configs[4] at 2.4 times its length: 8 channels x 1450 s x 96 kHz float32 = 4.45 GB -> 44.1 kHz."""
+    from oracle import pcm_oracle as P
+    from synthesizer_amd import _native as N
+    L = N.lib()
+    nch, inrate, outrate = 8, 96000, 44100
+    in_frames = 96000 * 1450 + 77
+    assert in_frames * nch * 4 > (1 << 32)
+    tile_frames = (1 << 21) - 3
+    tile = np.random.default_rng(56).uniform(-1, 1, (tile_frames, nch)).astype(np.float32)
+    src = N.DeviceBuffer(in_frames * nch * 4)
+    for f0 in range(0, in_frames, tile_frames):
+        k = min(tile_frames, in_frames - f0)
+        src.upload(tile[:k].reshape(-1), f0 * nch * 4)
+    nout = L.sh_resample_out_frames(in_frames, inrate, outrate)
+    assert nout == P.ratecv_out_frames(in_frames, inrate, outrate)
+    dst = N.DeviceBuffer(nout * nch * 4)
+    N.check(L.sh_resample(src.handle, in_frames, nch, 4, 1, inrate, outrate, dst.handle, None))
+    get = lambda idx: tile[idx % tile_frames]
+    w = 4096
+    in_mark = (1 << 32) // (nch * 4)                          # the input frame at byte 2^32
+    for first in (0, in_mark * outrate // inrate - w // 2, nout // 2 + 3, nout - w):
+        got = dst.download(np.float32, w * nch, first * nch * 4).reshape(w, nch)
+        assert np.array_equal(got, P.ratecv_f32_window(get, inrate, outrate, first, w)), first
+    src.free()
+    dst.free()
