@@ -211,7 +211,7 @@ int sh_ew_f64(int op, const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_o
 int sh_scan_f64(const sh_buf* x, uint32_t n, double carry_in, sh_buf* out, double* carry_out);
 
 /* ---- voice bank rendering: N voices -> stereo bus (the "Mixer sum bus" over oscillator voices) */
-/* materialise: voices_out[v*stride + i] = voice v at frame start+i (float32, voice-major) */
+/* materialise: voices_out[v*stride + i] = voice v at frame start+i (float32, voice-major); nframes <= 2^32 - 65536 */
 int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voices_out, size_t stride);
 /* fused generate-and-mix: bus_f32[i] = (sum_v gl_v x_v[i], sum_v gr_v x_v[i]), float32 x2 interleaved.
  * bus_f64 (optional) receives the float64 partial bus (frames x 2) used for the multi-GPU reduce.
@@ -224,7 +224,10 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
  * not sh_buf_alloc) ends the run first: it joins the streams and folds what is outstanding -- so such code must call
  * sh_sync() (or any other entry point) before touching the buffers.  Everything inside the library sees completed
  * buses.  To keep a run going while consuming its output, render into a ring of bus buffers and read a buffer only
- * after the run has been ended. */
+ * after the run has been ended.
+ * Any nframes is accepted: renders beyond 2^22 frames are carried out as a run of launches of 2^22 frames each into
+ * consecutive parts of the buffers (a launch's grid holds fewer than 2^32 work-items per dimension, and the partial
+ * buses of the voice groups are sized per launch). */
 int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64);
 /* The same render delivered as saturated int16 stereo PCM (frames x 2, interleaved): sample = trunc(scale * bus) of the
  * float32 bus, clamped to the int16 range -- exactly what sh_quantize_clip_f32 makes of sh_bank_render's bus_f32 -- but

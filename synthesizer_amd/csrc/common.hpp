@@ -106,6 +106,20 @@ int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* ou
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// A dispatch counts the WORK-ITEMS of each grid dimension in 32 bits: a launch with grid.x * block.x >= 2^32 wraps silently
+// (a kernel over 2^32 samples runs a handful of blocks and reports success -- tests/test_gpu_huge.py).  One-dimensional
+// launches of unbounded length therefore fold their blocks into two dimensions (the kernels number them with block_id() and
+// already guard against blocks beyond the data), and launches whose x dimension is a tile count are cut into several by
+// their entry points.
+constexpr unsigned GRID_X_MAX = 1u << 21;            // x at most 1024 threads: 2^31 work-items
+inline dim3 grid1d(size_t n, size_t per_block) {
+    size_t nb = (n + per_block - 1) / per_block;
+    if (nb == 0) nb = 1;
+    if (nb <= GRID_X_MAX) return dim3((unsigned)nb);
+    return dim3(GRID_X_MAX, (unsigned)((nb + GRID_X_MAX - 1) / GRID_X_MAX));
+}
+__device__ __forceinline__ size_t block_id() { return (size_t)blockIdx.y * gridDim.x + blockIdx.x; }
+
 // ---- 24-bit PCM (audioop width 3) -----------------------------------------------------------------------------------
 // audioop reads a 3-byte sample as GETINT24 (sign-extended) and, wherever it works through GETSAMPLE32 (ratecv, lin2lin) or
 // scales linearly (mul, tomono, tostereo, add, bias), the result for width 3 equals the width-4 operation on value << 8 taken

@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_bus_combine(const double2* __restrict__
                                                      float2* __restrict__ bus32, double2* __restrict__ bus64,
                                                      uint32_t* __restrict__ pcm16, double pcm_scale,
                                                      const uint32_t* __restrict__ gen_valid) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= nframes) return;
     double2 s = parts[i];
     for (uint32_t g = 1; g < ngroups; ++g) {
@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_bus_direct(const float* __re
 
 __global__ void k_bus_sum(const float2* __restrict__ parts, uint32_t ngroups, size_t group_stride,
                           uint32_t nframes, float2* __restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = sh::block_id() * blockDim.x + threadIdx.x;
     if (i >= nframes) return;
     float2 s = parts[i];
     for (uint32_t g = 1; g < ngroups; ++g) {
@@ -1603,14 +1603,14 @@ __global__ void k_bus_sum(const float2* __restrict__ parts, uint32_t ngroups, si
 }
 
 __global__ void k_bus_finalize(const double* __restrict__ in, size_t n, float* __restrict__ out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = sh::block_id() * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (float)in[i];
 }
 
 // ---- elementwise filters over float64 blocks ----------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ew_f64(int op, const double* a, const double* b, size_t n, double p0, double p1,
                                                 double* out64, float* out32) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= n) return;
     double v;
     switch (op) {
@@ -1875,7 +1875,7 @@ static int fold_bank(sh_bank* b) {
     S.pending_total -= n;
     for (int k = 0; k < n; ++k) {
         const sh::PendingCombine& pc = b->pending[k];
-        hipLaunchKernelGGL(k_bus_combine, dim3(sh::div_up(pc.nframes, 256)), dim3(256), 0, S.stream,
+        hipLaunchKernelGGL(k_bus_combine, sh::grid1d(pc.nframes, 256), dim3(256), 0, S.stream,
                            (const double2*)pc.parts, pc.groups, pc.nframes, (float2*)pc.o32, (double2*)pc.o64,
                            (uint32_t*)pc.o16, pc.scale, (const uint32_t*)pc.gen_valid);
         SH_CHECK_LAUNCH("k_bus_combine");
@@ -1911,7 +1911,7 @@ void free_render_buffers() {
 
 int bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out) {
     if (!nvalues) return SH_OK;
-    hipLaunchKernelGGL(k_bus_finalize, dim3(div_up(nvalues, 256)), dim3(256), 0, st, in, nvalues, out);
+    hipLaunchKernelGGL(k_bus_finalize, sh::grid1d(nvalues, 256), dim3(256), 0, st, in, nvalues, out);
     SH_CHECK_LAUNCH("k_bus_finalize");
     return SH_OK;
 }
@@ -2089,7 +2089,7 @@ static const shm::sc_pair* trig_table() { return (const shm::sc_pair*)sh::state(
 static int prepare(sh_bank* b, uint32_t first, uint32_t count, uint64_t start, uint32_t nframes) {
     // single-voice path (sh_osc_render): records go to slot 0 of the current set; any speculation is void
     b->void_specs();
-    hipLaunchKernelGGL(k_prepare, dim3(sh::div_up(count, 64)), dim3(64), 0, sh::state().stream,
+    hipLaunchKernelGGL(k_prepare, sh::grid1d(count, 64), dim3(64), 0, sh::state().stream,
                        ptrs(b), first, count, start, nframes, b->d_launch, b->d_launch_fm);
     SH_CHECK_LAUNCH("k_prepare");
     return SH_OK;
@@ -2121,7 +2121,7 @@ static int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStre
             if (!(in_run && (c == b->cur || c == b->last_target))) k = c;
     }
     b->spec[k].valid = false;
-    hipLaunchKernelGGL(k_prepare_chunks, dim3(sh::div_up(b->nvoices, 64)), dim3(64), 0, S.stream, ptrs(b), launch_set(b, k),
+    hipLaunchKernelGGL(k_prepare_chunks, sh::grid1d(b->nvoices, 64), dim3(64), 0, S.stream, ptrs(b), launch_set(b, k),
                        b->nvoices, start, nframes);
     SH_CHECK_LAUNCH("k_prepare_chunks");
     if (launch_stream != S.stream) {
@@ -2152,6 +2152,7 @@ int sh_osc_render(sh_bank* bank, uint32_t voice, const sh_buf* fm_cumsum, const 
     if (!bank || voice >= bank->nvoices) return sh::set_error(SH_ERR_INVALID, "sh_osc_render: bad bank/voice");
     if (!out_host && !out_f32 && !out_f64) return sh::set_error(SH_ERR_INVALID, "sh_osc_render: no destination");
     if (n == 0) return SH_OK;
+    if (n > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_osc_render: at most 2^32 - 65536 samples per call");
     const sh_voice& v = bank->h_voices[voice];
     if (v.fm_mode == SH_FM_BUFFER && (!fm_cumsum || fm_cumsum->bytes < (size_t)n * 8))
         return sh::set_error(SH_ERR_INVALID, "sh_osc_render: SH_FM_BUFFER voice needs fm_cumsum with >= n doubles");
@@ -2193,6 +2194,7 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
     SH_REQUIRE_INIT();
     if (!b || !voices_out) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: NULL argument");
     if (nframes == 0) return SH_OK;
+    if (nframes > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: at most 2^32 - 65536 frames per call");
     if (stride < nframes) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: stride < nframes");
     if (voices_out->bytes / 4 < (size_t)(b->nvoices - 1) * stride + nframes)
         return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: output buffer too small");
@@ -2497,15 +2499,41 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     return SH_OK;
 }
 
+// Renders of any length: the launch's x dimension is a tile count (tiles x threads per workgroup must stay below 2^32 work-items,
+// which the shapes of small banks reach first: sixteen waves on 128 frames), and a bank with several voice groups keeps
+// 32 bytes of partial buses per frame and group.  Long renders are therefore a run of launches of RENDER_MAX_FRAMES (87 s
+// at 48 kHz; consecutive blocks of one shape: the two-stream pipeline applies) into views of the caller's buffers.
+constexpr uint32_t RENDER_MAX_FRAMES = 1u << 22;
+static int bank_render_any(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64, sh_buf* pcm_i16, double pcm_scale) {
+    if (nframes <= RENDER_MAX_FRAMES) return bank_render(b, start, nframes, bus_f32, bus_f64, pcm_i16, pcm_scale);
+    SH_API_LOCK();                                           // (recursive) one call: nothing else gets between its launches
+    if (bus_f32 && bus_f32->bytes < (size_t)nframes * 8) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f32 too small");
+    if (bus_f64 && bus_f64->bytes < (size_t)nframes * 16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f64 too small");
+    if (pcm_i16 && pcm_i16->bytes < (size_t)nframes * 4) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_pcm: PCM buffer too small");
+    const double* rows = b ? b->launch_rows : nullptr;
+    int rc = SH_OK;
+    for (uint64_t off = 0; off < nframes && !rc; off += RENDER_MAX_FRAMES) {
+        const uint32_t n = nframes - off < RENDER_MAX_FRAMES ? (uint32_t)(nframes - off) : RENDER_MAX_FRAMES;
+        sh_buf v32{nullptr, 0, false, 0}, v64{nullptr, 0, false, 0}, v16{nullptr, 0, false, 0};
+        if (bus_f32) { v32.ptr = (char*)bus_f32->ptr + off * 8; v32.bytes = bus_f32->bytes - off * 8; }
+        if (bus_f64) { v64.ptr = (char*)bus_f64->ptr + off * 16; v64.bytes = bus_f64->bytes - off * 16; }
+        if (pcm_i16) { v16.ptr = (char*)pcm_i16->ptr + off * 4; v16.bytes = pcm_i16->bytes - off * 4; }
+        if (rows) b->launch_rows = rows + off;               // launch-relative rows (sh_bank_render_rows)
+        rc = bank_render(b, start + off, n, bus_f32 ? &v32 : nullptr, bus_f64 ? &v64 : nullptr, pcm_i16 ? &v16 : nullptr, pcm_scale);
+    }
+    if (rows) b->launch_rows = rows;
+    return rc;
+}
+
 extern "C" {
 
 int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64) {
-    return bank_render(b, start, nframes, bus_f32, bus_f64, nullptr, 0.0);
+    return bank_render_any(b, start, nframes, bus_f32, bus_f64, nullptr, 0.0);
 }
 
 int sh_bank_render_pcm(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* pcm_i16) {
     if (!pcm_i16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_pcm: NULL PCM buffer");
-    return bank_render(b, start, nframes, nullptr, nullptr, pcm_i16, scale);
+    return bank_render_any(b, start, nframes, nullptr, nullptr, pcm_i16, scale);
 }
 
 int sh_bank_set_rows(sh_bank* b, const int32_t* fm_row, const int32_t* pwm_row) {
@@ -2546,7 +2574,7 @@ int sh_bank_render_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_b
         b->launch_rows = (const double*)rows_f64->ptr;
         b->launch_row_stride = row_stride;
     }
-    int rc = bank_render(b, start, nframes, bus_f32, bus_f64, nullptr, 0.0);
+    int rc = bank_render_any(b, start, nframes, bus_f32, bus_f64, nullptr, 0.0);
     b->launch_rows = nullptr;
     b->launch_row_stride = 0;
     return rc;
@@ -2560,6 +2588,17 @@ int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32
     if (stride < nframes || voices->bytes / 4 < (size_t)(nvoices - 1) * stride + nframes)
         return sh::set_error(SH_ERR_INVALID, "sh_mix_bus_f32: voice buffer too small for %u x %u (stride %zu)", nvoices, nframes, stride);
     if (bus_f32->bytes < (size_t)nframes * 8) return sh::set_error(SH_ERR_INVALID, "sh_mix_bus_f32: bus too small");
+    constexpr uint32_t MIX_MAX_FRAMES = 1u << 24;            // per launch: tiles x 512 threads must stay below 2^32 work-items
+    if (nframes > MIX_MAX_FRAMES) {
+        for (uint64_t off = 0; off < nframes; off += MIX_MAX_FRAMES) {
+            const uint32_t n = nframes - off < MIX_MAX_FRAMES ? (uint32_t)(nframes - off) : MIX_MAX_FRAMES;
+            sh_buf v{(char*)voices->ptr + off * 4, voices->bytes - off * 4, false, 0};
+            sh_buf o{(char*)bus_f32->ptr + off * 8, bus_f32->bytes - off * 8, false, 0};
+            const int rc = sh_mix_bus_f32(&v, nvoices, stride, n, gains_lr, &o);
+            if (rc) return rc;
+        }
+        return SH_OK;
+    }
     constexpr int W = 8;
     const uint32_t tiles = sh::div_up(nframes, 256);
     // enough workgroups to cover 256 CUs several times over: split the voices into groups when the
@@ -2573,7 +2612,7 @@ int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32
     if (rc) return rc;
     hipStream_t st = sh::state().stream;
     if (tiles >= 1536 && (stride & 3) == 0 && ((uintptr_t)voices->ptr & 15) == 0 && ((uintptr_t)bus_f32->ptr & 15) == 0) {
-        hipLaunchKernelGGL((k_mix_bus_direct<8, 4>), dim3(sh::div_up(nframes, 256 * 8)), dim3(8 * 64), 0, st,
+        hipLaunchKernelGGL((k_mix_bus_direct<8, 4>), sh::grid1d(nframes, 256 * 8), dim3(8 * 64), 0, st,
                            (const float*)voices->ptr, nvoices, stride, nframes, (const float2*)gains_lr->ptr, (float2*)bus_f32->ptr);
         SH_CHECK_LAUNCH("k_mix_bus_direct");
         return SH_OK;
@@ -2585,7 +2624,7 @@ int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32
                        dst, (size_t)nframes);
     SH_CHECK_LAUNCH("k_mix_bus_f32");
     if (groups > 1) {
-        hipLaunchKernelGGL(k_bus_sum, dim3(sh::div_up(nframes, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_bus_sum, sh::grid1d(nframes, 256), dim3(256), 0, st,
                            (const float2*)parts, groups, (size_t)nframes, nframes, (float2*)bus_f32->ptr);
         SH_CHECK_LAUNCH("k_bus_sum");
     }
@@ -2617,7 +2656,7 @@ int sh_ew_f64(int op, const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_o
         d32 = (float*)sh::state().scratch;
     }
     hipStream_t st = sh::state().stream;
-    hipLaunchKernelGGL(k_ew_f64, dim3(sh::div_up(n, 256)), dim3(256), 0, st, op,
+    hipLaunchKernelGGL(k_ew_f64, sh::grid1d(n, 256), dim3(256), 0, st, op,
                        need_a ? (const double*)a->ptr + a_off : nullptr, need_b ? (const double*)b->ptr + b_off : nullptr,
                        n, p0, p1, out_f64 ? (double*)out_f64->ptr + out64_off : nullptr, d32);
     SH_CHECK_LAUNCH("k_ew_f64");
@@ -2654,6 +2693,7 @@ int sh_bank_generate_f64(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* r
     SH_REQUIRE_INIT();
     if (!b || !rows_out) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_f64: NULL argument");
     if (nframes == 0) return SH_OK;
+    if (nframes > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_f64: at most 2^32 - 65536 frames per call");
     if (row_stride < nframes || rows_out->bytes / 8 < (row0 + b->nvoices - 1) * row_stride + nframes)
         return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_f64: rows buffer too small");
     int rc = bank_check_plain(b, "sh_bank_generate_f64");

@@ -22,7 +22,7 @@ template <typename OutT, typename InT = float>
 __global__ __launch_bounds__(256) void k_quantize(const InT* __restrict__ in, size_t n, double scale,
                                                   double lo, double hi, OutT* __restrict__ out,
                                                   int* __restrict__ flag, int clip) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= n) return;
     double v = scale * (double)in[i];          // float64 product, like the Python expression
     double t = trunc(v);
@@ -56,7 +56,7 @@ __device__ __forceinline__ short quantize16(double p, bool& bad) {
 typedef float float4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_quantize_f32_i16_vec(const float4v* __restrict__ in, size_t nvec, double scale,
                                                               short4v* __restrict__ out, int* __restrict__ flag, int clip) {
-    const size_t base = (size_t)blockIdx.x * 512 + threadIdx.x;
+    const size_t base = sh::block_id() * 512 + threadIdx.x;
     float4v v[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) if (base + u * 256 < nvec) v[u] = __builtin_nontemporal_load(in + base + u * 256);
@@ -77,7 +77,7 @@ typedef double double2v __attribute__((ext_vector_type(2)));
 typedef short short2v __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_quantize_f64_i16_vec(const double2v* __restrict__ in, size_t nvec, double scale,
                                                               short2v* __restrict__ out, int* __restrict__ flag) {
-    const size_t base = (size_t)blockIdx.x * 512 + threadIdx.x;
+    const size_t base = sh::block_id() * 512 + threadIdx.x;
     double2v v[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) if (base + u * 256 < nvec) v[u] = __builtin_nontemporal_load(in + base + u * 256);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_quantize_f64_i16_vec(const double2v* __
 // ---- audioop.add (no __restrict__: Sample.mix_at adds in place) ---------------------------------
 __global__ __launch_bounds__(256) void k_add_i16_vec(const short8v* a, const short8v* b,
                                                      short8v* o, size_t nvec) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= nvec) return;
     o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
 }
@@ -104,21 +104,21 @@ __global__ __launch_bounds__(256) void k_add_i16_vec(const short8v* a, const sho
 template <typename T>
 __global__ __launch_bounds__(256) void k_add_scalar(const T* a, const T* b,
                                                     T* o, size_t n) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= n) return;
     o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
 }
 
 __global__ __launch_bounds__(256) void k_add_i32_vec(const int4v* a, const int4v* b,
                                                      int4v* o, size_t nvec) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= nvec) return;
     o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
 }
 
 __global__ __launch_bounds__(256) void k_add_i8_vec(const char16v* a, const char16v* b,
                                                     char16v* o, size_t nvec) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= nvec) return;
     o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
 }
@@ -755,15 +755,15 @@ int sh_quantize_f32(const sh_buf* in_f32, size_t in_off, size_t n, double scale,
     if (!n) return SH_OK;
     const double lo = -ldexp(1.0, 8 * width - 1), hi = ldexp(1.0, 8 * width - 1) - 1.0;
     const float* in = (const float*)in_f32->ptr + in_off;
-    dim3 grid(sh::div_up(n, 256));
+    const dim3 grid = sh::grid1d(n, 256);
     hipStream_t st = sh::state().stream;
     int* flag = sh::state().flag;
     if (width == 2) {
         short* o = (short*)out_pcm->ptr + out_off;
         const bool aligned = ((uintptr_t)in & 15) == 0 && ((uintptr_t)o & 7) == 0;
         const size_t nvec = aligned ? n / 4 : 0, done = nvec * 4;
-        if (nvec) hipLaunchKernelGGL(k_quantize_f32_i16_vec, dim3(sh::div_up(nvec, 512)), dim3(256), 0, st, (const float4v*)in, nvec, scale, (short4v*)o, flag, 0);
-        if (n > done) hipLaunchKernelGGL(k_quantize<short>, dim3(sh::div_up(n - done, 256)), dim3(256), 0, st, in + done, n - done, scale, lo, hi, o + done, flag, 0);
+        if (nvec) hipLaunchKernelGGL(k_quantize_f32_i16_vec, sh::grid1d(nvec, 512), dim3(256), 0, st, (const float4v*)in, nvec, scale, (short4v*)o, flag, 0);
+        if (n > done) hipLaunchKernelGGL(k_quantize<short>, sh::grid1d(n - done, 256), dim3(256), 0, st, in + done, n - done, scale, lo, hi, o + done, flag, 0);
     }
     else if (width == 1) hipLaunchKernelGGL(k_quantize<signed char>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (signed char*)out_pcm->ptr + out_off, flag, 0);
     else hipLaunchKernelGGL(k_quantize<int>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (int*)out_pcm->ptr + out_off, flag, 0);
@@ -785,15 +785,15 @@ int sh_quantize_f64(const sh_buf* in_f64, size_t in_off, size_t n, double scale,
     if (!n) return SH_OK;
     const double lo = -ldexp(1.0, 8 * width - 1), hi = ldexp(1.0, 8 * width - 1) - 1.0;
     const double* in = (const double*)in_f64->ptr + in_off;
-    dim3 grid(sh::div_up(n, 256));
+    const dim3 grid = sh::grid1d(n, 256);
     hipStream_t st = sh::state().stream;
     int* flag = sh::state().flag;
     if (width == 2) {
         short* out = (short*)out_pcm->ptr + out_off;
         const bool aligned = ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 3) == 0;
         const size_t nvec = aligned ? n / 2 : 0, done = nvec * 2;
-        if (nvec) hipLaunchKernelGGL(k_quantize_f64_i16_vec, dim3(sh::div_up(nvec, 512)), dim3(256), 0, st, (const double2v*)in, nvec, scale, (short2v*)out, flag);
-        if (n > done) hipLaunchKernelGGL((k_quantize<short, double>), dim3(sh::div_up(n - done, 256)), dim3(256), 0, st, in + done, n - done, scale, lo, hi, out + done, flag, 0);
+        if (nvec) hipLaunchKernelGGL(k_quantize_f64_i16_vec, sh::grid1d(nvec, 512), dim3(256), 0, st, (const double2v*)in, nvec, scale, (short2v*)out, flag);
+        if (n > done) hipLaunchKernelGGL((k_quantize<short, double>), sh::grid1d(n - done, 256), dim3(256), 0, st, in + done, n - done, scale, lo, hi, out + done, flag, 0);
     } else if (width == 1) hipLaunchKernelGGL((k_quantize<signed char, double>), grid, dim3(256), 0, st, in, n, scale, lo, hi, (signed char*)out_pcm->ptr + out_off, flag, 0);
     else hipLaunchKernelGGL((k_quantize<int, double>), grid, dim3(256), 0, st, in, n, scale, lo, hi, (int*)out_pcm->ptr + out_off, flag, 0);
     SH_CHECK_LAUNCH("k_quantize");
@@ -812,8 +812,8 @@ int sh_quantize_clip_f32(const sh_buf* in_f32, size_t n, double scale, sh_buf* o
     {
         hipStream_t st = sh::state().stream;
         const size_t nvec = n / 4, done = nvec * 4;
-        if (nvec) hipLaunchKernelGGL(k_quantize_f32_i16_vec, dim3(sh::div_up(nvec, 512)), dim3(256), 0, st, (const float4v*)in_f32->ptr, nvec, scale, (short4v*)out_i16->ptr, sh::state().flag, 1);
-        if (n > done) hipLaunchKernelGGL(k_quantize<short>, dim3(sh::div_up(n - done, 256)), dim3(256), 0, st,
+        if (nvec) hipLaunchKernelGGL(k_quantize_f32_i16_vec, sh::grid1d(nvec, 512), dim3(256), 0, st, (const float4v*)in_f32->ptr, nvec, scale, (short4v*)out_i16->ptr, sh::state().flag, 1);
+        if (n > done) hipLaunchKernelGGL(k_quantize<short>, sh::grid1d(n - done, 256), dim3(256), 0, st,
                                          (const float*)in_f32->ptr + done, n - done, scale, -32768.0, 32767.0, (short*)out_i16->ptr + done, sh::state().flag, 1);
     }
     SH_CHECK_LAUNCH("k_quantize(clip)");
@@ -826,7 +826,7 @@ static int pcm_add_dev(const char* a, const char* b, char* o, size_t nbytes, int
     size_t nvec = aligned ? nbytes / 16 : 0;
     size_t done = nvec * 16;
     if (nvec) {
-        dim3 grid(sh::div_up(nvec, 256));
+        const dim3 grid = sh::grid1d(nvec, 256);
         if (width == 2) hipLaunchKernelGGL(k_add_i16_vec, grid, dim3(256), 0, st, (const short8v*)a, (const short8v*)b, (short8v*)o, nvec);
         else if (width == 4) hipLaunchKernelGGL(k_add_i32_vec, grid, dim3(256), 0, st, (const int4v*)a, (const int4v*)b, (int4v*)o, nvec);
         else hipLaunchKernelGGL(k_add_i8_vec, grid, dim3(256), 0, st, (const char16v*)a, (const char16v*)b, (char16v*)o, nvec);
@@ -834,7 +834,7 @@ static int pcm_add_dev(const char* a, const char* b, char* o, size_t nbytes, int
     }
     size_t rest = (nbytes - done) / width;
     if (rest) {
-        dim3 grid(sh::div_up(rest, 256));
+        const dim3 grid = sh::grid1d(rest, 256);
         if (width == 2) hipLaunchKernelGGL(k_add_scalar<short>, grid, dim3(256), 0, st, (const short*)(a + done), (const short*)(b + done), (short*)(o + done), rest);
         else if (width == 4) hipLaunchKernelGGL(k_add_scalar<int>, grid, dim3(256), 0, st, (const int*)(a + done), (const int*)(b + done), (int*)(o + done), rest);
         else hipLaunchKernelGGL(k_add_scalar<signed char>, grid, dim3(256), 0, st, (const signed char*)(a + done), (const signed char*)(b + done), (signed char*)(o + done), rest);
@@ -926,10 +926,10 @@ int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint
     // distant rows: 5.8); fewer -> split the voices over the waves of a workgroup for parallelism
     const uint32_t columns = (uint32_t)sh::div_up(nsamples, 512);
     const bool aligned = (stride & 7) == 0 && ((uintptr_t)chunks->ptr & 15) == 0 && ((uintptr_t)out->ptr & 15) == 0;
-#define SH_CHAIN(W_, C_) hipLaunchKernelGGL((k_mix_chain_i16<W_, C_>), dim3(sh::div_up(nsamples, 512 * C_)), dim3(W_ * 64), 0, st, \
+#define SH_CHAIN(W_, C_) hipLaunchKernelGGL((k_mix_chain_i16<W_, C_>), sh::grid1d(nsamples, 512 * C_), dim3(W_ * 64), 0, st, \
                                             (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr)
     if (columns >= 1536 && aligned)
-        hipLaunchKernelGGL((k_mix_chain_direct<8, 4>), dim3(sh::div_up(nsamples, 512 * 8)), dim3(8 * 64), 0, st,
+        hipLaunchKernelGGL((k_mix_chain_direct<8, 4>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
                            (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
     else if (nvoices < 64) SH_CHAIN(2, 1);
     else if (columns >= 512) SH_CHAIN(8, 2);
@@ -973,7 +973,7 @@ int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offs
     const uint32_t n = (uint32_t)tab.size();
     dim3 grid(sh::div_up(nsamples, 512));
     if (sh::div_up(nsamples, 512) >= 1536)
-        hipLaunchKernelGGL((k_mix_chain_gather_direct<8, 4>), dim3(sh::div_up(nsamples, 512 * 8)), dim3(8 * 64), 0, st,
+        hipLaunchKernelGGL((k_mix_chain_gather_direct<8, 4>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
                            (const ChainSrc*)sh::state().scratch, n, nsamples, op);
     else if (n >= 64) hipLaunchKernelGGL(k_mix_chain_gather<8>, grid, dim3(8 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
     else hipLaunchKernelGGL(k_mix_chain_gather<2>, grid, dim3(2 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
@@ -992,8 +992,24 @@ size_t sh_resample_out_frames(size_t in_frames, int inrate, int outrate) {
 // in / out are the addresses input frame 0 / output frame 0 would have (range launches pass pointers shifted back by
 // the frames they do not hold: never dereferenced outside [held input), [m_base, m_end)).  in_frames = end of the
 // held input, m_base / m_end = output frame range.
+static int resample_launch(const void* in, size_t in_frames, int nch, int width, int is_float, int inrate, int outrate,
+                           void* out, size_t m_base, size_t m_end);
+
+// Output ranges of any length: one launch per 2^30 output samples at most (a dispatch holds fewer than 2^32 work-items per grid
+// dimension; the kernels work from absolute output positions, so a range cut at multiples of 4096 frames is the same range)
 static int resample_dev(const void* in, size_t in_frames, int nch, int width, int is_float, int inrate, int outrate,
                         void* out, size_t m_base, size_t m_end) {
+    size_t chunk = (((size_t)1 << 30) / (size_t)nch) & ~(size_t)4095;
+    if (chunk < 4096) chunk = 4096;
+    for (size_t m = m_base; m < m_end; m += chunk) {
+        const int rc = resample_launch(in, in_frames, nch, width, is_float, inrate, outrate, out, m, m_end - m < chunk ? m_end : m + chunk);
+        if (rc) return rc;
+    }
+    return SH_OK;
+}
+
+static int resample_launch(const void* in, size_t in_frames, int nch, int width, int is_float, int inrate, int outrate,
+                           void* out, size_t m_base, size_t m_end) {
     const size_t out_frames = m_end - m_base;        // frames this launch writes
     uint64_t g = gcd_u64((uint64_t)inrate, (uint64_t)outrate);
     RatecvArgs A;

@@ -27,7 +27,7 @@ template <> struct Lim<int> { static constexpr double lo = -2147483648.0, hi = 2
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_mul(const T* in, T* out, size_t nvec, double factor) {
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= nvec) return;
     vec_t v = reinterpret_cast<const vec_t*>(in)[i], r;
 #pragma unroll
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_mul(const T* in, T* out, size_t nvec, d
 // (Sample.fadeout: offset 1, slope -decrease; Sample.fadein: offset start_volume, slope increase)
 template <typename T>
 __global__ __launch_bounds__(256) void k_fade(const T* in, T* out, size_t n, double slope, double numsamples, double offset, int fadeout) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= n) return;
     const double ramp = (double)i * slope / numsamples;
     const double f = fadeout ? (1.0 - ramp) : (ramp + offset);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_fade(const T* in, T* out, size_t n, dou
 template <typename T>
 __global__ __launch_bounds__(256) void k_modulate(const T* __restrict__ in, T* __restrict__ out, size_t n,
                                                   const double* __restrict__ mod, size_t nmod, int* flag) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= n) return;
     const size_t k = i < nmod ? i : (i < 0xFFFFFFFFull && nmod < 0xFFFFFFFFull ? (size_t)((uint32_t)i % (uint32_t)nmod) : i % nmod);
     constexpr double HI = (double)((1ll << (8 * sizeof(T) - 1)) - 1), LO = -(double)(1ll << (8 * sizeof(T) - 1));
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_modulate(const T* __restrict__ in, T* _
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void k_pan_lfo(const T* __restrict__ in, T* __restrict__ out, size_t nframes,
                                                  const double* __restrict__ pan, int* flag) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= nframes) return;
     constexpr double HI = (double)((1ll << (8 * sizeof(T) - 1)) - 1), LO = -(double)(1ll << (8 * sizeof(T) - 1));
     const double p = pan[i];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_pan_lfo(const T* __restrict__ in, T* __
 // out[i] = in[i] / divisor in float64              (Sample.get_frames_as_floats; waveform modulators)
 template <typename T>
 __global__ __launch_bounds__(256) void k_to_f64(const T* __restrict__ in, double* __restrict__ out, size_t n, double divisor) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= n) return;
     out[i] = (double)in[i] / divisor;
 }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_to_f64(const T* __restrict__ in, double
 // out[i] = in[i] + bias, wrapping                (audioop.bias)
 template <typename T>
 __global__ __launch_bounds__(256) void k_bias(const T* in, T* out, size_t n, int bias) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= n) return;
     out[i] = (T)((unsigned)(int)in[i] + (unsigned)bias);
 }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_bias(const T* in, T* out, size_t n, int
 // out[i] = in[n-1-i]                             (audioop.reverse: samples, not frames)
 template <typename T>
 __global__ __launch_bounds__(256) void k_reverse(const T* __restrict__ in, T* __restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= n) return;
     out[i] = in[n - 1 - i];
 }
@@ -111,7 +111,7 @@ template <typename T, int F>
 __global__ __launch_bounds__(256) void k_tomono(const T* __restrict__ in, T* __restrict__ out, size_t nunits, double lf, double rf) {
     typedef T vin __attribute__((ext_vector_type(2 * F)));
     typedef T vout __attribute__((ext_vector_type(F)));
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= nunits) return;
     const vin v = reinterpret_cast<const vin*>(in)[i];
     vout r;
@@ -125,7 +125,7 @@ template <typename T, int F>
 __global__ __launch_bounds__(256) void k_tostereo(const T* __restrict__ in, T* __restrict__ out, size_t nunits, double lf, double rf) {
     typedef T vin __attribute__((ext_vector_type(F)));
     typedef T vout __attribute__((ext_vector_type(2 * F)));
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= nunits) return;
     vin v;
     if (F == 1) v[0] = in[i]; else v = reinterpret_cast<const vin*>(in)[i];
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_tostereo(const T* __restrict__ in, T* _
 // width conversion through the 32-bit form (GETSAMPLE32 / SETSAMPLE32)   (audioop.lin2lin)
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void k_lin2lin(const TI* __restrict__ in, TO* __restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= n) return;
     const int v32 = (int)((unsigned)(int)in[i] << (32 - 8 * (int)sizeof(TI)));
     out[i] = (TO)(v32 >> (32 - 8 * (int)sizeof(TO)));
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_sumsq_f64(const int* __restrict__ in, s
 // 24-bit <-> 32-bit: a thread converts four samples (12 bytes <-> 16 bytes); the 12 bytes are read / written as three
 // dwords when the 3-byte stream starts on a dword boundary, byte by byte otherwise (the tail always is).
 __global__ __launch_bounds__(256) void k_unpack24(const unsigned char* __restrict__ in, size_t n, int shift, int* __restrict__ out, int dwords) {
-    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;              // group of four samples
+    const size_t q = sh::block_id() * 256 + threadIdx.x;              // group of four samples
     if (q * 4 >= n) return;
     if (dwords && q * 4 + 4 <= n) {
         const unsigned* w = reinterpret_cast<const unsigned*>(in) + q * 3;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void k_unpack24(const unsigned char* __restric
 }
 
 __global__ __launch_bounds__(256) void k_pack24(const int* __restrict__ in, size_t n, int shift, unsigned char* __restrict__ out, int dwords) {
-    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t q = sh::block_id() * 256 + threadIdx.x;
     if (q * 4 >= n) return;
     if (dwords && q * 4 + 4 <= n) {
         const unsigned a = (unsigned)(in[q * 4] >> shift) & 0xFFFFFFu, b = (unsigned)(in[q * 4 + 1] >> shift) & 0xFFFFFFu;
@@ -494,14 +494,14 @@ int check_io(const sh_buf* in, size_t in_off, size_t in_bytes, const sh_buf* out
 namespace sh {
 int unpack24(const void* in, size_t nsamples, int shift, int32_t* out) {
     if (!nsamples) return SH_OK;
-    hipLaunchKernelGGL(k_unpack24, dim3(div_up((nsamples + 3) / 4, 256)), dim3(256), 0, state().stream, (const unsigned char*)in, nsamples, shift,
+    hipLaunchKernelGGL(k_unpack24, sh::grid1d((nsamples + 3) / 4, 256), dim3(256), 0, state().stream, (const unsigned char*)in, nsamples, shift,
                        (int*)out, ((uintptr_t)in & 3) == 0 ? 1 : 0);
     SH_CHECK_LAUNCH("k_unpack24");
     return SH_OK;
 }
 int pack24(const int32_t* in, size_t nsamples, int shift, void* out) {
     if (!nsamples) return SH_OK;
-    hipLaunchKernelGGL(k_pack24, dim3(div_up((nsamples + 3) / 4, 256)), dim3(256), 0, state().stream, (const int*)in, nsamples, shift,
+    hipLaunchKernelGGL(k_pack24, sh::grid1d((nsamples + 3) / 4, 256), dim3(256), 0, state().stream, (const int*)in, nsamples, shift,
                        (unsigned char*)out, ((uintptr_t)out & 3) == 0 ? 1 : 0);
     SH_CHECK_LAUNCH("k_pack24");
     return SH_OK;
@@ -553,8 +553,8 @@ int sh_pcm_mul(const sh_buf* in, size_t in_off, size_t nbytes, int width, double
         constexpr int V = 16 / sizeof(T);
         const bool aligned = (((uintptr_t)ip | (uintptr_t)op) & 15) == 0;
         size_t nvec = aligned ? nbytes / 16 : 0, done = nvec * 16, rest = (nbytes - done) / sizeof(T);
-        if (nvec) hipLaunchKernelGGL((k_mul<T, V>), dim3(sh::div_up(nvec, 256)), dim3(256), 0, st, (const T*)ip, (T*)op, nvec, factor);
-        if (rest) hipLaunchKernelGGL((k_mul<T, 1>), dim3(sh::div_up(rest, 256)), dim3(256), 0, st, (const T*)(ip + done), (T*)(op + done), rest, factor);
+        if (nvec) hipLaunchKernelGGL((k_mul<T, V>), sh::grid1d(nvec, 256), dim3(256), 0, st, (const T*)ip, (T*)op, nvec, factor);
+        if (rest) hipLaunchKernelGGL((k_mul<T, 1>), sh::grid1d(rest, 256), dim3(256), 0, st, (const T*)(ip + done), (T*)(op + done), rest, factor);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_mul");
     });
@@ -572,7 +572,7 @@ int sh_pcm_fade(const sh_buf* in, size_t in_off, size_t nbytes, int width, int f
     hipStream_t st = sh::state().stream;
     return dispatch_width(width, [&](auto tag) {
         typedef decltype(tag) T;
-        hipLaunchKernelGGL(k_fade<T>, dim3(sh::div_up(n, 256)), dim3(256), 0, st, (const T*)((const char*)in->ptr + in_off),
+        hipLaunchKernelGGL(k_fade<T>, sh::grid1d(n, 256), dim3(256), 0, st, (const T*)((const char*)in->ptr + in_off),
                            (T*)((char*)out->ptr + out_off), n, slope, (double)nbytes / (double)width, offset, fadeout);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_fade");
@@ -591,7 +591,7 @@ int sh_pcm_modulate(const sh_buf* in, size_t nbytes, int width, const sh_buf* mo
     sh::State& S = sh::state();
     rc = dispatch_width(width, [&](auto tag) {
         typedef decltype(tag) T;
-        hipLaunchKernelGGL(k_modulate<T>, dim3(sh::div_up(n, 256)), dim3(256), 0, S.stream, (const T*)in->ptr, (T*)out->ptr, n,
+        hipLaunchKernelGGL(k_modulate<T>, sh::grid1d(n, 256), dim3(256), 0, S.stream, (const T*)in->ptr, (T*)out->ptr, n,
                            (const double*)mod_f64->ptr, nmod, S.flag);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_modulate");
@@ -618,10 +618,10 @@ int sh_pcm_pan_lfo(const sh_buf* in, size_t nframes, int width, int nchannels, c
     rc = dispatch_width(width, [&](auto tag) {
         typedef decltype(tag) T;
         if (nchannels == 1)
-            hipLaunchKernelGGL((k_pan_lfo<T, 1>), dim3(sh::div_up(nframes, 256)), dim3(256), 0, S.stream, (const T*)in->ptr, (T*)out->ptr, nframes,
+            hipLaunchKernelGGL((k_pan_lfo<T, 1>), sh::grid1d(nframes, 256), dim3(256), 0, S.stream, (const T*)in->ptr, (T*)out->ptr, nframes,
                                (const double*)pan_f64->ptr, S.flag);
         else
-            hipLaunchKernelGGL((k_pan_lfo<T, 2>), dim3(sh::div_up(nframes, 256)), dim3(256), 0, S.stream, (const T*)in->ptr, (T*)out->ptr, nframes,
+            hipLaunchKernelGGL((k_pan_lfo<T, 2>), sh::grid1d(nframes, 256), dim3(256), 0, S.stream, (const T*)in->ptr, (T*)out->ptr, nframes,
                                (const double*)pan_f64->ptr, S.flag);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_pan_lfo");
@@ -646,7 +646,7 @@ int sh_pcm_to_f64(const sh_buf* in, size_t nsamples, int width, double divisor, 
     hipStream_t st = sh::state().stream;
     return dispatch_width(width, [&](auto tag) {
         typedef decltype(tag) T;
-        hipLaunchKernelGGL(k_to_f64<T>, dim3(sh::div_up(nsamples, 256)), dim3(256), 0, st, (const T*)in->ptr, (double*)out_f64->ptr, nsamples, divisor);
+        hipLaunchKernelGGL(k_to_f64<T>, sh::grid1d(nsamples, 256), dim3(256), 0, st, (const T*)in->ptr, (double*)out_f64->ptr, nsamples, divisor);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_to_f64");
     });
@@ -669,7 +669,7 @@ int sh_pcm_bias(const sh_buf* in, size_t nbytes, int width, int bias, sh_buf* ou
     hipStream_t st = sh::state().stream;
     return dispatch_width(width, [&](auto tag) {
         typedef decltype(tag) T;
-        hipLaunchKernelGGL(k_bias<T>, dim3(sh::div_up(n, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, n, bias);
+        hipLaunchKernelGGL(k_bias<T>, sh::grid1d(n, 256), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, n, bias);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_bias");
     });
@@ -692,7 +692,7 @@ int sh_pcm_reverse(const sh_buf* in, size_t nbytes, int width, sh_buf* out) {
     hipStream_t st = sh::state().stream;
     return dispatch_width(width, [&](auto tag) {
         typedef decltype(tag) T;
-        hipLaunchKernelGGL(k_reverse<T>, dim3(sh::div_up(n, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, n);
+        hipLaunchKernelGGL(k_reverse<T>, sh::grid1d(n, 256), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, n);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_reverse");
     });
@@ -712,8 +712,8 @@ int sh_pcm_tomono(const sh_buf* in, size_t nframes, int width, double lfactor, d
         typedef decltype(tag) T;
         constexpr int F = 8 / sizeof(T);                       // frames per 16-byte load
         const size_t nvec = nframes / F, done = nvec * F;
-        if (nvec) hipLaunchKernelGGL((k_tomono<T, F>), dim3(sh::div_up(nvec, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, nvec, lfactor, rfactor);
-        if (nframes > done) hipLaunchKernelGGL((k_tomono<T, 1>), dim3(sh::div_up(nframes - done, 256)), dim3(256), 0, st,
+        if (nvec) hipLaunchKernelGGL((k_tomono<T, F>), sh::grid1d(nvec, 256), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, nvec, lfactor, rfactor);
+        if (nframes > done) hipLaunchKernelGGL((k_tomono<T, 1>), sh::grid1d(nframes - done, 256), dim3(256), 0, st,
                                                (const T*)in->ptr + 2 * done, (T*)out->ptr + done, nframes - done, lfactor, rfactor);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_tomono");
@@ -734,8 +734,8 @@ int sh_pcm_tostereo(const sh_buf* in, size_t nframes, int width, double lfactor,
         typedef decltype(tag) T;
         constexpr int F = 8 / sizeof(T);                       // frames per 16-byte store
         const size_t nvec = nframes / F, done = nvec * F;
-        if (nvec) hipLaunchKernelGGL((k_tostereo<T, F>), dim3(sh::div_up(nvec, 256)), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, nvec, lfactor, rfactor);
-        if (nframes > done) hipLaunchKernelGGL((k_tostereo<T, 1>), dim3(sh::div_up(nframes - done, 256)), dim3(256), 0, st,
+        if (nvec) hipLaunchKernelGGL((k_tostereo<T, F>), sh::grid1d(nvec, 256), dim3(256), 0, st, (const T*)in->ptr, (T*)out->ptr, nvec, lfactor, rfactor);
+        if (nframes > done) hipLaunchKernelGGL((k_tostereo<T, 1>), sh::grid1d(nframes - done, 256), dim3(256), 0, st,
                                                (const T*)in->ptr + done, (T*)out->ptr + 2 * done, nframes - done, lfactor, rfactor);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_tostereo");
@@ -763,7 +763,7 @@ int sh_pcm_lin2lin(const sh_buf* in, size_t nsamples, int width, int new_width, 
     if (rc) return rc;
     if (!nsamples) return SH_OK;
     hipStream_t st = sh::state().stream;
-    dim3 grid(sh::div_up(nsamples, 256));
+    const dim3 grid = sh::grid1d(nsamples, 256);
 #define SH_L2L(TI, TO) hipLaunchKernelGGL((k_lin2lin<TI, TO>), grid, dim3(256), 0, st, (const TI*)in->ptr, (TO*)out->ptr, nsamples)
     if (width == 1 && new_width == 1) SH_L2L(signed char, signed char);
     else if (width == 1 && new_width == 2) SH_L2L(signed char, short);

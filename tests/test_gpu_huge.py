@@ -121,3 +121,90 @@ def test_resample_float32_8ch_beyond_4_gib(gpu):
         assert np.array_equal(got, P.ratecv_f32_window(get, inrate, outrate, first, w)), first
     src.free()
     dst.free()
+
+
+def test_bank_render_of_two_billion_frames_in_one_launch(gpu):
+    """sh_bank_render with nframes beyond 2^31 (12.4 hours of audio at 48 kHz, a 17 GB float32 bus) for a small bank of mixed
+    kinds: windows of the one launch -- head, either side of frame 2^31, tail -- against the same frames rendered as short
+    launches of their own (other launch shapes, other launch records: float64 rounding before the one rounding to float32),
+    and the first window against the oracle.  The library cuts such a render into launches of 2^22 frames: a launch's grid
+    counts work-items in 32 bits per dimension, and a bank with several voice groups keeps 32 B of partial buses per frame
+    and group."""
+    from oracle import c_oracle as CO
+    from oracle import synth_oracle as O
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    from synthesizer_amd.workloads import additive_voices
+    SR = 48000
+    harm = [(k, 1.0 / k) for k in range(1, 17)]
+
+    def voices(M):
+        return [M.Sine(440.0, 0.1, samplerate=SR), M.Harmonics(97.3, harm, amplitude=0.05, phase=0.2, samplerate=SR),
+                M.Square(311.0, 0.03, samplerate=SR), M.Sawtooth(55.5, 0.04, phase=0.7, samplerate=SR),
+                M.Sine(220.0, 0.08, fm_lfo=M.Sine(3.0, 0.01, samplerate=SR), samplerate=SR),
+                M.Triangle(1234.5, 0.05, samplerate=SR), M.Pulse(77.0, 0.02, pulsewidth=0.2, samplerate=SR),
+                M.Harmonics(1500.1, harm[:5], amplitude=0.03, samplerate=SR)]
+
+    gains = [(0.9, 0.1), (0.5, 0.5), (0.2, 0.8), (1.0, 0.0), (0.3, 0.7), (0.6, 0.4), (0.0, 1.0), (0.7, 0.7)]
+    bank = VoiceBank(voices(G), gains=gains)
+    n = (1 << 31) + (1 << 20) + 321
+    bus = N.DeviceBuffer(8 * n)
+    bank.render_device(n, 0, bus_f32=bus)
+    w = 20000
+    for first in (0, (1 << 31) - w // 2, (1 << 31) + 4097, 1_000_000_007, n - w):
+        got = bus.download(np.float32, 2 * w, 8 * first).reshape(w, 2)
+        want = bank.render(w, start=first)
+        assert np.max(np.abs(got.astype(np.float64) - want)) <= 2e-7, first
+        assert np.mean(got != want) < 0.01, first
+    rows = np.stack([CO.render(o, w) for o in voices(O)])
+    ref = np.array(CO.mix_bus(rows, gains), dtype=np.float64)
+    assert np.sqrt(np.mean((bus.download(np.float32, 2 * w).reshape(w, 2) - ref) ** 2)) <= 1e-6
+    bus.free()
+    # 256 voices -> several voice groups -> 2 x groups x 16 B of partial buses per frame: hundreds of GB at this length in one
+    # launch; as a run of RENDER_MAX_FRAMES launches (two-stream pipeline, partial buses of one launch each) it is 0.4 s of GPU
+    big, bg = additive_voices(G, 256, SR, seed=1, adsr={"sustain": 44000.0})     # released at frame 2.112e9: the last windows are silent
+    bank2 = VoiceBank(big, gains=bg)
+    out = N.DeviceBuffer(8 * n)
+    bank2.render_device(n, 0, bus_f32=out)
+    for first in (0, (1 << 22) - w // 2, 1_900_000_000, 2_112_000_000 + 2000, (1 << 31) - w // 2, n - w):   # 2^22: a seam between two launches
+        got = out.download(np.float32, 2 * w, 8 * first).reshape(w, 2)
+        want = bank2.render(w, start=first)
+        assert (np.abs(want).max() > 1e-3) == (first < 2_120_000_000), first
+        assert np.max(np.abs(got.astype(np.float64) - want)) <= 2e-7, first
+        assert np.mean(got != want) < 0.01, first
+    out.free()
+
+def test_one_sample_per_thread_kernels_beyond_2_32_samples(gpu):
+    """The elementwise Sample operations whose kernels take ONE sample per thread (bias, reverse, lin2lin, fade) on more than
+    2^32 samples of 8-bit PCM: a dispatch counts work-items in 32 bits per grid dimension, so these launches fold their
+    blocks into two dimensions (csrc/common.hpp grid1d / block_id) -- unfolded, the launch ran 2^20 threads and reported
+    success."""
+    from synthesizer_amd import _native as N
+    L = N.lib()
+    n = (1 << 32) + (1 << 20) + 77
+    tile = np.random.default_rng(99).integers(-128, 128, (1 << 24) - 7, dtype=np.int64).astype(np.int8)
+    src, dst = N.DeviceBuffer(n), N.DeviceBuffer(n)
+    _fill(src, tile, n)
+    w = 1 << 16
+    marks = (0, (1 << 31) - w // 2, (1 << 32) - w // 2, (1 << 32) + 4099, n - w)
+    at = lambda first: tile[np.arange(first, first + w) % len(tile)]
+    N.check(L.sh_pcm_bias(src.handle, n, 1, 3, dst.handle))
+    for first in marks:
+        assert dst.download(np.int8, w, first).tobytes() == audioop.bias(at(first).tobytes(), 1, 3), first
+    N.check(L.sh_pcm_reverse(src.handle, n, 1, dst.handle))
+    for first in marks:
+        want = tile[np.arange(n - 1 - first, n - 1 - first - w, -1) % len(tile)]
+        assert np.array_equal(dst.download(np.int8, w, first), want), first
+    N.check(L.sh_pcm_fade(src.handle, 0, n, 1, 1, 1.0, 1.0, dst.handle, 0))         # Sample.fadeout to silence over the whole length
+    for first in marks:
+        i = np.arange(first, first + w, dtype=np.float64)
+        ref = np.trunc(at(first).astype(np.float64) * (1.0 - i * 1.0 / float(n))).astype(np.int8)
+        assert np.array_equal(dst.download(np.int8, w, first), ref), first
+    dst.free()
+    wide = N.DeviceBuffer(2 * n)
+    N.check(L.sh_pcm_lin2lin(src.handle, n, 1, 2, wide.handle))
+    for first in marks:
+        assert wide.download(np.int16, w, 2 * first).tobytes() == audioop.lin2lin(at(first).tobytes(), 1, 2), first
+    src.free()
+    wide.free()
