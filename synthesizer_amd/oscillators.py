@@ -77,7 +77,7 @@ def series_polynomial(coef_by_k: Tuple[float, ...]) -> Optional[Tuple[float, ...
     return tuple(reversed(pf))
 
 
-@dataclass
+@dataclass(frozen=True)
 class EnvelopeSpec:
     n_attack_end: int
     n_decay_end: int
@@ -96,6 +96,7 @@ class EnvelopeSpec:
         return self.n_release_end + (1 if self.has_tail else 0)
 
 
+@lru_cache(maxsize=4096)          # a bank's voices usually share one ADSR: the four boundary searches are done once
 def envelope_spec(attack: float, decay: float, sustain: float, sustain_level: float, release: float,
                   samplerate: int, stop_at_end: bool = False) -> EnvelopeSpec:
     """Replay EnvelopeFilter's accumulated ``time`` exactly and return the sample indices at which

@@ -65,9 +65,8 @@ def build_phase_table(t0: float, inc: float, n_limit: int = N_LIMIT) -> List[Seg
             if _binade(t2) == b and (t2 - t1) == d:
                 # regular run: t + j*d for j = 0..k stays inside the binade
                 T, s = _mant(t)
-                D, s2 = _mant(d) if abs(d) >= _TINY else (0, 0)
-                # express d in units of 2**s (d is a multiple of the binade ulp)
-                D = int(Fraction(d) / (Fraction(2) ** s))
+                # d in units of 2**s: d is a multiple of the binade's ulp and |d| < 2**(s + 53), so the scaling is exact
+                D = int(ldexp(d, -s))
                 lo, hi = 1 << 52, (1 << 53) - 1
                 if T > 0:
                     k = (hi - T) // D if D > 0 else (T - lo) // (-D)
@@ -112,10 +111,11 @@ class PhaseTable:
         if self.t0 >= x:
             return 0
         X = Fraction(x)
-        lo, hi = 0, len(self.segments) - 1          # last piece whose start value is < x
+        x = float(x)
+        lo, hi = 0, len(self.segments) - 1          # last piece whose start value is < x (doubles compare exactly)
         while lo < hi:
             mid = (lo + hi + 1) // 2
-            if Fraction(self.segments[mid][1]) < X:
+            if self.segments[mid][1] < x:
                 lo = mid
             else:
                 hi = mid - 1
