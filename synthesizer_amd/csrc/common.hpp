@@ -120,6 +120,15 @@ inline dim3 grid1d(size_t n, size_t per_block) {
 }
 __device__ __forceinline__ size_t block_id() { return (size_t)blockIdx.y * gridDim.x + blockIdx.x; }
 
+// Rows that are read exactly once: streaming (non-temporal) loads are worth +10..13 % once the data no longer fits the 256 MB
+// Infinity Cache (mixers: 6.4 -> 7.2 TB/s on 2 GB) and cost 11 % when it does (36 MB: 8.9 -> 7.9 TB/s) -- the entry points
+// choose by the bytes a call reads (tools/mix_probe.py).
+constexpr size_t STREAM_BYTES = (size_t)128 << 20;
+template <bool NT, typename V>
+__device__ __forceinline__ V load_vec(const void* p) {
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p)) : *reinterpret_cast<const V*>(p);
+}
+
 // ---- 24-bit PCM (audioop width 3) -----------------------------------------------------------------------------------
 // audioop reads a 3-byte sample as GETINT24 (sign-extended) and, wherever it works through GETSAMPLE32 (ratecv, lin2lin) or
 // scales linearly (mul, tomono, tostereo, add, bias), the result for width 3 equals the width-4 operation on value << 8 taken

@@ -1460,7 +1460,14 @@ __global__ __launch_bounds__(256) void k_bus_combine(const double2* __restrict__
 // block = W waves; a wave owns 256 consecutive frames (float4 per lane) and a strided subset of
 // the voice rows of its group; partial (L,R) x4 per lane are summed across the block's waves in
 // LDS.  grid = (frame tiles, voice groups); groups > 1 write partial buses that k_bus_sum folds.
-template <int WAVES>
+template <bool NT>
+__device__ __forceinline__ float4 ldf4(const float* p) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v t = sh::load_vec<NT, f4v>(p);
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+
+template <int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_mix_bus_f32(const float* __restrict__ voices, uint32_t nvoices,
                                                             size_t stride, uint32_t nframes,
                                                             const float2* __restrict__ gains,
@@ -1486,22 +1493,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_bus_f32(const float* __restr
             float4 x[8];
             float2 gg[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = *reinterpret_cast<const float4*>(voices + (size_t)(v + k * WAVES) * stride + f0);
+            for (int k = 0; k < 8; ++k) x[k] = ldf4<NT>(voices + (size_t)(v + k * WAVES) * stride + f0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) gg[k] = gains[v + k * WAVES];
 #pragma unroll
             for (int k = 0; k < 8; ++k) { SH_ACC(x[k], gg[k]) }
         }
         for (; v + 3 * WAVES < v_end; v += 4 * WAVES) {
-            float4 x0 = *reinterpret_cast<const float4*>(voices + (size_t)v * stride + f0);
-            float4 x1 = *reinterpret_cast<const float4*>(voices + (size_t)(v + WAVES) * stride + f0);
-            float4 x2 = *reinterpret_cast<const float4*>(voices + (size_t)(v + 2 * WAVES) * stride + f0);
-            float4 x3 = *reinterpret_cast<const float4*>(voices + (size_t)(v + 3 * WAVES) * stride + f0);
+            float4 x0 = ldf4<NT>(voices + (size_t)v * stride + f0);
+            float4 x1 = ldf4<NT>(voices + (size_t)(v + WAVES) * stride + f0);
+            float4 x2 = ldf4<NT>(voices + (size_t)(v + 2 * WAVES) * stride + f0);
+            float4 x3 = ldf4<NT>(voices + (size_t)(v + 3 * WAVES) * stride + f0);
             float2 g0 = gains[v], g1 = gains[v + WAVES], g2 = gains[v + 2 * WAVES], g3 = gains[v + 3 * WAVES];
             SH_ACC(x0, g0) SH_ACC(x1, g1) SH_ACC(x2, g2) SH_ACC(x3, g3)
         }
         for (; v < v_end; v += WAVES) {
-            float4 x0 = *reinterpret_cast<const float4*>(voices + (size_t)v * stride + f0);
+            float4 x0 = ldf4<NT>(voices + (size_t)v * stride + f0);
             float2 g0 = gains[v];
             SH_ACC(x0, g0)
         }
@@ -1544,7 +1551,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_bus_f32(const float* __restr
 // Long buffers (the frame range alone fills the chip): no voice split -- a lane walks all the rows for its 4 frames,
 // a workgroup covers WAVES KB of every row it visits, no LDS.  (Same lesson as the integer fold, DESIGN.md section 4
 // item 15: eight waves fetching one 1 KB column of eight distant rows cost 10 % of the bandwidth.)
-template <int WAVES, int INFLIGHT>
+template <int WAVES, int INFLIGHT, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_mix_bus_direct(const float* __restrict__ voices, uint32_t nvoices, size_t stride,
                                                                uint32_t nframes, const float2* __restrict__ gains,
                                                                float2* __restrict__ out) {
@@ -1569,7 +1576,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_bus_direct(const float* __re
         float4 x[INFLIGHT];
         float2 gg[INFLIGHT];
 #pragma unroll
-        for (int k = 0; k < INFLIGHT; ++k) x[k] = *reinterpret_cast<const float4*>(col + (size_t)(v + k) * stride);
+        for (int k = 0; k < INFLIGHT; ++k) x[k] = ldf4<NT>(col + (size_t)(v + k) * stride);       // NT: 0.81 -> 0.90 of the HBM peak on 2 GB
 #pragma unroll
         for (int k = 0; k < INFLIGHT; ++k) gg[k] = gains[v + k];
 #pragma unroll
@@ -2611,15 +2618,18 @@ int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32
     int rc = sh::ensure_scratch(part_bytes);
     if (rc) return rc;
     hipStream_t st = sh::state().stream;
+    const bool stream = (size_t)nvoices * nframes * 4 > sh::STREAM_BYTES;              // rows beyond the Infinity Cache: streaming loads
     if (tiles >= 1536 && (stride & 3) == 0 && ((uintptr_t)voices->ptr & 15) == 0 && ((uintptr_t)bus_f32->ptr & 15) == 0) {
-        hipLaunchKernelGGL((k_mix_bus_direct<8, 4>), sh::grid1d(nframes, 256 * 8), dim3(8 * 64), 0, st,
-                           (const float*)voices->ptr, nvoices, stride, nframes, (const float2*)gains_lr->ptr, (float2*)bus_f32->ptr);
+        if (stream) hipLaunchKernelGGL((k_mix_bus_direct<8, 4, true>), sh::grid1d(nframes, 256 * 8), dim3(8 * 64), 0, st,
+                                       (const float*)voices->ptr, nvoices, stride, nframes, (const float2*)gains_lr->ptr, (float2*)bus_f32->ptr);
+        else hipLaunchKernelGGL((k_mix_bus_direct<8, 4, false>), sh::grid1d(nframes, 256 * 8), dim3(8 * 64), 0, st,
+                                (const float*)voices->ptr, nvoices, stride, nframes, (const float2*)gains_lr->ptr, (float2*)bus_f32->ptr);
         SH_CHECK_LAUNCH("k_mix_bus_direct");
         return SH_OK;
     }
     float2* parts = (float2*)sh::state().scratch;
     float2* dst = groups > 1 ? parts : (float2*)bus_f32->ptr;
-    hipLaunchKernelGGL(k_mix_bus_f32<W>, dim3(tiles, groups), dim3(W * 64), 0, st,
+    hipLaunchKernelGGL((k_mix_bus_f32<W, false>), dim3(tiles, groups), dim3(W * 64), 0, st,       // (plain loads: streaming ones gain nothing here)
                        (const float*)voices->ptr, nvoices, stride, nframes, (const float2*)gains_lr->ptr, vpg,
                        dst, (size_t)nframes);
     SH_CHECK_LAUNCH("k_mix_bus_f32");

@@ -94,11 +94,11 @@ __global__ __launch_bounds__(256) void k_quantize_f64_i16_vec(const double2v* __
 }
 
 // ---- audioop.add (no __restrict__: Sample.mix_at adds in place) ---------------------------------
-__global__ __launch_bounds__(256) void k_add_i16_vec(const short8v* a, const short8v* b,
-                                                     short8v* o, size_t nvec) {
+template <typename V, bool NT>
+__global__ __launch_bounds__(256) void k_add_vec(const V* a, const V* b, V* o, size_t nvec) {
     size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= nvec) return;
-    o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
+    o[i] = __builtin_elementwise_add_sat(sh::load_vec<NT, V>(a + i), sh::load_vec<NT, V>(b + i));     // NT (streaming sizes): +3 %
 }
 
 template <typename T>
@@ -109,19 +109,6 @@ __global__ __launch_bounds__(256) void k_add_scalar(const T* a, const T* b,
     o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
 }
 
-__global__ __launch_bounds__(256) void k_add_i32_vec(const int4v* a, const int4v* b,
-                                                     int4v* o, size_t nvec) {
-    size_t i = sh::block_id() * 256 + threadIdx.x;
-    if (i >= nvec) return;
-    o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
-}
-
-__global__ __launch_bounds__(256) void k_add_i8_vec(const char16v* a, const char16v* b,
-                                                    char16v* o, size_t nvec) {
-    size_t i = sh::block_id() * 256 + threadIdx.x;
-    if (i >= nvec) return;
-    o[i] = __builtin_elementwise_add_sat(a[i], b[i]);
-}
 
 // ---- mixer chain: mixed = add(...add(add(c0, c1), c2)..., c_{N-1}), saturating at every step ----
 // x -> clamp(x + s, lo, hi) composes into x -> clamp(x + a, L, U) (closed under composition), so
@@ -170,7 +157,7 @@ struct ChainFold {
 };
 
 // WAVES waves = (WAVES / COLS) voice ranges x COLS adjacent 1 KB columns: a workgroup visits COLS KB of a row at a time.
-template <int WAVES, int COLS>
+template <int WAVES, int COLS, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __restrict__ chunks, uint32_t nvoices,
                                                               size_t stride, uint32_t nsamples,
                                                               short* __restrict__ out) {
@@ -191,16 +178,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __res
     if (s0 < nsamples && v0 < v1) {
         if (vec) {
             uint32_t v = v0;
-            f.first(*reinterpret_cast<const short8v*>(chunks + (size_t)v * stride + s0));
+            f.first(sh::load_vec<NT, short8v>(chunks + (size_t)v * stride + s0));
             ++v;
             for (; v + 3 < v1; v += 4) {                  // four voice rows in flight
-                const short8v x0 = *reinterpret_cast<const short8v*>(chunks + (size_t)v * stride + s0);
-                const short8v x1 = *reinterpret_cast<const short8v*>(chunks + (size_t)(v + 1) * stride + s0);
-                const short8v x2 = *reinterpret_cast<const short8v*>(chunks + (size_t)(v + 2) * stride + s0);
-                const short8v x3 = *reinterpret_cast<const short8v*>(chunks + (size_t)(v + 3) * stride + s0);
+                const short8v x0 = sh::load_vec<NT, short8v>(chunks + (size_t)v * stride + s0);
+                const short8v x1 = sh::load_vec<NT, short8v>(chunks + (size_t)(v + 1) * stride + s0);
+                const short8v x2 = sh::load_vec<NT, short8v>(chunks + (size_t)(v + 2) * stride + s0);
+                const short8v x3 = sh::load_vec<NT, short8v>(chunks + (size_t)(v + 3) * stride + s0);
                 f.add(x0); f.add(x1); f.add(x2); f.add(x3);
             }
-            for (; v < v1; ++v) f.add(*reinterpret_cast<const short8v*>(chunks + (size_t)v * stride + s0));
+            for (; v < v1; ++v) f.add(sh::load_vec<NT, short8v>(chunks + (size_t)v * stride + s0));
         } else {
             for (uint32_t v = v0; v < v1; ++v) {
                 const short* row = chunks + (size_t)v * stride + s0;
@@ -241,7 +228,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __res
 // Long buffers: enough columns to fill the chip without splitting the voices, so a lane simply runs the reference's
 // loop -- mixed = add_sat(mixed, row) down all the rows, packed int16 -- and a workgroup walks WAVES KB of every row.
 // No fold state, no LDS; INFLIGHT independent row loads per lane.
-template <int WAVES, int INFLIGHT>
+template <int WAVES, int INFLIGHT, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_direct(const short* __restrict__ chunks, uint32_t nvoices, size_t stride,
                                                                  uint32_t nsamples, short* __restrict__ out) {
     const uint32_t s0 = (blockIdx.x * (WAVES * 64) + threadIdx.x) * 8;
@@ -253,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_direct(const short* __
         for (; v + INFLIGHT <= nvoices; v += INFLIGHT) {
             short8v x[INFLIGHT];
 #pragma unroll
-            for (int k = 0; k < INFLIGHT; ++k) x[k] = *reinterpret_cast<const short8v*>(col + (size_t)(v + k) * stride);
+            for (int k = 0; k < INFLIGHT; ++k) x[k] = sh::load_vec<NT, short8v>(col + (size_t)(v + k) * stride);     // NT: 0.81 -> 0.90 of the HBM peak on 2 GB
 #pragma unroll
             for (int k = 0; k < INFLIGHT; ++k) acc = __builtin_elementwise_add_sat(acc, x[k]);
         }
@@ -348,7 +335,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather(const ChainSrc*
 }
 
 // the direct loop over the pointer table (long samples: mix_samples of whole tracks)
-template <int WAVES, int INFLIGHT>
+template <int WAVES, int INFLIGHT, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather_direct(const ChainSrc* __restrict__ tab, uint32_t nsrc, uint32_t nsamples,
                                                                         short* __restrict__ out) {
     const uint32_t s0 = (blockIdx.x * (WAVES * 64) + threadIdx.x) * 8;
@@ -372,7 +359,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather_direct(const Ch
             for (int k = 0; k < INFLIGHT; ++k) whole = whole && wave_s0 + 512 <= c[k].n && (reinterpret_cast<uintptr_t>(c[k].p) & 15) == 0;
             if (whole) {
 #pragma unroll
-                for (int k = 0; k < INFLIGHT; ++k) x[k] = *reinterpret_cast<const short8v*>(c[k].p + s0);
+                for (int k = 0; k < INFLIGHT; ++k) x[k] = sh::load_vec<NT, short8v>(c[k].p + s0);
             } else {
 #pragma unroll
                 for (int k = 0; k < INFLIGHT; ++k) x[k] = chain_load8(c[k].p, c[k].n, s0);
@@ -503,7 +490,8 @@ __global__ __launch_bounds__(256) void k_resample(const T* __restrict__ in, T* _
 #pragma unroll
     for (int c = 0; c < VEC; ++c) res[c] = ratecv_sample<T, MODE>(prev[c], cur[c], d, A);
     const size_t out_at = (size_t)m * A.nch + (size_t)cg * VEC;
-    if (VEC == 1) out[out_at] = res[0]; else *reinterpret_cast<vec_t*>(out + out_at) = res;
+    // (streaming store: +4 % on the 8-channel rows; the frames-per-thread kernels below lose with it -- stereo float32 -14 %)
+    if (VEC == 1) out[out_at] = res[0]; else __builtin_nontemporal_store(res, reinterpret_cast<vec_t*>(out + out_at));
 }
 
 // Few channels (nch == VEC): one thread = FR consecutive output frames x all channels, so that the store
@@ -659,7 +647,8 @@ __global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in
     for (uint32_t v = threadIdx.x; v < span_vecs; v += 256) {
         const uint64_t e = lo_elem + (uint64_t)v * EPV;
         if (e + EPV <= total_elems) {
-            reinterpret_cast<ld_t*>(lds)[v] = *reinterpret_cast<const ld_t*>(in + e);
+            // streaming on both sides (input read once per workgroup, output never re-read): +1..3 % on the 16-bit rows
+            reinterpret_cast<ld_t*>(lds)[v] = __builtin_nontemporal_load(reinterpret_cast<const ld_t*>(in + e));
         } else {
             for (uint32_t k = 0; k < EPV; ++k) lds[v * EPV + k] = (e + k < total_elems) ? in[e + k] : (T)0;
         }
@@ -714,7 +703,7 @@ __global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in
         qe_elem += step_elem + (wrap ? (uint32_t)VEC : 0u);
     }
     if (m0 + FR <= out_frames) {
-        *reinterpret_cast<vec_t*>(out + m0 * VEC) = res;
+        __builtin_nontemporal_store(res, reinterpret_cast<vec_t*>(out + m0 * VEC));
     } else {
         for (int f = 0; f < FR && m0 + f < out_frames; ++f)
             for (int c = 0; c < VEC; ++c) out[(m0 + f) * VEC + c] = res[f * VEC + c];
@@ -827,9 +816,13 @@ static int pcm_add_dev(const char* a, const char* b, char* o, size_t nbytes, int
     size_t done = nvec * 16;
     if (nvec) {
         const dim3 grid = sh::grid1d(nvec, 256);
-        if (width == 2) hipLaunchKernelGGL(k_add_i16_vec, grid, dim3(256), 0, st, (const short8v*)a, (const short8v*)b, (short8v*)o, nvec);
-        else if (width == 4) hipLaunchKernelGGL(k_add_i32_vec, grid, dim3(256), 0, st, (const int4v*)a, (const int4v*)b, (int4v*)o, nvec);
-        else hipLaunchKernelGGL(k_add_i8_vec, grid, dim3(256), 0, st, (const char16v*)a, (const char16v*)b, (char16v*)o, nvec);
+        const bool stream = 2 * nbytes > sh::STREAM_BYTES;
+#define SH_ADD(V_) do { if (stream) hipLaunchKernelGGL((k_add_vec<V_, true>), grid, dim3(256), 0, st, (const V_*)a, (const V_*)b, (V_*)o, nvec); \
+                        else hipLaunchKernelGGL((k_add_vec<V_, false>), grid, dim3(256), 0, st, (const V_*)a, (const V_*)b, (V_*)o, nvec); } while (0)
+        if (width == 2) SH_ADD(short8v);
+        else if (width == 4) SH_ADD(int4v);
+        else SH_ADD(char16v);
+#undef SH_ADD
         SH_CHECK_LAUNCH("k_add_vec");
     }
     size_t rest = (nbytes - done) / width;
@@ -926,11 +919,16 @@ int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint
     // distant rows: 5.8); fewer -> split the voices over the waves of a workgroup for parallelism
     const uint32_t columns = (uint32_t)sh::div_up(nsamples, 512);
     const bool aligned = (stride & 7) == 0 && ((uintptr_t)chunks->ptr & 15) == 0 && ((uintptr_t)out->ptr & 15) == 0;
-#define SH_CHAIN(W_, C_) hipLaunchKernelGGL((k_mix_chain_i16<W_, C_>), sh::grid1d(nsamples, 512 * C_), dim3(W_ * 64), 0, st, \
+    const bool stream = (size_t)nvoices * nsamples * 2 > sh::STREAM_BYTES;           // rows beyond the Infinity Cache: streaming loads
+    // (the split kernel keeps plain loads: 1024 x 96 000 samples = 197 MB ran 13 % slower with streaming ones)
+#define SH_CHAIN(W_, C_) hipLaunchKernelGGL((k_mix_chain_i16<W_, C_, false>), sh::grid1d(nsamples, 512 * C_), dim3(W_ * 64), 0, st, \
                                             (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr)
-    if (columns >= 1536 && aligned)
-        hipLaunchKernelGGL((k_mix_chain_direct<8, 4>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
-                           (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
+    if (columns >= 1536 && aligned) {
+        if (stream) hipLaunchKernelGGL((k_mix_chain_direct<8, 4, true>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
+                                       (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
+        else hipLaunchKernelGGL((k_mix_chain_direct<8, 4, false>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
+                                (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
+    }
     else if (nvoices < 64) SH_CHAIN(2, 1);
     else if (columns >= 512) SH_CHAIN(8, 2);
     else SH_CHAIN(8, 1);
@@ -972,8 +970,13 @@ int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offs
     SH_HIP(hipMemcpyAsync(sh::state().scratch, tab.data(), tab.size() * sizeof(ChainSrc), hipMemcpyHostToDevice, st));
     const uint32_t n = (uint32_t)tab.size();
     dim3 grid(sh::div_up(nsamples, 512));
-    if (sh::div_up(nsamples, 512) >= 1536)
-        hipLaunchKernelGGL((k_mix_chain_gather_direct<8, 4>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
+    size_t read_bytes = 0;
+    for (const ChainSrc& c : tab) read_bytes += (size_t)c.n * 2;
+    if (sh::div_up(nsamples, 512) >= 1536 && read_bytes > sh::STREAM_BYTES)
+        hipLaunchKernelGGL((k_mix_chain_gather_direct<8, 4, true>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
+                           (const ChainSrc*)sh::state().scratch, n, nsamples, op);
+    else if (sh::div_up(nsamples, 512) >= 1536)
+        hipLaunchKernelGGL((k_mix_chain_gather_direct<8, 4, false>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
                            (const ChainSrc*)sh::state().scratch, n, nsamples, op);
     else if (n >= 64) hipLaunchKernelGGL(k_mix_chain_gather<8>, grid, dim3(8 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
     else hipLaunchKernelGGL(k_mix_chain_gather<2>, grid, dim3(2 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);

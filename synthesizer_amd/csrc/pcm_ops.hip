@@ -24,12 +24,12 @@ template <> struct Lim<short> { static constexpr double lo = -32768.0, hi = 3276
 template <> struct Lim<int> { static constexpr double lo = -2147483648.0, hi = 2147483647.0; };
 
 // out[i] = fbound(in[i] * factor)            (audioop.mul)
-template <typename T, int VEC>
+template <typename T, int VEC, bool NT = false>
 __global__ __launch_bounds__(256) void k_mul(const T* in, T* out, size_t nvec, double factor) {
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
     const size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= nvec) return;
-    vec_t v = reinterpret_cast<const vec_t*>(in)[i], r;
+    vec_t v = sh::load_vec<NT, vec_t>(reinterpret_cast<const vec_t*>(in) + i), r;       // NT (streaming sizes): +1 % (tomono: -1 %, left as it was)
 #pragma unroll
     for (int c = 0; c < VEC; ++c) r[c] = (T)fbound((double)v[c] * factor, Lim<T>::lo, Lim<T>::hi);
     reinterpret_cast<vec_t*>(out)[i] = r;
@@ -553,7 +553,8 @@ int sh_pcm_mul(const sh_buf* in, size_t in_off, size_t nbytes, int width, double
         constexpr int V = 16 / sizeof(T);
         const bool aligned = (((uintptr_t)ip | (uintptr_t)op) & 15) == 0;
         size_t nvec = aligned ? nbytes / 16 : 0, done = nvec * 16, rest = (nbytes - done) / sizeof(T);
-        if (nvec) hipLaunchKernelGGL((k_mul<T, V>), sh::grid1d(nvec, 256), dim3(256), 0, st, (const T*)ip, (T*)op, nvec, factor);
+        if (nvec && nbytes > sh::STREAM_BYTES) hipLaunchKernelGGL((k_mul<T, V, true>), sh::grid1d(nvec, 256), dim3(256), 0, st, (const T*)ip, (T*)op, nvec, factor);
+        else if (nvec) hipLaunchKernelGGL((k_mul<T, V, false>), sh::grid1d(nvec, 256), dim3(256), 0, st, (const T*)ip, (T*)op, nvec, factor);
         if (rest) hipLaunchKernelGGL((k_mul<T, 1>), sh::grid1d(rest, 256), dim3(256), 0, st, (const T*)(ip + done), (T*)(op + done), rest, factor);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? (int)SH_OK : sh::hip_error(e, "k_mul");
