@@ -374,7 +374,14 @@ class Oscillator:
                 want = min(want, limit - pos)
                 if want <= 0:
                     return
-            chunk = self.render_f64(want, start=pos)       # float64, like upstream's Python floats
+            try:
+                chunk = self.render_f64(want, start=pos)       # float64, like upstream's Python floats
+            except RuntimeError:
+                # a source that ends inside an envelope's phases (see EnvelopeFilter): upstream delivers every block before
+                # the one that needs the missing sample -- go on block by block until that one raises
+                if want <= bs:
+                    raise
+                chunk = self.render_f64(bs, start=pos)
             pos += len(chunk)
             values = chunk.tolist()
             for i in range(0, len(values), bs):
@@ -648,8 +655,9 @@ class EnvelopeFilter(Oscillator):
     def length(self) -> Optional[int]:
         if self._fused:
             return super().length
-        lens = [x for x in (self._gain.length, self._source.length) if x is not None]
-        return min(lens) if lens else None
+        # the envelope's own phases decide: attack .. release (+ the extra sample) with stop_at_end, endless silence
+        # after them without -- the source is not consulted once the release is over
+        return self._gain.length
 
     def _render_f64_device(self, start: int, n: int) -> N.DeviceBuffer:
         if self._fused:
@@ -657,11 +665,20 @@ class EnvelopeFilter(Oscillator):
         limit = self.length
         if limit is not None and start + n > limit:
             raise ValueError("stream ended before the requested range")
-        acc = self._source._render_f64_device(start, n)
-        gain = self._gain._render_f64_device(start, n)
-        N.check(N.lib().sh_ew_f64(N.SH_EW_MUL, acc.handle, 0, gain.handle, 0, n, 0.0, 0.0, acc.handle, 0, None, 0, None))
-        gain.free()
-        return acc
+        # upstream's generator pulls one source sample per envelope sample up to the end of the release (+ the extra
+        # sample) and none after; a source that ends inside that range ends the generator with next()'s StopIteration,
+        # which Python (PEP 479) hands to the consumer as RuntimeError
+        phases = self._gain.spec().env.length
+        n_src = max(0, min(start + n, phases) - start)
+        src_len = self._source.length
+        if src_len is not None and n_src and start + n_src > src_len:
+            raise RuntimeError("generator raised StopIteration")
+        gain = self._gain._render_f64_device(start, n)               # exactly 0.0 from the end of the phases on
+        if n_src:
+            src = self._source._render_f64_device(start, n_src)
+            N.check(N.lib().sh_ew_f64(N.SH_EW_MUL, src.handle, 0, gain.handle, 0, n_src, 0.0, 0.0, gain.handle, 0, None, 0, None))
+            src.free()
+        return gain
 
     def _render_device(self, start, n, out_host=None, out_f32=None, out_off=0, out_f64=None) -> None:
         if self._fused:

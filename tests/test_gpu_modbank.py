@@ -114,3 +114,53 @@ def test_envelope_over_filters_and_nested_envelopes_as_oscillators(gpu):
         # as someone's modulator and through the blocks() protocol
         blk_g, blk_o = next(g.blocks()), next(o.blocks())
         assert np.max(np.abs(np.array(blk_g) - np.array(blk_o))) <= 1e-12, k
+
+
+def test_envelope_over_a_source_that_ends(gpu):
+    """Upstream's EnvelopeFilter pulls one source sample per envelope sample up to the end of its release (+ the extra sample)
+    and none after.  A finite source that outlasts those phases does not end the stream (silence follows unless stop_at_end);
+    one that ends inside them ends the generator with next()'s StopIteration -- RuntimeError for the consumer (PEP 479), after
+    every complete block before the missing sample has been delivered."""
+    import itertools
+    from synthesizer_amd import oscillators as G
+    inner = lambda m, sustain: m.EnvelopeFilter(m.Sine(300.0, 0.7, samplerate=SR), 0.0, 0.01, sustain, 0.8, 0.01, stop_at_end=True)
+    # the source (0.12 s) outlasts the outer phases (0.06 s): the stream goes on as silence
+    make = lambda m: m.EnvelopeFilter(inner(m, 0.1), 0.01, 0.0, 0.03, 1.0, 0.02)
+    g, o = make(G), make(O)
+    n = 8000                                              # well past the end of the inner stream
+    want = np.array(o.take(n), dtype=np.float64)
+    got = g.render_f64(n, start=0)
+    assert g.length is None and len(got) == len(want) == n
+    assert np.max(np.abs(got - want)) <= 1e-12 and not got[int(0.061 * SR):].any() and got[100:200].any()
+    assert np.array_equal(g.render_f64(500, start=7000), np.zeros(500))           # random access beyond the source's end
+    # the source (0.03 s) ends inside the outer phases (0.12 s)
+    make = lambda m: m.EnvelopeFilter(inner(m, 0.01), 0.01, 0.0, 0.1, 1.0, 0.01)
+    g, o = make(G), make(O)
+    src_len = len(inner(O, 0.01).take(100000))
+    assert inner(G, 0.01).length == src_len
+    with pytest.raises(RuntimeError):
+        o.take(src_len + 1)
+    with pytest.raises(RuntimeError):
+        g.render_f64(src_len + 1, start=0)
+    upto = g.render_f64(src_len, start=0)                                         # up to the last sample the source has
+    whole = src_len // 512 * 512                                                  # (the oracle's take() pulls whole blocks)
+    assert len(upto) == src_len and np.max(np.abs(upto[:whole] - np.array(make(O).take(whole)))) <= 1e-12
+    # blocks(): the same whole blocks, then the same exception
+    def drain(osc):
+        out, it = [], osc.blocks()
+        try:
+            for blk in it:
+                out.append(blk)
+        except RuntimeError:
+            return out, True
+        return out, False
+    bg, raised_g = drain(make(G))
+    bo, raised_o = drain(make(O))
+    assert raised_g and raised_o and len(bg) == len(bo) == src_len // 512
+    assert np.max(np.abs(np.array(list(itertools.chain.from_iterable(bg))) - np.array(list(itertools.chain.from_iterable(bo))))) <= 1e-12
+    # as a voice of a bank: the same error when the launch needs the missing sample, none before
+    from synthesizer_amd.mixer import VoiceBank
+    bank = VoiceBank([make(G), G.Sine(100.0, 0.1, samplerate=SR)], gains=[(1.0, 0.0), (0.0, 1.0)])
+    assert bank.render(src_len, start=0)[:, 0].any()
+    with pytest.raises(RuntimeError):
+        bank.render(src_len + 10, start=0)
