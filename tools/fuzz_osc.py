@@ -89,6 +89,7 @@ bad = 0
 worst = 0.0
 recipes = []
 compared = refused = 0
+kinds = {}
 for case in range(cases):
     state = rng.bit_generator.state
     recipe = tree()
@@ -100,8 +101,10 @@ for case in range(cases):
             recipe(G).render_f64(n)
             print("case", case, "oracle raised", type(e).__name__, "but the GPU path rendered")
             bad += 1
-        except Exception:
+        except Exception as e2:
             refused += 1
+            if type(e2) is not type(e):
+                kinds[(type(e).__name__, type(e2).__name__)] = kinds.get((type(e).__name__, type(e2).__name__), 0) + 1
         continue
     got = recipe(G).render_f64(len(want) if len(want) < n else n)
     if len(got) != len(want):
@@ -120,6 +123,7 @@ for case in range(cases):
         bad += 1
     recipes.append(recipe)
     compared += 1
+print("exception types that differ (oracle, here):", kinds)
 print("graphs", cases, "compared", compared, "refused by both", refused, "mismatches", bad, "worst rms (continuous)", worst)
 
 # the same graphs as voices of a bank: bus against the oracle's float sum
