@@ -31,6 +31,8 @@
 
 namespace {
 
+constexpr int SEG_MAX = 24;            // segments of a transition launch
+
 struct BankPtrs {
     const sh_voice*   voices;
     const sh_segment* segs;
@@ -46,6 +48,16 @@ struct BankPtrs {
     size_t            row_stride;
     const int32_t*    fm_row;
     const int32_t*    pwm_row;
+    // per launch (a transition launch cut into segments, RENDER_*_SEG): segment s holds the launch's frames
+    // [seg_first[s], seg_first[s + 1]) and has a record set of its own (segment_set); nseg = 0 otherwise
+    uint32_t          nseg;
+    uint32_t          seg_first[SEG_MAX + 1];
+    // RENDER_GENERAL_SEG: the FIRST segment holds every voice (several piece ends per tile, sloped envelope) and a workgroup's
+    // walk through its group's list is the launch's critical path: there, gen_sub workgroups share a (tile, group) -- list
+    // entries dealt round robin -- and write float64 slices [(group * gen_sub + sub) * seg_first[1] + frame] of gen_scratch,
+    // which k_seg_combine adds in order into the group's general parts.  Later segments: sub 0 alone, straight into the parts.
+    uint32_t          gen_sub;
+    double2*          gen_scratch;
 };
 
 // Pointers to data that no thread of the running kernel writes are cast to the constant address space:
@@ -442,6 +454,13 @@ __global__ __launch_bounds__(64) void k_prepare_segments(BankPtrs B, LaunchSet b
     const uint32_t s = blockIdx.y;
     const uint32_t first = s * seg_frames;
     const uint32_t n = nframes - first < seg_frames ? nframes - first : seg_frames;
+    prepare_chunk(B, segment_set(base, s, nvoices), blockIdx.x, nvoices, start + first, n);
+}
+
+// The same for the unequal segments of a transition launch (B.seg_first): grid = (chunks, segments).
+__global__ __launch_bounds__(64) void k_prepare_segments_var(BankPtrs B, LaunchSet base, uint32_t nvoices, uint64_t start) {
+    const uint32_t s = blockIdx.y;
+    const uint32_t first = B.seg_first[s], n = B.seg_first[s + 1] - first;
     prepare_chunk(B, segment_set(base, s, nvoices), blockIdx.x, nvoices, start + first, n);
 }
 
@@ -1141,10 +1160,19 @@ __device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1
 // scratch; 37 instead of 42 us per block); the general kernel walks the general lists with four frames per lane, writes its
 // partial buses behind the lean kernel's (parts[groups + g]) and sets gen_valid[g] -- or, for a group without general voices
 // (the steady state of a note), leaves after one scalar load.  The fold adds the general parts whose flag is set.
-enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2, RENDER_LEAN_HARM_ONLY = 3, RENDER_GENERAL_ONLY = 4, RENDER_LEAN_ALL_ONLY = 5 };
-constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY; }
-constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY; }
-constexpr bool mode_has_lean(int mode) { return mode != RENDER_DIRECT && mode != RENDER_GENERAL_ONLY; }
+// RENDER_LEAN_HARM_SEG / RENDER_GENERAL_SEG: the split launch of a TRANSITION block (the first block of a note: the phase sum
+// runs through a dozen binades, the envelope through attack and decay) cut into segments with a record set each.  Piece ends
+// lie an octave apart (n = (2^k - t0) / inc), so a segment [a, b) with b <= 2a crosses at most one per voice -- which a lean
+// record handles -- where the launch as a whole crosses ten and sends every voice through the general code.  grid.x runs
+// over the tiles of all segments; a workgroup finds its segment first and from there on works in the segment's frame of
+// reference (records, tile, clamps); only its stores are launch-relative again.
+enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2, RENDER_LEAN_HARM_ONLY = 3, RENDER_GENERAL_ONLY = 4, RENDER_LEAN_ALL_ONLY = 5,
+       RENDER_LEAN_HARM_SEG = 6, RENDER_GENERAL_SEG = 7 };
+constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_HARM_SEG; }
+constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY || mode == RENDER_LEAN_HARM_SEG; }
+constexpr bool mode_general(int mode) { return mode == RENDER_GENERAL_ONLY || mode == RENDER_GENERAL_SEG; }
+constexpr bool mode_seg(int mode) { return mode == RENDER_LEAN_HARM_SEG || mode == RENDER_GENERAL_SEG; }
+constexpr bool mode_has_lean(int mode) { return mode != RENDER_DIRECT && !mode_general(mode); }
 template <int WAVES, int FPL, int MINW, int MODE>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                   uint32_t nvoices, uint32_t voices_per_group,
@@ -1160,7 +1188,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                                                                   uint32_t* __restrict__ prev_pcm16, double prev_pcm_scale,
                                                                   uint32_t* __restrict__ gen_valid,
                                                                   const uint32_t* __restrict__ prev_gen_valid) {
-    if constexpr (MODE == RENDER_GENERAL_ONLY) {
+    if constexpr (MODE == RENDER_GENERAL_ONLY) {       // (a segmented launch always writes its parts: see below)
         // a group without general voices in this launch: nothing to render, nothing to write (wave-uniform: scalar loads)
         const uint32_t c0g = (blockIdx.y * voices_per_group) / 64;
         uint32_t c1g = ((blockIdx.y + 1) * voices_per_group + 63) / 64;
@@ -1171,10 +1199,46 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         if (blockIdx.x == 0 && threadIdx.x == 0) gen_valid[blockIdx.y] = total ? 1u : 0u;
         if (total == 0) return;
     }
+    if constexpr (MODE == RENDER_GENERAL_SEG) {
+        // most (tile, group) pairs of a segmented launch hold no general voice: their parts are zeros, written before any set-up
+        // (the flags of a segmented launch say "every group's general parts are valid": its general voices are the first segment's)
+        // grid.x: the first segment's tiles gen_sub times over (tile-major), then the other segments' tiles
+        const uint32_t tiles_0 = (B.seg_first[1] - B.seg_first[0] + 64 * FPL - 1) / (64 * FPL);
+        uint32_t sidx = 0, tidx = blockIdx.x;
+        if (tidx >= tiles_0 * B.gen_sub) {
+            tidx -= tiles_0 * B.gen_sub;
+            sidx = 1;
+            for (;;) {
+                const uint32_t n_s = B.seg_first[sidx + 1] - B.seg_first[sidx];
+                const uint32_t tiles_s = (n_s + 64 * FPL - 1) / (64 * FPL);
+                if (tidx < tiles_s || sidx + 1 >= B.nseg) break;
+                tidx -= tiles_s;
+                ++sidx;
+            }
+        }
+        const uint32_t grp = blockIdx.y;
+        if (sidx > 0) {
+            const uint32_t nchs = (nvoices + 63) / 64;
+            const uint32_t c0g = (grp * voices_per_group) / 64;
+            uint32_t c1g = ((grp + 1) * voices_per_group + 63) / 64;
+            if (c1g > nchs) c1g = nchs;
+            const uint32_t SH_CONST_AS* cnt = as_const(cur.counts) + (size_t)sidx * 4 * nchs;
+            uint32_t total = 0;
+            for (uint32_t c = c0g; c < c1g; ++c) total += cnt[4 * c + 1];
+            if (total == 0) {
+                const uint32_t n_s = B.seg_first[sidx + 1] - B.seg_first[sidx];
+                for (uint32_t f = threadIdx.x; f < 64 * FPL; f += WAVES * 64) {
+                    const uint32_t raw = tidx * (64 * FPL) + f;
+                    if (raw < n_s) parts[(size_t)(gridDim.y + grp) * nframes + B.seg_first[sidx] + raw] = make_double2(0.0, 0.0);
+                }
+                return;
+            }
+        }
+    }
     // The previous launch of the stream (same shape) left its voice groups' partial buses unfolded: the workgroups of
     // group 0 fold their tile of it now, in group order, before their own work -- instead of a 5 us kernel between
     // every two render launches.
-    if (MODE != RENDER_GENERAL_ONLY && prev_parts && blockIdx.y == 0) {
+    if (!mode_general(MODE) && prev_parts && blockIdx.y == 0) {
         for (uint32_t f = threadIdx.x; f < 64 * FPL; f += WAVES * 64) {
             const uint32_t raw = blockIdx.x * (64 * FPL) + f;
             if (raw >= nframes) continue;
@@ -1204,7 +1268,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // kernel of its own (a 15 us kernel + a launch boundary per block otherwise).
     // The chunks of 64 voices are spread over the first workgroups (one wavefront each, on different CUs): a single
     // workgroup doing all of it competes with three rendering workgroups for its CU and ends up as the launch's tail.
-    if (MODE != RENDER_GENERAL_ONLY && next.launch) {
+    if (!mode_general(MODE) && next.launch) {
         const uint32_t nchunks = (nvoices + 63) / 64, nblocks = gridDim.x * gridDim.y;
         const uint32_t bid = blockIdx.y * gridDim.x + blockIdx.x;
         if (threadIdx.x < 64) {
@@ -1217,12 +1281,45 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile0 = blockIdx.x * (64 * FPL);
+    // a segmented launch: this workgroup's segment and its tile there (uniform); everything below up to the stores is
+    // relative to the segment.  Otherwise the launch is its own single segment.
+    uint32_t seg_off = 0, nfr = nframes, tile_index = blockIdx.x;
+    uint64_t st0 = start;
+    LaunchSet curS = cur;
+    uint32_t sub = 0, nsub = 1;
+    bool to_scratch = false;
+    if constexpr (mode_seg(MODE)) {
+        uint32_t sidx = 0;
+        if constexpr (MODE == RENDER_GENERAL_SEG) {
+            const uint32_t tiles_0 = (B.seg_first[1] - B.seg_first[0] + 64 * FPL - 1) / (64 * FPL);
+            if (tile_index < tiles_0 * B.gen_sub) {            // the first segment: gen_sub workgroups per (tile, group)
+                sub = tile_index % B.gen_sub;
+                tile_index /= B.gen_sub;
+                nsub = B.gen_sub;
+                to_scratch = true;
+            } else {
+                tile_index -= tiles_0 * (B.gen_sub - 1);       // as if the first segment's tiles came once
+            }
+        }
+        for (;;) {
+            const uint32_t n_s = B.seg_first[sidx + 1] - B.seg_first[sidx];
+            const uint32_t tiles_s = (n_s + 64 * FPL - 1) / (64 * FPL);
+            if (tile_index < tiles_s || sidx + 1 >= B.nseg) break;
+            tile_index -= tiles_s;
+            ++sidx;
+        }
+        seg_off = B.seg_first[sidx];
+        nfr = B.seg_first[sidx + 1] - seg_off;
+        st0 = start + seg_off;
+        curS = segment_set(cur, sidx, nvoices);
+    }
+    const uint32_t grp = blockIdx.y;                           // the voice group of this workgroup
+    const uint32_t tile0 = tile_index * (64 * FPL);
     uint32_t tile_last = tile0 + 64 * FPL - 1;
-    if (tile_last > nframes - 1) tile_last = nframes - 1;
+    if (tile_last > nfr - 1) tile_last = nfr - 1;
     // this group's voices: chunks [c0, c1) of 64 voices (voices_per_group is a multiple of 64 unless there is one group)
-    const uint32_t c0 = (blockIdx.y * voices_per_group) / 64;
-    uint32_t c1 = ((blockIdx.y + 1) * voices_per_group + 63) / 64;
+    const uint32_t c0 = (grp * voices_per_group) / 64;
+    uint32_t c1 = ((grp + 1) * voices_per_group + 63) / 64;
     const uint32_t nchunks = (nvoices + 63) / 64;
     if (c1 > nchunks) c1 = nchunks;
     uint32_t i[FPL];
@@ -1239,7 +1336,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
             uint32_t raw = tile0 + j * 64 + lane_;
-            i[j] = raw < nframes ? raw : nframes - 1;
+            i[j] = raw < nfr ? raw : nfr - 1;
             di[j] = (double)i[j];
         }
     };
@@ -1248,21 +1345,21 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         const uint32_t v0 = blockIdx.y * voices_per_group;
         uint32_t v1 = v0 + voices_per_group;
         if (v1 > nvoices) v1 = nvoices;
-        const VoiceLaunch SH_CONST_AS* rp = as_const(cur.launch) + v0 + wave;
+        const VoiceLaunch SH_CONST_AS* rp = as_const(curS.launch) + v0 + wave;
         for (uint32_t vi = v0 + wave; vi < v1; vi += WAVES, rp += WAVES) {
             const VoiceRegs r = load_record(rp);
             if (r.flags & FL_SILENT) continue;       // the note was released before this block: contributes exact zeros
-            general_voice<FPL>(r, cur.fm + vi, B, B.voices + vi, start, tile0, nframes, i, di, trig, accl, accr);
+            general_voice<FPL>(r, curS.fm + vi, B, B.voices + vi, st0, tile0, nfr, i, di, trig, accl, accr);
         }
     } else {
     // ---- fast voices: one table lookup, FPL-1 rotations, the Horner chains, two accumulations per frame ----
     // Wave w takes every WAVES-th list entry; the offset carries over from chunk to chunk so that the waves'
     // shares of the whole group differ by at most one voice.
-    uint32_t first = wave;                                    // position in the current chunk's list this wave starts at
-    if constexpr (MODE != RENDER_GENERAL_ONLY) {
+    uint32_t first = wave + sub * WAVES;                      // position in the current chunk's list this wave starts at
+    if constexpr (!mode_general(MODE)) {
     for (uint32_t c = c0; c < c1; ++c) {
-        const uint32_t nfast = as_const(cur.counts)[4 * c];
-        const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64 + first;
+        const uint32_t nfast = as_const(curS.counts)[4 * c];
+        const FastRec SH_CONST_AS* q = as_const(curS.fast) + c * 64 + first;
         uint32_t p = first;
         for (; p < nfast; p += WAVES, q += WAVES) {
             // the common 192 bytes in ONE batch of scalar loads: the empty asm makes these fields live here, so the
@@ -1281,10 +1378,21 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             // Every lean kind works from the lane's FIRST frame alone (no per-frame index arrays): the piece of the phase table
             // (first / second of the launch) is chosen by scalar selects, the one tile per crossing that straddles the piece end by
             // a uniform flag, and the frames follow 64 samples apart.
-            const uint32_t i0 = tile0 + lane;                         // the lane's first frame (< nframes + 64: harmless)
+            const uint32_t i0 = tile0 + lane;                         // the lane's first frame (< nfr + 64: harmless)
             const double di0 = (double)i0;
             double t_base = ta, dt = da, rc = rca, rs = rsa, off = 0.0, tb = ta, db = da, ob = 0.0;
             bool straddle = false;
+            if constexpr (MODE == RENDER_LEAN_HARM_SEG) {
+                // a segment is cut so that (nearly) every voice crosses ONE piece end in it: half the tiles lie behind it, and the
+                // second piece's fields belong in the first batch of loads (one round trip per record, not two)
+                const double tb2 = q->t0_b, db2 = q->dt_b, ob2 = q->off_b, rcb = q->rot_c_b, rsb = q->rot_s_b;
+                asm volatile("" :: "s"(tb2), "s"(db2), "s"(ob2), "s"(rcb), "s"(rsb));
+                if (remain != 0xFFFFFFFFu && tile_last >= remain) {
+                    tb = tb2; db = db2; ob = ob2;
+                    straddle = tile0 < remain;
+                    if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
+                }
+            } else
             if (remain != 0xFFFFFFFFu && tile_last >= remain) {       // not wholly on the first piece
                 tb = q->t0_b; db = q->dt_b; ob = q->off_b;
                 const double rcb = q->rot_c_b, rsb = q->rot_s_b;
@@ -1387,15 +1495,16 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     }
     if constexpr (!mode_lean_only(MODE)) {
     for (uint32_t c = c0; c < c1; ++c) {
-        const uint32_t ngen = as_const(cur.counts)[4 * c + 1];
-        const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
+        const uint32_t ngen = as_const(curS.counts)[4 * c + 1];
+        const uint32_t SH_CONST_AS* idx = as_const(curS.gen_idx) + c * 64;
+        const uint32_t step = WAVES * nsub;                        // (nsub > 1: the first segment of a general segmented launch)
         uint32_t p = first;
         uint32_t vi_next = p < ngen ? idx[p] : 0u;
-        for (; p < ngen; p += WAVES) {
+        for (; p < ngen; p += step) {
             const uint32_t vi = vi_next;
-            vi_next = p + WAVES < ngen ? idx[p + WAVES] : 0u;       // in flight with this voice's record: one round trip less
-            const VoiceRegs r = load_record(as_const(cur.launch) + vi);
-            general_voice<FPL>(r, cur.fm + vi, B, B.voices + vi, start, tile0, nframes, i, di, trig, accl, accr);
+            vi_next = p + step < ngen ? idx[p + step] : 0u;       // in flight with this voice's record: one round trip less
+            const VoiceRegs r = load_record(as_const(curS.launch) + vi);
+            general_voice<FPL>(r, curS.fm + vi, B, B.voices + vi, st0, tile0, nfr, i, di, trig, accl, accr);
         }
         first = p - ngen;
     }
@@ -1411,23 +1520,40 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     for (uint32_t row = wave; row < (uint32_t)FPL; row += WAVES) {
         const uint32_t f = row * 64 + lane;
         const uint32_t raw = tile0 + f;
-        if (raw < nframes) {
+        if (raw < nfr) {
             double l = red[0][0][f], rr = red[0][1][f];
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) {
                 l += red[w][0][f];
                 rr += red[w][1][f];
             }
-            if (parts) {
-                const uint32_t slot = MODE == RENDER_GENERAL_ONLY ? gridDim.y + blockIdx.y : blockIdx.y;
-                parts[(size_t)slot * nframes + raw] = make_double2(l, rr);
+            const size_t at = (size_t)seg_off + raw;            // launch-relative frame
+            if (MODE == RENDER_GENERAL_SEG && to_scratch) {
+                B.gen_scratch[(size_t)(grp * nsub + sub) * nfr + raw] = make_double2(l, rr);
+            } else if (parts) {
+                const uint32_t slot = mode_general(MODE) ? gridDim.y + grp : grp;
+                parts[(size_t)slot * nframes + at] = make_double2(l, rr);
             } else {
-                if (bus32) bus32[raw] = make_float2((float)l, (float)rr);
-                if (bus64) bus64[raw] = make_double2(l, rr);
-                if (pcm16) pcm16[raw] = pcm16_frame(l, rr, pcm_scale);
+                if (bus32) bus32[at] = make_float2((float)l, (float)rr);
+                if (bus64) bus64[at] = make_double2(l, rr);
+                if (pcm16) pcm16[at] = pcm16_frame(l, rr, pcm_scale);
             }
         }
     }
+}
+
+// The first segment of a general segmented launch: its nsub slices per group, added in order into the group's general parts.
+__global__ __launch_bounds__(256) void k_seg_combine(const double2* __restrict__ scratch, uint32_t nsub, uint32_t n0,
+                                                     double2* __restrict__ gen_parts, uint32_t nframes) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (f >= n0) return;
+    double2 acc = scratch[(size_t)(g * nsub) * n0 + f];
+    for (uint32_t k = 1; k < nsub; ++k) {
+        const double2 x = scratch[(size_t)(g * nsub + k) * n0 + f];
+        acc.x += x.x;
+        acc.y += x.y;
+    }
+    gen_parts[(size_t)g * nframes + f] = acc;
 }
 
 __global__ __launch_bounds__(256) void k_bus_combine(const double2* __restrict__ parts, uint32_t ngroups, uint32_t nframes,
@@ -1792,6 +1918,10 @@ struct sh_bank {
     int         npending = 0;
     void*       parts_buf[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t      parts_bytes[4] = {0, 0, 0, 0};
+    LaunchSet   seg_set[2] = {};           // record sets of a segmented transition launch (one per stream), seg_cap[k] segments each
+    uint32_t    seg_cap[2] = {0, 0};
+    void*       seg_scratch[2] = {nullptr, nullptr};   // ... and the slices of its first segment's general parts (BankPtrs::gen_scratch)
+    size_t      seg_scratch_bytes[2] = {0, 0};
     // modulation rows (sh_bank_set_rows / sh_bank_render_rows)
     int32_t*    d_fm_row = nullptr;
     int32_t*    d_pwm_row = nullptr;
@@ -1854,6 +1984,10 @@ static BankPtrs ptrs(const sh_bank* b) {
     p.row_stride = b->launch_row_stride;
     p.fm_row = b->d_fm_row;
     p.pwm_row = b->d_pwm_row;
+    p.nseg = 0;
+    for (int k = 0; k <= SEG_MAX; ++k) p.seg_first[k] = 0;
+    p.gen_sub = 1;
+    p.gen_scratch = nullptr;
     return p;
 }
 
@@ -2041,6 +2175,11 @@ int sh_bank_destroy(sh_bank* b) {
         if (sh::has_pending()) (void)sh::flush_pending();
         (void)hipStreamSynchronize(sh::state().stream);
         for (int k = 0; k < 4; ++k) if (b->parts_buf[k]) (void)hipFree(b->parts_buf[k]);
+        for (int k = 0; k < 2; ++k) {
+            LaunchSet& g = b->seg_set[k];
+            if (g.launch) { (void)hipFree(g.launch); (void)hipFree(g.fm); (void)hipFree(g.fast); (void)hipFree(g.gen_idx); (void)hipFree(g.counts); }
+            if (b->seg_scratch[k]) (void)hipFree(b->seg_scratch[k]);
+        }
         if (b->d_voices) (void)hipFree(b->d_voices);
         if (b->d_segs) (void)hipFree(b->d_segs);
         if (b->d_coefs) (void)hipFree(b->d_coefs);
@@ -2372,13 +2511,47 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     hipStream_t st = use_aux ? S.stream2 : S.stream;
     if (use_aux && n == 1) SH_HIP(hipStreamWaitEvent(S.stream2, S.ev_join, 0));
     const int prev_cur = b->cur;
-    rc = acquire_records(b, start, nframes, st, cont);
-    if (rc) return rc;
     // a bank with lean candidates + several voice groups: the launch is split into a lean and a general kernel
     // (see the RENDER_* modes); SYNTHHIP_NO_SPLIT=1 keeps the combined kernel
     static int no_split = -1;
     if (no_split < 0) { const char* e = getenv("SYNTHHIP_NO_SPLIT"); no_split = (e && e[0] == '1') ? 1 : 0; }
     const bool split = mode != RENDER_DIRECT && groups > 1 && !no_split;
+    // A transition launch (RENDER_*_SEG): cut where the envelopes become flat (every voice past its decay) and from there on
+    // into segments no longer than their own distance from the note's start -- piece ends of the phase sum lie an octave apart,
+    // so such a segment crosses at most one per voice; a cut, too, where the first voice leaves its sustain.  Tile-aligned cuts.
+    uint32_t seg_first[SEG_MAX + 1];
+    uint32_t nseg = 0;
+    {
+        static int no_seg = -1;
+        if (no_seg < 0) { const char* e = getenv("SYNTHHIP_NO_SEG"); no_seg = (e && e[0] == '1') ? 1 : 0; }
+        const uint64_t end = start + nframes;
+        if (split && mode == RENDER_LEAN_HARM && var == 484 && b->all_lean && !no_seg && !b->needs_rows && !b->no_general_voice(start, nframes)) {
+            const uint64_t T = (uint64_t)(64 * F);
+            uint64_t cuts[SEG_MAX + 2];
+            uint32_t nc = 0;
+            uint64_t pos = start;
+            cuts[nc++] = pos;
+            const uint64_t flat = b->env_flat_from, rel = b->env_flat_until;       // last decay end, first sustain end
+            if (pos < flat && flat < end) { pos = flat; cuts[nc++] = pos; }
+            bool ok = true;
+            while (ok && pos < end) {
+                uint64_t next = pos < T ? T : 2 * pos;                             // at most one piece end per voice in [pos, 2 pos)
+                if (pos < rel && rel < next) next = rel;
+                if (next >= end || end - next <= next / 64) next = end;            // (a very short rest joins the last segment)
+                if (nc > SEG_MAX) { ok = false; break; }
+                pos = next;
+                cuts[nc++] = pos;
+            }
+            if (ok && nc >= 3) {
+                nseg = nc - 1;
+                for (uint32_t k = 0; k < nc; ++k) seg_first[k] = (uint32_t)(cuts[k] - start);
+            }
+        }
+    }
+    if (nseg == 0) {
+        rc = acquire_records(b, start, nframes, st, cont);
+        if (rc) return rc;
+    }
     // partial buses: ring slot n % 4 (last read by the fold in launch n - 2, which is this stream's previous launch)
     double2* parts = nullptr;
     if (groups > 1) {
@@ -2432,6 +2605,64 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     LaunchSet next = launch_set(b, target < 0 ? 0 : target);
     if (target < 0) next.launch = nullptr;
     if ((debug & 1) && n >= 8) next.launch = nullptr;
+    if (nseg) {
+        const int ks = use_aux ? 1 : 0;
+        const uint32_t nchunks = sh::div_up(b->nvoices, 64);
+        LaunchSet& g = b->seg_set[ks];
+        if (b->seg_cap[ks] < nseg) {
+            SH_HIP(hipStreamSynchronize(S.stream));
+            SH_HIP(hipStreamSynchronize(S.stream2));
+            if (g.launch) { (void)hipFree(g.launch); (void)hipFree(g.fm); (void)hipFree(g.fast); (void)hipFree(g.gen_idx); (void)hipFree(g.counts); g = LaunchSet(); }
+            b->seg_cap[ks] = 0;
+            const size_t cap = SEG_MAX;
+            SH_HIP(hipMalloc((void**)&g.launch, sizeof(VoiceLaunch) * cap * b->nvoices));
+            SH_HIP(hipMalloc((void**)&g.fm, sizeof(VoiceFM) * cap * b->nvoices));
+            SH_HIP(hipMalloc((void**)&g.fast, sizeof(FastRec) * cap * b->nvoices));
+            SH_HIP(hipMalloc((void**)&g.gen_idx, sizeof(uint32_t) * cap * b->nvoices));
+            SH_HIP(hipMalloc((void**)&g.counts, sizeof(uint32_t) * 4 * cap * nchunks));
+            b->seg_cap[ks] = SEG_MAX;
+        }
+        BankPtrs P = ptrs(b);
+        P.nseg = nseg;
+        for (uint32_t k = 0; k <= nseg; ++k) P.seg_first[k] = seg_first[k];
+        hipLaunchKernelGGL(k_prepare_segments_var, dim3(nchunks, nseg), dim3(64), 0, st, P, g, b->nvoices, start);
+        SH_CHECK_LAUNCH("k_prepare_segments_var");
+        uint32_t tiles_lean = 0, tiles_gen = 0;
+        for (uint32_t k = 0; k < nseg; ++k) {
+            tiles_lean += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 8);
+            tiles_gen += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 4);
+        }
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_HARM_SEG>), dim3(tiles_lean, groups), dim3(256), 0, st, P,
+                           trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen);
+        SH_CHECK_LAUNCH("k_bank_render(lean, segments)");
+        SH_HIP(hipMemsetAsync(gen_valid, 1, (size_t)groups * sizeof(uint32_t), st));         // every group's general parts are written
+        // the first segment's groups are split SUB ways (BankPtrs::gen_sub): with sixteen waves per workgroup a wave walks two
+        // or three of the 128 voices of its group
+        static uint32_t SUB = 0;
+        if (!SUB) { const char* e = getenv("SYNTHHIP_GEN_SUB"); SUB = e ? (uint32_t)atoi(e) : 4u; if (SUB < 1 || SUB > 16) SUB = 4; }
+        const uint32_t n0 = seg_first[1];
+        const size_t scratch_need = (size_t)groups * SUB * n0 * sizeof(double2);
+        if (b->seg_scratch_bytes[ks] < scratch_need) {
+            SH_HIP(hipStreamSynchronize(S.stream));
+            SH_HIP(hipStreamSynchronize(S.stream2));
+            if (b->seg_scratch[ks]) { (void)hipFree(b->seg_scratch[ks]); b->seg_scratch[ks] = nullptr; b->seg_scratch_bytes[ks] = 0; }
+            SH_HIP(hipMalloc(&b->seg_scratch[ks], scratch_need));
+            b->seg_scratch_bytes[ks] = scratch_need;
+        }
+        P.gen_sub = SUB;
+        P.gen_scratch = (double2*)b->seg_scratch[ks];
+        LaunchSet none = g;
+        none.launch = nullptr;
+        hipLaunchKernelGGL((k_bank_render<16, 4, 1, RENDER_GENERAL_SEG>), dim3(tiles_gen + (SUB - 1) * sh::div_up(n0, 64 * 4), groups), dim3(1024), 0, st, P,
+                           trig_table(), b->nvoices, vpg, g, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
+                           (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
+                           gen_valid, (const uint32_t*)nullptr);
+        SH_CHECK_LAUNCH("k_bank_render(general, segments)");
+        hipLaunchKernelGGL(k_seg_combine, dim3(sh::div_up(n0, 256), groups), dim3(256), 0, st, (const double2*)b->seg_scratch[ks], SUB, n0,
+                           parts + (size_t)groups * nframes, nframes);
+        SH_CHECK_LAUNCH("k_seg_combine");
+    } else {
 #define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
     hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),    \
                        trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64, \
@@ -2473,6 +2704,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
                            (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
                            gen_valid, (const uint32_t*)nullptr);
         SH_CHECK_LAUNCH("k_bank_render(general lists)");
+    }
     }
     if (use_aux) {
         SH_HIP(hipEventRecord(S.ev_aux, S.stream2));

@@ -79,6 +79,82 @@ def test_split_launch_equals_combined_kernel_and_oracle(gpu, tmp_path):
     assert np.sqrt(np.mean((got - bus) ** 2)) <= 1e-6 / 3
 
 
+_CHILD_SEG = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_split import transition_bank, TRANSITION_BLOCKS
+from synthesizer_amd.mixer import VoiceBank
+voices, gains = transition_bank()
+bank = VoiceBank(voices, gains=gains)
+out = {}
+for n, start in TRANSITION_BLOCKS:
+    out["%%d_%%d" %% (n, start)] = bank.render(n, start=start)
+buf = bank.render_pcm_device(48000, 0)
+out["pcm"] = buf.download(np.int16, 96000)
+np.savez(sys.argv[1], **out)
+"""
+
+# attack and decay in block 0, the first releases in the block that starts at 2 s, silence after; a ragged block, a block
+# from the middle of the attack, a long one over everything (cut into launches of 2^22 frames AND into segments)
+TRANSITION_BLOCKS = [(48000, 0), (48000, 48000), (48000, 96000), (48000, 144000), (30001, 1234), (20000, 100000), (16384, 0),
+                     (200000, 0), (5000000, 0)]
+
+
+def transition_bank():
+    """384 additive voices; most share one ADSR, some leave their sustain earlier or decay longer, some start with a negative
+    phase (their phase sum passes zero: piece ends that do not lie an octave apart)."""
+    from synthesizer_amd import oscillators as G
+    v, g = additive_voices(G, 384, SR, seed=12, adsr={"sustain": 2.0})
+    harm = [(k, 1.0 / k) for k in range(1, 17)]
+    for i in (7, 130, 383):
+        v[i] = G.EnvelopeFilter(G.Harmonics(200.0 + i, harm, amplitude=0.01, phase=-0.4, samplerate=SR), 0.01, 0.05, 2.0, 0.6, 0.2)
+    v[50] = G.EnvelopeFilter(G.Harmonics(321.0, harm, amplitude=0.01, samplerate=SR), 0.02, 0.3, 1.2, 0.5, 0.1)      # longer decay, earlier release
+    v[51] = G.EnvelopeFilter(G.Harmonics(123.4, harm, amplitude=0.01, samplerate=SR), 0.0, 0.0, 0.7, 1.0, 0.05)      # no attack, released at 0.7 s
+    return v, g
+
+
+def test_segmented_transition_launches(gpu, tmp_path):
+    """The first block of a note as a segmented launch (RENDER_LEAN_HARM_SEG / RENDER_GENERAL_SEG: one batched prepare, the lean
+    kernel over all segments, the general kernel with the first segment's groups split further and k_seg_combine) against the
+    same launches unsegmented (SYNTHHIP_NO_SEG=1: every voice through the general code) and against the C oracle."""
+    from oracle import c_oracle as CO
+    from oracle import synth_oracle as O
+    from synthesizer_amd.mixer import VoiceBank
+    ref = tmp_path / "noseg.npz"
+    env = dict(os.environ, SYNTHHIP_NO_SEG="1")
+    p = subprocess.run([sys.executable, "-c", _CHILD_SEG % str(ROOT), str(ref)], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    want = np.load(ref)
+    voices, gains = transition_bank()
+    bank = VoiceBank(voices, gains=gains)
+    for n, start in TRANSITION_BLOCKS:
+        got = bank.render(n, start=start)
+        w = want["%d_%d" % (n, start)]
+        scale = max(1e-3, float(np.max(np.abs(w))))
+        assert np.max(np.abs(got.astype(np.float64) - w)) <= 1.3e-7 * scale, (n, start)
+        assert np.mean(got != w) < 2e-3, (n, start, float(np.mean(got != w)))
+    pcm = bank.render_pcm_device(48000, 0).download(np.int16, 96000)
+    assert np.max(np.abs(pcm.astype(np.int32) - want["pcm"].astype(np.int32))) <= 1 and np.mean(pcm != want["pcm"]) < 2e-3
+    # a run that starts with the segmented launch and goes on: blocks 0 .. 5 pipelined == the blocks one by one
+    from synthesizer_amd import _native as N
+    bufs = [N.DeviceBuffer(48000 * 8) for _ in range(6)]
+    for k in range(6):
+        bank.render_device(48000, k * 48000, bus_f32=bufs[k])
+    for k in range(6):
+        got = bufs[k].download(np.float32, 96000).reshape(48000, 2)
+        assert np.array_equal(got, bank.render(48000, start=k * 48000)), k
+    # the oracle on the first block and on the block of the releases: 48 of the voices, four times each
+    ov, _ = additive_voices(O, 384, SR, seed=12, adsr={"sustain": 2.0})
+    keep = [k for k in range(0, 384, 8) if k not in (7, 50, 51, 130, 383)]
+    small = VoiceBank([voices[k] for k in keep] * 4, gains=[gains[k] for k in keep] * 4)
+    rows = np.stack([CO.render(ov[k], 144000) for k in keep])
+    bus = np.array(CO.mix_bus(rows, [gains[k] for k in keep]), dtype=np.float64) * 4.0
+    for n, start in ((48000, 0), (48000, 96000)):
+        got = small.render(n, start=start)
+        assert np.abs(bus[start:start + n]).max() > 1e-3
+        assert np.sqrt(np.mean((got - bus[start:start + n]) ** 2)) <= 1e-6 / 3, (n, start)
+
+
 def test_segmented_materialisation_of_long_rows(gpu):
     """sh_bank_generate over rows longer than one 65 536-frame segment: one record set per segment from ONE prepare launch,
     the lean Harmonics kernel over all of them, the general / silent lists per segment where they can exist."""
