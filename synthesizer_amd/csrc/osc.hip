@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "devmath.hpp"
 #include <new>
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 #include <stdlib.h>
@@ -137,7 +138,8 @@ struct alignas(64) FastRec {
     double t0_b, dt_b;            // frames i >= remain: t(i) = fma(i - remain, dt_b, t0_b)
     double rot_c_b, rot_s_b;      // cos / sin of 64*dt_b
     // ---- k_generate_lists ----
-    double amplitude, g0u;        // unfolded: the voice's own sample is ((x * amplitude) + 0) * g0u
+    double amplitude, g0u;        // unfolded: the voice's own sample is ((x * amplitude) + 0) * g0u.  In the record sets of a
+                                  // segmented launch (prepare_chunk<true>): the slopes of gain_l / gain_r per frame instead
     uint32_t vi;                  // the voice
     uint32_t pad1;
     double pad2;
@@ -181,9 +183,13 @@ struct PrepInfo {                 // what prepare_voice found, for the classific
     uint32_t kind;                // LEAN_HARM / LEAN_FM
     double   amplitude, g0u, pulsewidth;
     double   fmv[11];             // LEAN_FM: the values that go to FastRec::poly[0..10]
+    double   slope_l, slope_r;    // a record set of sloped lean records (SLOPED): gain(i) = gain + i * slope on the envelope's line
     const double* harm;
 };
 
+// SLOPED (the record sets of a segmented transition launch): a polynomial-Harmonics voice on ONE envelope line of any slope is
+// lean too -- its record carries the line folded into the bus gains (gain + i * slope) -- not only one on a constant gain.
+template <bool SLOPED = false>
 __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first, uint32_t vi, uint64_t start, uint32_t nframes,
                                               VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm, PrepInfo& info) {
     // Fields are stored straight to the record (no local struct: a 368-byte private array would give
@@ -332,7 +338,17 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     // lean: the launch lies on the current table piece, or on it and the next one
     const bool one_piece = rem >= (uint64_t)nframes;
     const bool two_pieces = !one_piece && lo + 1 < cnt && ((lo + 2 < cnt) ? (tab[lo + 2].n0 - start >= (uint64_t)nframes) : true);
-    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm || lean_plain) && (one_piece || two_pieces);
+    bool lean_sloped = false;
+    info.slope_l = 0.0;
+    info.slope_r = 0.0;
+    if (SLOPED && (flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT | FL_ENV_UNIFORM)) == (FL_POLY | FL_ENV_UNIFORM) && v.bias == 0.0 && !v.flip) {
+        lean_sloped = true;                               // (not FL_FOLDED: slu != 0)
+        gain_l = (v.amplitude * g0u) * (double)v.gain_l;
+        gain_r = (v.amplitude * g0u) * (double)v.gain_r;
+        info.slope_l = (v.amplitude * slu) * (double)v.gain_l;
+        info.slope_r = (v.amplitude * slu) * (double)v.gain_r;
+    }
+    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm || lean_plain || lean_sloped) && (one_piece || two_pieces);
     info.remain = one_piece ? 0xFFFFFFFFu : (uint32_t)rem;
     info.t0_b = one_piece ? t_base : tab[lo + 1].t0;
     info.dt_b = one_piece ? dt : tab[lo + 1].dt;
@@ -378,6 +394,7 @@ __global__ void k_prepare(BankPtrs B, uint32_t first, uint32_t nvoices, uint64_t
 // One wavefront resolves the launch records of one chunk of 64 consecutive voices (lane = voice) and classifies them
 // (see LaunchSet); positions in the chunk's compacted lists come from wave ballots -- no inter-thread memory traffic,
 // no barrier, chunks are independent of each other.
+template <bool SLOPED = false>
 __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet& S, uint32_t c, uint32_t nvoices,
                                               uint64_t start, uint32_t nframes) {
     const uint32_t lane = threadIdx.x & 63;
@@ -385,7 +402,7 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
     PrepInfo info;
     info.fast = false;
     info.silent = true;
-    if (vi < nvoices) prepare_voice(B, 0u, vi, start, nframes, S.launch, S.fm, info);
+    if (vi < nvoices) prepare_voice<SLOPED>(B, 0u, vi, start, nframes, S.launch, S.fm, info);
     const bool is_fast = vi < nvoices && info.fast;
     const bool is_gen = vi < nvoices && !info.fast && !info.silent;
     const uint64_t mf = __ballot(is_fast), mg = __ballot(is_gen);
@@ -410,8 +427,8 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         f->off_b = (double)info.remain;
         f->remain = info.remain;
         f->kind = info.kind;
-        f->amplitude = info.amplitude;
-        f->g0u = info.g0u;
+        f->amplitude = SLOPED ? info.slope_l : info.amplitude;        // (SLOPED sets are read by RENDER_LEAN_HARM_SEG only)
+        f->g0u = SLOPED ? info.slope_r : info.g0u;
         f->vi = vi;
         f->pad1 = 0;
         f->pad2 = 0.0;
@@ -461,7 +478,7 @@ __global__ __launch_bounds__(64) void k_prepare_segments(BankPtrs B, LaunchSet b
 __global__ __launch_bounds__(64) void k_prepare_segments_var(BankPtrs B, LaunchSet base, uint32_t nvoices, uint64_t start) {
     const uint32_t s = blockIdx.y;
     const uint32_t first = B.seg_first[s], n = B.seg_first[s + 1] - first;
-    prepare_chunk(B, segment_set(base, s, nvoices), blockIdx.x, nvoices, start + first, n);
+    prepare_chunk<true>(B, segment_set(base, s, nvoices), blockIdx.x, nvoices, start + first, n);
 }
 
 struct VoiceRegs {                // the hot part of the launch record as plain scalars (SGPRs)
@@ -1120,10 +1137,12 @@ __device__ __forceinline__ uint32_t pcm16_frame(double l, double r, double scale
 // Rounding errors propagate through the recurrence like U_j(cos(64 dt)), i.e. grow at most linearly in j (FPL <= 8: < 25
 // ulp worst case, ~2 ulp typically); the rounding of k2 itself shifts the step angle by <= 1.1e-16 / |sin(64 dt)| per
 // step: below 1e-9 relative for all but ~1e-6 of voices, orders of magnitude inside the 1e-6 RMS contract in any case.
-template <int FPL, typename Theta>
+// SLOPED (segmented transition launches): the gains follow the envelope's line, gl + i * gls at the lane's frame i = dl + 64 j.
+template <int FPL, bool SLOPED = false, typename Theta>
 __device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1, double c1, double k2, bool straddle, Theta theta,
                                                  TrigTab trig, const double (&poly)[16], double gl, double gr,
-                                                 double (&accl)[FPL], double (&accr)[FPL]) {
+                                                 double (&accl)[FPL], double (&accr)[FPL],
+                                                 double gls = 0.0, double grs = 0.0, double dl = 0.0) {
 #pragma unroll
     for (int h = 0; h < FPL; h += 2) {
         const bool two = h + 1 < FPL;                 // compile-time after unrolling (FPL = 1: a single frame)
@@ -1134,12 +1153,24 @@ __device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1
             if (two) p1 = fma(p1, c1, poly[u]);
         }
         const double x0 = p0 * s0;
-        accl[h] = fma(gl, x0, accl[h]);
-        accr[h] = fma(gr, x0, accr[h]);
+        if (SLOPED) {
+            const double i0 = dl + (double)(h * 64);
+            accl[h] = fma(fma(i0, gls, gl), x0, accl[h]);
+            accr[h] = fma(fma(i0, grs, gr), x0, accr[h]);
+        } else {
+            accl[h] = fma(gl, x0, accl[h]);
+            accr[h] = fma(gr, x0, accr[h]);
+        }
         if (two) {
             const double x1 = p1 * s1;
-            accl[h + 1 < FPL ? h + 1 : h] = fma(gl, x1, accl[h + 1 < FPL ? h + 1 : h]);
-            accr[h + 1 < FPL ? h + 1 : h] = fma(gr, x1, accr[h + 1 < FPL ? h + 1 : h]);
+            if (SLOPED) {
+                const double i1 = dl + (double)((h + 1) * 64);
+                accl[h + 1 < FPL ? h + 1 : h] = fma(fma(i1, gls, gl), x1, accl[h + 1 < FPL ? h + 1 : h]);
+                accr[h + 1 < FPL ? h + 1 : h] = fma(fma(i1, grs, gr), x1, accr[h + 1 < FPL ? h + 1 : h]);
+            } else {
+                accl[h + 1 < FPL ? h + 1 : h] = fma(gl, x1, accl[h + 1 < FPL ? h + 1 : h]);
+                accr[h + 1 < FPL ? h + 1 : h] = fma(gr, x1, accr[h + 1 < FPL ? h + 1 : h]);
+            }
         }
         if (h + 2 < FPL) {
             if (straddle) {
@@ -1410,7 +1441,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                     s1 = fma(s0, rc, c0 * rs);
                     c1 = fma(c0, rc, -(s0 * rs));
                 }
-                lean_harm_frames<FPL>(s0, c0, s1, c1, rc + rc, straddle, theta, trig, poly, gl, gr, accl, accr);
+                if constexpr (MODE == RENDER_LEAN_HARM_SEG) {
+                    const double gls = q->amplitude, grs = q->g0u;       // (a segmented launch's records: the gains' slopes per frame)
+                    lean_harm_frames<FPL, true>(s0, c0, s1, c1, rc + rc, straddle, theta, trig, poly, gl, gr, accl, accr, gls, grs, di0);
+                } else {
+                    lean_harm_frames<FPL>(s0, c0, s1, c1, rc + rc, straddle, theta, trig, poly, gl, gr, accl, accr);
+                }
                 continue;
             }
             if constexpr (!mode_lean_harm(MODE)) {
@@ -1949,6 +1985,7 @@ struct sh_bank {
     // piece end per voice).  short_piece_end[k] = the largest end of any piece shorter than 2^k samples.
     bool        all_lean = false;          // every voice is a lean candidate (of any lean kind)
     uint64_t    env_flat_from = 0, env_flat_until = ~0ull;
+    std::vector<uint64_t> env_corners;     // the distinct attack / decay / sustain / release ends of the voices, sorted (empty when there are many)
     uint64_t    short_piece_end[34] = {};
     bool        no_general_voice(uint64_t start, uint32_t nframes) const {
         if (!all_lean || start < env_flat_from || start + nframes > env_flat_until) return false;
@@ -2116,6 +2153,10 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
                 if (v.env.n_decay_end > b->env_flat_from) b->env_flat_from = v.env.n_decay_end;
                 if (v.env.n_attack_end > b->env_flat_from) b->env_flat_from = v.env.n_attack_end;
                 if (v.env.n_sustain_end < b->env_flat_until) b->env_flat_until = v.env.n_sustain_end;
+                if (b->env_corners.size() <= 16) {
+                    for (uint64_t c : {v.env.n_attack_end, v.env.n_decay_end, v.env.n_sustain_end, v.env.n_release_end, v.env.n_release_end + 1})
+                        if (c && std::find(b->env_corners.begin(), b->env_corners.end(), c) == b->env_corners.end()) b->env_corners.push_back(c);
+                }
             }
             const uint32_t toff = v.fm_mode ? v.time_seg_offset : v.seg_offset, tcnt = v.fm_mode ? v.time_seg_count : v.seg_count;
             for (uint32_t k = 0; k + 1 < tcnt; ++k) {
@@ -2126,6 +2167,8 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             }
         }
     }
+    if (b->env_corners.size() > 16) b->env_corners.clear();       // voices with envelopes of their own: cut where they are all flat only
+    std::sort(b->env_corners.begin(), b->env_corners.end());
     std::vector<float2> gains(nvoices);
     for (uint32_t i = 0; i < nvoices; ++i) gains[i] = make_float2(voices[i].gain_l, voices[i].gain_r);
     int rc = upload_array(&b->d_voices, voices, nvoices, st);
@@ -2531,13 +2574,26 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             uint32_t nc = 0;
             uint64_t pos = start;
             cuts[nc++] = pos;
+            // cuts: the envelope corners the voices share (a sloped line is lean in a segmented launch's records, a corner is
+            // not) -- or, when the voices have envelopes of their own, the frame from which all of them are flat -- and, between
+            // those, doubling positions
             const uint64_t flat = b->env_flat_from, rel = b->env_flat_until;       // last decay end, first sustain end
-            if (pos < flat && flat < end) { pos = flat; cuts[nc++] = pos; }
+            const bool shared = !b->env_corners.empty();
+            if (!shared && pos < flat && flat < end) { pos = flat; cuts[nc++] = pos; }
             bool ok = true;
+            static long seg_min = -1;
+            if (seg_min < 0) { const char* e = getenv("SYNTHHIP_SEG_MIN"); seg_min = e ? atol(e) : 0; }
             while (ok && pos < end) {
                 uint64_t next = pos < T ? T : 2 * pos;                             // at most one piece end per voice in [pos, 2 pos)
-                if (pos < rel && rel < next) next = rel;
-                if (next >= end || end - next <= next / 64) next = end;            // (a very short rest joins the last segment)
+                if (pos == start && start < (uint64_t)seg_min && (uint64_t)seg_min < end) next = (uint64_t)seg_min;   // the dense first segment
+                else
+                if (shared) {
+                    for (uint64_t c : b->env_corners)
+                        if (c > pos && c < next) { next = c; break; }
+                } else if (pos < rel && rel < next) {
+                    next = rel;
+                }
+                if (next >= end || (end - next <= next / 64 && !shared)) next = end;   // (a very short rest joins the last segment)
                 if (nc > SEG_MAX) { ok = false; break; }
                 pos = next;
                 cuts[nc++] = pos;
