@@ -427,7 +427,7 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         f->off_b = (double)info.remain;
         f->remain = info.remain;
         f->kind = info.kind;
-        f->amplitude = SLOPED ? info.slope_l : info.amplitude;        // (SLOPED sets are read by RENDER_LEAN_HARM_SEG only)
+        f->amplitude = SLOPED ? info.slope_l : info.amplitude;        // (SLOPED sets are read by the RENDER_LEAN_*_SEG kernels only)
         f->g0u = SLOPED ? info.slope_r : info.g0u;
         f->vi = vi;
         f->pad1 = 0;
@@ -1198,11 +1198,11 @@ __device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1
 // over the tiles of all segments; a workgroup finds its segment first and from there on works in the segment's frame of
 // reference (records, tile, clamps); only its stores are launch-relative again.
 enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2, RENDER_LEAN_HARM_ONLY = 3, RENDER_GENERAL_ONLY = 4, RENDER_LEAN_ALL_ONLY = 5,
-       RENDER_LEAN_HARM_SEG = 6, RENDER_GENERAL_SEG = 7 };
+       RENDER_LEAN_HARM_SEG = 6, RENDER_GENERAL_SEG = 7, RENDER_LEAN_ALL_SEG = 8 };
 constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_HARM_SEG; }
-constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY || mode == RENDER_LEAN_HARM_SEG; }
+constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY || mode == RENDER_LEAN_HARM_SEG || mode == RENDER_LEAN_ALL_SEG; }
 constexpr bool mode_general(int mode) { return mode == RENDER_GENERAL_ONLY || mode == RENDER_GENERAL_SEG; }
-constexpr bool mode_seg(int mode) { return mode == RENDER_LEAN_HARM_SEG || mode == RENDER_GENERAL_SEG; }
+constexpr bool mode_seg(int mode) { return mode == RENDER_LEAN_HARM_SEG || mode == RENDER_GENERAL_SEG || mode == RENDER_LEAN_ALL_SEG; }
 constexpr bool mode_has_lean(int mode) { return mode != RENDER_DIRECT && !mode_general(mode); }
 template <int WAVES, int FPL, int MINW, int MODE>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             const double di0 = (double)i0;
             double t_base = ta, dt = da, rc = rca, rs = rsa, off = 0.0, tb = ta, db = da, ob = 0.0;
             bool straddle = false;
-            if constexpr (MODE == RENDER_LEAN_HARM_SEG) {
+            if constexpr (mode_seg(MODE)) {
                 // a segment is cut so that (nearly) every voice crosses ONE piece end in it: half the tiles lie behind it, and the
                 // second piece's fields belong in the first batch of loads (one round trip per record, not two)
                 const double tb2 = q->t0_b, db2 = q->dt_b, ob2 = q->off_b, rcb = q->rot_c_b, rsb = q->rot_s_b;
@@ -1441,7 +1441,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                     s1 = fma(s0, rc, c0 * rs);
                     c1 = fma(c0, rc, -(s0 * rs));
                 }
-                if constexpr (MODE == RENDER_LEAN_HARM_SEG) {
+                if constexpr (mode_seg(MODE)) {
                     const double gls = q->amplitude, grs = q->g0u;       // (a segmented launch's records: the gains' slopes per frame)
                     lean_harm_frames<FPL, true>(s0, c0, s1, c1, rc + rc, straddle, theta, trig, poly, gl, gr, accl, accr, gls, grs, di0);
                 } else {
@@ -2568,7 +2568,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         static int no_seg = -1;
         if (no_seg < 0) { const char* e = getenv("SYNTHHIP_NO_SEG"); no_seg = (e && e[0] == '1') ? 1 : 0; }
         const uint64_t end = start + nframes;
-        if (split && mode == RENDER_LEAN_HARM && var == 484 && b->all_lean && !no_seg && !b->needs_rows && !b->no_general_voice(start, nframes)) {
+        if (split && (mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_ALL) && var == 484 && b->all_lean && !no_seg && !b->needs_rows && !b->no_general_voice(start, nframes)) {
             const uint64_t T = (uint64_t)(64 * F);
             uint64_t cuts[SEG_MAX + 2];
             uint32_t nc = 0;
@@ -2688,9 +2688,14 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             tiles_lean += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 8);
             tiles_gen += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 4);
         }
-        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_HARM_SEG>), dim3(tiles_lean, groups), dim3(256), 0, st, P,
-                           trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen);
+        if (mode == RENDER_LEAN_HARM)
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_HARM_SEG>), dim3(tiles_lean, groups), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen);
+        else
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_ALL_SEG>), dim3(tiles_lean, groups), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen);
         SH_CHECK_LAUNCH("k_bank_render(lean, segments)");
         SH_HIP(hipMemsetAsync(gen_valid, 1, (size_t)groups * sizeof(uint32_t), st));         // every group's general parts are written
         // the first segment's groups are split SUB ways (BankPtrs::gen_sub): with sixteen waves per workgroup a wave walks two

@@ -82,7 +82,7 @@ def test_split_launch_equals_combined_kernel_and_oracle(gpu, tmp_path):
 _CHILD_SEG = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
-from tests.test_gpu_split import transition_bank, TRANSITION_BLOCKS
+from tests.test_gpu_split import transition_bank, mixed_kinds_bank, TRANSITION_BLOCKS
 from synthesizer_amd.mixer import VoiceBank
 voices, gains = transition_bank()
 bank = VoiceBank(voices, gains=gains)
@@ -91,6 +91,10 @@ for n, start in TRANSITION_BLOCKS:
     out["%%d_%%d" %% (n, start)] = bank.render(n, start=start)
 buf = bank.render_pcm_device(48000, 0)
 out["pcm"] = buf.download(np.int16, 96000)
+voices, gains = mixed_kinds_bank()
+bank = VoiceBank(voices, gains=gains)
+for n, start in TRANSITION_BLOCKS[:7]:
+    out["mixed_%%d_%%d" %% (n, start)] = bank.render(n, start=start)
 np.savez(sys.argv[1], **out)
 """
 
@@ -113,6 +117,25 @@ def transition_bank():
     return v, g
 
 
+def mixed_kinds_bank():
+    """256 voices that are all lean candidates, of every lean kind: FM Sine carriers with closed-form Sine LFOs, plain waveforms,
+    polynomial Harmonics -- with and without an envelope (the bank takes RENDER_LEAN_ALL_SEG)."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.workloads import fm_voices
+    rng = np.random.default_rng(77)
+    fv, fg = fm_voices(G, 96, SR, seed=5)
+    av, ag = additive_voices(G, 64, SR, seed=6, adsr={"sustain": 2.0})
+    voices, gains = list(fv) + list(av), list(fg) + list(ag)
+    env = lambda o: G.EnvelopeFilter(o, 0.01, 0.05, 2.0, 0.6, 0.2)
+    for k in range(96):
+        f, a, ph = float(rng.uniform(60, 3000)), float(rng.uniform(0.005, 0.02)), float(rng.uniform(0, 1))
+        kind = (G.Sine, G.Sawtooth, G.Square, G.Triangle)[k % 4]
+        o = kind(f, a, phase=ph, samplerate=SR) if k % 8 < 4 else G.Pulse(f, a, phase=ph, pulsewidth=0.3, samplerate=SR)
+        voices.append(env(o) if k % 3 == 0 else o)
+        gains.append((float(rng.uniform(0, 1)), float(rng.uniform(0, 1))))
+    return voices, gains
+
+
 def test_segmented_transition_launches(gpu, tmp_path):
     """The first block of a note as a segmented launch (RENDER_LEAN_HARM_SEG / RENDER_GENERAL_SEG: one batched prepare, the lean
     kernel over all segments, the general kernel with the first segment's groups split further and k_seg_combine) against the
@@ -133,6 +156,15 @@ def test_segmented_transition_launches(gpu, tmp_path):
         scale = max(1e-3, float(np.max(np.abs(w))))
         assert np.max(np.abs(got.astype(np.float64) - w)) <= 1.3e-7 * scale, (n, start)
         assert np.mean(got != w) < 2e-3, (n, start, float(np.mean(got != w)))
+    mv, mg = mixed_kinds_bank()
+    mbank = VoiceBank(mv, gains=mg)
+    for n, start in TRANSITION_BLOCKS[:7]:
+        got = mbank.render(n, start=start)
+        w = want["mixed_%d_%d" % (n, start)]
+        scale = max(1e-3, float(np.max(np.abs(w))))
+        # (naive Square / Pulse / Sawtooth voices: both paths evaluate the exact accumulated phase, edges included)
+        assert np.max(np.abs(got.astype(np.float64) - w)) <= 1.3e-7 * scale, ("mixed", n, start)
+        assert np.mean(got != w) < 2e-3, ("mixed", n, start, float(np.mean(got != w)))
     pcm = bank.render_pcm_device(48000, 0).download(np.int16, 96000)
     assert np.max(np.abs(pcm.astype(np.int32) - want["pcm"].astype(np.int32))) <= 1 and np.mean(pcm != want["pcm"]) < 2e-3
     # a run that starts with the segmented launch and goes on: blocks 0 .. 5 pipelined == the blocks one by one
