@@ -2670,13 +2670,13 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             SH_HIP(hipStreamSynchronize(S.stream2));
             if (g.launch) { (void)hipFree(g.launch); (void)hipFree(g.fm); (void)hipFree(g.fast); (void)hipFree(g.gen_idx); (void)hipFree(g.counts); g = LaunchSet(); }
             b->seg_cap[ks] = 0;
-            const size_t cap = SEG_MAX;
+            const size_t cap = nseg;                          // (grows with the launches that need more: 724 bytes per voice and segment)
             SH_HIP(hipMalloc((void**)&g.launch, sizeof(VoiceLaunch) * cap * b->nvoices));
             SH_HIP(hipMalloc((void**)&g.fm, sizeof(VoiceFM) * cap * b->nvoices));
             SH_HIP(hipMalloc((void**)&g.fast, sizeof(FastRec) * cap * b->nvoices));
             SH_HIP(hipMalloc((void**)&g.gen_idx, sizeof(uint32_t) * cap * b->nvoices));
             SH_HIP(hipMalloc((void**)&g.counts, sizeof(uint32_t) * 4 * cap * nchunks));
-            b->seg_cap[ks] = SEG_MAX;
+            b->seg_cap[ks] = nseg;
         }
         BankPtrs P = ptrs(b);
         P.nseg = nseg;
