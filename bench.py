@@ -32,6 +32,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import statistics
 import sys
 import time
@@ -390,9 +391,13 @@ def main() -> int:
     # float64 VALU lane-operations per voice-sample of the render kernel on this workload, from the committed rocprofv3
     # counters: (SQ_INSTS_VALU_FMA_F64 + MUL_F64 + ADD_F64) wave-instructions x 64 lanes / voice-samples per dispatch
     # (the render kernel = the k_bank_render instantiation with the most float64 FMAs: the lean kernel of a split launch)
+    # (the instantiations of a segmented transition launch -- MODE 6, 7, 8: block 0 of the profiled run -- are not the steady state)
+    def steady_render(name):
+        m = re.match(r"k_bank_render<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)>", name)
+        return bool(m) and int(m.group(1)) < 6
     render_name, render_counters = None, None
     for k_, v_ in prof["counters"].items():
-        if k_.startswith("k_bank_render") and (render_counters is None or v_.get("SQ_INSTS_VALU_FMA_F64", 0) > render_counters.get("SQ_INSTS_VALU_FMA_F64", 0)):
+        if steady_render(k_) and (render_counters is None or v_.get("SQ_INSTS_VALU_FMA_F64", 0) > render_counters.get("SQ_INSTS_VALU_FMA_F64", 0)):
             render_name, render_counters = k_, v_
     if render_counters and all(k in render_counters for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")):
         fma, mul, add = (render_counters[k] for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"))
@@ -405,7 +410,7 @@ def main() -> int:
         ops_source = "profiles/r01_summary.md (literal: no rNN_counters.json committed)"
     valu_achieved = local_voices * F * lane_ops / kern_s / 1e12
     # HBM traffic of one block: every k_bank_render dispatch of it (lean + general-lists kernel of a split launch)
-    render_traffic = [v_["hbm_bytes"] for k_, v_ in prof["traffic"].items() if k_.startswith("k_bank_render")]
+    render_traffic = [v_["hbm_bytes"] for k_, v_ in prof["traffic"].items() if steady_render(k_)]
     traffic_bytes = sum(render_traffic) if render_traffic else None
     out = {
         "metric": "Msamples/sec mixed to stereo bus, 1024-voice additive @48kHz",
