@@ -168,7 +168,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __res
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t col = wave % COLS, vg = wave / COLS;
-    const uint32_t s0 = ((blockIdx.x * COLS + col) * 64 + lane) * S;
+    const uint32_t s0 = (((uint32_t)sh::block_id() * COLS + col) * 64 + lane) * S;       // (grid1d folds beyond 2^21 workgroups)
     const uint32_t per = (nvoices + VG - 1) / VG;
     const uint32_t v0 = vg * per;
     uint32_t v1 = v0 + per;

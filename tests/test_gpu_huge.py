@@ -208,3 +208,31 @@ def test_one_sample_per_thread_kernels_beyond_2_32_samples(gpu):
         assert wide.download(np.int16, w, 2 * first).tobytes() == audioop.lin2lin(at(first).tobytes(), 1, 2), first
     src.free()
     wide.free()
+
+
+def test_mix_chain_beyond_2_30_samples(gpu):
+    """sh_mix_chain_i16 on rows of more than 2^30 samples with a stride that rules out the 16-byte path: the split kernel's grid
+    (one workgroup per 512 samples) is folded into two dimensions beyond 2^21 workgroups."""
+    from synthesizer_amd import _native as N
+    L = N.lib()
+    ns = (1 << 30) + (1 << 20) + 3
+    stride = ns + 5                                          # odd: rows 1 and 2 start off the 16-byte grid
+    nv = 3
+    tiles = [np.random.default_rng(40 + v).integers(-20000, 20000, (1 << 23) - 3 - 2 * v, dtype=np.int64).astype(np.int16) for v in range(nv)]
+    src = N.DeviceBuffer(2 * (stride * (nv - 1) + ns))
+    for v in range(nv):
+        t = tiles[v]
+        for e0 in range(0, ns, len(t)):
+            m = min(len(t), ns - e0)
+            src.upload(t[:m], 2 * (v * stride + e0))
+    dst = N.DeviceBuffer(2 * ns)
+    N.check(L.sh_mix_chain_i16(src.handle, nv, stride, ns, dst.handle))
+    w = 1 << 15
+    for first in (0, (1 << 30) - w // 2, (1 << 30) + 512 * 3 + 1, ns - w):
+        idx = np.arange(first, first + w)
+        want = tiles[0][idx % len(tiles[0])].tobytes()
+        for v in range(1, nv):
+            want = audioop.add(want, tiles[v][idx % len(tiles[v])].tobytes(), 2)
+        assert dst.download(np.int16, w, 2 * first).tobytes() == want, first
+    src.free()
+    dst.free()
