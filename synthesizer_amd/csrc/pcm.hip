@@ -278,8 +278,8 @@ __device__ __forceinline__ short8v chain_load8(const short* p, uint32_t n, uint3
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather(const ChainSrc* __restrict__ tab, uint32_t nsrc, uint32_t nsamples,
-                                                                 short* __restrict__ out) {
+__device__ __forceinline__ void mix_chain_gather_body(const ChainSrc* __restrict__ tab, uint32_t nsrc, uint32_t nsamples,
+                                                      short* __restrict__ out) {
     constexpr int S = 8;
     __shared__ int red[WAVES][3][S][64];
     const uint32_t lane = threadIdx.x & 63;
@@ -333,6 +333,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather(const ChainSrc*
             for (uint32_t j = 0; j < S && s0 + j < nsamples; ++j) out[s0 + j] = r[j];
         }
     }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather(const ChainSrc* __restrict__ tab, uint32_t nsrc, uint32_t nsamples,
+                                                                 short* __restrict__ out) {
+    mix_chain_gather_body<WAVES>(tab, nsrc, nsamples, out);
+}
+
+// The same with the source table IN the kernel arguments (up to 64 sources: one real-time mixer turn): no table upload in front of
+// the launch -- the copy of a pageable kilobyte costs more than the kernel.
+struct ChainTab { ChainSrc e[64]; };
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather_args(const ChainTab tab, uint32_t nsrc, uint32_t nsamples,
+                                                                      short* __restrict__ out) {
+    mix_chain_gather_body<WAVES>(tab.e, nsrc, nsamples, out);
 }
 
 // the direct loop over the pointer table (long samples: mix_samples of whole tracks)
@@ -963,6 +978,16 @@ int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offs
     short* op = (short*)out->ptr + out_sample_off;
     if (tab.empty()) {
         SH_HIP(hipMemsetAsync(op, 0, (size_t)nsamples * 2, st));
+        return SH_OK;
+    }
+    if (tab.size() <= 64 && sh::div_up(nsamples, 512) < 1536) {          // a mixer turn: the table travels in the kernel arguments
+        ChainTab args;
+        for (size_t k = 0; k < 64; ++k) args.e[k] = k < tab.size() ? tab[k] : ChainSrc{nullptr, 0, 0};
+        const uint32_t n = (uint32_t)tab.size();
+        dim3 grid(sh::div_up(nsamples, 512));
+        if (n >= 64) hipLaunchKernelGGL(k_mix_chain_gather_args<8>, grid, dim3(8 * 64), 0, st, args, n, nsamples, op);
+        else hipLaunchKernelGGL(k_mix_chain_gather_args<2>, grid, dim3(2 * 64), 0, st, args, n, nsamples, op);
+        SH_CHECK_LAUNCH("k_mix_chain_gather_args");
         return SH_OK;
     }
     int rc = sh::ensure_scratch(tab.size() * sizeof(ChainSrc));
