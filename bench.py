@@ -510,7 +510,7 @@ def main() -> int:
             bank.local.render_pcm_device(F, pos[0] * F, pcm=ring[pos[0] & 3])
             pos[0] += 1
         pcm_ms = steady(N, pcm_step, min_seconds=0.1, reps=K)
-        out["int16_stream"] = {"ms_per_step": pcm_ms, "value": VOICES_PER_GPU * F / (pcm_ms / 1e3) / 1e6, "unit": "Msamples/s",
+        out["int16_stream"] = {"ms_per_step": pcm_ms, "value": local_voices * F / (pcm_ms / 1e3) / 1e6, "unit": "Msamples/s",
                                "note": "sh_bank_render_pcm into a ring of 4 buffers: saturated int16 stereo straight from the "
                                        "partial-bus fold, launches pipelined like the headline's"}
         for b_ in ring:
@@ -530,7 +530,7 @@ def main() -> int:
             for k in range(30):                     # other frames in between: the clocks stay up, the records of block 0 go cold
                 bank.local.render_device(F, (step0 + k) * F, bus_f32=ring[k & 3])
         N.sync()
-        out["job_from_frame_0"] = {"blocks": 10, "ms": job_ms, "value": VOICES_PER_GPU * 10.0 * F / (job_ms / 1e3) / 1e6, "unit": "Msamples/s",
+        out["job_from_frame_0"] = {"blocks": 10, "ms": job_ms, "value": local_voices * 10.0 * F / (job_ms / 1e3) / 1e6, "unit": "Msamples/s",
                                    "note": "ten consecutive blocks starting at frame 0 (first block of the notes included), best of 12"}
         for b_ in ring:
             b_.free()
