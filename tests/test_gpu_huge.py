@@ -236,3 +236,25 @@ def test_mix_chain_beyond_2_30_samples(gpu):
         assert dst.download(np.int16, w, 2 * first).tobytes() == want, first
     src.free()
     dst.free()
+
+
+def test_24bit_add_beyond_2_31_samples(gpu):
+    """audioop.add on 2^31 + 2^22 samples of 24-bit PCM (6.5 GB per operand): the unpack / 32-bit add / pack route with its int32
+    temporaries of 8.6 GB each, whose kernels take four samples per thread in folded grids."""
+    from synthesizer_amd import _native as N
+    L = N.lib()
+    n = (1 << 31) + (1 << 22) + 8
+    rng = np.random.default_rng(24)
+    ta = rng.integers(0, 256, 3 * ((1 << 22) - 5), dtype=np.int64).astype(np.uint8)          # whole 3-byte samples
+    tb = rng.integers(0, 256, 3 * ((1 << 22) - 11), dtype=np.int64).astype(np.uint8)
+    a, b, o = N.DeviceBuffer(3 * n), N.DeviceBuffer(3 * n), N.DeviceBuffer(3 * n)
+    _fill(a, ta, 3 * n)
+    _fill(b, tb, 3 * n)
+    N.check(L.sh_pcm_add(a.handle, 0, b.handle, 0, 3 * n, 3, o.handle, 0))
+    w = 1 << 15                                               # samples per window
+    for first in (0, (1 << 31) - w // 2, ((1 << 32) // 3) - w // 2, (1 << 31) + (1 << 21) + 5, n - w):
+        idx = np.arange(3 * first, 3 * (first + w))
+        want = audioop.add(ta[idx % len(ta)].tobytes(), tb[idx % len(tb)].tobytes(), 3)
+        assert o.download(np.uint8, 3 * w, 3 * first).tobytes() == want, first
+    for x in (a, b, o):
+        x.free()
