@@ -258,3 +258,30 @@ def test_24bit_add_beyond_2_31_samples(gpu):
         assert o.download(np.uint8, 3 * w, 3 * first).tobytes() == want, first
     for x in (a, b, o):
         x.free()
+
+
+def test_quantise_beyond_2_32_samples(gpu):
+    """sh_quantize_f32 / sh_quantize_clip_f32 on 2^32 + 2^20 float32 samples (17 GB in, 8.6 GB out): the vector kernel's grid (2048
+    samples per workgroup) folds exactly there; windows against int(scale * v)."""
+    from oracle import synth_oracle as O
+    from synthesizer_amd import _native as N
+    L = N.lib()
+    n = (1 << 32) + (1 << 20) + 4
+    tile = np.random.default_rng(31).uniform(-1.0, 1.0, (1 << 24) - 9).astype(np.float32)
+    src, dst = N.DeviceBuffer(4 * n), N.DeviceBuffer(2 * n)
+    _fill(src, tile, n)
+    N.check(L.sh_quantize_f32(src.handle, 0, n, 32767.0, 2, dst.handle, 0))
+    w = 1 << 14
+    marks = (0, (1 << 31) - w // 2, (1 << 32) - w // 2, (1 << 32) + 2048 * 3 + 1, n - w)
+    for first in marks:
+        idx = np.arange(first, first + w)
+        want = np.trunc(32767.0 * tile[idx % len(tile)].astype(np.float64)).astype(np.int16)
+        assert np.array_equal(dst.download(np.int16, w, 2 * first), want), first
+    assert list(dst.download(np.int16, 64, 0)) == O.quantise([float(x) for x in tile[:64]])
+    N.check(L.sh_quantize_clip_f32(src.handle, n, 40000.0, dst.handle))
+    for first in marks:
+        idx = np.arange(first, first + w)
+        want = np.clip(np.trunc(40000.0 * tile[idx % len(tile)].astype(np.float64)), -32768, 32767).astype(np.int16)
+        assert np.array_equal(dst.download(np.int16, w, 2 * first), want), first
+    src.free()
+    dst.free()
