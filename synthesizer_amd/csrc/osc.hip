@@ -33,6 +33,9 @@
 namespace {
 
 constexpr int SEG_MAX = 24;            // segments of a transition launch
+// Unequal segments of a materialised row's head (n = 0: none): entry k holds the frames [first[k], first[k] + len[k]) and reads
+// record set set[k] (the lists launch skips the segments the host can prove free of general voices)
+struct SegTab { uint32_t n; uint32_t first[SEG_MAX]; uint32_t len[SEG_MAX]; uint32_t set[SEG_MAX]; };
 
 struct BankPtrs {
     const sh_voice*   voices;
@@ -475,10 +478,12 @@ __global__ __launch_bounds__(64) void k_prepare_segments(BankPtrs B, LaunchSet b
 }
 
 // The same for the unequal segments of a transition launch (B.seg_first): grid = (chunks, segments).
+// (SLOPED: the records of a render launch; the materialisation kernels need the unfolded amplitude and gain instead)
+template <bool SLOPED>
 __global__ __launch_bounds__(64) void k_prepare_segments_var(BankPtrs B, LaunchSet base, uint32_t nvoices, uint64_t start) {
     const uint32_t s = blockIdx.y;
     const uint32_t first = B.seg_first[s], n = B.seg_first[s + 1] - first;
-    prepare_chunk<true>(B, segment_set(base, s, nvoices), blockIdx.x, nvoices, start + first, n);
+    prepare_chunk<SLOPED>(B, segment_set(base, s, nvoices), blockIdx.x, nvoices, start + first, n);
 }
 
 struct VoiceRegs {                // the hot part of the launch record as plain scalars (SGPRs)
@@ -832,9 +837,29 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
 template <int FPL, bool LEAN>
 __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                          uint32_t nvoices, LaunchSet cur, uint64_t start, uint32_t n,
-                                                                         float* __restrict__ out32, size_t stride) {
+                                                                         float* __restrict__ out32, size_t stride,
+                                                                         SegTab tab = SegTab{0, {}, {}, {}}, uint32_t vsplit = 1) {
+    // tab.n != 0: the unequal segments of a row's head in ONE launch -- grid.x runs over the groups of four tiles of all segments,
+    // a workgroup finds its segment and from there on works relative to it (records, frames, output).  vsplit > 1: grid.y =
+    // chunks x vsplit, the general and silent voices of a chunk dealt round robin to vsplit workgroups (rows are independent:
+    // the first segment of a head holds EVERY voice, 64 per chunk, and a wave walking them all is the launch's critical path).
+    uint32_t tg = blockIdx.x;
+    if (tab.n) {
+        uint32_t sidx = 0;
+        for (;;) {
+            const uint32_t groups_s = (tab.len[sidx] + 4 * 64 * FPL - 1) / (4 * 64 * FPL);
+            if (tg < groups_s) break;
+            tg -= groups_s;
+            if (++sidx >= tab.n) return;
+        }
+        cur = segment_set(cur, tab.set[sidx], nvoices);
+        start += tab.first[sidx];
+        n = tab.len[sidx];
+        out32 += tab.first[sidx];
+    }
+    const uint32_t c = blockIdx.y / vsplit, vsub = blockIdx.y % vsplit;
     if constexpr (!LEAN) {                     // nothing but lean voices in this chunk: leave before the table is staged
-        const uint32_t SH_CONST_AS* cnt0 = as_const(cur.counts) + 4 * blockIdx.y;
+        const uint32_t SH_CONST_AS* cnt0 = as_const(cur.counts) + 4 * c;
         if (cnt0[1] + cnt0[2] == 0) return;
     }
     __shared__ shm::sc_pair trig[shm::TRIG_N];
@@ -842,7 +867,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile0 = (blockIdx.x * 4 + wave) * (64 * FPL);
+    const uint32_t tile0 = (tg * 4 + wave) * (64 * FPL);
     if (tile0 >= n) return;
     uint32_t tile_last = tile0 + 64 * FPL - 1;
     if (tile_last > n - 1) tile_last = n - 1;
@@ -854,9 +879,8 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
         i[j] = raw < n ? raw : n - 1;
         di[j] = (double)i[j];
     }
-    const uint32_t c = blockIdx.y;
     const uint32_t SH_CONST_AS* cnt = as_const(cur.counts) + 4 * c;
-    const uint32_t nfast = LEAN ? cnt[0] : 0u, ngen = cnt[1], nsilent = cnt[2];
+    const uint32_t nfast = (LEAN && vsub == 0) ? cnt[0] : 0u, ngen = cnt[1], nsilent = cnt[2];
     const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64;
     for (uint32_t p = 0; p < nfast; ++p, ++q) {
         const uint32_t remain = q->remain, kind = q->kind, vi = q->vi;
@@ -952,7 +976,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
         }
     }
     const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
-    for (uint32_t p = 0; p < ngen; ++p) {
+    for (uint32_t p = vsub; p < ngen; p += vsplit) {
         const uint32_t vi = idx[p];
         const VoiceRegs r = load_record(as_const(cur.launch) + vi);
         double x[FPL];
@@ -963,7 +987,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
             if (raw < n) out32[(size_t)vi * stride + raw] = (float)x[j];
         }
     }
-    for (uint32_t p = 0; p < nsilent; ++p) {
+    for (uint32_t p = vsub; p < nsilent; p += vsplit) {
         const uint32_t vi = idx[63 - p];
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
@@ -985,18 +1009,34 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 template <int FPL>
 __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
                                                                uint32_t total, uint32_t seg_frames,
-                                                               float* __restrict__ out32_all, size_t stride) {
+                                                               float* __restrict__ out32_all, size_t stride, SegTab tab) {
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t abs0 = (blockIdx.x * 4 + wave) * (64 * FPL);       // the tile's first frame in the whole launch
-    if (abs0 >= total) return;
-    const uint32_t seg = abs0 / seg_frames;                            // (uniform) its segment, and everything relative to it
-    const uint32_t seg_first = seg * seg_frames;
-    const uint32_t n = total - seg_first < seg_frames ? total - seg_first : seg_frames;
-    const uint32_t tile0 = abs0 - seg_first;
+    uint32_t seg, seg_first, n, tile0;                                 // (uniform) the wave's segment, and everything relative to it
+    if (tab.n) {                                                       // unequal segments: the head of rows that start with the notes
+        uint32_t t = blockIdx.x * 4 + wave;
+        seg = 0;
+        for (;;) {
+            const uint32_t tiles_s = (tab.len[seg] + 64 * FPL - 1) / (64 * FPL);
+            if (t < tiles_s) break;
+            t -= tiles_s;
+            if (++seg >= tab.n) return;
+        }
+        seg_first = tab.first[seg];
+        n = tab.len[seg];
+        tile0 = t * (64 * FPL);
+        seg = tab.set[seg];
+    } else {
+        const uint32_t abs0 = (blockIdx.x * 4 + wave) * (64 * FPL);   // the tile's first frame in the whole launch
+        if (abs0 >= total) return;
+        seg = abs0 / seg_frames;
+        seg_first = seg * seg_frames;
+        n = total - seg_first < seg_frames ? total - seg_first : seg_frames;
+        tile0 = abs0 - seg_first;
+    }
     const LaunchSet cur = segment_set(base, seg, nvoices);
     float* __restrict__ out32 = out32_all + seg_first;
     uint32_t tile_last = tile0 + 64 * FPL - 1;
@@ -2323,6 +2363,42 @@ static int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStre
     return SH_OK;
 }
 
+// The cuts of a transition launch / of the head of a materialised row (see RENDER_LEAN_HARM_SEG): with `corners`, the envelope
+// corners the voices share (sloped records: a line of any slope is lean, a corner is not) -- without, or when the voices have
+// envelopes of their own, the frame from which all of them are flat and the first sustain end -- and, between those, doubling
+// positions (at most one piece end of the phase sum per voice in [pos, 2 pos)); no segment longer than max_len.
+// seg_first[0 .. n] = launch-relative segment starts; returns n; the segments cover seg_first[n] <= nframes frames (fewer than
+// nframes only when SEG_MAX segments do not reach the end).
+static uint32_t plan_segments(const sh_bank* b, uint64_t start, uint32_t nframes, uint64_t T, uint64_t max_len, bool corners,
+                              uint32_t* seg_first) {
+    const uint64_t end = start + nframes;
+    uint64_t cuts[SEG_MAX + 2];
+    uint32_t nc = 0;
+    uint64_t pos = start;
+    cuts[nc++] = pos;
+    const uint64_t flat = b->env_flat_from, rel = b->env_flat_until;       // last decay end, first sustain end
+    const bool shared = corners && !b->env_corners.empty();
+    if (!shared && pos < flat && flat < end && flat - pos <= max_len) { pos = flat; cuts[nc++] = pos; }
+    static long seg_min = -1;
+    if (seg_min < 0) { const char* e = getenv("SYNTHHIP_SEG_MIN"); seg_min = e ? atol(e) : 0; }
+    while (pos < end && nc <= SEG_MAX) {
+        uint64_t next = pos < T ? T : 2 * pos;
+        if (pos == start && start < (uint64_t)seg_min && (uint64_t)seg_min < end) next = (uint64_t)seg_min;   // the dense first segment
+        else if (shared) {
+            for (uint64_t c : b->env_corners)
+                if (c > pos && c < next) { next = c; break; }
+        } else if (pos < rel && rel < next) {
+            next = rel;
+        }
+        if (next - pos > max_len) next = pos + max_len;
+        if (next >= end || (end - next <= next / 64 && !shared && end - pos <= max_len)) next = end;   // (a very short rest joins the last segment)
+        pos = next;
+        cuts[nc++] = pos;
+    }
+    for (uint32_t k = 0; k < nc; ++k) seg_first[k] = (uint32_t)(cuts[k] - start);
+    return nc - 1;
+}
+
 static bool speculation_enabled() {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("SYNTHHIP_NO_SPECULATION"); enabled = (e && e[0] == '1') ? 0 : 1; }
@@ -2396,11 +2472,79 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
         // Long rows, every lean candidate a polynomial Harmonics voice: the lean records by the recurrence kernel at sixteen frames
         // per lane, then the general and silent lists -- unless the segment provably has none.  Rows longer than a segment get
         // one record set per segment, all resolved by ONE prepare launch.
-        constexpr int LF = 16;                               // 1024 x 480 000 on MI355X: 16 frames per lane 496 us, 8: 508
+        // frames per lane of the lean kernel: sixteen on long rows (1024 x 480 000: 496 us, eight: 508), fewer when that leaves
+        // the chip short of workgroups (1024 x 48 000 at sixteen: 12 x 16 = 192 workgroups of four 1024-frame tiles)
+        int lf = 16;
+        while (lf > 4 && (uint64_t)sh::div_up(nframes, 256 * lf) * sh::div_up(b->nvoices, 64) < 512) lf /= 2;
+        {
+            static int forced = -1;
+            if (forced < 0) { const char* e = getenv("SYNTHHIP_GEN_LF"); forced = e ? atoi(e) : 0; }
+            if (forced == 4 || forced == 8 || forced == 16) lf = forced;
+        }
+        const int LF = lf;
+#define SH_GEN_LEAN(GRID_, ...) do { \
+            if (LF == 16) hipLaunchKernelGGL(k_generate_lean_harm<16>, GRID_, dim3(256), 0, st, __VA_ARGS__); \
+            else if (LF == 8) hipLaunchKernelGGL(k_generate_lean_harm<8>, GRID_, dim3(256), 0, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL(k_generate_lean_harm<4>, GRID_, dim3(256), 0, st, __VA_ARGS__); } while (0)
         constexpr uint32_t SEG = 65536;                      // frames per segment (a multiple of the 1024-frame tile)
-        const uint32_t nseg = sh::div_up(nframes, SEG);
         hipStream_t st = sh::state().stream;
         const uint32_t nchunks = sh::div_up(b->nvoices, 64);
+        // Rows that start with the notes (attack, decay, a dozen binades of the phase sum in the first 65 536 frames): the head
+        // is cut like a transition launch of the render path (plan_segments: where the envelopes are flat, then doubling
+        // positions) so that its voices stay lean -- one prepare launch, one lean launch, ONE lists launch over all segments with
+        // the general voices of a chunk dealt to eight workgroups; the rest of the row follows with equal segments.
+        static int no_seg = -1;
+        if (no_seg < 0) { const char* e = getenv("SYNTHHIP_NO_SEG"); no_seg = (e && e[0] == '1') ? 1 : 0; }
+        if (start < SEG && b->all_lean && !no_seg && !b->no_general_voice(start, nframes < SEG ? nframes : SEG)) {
+            uint32_t cut[SEG_MAX + 1];
+            SegTab tab, ltab;
+            tab.n = plan_segments(b, start, nframes, 64 * LF, SEG, false, cut);
+            if (tab.n >= 2) {
+                const uint32_t head = cut[tab.n];                        // frames the segments cover (all of them, or what SEG_MAX cuts reach)
+                ltab.n = 0;
+                for (uint32_t k = 0; k < tab.n; ++k) {
+                    tab.first[k] = cut[k]; tab.len[k] = cut[k + 1] - cut[k]; tab.set[k] = k;
+                    if (!b->no_general_voice(start + cut[k], cut[k + 1] - cut[k])) {     // (the lists launch: where general or silent voices can be)
+                        ltab.first[ltab.n] = cut[k]; ltab.len[ltab.n] = cut[k + 1] - cut[k]; ltab.set[ltab.n] = k;
+                        ++ltab.n;
+                    }
+                }
+                if (b->gen_segs < tab.n) {
+                    SH_HIP(hipStreamSynchronize(st));
+                    LaunchSet& g = b->gen_set;
+                    if (g.launch) { (void)hipFree(g.launch); (void)hipFree(g.fm); (void)hipFree(g.fast); (void)hipFree(g.gen_idx); (void)hipFree(g.counts); g = LaunchSet(); }
+                    b->gen_segs = 0;
+                    const size_t cap = tab.n;
+                    SH_HIP(hipMalloc((void**)&g.launch, sizeof(VoiceLaunch) * cap * b->nvoices));
+                    SH_HIP(hipMalloc((void**)&g.fm, sizeof(VoiceFM) * cap * b->nvoices));
+                    SH_HIP(hipMalloc((void**)&g.fast, sizeof(FastRec) * cap * b->nvoices));
+                    SH_HIP(hipMalloc((void**)&g.gen_idx, sizeof(uint32_t) * cap * b->nvoices));
+                    SH_HIP(hipMalloc((void**)&g.counts, sizeof(uint32_t) * 4 * cap * nchunks));
+                    b->gen_segs = tab.n;
+                }
+                const LaunchSet base = b->gen_set;
+                BankPtrs P = ptrs(b);
+                P.nseg = tab.n;
+                uint32_t tiles = 0, list_groups = 0;
+                for (uint32_t k = 0; k <= tab.n; ++k) P.seg_first[k] = cut[k];
+                for (uint32_t k = 0; k < tab.n; ++k) tiles += sh::div_up(tab.len[k], 64 * LF);
+                for (uint32_t k = 0; k < ltab.n; ++k) list_groups += sh::div_up(ltab.len[k], 4 * 64 * 4);
+                hipLaunchKernelGGL(k_prepare_segments_var<false>, dim3(nchunks, tab.n), dim3(64), 0, st, P, base, b->nvoices, start);
+                SH_CHECK_LAUNCH("k_prepare_segments_var");
+                SH_GEN_LEAN(dim3(sh::div_up(tiles, 4), nchunks), trig_table(), base, b->nvoices, head, SEG, o, stride, tab);
+                SH_CHECK_LAUNCH("k_generate_lean_harm");
+                constexpr uint32_t VSPLIT = 8;
+                if (ltab.n) {
+                    hipLaunchKernelGGL((k_generate_lists<4, false>), dim3(list_groups, nchunks * VSPLIT), dim3(256), 0, st,
+                                       ptrs(b), trig_table(), b->nvoices, base, start, head, o, stride, ltab, VSPLIT);
+                    SH_CHECK_LAUNCH("k_generate_lists");
+                }
+                if (head == nframes) return SH_OK;
+                sh_buf rest{(char*)voices_out->ptr + (size_t)head * 4, voices_out->bytes - (size_t)head * 4, false, 0};
+                return sh_bank_generate(b, start + head, nframes - head, &rest, stride);
+            }
+        }
+        const uint32_t nseg = sh::div_up(nframes, SEG);
         LaunchSet base;
         if (nseg == 1) {
             rc = acquire_records(b, start, nframes, st, false);
@@ -2423,8 +2567,11 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
             hipLaunchKernelGGL(k_prepare_segments, dim3(nchunks, nseg), dim3(64), 0, st, ptrs(b), base, b->nvoices, start, nframes, SEG);
             SH_CHECK_LAUNCH("k_prepare_segments");
         }
-        hipLaunchKernelGGL(k_generate_lean_harm<LF>, dim3(sh::div_up(nframes, 256 * LF), nchunks), dim3(256), 0, st,
-                           trig_table(), base, b->nvoices, nframes, nseg == 1 ? (nframes + 1023u) / 1024u * 1024u : SEG, o, stride);
+        SegTab none;
+        none.n = 0;
+        SH_GEN_LEAN(dim3(sh::div_up(nframes, 256 * LF), nchunks), trig_table(), base, b->nvoices, nframes,
+                    nseg == 1 ? (nframes + 1023u) / 1024u * 1024u : SEG, o, stride, none);
+#undef SH_GEN_LEAN
         SH_CHECK_LAUNCH("k_generate_lean_harm");
         for (uint32_t sg = 0; sg < nseg; ++sg) {
             const uint32_t first = sg * SEG, n = nframes - first < SEG ? nframes - first : SEG;
@@ -2567,41 +2714,9 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     {
         static int no_seg = -1;
         if (no_seg < 0) { const char* e = getenv("SYNTHHIP_NO_SEG"); no_seg = (e && e[0] == '1') ? 1 : 0; }
-        const uint64_t end = start + nframes;
         if (split && (mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_ALL) && var == 484 && b->all_lean && !no_seg && !b->needs_rows && !b->no_general_voice(start, nframes)) {
-            const uint64_t T = (uint64_t)(64 * F);
-            uint64_t cuts[SEG_MAX + 2];
-            uint32_t nc = 0;
-            uint64_t pos = start;
-            cuts[nc++] = pos;
-            // cuts: the envelope corners the voices share (a sloped line is lean in a segmented launch's records, a corner is
-            // not) -- or, when the voices have envelopes of their own, the frame from which all of them are flat -- and, between
-            // those, doubling positions
-            const uint64_t flat = b->env_flat_from, rel = b->env_flat_until;       // last decay end, first sustain end
-            const bool shared = !b->env_corners.empty();
-            if (!shared && pos < flat && flat < end) { pos = flat; cuts[nc++] = pos; }
-            bool ok = true;
-            static long seg_min = -1;
-            if (seg_min < 0) { const char* e = getenv("SYNTHHIP_SEG_MIN"); seg_min = e ? atol(e) : 0; }
-            while (ok && pos < end) {
-                uint64_t next = pos < T ? T : 2 * pos;                             // at most one piece end per voice in [pos, 2 pos)
-                if (pos == start && start < (uint64_t)seg_min && (uint64_t)seg_min < end) next = (uint64_t)seg_min;   // the dense first segment
-                else
-                if (shared) {
-                    for (uint64_t c : b->env_corners)
-                        if (c > pos && c < next) { next = c; break; }
-                } else if (pos < rel && rel < next) {
-                    next = rel;
-                }
-                if (next >= end || (end - next <= next / 64 && !shared)) next = end;   // (a very short rest joins the last segment)
-                if (nc > SEG_MAX) { ok = false; break; }
-                pos = next;
-                cuts[nc++] = pos;
-            }
-            if (ok && nc >= 3) {
-                nseg = nc - 1;
-                for (uint32_t k = 0; k < nc; ++k) seg_first[k] = (uint32_t)(cuts[k] - start);
-            }
+            nseg = plan_segments(b, start, nframes, (uint64_t)(64 * F), ~0ull, true, seg_first);
+            if (nseg < 2 || seg_first[nseg] != nframes) nseg = 0;        // nothing to cut, or more cuts than a launch carries
         }
     }
     if (nseg == 0) {
@@ -2681,7 +2796,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         BankPtrs P = ptrs(b);
         P.nseg = nseg;
         for (uint32_t k = 0; k <= nseg; ++k) P.seg_first[k] = seg_first[k];
-        hipLaunchKernelGGL(k_prepare_segments_var, dim3(nchunks, nseg), dim3(64), 0, st, P, g, b->nvoices, start);
+        hipLaunchKernelGGL(k_prepare_segments_var<true>, dim3(nchunks, nseg), dim3(64), 0, st, P, g, b->nvoices, start);
         SH_CHECK_LAUNCH("k_prepare_segments_var");
         uint32_t tiles_lean = 0, tiles_gen = 0;
         for (uint32_t k = 0; k < nseg; ++k) {

@@ -212,6 +212,32 @@ def test_segmented_materialisation_of_long_rows(gpu):
     assert np.sqrt(np.mean((two.astype(np.float64) - fused) ** 2)) <= 5e-7
 
 
+def test_materialisation_from_the_start_of_the_notes(gpu):
+    """sh_bank_generate over rows that start at frame 0: the head (attack, decay, a dozen binades of the phase sum) is cut into
+    unequal segments with a record set each (plan_segments, k_prepare_segments_var<false>, the lean and the lists kernel driven
+    by the segment table, the general voices of a chunk dealt to several workgroups), the rest follows with equal segments."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    nv, n = 192, 300_000
+    v, g = additive_voices(G, nv, SR, seed=21, adsr={"sustain": 3.0})
+    harm = [(k, 1.0 / k) for k in range(1, 17)]
+    v[3] = G.EnvelopeFilter(G.Harmonics(150.0, harm, amplitude=0.02, phase=-0.3, samplerate=SR), 0.01, 0.05, 3.0, 0.6, 0.2)
+    v[70] = G.EnvelopeFilter(G.Harmonics(250.0, harm, amplitude=0.02, samplerate=SR), 0.0, 0.02, 0.1, 0.5, 0.05)       # released and silent early
+    bank = VoiceBank(v, gains=g)
+    rows = bank.generate(n, start=0)
+    assert rows.shape == (nv, n)
+    for i in (0, 3, 63, 64, 70, 191):
+        one = v[i].render(n, start=0)
+        assert np.max(np.abs(rows[i] - one)) < 2e-7 and np.mean(rows[i] != one) < 0.01, i
+    assert not rows[70, int(0.2 * SR):].any()
+    for start, cnt in ((0, 20_000), (0, 48_000), (100, 70_000), (40_000, 30_000), (65_000, 9000), (0, 8192)):
+        part = bank.generate(cnt, start=start)
+        assert np.max(np.abs(part - rows[:, start:start + cnt])) < 2e-7, (start, cnt)
+    two = bank.render_two_step(n, start=0)
+    fused = bank.render(n, start=0)
+    assert np.sqrt(np.mean((two.astype(np.float64) - fused) ** 2)) <= 5e-7
+
+
 def test_recurrence_at_frequencies_where_the_step_angle_is_degenerate(gpu):
     """The lean loop steps 64 samples by x[j] = 2cos(d) x[j-1] - x[j-2], d = 64*dt.  Where sin(d) is tiny -- 750 Hz at 48 kHz is
     d = 2 pi exactly, 375 Hz d = pi, and their neighbours -- 2cos(d) pins the step angle least precisely (error ~1e-16/|sin d|
