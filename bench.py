@@ -543,12 +543,15 @@ def main() -> int:
         bus = N.DeviceBuffer(F2 * 8)
         gen_ms = steady(N, lambda: bank.local.generate_device(F2, Wm * F, out=vbuf), min_seconds=0.03, reps=3)
         mix_ms = steady(N, lambda: bank.local.mix_device(vbuf, F2, bus_f32=bus), min_seconds=0.03, reps=3)
+        gen0_ms = steady(N, lambda: bank.local.generate_device(F2, 0, out=vbuf), min_seconds=0.03, reps=3)     # rows that start with the notes
         mix_bytes = (4.0 * nv + 8.0) * F2
         gen_bytes = 4.0 * nv * F2
         tm, tg = _by_prefix(prof["traffic"], "k_mix_bus"), _by_prefix(prof["traffic"], "k_generate")
         out["two_step"] = {
             "frames_per_launch": F2, "voices": nv,
             "value": nv * F2 / ((gen_ms + mix_ms) / 1e3) / 1e6, "unit": "Msamples/s",
+            "from_frame_0": {"generate_ms": gen0_ms, "value": nv * F2 / ((gen0_ms + mix_ms) / 1e3) / 1e6, "unit": "Msamples/s",
+                             "note": "the same rows starting with the notes (attack, decay, the first binades of the phase sum: the head of the rows in unequal segments)"},
             "roofline_mix": {"kernel": "k_mix_bus_direct<8,4>", "bound": "hbm", "achieved": mix_bytes / (mix_ms / 1e3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mix_bytes / (mix_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                              "traffic": tm["hbm_bytes"] if tm else None, "avg_launch_ms": mix_ms, "bytes_per_frame": 4 * nv + 8,
