@@ -149,6 +149,32 @@ const char* sh_last_error(void);
 const char* sh_version(void);
 int  sh_sync(void);                       /* wait for the stream */
 
+/* What the library did behind the caller's back since sh_init: driver allocations (hipMalloc: pool misses, growing blocks),
+ * driver frees, host-side stream synchronisations it inserted on its own (NOT the caller's sh_sync / downloads / timers), and
+ * buffers served from the pool.  A streaming caller in its steady state -- blocks of lengths it has rendered before, buffers
+ * of sizes it has used before -- must leave the first three unchanged (tests/test_gpu_bank.py asserts it). */
+typedef struct sh_counters {
+    uint64_t device_allocs, device_frees, stream_syncs, pool_hits;
+} sh_counters;
+int  sh_debug_counters(sh_counters* out);
+
+/* Measurement knobs: environment variables read ONCE, by sh_init.  None changes a result -- they choose between code paths
+ * that produce the same buses, so that A/B timings can be taken with one library (tools/):
+ *   SYNTHHIP_NO_SPECULATION=1     launch records by a prepare kernel in front of every render (no records two launches ahead)
+ *   SYNTHHIP_NO_OVERLAP=1         consecutive renders of a bank stay on one stream
+ *   SYNTHHIP_NO_SMALL_PIPELINE=1  single-group (small) banks render on one stream; several-group banks still alternate
+ *   SYNTHHIP_PREPARE_IN_TILE=1    the records of the block two launches on are resolved by the first tile workgroups in front of
+ *                                 their own work instead of by workgroups of their own
+ *   SYNTHHIP_NO_SPLIT=1           lean and general code in one render kernel
+ *   SYNTHHIP_NO_SEG=1             transition launches / the heads of materialised rows are not cut into segments
+ *   SYNTHHIP_ALWAYS_GENERAL=1     the general-lists kernel of a split launch is launched even when provably idle
+ *   SYNTHHIP_VARIANT=WFM          render kernel shape: waves per workgroup, frames per lane, min waves per SIMD (e.g. 484)
+ *   SYNTHHIP_GROUPS=n             voice groups of a render launch
+ *   SYNTHHIP_GEN_LF=4|8|16        frames per lane of the lean materialisation kernel;  SYNTHHIP_GEN_ROWS=1|2 rows per wave
+ *   SYNTHHIP_GEN_SUB=1..16        split of a segmented launch's first segment;  SYNTHHIP_SEG_MIN=frames of its dense first segment
+ *   SYNTHHIP_RESAMPLE_PK=0|1      the packed 16-bit mono resample kernel off / on
+ * (SYNTHHIP_LIB, read by the Python binding, names another build of this library to load.) */
+
 /* ---- device buffers ---------------------------------------------------------------- */
 int    sh_buf_alloc(size_t bytes, sh_buf** out);
 int    sh_buf_free(sh_buf* b);

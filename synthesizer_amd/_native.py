@@ -57,6 +57,10 @@ assert SEGMENT_DTYPE.itemsize == 24 and PARTIAL_DTYPE.itemsize == 16 and ENVELOP
 assert VOICE_DTYPE.itemsize == 240, VOICE_DTYPE.itemsize
 
 
+class Counters(C.Structure):
+    _fields_ = [("device_allocs", C.c_uint64), ("device_frees", C.c_uint64), ("stream_syncs", C.c_uint64), ("pool_hits", C.c_uint64)]
+
+
 class DevInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int32),
                 ("clock_mhz", C.c_int32), ("hbm_bytes", C.c_uint64), ("wavefront", C.c_int32), ("device", C.c_int32)]
@@ -73,6 +77,7 @@ _SIGNATURES = {
     "sh_last_error": (C.c_char_p, []),
     "sh_version": (C.c_char_p, []),
     "sh_sync": (C.c_int, []),
+    "sh_debug_counters": (C.c_int, [C.POINTER(Counters)]),
     "sh_buf_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
     "sh_buf_free": (C.c_int, [_P]),
     "sh_buf_view": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
@@ -158,6 +163,8 @@ def lib() -> C.CDLL:
                 "There is no CPU fallback." % LIB_PATH)
         handle = C.CDLL(str(LIB_PATH))
         for name, (res, args) in _SIGNATURES.items():
+            if "SYNTHHIP_LIB" in os.environ and not hasattr(handle, name):
+                continue                    # an older build named for an A/B timing (tools/): what it lacks cannot be called
             fn = getattr(handle, name)      # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
@@ -216,6 +223,13 @@ def device_info() -> dict:
     return {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": info.compute_units,
             "clock_mhz": info.clock_mhz, "hbm_bytes": info.hbm_bytes, "wavefront": info.wavefront,
             "device": info.device}
+
+
+def debug_counters() -> dict:
+    """Driver allocations / frees / self-inserted stream synchronisations / pool hits since sh_init (sh_debug_counters)."""
+    c = Counters()
+    check(lib().sh_debug_counters(C.byref(c)))
+    return {"device_allocs": c.device_allocs, "device_frees": c.device_frees, "stream_syncs": c.stream_syncs, "pool_hits": c.pool_hits}
 
 
 def sync() -> None:

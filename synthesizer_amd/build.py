@@ -17,12 +17,12 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libsynthhip.so"
-SOURCES = ["runtime.hip", "osc.hip", "pcm.hip", "pcm_ops.hip", "dist.hip"]
-HEADERS = ["common.hpp", "devmath.hpp", "../../include/synthhip.h"]
+SOURCES = ["runtime.hip", "osc_bank.hip", "osc_render.hip", "osc_generate.hip", "osc_mixbus.hip", "osc_scan.hip", "pcm.hip", "pcm_ops.hip", "dist.hip"]
+HEADERS = ["common.hpp", "devmath.hpp", "osc_device.hpp", "osc_host.hpp", "../../include/synthhip.h"]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off",          # fused multiply-add only where fma() is written (bit-exact PCM paths)
     "-fno-fast-math",
     "-fgpu-rdc" if False else "-fno-gpu-rdc",
@@ -31,12 +31,18 @@ FLAGS = [
 ]
 
 
+def extra_flags() -> list:
+    """SYNTHHIP_BUILD_FLAGS: extra compiler flags of a diagnostic build (e.g. -DSH_DIAG: in-kernel timestamps; never the
+    shipped library -- the flags are part of the embedded source hash)."""
+    return os.environ.get("SYNTHHIP_BUILD_FLAGS", "").split()
+
+
 def source_hash() -> str:
     """SHA-256 (16 hex digits) over the sources, headers and compiler flags the library is built from."""
     h = hashlib.sha256()
     for f in [CSRC / s for s in SOURCES] + [(CSRC / x).resolve() for x in HEADERS]:
         h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + extra_flags()).encode())
     return h.hexdigest()[:16]
 
 
@@ -63,15 +69,34 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if force or needs_build():
             tmp = LIB.with_suffix(".so.tmp%d" % os.getpid())
-            cmd = [HIPCC] + FLAGS + ['-DSH_SOURCE_HASH="%s"' % source_hash()] + [str(CSRC / s) for s in SOURCES] + ["-o", str(tmp), "-ldl"]
-            if verbose:
-                print(" ".join(cmd), flush=True)
+            objdir = HERE / "build" / ("obj%d" % os.getpid())
+            objdir.mkdir(parents=True, exist_ok=True)
+            defs = ['-DSH_SOURCE_HASH="%s"' % source_hash()] + extra_flags()
+            # one hipcc per translation unit, all at once (no relocatable device code: every kernel lives in the unit that launches it)
+            jobs = []
+            for src in SOURCES:
+                obj = objdir / (src + ".o")
+                cmd = [HIPCC] + FLAGS + defs + ["-c", str(CSRC / src), "-o", str(obj)]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                jobs.append((src, obj, subprocess.Popen(cmd)))
             try:
-                subprocess.run(cmd, check=True)
+                failed = [src for src, _obj, p in jobs if p.wait() != 0]
+                if failed:
+                    raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
+                link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [str(obj) for _s, obj, _p in jobs] + ["-o", str(tmp), "-ldl"]
+                if verbose:
+                    print(" ".join(link), flush=True)
+                subprocess.run(link, check=True)
                 os.replace(tmp, LIB)
             finally:
+                for _s, _obj, p in jobs:
+                    if p.poll() is None:
+                        p.kill()
                 if tmp.exists():
                     tmp.unlink()
+                import shutil
+                shutil.rmtree(objdir, ignore_errors=True)
     return LIB
 
 

@@ -49,15 +49,51 @@ struct State {
     // Bank renders that still owe the fold of their partial buses (over all banks: each bank keeps its own run of pipelined
     // launches, its pending folds and its ring of partial-bus buffers -- osc.hip, struct sh_bank)
     int         pending_total = 0;
+    int         open_runs = 0;         // banks whose run of pipelined renders is open (single-group banks owe no fold, but their
+                                       // launches alternate streams all the same: other entry points must join them first)
     // second render stream and the events that tie it to `stream`
     hipStream_t stream2 = nullptr;
     hipEvent_t  ev_join = nullptr;      // on `stream` when a run of renders starts: stream2's first launch of the run waits for it
     hipEvent_t  ev_aux = nullptr;       // on stream2 after every launch there: `stream` waits for it when the run ends
     hipEvent_t  ev_prep = nullptr;      // on `stream` after a prepare kernel that a stream2 launch needs
+    hipEvent_t  ev_sync = nullptr;      // join_streams: on `stream`, waited for by stream2
     bool        aux_busy = false;       // stream2 holds work `stream` has not waited for
 };
 
 State& state();
+
+// Measurement knobs, read from the environment ONCE (sh_init) -- include/synthhip.h lists them.  None of them changes a result;
+// they select between code paths that produce the same buses so that A/B timings can be taken with one library.
+struct Knobs {
+    bool no_speculation = false;   // SYNTHHIP_NO_SPECULATION=1: launch records by a prepare kernel in front of every render
+    bool no_overlap = false;       // SYNTHHIP_NO_OVERLAP=1: consecutive renders stay on one stream
+    bool no_split = false;         // SYNTHHIP_NO_SPLIT=1: lean and general code in one kernel
+    bool no_seg = false;           // SYNTHHIP_NO_SEG=1: transition launches / row heads are not cut into segments
+    bool always_general = false;   // SYNTHHIP_ALWAYS_GENERAL=1: the general-lists kernel of a split launch is always launched
+    bool no_small_pipeline = false;// SYNTHHIP_NO_SMALL_PIPELINE=1: single-group banks render on one stream (round-2 behaviour)
+    bool prepare_in_tile = false;  // SYNTHHIP_PREPARE_IN_TILE=1: the next-but-one block's records are resolved by the first tile workgroups
+                                   //   before their own work (round-2 behaviour) instead of by workgroups of their own
+    int  variant = 0;              // SYNTHHIP_VARIANT=WFM: waves, frames per lane, min waves per SIMD of the render kernel
+    int  groups = 0;               // SYNTHHIP_GROUPS: voice groups of a render launch
+    int  gen_lf = 0;               // SYNTHHIP_GEN_LF=4|8|16: frames per lane of the lean materialisation kernel
+    int  gen_sub = 4;              // SYNTHHIP_GEN_SUB=1..16: split of a segmented launch's first segment
+    long seg_min = 0;              // SYNTHHIP_SEG_MIN: frames of a segmented launch's dense first segment
+    int  gen_rows = 0;             // SYNTHHIP_GEN_ROWS=1|2: rows per wave of the lean materialisation kernel
+    int  resample_pk = -1;         // SYNTHHIP_RESAMPLE_PK=0|1: packed 16-bit mono resample kernel
+    int  pool_fill = -1;           // SYNTHHIP_POOL_FILL=0..255: blocks that grow are filled with this byte first (diagnostics)
+};
+const Knobs& knobs();
+void load_knobs();                 // sh_init
+
+// What the library has done behind the caller's back since sh_init (sh_debug_counters): a streaming caller's steady state
+// must leave all of them unchanged.
+struct Counters {
+    uint64_t device_allocs = 0;    // hipMalloc calls (pool misses included)
+    uint64_t device_frees = 0;     // hipFree calls
+    uint64_t stream_syncs = 0;     // host-side waits the library inserted on its own (growing a buffer; NOT the caller's sh_sync / downloads)
+    uint64_t pool_hits = 0;        // buffers handed out again without touching the driver
+};
+Counters& counters();
 // Every extern "C" entry point holds this for its whole body: one stream, one scratch buffer, one pool and one pending
 // fold are shared by all callers, and the real-time mixer is driven from two threads (one adds samples, one pulls
 // chunks).  Recursive: entry points call each other.
@@ -69,9 +105,19 @@ int  ensure_scratch(size_t bytes);
 int  pool_alloc(size_t bytes, void** ptr, size_t* cap);   // device buffer pool (runtime.hip)
 void pool_free(void* ptr, size_t cap);
 void pool_trim();
+// A pool-backed device block that only grows (partial buses, record sets of segmented launches): growing it makes both render
+// streams wait for each other (events, no host synchronisation), gives the old block back to the pool and takes a larger one --
+// the contents are NOT kept.
+struct Pooled {
+    void*  ptr = nullptr;
+    size_t cap = 0;
+};
+int  join_streams();                   // stream waits for stream2 and stream2 for stream (osc_render.hip)
+int  grow_pooled(Pooled& p, size_t bytes);
+void release_pooled(Pooled& p);
 int  flush_pending();                  // end every bank's run of renders: join stream2, fold all outstanding partial buses now (osc.hip)
 void free_render_buffers();            // the banks' partial-bus rings (sh_shutdown)
-inline bool has_pending() { return state().pending_total != 0 || state().aux_busy; }
+inline bool has_pending() { return state().pending_total != 0 || state().aux_busy || state().open_runs != 0; }
 int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out);   // float64 bus -> float32 (osc.hip)
 
 #define SH_REQUIRE_INIT_KEEP_PENDING()                                                 \

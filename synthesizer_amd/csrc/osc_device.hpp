@@ -1,0 +1,1092 @@
+// osc_device.hpp -- device-side records and arithmetic shared by the oscillator-bank kernels (gfx950).
+//
+// One thread per output sample.  The reference's per-voice generator state
+// (oscillators.py: running `t`, FM `phase_correction`, EnvelopeFilter `time`/`amp`) is
+// replaced by closed forms of the sample index:
+//   * non-FM phase: exact piecewise-linear table of the float64 accumulation (sh_segment)
+//   * FM phase:     theta_n = phase0 + f*T_n + f*inc*L(n), T = accumulated time table,
+//                   L = running sum of the LFO (closed form for a Sine LFO, or a scanned buffer)
+//   * envelope:     integer sample boundaries + slopes prepared by the host
+// Arithmetic is float64 up to the final store (one rounding to float32), built with
+// -ffp-contract=off so that a*b+c is fused only where fma() is written.
+//
+// Translation units (each compiled on its own, no relocatable device code: a kernel lives where it is launched):
+//   osc_bank.hip      the voice table in HBM (sh_bank), the launch records of a block (k_prepare*: everything that depends on
+//                     `start` resolved once per voice, voices classified into lean / general / silent lists)
+//   osc_render.hip    fused generate-and-mix (k_bank_render), the fold of the voice groups' partial buses, the two-stream
+//                     pipeline of consecutive blocks
+//   osc_generate.hip  voices materialised as PCM rows (k_generate*), single oscillators (sh_osc_render)
+//   osc_mixbus.hip    the HBM-bound mixer over materialised float32 voices
+//   osc_scan.hip      float64 running sums (arbitrary fm_lfo modulators) and the elementwise filter kernel
+#pragma once
+#include "common.hpp"
+#include "devmath.hpp"
+#include <type_traits>
+
+namespace shosc {
+
+constexpr int SEG_MAX = 24;            // segments of a transition launch
+// Unequal segments of a materialised row's head (n = 0: none): entry k holds the frames [first[k], first[k] + len[k]) and reads
+// record set set[k] (the lists launch skips the segments the host can prove free of general voices)
+struct SegTab { uint32_t n; uint32_t first[SEG_MAX]; uint32_t len[SEG_MAX]; uint32_t set[SEG_MAX]; };
+
+struct BankPtrs {
+    const sh_voice*   voices;
+    const sh_segment* segs;
+    const double*     coefs;
+    const sh_partial* partials;
+    uint32_t*         hint;       // per voice: table piece of the last prepared launch (streaming: same or next piece)
+    const double2*    seg_rot;    // per table piece: (cos, sin)(64*dt), computed once on the host at bank creation
+    const double2*    lfo_rot;    // per voice: (cos, sin)(64*lfo_d)
+    // per launch (sh_bank_render_rows): float64 rows [row][row_stride], launch-relative -- the running LFO sum of an
+    // SH_FM_BUFFER voice (fm_row), the pulse width per sample of a Pulse with a pwm_lfo (pwm_row), or the samples themselves of
+    // an SH_BUFFER voice (fm_row); -1 = none.  NULL outside such launches.
+    const double*     rows;
+    size_t            row_stride;
+    const int32_t*    fm_row;
+    const int32_t*    pwm_row;
+    // per launch (a transition launch cut into segments, RENDER_*_SEG): segment s holds the launch's frames
+    // [seg_first[s], seg_first[s + 1]) and has a record set of its own (segment_set); nseg = 0 otherwise
+    uint32_t          nseg;
+    uint32_t          seg_first[SEG_MAX + 1];
+    // RENDER_GENERAL_SEG: the FIRST segment holds every voice (several piece ends per tile, sloped envelope) and a workgroup's
+    // walk through its group's list is the launch's critical path: there, gen_sub workgroups share a (tile, group) -- list
+    // entries dealt round robin -- and write float64 slices [(group * gen_sub + sub) * seg_first[1] + frame] of gen_scratch,
+    // which k_seg_combine adds in order into the group's general parts.  Later segments: sub 0 alone, straight into the parts.
+    uint32_t          gen_sub;
+    double2*          gen_scratch;
+};
+
+// Pointers to data that no thread of the running kernel writes are cast to the constant address space:
+// a wave-uniform load through such a pointer is a scalar load (s_load_dwordxN into SGPRs) instead of a
+// per-lane vector load.
+#define SH_CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const T SH_CONST_AS* as_const(const T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const T SH_CONST_AS*)p;
+#pragma clang diagnostic pop
+}
+
+// Per-launch voice record, written by k_prepare and read (as one batch of scalar loads) by the render
+// kernels.  Everything that depends on `start` is resolved here once per voice instead of once per
+// wave: the phase-table piece that holds `start`, and the envelope as lines in the launch-relative frame
+// index i = n - start.  The scalar unit (one per CU) is the scarce resource of these kernels, so the
+// record is laid out to cost the hot path one batch of loads and almost no scalar arithmetic.
+constexpr uint32_t FL_KIND = 0xF, FL_FM_SHIFT = 4, FL_FM = 0x30, FL_DENSE = 0x40, FL_ENV_UNIFORM = 0x80,
+                   FL_POLY = 0x100, FL_FOLDED = 0x200, FL_FLIP = 0x400, FL_SILENT = 0x800;
+constexpr uint32_t NO_TAIL = 0xFFFFFFFFu;
+constexpr int NXP = 12;                             // following phase-table pieces a launch record lists
+
+struct alignas(16) VoiceLaunch {
+    // ---- hot part (96 bytes) ----
+    double   t_base, dt;          // table value at `start` and the increment of its piece
+    uint32_t remain;              // frames from `start` that stay on the piece (saturated)
+    uint32_t flags;               // kind | fm_mode << 4 | dense << 6 | env_uniform << 7 | poly << 8
+    const double* harm;           // coefficients (dense / poly) or partials (sparse), absolute address
+    double   amplitude, bias;
+    double   gain_l, gain_r;
+    double   g0u, slu;            // FL_ENV_UNIFORM: the whole launch lies on one envelope piece, gain(i) = fma(i, slu, g0u)
+    uint32_t harm_cnt;
+    uint32_t seg;                 // piece index (slow path resumes the walk here)
+    uint32_t tail_i;              // launch-relative index of the post-release extra sample, or NO_TAIL
+    uint32_t nx_count;            // following table pieces listed in nx_end
+    double   poly[16];            // FL_POLY: the 16 polynomial coefficients, copied here so that the record
+                                  // and the coefficients arrive in ONE batch of scalar loads
+    double   rot_c, rot_s;        // cos / sin of 64*dt: a lane's second frame is 64 samples after its first, so its
+                                  // (sin, cos) is one rotation of the first frame's instead of a second table lookup
+    // ---- cold part: launches that cross an envelope boundary, Pulse ----
+    uint32_t eb[4];               // launch-relative ends of attack / decay / sustain / release (saturated)
+    double   g0[4], slope[4];     // gain(i) = fma(i, slope[p], g0[p]) on piece p; 0 after release
+    double   tail_amp;
+    double   pulsewidth;
+    // the table pieces that follow inside the launch (the first second of a note runs through a dozen binades of the
+    // phase sum): piece k (table index seg+1+k) holds the frames [nx_start(k), nx_end[k]), nx_start(0) = remain,
+    // nx_start(k) = nx_end[k-1]; there t = fma(i - nx_start(k), dt, t0) with the piece's (t0, dt) from the table
+    uint32_t nx_end[NXP];
+};
+static_assert(sizeof(VoiceLaunch) == 384, "VoiceLaunch layout");
+
+struct alignas(16) VoiceFM {      // only read for FM voices
+    double frequency, phase0, f_inc;      // theta = frequency*T + fma(f_inc, L, phase0)
+    double lfo_a_rel, lfo_d, lfo_K, lfo_C0, lfo_bias;   // L(i) = K*(C0 - cos(a_rel + i*d)) + bias*(start+i)
+    double lfo_rot_c, lfo_rot_s;          // cos / sin of 64*lfo_d: the LFO angle of a lane's next frame is one rotation away
+};
+static_assert(sizeof(VoiceFM) == 80, "VoiceFM layout");
+
+// The common voice of an additive bank in steady state -- polynomial Harmonics, no FM, amplitude and (constant)
+// envelope gain folded into the bus gains, the launch on one table piece or crossing one piece end -- needs only
+// this much per launch.
+// The render kernel walks these records in a loop of its own, with none of the general code's flag tests.
+struct alignas(64) FastRec {
+    // ---- the first 192 bytes are all a launch without a piece crossing needs: three s_load_dwordx16 ----
+    double t_base, dt;            // frames i < remain: t(i) = fma(i, dt, t_base)
+    double gain_l, gain_r;        // amplitude * envelope gain * bus gain
+    double rot_c, rot_s;          // cos / sin of 64*dt
+    double poly[16];              // sum_k a_k sin(k t) = sin(t) * P(cos t)
+    uint32_t remain;              // 0xFFFFFFFF: no crossing in this launch
+    uint32_t kind;                // LEAN_HARM: the fields as described; LEAN_FM: Sine carrier with a closed-form Sine LFO --
+                                  // t is the accumulated TIME table, poly[0..10] = frequency, phase0, f_inc, lfo_a_rel, lfo_d,
+                                  // lfo_K, lfo_C0, lfo_bias, lfo_rot_c, lfo_rot_s, (double)start (see VoiceFM)
+    double off_b;                 // (double)remain
+    // ---- read only when the launch crosses ONE end of a phase-table piece (a binade of the running sum), at `remain` ----
+    double t0_b, dt_b;            // frames i >= remain: t(i) = fma(i - remain, dt_b, t0_b)
+    double rot_c_b, rot_s_b;      // cos / sin of 64*dt_b
+    // ---- k_generate_lists ----
+    double amplitude, g0u;        // unfolded: the voice's own sample is ((x * amplitude) + 0) * g0u.  In the record sets of a
+                                  // segmented launch (prepare_chunk<true>): the slopes of gain_l / gain_r per frame instead
+    uint32_t vi;                  // the voice
+    uint32_t pad1;
+    double pad2;
+};
+static_assert(offsetof(FastRec, t0_b) == 192, "FastRec: common part is 192 bytes");
+static_assert(sizeof(FastRec) == 256, "FastRec layout");
+constexpr uint32_t LEAN_HARM = 0, LEAN_FM = 1,                 // ... and the plain waveforms without FM (t in turns, Sine: radians);
+                   LEAN_SINE = 2, LEAN_SAW = 3, LEAN_SQUARE = 4, LEAN_TRIANGLE = 5, LEAN_PULSE = 6;    // Pulse: poly[0] = pulsewidth
+
+// The accumulated t of a lane's frame j (64 samples apart) on the launch's first or second phase-table piece -- by VALUE
+// members (a lambda capturing by reference kept its closure, and with it every captured scalar, in scratch memory).
+struct LaneTheta {
+    double   di0;                 // the lane's first frame
+    double   t_base, dt, off;     // the tile's piece when it lies on one (uniform): t = fma(i - off, dt, t_base)
+    double   ta, da, tb, db, ob;  // both pieces, for the tile that straddles the end of the first at `remain`
+    uint32_t i0, remain;
+    bool     straddle;
+    __device__ __forceinline__ double operator()(int j) const {
+        const double dd = di0 + (double)(j * 64);
+        if (!straddle) return fma(dd - off, dt, t_base);
+        return i0 + (uint32_t)j * 64u < remain ? fma(dd, da, ta) : fma(dd - ob, db, tb);
+    }
+};
+
+// One set of per-launch data (double-buffered in the bank).  Voices are classified per chunk of 64 consecutive
+// voices: the fast voices of chunk c get a FastRec, compacted at fast[64c ..], the others are listed by index in
+// gen_idx[64c ..] (both in ascending voice order: the summation order is fixed), silent voices appear in neither.
+struct LaunchSet {
+    VoiceLaunch* launch;
+    VoiceFM*     fm;
+    FastRec*     fast;
+    uint32_t*    gen_idx;
+    uint32_t*    counts;          // per chunk: [4c] = lean voices, [4c+1] = general voices, [4c+2] = silent voices
+};
+
+struct PrepInfo {                 // what prepare_voice found, for the classification
+    bool   fast, silent;
+    double t_base, dt, gain_l, gain_r, rot_c, rot_s;
+    double t0_b, dt_b, rot_c_b, rot_s_b;
+    uint32_t remain;
+    uint32_t kind;                // LEAN_HARM / LEAN_FM
+    double   amplitude, g0u, pulsewidth;
+    double   fmv[11];             // LEAN_FM: the values that go to FastRec::poly[0..10]
+    double   slope_l, slope_r;    // a record set of sloped lean records (SLOPED): gain(i) = gain + i * slope on the envelope's line
+    double   poly[16];            // FL_POLY: the coefficients (read once, with the table pieces; the lean record is written from here)
+};
+
+#ifdef SH_OLD_PREPARE
+// SLOPED (the record sets of a segmented transition launch): a polynomial-Harmonics voice on ONE envelope line of any slope is
+// lean too -- its record carries the line folded into the bus gains (gain + i * slope) -- not only one on a constant gain.
+template <bool SLOPED = false>
+__device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first, uint32_t vi, uint64_t start, uint32_t nframes,
+                                              VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm, PrepInfo& info) {
+    // Fields are stored straight to the record (no local struct: a 368-byte private array would give
+    // every wave of the render kernel a scratch allocation).
+    const sh_voice& v = B.voices[first + vi];
+    VoiceLaunch* __restrict__ o = out + vi;
+    const bool fm = v.fm_mode != SH_FM_NONE;
+    const uint32_t off = fm ? v.time_seg_offset : v.seg_offset;
+    const uint32_t cnt = fm ? v.time_seg_count : v.seg_count;
+    const sh_segment* tab = B.segs + off;
+    uint32_t lo = B.hint[first + vi];
+    if (lo < cnt && tab[lo].n0 <= start && lo + 2 < cnt && start < tab[lo + 2].n0) {
+        if (start >= tab[lo + 1].n0) ++lo;                     // streaming: still on the piece, or on the next one
+    } else {
+        lo = 0;
+        uint32_t hi = cnt - 1;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (tab[mid].n0 <= start) lo = mid; else hi = mid - 1;
+        }
+    }
+    B.hint[first + vi] = lo;
+    const double dt = tab[lo].dt;
+    const double t_base = fma((double)(start - tab[lo].n0), dt, tab[lo].t0);
+    const uint64_t rem = (lo + 1 < cnt) ? (tab[lo + 1].n0 - start) : 0xFFFFFFFFull;
+    o->t_base = t_base;
+    o->dt = dt;
+    o->remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
+    o->seg = lo;
+    {
+        uint32_t count = 0;
+        uint64_t piece_start = rem;                           // launch-relative first frame of the next piece
+#pragma unroll 1
+        for (int k = 0; k < NXP; ++k) {
+            const uint32_t pi = lo + 1 + k;
+            uint32_t end = 0xFFFFFFFFu;
+            if (count == (uint32_t)k && pi < cnt && piece_start < (uint64_t)nframes) {      // still inside the launch
+                const uint64_t e = (pi + 1 < cnt) ? (tab[pi + 1].n0 - start) : 0xFFFFFFFFull;
+                end = e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
+                piece_start = e;
+                count = (uint32_t)k + 1;
+            }
+            o->nx_end[k] = end;
+        }
+        o->nx_count = count;
+    }
+    uint32_t flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
+                     (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u) | (v.flip ? FL_FLIP : 0u);
+    const double* harm = v.harm_dense ? (B.coefs + v.harm_offset) : reinterpret_cast<const double*>(B.partials + v.harm_offset);
+    o->harm = harm;
+    o->harm_cnt = v.harm_count;
+    o->amplitude = v.amplitude;
+    o->bias = v.bias;
+    o->pulsewidth = v.pulsewidth;
+    double gain_l = (double)v.gain_l, gain_r = (double)v.gain_r;
+    // envelope as four lines in the launch-relative frame index
+    uint32_t eb0, eb1, eb2, eb3, tail_i = NO_TAIL;
+    double g00, g01, g02, g03, s0, s1, s2, s3, tail_amp = 0.0;
+    const sh_envelope& e = v.env;
+    if (e.enabled) {
+        const uint64_t d0 = e.n_attack_end > start ? e.n_attack_end - start : 0;
+        const uint64_t d1 = e.n_decay_end > start ? e.n_decay_end - start : 0;
+        const uint64_t d2 = e.n_sustain_end > start ? e.n_sustain_end - start : 0;
+        const uint64_t d3 = e.n_release_end > start ? e.n_release_end - start : 0;
+        eb0 = d0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d0;
+        eb1 = d1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d1;
+        eb2 = d2 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d2;
+        eb3 = d3 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d3;
+        const double st = (double)start;
+        g00 = st * e.attack_slope;                                      // gain(n) = n * attack_slope
+        s0 = e.attack_slope;
+        g01 = fma(st - (double)e.n_attack_end, e.decay_slope, 1.0);     // 1 + (n - nA) * decay_slope
+        s1 = e.decay_slope;
+        g02 = e.sustain_level;
+        s2 = 0.0;
+        g03 = fma(st - (double)e.n_sustain_end, e.release_slope, e.sustain_level);
+        s3 = e.release_slope;
+        if (e.has_tail && e.n_release_end >= start && e.n_release_end - start < 0xFFFFFFFFull) {
+            tail_i = (uint32_t)(e.n_release_end - start);
+            tail_amp = e.tail_amp;
+        }
+    } else {                       // no envelope: an endless sustain piece of gain 1
+        eb0 = 0; eb1 = 0; eb2 = 0xFFFFFFFFu; eb3 = 0xFFFFFFFFu;
+        g00 = g01 = g02 = g03 = 1.0;
+        s0 = s1 = s2 = s3 = 0.0;
+    }
+    o->eb[0] = eb0; o->eb[1] = eb1; o->eb[2] = eb2; o->eb[3] = eb3;
+    o->g0[0] = g00; o->g0[1] = g01; o->g0[2] = g02; o->g0[3] = g03;
+    o->slope[0] = s0; o->slope[1] = s1; o->slope[2] = s2; o->slope[3] = s3;
+    o->tail_i = tail_i;
+    o->tail_amp = tail_amp;
+    // does the whole launch [0, nframes) sit on one envelope piece?
+    double g0u = 0.0, slu = 0.0;
+    {
+        const uint32_t last = nframes ? nframes - 1 : 0;
+        const bool tail_here = tail_i != NO_TAIL && tail_i <= last;
+        if (eb0 > 0) { if (last < eb0) { flags |= FL_ENV_UNIFORM; g0u = g00; slu = s0; } }
+        else if (eb1 > 0) { if (last < eb1) { flags |= FL_ENV_UNIFORM; g0u = g01; slu = s1; } }
+        else if (eb2 > 0) { if (last < eb2) { flags |= FL_ENV_UNIFORM; g0u = g02; slu = s2; } }
+        else if (eb3 > 0) { if (last < eb3) { flags |= FL_ENV_UNIFORM; g0u = g03; slu = s3; } }
+        else if (!tail_here) flags |= FL_ENV_UNIFORM | FL_SILENT;      // released before this launch: silent throughout
+    }
+    o->g0u = g0u;
+    o->slu = slu;
+    const double2 rot = B.seg_rot[off + lo];
+    const double rc = rot.x, rs = rot.y;
+    o->rot_c = rc;
+    o->rot_s = rs;
+    if (flags & FL_POLY) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) o->poly[u] = harm[u];
+        // bias == 0 and a constant envelope gain: fold amplitude and envelope into the bus gains, so the
+        // inner loop is h = P(c)*s; L += GL*h; R += GR*h.  (Differs from the unfolded order by float64
+        // rounding only, ~1e-16 relative.)  Bank kernels only: k_generate needs the voice sample itself.
+        if (v.bias == 0.0 && !v.flip && (flags & FL_ENV_UNIFORM) && slu == 0.0) {
+            flags |= FL_FOLDED;
+            gain_l = (v.amplitude * g0u) * gain_l;
+            gain_r = (v.amplitude * g0u) * gain_r;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) o->poly[u] = 0.0;
+    }
+    o->gain_l = gain_l;
+    o->gain_r = gain_r;
+    o->flags = flags;
+    // Other voices that can take the lean loop: a Sine carrier with a closed-form Sine LFO, and the plain waveforms without
+    // FM.  Their record folds amplitude and envelope into the gains like FL_FOLDED does (the general code is not told: its
+    // paths apply the amplitude themselves).
+    const bool lean_env = v.bias == 0.0 && !v.flip && (flags & FL_ENV_UNIFORM) && slu == 0.0 && !(flags & FL_SILENT);
+    const bool lean_fm = lean_env && v.kind == SH_SINE && v.fm_mode == SH_FM_SINE;
+    const bool lean_plain = lean_env && v.fm_mode == SH_FM_NONE &&
+                            (v.kind == SH_SINE || v.kind == SH_SAWTOOTH || v.kind == SH_SQUARE || v.kind == SH_TRIANGLE || v.kind == SH_PULSE);
+    info.kind = lean_fm ? LEAN_FM
+              : !lean_plain ? LEAN_HARM
+              : v.kind == SH_SINE ? LEAN_SINE : v.kind == SH_SAWTOOTH ? LEAN_SAW : v.kind == SH_SQUARE ? LEAN_SQUARE
+              : v.kind == SH_TRIANGLE ? LEAN_TRIANGLE : LEAN_PULSE;
+    info.amplitude = v.amplitude;
+    info.g0u = g0u;
+    info.pulsewidth = v.pulsewidth;
+    if (lean_fm || lean_plain) {
+        gain_l = (v.amplitude * g0u) * gain_l;
+        gain_r = (v.amplitude * g0u) * gain_r;
+    }
+    info.silent = (flags & FL_SILENT) != 0;
+    // lean: the launch lies on the current table piece, or on it and the next one
+    const bool one_piece = rem >= (uint64_t)nframes;
+    const bool two_pieces = !one_piece && lo + 1 < cnt && ((lo + 2 < cnt) ? (tab[lo + 2].n0 - start >= (uint64_t)nframes) : true);
+    bool lean_sloped = false;
+    info.slope_l = 0.0;
+    info.slope_r = 0.0;
+    if (SLOPED && (flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT | FL_ENV_UNIFORM)) == (FL_POLY | FL_ENV_UNIFORM) && v.bias == 0.0 && !v.flip) {
+        lean_sloped = true;                               // (not FL_FOLDED: slu != 0)
+        gain_l = (v.amplitude * g0u) * (double)v.gain_l;
+        gain_r = (v.amplitude * g0u) * (double)v.gain_r;
+        info.slope_l = (v.amplitude * slu) * (double)v.gain_l;
+        info.slope_r = (v.amplitude * slu) * (double)v.gain_r;
+    }
+    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm || lean_plain || lean_sloped) && (one_piece || two_pieces);
+    info.remain = one_piece ? 0xFFFFFFFFu : (uint32_t)rem;
+    info.t0_b = one_piece ? t_base : tab[lo + 1].t0;
+    info.dt_b = one_piece ? dt : tab[lo + 1].dt;
+    {
+        const double2 rb = B.seg_rot[off + (one_piece ? lo : lo + 1)];
+        info.rot_c_b = rb.x;
+        info.rot_s_b = rb.y;
+    }
+    info.t_base = t_base;
+    info.dt = dt;
+    info.gain_l = gain_l;
+    info.gain_r = gain_r;
+    info.rot_c = rc;
+    info.rot_s = rs;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) info.poly[u] = (flags & FL_POLY) ? harm[u] : 0.0;
+    if (fm) {
+        VoiceFM* __restrict__ f = out_fm + vi;
+        f->frequency = v.frequency;
+        f->phase0 = v.fm_phase0;
+        f->f_inc = v.frequency * v.fm_inc;
+        f->lfo_a_rel = fma((double)start - 0.5, v.lfo_d, v.lfo_a);     // arg(i) = a + (start + i - 0.5) * d
+        f->lfo_d = v.lfo_d;
+        f->lfo_K = v.lfo_K;
+        f->lfo_C0 = v.lfo_C0;
+        f->lfo_bias = v.lfo_bias;
+        const double2 lrot = B.lfo_rot[first + vi];
+        f->lfo_rot_c = lrot.x;
+        f->lfo_rot_s = lrot.y;
+        info.fmv[0] = v.frequency; info.fmv[1] = v.fm_phase0; info.fmv[2] = v.frequency * v.fm_inc;
+        info.fmv[3] = fma((double)start - 0.5, v.lfo_d, v.lfo_a);
+        info.fmv[4] = v.lfo_d; info.fmv[5] = v.lfo_K; info.fmv[6] = v.lfo_C0; info.fmv[7] = v.lfo_bias;
+        info.fmv[8] = lrot.x; info.fmv[9] = lrot.y; info.fmv[10] = (double)start;
+    }
+}
+#else
+// SLOPED (the record sets of a segmented transition launch): a polynomial-Harmonics voice on ONE envelope line of any slope is
+// lean too -- its record carries the line folded into the bus gains (gain + i * slope) -- not only one on a constant gain.
+template <bool SLOPED = false>
+__device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first, uint32_t vi, uint64_t start, uint32_t nframes,
+                                              VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm, PrepInfo& info) {
+    // Fields are stored straight to the record (no local struct: a 368-byte private array would give
+    // every wave of the render kernel a scratch allocation).
+    // The loads are arranged in BATCHES of independent requests -- the voice and its hint; then the table pieces around the
+    // hint, their rotations and the polynomial; then (transition launches only) the ends of the following pieces -- because a
+    // lane's chain of dependent round trips IS the time this step takes: one wavefront resolves 64 voices, nothing hides its
+    // latency, and in a stream the step runs inside every render launch (eight dependent round trips took 8 us; three take 3).
+    const sh_voice& v = B.voices[first + vi];
+    VoiceLaunch* __restrict__ o = out + vi;
+    const bool fm = v.fm_mode != SH_FM_NONE;
+    const uint32_t off = fm ? v.time_seg_offset : v.seg_offset;
+    const uint32_t cnt = fm ? v.time_seg_count : v.seg_count;
+    const sh_segment* tab = B.segs + off;
+    const double2* rots = B.seg_rot + off;
+    const uint32_t hint = B.hint[first + vi];
+    const uint32_t last_piece = cnt - 1;
+    const bool poly_form = v.harm_dense == 2;
+    const double* harm = v.harm_dense ? (B.coefs + v.harm_offset) : reinterpret_cast<const double*>(B.partials + v.harm_offset);
+    // ---- second batch: pieces hint .. hint + 3 (indices clamped into the table), rotations, polynomial ----
+    const uint32_t h0 = hint < cnt ? hint : 0u;
+    const uint32_t h1 = h0 + 1 < cnt ? h0 + 1 : last_piece, h2 = h0 + 2 < cnt ? h0 + 2 : last_piece, h3 = h0 + 3 < cnt ? h0 + 3 : last_piece;
+    uint64_t p0_n0 = tab[h0].n0, p1_n0 = tab[h1].n0, p2_n0 = tab[h2].n0;
+    const uint64_t p3_n0 = tab[h3].n0;
+    double p0_t0 = tab[h0].t0, p0_dt = tab[h0].dt, p1_t0 = tab[h1].t0, p1_dt = tab[h1].dt;
+    const double p2_t0 = tab[h2].t0, p2_dt = tab[h2].dt;
+    double2 r0 = rots[h0], r1 = rots[h1];
+    const double2 r2 = rots[h2];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) info.poly[u] = poly_form ? harm[u] : 0.0;
+    uint32_t lo;
+    if (hint < cnt && p0_n0 <= start && hint + 2 < cnt && start < p2_n0) {
+        lo = hint;
+        if (start >= p1_n0) {                                  // streaming: still on the piece, or on the next one
+            lo = hint + 1;
+            p0_n0 = p1_n0; p0_t0 = p1_t0; p0_dt = p1_dt;
+            p1_n0 = p2_n0; p1_t0 = p2_t0; p1_dt = p2_dt;
+            p2_n0 = p3_n0;
+            r0 = r1;
+            r1 = r2;
+        }
+    } else {
+        lo = 0;
+        uint32_t hi = cnt - 1;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (tab[mid].n0 <= start) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t l1 = lo + 1 < cnt ? lo + 1 : last_piece, l2 = lo + 2 < cnt ? lo + 2 : last_piece;
+        p0_n0 = tab[lo].n0; p0_t0 = tab[lo].t0; p0_dt = tab[lo].dt;
+        p1_n0 = tab[l1].n0; p1_t0 = tab[l1].t0; p1_dt = tab[l1].dt;
+        p2_n0 = tab[l2].n0;
+        r0 = rots[lo];
+        r1 = rots[l1];
+    }
+    // from here on: piece lo = (p0_n0, p0_t0, p0_dt) with rotation r0, piece lo + 1 = (p1_*) with r1 where it exists, and the
+    // start of piece lo + 2 = p2_n0 where it exists
+    B.hint[first + vi] = lo;
+    const double dt = p0_dt;
+    const double t_base = fma((double)(start - p0_n0), dt, p0_t0);
+    const uint64_t rem = (lo + 1 < cnt) ? (p1_n0 - start) : 0xFFFFFFFFull;
+    o->t_base = t_base;
+    o->dt = dt;
+    o->remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
+    o->seg = lo;
+    if (rem >= (uint64_t)nframes) {                          // the launch stays on the piece: nothing follows inside it
+#pragma unroll
+        for (int k = 0; k < NXP; ++k) o->nx_end[k] = 0xFFFFFFFFu;
+        o->nx_count = 0;
+    } else {
+        // ---- third batch: the starts of the pieces lo + 2 .. lo + 1 + NXP (the ends of the pieces that follow) ----
+        uint64_t nxn[NXP];
+#pragma unroll
+        for (int k = 0; k < NXP; ++k) {
+            const uint32_t q = lo + 2 + (uint32_t)k;
+            nxn[k] = tab[q < cnt ? q : last_piece].n0;
+        }
+        uint32_t count = 0;
+        uint64_t piece_start = rem;                           // launch-relative first frame of the next piece
+#pragma unroll
+        for (int k = 0; k < NXP; ++k) {
+            const uint32_t pi = lo + 1 + k;
+            uint32_t end = 0xFFFFFFFFu;
+            if (count == (uint32_t)k && pi < cnt && piece_start < (uint64_t)nframes) {      // still inside the launch
+                const uint64_t e = (pi + 1 < cnt) ? (nxn[k] - start) : 0xFFFFFFFFull;
+                end = e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
+                piece_start = e;
+                count = (uint32_t)k + 1;
+            }
+            o->nx_end[k] = end;
+        }
+        o->nx_count = count;
+    }
+    uint32_t flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
+                     (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u) | (v.flip ? FL_FLIP : 0u);
+    o->harm = harm;
+    o->harm_cnt = v.harm_count;
+    o->amplitude = v.amplitude;
+    o->bias = v.bias;
+    o->pulsewidth = v.pulsewidth;
+    double gain_l = (double)v.gain_l, gain_r = (double)v.gain_r;
+    // envelope as four lines in the launch-relative frame index
+    uint32_t eb0, eb1, eb2, eb3, tail_i = NO_TAIL;
+    double g00, g01, g02, g03, s0, s1, s2, s3, tail_amp = 0.0;
+    const sh_envelope& e = v.env;
+    if (e.enabled) {
+        const uint64_t d0 = e.n_attack_end > start ? e.n_attack_end - start : 0;
+        const uint64_t d1 = e.n_decay_end > start ? e.n_decay_end - start : 0;
+        const uint64_t d2 = e.n_sustain_end > start ? e.n_sustain_end - start : 0;
+        const uint64_t d3 = e.n_release_end > start ? e.n_release_end - start : 0;
+        eb0 = d0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d0;
+        eb1 = d1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d1;
+        eb2 = d2 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d2;
+        eb3 = d3 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d3;
+        const double st = (double)start;
+        g00 = st * e.attack_slope;                                      // gain(n) = n * attack_slope
+        s0 = e.attack_slope;
+        g01 = fma(st - (double)e.n_attack_end, e.decay_slope, 1.0);     // 1 + (n - nA) * decay_slope
+        s1 = e.decay_slope;
+        g02 = e.sustain_level;
+        s2 = 0.0;
+        g03 = fma(st - (double)e.n_sustain_end, e.release_slope, e.sustain_level);
+        s3 = e.release_slope;
+        if (e.has_tail && e.n_release_end >= start && e.n_release_end - start < 0xFFFFFFFFull) {
+            tail_i = (uint32_t)(e.n_release_end - start);
+            tail_amp = e.tail_amp;
+        }
+    } else {                       // no envelope: an endless sustain piece of gain 1
+        eb0 = 0; eb1 = 0; eb2 = 0xFFFFFFFFu; eb3 = 0xFFFFFFFFu;
+        g00 = g01 = g02 = g03 = 1.0;
+        s0 = s1 = s2 = s3 = 0.0;
+    }
+    o->eb[0] = eb0; o->eb[1] = eb1; o->eb[2] = eb2; o->eb[3] = eb3;
+    o->g0[0] = g00; o->g0[1] = g01; o->g0[2] = g02; o->g0[3] = g03;
+    o->slope[0] = s0; o->slope[1] = s1; o->slope[2] = s2; o->slope[3] = s3;
+    o->tail_i = tail_i;
+    o->tail_amp = tail_amp;
+    // does the whole launch [0, nframes) sit on one envelope piece?
+    double g0u = 0.0, slu = 0.0;
+    {
+        const uint32_t last = nframes ? nframes - 1 : 0;
+        const bool tail_here = tail_i != NO_TAIL && tail_i <= last;
+        if (eb0 > 0) { if (last < eb0) { flags |= FL_ENV_UNIFORM; g0u = g00; slu = s0; } }
+        else if (eb1 > 0) { if (last < eb1) { flags |= FL_ENV_UNIFORM; g0u = g01; slu = s1; } }
+        else if (eb2 > 0) { if (last < eb2) { flags |= FL_ENV_UNIFORM; g0u = g02; slu = s2; } }
+        else if (eb3 > 0) { if (last < eb3) { flags |= FL_ENV_UNIFORM; g0u = g03; slu = s3; } }
+        else if (!tail_here) flags |= FL_ENV_UNIFORM | FL_SILENT;      // released before this launch: silent throughout
+    }
+    o->g0u = g0u;
+    o->slu = slu;
+    const double rc = r0.x, rs = r0.y;
+    o->rot_c = rc;
+    o->rot_s = rs;
+    if (flags & FL_POLY) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) o->poly[u] = info.poly[u];
+        // bias == 0 and a constant envelope gain: fold amplitude and envelope into the bus gains, so the
+        // inner loop is h = P(c)*s; L += GL*h; R += GR*h.  (Differs from the unfolded order by float64
+        // rounding only, ~1e-16 relative.)  Bank kernels only: k_generate needs the voice sample itself.
+        if (v.bias == 0.0 && !v.flip && (flags & FL_ENV_UNIFORM) && slu == 0.0) {
+            flags |= FL_FOLDED;
+            gain_l = (v.amplitude * g0u) * gain_l;
+            gain_r = (v.amplitude * g0u) * gain_r;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) o->poly[u] = 0.0;
+    }
+    o->gain_l = gain_l;
+    o->gain_r = gain_r;
+    o->flags = flags;
+    // Other voices that can take the lean loop: a Sine carrier with a closed-form Sine LFO, and the plain waveforms without
+    // FM.  Their record folds amplitude and envelope into the gains like FL_FOLDED does (the general code is not told: its
+    // paths apply the amplitude themselves).
+    const bool lean_env = v.bias == 0.0 && !v.flip && (flags & FL_ENV_UNIFORM) && slu == 0.0 && !(flags & FL_SILENT);
+    const bool lean_fm = lean_env && v.kind == SH_SINE && v.fm_mode == SH_FM_SINE;
+    const bool lean_plain = lean_env && v.fm_mode == SH_FM_NONE &&
+                            (v.kind == SH_SINE || v.kind == SH_SAWTOOTH || v.kind == SH_SQUARE || v.kind == SH_TRIANGLE || v.kind == SH_PULSE);
+    info.kind = lean_fm ? LEAN_FM
+              : !lean_plain ? LEAN_HARM
+              : v.kind == SH_SINE ? LEAN_SINE : v.kind == SH_SAWTOOTH ? LEAN_SAW : v.kind == SH_SQUARE ? LEAN_SQUARE
+              : v.kind == SH_TRIANGLE ? LEAN_TRIANGLE : LEAN_PULSE;
+    info.amplitude = v.amplitude;
+    info.g0u = g0u;
+    info.pulsewidth = v.pulsewidth;
+    if (lean_fm || lean_plain) {
+        gain_l = (v.amplitude * g0u) * gain_l;
+        gain_r = (v.amplitude * g0u) * gain_r;
+    }
+    info.silent = (flags & FL_SILENT) != 0;
+    // lean: the launch lies on the current table piece, or on it and the next one
+    const bool one_piece = rem >= (uint64_t)nframes;
+    const bool two_pieces = !one_piece && lo + 1 < cnt && ((lo + 2 < cnt) ? (p2_n0 - start >= (uint64_t)nframes) : true);
+    bool lean_sloped = false;
+    info.slope_l = 0.0;
+    info.slope_r = 0.0;
+    if (SLOPED && (flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT | FL_ENV_UNIFORM)) == (FL_POLY | FL_ENV_UNIFORM) && v.bias == 0.0 && !v.flip) {
+        lean_sloped = true;                               // (not FL_FOLDED: slu != 0)
+        gain_l = (v.amplitude * g0u) * (double)v.gain_l;
+        gain_r = (v.amplitude * g0u) * (double)v.gain_r;
+        info.slope_l = (v.amplitude * slu) * (double)v.gain_l;
+        info.slope_r = (v.amplitude * slu) * (double)v.gain_r;
+    }
+    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm || lean_plain || lean_sloped) && (one_piece || two_pieces);
+    info.remain = one_piece ? 0xFFFFFFFFu : (uint32_t)rem;
+    info.t0_b = one_piece ? t_base : p1_t0;
+    info.dt_b = one_piece ? dt : p1_dt;
+    info.rot_c_b = one_piece ? r0.x : r1.x;
+    info.rot_s_b = one_piece ? r0.y : r1.y;
+    info.t_base = t_base;
+    info.dt = dt;
+    info.gain_l = gain_l;
+    info.gain_r = gain_r;
+    info.rot_c = rc;
+    info.rot_s = rs;
+    if (fm) {
+        VoiceFM* __restrict__ f = out_fm + vi;
+        f->frequency = v.frequency;
+        f->phase0 = v.fm_phase0;
+        f->f_inc = v.frequency * v.fm_inc;
+        f->lfo_a_rel = fma((double)start - 0.5, v.lfo_d, v.lfo_a);     // arg(i) = a + (start + i - 0.5) * d
+        f->lfo_d = v.lfo_d;
+        f->lfo_K = v.lfo_K;
+        f->lfo_C0 = v.lfo_C0;
+        f->lfo_bias = v.lfo_bias;
+        const double2 lrot = B.lfo_rot[first + vi];
+        f->lfo_rot_c = lrot.x;
+        f->lfo_rot_s = lrot.y;
+        info.fmv[0] = v.frequency; info.fmv[1] = v.fm_phase0; info.fmv[2] = v.frequency * v.fm_inc;
+        info.fmv[3] = fma((double)start - 0.5, v.lfo_d, v.lfo_a);
+        info.fmv[4] = v.lfo_d; info.fmv[5] = v.lfo_K; info.fmv[6] = v.lfo_C0; info.fmv[7] = v.lfo_bias;
+        info.fmv[8] = lrot.x; info.fmv[9] = lrot.y; info.fmv[10] = (double)start;
+    }
+}
+
+#endif
+
+// One wavefront resolves the launch records of one chunk of 64 consecutive voices (lane = voice) and classifies them
+// (see LaunchSet); positions in the chunk's compacted lists come from wave ballots -- no inter-thread memory traffic,
+// no barrier, chunks are independent of each other.
+template <bool SLOPED = false>
+__device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet& S, uint32_t c, uint32_t nvoices,
+                                              uint64_t start, uint32_t nframes) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t vi = c * 64 + lane;
+    PrepInfo info;
+    info.fast = false;
+    info.silent = true;
+    if (vi < nvoices) prepare_voice<SLOPED>(B, 0u, vi, start, nframes, S.launch, S.fm, info);
+    const bool is_fast = vi < nvoices && info.fast;
+    const bool is_gen = vi < nvoices && !info.fast && !info.silent;
+    const uint64_t mf = __ballot(is_fast), mg = __ballot(is_gen);
+    const uint64_t below = (1ull << lane) - 1ull;
+    if (is_fast) {
+        FastRec* __restrict__ f = S.fast + c * 64 + (uint32_t)__popcll(mf & below);
+        f->t_base = info.t_base; f->dt = info.dt;
+        f->gain_l = info.gain_l; f->gain_r = info.gain_r;
+        f->rot_c = info.rot_c; f->rot_s = info.rot_s;
+        if (info.kind == LEAN_FM) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f->poly[u] = u < 11 ? info.fmv[u] : 0.0;
+        } else if (info.kind != LEAN_HARM) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f->poly[u] = u == 0 ? info.pulsewidth : 0.0;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f->poly[u] = info.poly[u];
+        }
+        f->t0_b = info.t0_b; f->dt_b = info.dt_b;
+        f->rot_c_b = info.rot_c_b; f->rot_s_b = info.rot_s_b;
+        f->off_b = (double)info.remain;
+        f->remain = info.remain;
+        f->kind = info.kind;
+        f->amplitude = SLOPED ? info.slope_l : info.amplitude;        // (SLOPED sets are read by the RENDER_LEAN_*_SEG kernels only)
+        f->g0u = SLOPED ? info.slope_r : info.g0u;
+        f->vi = vi;
+        f->pad1 = 0;
+        f->pad2 = 0.0;
+    }
+    if (is_gen) S.gen_idx[c * 64 + (uint32_t)__popcll(mg & below)] = vi;
+    // silent voices: listed from the END of the chunk's index slots (the render kernel never looks there; k_generate_lists
+    // zero-fills their rows)
+    const bool is_silent = vi < nvoices && info.silent;
+    const uint64_t ms = __ballot(is_silent);
+    if (is_silent) S.gen_idx[c * 64 + 63 - (uint32_t)__popcll(ms & below)] = vi;
+    if (lane == 0) {
+        S.counts[4 * c] = (uint32_t)__popcll(mf);
+        S.counts[4 * c + 1] = (uint32_t)__popcll(mg);
+        S.counts[4 * c + 2] = (uint32_t)__popcll(ms);
+        S.counts[4 * c + 3] = 0;
+    }
+}
+
+// Segment s of a long materialisation: the frames [s * seg_frames, ...) of the launch get a record set of their own, laid out
+// one after the other in arrays of nseg * nvoices records (counts: nseg * 4 * nchunks).
+// (A set holds whole chunks -- 64 * nchunks slots per array: the lists of a chunk are addressed by chunk, 64 c + position, and
+// the silent list of the last, partly filled chunk grows down from slot 64 c + 63.  With nvoices slots per set that list wrote
+// past the end of the set: into the next segment's first chunk, or, from the last segment, past the array -- found in round 3
+// when the arrays of a segmented launch became neighbours in one block.)
+__host__ __device__ __forceinline__ size_t set_slots(uint32_t nvoices) { return (size_t)((nvoices + 63) / 64) * 64; }
+__device__ __forceinline__ LaunchSet segment_set(const LaunchSet& base, uint32_t s, uint32_t nvoices) {
+    const uint32_t nchunks = (nvoices + 63) / 64;
+    const size_t stride = set_slots(nvoices);
+    LaunchSet r;
+    r.launch = base.launch + (size_t)s * stride;
+    r.fm = base.fm + (size_t)s * stride;
+    r.fast = base.fast + (size_t)s * stride;
+    r.gen_idx = base.gen_idx + (size_t)s * stride;
+    r.counts = base.counts + (size_t)s * 4 * nchunks;
+    return r;
+}
+
+struct VoiceRegs {                // the hot part of the launch record as plain scalars (SGPRs)
+    double   t_base, dt;
+    uint32_t remain, flags;
+    const double SH_CONST_AS* harm;
+    double   amplitude, bias, gain_l, gain_r, g0u, slu;
+    uint32_t harm_cnt;
+    double   poly[16];            // loaded unconditionally with the rest: one batch, one wait per voice
+    double   rot_c, rot_s;
+    const VoiceLaunch SH_CONST_AS* rec;   // cold fields are read through this where needed
+};
+
+__device__ __forceinline__ VoiceRegs load_record(const VoiceLaunch SH_CONST_AS* p) {
+    VoiceRegs r;
+    r.t_base = p->t_base; r.dt = p->dt;
+    r.remain = p->remain; r.flags = p->flags;
+    r.harm = as_const(p->harm);
+    r.amplitude = p->amplitude; r.bias = p->bias;
+    r.gain_l = p->gain_l; r.gain_r = p->gain_r;
+    r.g0u = p->g0u; r.slu = p->slu;
+    r.harm_cnt = p->harm_cnt;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) r.poly[u] = p->poly[u];
+    r.rot_c = p->rot_c; r.rot_s = p->rot_s;
+    r.rec = p;
+    return r;
+}
+
+typedef const shm::sc_pair* TrigTab;     // LDS
+
+// FPL samples per lane of one voice (frames i[j], launch-relative), float64.  Every argument except
+// i/di is wave-uniform, so the branches on kind / fm_mode / envelope do not diverge.
+//   tile_last: last frame index any lane of this wave touches (uniform)
+template <int FPL, bool BANK>
+__device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* __restrict__ fmrec,
+                                            const BankPtrs& B, const sh_voice* __restrict__ vfull,
+                                            uint64_t start, uint32_t tile_last,
+                                            const uint32_t (&i)[FPL], const double (&di)[FPL],
+                                            const double* __restrict__ fm_cumsum, const double* __restrict__ pwm,
+                                            TrigTab trig, double (&x)[FPL]) {
+    double th[FPL];
+    bool linear = false;          // th[j] = th[0] + 64*j*dt exactly (all frames of the tile on one table piece, no FM)
+    double rot_c = r.rot_c, rot_s = r.rot_s;      // (cos, sin)(64*dt) of that piece
+    // ---- phase: the reference's accumulated t at each frame ----
+    if (tile_last < r.remain) {
+        linear = (r.flags & FL_FM) == 0;
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) th[j] = fma(di[j], r.dt, r.t_base);      // exact (stays on the piece)
+    } else {
+        // the launch crosses a binade of the running sum.  Tiles wholly on the NEXT piece use it directly;
+        // anything else looks its piece up in the voice's table: once per wave for the tile's first frame
+        // (scalar binary search), then per lane only for the lanes past that piece's end.
+        const VoiceLaunch SH_CONST_AS* q = r.rec;
+        const uint32_t tile_first = tile_last & ~(uint32_t)(64 * FPL - 1);
+        // k = index of the following piece that holds the tile's first frame (uniform): the number of listed piece
+        // ends at or before it
+        uint32_t k = 0;
+#pragma unroll
+        for (int u = 0; u < NXP; ++u) k += tile_first >= q->nx_end[u];
+        const uint32_t nx_count = q->nx_count;
+        const bool fm_t = (r.flags & FL_FM) != 0;
+        uint32_t k_end = 0, k_start = 0;
+        if (k < nx_count) {
+            k_end = q->nx_end[k];
+            k_start = k ? q->nx_end[k - 1] : r.remain;
+        }
+        if (tile_first >= r.remain && k < nx_count && tile_last < k_end) {
+            const sh_segment SH_CONST_AS* pc = as_const(B.segs) + (fm_t ? vfull->time_seg_offset : vfull->seg_offset) + q->seg + 1 + k;
+            const double tb = pc->t0, dk = pc->dt, off = (double)k_start;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) th[j] = fma(di[j] - off, dk, tb);
+            if ((r.flags & FL_FM) == 0) {                     // still one piece per tile: the rotation shortcut applies
+                const double2 SH_CONST_AS* rt = as_const(B.seg_rot) + vfull->seg_offset + q->seg + 1 + k;
+                rot_c = rt->x;
+                rot_s = rt->y;
+                linear = true;
+            }
+        } else {
+            const bool fm = (r.flags & FL_FM) != 0;
+            const sh_segment SH_CONST_AS* tab = as_const(B.segs) + (fm ? vfull->time_seg_offset : vfull->seg_offset);
+            const uint32_t cnt = fm ? vfull->time_seg_count : vfull->seg_count;
+            const uint64_t n_first = start + tile_first;
+            uint32_t lo = 0, hi = cnt - 1;                      // uniform: last piece with n0 <= n_first
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (tab[mid].n0 <= n_first) lo = mid; else hi = mid - 1;
+            }
+            const uint64_t p_n0 = tab[lo].n0;
+            const double p_t0 = tab[lo].t0, p_dt = tab[lo].dt;
+            const uint64_t p_end = (lo + 1 < cnt) ? tab[lo + 1].n0 : ~0ull;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                const uint64_t n = start + i[j];
+                if (n < p_end) {
+                    th[j] = fma((double)(n - p_n0), p_dt, p_t0);
+                } else {                                        // lanes beyond the tile's first piece
+                    uint32_t sgi = lo;
+                    while (sgi + 1 < cnt && tab[sgi + 1].n0 <= n) ++sgi;
+                    th[j] = fma((double)(n - tab[sgi].n0), tab[sgi].dt, tab[sgi].t0);
+                }
+            }
+        }
+    }
+    if (r.flags & FL_FM) {
+        const uint32_t fm_mode = (r.flags & FL_FM) >> FL_FM_SHIFT;
+        const VoiceFM SH_CONST_AS* fp = as_const(fmrec);
+        struct { double frequency, phase0, f_inc, lfo_a_rel, lfo_d, lfo_K, lfo_C0, lfo_bias; } f;
+        f.frequency = fp->frequency; f.phase0 = fp->phase0; f.f_inc = fp->f_inc; f.lfo_a_rel = fp->lfo_a_rel;
+        f.lfo_d = fp->lfo_d; f.lfo_K = fp->lfo_K; f.lfo_C0 = fp->lfo_C0; f.lfo_bias = fp->lfo_bias;
+        if (fm_mode == SH_FM_SINE) {
+            // LFO angle a_rel + i*d is exactly linear in i: table lookup for the lane's first frame, rotation
+            // by 64*d for the following ones
+            double ls, lc;
+            shm::sincos_tab(fma(di[0], f.lfo_d, f.lfo_a_rel), trig, ls, lc);
+            const double rc = fp->lfo_rot_c, rs = fp->lfo_rot_s;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                if (j > 0) {
+                    const double ns = fma(ls, rc, lc * rs), nc = fma(lc, rc, -(ls * rs));
+                    ls = ns;
+                    lc = nc;
+                }
+                const double Ln = fma(f.lfo_K, f.lfo_C0 - lc, f.lfo_bias * ((double)start + di[j]));
+                th[j] = f.frequency * th[j] + fma(f.f_inc, Ln, f.phase0);      // t*freq + phase_correction
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) th[j] = f.frequency * th[j] + fma(f.f_inc, fm_cumsum[i[j]], f.phase0);
+        }
+    }
+    // ---- waveform ----
+    if (r.flags & FL_POLY) {
+        // Harmonics with k <= 16: sum_k a_k sin(k t) = sin(t) * P(cos t), P of degree 15 (coefficients
+        // converted on the host in exact rational arithmetic), Horner: 15 FMAs instead of 32 Clenshaw ops
+        double sn[FPL], cs[FPL], pv[FPL];
+        if (FPL > 1 && linear) {
+            shm::sincos_tab(th[0], trig, sn[0], cs[0]);
+#pragma unroll
+            for (int j = 1; j < FPL; ++j) {               // rotate by 64*dt: 4 float64 ops instead of 17
+                sn[j] = fma(sn[j - 1], rot_c, cs[j - 1] * rot_s);
+                cs[j] = fma(cs[j - 1], rot_c, -(sn[j - 1] * rot_s));
+            }
+        } else {
+            shm::sincos_tab_n<FPL>(th, trig, sn, cs);
+        }
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) pv[j] = fma(r.poly[0], cs[j], r.poly[1]);
+#pragma unroll
+        for (int u = 2; u < 16; ++u) {                // Horner, the FPL chains interleaved
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) pv[j] = fma(pv[j], cs[j], r.poly[u]);
+        }
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) x[j] = pv[j] * sn[j];
+        if (BANK && (r.flags & FL_FOLDED)) return;          // amplitude and envelope live in the bus gains
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) x[j] = x[j] * r.amplitude + r.bias;
+    } else {
+        switch (r.flags & FL_KIND) {
+        case SH_SINE:
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                double sn, cs;
+                shm::sincos_tab(th[j], trig, sn, cs);
+                x[j] = sn * r.amplitude + r.bias;
+            }
+            break;
+        case SH_SAWTOOTH:
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = shm::saw_value(th[j], r.amplitude * 2.0, r.bias);
+            break;
+        case SH_SQUARE:
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = shm::square_value(th[j], r.amplitude, r.bias);
+            break;
+        case SH_TRIANGLE:
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = shm::triangle_value(th[j], 4.0 * r.amplitude, r.bias);
+            break;
+        case SH_LINEAR:
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = th[j];
+            break;
+        case SH_BUFFER:                            // the samples were rendered elsewhere (a filter graph): row[i]
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = fm_cumsum ? fm_cumsum[i[j]] : 0.0;
+            break;
+        case SH_NOISE: {
+            const uint64_t seed = vfull->noise_seed;
+            const uint32_t hold = vfull->noise_hold;
+            const double a2 = r.amplitude * 2.0;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                const uint64_t n = start + i[j];
+                const uint64_t h = n <= 0xFFFFFFFFull ? (uint64_t)((uint32_t)n / hold) : n / hold;
+                uint64_t z = seed + h * 0x9E3779B97F4A7C15ull;                  // splitmix64 of the held-value counter
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                z ^= z >> 31;
+                const double u = (double)(z >> 11) * 0x1.0p-53;
+                x[j] = (-r.amplitude + a2 * u) + r.bias;
+            }
+        } break;
+        case SH_PULSE: {
+            const double pw = r.rec->pulsewidth;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = shm::pulse_value(th[j], pwm ? pwm[i[j]] : pw, r.amplitude, r.bias);
+        } break;
+        default: {   // SH_HARMONICS, general forms
+            double h[FPL];
+            if (r.flags & FL_DENSE) {
+                // Clenshaw: b_k = a_k + 2cos(t) b_{k+1} - b_{k+2}; sum_k a_k sin(k t) = b_1 sin(t)
+                double sn[FPL], c2[FPL], b1[FPL], b2[FPL];
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    double c;
+                    shm::sincos_tab(th[j], trig, sn[j], c);
+                    c2[j] = c + c;
+                    b1[j] = 0.0;
+                    b2[j] = 0.0;
+                }
+                for (uint32_t k = 0; k < r.harm_cnt; k += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double ak = r.harm[k + u];
+#pragma unroll
+                        for (int j = 0; j < FPL; ++j) {
+                            double bn = fma(c2[j], b1[j], ak - b2[j]);
+                            b2[j] = b1[j];
+                            b1[j] = bn;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) h[j] = b1[j] * sn[j];
+            } else {
+                const sh_partial SH_CONST_AS* p = reinterpret_cast<const sh_partial SH_CONST_AS*>(r.harm);
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) h[j] = 0.0;
+                for (uint32_t k = 0; k < r.harm_cnt; ++k) {
+                    const double pk = p[k].k, pa = p[k].amp;
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) {
+                        double sn, cs;
+                        shm::sincos_tab(th[j] * pk, trig, sn, cs);
+                        h[j] += sn * pa;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = h[j] * r.amplitude + r.bias;
+        } break;
+        }
+    }
+    if (r.flags & FL_FLIP) {                    // SawtoothH: "we have to flip the wave"
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) x[j] = r.bias * 2.0 - x[j];
+    }
+    // ---- envelope ----
+    if (r.flags & FL_ENV_UNIFORM) {            // the whole launch lies on one piece (the common case)
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) x[j] = x[j] * fma(di[j], r.slu, r.g0u);
+    } else {                                   // this launch crosses attack/decay/sustain/release ends
+        const VoiceLaunch SH_CONST_AS* q = r.rec;
+        const uint32_t e0 = q->eb[0], e1 = q->eb[1], e2 = q->eb[2], e3 = q->eb[3], ti = q->tail_i;
+        const uint32_t tile_first = tile_last & ~(uint32_t)(64 * FPL - 1);
+        const uint32_t p = (tile_first >= e0) + (tile_first >= e1) + (tile_first >= e2) + (tile_first >= e3);
+        const uint32_t pend = p < 4 ? q->eb[p & 3] : 0xFFFFFFFFu;
+        const bool tail_here = ti != NO_TAIL && ti >= tile_first && ti <= tile_last;
+        if ((p == 4 || tile_last < pend) && !tail_here) {       // the tile lies on one piece: uniform line
+            const double g0 = p < 4 ? q->g0[p & 3] : 0.0, sl = p < 4 ? q->slope[p & 3] : 0.0;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = x[j] * fma(di[j], sl, g0);
+        } else {                                                // the few tiles that straddle a piece end
+            const double g00 = q->g0[0], g01 = q->g0[1], g02 = q->g0[2], g03 = q->g0[3];
+            const double s0 = q->slope[0], s1 = q->slope[1], s2 = q->slope[2], s3 = q->slope[3];
+            const double ta = q->tail_amp;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                const uint32_t ii = i[j];
+                const double g0 = ii < e0 ? g00 : ii < e1 ? g01 : ii < e2 ? g02 : g03;
+                const double sl = ii < e0 ? s0 : ii < e1 ? s1 : ii < e2 ? s2 : s3;
+                double g = fma(di[j], sl, g0);
+                if (ii >= e3) g = (ii == ti) ? ta : 0.0;
+                x[j] = x[j] * g;
+            }
+        }
+    }
+}
+
+// One voice through the general code, accumulated into the lane's partial bus.  With more than four frames per lane
+// (the lean loop likes eight: one table lookup serves them all) the general code still runs four at a time, so that its
+// register needs stay those of the four-frame kernel.
+template <int FPL>
+__device__ __forceinline__ void general_voice(const VoiceRegs& r, const VoiceFM* __restrict__ fmrec, const BankPtrs& B,
+                                              const sh_voice* __restrict__ vfull, uint64_t start, uint32_t tile0, uint32_t nframes,
+                                              const uint32_t (&i)[FPL], const double (&di)[FPL], TrigTab trig,
+                                              double (&accl)[FPL], double (&accr)[FPL]) {
+    constexpr int GF = FPL > 4 ? 4 : FPL;
+    static_assert(FPL % GF == 0, "frames per lane: 1, 2, 4 or a multiple of 4");
+    const double* fm_p = nullptr;
+    const double* pwm_p = nullptr;
+    if (B.rows) {                                              // (uniform) this voice's rows of the launch's modulation matrix
+        const uint32_t vidx = (uint32_t)(vfull - B.voices);
+        const int32_t fr = as_const(B.fm_row)[vidx], pr = as_const(B.pwm_row)[vidx];
+        if (fr >= 0) fm_p = B.rows + (size_t)fr * B.row_stride;
+        if (pr >= 0) pwm_p = B.rows + (size_t)pr * B.row_stride;
+    }
+#pragma unroll
+    for (int h = 0; h < FPL / GF; ++h) {
+        const uint32_t first = tile0 + (uint32_t)h * 64 * GF;
+        if (h > 0 && first >= nframes) break;                 // uniform: this part of the tile lies beyond the launch
+        uint32_t last = first + 64 * GF - 1;
+        if (last > nframes - 1) last = nframes - 1;
+        uint32_t ih[GF];
+        double dh[GF], x[GF];
+#pragma unroll
+        for (int j = 0; j < GF; ++j) { ih[j] = i[h * GF + j]; dh[j] = di[h * GF + j]; }
+        voice_block<GF, true>(r, fmrec, B, vfull, start, last, ih, dh, fm_p, pwm_p, trig, x);
+#pragma unroll
+        for (int j = 0; j < GF; ++j) {
+            accl[h * GF + j] = fma(r.gain_l, x[j], accl[h * GF + j]);
+            accr[h * GF + j] = fma(r.gain_r, x[j], accr[h * GF + j]);
+        }
+    }
+}
+
+// One stereo frame of the float64 bus as saturated int16 PCM: what sh_quantize_clip_f32 makes of the float32 bus
+// (rounded to float32 first, float64 product with the scale, truncation toward zero, clamp; NaN -> 0), packed (L | R << 16).
+__device__ __forceinline__ uint32_t pcm16_frame(double l, double r, double scale) {
+    double tl = trunc(scale * (double)(float)l), tr = trunc(scale * (double)(float)r);
+    tl = tl != tl ? 0.0 : (tl > 32767.0 ? 32767.0 : (tl < -32768.0 ? -32768.0 : tl));
+    tr = tr != tr ? 0.0 : (tr > 32767.0 ? 32767.0 : (tr < -32768.0 ? -32768.0 : tr));
+    return ((uint32_t)(int)tl & 0xFFFFu) | ((uint32_t)(int)tr << 16);
+}
+
+// The lean Harmonics arithmetic for FPL frames of one lane, 64 samples apart: frame 0 by table lookup (s0, c0), frame 1 by
+// one rotation (s1, c1), frames j >= 2 by the three-term recurrence x[j] = k2 x[j-1] - x[j-2], k2 = 2cos(64 dt) -- one FMA
+// per value where a rotation takes two FMAs and two MULs -- consumed pair by pair, so that no array of FPL sines ever
+// lives in registers and the accumulators are updated in place on every path.  The one tile per crossing that straddles a
+// phase-table piece end (`straddle`, wave-uniform) cannot step that way: there every pair is looked up afresh from
+// theta(frame), which picks the piece per lane.
+// Rounding errors propagate through the recurrence like U_j(cos(64 dt)), i.e. grow at most linearly in j (FPL <= 8: < 25
+// ulp worst case, ~2 ulp typically); the rounding of k2 itself shifts the step angle by <= 1.1e-16 / |sin(64 dt)| per
+// step: below 1e-9 relative for all but ~1e-6 of voices, orders of magnitude inside the 1e-6 RMS contract in any case.
+// SLOPED (segmented transition launches): the gains follow the envelope's line, gl + i * gls at the lane's frame i = dl + 64 j.
+template <int FPL, bool SLOPED = false, typename Theta>
+__device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1, double c1, double k2, bool straddle, Theta theta,
+                                                 TrigTab trig, const double (&poly)[16], double gl, double gr,
+                                                 double (&accl)[FPL], double (&accr)[FPL],
+                                                 double gls = 0.0, double grs = 0.0, double dl = 0.0) {
+#pragma unroll
+    for (int h = 0; h < FPL; h += 2) {
+        const bool two = h + 1 < FPL;                 // compile-time after unrolling (FPL = 1: a single frame)
+        double p0 = fma(poly[0], c0, poly[1]), p1 = fma(poly[0], c1, poly[1]);
+#pragma unroll
+        for (int u = 2; u < 16; ++u) {
+            p0 = fma(p0, c0, poly[u]);
+            if (two) p1 = fma(p1, c1, poly[u]);
+        }
+        const double x0 = p0 * s0;
+        if (SLOPED) {
+            const double i0 = dl + (double)(h * 64);
+            accl[h] = fma(fma(i0, gls, gl), x0, accl[h]);
+            accr[h] = fma(fma(i0, grs, gr), x0, accr[h]);
+        } else {
+            accl[h] = fma(gl, x0, accl[h]);
+            accr[h] = fma(gr, x0, accr[h]);
+        }
+        if (two) {
+            const double x1 = p1 * s1;
+            if (SLOPED) {
+                const double i1 = dl + (double)((h + 1) * 64);
+                accl[h + 1 < FPL ? h + 1 : h] = fma(fma(i1, gls, gl), x1, accl[h + 1 < FPL ? h + 1 : h]);
+                accr[h + 1 < FPL ? h + 1 : h] = fma(fma(i1, grs, gr), x1, accr[h + 1 < FPL ? h + 1 : h]);
+            } else {
+                accl[h + 1 < FPL ? h + 1 : h] = fma(gl, x1, accl[h + 1 < FPL ? h + 1 : h]);
+                accr[h + 1 < FPL ? h + 1 : h] = fma(gr, x1, accr[h + 1 < FPL ? h + 1 : h]);
+            }
+        }
+        if (h + 2 < FPL) {
+            if (straddle) {
+                shm::sincos_tab(theta(h + 2), trig, s0, c0);
+                if (h + 3 < FPL) shm::sincos_tab(theta(h + 3), trig, s1, c1);
+            } else {
+                const double s2 = fma(k2, s1, -s0), c2 = fma(k2, c1, -c0);
+                const double s3 = fma(k2, s2, -s1), c3 = fma(k2, c2, -c1);
+                s0 = s2; c0 = c2; s1 = s3; c1 = c3;
+            }
+        }
+    }
+}
+
+}  // namespace shosc

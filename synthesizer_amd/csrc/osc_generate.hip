@@ -1,0 +1,548 @@
+// osc_generate.hip -- voices materialised as PCM rows in HBM, and single oscillators.
+//
+// Kernels
+//   k_generate            grid (frame tiles, voice groups): voice-major float32 / float64 rows (4 B per voice-sample)
+//   k_generate_lists      whole-bank materialisation through the launch's lean / general / silent lists
+//   k_generate_lean_harm  the lean polynomial-Harmonics records by the recurrence, sixteen frames per lane
+#include "osc_host.hpp"
+#include <stdlib.h>
+
+namespace {
+
+// voice-major materialisation: out[v*stride + i].  grid = (groups of 4 tiles, voice groups); block = 4
+// waves on 4 consecutive tiles; each wave walks the voices of its group (so the 8 KB sin/cos table in LDS
+// is filled once per block, not once per voice) and stores one coalesced row segment per voice.
+template <int FPL>
+__global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, const shm::sc_pair* __restrict__ trig_g, uint32_t first,
+                                                  uint32_t nvoices, uint32_t voices_per_group,
+                                                  const VoiceLaunch* __restrict__ launch,
+                                                  const VoiceFM* __restrict__ launch_fm,
+                                                  uint64_t start, uint32_t n,
+                                                  const double* __restrict__ fm_cumsum,
+                                                  const double* __restrict__ pwm,
+                                                  float* __restrict__ out32, double* __restrict__ out64,
+                                                  size_t stride) {
+    __shared__ shm::sc_pair trig[shm::TRIG_N];
+    for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile0 = (blockIdx.x * 4 + wave) * (64 * FPL);
+    if (tile0 >= n) return;
+    uint32_t tile_last = tile0 + 64 * FPL - 1;
+    if (tile_last > n - 1) tile_last = n - 1;
+    uint32_t i[FPL];
+    double di[FPL];
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        uint32_t raw = tile0 + j * 64 + lane;
+        i[j] = raw < n ? raw : n - 1;
+        di[j] = (double)i[j];
+    }
+    const uint32_t v0 = blockIdx.y * voices_per_group;
+    uint32_t v1 = v0 + voices_per_group;
+    if (v1 > nvoices) v1 = nvoices;
+    const VoiceLaunch SH_CONST_AS* rp = as_const(launch) + v0;
+    for (uint32_t vi = v0; vi < v1; ++vi, ++rp) {
+        const VoiceRegs r = load_record(rp);
+        double x[FPL];
+        if (r.flags & FL_SILENT) {
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = 0.0;
+        } else {
+            voice_block<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, start, tile_last, i, di, fm_cumsum, pwm, trig, x);
+        }
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            uint32_t raw = tile0 + j * 64 + lane;
+            if (raw < n) {
+                if (out32) out32[(size_t)vi * stride + raw] = (float)x[j];
+                if (out64) out64[(size_t)vi * stride + raw] = x[j];
+            }
+        }
+    }
+}
+
+// Whole-bank materialisation through the launch's voice lists (see LaunchSet): grid = (groups of 4 tiles, 64-voice chunks);
+// a wave owns one tile and walks the chunk's lean records with the loop of k_bank_render (the sample is rounded and
+// stored instead of accumulated), then the general list through voice_block, then zero-fills the rows of silent voices.
+// The lean arithmetic repeats the general code's order -- ((x * amplitude) + 0) * g0u.
+// LEAN = false: only the general and the silent list (the lean records went through k_generate_lean_harm).
+template <int FPL, bool LEAN>
+__global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
+                                                                         uint32_t nvoices, LaunchSet cur, uint64_t start, uint32_t n,
+                                                                         float* __restrict__ out32, size_t stride,
+                                                                         SegTab tab = SegTab{0, {}, {}, {}}, uint32_t vsplit = 1) {
+    // tab.n != 0: the unequal segments of a row's head in ONE launch -- grid.x runs over the groups of four tiles of all segments,
+    // a workgroup finds its segment and from there on works relative to it (records, frames, output).  vsplit > 1: grid.y =
+    // chunks x vsplit, the general and silent voices of a chunk dealt round robin to vsplit workgroups (rows are independent:
+    // the first segment of a head holds EVERY voice, 64 per chunk, and a wave walking them all is the launch's critical path).
+    uint32_t tg = blockIdx.x;
+    if (tab.n) {
+        uint32_t sidx = 0;
+        for (;;) {
+            const uint32_t groups_s = (tab.len[sidx] + 4 * 64 * FPL - 1) / (4 * 64 * FPL);
+            if (tg < groups_s) break;
+            tg -= groups_s;
+            if (++sidx >= tab.n) return;
+        }
+        cur = segment_set(cur, tab.set[sidx], nvoices);
+        start += tab.first[sidx];
+        n = tab.len[sidx];
+        out32 += tab.first[sidx];
+    }
+    const uint32_t c = blockIdx.y / vsplit, vsub = blockIdx.y % vsplit;
+    if constexpr (!LEAN) {                     // nothing but lean voices in this chunk: leave before the table is staged
+        const uint32_t SH_CONST_AS* cnt0 = as_const(cur.counts) + 4 * c;
+        if (cnt0[1] + cnt0[2] == 0) return;
+    }
+    __shared__ shm::sc_pair trig[shm::TRIG_N];
+    for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile0 = (tg * 4 + wave) * (64 * FPL);
+    if (tile0 >= n) return;
+    uint32_t tile_last = tile0 + 64 * FPL - 1;
+    if (tile_last > n - 1) tile_last = n - 1;
+    uint32_t i[FPL];
+    double di[FPL];
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        uint32_t raw = tile0 + j * 64 + lane;
+        i[j] = raw < n ? raw : n - 1;
+        di[j] = (double)i[j];
+    }
+    const uint32_t SH_CONST_AS* cnt = as_const(cur.counts) + 4 * c;
+    const uint32_t nfast = (LEAN && vsub == 0) ? cnt[0] : 0u, ngen = cnt[1], nsilent = cnt[2];
+    const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64;
+    for (uint32_t p = 0; p < nfast; ++p, ++q) {
+        const uint32_t remain = q->remain, kind = q->kind, vi = q->vi;
+        const double amp = q->amplitude, g0u = q->g0u;
+        const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
+        const double tb = q->t0_b, db = q->dt_b, rcb = q->rot_c_b, rsb = q->rot_s_b, ob = q->off_b;
+        double poly[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+        asm volatile("" :: "s"(amp), "s"(g0u), "s"(remain), "s"(kind), "s"(vi), "s"(ta), "s"(da), "s"(rca), "s"(rsa), "s"(tb), "s"(db),
+                     "s"(rcb), "s"(rsb), "s"(ob), "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
+                     "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
+                     "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
+        double x[FPL];
+        if (kind == LEAN_FM) {
+            double T[FPL];
+            if (remain == 0xFFFFFFFFu || tile_last < remain) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) T[j] = fma(di[j], da, ta);
+            } else if (tile0 >= remain) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) T[j] = fma(di[j] - ob, db, tb);
+            } else {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) T[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+            }
+            double ls, lc, th[FPL], sn[FPL], cs[FPL];
+            shm::sincos_tab(fma(di[0], poly[4], poly[3]), trig, ls, lc);
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                if (j > 0) {
+                    const double ns = fma(ls, poly[8], lc * poly[9]), nc = fma(lc, poly[8], -(ls * poly[9]));
+                    ls = ns;
+                    lc = nc;
+                }
+                const double Ln = fma(poly[5], poly[6] - lc, poly[7] * (poly[10] + di[j]));
+                th[j] = poly[0] * T[j] + fma(poly[2], Ln, poly[1]);
+            }
+            shm::sincos_tab_n<FPL>(th, trig, sn, cs);
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = sn[j];
+        } else if (kind >= LEAN_SAW) {                       // Sawtooth / Square / Triangle / Pulse at unit amplitude
+            double th[FPL];
+            if (remain == 0xFFFFFFFFu || tile_last < remain) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) th[j] = fma(di[j], da, ta);
+            } else if (tile0 >= remain) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) th[j] = fma(di[j] - ob, db, tb);
+            } else {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) th[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+            }
+#pragma unroll
+            for (int j = 0; j < FPL; ++j)
+                x[j] = kind == LEAN_SAW ? shm::saw_value(th[j], 2.0, 0.0)
+                     : kind == LEAN_SQUARE ? shm::square_value(th[j], 1.0, 0.0)
+                     : kind == LEAN_TRIANGLE ? shm::triangle_value(th[j], 4.0, 0.0)
+                     : shm::pulse_value(th[j], poly[0], 1.0, 0.0);
+        } else {
+            double sn[FPL], cs[FPL], pv[FPL];
+            if (remain == 0xFFFFFFFFu || tile0 >= remain || tile_last < remain) {
+                const bool on_b = remain != 0xFFFFFFFFu && tile0 >= remain;
+                const double t_base = on_b ? tb : ta, dt = on_b ? db : da;
+                const double rc = on_b ? rcb : rca, rs = on_b ? rsb : rsa;
+                const double off = on_b ? ob : 0.0;
+                shm::sincos_tab(fma(di[0] - off, dt, t_base), trig, sn[0], cs[0]);
+#pragma unroll
+                for (int j = 1; j < FPL; ++j) {
+                    sn[j] = fma(sn[j - 1], rc, cs[j - 1] * rs);
+                    cs[j] = fma(cs[j - 1], rc, -(sn[j - 1] * rs));
+                }
+            } else {
+                double th[FPL];
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) th[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
+                shm::sincos_tab_n<FPL>(th, trig, sn, cs);
+            }
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) pv[j] = fma(poly[0], cs[j], poly[1]);
+#pragma unroll
+            for (int u = 2; u < 16; ++u) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) pv[j] = fma(pv[j], cs[j], poly[u]);
+            }
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) x[j] = kind == LEAN_SINE ? sn[j] : pv[j] * sn[j];
+        }
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const uint32_t raw = tile0 + j * 64 + lane;
+            if (raw < n) out32[(size_t)vi * stride + raw] = (float)((x[j] * amp + 0.0) * g0u);
+        }
+    }
+    const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
+    for (uint32_t p = vsub; p < ngen; p += vsplit) {
+        const uint32_t vi = idx[p];
+        const VoiceRegs r = load_record(as_const(cur.launch) + vi);
+        double x[FPL];
+        voice_block<FPL, false>(r, cur.fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const uint32_t raw = tile0 + j * 64 + lane;
+            if (raw < n) out32[(size_t)vi * stride + raw] = (float)x[j];
+        }
+    }
+    for (uint32_t p = vsub; p < nsilent; p += vsplit) {
+        const uint32_t vi = idx[63 - p];
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const uint32_t raw = tile0 + j * 64 + lane;
+            if (raw < n) out32[(size_t)vi * stride + raw] = 0.0f;
+        }
+    }
+}
+
+// Materialisation of the lean polynomial-Harmonics records of a launch (banks whose lean candidates are all of that kind):
+// grid = (groups of 4 tiles of 64*FPL frames, 64-voice chunks); a wave owns one tile and walks the chunk's lean records with
+// the arithmetic of the render kernel's lean loop -- one table lookup, one rotation, the three-term recurrence, Horner -- and
+// stores FPL coalesced 256-byte row segments per record: base address of the row in SGPRs, one lane offset for all rows, the
+// frame's 256*j bytes as the instruction's immediate.  No general code in this kernel (k_generate_lists<4, false> follows
+// for the general and silent lists): 4 B written per voice-sample is what should bind it, not the scalar unit.
+// The sample repeats the general code's order, ((x * amplitude) + 0) * g0u, before its one rounding to float32.
+// A long row is cut into segments of seg_frames (a multiple of the tile) with a record set each (k_prepare_segments): a
+// record describes at most two phase-table pieces, and ten seconds of a high voice run through more.
+template <int FPL>
+__global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
+                                                               uint32_t total, uint32_t seg_frames,
+                                                               float* __restrict__ out32_all, size_t stride, SegTab tab) {
+    __shared__ shm::sc_pair trig[shm::TRIG_N];
+    for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t seg, seg_first, n, tile0;                                 // (uniform) the wave's segment, and everything relative to it
+    if (tab.n) {                                                       // unequal segments: the head of rows that start with the notes
+        uint32_t t = blockIdx.x * 4 + wave;
+        seg = 0;
+        for (;;) {
+            const uint32_t tiles_s = (tab.len[seg] + 64 * FPL - 1) / (64 * FPL);
+            if (t < tiles_s) break;
+            t -= tiles_s;
+            if (++seg >= tab.n) return;
+        }
+        seg_first = tab.first[seg];
+        n = tab.len[seg];
+        tile0 = t * (64 * FPL);
+        seg = tab.set[seg];
+    } else {
+        const uint32_t abs0 = (blockIdx.x * 4 + wave) * (64 * FPL);   // the tile's first frame in the whole launch
+        if (abs0 >= total) return;
+        seg = abs0 / seg_frames;
+        seg_first = seg * seg_frames;
+        n = total - seg_first < seg_frames ? total - seg_first : seg_frames;
+        tile0 = abs0 - seg_first;
+    }
+    const LaunchSet cur = segment_set(base, seg, nvoices);
+    float* __restrict__ out32 = out32_all + seg_first;
+    uint32_t tile_last = tile0 + 64 * FPL - 1;
+    if (tile_last > n - 1) tile_last = n - 1;
+    const uint32_t c = blockIdx.y;
+    const uint32_t nfast = as_const(cur.counts)[4 * c];
+    const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64;
+    const uint32_t i0 = tile0 + lane;
+    const double di0 = (double)i0;
+    float* __restrict__ col = out32 + i0;                      // + vi * stride per record (uniform), + 64 * j per frame
+    for (uint32_t p = 0; p < nfast; ++p, ++q) {
+        const uint32_t remain = q->remain, vi = q->vi;
+        const double amp = q->amplitude, g0u = q->g0u;
+        const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
+        double poly[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+        asm volatile("" :: "s"(amp), "s"(g0u), "s"(remain), "s"(vi), "s"(ta), "s"(da), "s"(rca), "s"(rsa),
+                     "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
+                     "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
+                     "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
+        double t_base = ta, dt = da, rc = rca, rs = rsa, off = 0.0, tb = ta, db = da, ob = 0.0;
+        bool straddle = false;
+        if (remain != 0xFFFFFFFFu && tile_last >= remain) {   // not wholly on the first piece
+            tb = q->t0_b; db = q->dt_b; ob = q->off_b;
+            const double rcb = q->rot_c_b, rsb = q->rot_s_b;
+            straddle = tile0 < remain;
+            if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
+        }
+        const LaneTheta theta{di0, t_base, dt, off, ta, da, tb, db, ob, i0, remain, straddle};
+        double s0, c0, s1, c1;
+        shm::sincos_tab(theta(0), trig, s0, c0);
+        if (straddle) {
+            shm::sincos_tab(theta(1), trig, s1, c1);
+        } else {
+            s1 = fma(s0, rc, c0 * rs);
+            c1 = fma(c0, rc, -(s0 * rs));
+        }
+        const double k2 = rc + rc;
+        float* __restrict__ row = col + (size_t)vi * stride;
+        // amplitude and (constant) envelope gain scale the sine ONCE: the recurrence is linear, so every later frame's sine
+        // arrives scaled and the sample is one product, p * s (differs from the general code's ((x * amplitude) + 0) * g0u
+        // by float64 rounding only)
+        const double ag = amp * g0u;
+        s0 *= ag;
+        s1 *= ag;
+        auto frames = [&](auto full_tile) {
+            constexpr bool FULL = decltype(full_tile)::value;
+#pragma unroll
+            for (int h = 0; h < FPL; h += 2) {
+                double p0 = fma(poly[0], c0, poly[1]), p1 = fma(poly[0], c1, poly[1]);
+#pragma unroll
+                for (int u = 2; u < 16; ++u) {
+                    p0 = fma(p0, c0, poly[u]);
+                    p1 = fma(p1, c1, poly[u]);
+                }
+                // streaming stores: the rows are not read again by this kernel (1.97 GB per launch of the benchmark shape)
+                if (FULL || i0 + (uint32_t)h * 64u < n) __builtin_nontemporal_store((float)(p0 * s0), row + h * 64);
+                if (FULL || i0 + (uint32_t)(h + 1) * 64u < n) __builtin_nontemporal_store((float)(p1 * s1), row + (h + 1) * 64);
+                if (h + 2 < FPL) {
+                    if (straddle) {
+                        shm::sincos_tab(theta(h + 2), trig, s0, c0);
+                        shm::sincos_tab(theta(h + 3), trig, s1, c1);
+                        s0 *= ag;
+                        s1 *= ag;
+                    } else {
+                        const double s2 = fma(k2, s1, -s0), c2 = fma(k2, c1, -c0);
+                        const double s3 = fma(k2, s2, -s1), c3 = fma(k2, c2, -c1);
+                        s0 = s2; c0 = c2; s1 = s3; c1 = c3;
+                    }
+                }
+            }
+        };
+        if (tile0 + 64 * FPL <= n) frames(std::true_type()); else frames(std::false_type());
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sh_osc_render(sh_bank* bank, uint32_t voice, const sh_buf* fm_cumsum, const sh_buf* pwm,
+                  uint64_t start, uint32_t n, float* out_host, sh_buf* out_f32, size_t out_off, sh_buf* out_f64) {
+    SH_REQUIRE_INIT();
+    if (!bank || voice >= bank->nvoices) return sh::set_error(SH_ERR_INVALID, "sh_osc_render: bad bank/voice");
+    if (!out_host && !out_f32 && !out_f64) return sh::set_error(SH_ERR_INVALID, "sh_osc_render: no destination");
+    if (n == 0) return SH_OK;
+    if (n > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_osc_render: at most 2^32 - 65536 samples per call");
+    const sh_voice& v = bank->h_voices[voice];
+    if (v.fm_mode == SH_FM_BUFFER && (!fm_cumsum || fm_cumsum->bytes < (size_t)n * 8))
+        return sh::set_error(SH_ERR_INVALID, "sh_osc_render: SH_FM_BUFFER voice needs fm_cumsum with >= n doubles");
+    if (pwm && pwm->bytes < (size_t)n * 8) return sh::set_error(SH_ERR_INVALID, "sh_osc_render: pwm buffer too small");
+    if (out_f32 && (out_off > out_f32->bytes / 4 || n > out_f32->bytes / 4 - out_off))
+        return sh::set_error(SH_ERR_INVALID, "sh_osc_render: out_f32 too small");
+    if (out_f64 && out_f64->bytes < (size_t)n * 8) return sh::set_error(SH_ERR_INVALID, "sh_osc_render: out_f64 too small");
+    float* d32 = out_f32 ? (float*)out_f32->ptr + out_off : nullptr;
+    if (!d32 && out_host) {
+        int rc = sh::ensure_scratch((size_t)n * 4);
+        if (rc) return rc;
+        d32 = (float*)sh::state().scratch;
+    }
+    int rc = prepare_single(bank, voice, 1, start, n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_generate<1>, dim3(sh::div_up(n, 256), 1), dim3(256), 0, sh::state().stream,
+                       ptrs(bank), trig_table(), voice, 1u, 1u, bank->d_launch, bank->d_launch_fm, start, n,
+                       fm_cumsum ? (const double*)fm_cumsum->ptr : nullptr,
+                       pwm ? (const double*)pwm->ptr : nullptr,
+                       d32, out_f64 ? (double*)out_f64->ptr : nullptr, (size_t)0);
+    SH_CHECK_LAUNCH("k_generate");
+    if (out_host) {
+        SH_HIP(hipMemcpyAsync(out_host, d32, (size_t)n * 4, hipMemcpyDeviceToHost, sh::state().stream));
+        SH_HIP(hipStreamSynchronize(sh::state().stream));
+    }
+    return SH_OK;
+}
+
+int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voices_out, size_t stride) {
+    SH_REQUIRE_INIT();
+    if (!b || !voices_out) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: NULL argument");
+    if (nframes == 0) return SH_OK;
+    if (nframes > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: at most 2^32 - 65536 frames per call");
+    if (stride < nframes) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: stride < nframes");
+    if (voices_out->bytes / 4 < (size_t)(b->nvoices - 1) * stride + nframes)
+        return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: output buffer too small");
+    int rc = bank_check_plain(b, "sh_bank_generate");
+    if (rc) return rc;
+    // frames per lane: 4 for long rows (one sin/cos lookup + three rotations per voice, as in k_bank_render), else 2 / 1
+    const int fpl = nframes >= 8192 ? 4 : (nframes >= 2048 ? 2 : 1);
+    float* o = (float*)voices_out->ptr;
+    if (fpl == 4 && b->lean_candidates != 0 && b->lean_fm_candidates == 0) {
+        // Long rows, every lean candidate a polynomial Harmonics voice: the lean records by the recurrence kernel at sixteen frames
+        // per lane, then the general and silent lists -- unless the segment provably has none.  Rows longer than a segment get
+        // one record set per segment, all resolved by ONE prepare launch.
+        // frames per lane of the lean kernel: sixteen on long rows (1024 x 480 000: 496 us, eight: 508), fewer when that leaves
+        // the chip short of workgroups (1024 x 48 000 at sixteen: 12 x 16 = 192 workgroups of four 1024-frame tiles)
+        int lf = 16;
+        while (lf > 4 && (uint64_t)sh::div_up(nframes, 256 * lf) * sh::div_up(b->nvoices, 64) < 512) lf /= 2;
+        {
+            const int forced = sh::knobs().gen_lf;
+            if (forced == 4 || forced == 8 || forced == 16) lf = forced;
+        }
+        const int LF = lf;
+#define SH_GEN_LEAN(GRID_, ...) do { \
+            if (LF == 16) hipLaunchKernelGGL(k_generate_lean_harm<16>, GRID_, dim3(256), 0, st, __VA_ARGS__); \
+            else if (LF == 8) hipLaunchKernelGGL(k_generate_lean_harm<8>, GRID_, dim3(256), 0, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL(k_generate_lean_harm<4>, GRID_, dim3(256), 0, st, __VA_ARGS__); } while (0)
+        constexpr uint32_t SEG = 65536;                      // frames per segment (a multiple of the 1024-frame tile)
+        hipStream_t st = sh::state().stream;
+        const uint32_t nchunks = sh::div_up(b->nvoices, 64);
+        // Rows that start with the notes (attack, decay, a dozen binades of the phase sum in the first 65 536 frames): the head
+        // is cut like a transition launch of the render path (plan_segments: where the envelopes are flat, then doubling
+        // positions) so that its voices stay lean -- one prepare launch, one lean launch, ONE lists launch over all segments with
+        // the general voices of a chunk dealt to eight workgroups; the rest of the row follows with equal segments.
+        const bool no_seg = sh::knobs().no_seg;
+        if (start < SEG && b->all_lean && !no_seg && !b->no_general_voice(start, nframes < SEG ? nframes : SEG)) {
+            uint32_t cut[SEG_MAX + 1];
+            SegTab tab, ltab;
+            tab.n = plan_segments(b, start, nframes, 64 * LF, SEG, false, cut);
+            if (tab.n >= 2) {
+                const uint32_t head = cut[tab.n];                        // frames the segments cover (all of them, or what SEG_MAX cuts reach)
+                ltab.n = 0;
+                for (uint32_t k = 0; k < tab.n; ++k) {
+                    tab.first[k] = cut[k]; tab.len[k] = cut[k + 1] - cut[k]; tab.set[k] = k;
+                    if (!b->no_general_voice(start + cut[k], cut[k + 1] - cut[k])) {     // (the lists launch: where general or silent voices can be)
+                        ltab.first[ltab.n] = cut[k]; ltab.len[ltab.n] = cut[k + 1] - cut[k]; ltab.set[ltab.n] = k;
+                        ++ltab.n;
+                    }
+                }
+                rc = grow_segment_sets(b->gen_block, b->gen_set, b->gen_segs, tab.n, b->nvoices);
+                if (rc) return rc;
+                const LaunchSet base = b->gen_set;
+                BankPtrs P = ptrs(b);
+                P.nseg = tab.n;
+                uint32_t tiles = 0, list_groups = 0;
+                for (uint32_t k = 0; k <= tab.n; ++k) P.seg_first[k] = cut[k];
+                for (uint32_t k = 0; k < tab.n; ++k) tiles += sh::div_up(tab.len[k], 64 * LF);
+                for (uint32_t k = 0; k < ltab.n; ++k) list_groups += sh::div_up(ltab.len[k], 4 * 64 * 4);
+                rc = launch_prepare_segments_var(st, false, P, base, b->nvoices, tab.n, start);
+                if (rc) return rc;
+                SH_GEN_LEAN(dim3(sh::div_up(tiles, 4), nchunks), trig_table(), base, b->nvoices, head, SEG, o, stride, tab);
+                SH_CHECK_LAUNCH("k_generate_lean_harm");
+                constexpr uint32_t VSPLIT = 8;
+                if (ltab.n) {
+                    hipLaunchKernelGGL((k_generate_lists<4, false>), dim3(list_groups, nchunks * VSPLIT), dim3(256), 0, st,
+                                       ptrs(b), trig_table(), b->nvoices, base, start, head, o, stride, ltab, VSPLIT);
+                    SH_CHECK_LAUNCH("k_generate_lists");
+                }
+                if (head == nframes) return SH_OK;
+                sh_buf rest{(char*)voices_out->ptr + (size_t)head * 4, voices_out->bytes - (size_t)head * 4, false, 0};
+                return sh_bank_generate(b, start + head, nframes - head, &rest, stride);
+            }
+        }
+        const uint32_t nseg = sh::div_up(nframes, SEG);
+        LaunchSet base;
+        if (nseg == 1) {
+            rc = acquire_records(b, start, nframes, st, false);
+            if (rc) return rc;
+            base = launch_set(b, b->cur);
+        } else {
+            rc = grow_segment_sets(b->gen_block, b->gen_set, b->gen_segs, nseg, b->nvoices);
+            if (rc) return rc;
+            base = b->gen_set;
+            rc = launch_prepare_segments(st, ptrs(b), base, b->nvoices, nseg, start, nframes, SEG);
+            if (rc) return rc;
+        }
+        SegTab none;
+        none.n = 0;
+        SH_GEN_LEAN(dim3(sh::div_up(nframes, 256 * LF), nchunks), trig_table(), base, b->nvoices, nframes,
+                    nseg == 1 ? (nframes + 1023u) / 1024u * 1024u : SEG, o, stride, none);
+#undef SH_GEN_LEAN
+        SH_CHECK_LAUNCH("k_generate_lean_harm");
+        for (uint32_t sg = 0; sg < nseg; ++sg) {
+            const uint32_t first = sg * SEG, n = nframes - first < SEG ? nframes - first : SEG;
+            if (b->no_general_voice(start + first, n)) continue;
+            LaunchSet cur = base;
+            if (nseg > 1) {
+                const size_t stride = set_slots(b->nvoices);          // (segment_set's layout)
+                cur.launch += (size_t)sg * stride; cur.fm += (size_t)sg * stride; cur.fast += (size_t)sg * stride;
+                cur.gen_idx += (size_t)sg * stride; cur.counts += (size_t)sg * 4 * nchunks;
+            }
+            hipLaunchKernelGGL((k_generate_lists<4, false>), dim3(sh::div_up(n, 1024), nchunks), dim3(256), 0, st,
+                               ptrs(b), trig_table(), b->nvoices, cur, start + first, n, o + first, stride);
+            SH_CHECK_LAUNCH("k_generate_lists");
+        }
+        return SH_OK;
+    }
+    rc = acquire_records(b, start, nframes, sh::state().stream, false);
+    if (rc) return rc;
+    const uint32_t tile_groups = sh::div_up(nframes, 256 * fpl);
+    // voices per block: as many as keeps >= ~4096 blocks in flight (and gridDim.y <= 65535)
+    uint32_t vpg = 1;
+    while (vpg < 64 && (uint64_t)tile_groups * ((b->nvoices + 2 * vpg - 1) / (2 * vpg)) >= 4096) vpg *= 2;
+    while ((b->nvoices + vpg - 1) / vpg > 65535) vpg *= 2;
+    const uint32_t groups = (b->nvoices + vpg - 1) / vpg;
+#define SH_GEN(F_) hipLaunchKernelGGL(k_generate<F_>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,            \
+                                      ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, \
+                                      (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride)
+    if (fpl == 4 && b->lean_candidates != 0) {
+        // long rows of a bank with lean candidates: one workgroup column per 64-voice chunk, walking the launch's lists
+        hipLaunchKernelGGL((k_generate_lists<4, true>), dim3(tile_groups, sh::div_up(b->nvoices, 64)), dim3(256), 0, sh::state().stream,
+                           ptrs(b), trig_table(), b->nvoices, launch_set(b, b->cur), start, nframes, o, stride);
+    } else if (fpl == 4) SH_GEN(4); else if (fpl == 2) SH_GEN(2); else SH_GEN(1);
+#undef SH_GEN
+    SH_CHECK_LAUNCH("k_generate");
+    return SH_OK;
+}
+
+int sh_bank_generate_f64(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* rows_out, size_t row0, size_t row_stride) {
+    SH_REQUIRE_INIT();
+    if (!b || !rows_out) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_f64: NULL argument");
+    if (nframes == 0) return SH_OK;
+    if (nframes > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_f64: at most 2^32 - 65536 frames per call");
+    if (row_stride < nframes || rows_out->bytes / 8 < (row0 + b->nvoices - 1) * row_stride + nframes)
+        return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_f64: rows buffer too small");
+    int rc = bank_check_plain(b, "sh_bank_generate_f64");
+    if (rc) return rc;
+    rc = acquire_records(b, start, nframes, sh::state().stream, false);
+    if (rc) return rc;
+    const int fpl = nframes >= 8192 ? 4 : (nframes >= 2048 ? 2 : 1);
+    const uint32_t tile_groups = sh::div_up(nframes, 256 * fpl);
+    uint32_t vpg = 1;
+    while (vpg < 64 && (uint64_t)tile_groups * ((b->nvoices + 2 * vpg - 1) / (2 * vpg)) >= 4096) vpg *= 2;
+    while ((b->nvoices + vpg - 1) / vpg > 65535) vpg *= 2;
+    const uint32_t groups = (b->nvoices + vpg - 1) / vpg;
+    double* o = (double*)rows_out->ptr + row0 * row_stride;
+#define SH_GEN64(F_) hipLaunchKernelGGL(k_generate<F_>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,          \
+                                        ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, \
+                                        (const double*)nullptr, (const double*)nullptr, (float*)nullptr, o, row_stride)
+    if (fpl == 4) SH_GEN64(4); else if (fpl == 2) SH_GEN64(2); else SH_GEN64(1);
+#undef SH_GEN64
+    SH_CHECK_LAUNCH("k_generate(f64 rows)");
+    return SH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,924 @@
+// osc_render.hip -- fused generate-and-mix of a voice bank into the stereo bus.
+//
+// Kernels
+//   k_bank_render     block = W waves on one tile of 64*FPL frames; a wave walks its share of the
+//                     lean list (record in SGPRs, one table lookup + rotations + Horner per voice) and of the general
+//                     list (voice_block); float64 partial (L, R) per lane, LDS-staged sum across the waves
+//   k_bus_combine     folds the voice groups' partial buses in group order, rounds to float32
+//   k_seg_combine     the slices of a segmented launch's first segment
+#include "osc_host.hpp"
+#include <stdlib.h>
+
+namespace {
+
+// fused generate-and-mix.  grid = (frame tiles, voice groups); block = WAVES waves on ONE tile of 64*FPL
+// frames; wave w walks voices v0+w, v0+w+WAVES, ... of its group with the voice record in SGPRs; float64
+// partial (L, R) per lane; LDS-staged sum across the waves; one store per frame.  With one group the block
+// writes the final bus; with several it writes a float64 partial bus per group and k_bus_combine folds
+// them in group order -- either way voices are summed in a fixed order (reproducible run to run).
+// MODE (a static property of the bank): RENDER_DIRECT -- no voice could ever take the lean loop: walk the voice table
+// directly; RENDER_LEAN_HARM -- lean loop for polynomial Harmonics only; RENDER_LEAN_ALL -- also for FM Sine voices (kept
+// out of the Harmonics-only kernel: the extra branch and code cost its loop 5 %).
+// ... RENDER_LEAN_HARM_ONLY / RENDER_GENERAL_ONLY: the same launch as TWO kernels on one stream (banks whose lean candidates are all
+// polynomial Harmonics, several voice groups).  The lean kernel compiles without the general code and so without its
+// registers, scalar pressure and scratch (108 VGPRs at eight frames per lane where the combined kernel needs 128 + 280 bytes of
+// scratch; 37 instead of 42 us per block); the general kernel walks the general lists with four frames per lane, writes its
+// partial buses behind the lean kernel's (parts[groups + g]) and sets gen_valid[g] -- or, for a group without general voices
+// (the steady state of a note), leaves after one scalar load.  The fold adds the general parts whose flag is set.
+// RENDER_LEAN_HARM_SEG / RENDER_GENERAL_SEG: the split launch of a TRANSITION block (the first block of a note: the phase sum
+// runs through a dozen binades, the envelope through attack and decay) cut into segments with a record set each.  Piece ends
+// lie an octave apart (n = (2^k - t0) / inc), so a segment [a, b) with b <= 2a crosses at most one per voice -- which a lean
+// record handles -- where the launch as a whole crosses ten and sends every voice through the general code.  grid.x runs
+// over the tiles of all segments; a workgroup finds its segment first and from there on works in the segment's frame of
+// reference (records, tile, clamps); only its stores are launch-relative again.
+enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2, RENDER_LEAN_HARM_ONLY = 3, RENDER_GENERAL_ONLY = 4, RENDER_LEAN_ALL_ONLY = 5,
+       RENDER_LEAN_HARM_SEG = 6, RENDER_GENERAL_SEG = 7, RENDER_LEAN_ALL_SEG = 8 };
+constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_HARM_SEG; }
+constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY || mode == RENDER_LEAN_HARM_SEG || mode == RENDER_LEAN_ALL_SEG; }
+constexpr bool mode_general(int mode) { return mode == RENDER_GENERAL_ONLY || mode == RENDER_GENERAL_SEG; }
+constexpr bool mode_seg(int mode) { return mode == RENDER_LEAN_HARM_SEG || mode == RENDER_GENERAL_SEG || mode == RENDER_LEAN_ALL_SEG; }
+constexpr bool mode_has_lean(int mode) { return mode != RENDER_DIRECT && !mode_general(mode); }
+template <int WAVES, int FPL, int MINW, int MODE>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
+                                                                  uint32_t nvoices, uint32_t voices_per_group,
+                                                                  LaunchSet cur, LaunchSet next, uint64_t next_start,
+                                                                  uint64_t start, uint32_t nframes,
+                                                                  float2* __restrict__ bus32,
+                                                                  double2* __restrict__ bus64,
+                                                                  double2* __restrict__ parts,
+                                                                  const double2* __restrict__ prev_parts,
+                                                                  float2* __restrict__ prev_bus32,
+                                                                  double2* __restrict__ prev_bus64,
+                                                                  uint32_t* __restrict__ pcm16, double pcm_scale,
+                                                                  uint32_t* __restrict__ prev_pcm16, double prev_pcm_scale,
+                                                                  uint32_t* __restrict__ gen_valid,
+                                                                  const uint32_t* __restrict__ prev_gen_valid,
+                                                                  uint32_t prep_wgs) {
+    // prep_wgs > 0 (lean / direct / combined modes only): the first prep_wgs workgroups of every row of the grid do not render.
+    // Sequential streaming is the common call pattern: a launch also resolves the launch records of the block expected two
+    // launches on (next_start = start + 2 * nframes: the launch in between runs beside this one on the other stream and got
+    // its records from this one's predecessor) into a free record set, so that launch needs no prepare kernel of its own
+    // (a 13 us kernel + a launch boundary per block otherwise).  One wavefront per chunk of 64 voices, each in a workgroup of
+    // its own that is dispatched FIRST and leaves: beside the rendering workgroups, not in front of one (as the first step of
+    // the first tiles' workgroups -- round 2 -- the step was the whole launch's critical path for small banks: 8 of 13 us).
+    if (!mode_general(MODE) && prep_wgs) {
+        if (blockIdx.x < prep_wgs) {
+            if (next.launch && threadIdx.x < 64) {
+                const uint32_t c = blockIdx.y * prep_wgs + blockIdx.x;
+                if (c < (nvoices + 63) / 64) prepare_chunk(B, next, c, nvoices, next_start, nframes);
+            }
+            return;
+        }
+    }
+    const uint32_t bx = blockIdx.x - (mode_general(MODE) ? 0u : prep_wgs);       // the tile (or, segmented: the tile counter) of this workgroup
+    if constexpr (MODE == RENDER_GENERAL_ONLY) {       // (a segmented launch always writes its parts: see below)
+        // a group without general voices in this launch: nothing to render, nothing to write (wave-uniform: scalar loads)
+        const uint32_t c0g = (blockIdx.y * voices_per_group) / 64;
+        uint32_t c1g = ((blockIdx.y + 1) * voices_per_group + 63) / 64;
+        const uint32_t nch = (nvoices + 63) / 64;
+        if (c1g > nch) c1g = nch;
+        uint32_t total = 0;
+        for (uint32_t c = c0g; c < c1g; ++c) total += as_const(cur.counts)[4 * c + 1];
+        if (bx == 0 && threadIdx.x == 0) gen_valid[blockIdx.y] = total ? 1u : 0u;
+        if (total == 0) return;
+    }
+    if constexpr (MODE == RENDER_GENERAL_SEG) {
+        // most (tile, group) pairs of a segmented launch hold no general voice: their parts are zeros, written before any set-up
+        // (the flags of a segmented launch say "every group's general parts are valid": its general voices are the first segment's)
+        // grid.x: the first segment's tiles gen_sub times over (tile-major), then the other segments' tiles
+        const uint32_t tiles_0 = (B.seg_first[1] - B.seg_first[0] + 64 * FPL - 1) / (64 * FPL);
+        uint32_t sidx = 0, tidx = bx;
+        if (tidx >= tiles_0 * B.gen_sub) {
+            tidx -= tiles_0 * B.gen_sub;
+            sidx = 1;
+            for (;;) {
+                const uint32_t n_s = B.seg_first[sidx + 1] - B.seg_first[sidx];
+                const uint32_t tiles_s = (n_s + 64 * FPL - 1) / (64 * FPL);
+                if (tidx < tiles_s || sidx + 1 >= B.nseg) break;
+                tidx -= tiles_s;
+                ++sidx;
+            }
+        }
+        const uint32_t grp = blockIdx.y;
+        if (sidx > 0) {
+            const uint32_t nchs = (nvoices + 63) / 64;
+            const uint32_t c0g = (grp * voices_per_group) / 64;
+            uint32_t c1g = ((grp + 1) * voices_per_group + 63) / 64;
+            if (c1g > nchs) c1g = nchs;
+            const uint32_t SH_CONST_AS* cnt = as_const(cur.counts) + (size_t)sidx * 4 * nchs;
+            uint32_t total = 0;
+            for (uint32_t c = c0g; c < c1g; ++c) total += cnt[4 * c + 1];
+            if (total == 0) {
+                const uint32_t n_s = B.seg_first[sidx + 1] - B.seg_first[sidx];
+                for (uint32_t f = threadIdx.x; f < 64 * FPL; f += WAVES * 64) {
+                    const uint32_t raw = tidx * (64 * FPL) + f;
+                    if (raw < n_s) parts[(size_t)(gridDim.y + grp) * nframes + B.seg_first[sidx] + raw] = make_double2(0.0, 0.0);
+                }
+                return;
+            }
+        }
+    }
+    // The previous launch of the stream (same shape) left its voice groups' partial buses unfolded: the workgroups of
+    // group 0 fold their tile of it now, in group order, before their own work -- instead of a 5 us kernel between
+    // every two render launches.
+    if (!mode_general(MODE) && prev_parts && blockIdx.y == 0) {
+        for (uint32_t f = threadIdx.x; f < 64 * FPL; f += WAVES * 64) {
+            const uint32_t raw = bx * (64 * FPL) + f;
+            if (raw >= nframes) continue;
+            double2 acc = prev_parts[raw];
+            for (uint32_t g = 1; g < gridDim.y; ++g) {
+                const double2 pp = prev_parts[(size_t)g * nframes + raw];
+                acc.x += pp.x;
+                acc.y += pp.y;
+            }
+            if (prev_gen_valid) {                              // the general kernel's parts of that launch, where it wrote any
+                for (uint32_t g = 0; g < gridDim.y; ++g) {
+                    if (as_const(prev_gen_valid)[g]) {
+                        const double2 pp = prev_parts[(size_t)(gridDim.y + g) * nframes + raw];
+                        acc.x += pp.x;
+                        acc.y += pp.y;
+                    }
+                }
+            }
+            if (prev_bus32) prev_bus32[raw] = make_float2((float)acc.x, (float)acc.y);
+            if (prev_bus64) prev_bus64[raw] = acc;
+            if (prev_pcm16) prev_pcm16[raw] = pcm16_frame(acc.x, acc.y, prev_pcm_scale);
+        }
+    }
+    // (SYNTHHIP_PREPARE_IN_TILE=1, for A/B timings: the round-2 placement of the prepare step -- the chunks of 64 voices spread
+    // over the first tile workgroups, one wavefront each, in front of their own work)
+    if (!mode_general(MODE) && next.launch && !prep_wgs) {
+        const uint32_t nchunks = (nvoices + 63) / 64, nblocks = gridDim.x * gridDim.y;
+        const uint32_t bid = blockIdx.y * gridDim.x + bx;
+        if (threadIdx.x < 64) {
+            for (uint32_t c = bid; c < nchunks; c += nblocks) prepare_chunk(B, next, c, nvoices, next_start, nframes);
+        }
+    }
+    __shared__ double red[WAVES][2][64 * FPL];
+    __shared__ shm::sc_pair trig[shm::TRIG_N];
+    for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += WAVES * 64) trig[k] = trig_g[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // a segmented launch: this workgroup's segment and its tile there (uniform); everything below up to the stores is
+    // relative to the segment.  Otherwise the launch is its own single segment.
+    uint32_t seg_off = 0, nfr = nframes, tile_index = bx;
+    uint64_t st0 = start;
+    LaunchSet curS = cur;
+    uint32_t sub = 0, nsub = 1;
+    bool to_scratch = false;
+    if constexpr (mode_seg(MODE)) {
+        uint32_t sidx = 0;
+        if constexpr (MODE == RENDER_GENERAL_SEG) {
+            const uint32_t tiles_0 = (B.seg_first[1] - B.seg_first[0] + 64 * FPL - 1) / (64 * FPL);
+            if (tile_index < tiles_0 * B.gen_sub) {            // the first segment: gen_sub workgroups per (tile, group)
+                sub = tile_index % B.gen_sub;
+                tile_index /= B.gen_sub;
+                nsub = B.gen_sub;
+                to_scratch = true;
+            } else {
+                tile_index -= tiles_0 * (B.gen_sub - 1);       // as if the first segment's tiles came once
+            }
+        }
+        for (;;) {
+            const uint32_t n_s = B.seg_first[sidx + 1] - B.seg_first[sidx];
+            const uint32_t tiles_s = (n_s + 64 * FPL - 1) / (64 * FPL);
+            if (tile_index < tiles_s || sidx + 1 >= B.nseg) break;
+            tile_index -= tiles_s;
+            ++sidx;
+        }
+        seg_off = B.seg_first[sidx];
+        nfr = B.seg_first[sidx + 1] - seg_off;
+        st0 = start + seg_off;
+        curS = segment_set(cur, sidx, nvoices);
+    }
+    const uint32_t grp = blockIdx.y;                           // the voice group of this workgroup
+    const uint32_t tile0 = tile_index * (64 * FPL);
+    uint32_t tile_last = tile0 + 64 * FPL - 1;
+    if (tile_last > nfr - 1) tile_last = nfr - 1;
+    // this group's voices: chunks [c0, c1) of 64 voices (voices_per_group is a multiple of 64 unless there is one group)
+    const uint32_t c0 = (grp * voices_per_group) / 64;
+    uint32_t c1 = ((grp + 1) * voices_per_group + 63) / 64;
+    const uint32_t nchunks = (nvoices + 63) / 64;
+    if (c1 > nchunks) c1 = nchunks;
+    uint32_t i[FPL];
+    double di[FPL], accl[FPL], accr[FPL];
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        accl[j] = 0.0;
+        accr[j] = 0.0;
+    }
+    // the frames of this lane, launch-relative (clamped into the launch: out-of-range lanes compute a valid sample and do not
+    // store it).  The lean Harmonics loop does not use the arrays -- it works from the lane's first frame alone -- so in that
+    // mode they are only built after it, for the general code: they would cost 3 registers per frame for the whole loop.
+    auto build_frames = [&](uint32_t lane_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            uint32_t raw = tile0 + j * 64 + lane_;
+            i[j] = raw < nfr ? raw : nfr - 1;
+            di[j] = (double)i[j];
+        }
+    };
+    if constexpr (!mode_has_lean(MODE)) build_frames(lane);        // (the lean loops work from the lane's first frame alone)
+    if constexpr (MODE == RENDER_DIRECT) {
+        const uint32_t v0 = blockIdx.y * voices_per_group;
+        uint32_t v1 = v0 + voices_per_group;
+        if (v1 > nvoices) v1 = nvoices;
+        const VoiceLaunch SH_CONST_AS* rp = as_const(curS.launch) + v0 + wave;
+        for (uint32_t vi = v0 + wave; vi < v1; vi += WAVES, rp += WAVES) {
+            const VoiceRegs r = load_record(rp);
+            if (r.flags & FL_SILENT) continue;       // the note was released before this block: contributes exact zeros
+            general_voice<FPL>(r, curS.fm + vi, B, B.voices + vi, st0, tile0, nfr, i, di, trig, accl, accr);
+        }
+    } else {
+    // ---- fast voices: one table lookup, FPL-1 rotations, the Horner chains, two accumulations per frame ----
+    // Wave w takes every WAVES-th list entry; the offset carries over from chunk to chunk so that the waves'
+    // shares of the whole group differ by at most one voice.
+    uint32_t first = wave + sub * WAVES;                      // position in the current chunk's list this wave starts at
+    if constexpr (!mode_general(MODE)) {
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t nfast = as_const(curS.counts)[4 * c];
+        const FastRec SH_CONST_AS* q = as_const(curS.fast) + c * 64 + first;
+        uint32_t p = first;
+        for (; p < nfast; p += WAVES, q += WAVES) {
+            // the common 192 bytes in ONE batch of scalar loads: the empty asm makes these fields live here, so the
+            // compiler cannot sink their loads behind the tests below (it did: three dependent round trips per voice).
+            // The second piece's fields are NOT in the list: their loads stay inside the rare crossing branches.
+            const double gl = q->gain_l, gr = q->gain_r;
+            const uint32_t remain = q->remain, kind = q->kind;
+            const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
+            double poly[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+            asm volatile("" :: "s"(gl), "s"(gr), "s"(remain), "s"(kind), "s"(ta), "s"(da), "s"(rca), "s"(rsa),
+                         "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
+                         "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
+                         "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
+            // Every lean kind works from the lane's FIRST frame alone (no per-frame index arrays): the piece of the phase table
+            // (first / second of the launch) is chosen by scalar selects, the one tile per crossing that straddles the piece end by
+            // a uniform flag, and the frames follow 64 samples apart.
+            const uint32_t i0 = tile0 + lane;                         // the lane's first frame (< nfr + 64: harmless)
+            const double di0 = (double)i0;
+            double t_base = ta, dt = da, rc = rca, rs = rsa, off = 0.0, tb = ta, db = da, ob = 0.0;
+            bool straddle = false;
+            if constexpr (mode_seg(MODE)) {
+                // a segment is cut so that (nearly) every voice crosses ONE piece end in it: half the tiles lie behind it, and the
+                // second piece's fields belong in the first batch of loads (one round trip per record, not two)
+                const double tb2 = q->t0_b, db2 = q->dt_b, ob2 = q->off_b, rcb = q->rot_c_b, rsb = q->rot_s_b;
+                asm volatile("" :: "s"(tb2), "s"(db2), "s"(ob2), "s"(rcb), "s"(rsb));
+                if (remain != 0xFFFFFFFFu && tile_last >= remain) {
+                    tb = tb2; db = db2; ob = ob2;
+                    straddle = tile0 < remain;
+                    if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
+                }
+            } else
+            if (remain != 0xFFFFFFFFu && tile_last >= remain) {       // not wholly on the first piece
+                tb = q->t0_b; db = q->dt_b; ob = q->off_b;
+                const double rcb = q->rot_c_b, rsb = q->rot_s_b;
+                straddle = tile0 < remain;
+                if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
+            }
+            const LaneTheta theta{di0, t_base, dt, off, ta, da, tb, db, ob, i0, remain, straddle};    // the accumulated t at frame j
+            if (mode_lean_harm(MODE) || kind == LEAN_HARM) {
+                // polynomial Harmonics: lookup + one rotation + the three-term recurrence (lean_harm_frames)
+                double s0, c0, s1, c1;
+                shm::sincos_tab(theta(0), trig, s0, c0);
+                if (straddle) {
+                    if (FPL > 1) shm::sincos_tab(theta(1), trig, s1, c1); else { s1 = s0; c1 = c0; }
+                } else {
+                    s1 = fma(s0, rc, c0 * rs);
+                    c1 = fma(c0, rc, -(s0 * rs));
+                }
+                if constexpr (mode_seg(MODE)) {
+                    const double gls = q->amplitude, grs = q->g0u;       // (a segmented launch's records: the gains' slopes per frame)
+                    lean_harm_frames<FPL, true>(s0, c0, s1, c1, rc + rc, straddle, theta, trig, poly, gl, gr, accl, accr, gls, grs, di0);
+                } else {
+                    lean_harm_frames<FPL>(s0, c0, s1, c1, rc + rc, straddle, theta, trig, poly, gl, gr, accl, accr);
+                }
+                continue;
+            }
+            if constexpr (!mode_lean_harm(MODE)) {
+            if (kind == LEAN_SINE) {
+                // a plain Sine: the same recurrence on the sine alone (the amplitude lives in the gains)
+                double s0, c0, s1, c1;
+                shm::sincos_tab(theta(0), trig, s0, c0);
+                if (straddle) {
+                    if (FPL > 1) shm::sincos_tab(theta(1), trig, s1, c1); else { s1 = s0; c1 = c0; }
+                } else {
+                    s1 = fma(s0, rc, c0 * rs);
+                }
+                const double k2 = rc + rc;
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    accl[j] = fma(gl, s0, accl[j]);
+                    accr[j] = fma(gr, s0, accr[j]);
+                    if (j + 1 < FPL) {
+                        double s2;
+                        if (straddle) { if (j + 2 < FPL) shm::sincos_tab(theta(j + 2), trig, s2, c1); else s2 = 0.0; }
+                        else s2 = fma(k2, s1, -s0);
+                        s0 = s1;
+                        s1 = s2;
+                    }
+                }
+                continue;
+            }
+            if (kind == LEAN_FM) {
+                // Sine carrier, closed-form Sine LFO (the arithmetic of voice_block's FM path).  theta(j) is the accumulated TIME;
+                // the LFO angle a_rel + i*d is exactly linear in i, and only its COSINE enters L(i) = K (C0 - cos) + bias*(start+i):
+                // one table lookup for the lane's first frame, one rotation for the second, then cos[j] = 2cos(64d) cos[j-1] - cos[j-2].
+                const double frequency = poly[0], phase0 = poly[1], f_inc = poly[2], lfo_a_rel = poly[3], lfo_d = poly[4];
+                const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], lrc = poly[8], lrs = poly[9], startd = poly[10];
+                double ls0, lc0;
+                shm::sincos_tab(fma(di0, lfo_d, lfo_a_rel), trig, ls0, lc0);
+                double lc1 = fma(lc0, lrc, -(ls0 * lrs));
+                const double lk2 = lrc + lrc;
+#pragma unroll
+                for (int h = 0; h < FPL; h += 4) {            // four carriers at a time: their table reads are in flight together
+                    constexpr int Q = FPL < 4 ? FPL : 4;
+                    double th[Q], sn[Q], cs[Q];
+#pragma unroll
+                    for (int jj = 0; jj < Q; ++jj) {
+                        const int j = h + jj;
+                        const double Ln = fma(lfo_K, lfo_C0 - lc0, lfo_bias * (startd + (di0 + (double)(j * 64))));
+                        th[jj] = frequency * theta(j) + fma(f_inc, Ln, phase0);
+                        const double lc2 = fma(lk2, lc1, -lc0);
+                        lc0 = lc1;
+                        lc1 = lc2;
+                    }
+                    shm::sincos_tab_n<Q>(th, trig, sn, cs);
+#pragma unroll
+                    for (int jj = 0; jj < Q; ++jj) {
+                        accl[h + jj] = fma(gl, sn[jj], accl[h + jj]);
+                        accr[h + jj] = fma(gr, sn[jj], accr[h + jj]);
+                    }
+                }
+                continue;
+            }
+            // Sawtooth / Square / Triangle / Pulse at unit amplitude (the amplitude lives in the gains): t in turns, frame by frame
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                const double th = theta(j);
+                const double x = kind == LEAN_SAW ? shm::saw_value(th, 2.0, 0.0)
+                               : kind == LEAN_SQUARE ? shm::square_value(th, 1.0, 0.0)
+                               : kind == LEAN_TRIANGLE ? shm::triangle_value(th, 4.0, 0.0)
+                               : shm::pulse_value(th, poly[0], 1.0, 0.0);
+                accl[j] = fma(gl, x, accl[j]);
+                accr[j] = fma(gr, x, accr[j]);
+            }
+            }
+        }
+        first = p - nfast;                                    // 0 .. WAVES-1: where the stride lands in the next list
+    }
+    }
+    // ---- every other sounding voice: the general code (the stride simply continues, so the extra voices go to the
+    // waves that got one fast voice fewer) ----
+    if constexpr (MODE == RENDER_LEAN_HARM || MODE == RENDER_LEAN_ALL) {
+        uint32_t lane_late = lane;
+        asm volatile("" : "+v"(lane_late));       // defined here, after the loop above: the arrays cannot be built earlier
+        build_frames(lane_late);
+    }
+    if constexpr (!mode_lean_only(MODE)) {
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t ngen = as_const(curS.counts)[4 * c + 1];
+        const uint32_t SH_CONST_AS* idx = as_const(curS.gen_idx) + c * 64;
+        const uint32_t step = WAVES * nsub;                        // (nsub > 1: the first segment of a general segmented launch)
+        uint32_t p = first;
+        uint32_t vi_next = p < ngen ? idx[p] : 0u;
+        for (; p < ngen; p += step) {
+            const uint32_t vi = vi_next;
+            vi_next = p + step < ngen ? idx[p + step] : 0u;       // in flight with this voice's record: one round trip less
+            const VoiceRegs r = load_record(as_const(curS.launch) + vi);
+            general_voice<FPL>(r, curS.fm + vi, B, B.voices + vi, st0, tile0, nfr, i, di, trig, accl, accr);
+        }
+        first = p - ngen;
+    }
+    }
+    }
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        red[wave][0][j * 64 + lane] = accl[j];
+        red[wave][1][j * 64 + lane] = accr[j];
+    }
+    __syncthreads();
+    // each wave finishes 64-frame rows of the tile: rows wave, wave + WAVES, ...
+    for (uint32_t row = wave; row < (uint32_t)FPL; row += WAVES) {
+        const uint32_t f = row * 64 + lane;
+        const uint32_t raw = tile0 + f;
+        if (raw < nfr) {
+            double l = red[0][0][f], rr = red[0][1][f];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                l += red[w][0][f];
+                rr += red[w][1][f];
+            }
+            const size_t at = (size_t)seg_off + raw;            // launch-relative frame
+            if (MODE == RENDER_GENERAL_SEG && to_scratch) {
+                B.gen_scratch[(size_t)(grp * nsub + sub) * nfr + raw] = make_double2(l, rr);
+            } else if (parts) {
+                const uint32_t slot = mode_general(MODE) ? gridDim.y + grp : grp;
+                parts[(size_t)slot * nframes + at] = make_double2(l, rr);
+            } else {
+                if (bus32) bus32[at] = make_float2((float)l, (float)rr);
+                if (bus64) bus64[at] = make_double2(l, rr);
+                if (pcm16) pcm16[at] = pcm16_frame(l, rr, pcm_scale);
+            }
+        }
+    }
+}
+
+// The first segment of a general segmented launch: its nsub slices per group, added in order into the group's general parts.
+__global__ __launch_bounds__(256) void k_seg_combine(const double2* __restrict__ scratch, uint32_t nsub, uint32_t n0,
+                                                     double2* __restrict__ gen_parts, uint32_t nframes) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (f >= n0) return;
+    double2 acc = scratch[(size_t)(g * nsub) * n0 + f];
+    for (uint32_t k = 1; k < nsub; ++k) {
+        const double2 x = scratch[(size_t)(g * nsub + k) * n0 + f];
+        acc.x += x.x;
+        acc.y += x.y;
+    }
+    gen_parts[(size_t)g * nframes + f] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_bus_combine(const double2* __restrict__ parts, uint32_t ngroups, uint32_t nframes,
+                                                     float2* __restrict__ bus32, double2* __restrict__ bus64,
+                                                     uint32_t* __restrict__ pcm16, double pcm_scale,
+                                                     const uint32_t* __restrict__ gen_valid) {
+    const size_t i = sh::block_id() * 256 + threadIdx.x;
+    if (i >= nframes) return;
+    double2 s = parts[i];
+    for (uint32_t g = 1; g < ngroups; ++g) {
+        const double2 p = parts[(size_t)g * nframes + i];
+        s.x += p.x;
+        s.y += p.y;
+    }
+    if (gen_valid) {                                   // split launch: the general kernel's parts, same order as the in-kernel fold
+        for (uint32_t g = 0; g < ngroups; ++g) {
+            if (gen_valid[g]) {
+                const double2 p = parts[(size_t)(ngroups + g) * nframes + i];
+                s.x += p.x;
+                s.y += p.y;
+            }
+        }
+    }
+    if (bus32) bus32[i] = make_float2((float)s.x, (float)s.y);
+    if (bus64) bus64[i] = s;
+    if (pcm16) pcm16[i] = pcm16_frame(s.x, s.y, pcm_scale);
+}
+
+}  // namespace
+
+namespace {
+
+// Memory that render launches write (directly, or through a fold they owe / carry out) while some bank's run is open.  The two
+// render streams are ordered against each other only where a run starts (ev_join) and where one ends (ev_aux): a launch on
+// stream2 is NOT behind what the main stream was given after its run began.  So every launch checks what it is about to
+// write against this list -- another bank's entry: every run ends first (sh::flush_pending: the order of the two writes must
+// be the callers'); an entry of its own bank written on the OTHER stream (single-group launches write the caller's buffers
+// themselves): its own run ends first.  The list is emptied whenever the streams are fully joined.
+struct WriteRec { const char* lo; const char* hi; const sh_bank* owner; uint8_t streams; };     // streams: bit 0 `stream`, bit 1 stream2
+std::vector<WriteRec>& bank_writes() {
+    static std::vector<WriteRec> v;
+    return v;
+}
+bool overlaps_writes(const sh_bank* b, bool own, uint8_t streams, const void* p, size_t bytes) {
+    if (!p) return false;
+    const char* lo = (const char*)p;
+    for (const WriteRec& r : bank_writes())
+        if ((r.owner == b) == own && (!own || (r.streams & streams)) && lo < r.hi && r.lo < lo + bytes) return true;
+    return false;
+}
+void note_write(const sh_bank* b, const void* p, size_t bytes, uint8_t stream_bit) {
+    if (!p) return;
+    const char* lo = (const char*)p;
+    for (WriteRec& r : bank_writes())
+        if (r.owner == b && r.lo == lo) { if (lo + bytes > r.hi) r.hi = lo + bytes; r.streams |= stream_bit; return; }
+    bank_writes().push_back(WriteRec{lo, lo + bytes, b, stream_bit});
+}
+
+}  // namespace
+
+namespace shosc {
+
+// Fold what one bank still owes (oldest first: a bus used for two blocks ends up holding the later one) on the main stream and
+// end its run.  The caller has joined stream2 into the main stream.
+int fold_bank(sh_bank* b) {
+    sh::State& S = sh::state();
+    if (b->run_active) S.open_runs -= 1;
+    b->run_active = false;
+    b->run_count = 0;
+    // (the caller has made the main stream wait for stream2, and this bank's next stream2 launch will wait for the main stream:
+    // its own earlier writes are ordered from here on; with no run open anywhere, everybody's are)
+    for (WriteRec& r : bank_writes()) if (r.owner == b) r.streams = 0;
+    if (S.open_runs == 0) bank_writes().clear();
+    const int n = b->npending;
+    b->npending = 0;
+    S.pending_total -= n;
+    for (int k = 0; k < n; ++k) {
+        const sh::PendingCombine& pc = b->pending[k];
+        hipLaunchKernelGGL(k_bus_combine, sh::grid1d(pc.nframes, 256), dim3(256), 0, S.stream,
+                           (const double2*)pc.parts, pc.groups, pc.nframes, (float2*)pc.o32, (double2*)pc.o64,
+                           (uint32_t*)pc.o16, pc.scale, (const uint32_t*)pc.gen_valid);
+        SH_CHECK_LAUNCH("k_bus_combine");
+    }
+    return SH_OK;
+}
+
+int join_aux() {
+    sh::State& S = sh::state();
+    if (S.aux_busy) {
+        S.aux_busy = false;
+        SH_HIP(hipStreamWaitEvent(S.stream, S.ev_aux, 0));
+    }
+    return SH_OK;
+}
+
+}  // namespace shosc
+
+namespace sh {
+int flush_pending() {
+    int rc = join_aux();
+    if (rc) return rc;
+    for (sh_bank* b : live_banks()) {                     // every bank's run ends here: the next one starts on `stream`
+        rc = fold_bank(b);
+        if (rc) return rc;
+    }
+    bank_writes().clear();
+    return SH_OK;
+}
+
+// Both render streams wait for each other (events only): whatever either has been given so far precedes whatever either is
+// given from here on.  Used when a device block the launches of both streams use changes hands (grow_pooled).
+int join_streams() {
+    State& S = state();
+    int rc = join_aux();
+    if (rc) return rc;
+    SH_HIP(hipEventRecord(S.ev_sync, S.stream));
+    SH_HIP(hipStreamWaitEvent(S.stream2, S.ev_sync, 0));
+    return SH_OK;
+}
+
+void free_render_buffers() {
+    for (sh_bank* b : live_banks()) {
+        for (int k = 0; k < 4; ++k) release_pooled(b->parts[k]);
+        for (int k = 0; k < 2; ++k) {
+            release_pooled(b->seg_block[k]);
+            release_pooled(b->seg_scratch[k]);
+            b->seg_cap[k] = 0;
+        }
+        release_pooled(b->gen_block);
+        b->gen_segs = 0;
+    }
+}
+}  // namespace sh
+
+// the render behind sh_bank_render (float32 / float64 bus) and sh_bank_render_pcm (int16 PCM straight from the fold)
+static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64, sh_buf* pcm_i16, double pcm_scale) {
+    SH_REQUIRE_INIT_KEEP_PENDING();          // a pending fold of the previous render is taken over by this launch (below)
+    const bool no_out = !bus_f32 && !bus_f64 && !pcm_i16;
+    if (!b || nframes == 0 || no_out) {
+        int rcp = sh::flush_pending();
+        if (rcp) return rcp;
+    }
+    if (!b || no_out) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: NULL argument");
+    if (nframes == 0) return SH_OK;
+    if (bus_f32 && bus_f32->bytes < (size_t)nframes * 8) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f32 too small");
+    if (bus_f64 && bus_f64->bytes < (size_t)nframes * 16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f64 too small");
+    if (pcm_i16 && pcm_i16->bytes < (size_t)nframes * 4) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_pcm: PCM buffer too small");
+    int rc = bank_check_plain(b, "sh_bank_render");
+    if (rc) return rc;
+    float2* o32 = bus_f32 ? (float2*)bus_f32->ptr : nullptr;
+    double2* o64 = bus_f64 ? (double2*)bus_f64->ptr : nullptr;
+    uint32_t* o16 = pcm_i16 ? (uint32_t*)pcm_i16->ptr : nullptr;
+    const size_t n32 = (size_t)nframes * 8, n64 = (size_t)nframes * 16, n16 = (size_t)nframes * 4;
+    sh::State& S = sh::state();
+    const sh::Knobs& K = sh::knobs();
+    // variant = WAVES*100 + FPL*10 + MINW (SYNTHHIP_VARIANT overrides the tuned default)
+    int var = K.variant;
+    const int mode = b->lean_candidates == 0 ? RENDER_DIRECT : (b->lean_fm_candidates ? RENDER_LEAN_ALL : RENDER_LEAN_HARM);
+    // mostly-lean banks take eight frames per lane on long blocks: the recurrences make every frame after the second cost one or
+    // two FMAs of trigonometry (one table lookup per eight frames)
+    if (var == 0) var = b->nvoices >= 128 ? (2 * b->lean_candidates >= b->nvoices ? (nframes >= 16384 ? 484 : 444) : 844)
+                                          : (b->nvoices >= 64 ? 826 : (b->nvoices >= 8 ? 421 : 211));
+    const int W = var / 100, F = (var / 10) % 10;
+    // Voice groups: split the voices when the frame range alone gives too few tiles for 256 CUs -- up to ONE round of
+    // resident workgroups (1024 slots of four waves), not beyond: 752 workgroups that all start at once beat 1504 whose
+    // second round runs half empty (MI355X, 1024 voices x 48 000 frames: 4 groups of 188 tiles 46.7 us, 8 groups 47.2, 16
+    // groups 50.1; eight frames per lane: 8 groups of 94 tiles 36.9, 16 groups 38.9, 4 groups 40.3).  SYNTHHIP_GROUPS overrides.
+    const uint32_t tiles = sh::div_up(nframes, 64 * F);
+    const uint32_t slots = 4096u / (uint32_t)W;
+    uint32_t groups = 1;
+    if (W == 4) {
+        while (tiles * groups * 2 <= slots && b->nvoices / (groups * 2) >= (uint32_t)(4 * W)) groups *= 2;
+    } else {                                                 // the eight-wave shapes of small / non-lean banks: cover the chip several times over
+        while (tiles * groups < 1024 && b->nvoices / (groups * 2) >= (uint32_t)(4 * W)) groups *= 2;
+    }
+    if (K.groups > 0) groups = (uint32_t)K.groups;
+    uint32_t vpg = (b->nvoices + groups - 1) / groups;
+    if (groups > 1) vpg = (vpg + 63) & ~63u;                // groups are made of whole 64-voice chunks (the lists' unit)
+    groups = (b->nvoices + vpg - 1) / vpg;                  // no empty trailing groups
+    // A RUN: consecutive renders of a bank (same shape, the next block each time) alternate between two HIP streams so that the
+    // tail of one launch -- its launch latency, for a small bank: nearly all of it -- is filled by the next; with several voice
+    // groups a launch also folds the partial buses of the launch before its predecessor.  A single-group launch writes the
+    // caller's buffers itself, so it may only run beside its predecessor when the two do not write the same memory (a ring of
+    // bus buffers; a caller that renders every block into ONE buffer stays on one stream, as in round 2).
+    const bool may_pipeline = !K.no_speculation && !K.no_overlap;
+    const bool direct = groups == 1;
+    bool pipelined = groups > 1 || (may_pipeline && !K.no_small_pipeline);
+    bool cont = pipelined && b->run_active && b->run_nframes == nframes && b->run_groups == groups &&
+                b->run_tile == (uint32_t)(64 * F) && b->run_next_start == start;
+    if (direct && pipelined) {
+        // memory the previous launch of this bank wrote directly: beside it (other stream) this launch must not write there
+        const bool same = (o32 && b->overlaps_last_direct(o32, n32)) || (o64 && b->overlaps_last_direct(o64, n64)) ||
+                          (o16 && b->overlaps_last_direct(o16, n16));
+        if (same) { pipelined = false; cont = false; }
+        // ... and memory an older launch of the run wrote on the OTHER stream (a ring with an odd number of buffers): new run
+        else if (cont) {
+            const uint8_t other = (b->run_count & 1) ? 1u : 2u;      // this launch goes to stream2 when run_count is odd: the other is `stream`
+            if (overlaps_writes(b, true, other, o32, n32) || overlaps_writes(b, true, other, o64, n64) || overlaps_writes(b, true, other, o16, n16))
+                cont = false;
+        }
+    }
+    // an output buffer another bank's launches may still write (a fold it owes, a fold one of its launches is doing right now on
+    // the other stream, a direct write): the order of the writes must be the callers' -- end every run
+    if (overlaps_writes(b, false, 3, o32, n32) || overlaps_writes(b, false, 3, o64, n64) || overlaps_writes(b, false, 3, o16, n16) ||
+        bank_writes().size() > 256) {
+        rc = sh::flush_pending();
+        if (rc) return rc;
+        cont = false;
+    }
+    if (!cont) {
+        // this bank's own leftovers are folded now; the other banks' runs go on
+        if (b->npending || b->run_active) {
+            rc = join_aux();
+            if (!rc) rc = fold_bank(b);
+            if (rc) return rc;
+        }
+        if (pipelined) {
+            b->run_active = true;
+            S.open_runs += 1;
+            b->run_nframes = nframes;
+            b->run_groups = groups;
+            b->run_tile = (uint32_t)(64 * F);
+            b->run_count = 0;
+            SH_HIP(hipEventRecord(S.ev_join, S.stream));    // everything enqueued so far: stream2's first launch of the run waits for it
+        }
+    }
+    const uint32_t n = pipelined ? b->run_count : 0;
+    const bool two_streams = pipelined && may_pipeline;
+    const bool use_aux = two_streams && (n & 1);
+    hipStream_t st = use_aux ? S.stream2 : S.stream;
+    if (use_aux && n == 1) SH_HIP(hipStreamWaitEvent(S.stream2, S.ev_join, 0));
+    const int prev_cur = b->cur;
+    // a bank with lean candidates + several voice groups: the launch is split into a lean and a general kernel
+    // (see the RENDER_* modes); SYNTHHIP_NO_SPLIT=1 keeps the combined kernel
+    const bool split = mode != RENDER_DIRECT && groups > 1 && !K.no_split;
+    // A transition launch (RENDER_*_SEG): cut where the envelopes become flat (every voice past its decay) and from there on
+    // into segments no longer than their own distance from the note's start -- piece ends of the phase sum lie an octave apart,
+    // so such a segment crosses at most one per voice; a cut, too, where the first voice leaves its sustain.  Tile-aligned cuts.
+    uint32_t seg_first[SEG_MAX + 1];
+    uint32_t nseg = 0;
+    if (split && (mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_ALL) && var == 484 && b->all_lean && !K.no_seg && !b->needs_rows && !b->no_general_voice(start, nframes)) {
+        nseg = plan_segments(b, start, nframes, (uint64_t)(64 * F), ~0ull, true, seg_first);
+        if (nseg < 2 || seg_first[nseg] != nframes) nseg = 0;        // nothing to cut, or more cuts than a launch carries
+    }
+    if (nseg == 0) {
+        rc = acquire_records(b, start, nframes, st, cont);
+        if (rc) return rc;
+    }
+    // partial buses: ring slot n % 4 (last read by the fold in launch n - 2, which is this stream's previous launch)
+    double2* parts = nullptr;
+    if (groups > 1) {
+        const int k = (int)(n & 3);
+        // split launch: the general kernel's parts follow the lean kernel's, then one flag per group
+        const size_t need = split ? 2 * (size_t)groups * nframes * sizeof(double2) + (size_t)groups * sizeof(uint32_t)
+                                  : (size_t)groups * nframes * sizeof(double2);
+        rc = sh::grow_pooled(b->parts[k], need);
+        if (rc) return rc;
+        parts = (double2*)b->parts[k].ptr;
+    }
+    // ... and the general-lists kernel is only launched when the launch CAN hold a general voice
+    const bool with_general = split && (K.always_general || !b->no_general_voice(start, nframes));
+    uint32_t* gen_valid = with_general ? (uint32_t*)(parts + 2 * (size_t)groups * nframes) : nullptr;
+    // the fold this launch takes over: the older of two outstanding ones (launch n - 2's)
+    const bool take_over = b->npending == 2;
+    const sh::PendingCombine prev = take_over ? b->pending[0] : sh::PendingCombine();
+    const double2* pv_parts = take_over ? (const double2*)prev.parts : nullptr;
+    float2* pv32 = take_over ? (float2*)prev.o32 : nullptr;
+    double2* pv64 = take_over ? (double2*)prev.o64 : nullptr;
+    uint32_t* pv16 = take_over ? (uint32_t*)prev.o16 : nullptr;
+    const double pv_scale = take_over ? prev.scale : 0.0;
+    const uint32_t* pv_gen = take_over ? (const uint32_t*)prev.gen_valid : nullptr;
+    b->last_groups = groups;
+    const LaunchSet cur = launch_set(b, b->cur);
+    // the records of the block two launches on go to a set that is neither this launch's, nor its predecessor's (perhaps
+    // still executing), nor the one holding the block in between
+    const uint64_t next_start = start + 2 * (uint64_t)nframes;
+    int target = -1;
+    if (!K.no_speculation) {
+        for (int c = 0; c < sh_bank::NSETS && target < 0; ++c) {
+            const bool holds_between = b->spec[c].valid && b->spec[c].start == start + nframes && b->spec[c].nframes == nframes;
+            if (c != b->cur && !(cont && (c == prev_cur || c == b->last_target)) && !holds_between) target = c;
+        }
+    }
+    LaunchSet next = launch_set(b, target < 0 ? 0 : target);
+    if (target < 0) next.launch = nullptr;
+    // the workgroups that resolve those records: one per chunk of 64 voices, dispatched in front of the tiles' (prep_wgs per row of the grid)
+    const uint32_t nchunks = sh::div_up(b->nvoices, 64);
+    const uint32_t prep_wgs = (next.launch && !K.prepare_in_tile) ? sh::div_up(nchunks, groups) : 0u;
+    if (nseg) {
+        const int ks = use_aux ? 1 : 0;
+        LaunchSet& g = b->seg_set[ks];
+        rc = grow_segment_sets(b->seg_block[ks], g, b->seg_cap[ks], nseg, b->nvoices);
+        if (rc) return rc;
+        BankPtrs P = ptrs(b);
+        P.nseg = nseg;
+        for (uint32_t k = 0; k <= nseg; ++k) P.seg_first[k] = seg_first[k];
+        rc = launch_prepare_segments_var(st, true, P, g, b->nvoices, nseg, start);
+        if (rc) return rc;
+        uint32_t tiles_lean = 0, tiles_gen = 0;
+        for (uint32_t k = 0; k < nseg; ++k) {
+            tiles_lean += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 8);
+            tiles_gen += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 4);
+        }
+        if (mode == RENDER_LEAN_HARM)
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_HARM_SEG>), dim3(prep_wgs + tiles_lean, groups), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
+        else
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_ALL_SEG>), dim3(prep_wgs + tiles_lean, groups), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
+        SH_CHECK_LAUNCH("k_bank_render(lean, segments)");
+        SH_HIP(hipMemsetAsync(gen_valid, 1, (size_t)groups * sizeof(uint32_t), st));         // every group's general parts are written
+        // the first segment's groups are split SUB ways (BankPtrs::gen_sub): with sixteen waves per workgroup a wave walks two
+        // or three of the 128 voices of its group
+        const uint32_t SUB = (uint32_t)K.gen_sub;
+        const uint32_t n0 = seg_first[1];
+        rc = sh::grow_pooled(b->seg_scratch[ks], (size_t)groups * SUB * n0 * sizeof(double2));
+        if (rc) return rc;
+        P.gen_sub = SUB;
+        P.gen_scratch = (double2*)b->seg_scratch[ks].ptr;
+        LaunchSet none = g;
+        none.launch = nullptr;
+        hipLaunchKernelGGL((k_bank_render<16, 4, 1, RENDER_GENERAL_SEG>), dim3(tiles_gen + (SUB - 1) * sh::div_up(n0, 64 * 4), groups), dim3(1024), 0, st, P,
+                           trig_table(), b->nvoices, vpg, g, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
+                           (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
+                           gen_valid, (const uint32_t*)nullptr, 0u);
+        SH_CHECK_LAUNCH("k_bank_render(general, segments)");
+        hipLaunchKernelGGL(k_seg_combine, dim3(sh::div_up(n0, 256), groups), dim3(256), 0, st, (const double2*)b->seg_scratch[ks].ptr, SUB, n0,
+                           parts + (size_t)groups * nframes, nframes);
+        SH_CHECK_LAUNCH("k_seg_combine");
+    } else {
+#define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
+    hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(prep_wgs + tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),    \
+                       trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64, \
+                       o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs)
+#define SH_LAUNCH_RENDER(W_, F_, M_)                                                 \
+    do {                                                                             \
+        if (split && mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM_ONLY); \
+        else if (split) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_ALL_ONLY);            \
+        else if (mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM);  \
+        else if (mode == RENDER_LEAN_ALL) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_ALL); \
+        else SH_LAUNCH_MODE(W_, F_, M_, RENDER_DIRECT);                              \
+    } while (0)
+    switch (var) {
+    case 1621: SH_LAUNCH_RENDER(16, 2, 1); break;
+    case 1611: SH_LAUNCH_RENDER(16, 1, 1); break;
+    case 826: SH_LAUNCH_RENDER(8, 2, 6); break;
+    case 821: SH_LAUNCH_RENDER(8, 2, 1); break;
+    case 828: SH_LAUNCH_RENDER(8, 2, 8); break;
+    case 841: SH_LAUNCH_RENDER(8, 4, 1); break;
+    case 844: SH_LAUNCH_RENDER(8, 4, 4); break;
+    case 421: SH_LAUNCH_RENDER(4, 2, 1); break;
+    case 411: SH_LAUNCH_RENDER(4, 1, 1); break;
+    case 441: SH_LAUNCH_RENDER(4, 4, 1); break;
+    case 444: SH_LAUNCH_RENDER(4, 4, 4); break;
+    case 484: SH_LAUNCH_RENDER(4, 8, 4); break;
+    case 884: SH_LAUNCH_RENDER(8, 8, 4); break;
+    case 211: SH_LAUNCH_RENDER(2, 1, 1); break;
+    case 221: SH_LAUNCH_RENDER(2, 2, 1); break;
+    default: return sh::set_error(SH_ERR_INVALID, "sh_bank_render: unknown SYNTHHIP_VARIANT %d", var);
+    }
+#undef SH_LAUNCH_RENDER
+#undef SH_LAUNCH_MODE
+    SH_CHECK_LAUNCH("k_bank_render");
+    if (with_general) {
+        // the general lists of the same launch: four waves x four frames per lane whatever the lean kernel's shape (the parts
+        // are indexed by frame), same voice groups, behind the lean kernel on the same stream
+        LaunchSet none = cur;
+        none.launch = nullptr;
+        hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_ONLY>), dim3(sh::div_up(nframes, 256), groups), dim3(256), 0, st, ptrs(b),
+                           trig_table(), b->nvoices, vpg, cur, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
+                           (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
+                           gen_valid, (const uint32_t*)nullptr, 0u);
+        SH_CHECK_LAUNCH("k_bank_render(general lists)");
+    }
+    }
+    if (use_aux) {
+        SH_HIP(hipEventRecord(S.ev_aux, S.stream2));
+        S.aux_busy = true;
+    }
+    const uint8_t stream_bit = use_aux ? 2u : 1u;
+    if (take_over) {                                        // folded by this launch -- which may be running for a while yet: the
+        note_write(b, prev.o32, (size_t)prev.nframes * 8, stream_bit);           // buses it folds into stay on record (they are: from
+        note_write(b, prev.o64, (size_t)prev.nframes * 16, stream_bit);          // the launch that rendered them; now with this stream)
+        note_write(b, prev.o16, (size_t)prev.nframes * 4, stream_bit);
+        b->pending[0] = b->pending[1];
+        b->npending = 1;
+        S.pending_total -= 1;
+    }
+    if (groups > 1) {                                       // this launch's partial buses: folded two launches on, or by the next other API call
+        sh::PendingCombine& pc = b->pending[b->npending++];
+        S.pending_total += 1;
+        pc.parts = parts;
+        pc.groups = groups;
+        pc.nframes = nframes;
+        pc.o32 = o32;
+        pc.o64 = o64;
+        pc.o16 = o16;
+        pc.scale = pcm_scale;
+        pc.gen_valid = gen_valid;
+    }
+    if (S.open_runs > 0) {
+        // on record while any run is open (this bank's or another's): direct writes with their stream; the buses a pending fold
+        // will write from now (another bank must not slip a write in between), the stream follows when a launch takes the fold over
+        note_write(b, o32, n32, direct ? stream_bit : 0);
+        note_write(b, o64, n64, direct ? stream_bit : 0);
+        note_write(b, o16, n16, direct ? stream_bit : 0);
+    }
+    if (pipelined) {
+        b->run_count = n + 1;
+        b->run_next_start = start + nframes;
+    }
+    b->last_direct[0] = b->last_direct[1] = b->last_direct[2] = sh_bank::Range{nullptr, nullptr};
+    if (direct) {
+        if (o32) b->last_direct[0] = sh_bank::Range{(const char*)o32, (const char*)o32 + n32};
+        if (o64) b->last_direct[1] = sh_bank::Range{(const char*)o64, (const char*)o64 + n64};
+        if (o16) b->last_direct[2] = sh_bank::Range{(const char*)o16, (const char*)o16 + n16};
+    }
+    b->last_target = target;
+    if (target >= 0) {
+        b->spec[target].valid = true;
+        b->spec[target].start = next_start;
+        b->spec[target].nframes = nframes;
+    }
+    return SH_OK;
+}
+
+// Renders of any length: the launch's x dimension is a tile count (tiles x threads per workgroup must stay below 2^32 work-items,
+// which the shapes of small banks reach first: sixteen waves on 128 frames), and a bank with several voice groups keeps
+// 32 bytes of partial buses per frame and group.  Long renders are therefore a run of launches of RENDER_MAX_FRAMES (87 s
+// at 48 kHz; consecutive blocks of one shape: the two-stream pipeline applies) into views of the caller's buffers.
+constexpr uint32_t RENDER_MAX_FRAMES = 1u << 22;
+static int bank_render_any(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64, sh_buf* pcm_i16, double pcm_scale) {
+    if (nframes <= RENDER_MAX_FRAMES) return bank_render(b, start, nframes, bus_f32, bus_f64, pcm_i16, pcm_scale);
+    SH_API_LOCK();                                           // (recursive) one call: nothing else gets between its launches
+    if (bus_f32 && bus_f32->bytes < (size_t)nframes * 8) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f32 too small");
+    if (bus_f64 && bus_f64->bytes < (size_t)nframes * 16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f64 too small");
+    if (pcm_i16 && pcm_i16->bytes < (size_t)nframes * 4) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_pcm: PCM buffer too small");
+    const double* rows = b ? b->launch_rows : nullptr;
+    int rc = SH_OK;
+    for (uint64_t off = 0; off < nframes && !rc; off += RENDER_MAX_FRAMES) {
+        const uint32_t n = nframes - off < RENDER_MAX_FRAMES ? (uint32_t)(nframes - off) : RENDER_MAX_FRAMES;
+        sh_buf v32{nullptr, 0, false, 0}, v64{nullptr, 0, false, 0}, v16{nullptr, 0, false, 0};
+        if (bus_f32) { v32.ptr = (char*)bus_f32->ptr + off * 8; v32.bytes = bus_f32->bytes - off * 8; }
+        if (bus_f64) { v64.ptr = (char*)bus_f64->ptr + off * 16; v64.bytes = bus_f64->bytes - off * 16; }
+        if (pcm_i16) { v16.ptr = (char*)pcm_i16->ptr + off * 4; v16.bytes = pcm_i16->bytes - off * 4; }
+        if (rows) b->launch_rows = rows + off;               // launch-relative rows (sh_bank_render_rows)
+        rc = bank_render(b, start + off, n, bus_f32 ? &v32 : nullptr, bus_f64 ? &v64 : nullptr, pcm_i16 ? &v16 : nullptr, pcm_scale);
+    }
+    if (rows) b->launch_rows = rows;
+    return rc;
+}
+
+extern "C" {
+
+int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64) {
+    return bank_render_any(b, start, nframes, bus_f32, bus_f64, nullptr, 0.0);
+}
+
+int sh_bank_render_pcm(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* pcm_i16) {
+    if (!pcm_i16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_pcm: NULL PCM buffer");
+    return bank_render_any(b, start, nframes, nullptr, nullptr, pcm_i16, scale);
+}
+
+int sh_bank_render_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
+                        sh_buf* bus_f32, sh_buf* bus_f64) {
+    if (!b || !rows_f64) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_rows: NULL argument");
+    SH_API_LOCK();                                           // held across bank_render (recursive): the rows belong to this call
+    {
+        if (!b->d_fm_row) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_rows: sh_bank_set_rows has not been called");
+        if (row_stride < nframes) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_rows: row_stride < nframes");
+        if (b->fm_row_max >= 0 && rows_f64->bytes / 8 < (size_t)b->fm_row_max * row_stride + nframes)
+            return sh::set_error(SH_ERR_INVALID, "sh_bank_render_rows: rows buffer too small for row %d", b->fm_row_max);
+        b->launch_rows = (const double*)rows_f64->ptr;
+        b->launch_row_stride = row_stride;
+    }
+    int rc = bank_render_any(b, start, nframes, bus_f32, bus_f64, nullptr, 0.0);
+    b->launch_rows = nullptr;
+    b->launch_row_stride = 0;
+    return rc;
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 #include <unordered_map>
 
@@ -14,6 +15,36 @@ static thread_local char g_err[512] = "";
 State& state() {
     static State s;
     return s;
+}
+
+static Knobs g_knobs;
+const Knobs& knobs() { return g_knobs; }
+Counters& counters() {
+    static Counters c;
+    return c;
+}
+
+void load_knobs() {
+    auto flag = [](const char* name) { const char* e = getenv(name); return e && e[0] == '1'; };
+    auto num = [](const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; };
+    Knobs k;
+    k.no_speculation = flag("SYNTHHIP_NO_SPECULATION");
+    k.no_overlap = flag("SYNTHHIP_NO_OVERLAP");
+    k.no_split = flag("SYNTHHIP_NO_SPLIT");
+    k.no_seg = flag("SYNTHHIP_NO_SEG");
+    k.always_general = flag("SYNTHHIP_ALWAYS_GENERAL");
+    k.no_small_pipeline = flag("SYNTHHIP_NO_SMALL_PIPELINE");
+    k.prepare_in_tile = flag("SYNTHHIP_PREPARE_IN_TILE");
+    k.variant = (int)num("SYNTHHIP_VARIANT", 0);
+    k.groups = (int)num("SYNTHHIP_GROUPS", 0);
+    k.gen_lf = (int)num("SYNTHHIP_GEN_LF", 0);
+    k.gen_sub = (int)num("SYNTHHIP_GEN_SUB", 4);
+    if (k.gen_sub < 1 || k.gen_sub > 16) k.gen_sub = 4;
+    k.seg_min = num("SYNTHHIP_SEG_MIN", 0);
+    k.gen_rows = (int)num("SYNTHHIP_GEN_ROWS", 0);
+    k.resample_pk = (int)num("SYNTHHIP_RESAMPLE_PK", -1);
+    k.pool_fill = (int)num("SYNTHHIP_POOL_FILL", -1);
+    g_knobs = k;
 }
 
 std::recursive_mutex& api_mutex() {
@@ -67,8 +98,10 @@ int pool_alloc(size_t bytes, void** ptr, size_t* cap) {
         it->second.pop_back();
         g_pool.cached -= c;
         *cap = c;
+        counters().pool_hits += 1;
         return SH_OK;
     }
+    counters().device_allocs += 1;
     hipError_t e = hipMalloc(ptr, c);
     if (e == hipErrorOutOfMemory && g_pool.cached) {        // give the cache back and try once more
         pool_trim();
@@ -81,6 +114,8 @@ int pool_alloc(size_t bytes, void** ptr, size_t* cap) {
 
 void pool_free(void* ptr, size_t cap) {
     if (g_pool.cached + cap > Pool::LIMIT) {
+        counters().stream_syncs += 1;
+        counters().device_frees += 1;
         (void)hipStreamSynchronize(state().stream);
         (void)hipFree(ptr);
         return;
@@ -92,24 +127,48 @@ void pool_free(void* ptr, size_t cap) {
 void pool_trim() {
     if (state().stream) (void)hipStreamSynchronize(state().stream);
     for (auto& kv : g_pool.free_)
-        for (void* p : kv.second) (void)hipFree(p);
+        for (void* p : kv.second) { counters().device_frees += 1; (void)hipFree(p); }
     g_pool.free_.clear();
     g_pool.cached = 0;
 }
 
 int ensure_scratch(size_t bytes) {
+    // (entry points that use the scratch hold no run of renders: SH_REQUIRE_INIT joined the streams; the pool's reuse is
+    // ordered by the main stream)
     State& s = state();
     if (s.scratch_bytes >= bytes) return SH_OK;
     if (s.scratch) {
-        SH_HIP(hipStreamSynchronize(s.stream));
-        SH_HIP(hipFree(s.scratch));
+        pool_free(s.scratch, s.scratch_bytes);
         s.scratch = nullptr;
         s.scratch_bytes = 0;
     }
     size_t want = bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes;
-    SH_HIP(hipMalloc(&s.scratch, want));
-    s.scratch_bytes = want;
-    return SH_OK;
+    return pool_alloc(want, &s.scratch, &s.scratch_bytes);
+}
+
+int grow_pooled(Pooled& p, size_t bytes) {
+    if (p.cap >= bytes && p.ptr) return SH_OK;
+    if (p.ptr) {
+        // launches on either stream may still use the old block, and the block that comes back from the pool may still be in use
+        // by work on the main stream: order the two streams both ways, then hand over
+        int rc = join_streams();
+        if (rc) return rc;
+        pool_free(p.ptr, p.cap);
+        p.ptr = nullptr;
+        p.cap = 0;
+    }
+    int rc = pool_alloc(bytes, &p.ptr, &p.cap);
+    if (!rc && knobs().pool_fill >= 0) {                     // (diagnostics: poison / clear what comes from the pool)
+        SH_HIP(hipMemsetAsync(p.ptr, knobs().pool_fill, p.cap, state().stream));
+        rc = join_streams();
+    }
+    return rc;
+}
+
+void release_pooled(Pooled& p) {
+    if (p.ptr) pool_free(p.ptr, p.cap);
+    p.ptr = nullptr;
+    p.cap = 0;
 }
 
 }  // namespace sh
@@ -142,6 +201,8 @@ int sh_init(int device) {
         if (s.device == device) return SH_OK;
         return sh::set_error(SH_ERR_INVALID, "already initialised on device %d", s.device);
     }
+    sh::load_knobs();
+    sh::counters() = sh::Counters();
     int n = sh_device_count();
     if (n <= 0) return sh::set_error(SH_ERR_NOTINIT, "no HIP device visible");
     if (device < 0 || device >= n) return sh::set_error(SH_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
@@ -151,6 +212,7 @@ int sh_init(int device) {
     SH_HIP(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
     SH_HIP(hipEventCreateWithFlags(&s.ev_aux, hipEventDisableTiming));
     SH_HIP(hipEventCreateWithFlags(&s.ev_prep, hipEventDisableTiming));
+    SH_HIP(hipEventCreateWithFlags(&s.ev_sync, hipEventDisableTiming));
     SH_HIP(hipEventCreate(&s.ev_start));
     SH_HIP(hipEventCreate(&s.ev_stop));
     SH_HIP(hipMalloc((void**)&s.flag, sizeof(int) * 16));
@@ -182,12 +244,13 @@ int sh_shutdown(void) {
     if (sh::has_pending()) sh::flush_pending();
     (void)hipStreamSynchronize(s.stream);
     (void)hipStreamSynchronize(s.stream2);
-    sh::pool_trim();
-    if (s.scratch) (void)hipFree(s.scratch);
     sh::free_render_buffers();
+    if (s.scratch) sh::pool_free(s.scratch, s.scratch_bytes);
+    sh::pool_trim();
     (void)hipEventDestroy(s.ev_join);
     (void)hipEventDestroy(s.ev_aux);
     (void)hipEventDestroy(s.ev_prep);
+    (void)hipEventDestroy(s.ev_sync);
     (void)hipStreamDestroy(s.stream2);
     if (s.flag) (void)hipFree(s.flag);
     if (s.trig) (void)hipFree(s.trig);
@@ -212,6 +275,17 @@ int sh_device_info(sh_devinfo* out) {
     out->hbm_bytes = p.totalGlobalMem;
     out->wavefront = p.warpSize;
     out->device = state().device;
+    return SH_OK;
+}
+
+int sh_debug_counters(sh_counters* out) {
+    SH_API_LOCK();
+    if (!out) return sh::set_error(SH_ERR_INVALID, "sh_debug_counters: out is NULL");
+    const sh::Counters& c = sh::counters();
+    out->device_allocs = c.device_allocs;
+    out->device_frees = c.device_frees;
+    out->stream_syncs = c.stream_syncs;
+    out->pool_hits = c.pool_hits;
     return SH_OK;
 }
 
