@@ -251,24 +251,141 @@ def pcm_rows(N):
     return rows
 
 
-def config_rows(N):
+def config_roofline(prof, tag, voice_samples, ms, algorithmic_bytes):
+    """Roofline of a BASELINE config's render launch from the committed counters of ITS profiling pass (profiles/rNN_counters.json,
+    key "<tag>:<kernel>"; tools/profile_round.sh runs bench.py --only-config <tag> under rocprofv3): float64 lane-operations per
+    voice-sample = (FMA + MUL + ADD wave-instructions) x 64 / voice-samples per dispatch, against the issue peak; HBM traffic
+    per dispatch against the algorithmic bytes."""
+    best, name = None, None
+    for k_, v_ in prof["counters"].items():
+        if k_.startswith(tag + ":") and "k_bank_render" in k_ and (best is None or v_.get("SQ_INSTS_VALU_FMA_F64", 0) > best.get("SQ_INSTS_VALU_FMA_F64", 0)):
+            best, name = v_, k_
+    if not best or not all(k in best for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")):
+        return {"bound": "valu_f64", "note": "no counters for this config in profiles/ (tools/profile_round.sh writes them)"}
+    ops = (best["SQ_INSTS_VALU_FMA_F64"] + best["SQ_INSTS_VALU_MUL_F64"] + best["SQ_INSTS_VALU_ADD_F64"]) * 64.0 / voice_samples
+    achieved = voice_samples * ops / (ms / 1e3) / 1e12
+    traffic = sum(v_["hbm_bytes"] for k_, v_ in prof["traffic"].items() if k_.startswith(tag + ":") and "k_bank_render" in k_) or None
+    return {"kernel": name.split(":", 1)[1], "bound": "valu_f64", "ops_per_voice_sample": ops, "achieved": achieved, "peak": FP64_PEAK_TOPS,
+            "unit": "T f64 lane-ops/s", "frac": achieved / FP64_PEAK_TOPS, "avg_launch_ms": ms,
+            "valu_busy_note": "all VALU wave-instructions x 4 cycles / 1024 SIMDs / launch time = %.2f" %
+                              (best.get("SQ_INSTS_VALU", 0) * 4.0 / 1024 / 2.4e9 / (ms / 1e3)) if best.get("SQ_INSTS_VALU") else None,
+            "traffic": traffic, "algorithmic_bytes": algorithmic_bytes,
+            "traffic_over_algorithmic": traffic / algorithmic_bytes if traffic else None,
+            "source": prof.get("counters_source")}
+
+
+class _stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: what a native library prints on stdout (librccl's version banner
+    at communicator creation) must not end up beside the ONE JSON line this script owes its caller."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
+def config4_rows(N, K):
+    """BASELINE configs[3] as far as ONE GPU goes: (a) the whole 8192-voice table on this GPU (what --scaling strong reports at
+    N = 1); (b) one rank's share -- 1024 voices -- driven down the multi-rank path: DistVoiceBank's slot ring, float64 partial
+    buses, ncclReduce on a 1-rank communicator on the communication stream, the rounding to float32 behind it -- per block, with
+    and without the exchange."""
+    from synthesizer_amd import dist
+    out = {}
+    voices, gains = build_voices(STRONG_VOICES)
+    bank = dist.DistVoiceBank(voices, gains, 0, 1)
+    pos = [5]
+
+    def step():
+        bank.render_device(SR, pos[0] * SR)
+        pos[0] += 1
+    for _ in range(4):
+        step()
+    ms = steady(N, step, min_seconds=0.1, reps=K)
+    out["strong_8192v_n1"] = {"voices": STRONG_VOICES, "ms_per_step": ms, "value": STRONG_VOICES * SR / (ms / 1e3) / 1e6, "unit": "Msamples/s",
+                              "note": "the whole configs[3] table on one GPU (bench.py --scaling strong --gpus 1), float32 bus, steady state"}
+    del bank
+    try:
+        with _stdout_to_stderr():
+            dist.init(0, 1, broadcast=lambda payload, rank, world, n: payload)
+        local_v, local_g = voices[:VOICES_PER_GPU], gains[:VOICES_PER_GPU]
+        ring = dist.DistVoiceBank(local_v, local_g, 0, 1, batch=8)
+        ring.world, ring.batch = 2, 8                 # the multi-rank code path on a 1-rank communicator: same calls, the reduce is the identity
+        pos = [5]
+
+        def ring_step():
+            ring.render_device(SR, pos[0] * SR)
+            pos[0] += 1
+        for _ in range(16):
+            ring_step()
+        # (steady(): loops of 4 batches between HIP events until the clocks are up, median loop -- a single shot after the pause
+        # in which the bank was built measures the clock governor; timer_stop ends the run: one drain per 4 batches stays in)
+        with_x = steady(N, ring_step, min_seconds=0.15, reps=32)
+        ring.flush()
+        N.sync()
+        # the same renders (float64 partial bus out) without the exchange
+        bufs = [N.DeviceBuffer(SR * 16) for _ in range(4)]
+        p2 = [5]
+
+        def local_step():
+            ring.local.render_device(SR, p2[0] * SR, bus_f32=None, bus_f64=bufs[p2[0] & 3])
+            p2[0] += 1
+        without_x = steady(N, local_step, min_seconds=0.1, reps=K)
+        # one blocking reduce of a batch message, back to back
+        nval = 8 * SR * 2
+        msg = N.DeviceBuffer(nval * 8)
+        msg.zero()
+        red = steady(N, lambda: N.check(N.lib().sh_dist_reduce_bus(msg.handle, nval, 0)), min_seconds=0.02, reps=5)
+        out["rank_local_1024v"] = {"voices": VOICES_PER_GPU, "ms_per_step_with_exchange": with_x, "ms_per_step_render_only_f64_bus": without_x,
+                                   "blocking_reduce_ms_per_batch_of_8": red, "reduce_message_bytes": nval * 8,
+                                   "value": VOICES_PER_GPU * SR / (with_x / 1e3) / 1e6, "unit": "Msamples/s",
+                                   "note": "one rank's share of configs[3] through DistVoiceBank(batch=8)'s slot ring: render -> float64 partial bus -> "
+                                           "ncclReduce (1-rank communicator, communication stream; enqueued a few launches after the slot filled up, behind marks on both render "
+                                           "streams: the run of pipelined renders is never ended) -> float32; HIP events, loops of 32 blocks"}
+        for b_ in bufs:
+            b_.free()
+        msg.free()
+    except Exception as e:                               # no librccl on the box: the render-only row stands alone
+        out["rank_local_1024v"] = {"error": str(e)}
+    finally:
+        try:
+            dist.shutdown()
+        except Exception:
+            pass
+    out["note"] = "the 8-GPU run itself: python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 [--scaling strong]"
+    return out
+
+
+def config_rows(N, prof=None, only=None, K=20):
     """The BASELINE configs other than the headline, each on its own steady-state loop (one MI355X)."""
     import numpy as np
     from synthesizer_amd import oscillators as G
     from synthesizer_amd import workloads as W
     from synthesizer_amd.mixer import VoiceBank
     rows = {}
-    # configs[0]: single 440 Hz Sine, 1 s @ 44.1 kHz mono, delivered to a host array (the call includes the D2H copy)
-    osc = G.Sine(440, samplerate=44100)
-    osc.render(44100)
-    t0 = time.perf_counter()
-    for _ in range(200):
-        osc.render(44100, start=0)
-    dt = (time.perf_counter() - t0) / 200
-    rows["config1_sine_440Hz_1s_44k1_mono_to_host"] = {"ms": dt * 1e3, "Msamples_per_s": 44100 / dt / 1e6,
-                                                        "note": "Oscillator.render -> numpy float32 on the host, wall clock, PCIe copy included"}
+    prof = prof or {"counters": {}, "traffic": {}}
 
-    def bank_row(name, voices, gains, note):
+    def _config1_row(G):
+        # configs[0]: single 440 Hz Sine, 1 s @ 44.1 kHz mono, delivered to a host array (the call includes the D2H copy)
+        osc = G.Sine(440, samplerate=44100)
+        osc.render(44100)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            osc.render(44100, start=0)
+        dt = (time.perf_counter() - t0) / 200
+        return {"config1_sine_440Hz_1s_44k1_mono_to_host": {"ms": dt * 1e3, "Msamples_per_s": 44100 / dt / 1e6,
+                                                            "note": "Oscillator.render -> numpy float32 on the host, wall clock, PCIe copy included"}}
+
+    def bank_row(name, tag, voices, gains, note):
         bank = VoiceBank(voices, gains=gains)
         ring = [N.DeviceBuffer(SR * 8) for _ in range(4)]
         pos = [0]
@@ -279,16 +396,31 @@ def config_rows(N):
         for _ in range(8):
             step()
         ms = steady(N, step, min_seconds=0.1, reps=20)
+        t0 = time.perf_counter()
+        for _ in range(400):
+            step()
+        host_us = (time.perf_counter() - t0) / 400 * 1e6
+        N.sync()
         rows[name] = {"voices": len(voices), "ms_per_1s_block": ms, "Msamples_per_s": len(voices) * SR / (ms / 1e3) / 1e6,
-                      "realtime_factor": 1e3 / ms, "note": note}
+                      "realtime_factor": 1e3 / ms, "host_enqueue_us_per_block": host_us, "note": note,
+                      "roofline": config_roofline(prof, tag, float(len(voices)) * SR, ms, 8.0 * SR)}
         for b in ring:
             b.free()
-    v, g = W.additive_voices(G, 64, SR, seed=0, partials=PARTIALS, adsr=ADSR_BENCH)
-    bank_row("config2_additive_64v_adsr_48k_stereo", v, g, "64 Harmonics x16 voices + ADSR -> float32 stereo bus; launch-bound (64 voices do not fill 256 CUs)")
-    v, g = W.fm_voices(G, 1024, SR, seed=1)
-    bank_row("config3_fm_1024v_48k_stereo", v, g, "1024 Sine carriers, each with a Sine fm_lfo (closed-form running sum), -> float32 stereo bus")
-    rows["config4_8192v_8gpu"] = {"note": "python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 [--scaling strong]; not measurable on a 1-GPU box"}
-    rows["config5_resample_8ch_600s_96k_to_44k1"] = {"note": "pcm_rows.resample_f32_8ch_600s_96k_to_44k1"}
+    if only in (None, "config1"):
+        rows.update(_config1_row(G))
+    if only in (None, "config2"):
+        v, g = W.additive_voices(G, 64, SR, seed=0, partials=PARTIALS, adsr=ADSR_BENCH)
+        bank_row("config2_additive_64v_adsr_48k_stereo", "config2", v, g,
+                 "64 Harmonics x16 voices + ADSR -> float32 stereo bus into a ring of 4 buffers; latency-bound (64 voices x 48 000 frames are 2 us of "
+                 "arithmetic): consecutive blocks alternate between two streams, the records of the block two launches on are resolved "
+                 "by a workgroup of their own")
+    if only in (None, "config3"):
+        v, g = W.fm_voices(G, 1024, SR, seed=1)
+        bank_row("config3_fm_1024v_48k_stereo", "config3", v, g, "1024 Sine carriers, each with a Sine fm_lfo (closed-form running sum), -> float32 stereo bus")
+    if only in (None, "config4"):
+        rows["config4_8192v_8gpu"] = config4_rows(N, K)
+    if only is None:
+        rows["config5_resample_8ch_600s_96k_to_44k1"] = {"note": "pcm_rows.resample_f32_8ch_600s_96k_to_44k1"}
     return rows
 
 
@@ -307,6 +439,8 @@ def main() -> int:
     ap.add_argument("--no-pcm-rows", action="store_true", help="skip the resample / integer-mix rows")
     ap.add_argument("--no-two-step", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the rows of the other BASELINE configs")
+    ap.add_argument("--only-config", choices=("config2", "config3", "config4"), default=None,
+                    help="run ONLY that config's row and print it (tools/profile_round.sh: one rocprofv3 pass per config)")
     ap.add_argument("--reduce-batch", type=int, default=8, help="blocks per RCCL reduce when --gpus > 1 (also the length of a run of pipelined renders)")
     args = ap.parse_args()
 
@@ -333,6 +467,10 @@ def main() -> int:
         dist.init(rank, world, broadcast=gloo_broadcast)
 
     K, Wm, F = args.steps, args.warmup, args.frames
+    if args.only_config:
+        rows = config_rows(N, committed_profile(), only=args.only_config, K=K)
+        print(json.dumps({"only_config": args.only_config, "library": N.lib().sh_version().decode(), "configs": rows}), flush=True)
+        return 0
     total_voices = STRONG_VOICES if args.scaling == "strong" else VOICES_PER_GPU * world
     voices, gains = build_voices(total_voices)
     bank = dist.DistVoiceBank(voices, gains, rank, world, batch=args.reduce_batch)
@@ -376,6 +514,21 @@ def main() -> int:
         timed += wall
         if (timed >= args.min_seconds and len(passes) >= 3) or len(passes) >= args.max_passes:
             break
+    # self-check: the last block of the last timed pass (left in the bank's bus buffer by the pipelined run) against a fresh
+    # single render of the same block (records by a prepare kernel, fold by k_bus_combine: none of the run's machinery)
+    verified = None
+    if world == 1:
+        import numpy as np
+        last = (step0 - 1) * F
+        got = bank._bus32[0].download(np.float32, F * 2)
+        chk = N.DeviceBuffer(F * 8)
+        bank.local.render_device(F, last, bus_f32=chk)
+        ref = chk.download(np.float32, F * 2)
+        chk.free()
+        verified = {"ok": bool(np.array_equal(got, ref) and np.isfinite(got).all() and float(np.abs(got).max()) > 1e-3),
+                    "block_start_frame": int(last), "abs_max": float(np.abs(got).max()),
+                    "checksum_f64": float(got.astype(np.float64).sum()),
+                    "note": "last timed block, downloaded after the timed region, == a fresh single render of that block (bit for bit)"}
     walls = sorted(p[0] for p in passes)
     wall = statistics.median(walls)
     ev_ms = statistics.median(sorted(p[1] for p in passes))
@@ -435,6 +588,7 @@ def main() -> int:
         "realtime_factor": F * K / wall / SR,
         "device": info["name"] or "AMD Instinct MI355X", "arch": info["arch"],
         "library": L.sh_version().decode(),
+        "verified": verified,
         "roofline": {
             "kernel": render_name or "k_bank_render<4, 8, 4, 3>", "bound": "valu_f64",
             "kernel_note": "k_bank_render<WAVES, FPL, MINW, MODE>: <4, 8, 4, 3> = the lean Harmonics kernel of a split launch (table lookup + "
@@ -566,7 +720,7 @@ def main() -> int:
 
     # ---- the other BASELINE configs (rank 0, N = 1) ----
     if rank == 0 and world == 1 and not args.no_configs:
-        out["configs"] = config_rows(N)
+        out["configs"] = config_rows(N, prof, K=K)
 
     # ---- the integer / float PCM rows (rank 0): Sample.resample (configs[4]) and the mixer chain ----
     if rank == 0 and not args.no_pcm_rows:

@@ -173,6 +173,7 @@ int  sh_debug_counters(sh_counters* out);
  *   SYNTHHIP_GEN_LF=4|8|16        frames per lane of the lean materialisation kernel;  SYNTHHIP_GEN_ROWS=1|2 rows per wave
  *   SYNTHHIP_GEN_SUB=1..16        split of a segmented launch's first segment;  SYNTHHIP_SEG_MIN=frames of its dense first segment
  *   SYNTHHIP_RESAMPLE_PK=0|1      the packed 16-bit mono resample kernel off / on
+ *   SYNTHHIP_COMM_PRIORITY=-1|0|1 priority of the communication stream of the multi-GPU path (high / as the render streams / low)
  * (SYNTHHIP_LIB, read by the Python binding, names another build of this library to load.) */
 
 /* ---- device buffers ---------------------------------------------------------------- */
@@ -277,6 +278,9 @@ int sh_bank_generate_f64(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* r
 int sh_scan_rows_f64(sh_buf* rows, size_t row0, uint32_t nrows, uint32_t n, size_t row_stride, sh_buf* carry);
 int sh_bank_render_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
                         sh_buf* bus_f32, sh_buf* bus_f64);
+/* sh_bank_generate (the reference-shaped two-step route: every voice as a float32 row) for such a bank */
+int sh_bank_generate_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
+                          sh_buf* voices_out, size_t stride);
 
 /* ---- mixer sum bus over materialised voices ------------------------------------------ */
 /* float32: bus[i] = sum_v gains[v] * voices[v*stride+i]; gains = device buffer of nvoices x (l, r) floats */
@@ -293,6 +297,13 @@ int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint
  * is not allowed. */
 int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
                             uint32_t nsamples, sh_buf* out, size_t out_sample_off);
+
+/* The same two folds for every sample width audioop.add takes (1, 2, 3, 4 bytes; offsets, strides and counts in SAMPLES;
+ * width 2 = the two functions above): upstream's mixer calls audioop.add(mixed, chunk, samplewidth) with the width of its
+ * output format, which need not be 16 bits. */
+int sh_mix_chain(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint32_t nsamples, int width, sh_buf* out);
+int sh_mix_chain_gather(const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
+                        uint32_t nsamples, int width, sh_buf* out, size_t out_sample_off);
 
 /* ---- Sample.from_osc_block: int(scale*v), truncation toward zero; SH_ERR_OVERFLOW if out of range */
 int sh_quantize_f32(const sh_buf* in_f32, size_t in_off, size_t n, double scale, int width,
@@ -380,6 +391,15 @@ int sh_dist_barrier(void);
 int sh_dist_slots(void);
 int sh_dist_reduce_bus_async(sh_buf* bus_f64, size_t nvalues, int root, sh_buf* bus_f32, int slot);
 int sh_dist_wait_slot(int slot);
+/* The two calls above end the run of pipelined renders they are made in (like every entry point that can touch a bus buffer): a
+ * pipeline drain per batch.  These three do not.  sh_dist_mark_slot(slot): call once the slot's last render lies at least two
+ * launches back in its bank's run -- every partial bus of the slot has been folded by then -- it records where both render streams
+ * stand.  sh_dist_reduce_bus_lagged: call a few launches after the mark; the collective waits for the two marks only, and the run
+ * goes on (without a mark, or if a fold into the buffers is still owed, it behaves like sh_dist_reduce_bus_async).
+ * sh_dist_wait_slot_keep makes both render streams wait for the slot's collective. */
+int sh_dist_mark_slot(int slot);
+int sh_dist_reduce_bus_lagged(sh_buf* bus_f64, size_t nvalues, int root, sh_buf* bus_f32, int slot);
+int sh_dist_wait_slot_keep(int slot);
 /* float64 bus -> float32 bus after the reduce */
 int sh_bus_finalize(const sh_buf* bus_f64, size_t nvalues, sh_buf* bus_f32);
 

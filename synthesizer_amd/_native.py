@@ -103,9 +103,12 @@ _SIGNATURES = {
     "sh_bank_generate_f64": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t, C.c_size_t]),
     "sh_scan_rows_f64": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t, _P]),
     "sh_bank_render_rows": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t, _P, _P]),
+    "sh_bank_generate_rows": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t, _P, C.c_size_t]),
     "sh_mix_bus_f32": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P, _P]),
     "sh_mix_chain_i16": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P]),
     "sh_mix_chain_gather_i16": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, _P, C.c_size_t]),
+    "sh_mix_chain": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, C.c_int, _P]),
+    "sh_mix_chain_gather": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, _P, C.c_size_t]),
     "sh_quantize_f32": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_double, C.c_int, _P, C.c_size_t]),
     "sh_quantize_f64": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_double, C.c_int, _P, C.c_size_t]),
     "sh_quantize_clip_f32": (C.c_int, [_P, C.c_size_t, C.c_double, _P]),
@@ -139,6 +142,9 @@ _SIGNATURES = {
     "sh_dist_slots": (C.c_int, []),
     "sh_dist_reduce_bus_async": (C.c_int, [_P, C.c_size_t, C.c_int, _P, C.c_int]),
     "sh_dist_wait_slot": (C.c_int, [C.c_int]),
+    "sh_dist_mark_slot": (C.c_int, [C.c_int]),
+    "sh_dist_reduce_bus_lagged": (C.c_int, [_P, C.c_size_t, C.c_int, _P, C.c_int]),
+    "sh_dist_wait_slot_keep": (C.c_int, [C.c_int]),
     "sh_bus_finalize": (C.c_int, [_P, C.c_size_t, _P]),
 }
 
@@ -150,13 +156,18 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if "SYNTHHIP_LIB" not in os.environ:
+            from . import build as _build
             try:                                    # in-tree build when missing or stale (embedded source hash != the tree's)
-                from . import build as _build
                 _build.build(verbose=False)
             except Exception as exc:
-                raise NativeLibraryMissing(
-                    "%s not found and building it failed (%s): run `python -m synthesizer_amd.build` "
-                    "(hipcc, gfx950).  There is no CPU fallback." % (LIB_PATH, exc))
+                if not LIB_PATH.exists():
+                    raise NativeLibraryMissing(
+                        "%s not found and building it failed (%s): run `python -m synthesizer_amd.build` "
+                        "(hipcc, gfx950).  There is no CPU fallback." % (LIB_PATH, exc))
+                # a shipped library on a box without the compiler: use it, but say that it is not what the tree describes
+                import warnings
+                warnings.warn("%s is stale (built from sources %s, the tree is %s) and rebuilding it failed (%s): loading it as it is"
+                              % (LIB_PATH, _build.built_hash() or "?", _build.source_hash(), exc), RuntimeWarning)
         if not LIB_PATH.exists():
             raise NativeLibraryMissing(
                 "%s not found: build it with `python -m synthesizer_amd.build` (hipcc, gfx950). "

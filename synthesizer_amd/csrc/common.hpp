@@ -80,6 +80,7 @@ struct Knobs {
     long seg_min = 0;              // SYNTHHIP_SEG_MIN: frames of a segmented launch's dense first segment
     int  gen_rows = 0;             // SYNTHHIP_GEN_ROWS=1|2: rows per wave of the lean materialisation kernel
     int  resample_pk = -1;         // SYNTHHIP_RESAMPLE_PK=0|1: packed 16-bit mono resample kernel
+    int  comm_priority = 0;        // SYNTHHIP_COMM_PRIORITY=-1|0|1: priority of the communication stream (high / as the render streams / low)
     int  pool_fill = -1;           // SYNTHHIP_POOL_FILL=0..255: blocks that grow are filled with this byte first (diagnostics)
 };
 const Knobs& knobs();
@@ -117,6 +118,7 @@ int  grow_pooled(Pooled& p, size_t bytes);
 void release_pooled(Pooled& p);
 int  flush_pending();                  // end every bank's run of renders: join stream2, fold all outstanding partial buses now (osc.hip)
 void free_render_buffers();            // the banks' partial-bus rings (sh_shutdown)
+bool fold_owed_into(const void* p, size_t bytes);   // does any bank still owe a fold into this memory? (osc_render.hip)
 inline bool has_pending() { return state().pending_total != 0 || state().aux_busy || state().open_runs != 0; }
 int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out);   // float64 bus -> float32 (osc.hip)
 

@@ -6,6 +6,7 @@
 // latency-bound: callers batch >= 1 s per call.  librccl.so is dlopen()ed on first use so that
 // single-GPU users never pay for loading it.
 #include "common.hpp"
+#include <stdlib.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <stdio.h>
@@ -27,6 +28,8 @@ struct Rccl {
     // pipelined reduce: the collective of block s runs on comm_stream while the main stream renders s+1
     static constexpr int SLOTS = 4;
     hipEvent_t ev_rendered[SLOTS] = {};
+    hipEvent_t ev_rendered2[SLOTS] = {};      // (the second render stream's, for sh_dist_reduce_bus_lagged)
+    bool       marked[SLOTS] = {};            // sh_dist_mark_slot has recorded the two events for the slot's current contents
     hipEvent_t ev_done[SLOTS] = {};
 };
 
@@ -97,9 +100,20 @@ int sh_dist_init(int rank, int world, const void* id128) {
     r.world = world;
     SH_HIP(hipMalloc((void**)&r.token, sizeof(double)));
     SH_HIP(hipMemsetAsync(r.token, 0, sizeof(double), sh::state().stream));
-    SH_HIP(hipStreamCreateWithFlags(&sh::state().comm_stream, hipStreamNonBlocking));
+    {
+        // The communication stream is created like the render streams.  A stream of another PRIORITY (SYNTHHIP_COMM_PRIORITY = -1
+        // high, 1 low) gets a hardware queue of its own, but with two priority levels active the render launches themselves slow
+        // down (rocprofv3 / tools/ring_probe.py, round 3, 1024 voices, 8 blocks per batch: 59 and 60 us per block against 46 in a
+        // cold single shot); what keeps the exchange off the renders' critical path is WHEN it is enqueued (sh_dist_mark_slot).
+        int lo_prio = 0, hi_prio = 0;
+        SH_HIP(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+        const int want = sh::knobs().comm_priority;
+        if (want == 0) SH_HIP(hipStreamCreateWithFlags(&sh::state().comm_stream, hipStreamNonBlocking));
+        else SH_HIP(hipStreamCreateWithPriority(&sh::state().comm_stream, hipStreamNonBlocking, want < 0 ? hi_prio : lo_prio));
+    }
     for (int k = 0; k < Rccl::SLOTS; ++k) {
         SH_HIP(hipEventCreateWithFlags(&r.ev_rendered[k], hipEventDisableTiming));
+        SH_HIP(hipEventCreateWithFlags(&r.ev_rendered2[k], hipEventDisableTiming));
         SH_HIP(hipEventCreateWithFlags(&r.ev_done[k], hipEventDisableTiming));
     }
     return SH_OK;
@@ -117,6 +131,7 @@ int sh_dist_shutdown(void) {
         r.comm = nullptr;
         for (int k = 0; k < Rccl::SLOTS; ++k) {
             if (r.ev_rendered[k]) { (void)hipEventDestroy(r.ev_rendered[k]); r.ev_rendered[k] = nullptr; }
+            if (r.ev_rendered2[k]) { (void)hipEventDestroy(r.ev_rendered2[k]); r.ev_rendered2[k] = nullptr; }
             if (r.ev_done[k]) { (void)hipEventDestroy(r.ev_done[k]); r.ev_done[k] = nullptr; }
         }
         if (sh::state().comm_stream) { (void)hipStreamDestroy(sh::state().comm_stream); sh::state().comm_stream = nullptr; }
@@ -164,6 +179,7 @@ int sh_dist_reduce_bus_async(sh_buf* bus_f64, size_t nvalues, int root, sh_buf* 
     if (bus_f32 && bus_f32->bytes < nvalues * 4) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_async: bus_f32 too small");
     if (root < 0 || root >= r.world) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_async: bad root");
     if (slot < 0 || slot >= Rccl::SLOTS) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_async: slot %d outside 0..%d", slot, Rccl::SLOTS - 1);
+    r.marked[slot] = false;
     hipStream_t main = sh::state().stream, comm = sh::state().comm_stream;
     SH_HIP(hipEventRecord(r.ev_rendered[slot], main));
     SH_HIP(hipStreamWaitEvent(comm, r.ev_rendered[slot], 0));
@@ -173,6 +189,62 @@ int sh_dist_reduce_bus_async(sh_buf* bus_f64, size_t nvalues, int root, sh_buf* 
         if (rc) return rc;
     }
     SH_HIP(hipEventRecord(r.ev_done[slot], comm));
+    return SH_OK;
+}
+
+// The same in two steps that do not end the run of renders (sh_dist_reduce_bus_async does: SH_REQUIRE_INIT joins the streams
+// and folds what is outstanding -- a pipeline drain per batch, 10 us per block at 8 blocks per batch):
+//   sh_dist_mark_slot, called once the slot's last render lies two launches back in its bank's run -- every partial bus of the
+//     slot has been folded by then (launch n + 2 folds launch n's), on one of the two render streams -- records where both
+//     streams stand;
+//   sh_dist_reduce_bus_lagged, called a few launches LATER, makes the communication stream wait for those two marks and
+//     enqueues the collective.  Later, because the communication stream shares a hardware queue with a render stream (rocprofv3:
+//     the rounding kernel ran in stream2's queue): a wait that is not yet satisfied when the queue reaches it holds up the
+//     renders behind it -- a mark that fired long ago costs nothing.
+// If a fold into the slot's buffer is still owed (the caller did not wait two launches) the reduce IS sh_dist_reduce_bus_async.
+int sh_dist_mark_slot(int slot) {
+    SH_REQUIRE_INIT_KEEP_PENDING();
+    Rccl& r = R();
+    if (!r.comm) return sh::set_error(SH_ERR_RCCL, "sh_dist_mark_slot: sh_dist_init not called");
+    if (slot < 0 || slot >= Rccl::SLOTS) return sh::set_error(SH_ERR_INVALID, "sh_dist_mark_slot: slot %d outside 0..%d", slot, Rccl::SLOTS - 1);
+    SH_HIP(hipEventRecord(r.ev_rendered[slot], sh::state().stream));
+    SH_HIP(hipEventRecord(r.ev_rendered2[slot], sh::state().stream2));
+    r.marked[slot] = true;
+    return SH_OK;
+}
+
+int sh_dist_reduce_bus_lagged(sh_buf* bus_f64, size_t nvalues, int root, sh_buf* bus_f32, int slot) {
+    SH_REQUIRE_INIT_KEEP_PENDING();
+    Rccl& r = R();
+    if (!r.comm) return sh::set_error(SH_ERR_RCCL, "sh_dist_reduce_bus_lagged: sh_dist_init not called");
+    if (!bus_f64 || bus_f64->bytes < nvalues * 8) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_lagged: buffer too small");
+    if (bus_f32 && bus_f32->bytes < nvalues * 4) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_lagged: bus_f32 too small");
+    if (root < 0 || root >= r.world) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_lagged: bad root");
+    if (slot < 0 || slot >= Rccl::SLOTS) return sh::set_error(SH_ERR_INVALID, "sh_dist_reduce_bus_lagged: slot %d outside 0..%d", slot, Rccl::SLOTS - 1);
+    const bool marked = r.marked[slot];
+    r.marked[slot] = false;
+    if (!marked || sh::fold_owed_into(bus_f64->ptr, nvalues * 8) || (bus_f32 && sh::fold_owed_into(bus_f32->ptr, nvalues * 4)))
+        return sh_dist_reduce_bus_async(bus_f64, nvalues, root, bus_f32, slot);
+    hipStream_t comm = sh::state().comm_stream;
+    SH_HIP(hipStreamWaitEvent(comm, r.ev_rendered[slot], 0));
+    SH_HIP(hipStreamWaitEvent(comm, r.ev_rendered2[slot], 0));
+    if (nvalues) SH_RCCL(r.Reduce(bus_f64->ptr, bus_f64->ptr, nvalues, ncclFloat64, ncclSum, root, r.comm, comm));
+    if (r.rank == root && bus_f32) {
+        int rc = sh::bus_finalize_on(comm, (const double*)bus_f64->ptr, nvalues, (float*)bus_f32->ptr);
+        if (rc) return rc;
+    }
+    SH_HIP(hipEventRecord(r.ev_done[slot], comm));
+    return SH_OK;
+}
+
+// sh_dist_wait_slot without ending the run of renders: both render streams wait for the slot's collective.
+int sh_dist_wait_slot_keep(int slot) {
+    SH_REQUIRE_INIT_KEEP_PENDING();
+    Rccl& r = R();
+    if (!r.comm) return sh::set_error(SH_ERR_RCCL, "sh_dist_wait_slot_keep: sh_dist_init not called");
+    if (slot < 0 || slot >= Rccl::SLOTS) return sh::set_error(SH_ERR_INVALID, "sh_dist_wait_slot_keep: bad slot");
+    SH_HIP(hipStreamWaitEvent(sh::state().stream, r.ev_done[slot], 0));    // no-op until the slot has been used
+    SH_HIP(hipStreamWaitEvent(sh::state().stream2, r.ev_done[slot], 0));
     return SH_OK;
 }
 

@@ -124,7 +124,10 @@ int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t la
     if (k < 0) {
         // every other set holds a resolved block (not reachable with the call patterns that keep a run alive; kept safe
         // anyway): an older launch on stream2 may still be filling the one taken here, so order the prepare after it
-        if (in_run && S.aux_busy) SH_HIP(hipStreamWaitEvent(S.stream, S.ev_aux, 0));
+        if (in_run && S.aux_busy) {
+            SH_HIP(hipEventRecord(S.ev_aux, S.stream2));
+            SH_HIP(hipStreamWaitEvent(S.stream, S.ev_aux, 0));
+        }
         for (int c = 0; c < sh_bank::NSETS && k < 0; ++c)
             if (!(in_run && (c == b->cur || c == b->last_target))) k = c;
     }

@@ -50,7 +50,14 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
 #pragma unroll
             for (int j = 0; j < FPL; ++j) x[j] = 0.0;
         } else {
-            voice_block<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, start, tile_last, i, di, fm_cumsum, pwm, trig, x);
+            const double* fm_p = fm_cumsum;
+            const double* pwm_p = pwm;
+            if (B.rows) {                                          // (uniform) a bank with modulation rows: this voice's rows of the launch's matrix
+                const int32_t fr = as_const(B.fm_row)[first + vi], pr = as_const(B.pwm_row)[first + vi];
+                fm_p = fr >= 0 ? B.rows + (size_t)fr * B.row_stride : nullptr;
+                pwm_p = pr >= 0 ? B.rows + (size_t)pr * B.row_stride : nullptr;
+            }
+            voice_block<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, start, tile_last, i, di, fm_p, pwm_p, trig, x);
         }
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
@@ -400,7 +407,8 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
     // frames per lane: 4 for long rows (one sin/cos lookup + three rotations per voice, as in k_bank_render), else 2 / 1
     const int fpl = nframes >= 8192 ? 4 : (nframes >= 2048 ? 2 : 1);
     float* o = (float*)voices_out->ptr;
-    if (fpl == 4 && b->lean_candidates != 0 && b->lean_fm_candidates == 0) {
+    const bool with_rows = b->launch_rows != nullptr;             // sh_bank_generate_rows: every voice through the general kernel, which reads the rows
+    if (!with_rows && fpl == 4 && b->lean_candidates != 0 && b->lean_fm_candidates == 0) {
         // Long rows, every lean candidate a polynomial Harmonics voice: the lean records by the recurrence kernel at sixteen frames
         // per lane, then the general and silent lists -- unless the segment provably has none.  Rows longer than a segment get
         // one record set per segment, all resolved by ONE prepare launch.
@@ -508,7 +516,7 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
 #define SH_GEN(F_) hipLaunchKernelGGL(k_generate<F_>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,            \
                                       ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, \
                                       (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride)
-    if (fpl == 4 && b->lean_candidates != 0) {
+    if (!with_rows && fpl == 4 && b->lean_candidates != 0) {
         // long rows of a bank with lean candidates: one workgroup column per 64-voice chunk, walking the launch's lists
         hipLaunchKernelGGL((k_generate_lists<4, true>), dim3(tile_groups, sh::div_up(b->nvoices, 64)), dim3(256), 0, sh::state().stream,
                            ptrs(b), trig_table(), b->nvoices, launch_set(b, b->cur), start, nframes, o, stride);
@@ -516,6 +524,22 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
 #undef SH_GEN
     SH_CHECK_LAUNCH("k_generate");
     return SH_OK;
+}
+
+int sh_bank_generate_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
+                          sh_buf* voices_out, size_t stride) {
+    if (!b || !rows_f64) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_rows: NULL argument");
+    SH_API_LOCK();                                           // held across sh_bank_generate (recursive): the rows belong to this call
+    if (!b->d_fm_row) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_rows: sh_bank_set_rows has not been called");
+    if (row_stride < nframes) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_rows: row_stride < nframes");
+    if (b->fm_row_max >= 0 && rows_f64->bytes / 8 < (size_t)b->fm_row_max * row_stride + nframes)
+        return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_rows: rows buffer too small for row %d", b->fm_row_max);
+    b->launch_rows = (const double*)rows_f64->ptr;
+    b->launch_row_stride = row_stride;
+    const int rc = sh_bank_generate(b, start, nframes, voices_out, stride);
+    b->launch_rows = nullptr;
+    b->launch_row_stride = 0;
+    return rc;
 }
 
 int sh_bank_generate_f64(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* rows_out, size_t row0, size_t row_stride) {

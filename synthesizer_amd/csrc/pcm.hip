@@ -399,6 +399,67 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_gather_direct(const Ch
     }
 }
 
+// ---- the mixer fold for the other sample widths audioop.add takes (8, 24 and 32 bits) -------------------------------------
+// The reference's loop as it stands -- mixed = clamp(mixed + sample) down the sources, in their order, per output sample --
+// with four consecutive samples per thread and the source table read by scalar loads (uniform).  8-bit and 24-bit samples are
+// assembled from bytes (a 24-bit sample: GETINT24, sign-extended; stored back as its three low bytes), 32-bit sums are taken in
+// 64 bits.  Sources past their end count as silence.  These widths are the mixer's side door -- WAV files that were not
+// converted to 16 bits first -- so the kernel is the plain one; the 16-bit shapes above are the tuned ones.
+struct ChainSrcB {
+    const unsigned char* p;
+    uint32_t n;               // samples available
+    uint32_t pad;
+};
+
+template <int WIDTH>
+__device__ __forceinline__ long long chain_get(const unsigned char* p, size_t i) {
+    if (WIDTH == 1) return (long long)(signed char)p[i];
+    if (WIDTH == 3) {
+        const unsigned char* q = p + 3 * i;
+        return (long long)((int)q[0] | ((int)q[1] << 8) | ((int)(signed char)q[2] << 16));
+    }
+    int v;
+    __builtin_memcpy(&v, p + 4 * i, 4);
+    return (long long)v;
+}
+
+template <int WIDTH>
+__device__ __forceinline__ void chain_put(unsigned char* p, size_t i, long long x) {
+    if (WIDTH == 1) { p[i] = (unsigned char)(signed char)x; return; }
+    if (WIDTH == 3) {
+        unsigned char* q = p + 3 * i;
+        const int v = (int)x;
+        q[0] = (unsigned char)(v & 0xFF); q[1] = (unsigned char)((v >> 8) & 0xFF); q[2] = (unsigned char)((v >> 16) & 0xFF);
+        return;
+    }
+    const int v = (int)x;
+    __builtin_memcpy(p + 4 * i, &v, 4);
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(256) void k_mix_chain_gather_w(const ChainSrcB* __restrict__ tab, uint32_t nsrc, uint32_t nsamples,
+                                                            unsigned char* __restrict__ out) {
+    const size_t s0 = (sh::block_id() * 256 + threadIdx.x) * 4;
+    if (s0 >= nsamples) return;
+    constexpr long long HI = WIDTH == 1 ? 127LL : (WIDTH == 3 ? 8388607LL : 2147483647LL), LO = -HI - 1;
+    long long acc[4] = {0, 0, 0, 0};
+    for (uint32_t v = 0; v < nsrc; ++v) {
+        const unsigned char* p = tab[v].p;
+        const uint32_t n = tab[v].n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = s0 + j;
+            if (i < n) {
+                const long long t = acc[j] + chain_get<WIDTH>(p, i);
+                acc[j] = t > HI ? HI : (t < LO ? LO : t);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (s0 + j < nsamples) chain_put<WIDTH>(out, s0 + j, acc[j]);
+}
+
 // ---- audioop.ratecv / float32 resample ----------------------------------------------------------
 // One thread per output sample (frame m, channel c).  Output m interpolates input frames j-1 and j,
 // j = ceil(m*inrate/outrate), d = j*outrate - m*inrate (rates gcd-reduced): identical index
@@ -1008,6 +1069,63 @@ int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offs
     else hipLaunchKernelGGL(k_mix_chain_gather<2>, grid, dim3(2 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
     SH_CHECK_LAUNCH("k_mix_chain_gather");
     return SH_OK;
+}
+
+int sh_mix_chain_gather(const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
+                        uint32_t nsamples, int width, sh_buf* out, size_t out_sample_off) {
+    if (width == 2) return sh_mix_chain_gather_i16(srcs, sample_offsets, nsamples_each, nsrc, nsamples, out, out_sample_off);
+    SH_REQUIRE_INIT();
+    if (width != 1 && width != 3 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather: width %d not in {1, 2, 3, 4}", width);
+    if (!out || (nsrc && (!srcs || !sample_offsets || !nsamples_each))) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather: NULL argument");
+    if (nsrc > 32768) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather: at most 32768 sources");
+    if (nsamples > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather: at most 2^32 - 65536 samples per call");
+    const size_t w = (size_t)width;
+    if (out_sample_off > out->bytes / w || nsamples > out->bytes / w - out_sample_off)
+        return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather: output range outside buffer");
+    if (!nsamples) return SH_OK;
+    std::vector<ChainSrcB> tab;
+    tab.reserve(nsrc);
+    for (uint32_t v = 0; v < nsrc; ++v) {
+        if (!nsamples_each[v]) continue;                  // silence: the fold's identity
+        if (!srcs[v] || sample_offsets[v] > srcs[v]->bytes / w || nsamples_each[v] > srcs[v]->bytes / w - sample_offsets[v])
+            return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather: source %u range outside its buffer", v);
+        ChainSrcB c;
+        c.p = (const unsigned char*)srcs[v]->ptr + sample_offsets[v] * w;
+        c.n = nsamples_each[v] < nsamples ? nsamples_each[v] : nsamples;
+        c.pad = 0;
+        tab.push_back(c);
+    }
+    hipStream_t st = sh::state().stream;
+    unsigned char* op = (unsigned char*)out->ptr + out_sample_off * w;
+    if (tab.empty()) {
+        SH_HIP(hipMemsetAsync(op, 0, (size_t)nsamples * w, st));
+        return SH_OK;
+    }
+    int rc = sh::ensure_scratch(tab.size() * sizeof(ChainSrcB));
+    if (rc) return rc;
+    SH_HIP(hipMemcpyAsync(sh::state().scratch, tab.data(), tab.size() * sizeof(ChainSrcB), hipMemcpyHostToDevice, st));
+    const uint32_t n = (uint32_t)tab.size();
+    const dim3 grid = sh::grid1d(nsamples, 1024);
+    const ChainSrcB* dt = (const ChainSrcB*)sh::state().scratch;
+    if (width == 1) hipLaunchKernelGGL(k_mix_chain_gather_w<1>, grid, dim3(256), 0, st, dt, n, nsamples, op);
+    else if (width == 3) hipLaunchKernelGGL(k_mix_chain_gather_w<3>, grid, dim3(256), 0, st, dt, n, nsamples, op);
+    else hipLaunchKernelGGL(k_mix_chain_gather_w<4>, grid, dim3(256), 0, st, dt, n, nsamples, op);
+    SH_CHECK_LAUNCH("k_mix_chain_gather_w");
+    return SH_OK;
+}
+
+int sh_mix_chain(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint32_t nsamples, int width, sh_buf* out) {
+    if (width == 2) return sh_mix_chain_i16(chunks, nvoices, stride, nsamples, out);
+    if (!chunks || !out || nvoices == 0) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain: NULL argument");
+    if (nvoices > 32768) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain: at most 32768 voices");
+    if (width != 1 && width != 3 && width != 4) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain: width %d not in {1, 2, 3, 4}", width);
+    if (stride < nsamples || chunks->bytes / (size_t)width < (size_t)(nvoices - 1) * stride + nsamples)
+        return sh::set_error(SH_ERR_INVALID, "sh_mix_chain: chunk buffer too small");
+    std::vector<const sh_buf*> srcs(nvoices, chunks);
+    std::vector<size_t> offs(nvoices);
+    std::vector<uint32_t> lens(nvoices, nsamples);
+    for (uint32_t v = 0; v < nvoices; ++v) offs[v] = (size_t)v * stride;
+    return sh_mix_chain_gather(srcs.data(), offs.data(), lens.data(), nvoices, nsamples, width, out, 0);
 }
 
 size_t sh_resample_out_frames(size_t in_frames, int inrate, int outrate) {

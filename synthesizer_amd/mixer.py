@@ -42,17 +42,19 @@ class _RowMatrix:
     one launch per group (a bank of modulators, sh_bank_generate_f64); anything else -- a modulator that is itself
     modulated by an arbitrary oscillator, a filter graph -- renders into its row on its own."""
 
-    def __init__(self, fm_sources: Sequence[Oscillator], other_sources: Sequence[Oscillator], samplerate: int) -> None:
+    def __init__(self, fm_sources: Sequence[Oscillator], other_sources: Sequence[Oscillator], samplerate: int,
+                 other_roles: Optional[Sequence[str]] = None) -> None:
         self.nfm = len(fm_sources)
         self.nrows = len(fm_sources) + len(other_sources)
         self.samplerate = samplerate
         self.fm_rows: List[int] = []
         self.other_rows: List[int] = []
-        self._banks: List[Tuple[N.Bank, int]] = []              # (bank of closed-form sources, first row)
-        self._singles: List[Tuple[Oscillator, int]] = []        # (source, row)
+        self._banks: List[Tuple[N.Bank, int, bool]] = []        # (bank of closed-form sources, first row, fm rows?)
+        self._singles: List[Tuple[Oscillator, int, str]] = []   # (source, row, "fm" | "pwm" | "voice")
 
-        def place(sources, first_row, out_rows):
+        def place(sources, first_row, out_rows, roles):
             bankable, single = [], []
+            is_fm = roles is None
             for k, m in enumerate(sources):
                 if m.samplerate != samplerate:
                     raise ValueError("a modulator must run at the sample rate of its voice")
@@ -65,18 +67,18 @@ class _RowMatrix:
             rows = [0] * len(sources)
             r = first_row
             if bankable:
-                self._banks.append((N.Bank(*pack_voices([sp for _, _, sp in bankable])), r))
+                self._banks.append((N.Bank(*pack_voices([sp for _, _, sp in bankable])), r, is_fm))
                 for k, _m, _sp in bankable:
                     rows[k] = r
                     r += 1
             for k, m, _sp in single:
                 rows[k] = r
-                self._singles.append((m, r))
+                self._singles.append((m, r, "fm" if is_fm else roles[k]))
                 r += 1
             out_rows.extend(rows)
 
-        place(fm_sources, 0, self.fm_rows)
-        place(other_sources, self.nfm, self.other_rows)
+        place(fm_sources, 0, self.fm_rows, None)
+        place(other_sources, self.nfm, self.other_rows, list(other_roles) if other_roles is not None else ["voice"] * len(other_sources))
         self._buf: Optional[N.DeviceBuffer] = None
         self._stride = 0
         self._carry: Optional[N.DeviceBuffer] = None
@@ -85,12 +87,26 @@ class _RowMatrix:
             self._carry.zero()
         self._pos = 0                                           # the carries hold L(_pos)
 
-    def _render(self, start: int, n: int) -> None:
+    def _render(self, start: int, n: int, fm_only: bool = False) -> None:
+        """Rows of frames [start, start + n).  fm_only: a replay of the running sums on the way to a later block -- only the fm
+        rows carry state from block to block, the others are not touched."""
         L = N.lib()
-        for bank, row0 in self._banks:
-            N.check(L.sh_bank_generate_f64(bank.handle, start, n, self._buf.handle, row0, self._stride))
-        for m, row in self._singles:
-            m._render_device(start, n, out_f64=self._buf.view(row * self._stride * 8, n * 8))
+        for bank, row0, is_fm in self._banks:
+            if is_fm or not fm_only:
+                N.check(L.sh_bank_generate_f64(bank.handle, start, n, self._buf.handle, row0, self._stride))
+        for m, row, role in self._singles:
+            if fm_only and role != "fm":
+                continue
+            # a VOICE that ends (an envelope with stop_at_end over a filter graph, a filter over a finite source) is silent from
+            # there on, like a fused stop_at_end voice of the same bank; a modulator that ends before its carrier is an error,
+            # as upstream (the carrier's next() on it raises)
+            avail = n
+            if role == "voice" and m.length is not None:
+                avail = max(0, min(n, m.length - start))
+            if avail:
+                m._render_device(start, avail, out_f64=self._buf.view(row * self._stride * 8, avail * 8))
+            if avail < n:
+                N.check(L.sh_ew_f64(N.SH_EW_FILL, None, 0, None, 0, n - avail, 0.0, 0.0, self._buf.handle, row * self._stride + avail, None, 0, None))
         if self.nfm:
             N.check(L.sh_scan_rows_f64(self._buf.handle, 0, self.nfm, n, self._stride, self._carry.handle))
             self._pos = start + n
@@ -104,7 +120,7 @@ class _RowMatrix:
                 self._carry.zero()
                 self._pos = 0
             while self._pos < start:
-                self._render(self._pos, min(self._stride, start - self._pos))
+                self._render(self._pos, min(self._stride, start - self._pos), fm_only=True)
         self._render(start, n)
         return self._buf, self._stride
 
@@ -155,7 +171,8 @@ class VoiceBank:
         if fm_src or other_src:
             fm_row = np.full(self.nvoices, -1, dtype=np.int32)
             pwm_row = np.full(self.nvoices, -1, dtype=np.int32)
-            self._rows = _RowMatrix([m for _, m in fm_src], [m for _, _, m in other_src], self.samplerate)
+            self._rows = _RowMatrix([m for _, m in fm_src], [m for _, _, m in other_src], self.samplerate,
+                                    other_roles=[what for what, _, _ in other_src])
             for (i, _m), r in zip(fm_src, self._rows.fm_rows):
                 fm_row[i] = r
             for (what, i, _m), r in zip(other_src, self._rows.other_rows):
@@ -216,11 +233,14 @@ class VoiceBank:
                         stride: Optional[int] = None) -> N.DeviceBuffer:
         """Every voice as float32 PCM in HBM, voice-major: out[v*stride + i]."""
         stride = nframes if stride is None else stride
-        if self._rows is not None:
-            raise NotImplementedError("voices modulated by arbitrary oscillators (or rendered from filter graphs) take the fused "
-                                      "render; materialise such a voice with Oscillator.render")
         if out is None:
             out = N.DeviceBuffer(self.nvoices * stride * 4)
+        if self._rows is not None and nframes:
+            # voices that read rows of the launch's float64 matrix (arbitrary fm_lfo / pwm_lfo, filter graphs): the same matrix
+            # the fused render fills, read by the general materialisation kernel
+            rows, rstride = self._rows.fill(start, nframes)
+            N.check(N.lib().sh_bank_generate_rows(self._bank.handle, start, nframes, rows.handle, rstride, out.handle, stride))
+            return out
         N.check(N.lib().sh_bank_generate(self._bank.handle, start, nframes, out.handle, stride))
         return out
 
@@ -268,13 +288,15 @@ def mix_bus(voices: np.ndarray, gains: Sequence[Tuple[float, float]]) -> np.ndar
     return out
 
 
-def _gather_i16(sources: Sequence[Tuple[N.DeviceBuffer, int, int]], nsamples: int, out: N.DeviceBuffer, out_sample_off: int = 0) -> None:
-    """out[out_sample_off : +nsamples] = ordered saturating fold of (buffer, first sample, samples available) sources."""
+def _gather(sources: Sequence[Tuple[N.DeviceBuffer, int, int]], nsamples: int, out: N.DeviceBuffer, width: int = 2,
+            out_sample_off: int = 0) -> None:
+    """out[out_sample_off : +nsamples] = ordered saturating fold of (buffer, first sample, samples available) sources of
+    `width`-byte samples: mixed = audioop.add(mixed, chunk, width) down the list."""
     n = len(sources)
     bufs = (C.c_void_p * max(n, 1))(*[b.handle for b, _o, _n in sources])
     offs = (C.c_size_t * max(n, 1))(*[o for _b, o, _n in sources])
     lens = (C.c_uint32 * max(n, 1))(*[min(k, 0xFFFFFFFF) for _b, _o, k in sources])
-    N.check(N.lib().sh_mix_chain_gather_i16(bufs, offs, lens, n, nsamples, out.handle, out_sample_off))
+    N.check(N.lib().sh_mix_chain_gather(bufs, offs, lens, n, nsamples, width, out.handle, out_sample_off))
 
 
 def mix_samples(samples: Sequence[Sample], name: str = "mix") -> Sample:
@@ -290,24 +312,10 @@ def mix_samples(samples: Sequence[Sample], name: str = "mix") -> Sample:
     out = Sample(name=name, samplerate=first.samplerate, nchannels=first.nchannels, samplewidth=width)
     if nbytes == 0:
         return out
-    L = N.lib()
-    if width == 2:
-        nsamples = nbytes // 2
-        dst = N.DeviceBuffer(nbytes)
-        _gather_i16([(s._device(), 0, len(s) * s.nchannels) for s in samples], nsamples, dst)
-        out._set_device(dst, nbytes)
-        return out
-    # other widths: the literal chain of pairwise saturating adds
-    acc = N.DeviceBuffer(nbytes)
-    acc.zero()
-    n0 = len(first) * width * first.nchannels
-    if n0:
-        N.check(L.sh_buf_copy(acc.handle, 0, first._device().handle, 0, n0))
-    for s in samples[1:]:
-        n = len(s) * width * s.nchannels
-        if n:
-            N.check(L.sh_pcm_add(acc.handle, 0, s._device().handle, 0, n, width, acc.handle, 0))
-    out._set_device(acc, nbytes)
+    nsamples = nbytes // width
+    dst = N.DeviceBuffer(nbytes)
+    _gather([(s._device(), 0, len(s) * s.nchannels) for s in samples], nsamples, dst, width)
+    out._set_device(dst, nbytes)
     return out
 
 
@@ -328,8 +336,8 @@ class RealTimeMixer:
     """Real-time sample mixer: samples play from the moment they are added; every turn of ``chunks()`` yields
     ``chunksize`` bytes, the saturating sum -- in the order the samples were added -- of the current chunk of every
     active sample.  A sample that ran out is dropped (``all_played_callback`` fires when the last one goes); with
-    nothing playing the mixer yields silence.  Samples must be in the mixer's format (16-bit by default: the fold
-    kernel is the int16 one).  Mirrors upstream ``synthplayer/playback.py`` ``RealTimeMixer`` ([RECALL], tree not
+    nothing playing the mixer yields silence.  Samples must be in the mixer's format (``samplewidth`` bytes per sample, 16-bit
+    by default; 8-, 24- and 32-bit mixers fold with the same rule, ``audioop.add(mixed, chunk, samplewidth)``).  Mirrors upstream ``synthplayer/playback.py`` ``RealTimeMixer`` ([RECALL], tree not
     mounted): ``add_sample`` / ``remove_sample`` / ``clear_sources`` / ``chunks``.
 
     The PCM stays in HBM: ``add_sample`` uploads (or reuses the resident buffer of) the sample once, a chunk turn is
@@ -337,11 +345,12 @@ class RealTimeMixer:
     buffer instead, for a consumer that keeps going on the GPU (level metering, resampling)."""
 
     def __init__(self, chunksize: int, all_played_callback: Optional[Callable[[], None]] = None, samplewidth: int = 2) -> None:
-        if samplewidth != 2:
-            raise NotImplementedError("the mixer folds 16-bit chunks")
-        if chunksize <= 0 or chunksize % 2:
+        if samplewidth not in (1, 2, 3, 4):
+            raise ValueError("samplewidth must be 1, 2, 3 or 4")
+        if chunksize <= 0 or chunksize % samplewidth:
             raise ValueError("chunksize must be a positive whole number of samples")
         self.chunksize = chunksize
+        self.samplewidth = samplewidth
         self.all_played_callback = all_played_callback or (lambda: None)
         self.add_lock = threading.Lock()
         self.chunks_mixed = 0
@@ -351,8 +360,8 @@ class RealTimeMixer:
 
     def add_sample(self, sample: Sample, repeat: bool = False, chunk_delay: int = 0, sid: Optional[int] = None) -> int:
         """Start playing a sample; returns its id.  ``repeat`` loops it forever, ``chunk_delay`` holds it back."""
-        if sample.samplewidth != 2:
-            raise ValueError("sample width must be 2")
+        if sample.samplewidth != self.samplewidth:
+            raise ValueError("sample width must be %d" % self.samplewidth)
         nbytes = len(sample) * sample.samplewidth * sample.nchannels
         if repeat and nbytes:
             # upstream: data repeated up to at least one chunk, then one more chunk of its start appended
@@ -394,12 +403,13 @@ class RealTimeMixer:
             if src.delay > 0:
                 src.delay -= 1
                 continue
+            w = self.samplewidth
             if src.loop_bytes:
-                sources.append((src.buf, src.pos // 2, self.chunksize // 2))
+                sources.append((src.buf, src.pos // w, self.chunksize // w))
                 src.pos = (src.pos + self.chunksize) % src.loop_bytes
             elif src.pos < src.nbytes:
                 n = min(self.chunksize, src.nbytes - src.pos)
-                sources.append((src.buf, src.pos // 2, n // 2))
+                sources.append((src.buf, src.pos // w, n // w))
                 src.pos += self.chunksize
             else:
                 finished.append(sid)
@@ -411,7 +421,7 @@ class RealTimeMixer:
             if empty:
                 self.all_played_callback()
         out = self._out[self.chunks_mixed & 1]
-        _gather_i16(sources, self.chunksize // 2, out)
+        _gather(sources, self.chunksize // self.samplewidth, out, self.samplewidth)
         self.chunks_mixed += 1
         return out
 

@@ -37,6 +37,12 @@ __all__ = ["Oscillator", "Sine", "Triangle", "Sawtooth", "Square", "Pulse", "Har
            "NullFilter", "DelayFilter", "EchoFilter"]
 
 _SUPERBLOCK = 128          # blocks rendered per kernel launch behind blocks()
+
+
+class _SourceExhausted(RuntimeError):
+    """The source of an envelope ended inside the envelope's phases: upstream's generator ends with next()'s StopIteration,
+    which Python (PEP 479) hands to the consumer as RuntimeError("generator raised StopIteration").  A class of its own so
+    that blocks() can tell it from a device error (SynthHipError is a RuntimeError too)."""
 _DENSE_MAX_K = 4096        # Harmonics: use the Clenshaw (dense) form when max k <= min(this, 8*len+64)
 
 
@@ -368,19 +374,21 @@ class Oscillator:
         bs = params.norm_osc_blocksize
         pos = 0
         limit = self.length
+        single = False                                         # fell back to one block per launch
         while True:
-            want = bs * _SUPERBLOCK
+            want = bs if single else bs * _SUPERBLOCK
             if limit is not None:
                 want = min(want, limit - pos)
                 if want <= 0:
                     return
             try:
                 chunk = self.render_f64(want, start=pos)       # float64, like upstream's Python floats
-            except RuntimeError:
+            except _SourceExhausted:
                 # a source that ends inside an envelope's phases (see EnvelopeFilter): upstream delivers every block before
                 # the one that needs the missing sample -- go on block by block until that one raises
                 if want <= bs:
                     raise
+                single = True
                 chunk = self.render_f64(bs, start=pos)
             pos += len(chunk)
             values = chunk.tolist()
@@ -672,7 +680,7 @@ class EnvelopeFilter(Oscillator):
         n_src = max(0, min(start + n, phases) - start)
         src_len = self._source.length
         if src_len is not None and n_src and start + n_src > src_len:
-            raise RuntimeError("generator raised StopIteration")
+            raise _SourceExhausted("generator raised StopIteration")
         gain = self._gain._render_f64_device(start, n)               # exactly 0.0 from the end of the phases on
         if n_src:
             src = self._source._render_f64_device(start, n_src)

@@ -63,8 +63,45 @@ def test_bank_with_arbitrary_modulators_and_filter_voices(gpu):
     pcm = bank.render_sample(2000).get_frames_numpy()
     ref = np.clip(np.trunc(32767.0 * bank.render(2000).astype(np.float64)), -32768, 32767).astype(np.int16)
     assert np.array_equal(pcm, ref)
-    with pytest.raises(NotImplementedError):
-        bank.generate(100)
+    # the reference-shaped two-step route for such a bank: every voice as a float32 row (the general materialisation kernel reads
+    # the same matrix of rows), then the HBM-bound mix -- rows equal the voices rendered one by one, the mix equals the fused bus
+    rows = bank.generate(n)
+    assert rows.shape == (len(gv), n)
+    for i, v in enumerate(_voices(G)):
+        one = v.render(n, start=0)
+        assert np.max(np.abs(rows[i] - one)) < 1.5e-7, i
+    two = bank.render_two_step(n)
+    assert rms(two, want[:n]) <= RMS_TOL
+    late = bank.generate(500, start=n)                # rows that start inside the running sums
+    for i, ov_ in enumerate(_voices(O)):
+        assert np.max(np.abs(late[i] - np.array(ov_.take(n + 500)[n:], dtype=np.float32))) < 2e-7, i
+
+
+def test_voices_that_end_inside_a_bank_go_silent(gpu):
+    """A voice that is no single record (an envelope with stop_at_end over a filter graph) and ends: from there on it is
+    silent, like a fused stop_at_end voice beside it -- a block that straddles its end is zero-padded, a block past it renders
+    (such a bank could not be rendered past that voice's end)."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+
+    def build(m):
+        return [m.EnvelopeFilter(m.MixingFilter(m.Sine(600.0, 0.2, samplerate=SR), m.Square(300.0, 0.1, samplerate=SR)),
+                                 0.01, 0.02, 0.03, 0.6, 0.02, stop_at_end=True),            # 3841 samples, rendered into a row
+                m.EnvelopeFilter(m.Sine(440.0, 0.3, samplerate=SR), 0.01, 0.01, 0.02, 0.5, 0.02, stop_at_end=True),   # fused, 2881 samples
+                m.Sine(220.0, 0.2, samplerate=SR)]
+    gv, ov = build(G), build(O)
+    gains = [(0.5, 0.25), (0.25, 0.5), (0.5, 0.5)]
+    bank = VoiceBank(gv, gains=gains)
+    n = 6000
+    rows = []
+    for v in ov:
+        x = v.take(n)
+        rows.append(list(x) + [0.0] * (n - len(x)))
+    want = np.array(O.mix_bus(rows, gains), dtype=np.float64)
+    assert len(ov[0].take(n)) < 4000 < n
+    assert rms(bank.render(n), want) <= RMS_TOL                       # one block over both ends
+    assert rms(bank.render(1000, start=3500), want[3500:4500]) <= RMS_TOL     # straddles the row voice's end
+    assert rms(bank.render(1000, start=5000), want[5000:]) <= RMS_TOL         # past it
 
 
 def test_large_bank_with_modulated_voices_among_lean_ones(gpu):

@@ -102,8 +102,10 @@ def test_mixer_argument_checks(gpu):
     from synthesizer_amd.sample import Sample
     with pytest.raises(ValueError):
         RealTimeMixer(0)
-    with pytest.raises(NotImplementedError):
-        RealTimeMixer(512, samplewidth=4)
+    with pytest.raises(ValueError):
+        RealTimeMixer(512, samplewidth=5)
+    with pytest.raises(ValueError):
+        RealTimeMixer(514, samplewidth=4)            # not a whole number of 32-bit samples
     with pytest.raises(ValueError):
         RealTimeMixer(512).add_sample(Sample.from_raw_frames(bytes(16), 4, 8000, 1))
 
@@ -196,3 +198,59 @@ def test_long_buffers_every_kernel_shape(gpu, nsamples):
     cnt = (C.c_uint32 * 2)(len(ragged[0]), len(ragged[1]))
     N.check(N.lib().sh_mix_chain_gather_i16(bufs, offs, cnt, 2, nsamples, out.handle, 0))
     assert out.download_bytes(nsamples * 2) == _audioop_fold(ragged[:2], nsamples)
+
+
+def _rand_pcm(rng, nsamples, width, scale=1.0):
+    """nsamples random samples of `width` bytes, little endian, loud enough to saturate sums."""
+    bits = 8 * width
+    x = (rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), nsamples) * scale).astype(np.int64)
+    if width == 3:
+        b = np.zeros((nsamples, 3), dtype=np.uint8)
+        u = x & 0xFFFFFF
+        b[:, 0], b[:, 1], b[:, 2] = u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF
+        return b.tobytes()
+    return x.astype({1: np.int8, 2: np.int16, 4: np.int32}[width]).tobytes()
+
+
+@pytest.mark.parametrize("width", [1, 2, 3, 4])
+def test_mixer_of_every_sample_width(gpu, width):
+    """a11 for the widths audioop.add takes: RealTimeMixer(samplewidth=w) chunk for chunk against the oracle's loop of
+    audioop.add(mixed, chunk, w), mix_samples against the same fold over whole samples, and the strided entry point
+    (sh_mix_chain) against a loop of live audioop.add."""
+    import audioop
+    from synthesizer_amd import _native as N
+    from synthesizer_amd.mixer import RealTimeMixer, mix_samples
+    from synthesizer_amd.sample import Sample
+    rng = np.random.default_rng(100 + width)
+    chunksize = 1200 * width
+    mixer, ref = RealTimeMixer(chunksize, samplewidth=width), RefRealTimeMixer(chunksize, samplewidth=width)
+    raws = []
+    for n, scale, repeat, delay in [(3000, 1.0, False, 0), (9001, 0.6, False, 2), (257, 1.0, True, 0), (5000, 0.7, False, 1),
+                                    (600, 1.0, False, 0), (7, 1.0, True, 1), (0, 1.0, False, 0)]:
+        raw = _rand_pcm(rng, n, width, scale)
+        raws.append(raw)
+        s = Sample.from_raw_frames(raw, width, 8000, 1)
+        assert mixer.add_sample(s, repeat=repeat, chunk_delay=delay) == ref.add_sample(RefSample(raw, width, 8000, 1), repeat=repeat, chunk_delay=delay)
+    got, want = mixer.chunks(), ref.chunks()
+    for turn in range(10):
+        a, b = bytes(next(got)), next(want)
+        assert len(a) == chunksize and a == b, "width %d turn %d" % (width, turn)
+    with pytest.raises(ValueError):
+        mixer.add_sample(Sample.from_raw_frames(_rand_pcm(rng, 10, 2 if width != 2 else 1), 2 if width != 2 else 1, 8000, 1))
+    # whole samples: pad with silence to the longest, fold in order
+    samples = [Sample.from_raw_frames(r, width, 8000, 1) for r in raws[:5]]
+    longest = max(len(r) for r in raws[:5])
+    acc = raws[0] + bytes(longest - len(raws[0]))
+    for r in raws[1:5]:
+        acc = audioop.add(acc, r + bytes(longest - len(r)), width)
+    assert bytes(mix_samples(samples).view_frame_data()) == acc
+    # the strided form: nv rows of one buffer
+    nv, ns = 37, 5003
+    rows = [_rand_pcm(rng, ns, width, 0.2) for _ in range(nv)]
+    buf = N.DeviceBuffer.from_bytes(b"".join(rows))
+    out = N.DeviceBuffer(ns * width)
+    N.check(N.lib().sh_mix_chain(buf.handle, nv, ns, ns, width, out.handle))
+    acc = rows[0]
+    for r in rows[1:]:
+        acc = audioop.add(acc, r, width)
+    assert out.download_bytes(ns * width) == acc

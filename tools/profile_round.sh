@@ -24,5 +24,17 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INST
     --output-format csv -d "$D" -o sq1 -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES \
     --output-format csv -d "$D" -o sq2 -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
+# the other BASELINE configs that fit one GPU, each in passes of its own (bench.py --only-config: that config's steady-state loop
+# and nothing else), so that its kernels' durations and counters are not averaged with the headline's launches of the same kernel
+for CFG in config2 config3; do
+  CMD="python bench.py --only-config $CFG"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o ${CFG}_stats -- $CMD > gpurun_out/prof_${TAG}_${CFG}.json 2>> gpurun_out/prof_${TAG}_stats.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$D" -o ${CFG}_fetch -- $CMD > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$D" -o ${CFG}_write -- $CMD > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_WAVES SQ_WAVE_CYCLES \
+      --output-format csv -d "$D" -o ${CFG}_sq1 -- $CMD > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES \
+      --output-format csv -d "$D" -o ${CFG}_sq2 -- $CMD > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
+done
 rm -f "$D"/*_kernel_trace.csv "$D"/*_domain_stats.csv          # large; the stats and counter tables are what is summarised
 ls -la "$D"

@@ -69,14 +69,14 @@ if serial.exists():
         (out / ("%s_bench_serial_under_rocprof.json" % tag)).write_text(_json.dumps(sb) + "\n")
 
 
-def counters(fname):
+def counters(fname, prefix=""):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
     p = src / fname
     if not p.exists():
         return agg, meta
     for r in csv.DictReader(open(p)):
-        k = short(r["Kernel_Name"])
+        k = prefix + short(r["Kernel_Name"])
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"])
     return agg, meta
@@ -109,10 +109,56 @@ for fname, title in (("sq1_counter_collection.csv", "SQ instruction mix"), ("sq2
         for cn, v in sorted(agg[k].items()):
             lines.append("| %s | %.0f |" % (cn, sum(v) / len(v)))
         lines.append("")
+# ---- the other BASELINE configs: passes of their own (bench.py --only-config), keys "configN:<kernel>" ----
+import json
+cfg_traffic, cfg_counters = {}, {}
+for cfg in ("config2", "config3"):
+    st = src / ("%s_stats_kernel_stats.csv" % cfg)
+    if not st.exists():
+        continue
+    shutil.copy(st, out / ("%s_%s_kernel_stats.csv" % (tag, cfg)))
+    row_json = src.parent / ("%s_%s.json" % (src.name, cfg))
+    row = None
+    try:
+        row = json.loads([l for l in row_json.read_text().splitlines() if l.startswith("{")][-1])
+    except Exception:
+        pass
+    lines += ["", "## %s: `rocprofv3 ... -- python bench.py --only-config %s`" % (cfg, cfg), ""]
+    if row:
+        for name, r in row.get("configs", {}).items():
+            if "ms_per_1s_block" in r:
+                lines.append("bench row under rocprofv3: **%s** %.2f us per 1-s block (HIP events), host enqueue %.1f us per block" %
+                             (name, r["ms_per_1s_block"] * 1e3, r.get("host_enqueue_us_per_block", float("nan"))))
+        lines.append("")
+    lines += ["| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(st)):
+        lines.append("| %s | %s | %.1f | %.1f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                               float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    cf, _ = counters("%s_fetch_counter_collection.csv" % cfg)
+    cw, _ = counters("%s_write_counter_collection.csv" % cfg)
+    lines += ["", "| kernel | read MB (FETCH_SIZE x2) | write MB |", "|---|---|---|"]
+    for k in sorted(set(cf) | set(cw)):
+        if not k.startswith("k_"):
+            continue
+        fv, wv = cf[k].get("FETCH_SIZE", [0]), cw[k].get("WRITE_SIZE", [0])
+        fa, wa = sum(fv) / len(fv), sum(wv) / len(wv)
+        lines.append("| %s | %.2f | %.2f |" % (k, fa * 1024 * 2 / 1e6, wa * 1024 / 1e6))
+        cfg_traffic["%s:%s" % (cfg, k)] = {"fetch_size_kib_raw": fa, "write_size_kib": wa, "read_bytes_corrected_x2": fa * 1024 * 2,
+                                           "write_bytes": wa * 1024, "hbm_bytes": fa * 1024 * 2 + wa * 1024}
+    for fname in ("%s_sq1_counter_collection.csv" % cfg, "%s_sq2_counter_collection.csv" % cfg):
+        agg, meta = counters(fname)
+        for k in sorted(agg):
+            if not k.startswith("k_bank_render"):
+                continue
+            cfg_counters.setdefault("%s:%s" % (cfg, k), {}).update({cn: sum(v) / len(v) for cn, v in agg[k].items()})
+    for k in sorted(cfg_counters):
+        if k.startswith(cfg + ":"):
+            lines += ["", "**%s**" % k, "", "| counter | value |", "|---|---|"]
+            for cn, v in sorted(cfg_counters[k].items()):
+                lines.append("| %s | %.0f |" % (cn, v))
 (out / ("%s_summary.md" % tag)).write_text("\n".join(lines) + "\n")
 # machine-readable traffic per dispatch (bytes), read by bench.py for roofline.traffic
-import json
-traffic = {}
+traffic = dict(cfg_traffic)
 for k in sorted(set(f) | set(w)):
     if not k.startswith("k_"):
         continue
@@ -125,7 +171,7 @@ for k in sorted(set(f) | set(w)):
 (out / ("%s_traffic.json" % tag)).write_text(json.dumps(traffic, indent=1) + "\n")
 # machine-readable SQ counters per dispatch (averages), read by bench.py for the float64 lane-ops per voice-sample;
 # _meta.source_hash = hash of the kernel sources the profiled library was built from (tools/profile_round.sh records it)
-allc = {}
+allc = dict(cfg_counters)
 for fname in ("sq1_counter_collection.csv", "sq2_counter_collection.csv"):
     agg, _m = counters(fname)
     for k, cs in agg.items():
