@@ -124,6 +124,10 @@ typedef struct sh_voice {
     uint64_t noise_seed;
     uint32_t noise_hold;       /* samples per held value, >= 1: int(samplerate / frequency) */
     uint32_t reserved0;
+    /* Onset: the voice is silent in frames n < start_frame and plays its sample n - start_frame from there (phase tables,
+     * envelope boundaries, FM sums and noise counters all count from the onset): upstream's DelayFilter(voice, seconds) with
+     * seconds >= 0, start_frame = int(samplerate * seconds), fused into the voice.  0 for voices that read rows. */
+    uint64_t start_frame;
 } sh_voice;
 
 typedef struct sh_devinfo {

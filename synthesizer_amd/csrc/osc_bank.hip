@@ -247,6 +247,9 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             return sh::set_error(SH_ERR_INVALID, "voice %u: noise_hold must be >= 1", i);
         if ((v.kind == SH_NOISE || v.kind == SH_LINEAR || v.kind == SH_BUFFER) && v.fm_mode != SH_FM_NONE)
             return sh::set_error(SH_ERR_INVALID, "voice %u: kind %d has no FM form", i, v.kind);
+        if (v.start_frame && (v.kind == SH_BUFFER || v.fm_mode == SH_FM_BUFFER))
+            return sh::set_error(SH_ERR_INVALID, "voice %u: a voice that reads a row of the launch's matrix cannot have an onset (delay its sources)", i);
+        if (v.start_frame > (1ull << 62)) return sh::set_error(SH_ERR_INVALID, "voice %u: start_frame beyond 2^62", i);
         if (v.fm_mode < SH_FM_NONE || v.fm_mode > SH_FM_BUFFER)
             return sh::set_error(SH_ERR_INVALID, "voice %u: unknown fm_mode %d", i, v.fm_mode);
         uint32_t off = v.fm_mode ? v.time_seg_offset : v.seg_offset;
@@ -281,16 +284,20 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             b->lean_candidates += 1;
             if (voices[i].kind != SH_HARMONICS) b->lean_fm_candidates += 1;       // needs the kernel with all record kinds
         }
+    for (uint32_t i = 0; i < nvoices; ++i)
+        if (voices[i].start_frame) b->has_onsets = true;
     {
         b->all_lean = b->lean_candidates == nvoices;
         for (uint32_t i = 0; i < nvoices && b->all_lean; ++i) {
             const sh_voice& v = voices[i];
+            const uint64_t on = v.start_frame;               // (absolute frames: the voice's own boundaries + its onset)
+            if (on > b->env_flat_from) b->env_flat_from = on;     // a launch in front of or across an onset is not "all voices on their sustain"
             if (v.env.enabled) {
-                if (v.env.n_decay_end > b->env_flat_from) b->env_flat_from = v.env.n_decay_end;
-                if (v.env.n_attack_end > b->env_flat_from) b->env_flat_from = v.env.n_attack_end;
-                if (v.env.n_sustain_end < b->env_flat_until) b->env_flat_until = v.env.n_sustain_end;
+                if (v.env.n_decay_end + on > b->env_flat_from) b->env_flat_from = v.env.n_decay_end + on;
+                if (v.env.n_attack_end + on > b->env_flat_from) b->env_flat_from = v.env.n_attack_end + on;
+                if (v.env.n_sustain_end + on < b->env_flat_until) b->env_flat_until = v.env.n_sustain_end + on;
                 if (b->env_corners.size() <= 16) {
-                    for (uint64_t c : {v.env.n_attack_end, v.env.n_decay_end, v.env.n_sustain_end, v.env.n_release_end, v.env.n_release_end + 1})
+                    for (uint64_t c : {on, v.env.n_attack_end + on, v.env.n_decay_end + on, v.env.n_sustain_end + on, v.env.n_release_end + on, v.env.n_release_end + on + 1})
                         if (c && std::find(b->env_corners.begin(), b->env_corners.end(), c) == b->env_corners.end()) b->env_corners.push_back(c);
                 }
             }
@@ -299,7 +306,7 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
                 const uint64_t a = segs[toff + k].n0, e = segs[toff + k + 1].n0;
                 const uint64_t len = e - a;
                 for (int q = 0; q < 34; ++q)
-                    if (len < (1ull << q) && e > b->short_piece_end[q]) b->short_piece_end[q] = e;
+                    if (len < (1ull << q) && e + on > b->short_piece_end[q]) b->short_piece_end[q] = e + on;
             }
         }
     }
@@ -413,6 +420,7 @@ int sh_bank_set_rows(sh_bank* b, const int32_t* fm_row, const int32_t* pwm_row) 
         if ((v.fm_mode == SH_FM_BUFFER || v.kind == SH_BUFFER) && fm_row[i] < 0)
             return sh::set_error(SH_ERR_INVALID, "sh_bank_set_rows: voice %u (SH_FM_BUFFER / SH_BUFFER) needs a row", i);
         if (pwm_row[i] >= 0 && v.kind != SH_PULSE) return sh::set_error(SH_ERR_INVALID, "sh_bank_set_rows: voice %u has a pwm row but is no Pulse", i);
+        if (pwm_row[i] >= 0 && v.start_frame) return sh::set_error(SH_ERR_INVALID, "sh_bank_set_rows: voice %u has an onset and cannot read a row", i);
     }
     hipStream_t st = sh::state().stream;
     if (!b->d_fm_row) {

@@ -75,7 +75,7 @@ __device__ __forceinline__ const T SH_CONST_AS* as_const(const T* p) {
 // index i = n - start.  The scalar unit (one per CU) is the scarce resource of these kernels, so the
 // record is laid out to cost the hot path one batch of loads and almost no scalar arithmetic.
 constexpr uint32_t FL_KIND = 0xF, FL_FM_SHIFT = 4, FL_FM = 0x30, FL_DENSE = 0x40, FL_ENV_UNIFORM = 0x80,
-                   FL_POLY = 0x100, FL_FOLDED = 0x200, FL_FLIP = 0x400, FL_SILENT = 0x800;
+                   FL_POLY = 0x100, FL_FOLDED = 0x200, FL_FLIP = 0x400, FL_SILENT = 0x800, FL_ONSET = 0x1000;
 constexpr uint32_t NO_TAIL = 0xFFFFFFFFu;
 constexpr int NXP = 12;                             // following phase-table pieces a launch record lists
 
@@ -105,8 +105,14 @@ struct alignas(16) VoiceLaunch {
     // phase sum): piece k (table index seg+1+k) holds the frames [nx_start(k), nx_end[k]), nx_start(0) = remain,
     // nx_start(k) = nx_end[k-1]; there t = fma(i - nx_start(k), dt, t0) with the piece's (t0, dt) from the table
     uint32_t nx_end[NXP];
+    // a voice with an onset (sh_voice::start_frame): everything above is relative to the VOICE's sample index.  start_rel = the
+    // voice's index at the launch's first frame it sounds in; onset_i > 0 only in the one launch that holds the onset: the voice
+    // is silent in frames i < onset_i and its sample index there is i - onset_i (start_rel = 0)
+    uint64_t start_rel;
+    uint32_t onset_i;
+    uint32_t pad_;
 };
-static_assert(sizeof(VoiceLaunch) == 384, "VoiceLaunch layout");
+static_assert(sizeof(VoiceLaunch) == 400, "VoiceLaunch layout");
 
 struct alignas(16) VoiceFM {      // only read for FM voices
     double frequency, phase0, f_inc;      // theta = frequency*T + fma(f_inc, L, phase0)
@@ -183,209 +189,10 @@ struct PrepInfo {                 // what prepare_voice found, for the classific
     double   poly[16];            // FL_POLY: the coefficients (read once, with the table pieces; the lean record is written from here)
 };
 
-#ifdef SH_OLD_PREPARE
 // SLOPED (the record sets of a segmented transition launch): a polynomial-Harmonics voice on ONE envelope line of any slope is
 // lean too -- its record carries the line folded into the bus gains (gain + i * slope) -- not only one on a constant gain.
 template <bool SLOPED = false>
-__device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first, uint32_t vi, uint64_t start, uint32_t nframes,
-                                              VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm, PrepInfo& info) {
-    // Fields are stored straight to the record (no local struct: a 368-byte private array would give
-    // every wave of the render kernel a scratch allocation).
-    const sh_voice& v = B.voices[first + vi];
-    VoiceLaunch* __restrict__ o = out + vi;
-    const bool fm = v.fm_mode != SH_FM_NONE;
-    const uint32_t off = fm ? v.time_seg_offset : v.seg_offset;
-    const uint32_t cnt = fm ? v.time_seg_count : v.seg_count;
-    const sh_segment* tab = B.segs + off;
-    uint32_t lo = B.hint[first + vi];
-    if (lo < cnt && tab[lo].n0 <= start && lo + 2 < cnt && start < tab[lo + 2].n0) {
-        if (start >= tab[lo + 1].n0) ++lo;                     // streaming: still on the piece, or on the next one
-    } else {
-        lo = 0;
-        uint32_t hi = cnt - 1;
-        while (lo < hi) {
-            uint32_t mid = (lo + hi + 1) >> 1;
-            if (tab[mid].n0 <= start) lo = mid; else hi = mid - 1;
-        }
-    }
-    B.hint[first + vi] = lo;
-    const double dt = tab[lo].dt;
-    const double t_base = fma((double)(start - tab[lo].n0), dt, tab[lo].t0);
-    const uint64_t rem = (lo + 1 < cnt) ? (tab[lo + 1].n0 - start) : 0xFFFFFFFFull;
-    o->t_base = t_base;
-    o->dt = dt;
-    o->remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
-    o->seg = lo;
-    {
-        uint32_t count = 0;
-        uint64_t piece_start = rem;                           // launch-relative first frame of the next piece
-#pragma unroll 1
-        for (int k = 0; k < NXP; ++k) {
-            const uint32_t pi = lo + 1 + k;
-            uint32_t end = 0xFFFFFFFFu;
-            if (count == (uint32_t)k && pi < cnt && piece_start < (uint64_t)nframes) {      // still inside the launch
-                const uint64_t e = (pi + 1 < cnt) ? (tab[pi + 1].n0 - start) : 0xFFFFFFFFull;
-                end = e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
-                piece_start = e;
-                count = (uint32_t)k + 1;
-            }
-            o->nx_end[k] = end;
-        }
-        o->nx_count = count;
-    }
-    uint32_t flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
-                     (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u) | (v.flip ? FL_FLIP : 0u);
-    const double* harm = v.harm_dense ? (B.coefs + v.harm_offset) : reinterpret_cast<const double*>(B.partials + v.harm_offset);
-    o->harm = harm;
-    o->harm_cnt = v.harm_count;
-    o->amplitude = v.amplitude;
-    o->bias = v.bias;
-    o->pulsewidth = v.pulsewidth;
-    double gain_l = (double)v.gain_l, gain_r = (double)v.gain_r;
-    // envelope as four lines in the launch-relative frame index
-    uint32_t eb0, eb1, eb2, eb3, tail_i = NO_TAIL;
-    double g00, g01, g02, g03, s0, s1, s2, s3, tail_amp = 0.0;
-    const sh_envelope& e = v.env;
-    if (e.enabled) {
-        const uint64_t d0 = e.n_attack_end > start ? e.n_attack_end - start : 0;
-        const uint64_t d1 = e.n_decay_end > start ? e.n_decay_end - start : 0;
-        const uint64_t d2 = e.n_sustain_end > start ? e.n_sustain_end - start : 0;
-        const uint64_t d3 = e.n_release_end > start ? e.n_release_end - start : 0;
-        eb0 = d0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d0;
-        eb1 = d1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d1;
-        eb2 = d2 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d2;
-        eb3 = d3 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d3;
-        const double st = (double)start;
-        g00 = st * e.attack_slope;                                      // gain(n) = n * attack_slope
-        s0 = e.attack_slope;
-        g01 = fma(st - (double)e.n_attack_end, e.decay_slope, 1.0);     // 1 + (n - nA) * decay_slope
-        s1 = e.decay_slope;
-        g02 = e.sustain_level;
-        s2 = 0.0;
-        g03 = fma(st - (double)e.n_sustain_end, e.release_slope, e.sustain_level);
-        s3 = e.release_slope;
-        if (e.has_tail && e.n_release_end >= start && e.n_release_end - start < 0xFFFFFFFFull) {
-            tail_i = (uint32_t)(e.n_release_end - start);
-            tail_amp = e.tail_amp;
-        }
-    } else {                       // no envelope: an endless sustain piece of gain 1
-        eb0 = 0; eb1 = 0; eb2 = 0xFFFFFFFFu; eb3 = 0xFFFFFFFFu;
-        g00 = g01 = g02 = g03 = 1.0;
-        s0 = s1 = s2 = s3 = 0.0;
-    }
-    o->eb[0] = eb0; o->eb[1] = eb1; o->eb[2] = eb2; o->eb[3] = eb3;
-    o->g0[0] = g00; o->g0[1] = g01; o->g0[2] = g02; o->g0[3] = g03;
-    o->slope[0] = s0; o->slope[1] = s1; o->slope[2] = s2; o->slope[3] = s3;
-    o->tail_i = tail_i;
-    o->tail_amp = tail_amp;
-    // does the whole launch [0, nframes) sit on one envelope piece?
-    double g0u = 0.0, slu = 0.0;
-    {
-        const uint32_t last = nframes ? nframes - 1 : 0;
-        const bool tail_here = tail_i != NO_TAIL && tail_i <= last;
-        if (eb0 > 0) { if (last < eb0) { flags |= FL_ENV_UNIFORM; g0u = g00; slu = s0; } }
-        else if (eb1 > 0) { if (last < eb1) { flags |= FL_ENV_UNIFORM; g0u = g01; slu = s1; } }
-        else if (eb2 > 0) { if (last < eb2) { flags |= FL_ENV_UNIFORM; g0u = g02; slu = s2; } }
-        else if (eb3 > 0) { if (last < eb3) { flags |= FL_ENV_UNIFORM; g0u = g03; slu = s3; } }
-        else if (!tail_here) flags |= FL_ENV_UNIFORM | FL_SILENT;      // released before this launch: silent throughout
-    }
-    o->g0u = g0u;
-    o->slu = slu;
-    const double2 rot = B.seg_rot[off + lo];
-    const double rc = rot.x, rs = rot.y;
-    o->rot_c = rc;
-    o->rot_s = rs;
-    if (flags & FL_POLY) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) o->poly[u] = harm[u];
-        // bias == 0 and a constant envelope gain: fold amplitude and envelope into the bus gains, so the
-        // inner loop is h = P(c)*s; L += GL*h; R += GR*h.  (Differs from the unfolded order by float64
-        // rounding only, ~1e-16 relative.)  Bank kernels only: k_generate needs the voice sample itself.
-        if (v.bias == 0.0 && !v.flip && (flags & FL_ENV_UNIFORM) && slu == 0.0) {
-            flags |= FL_FOLDED;
-            gain_l = (v.amplitude * g0u) * gain_l;
-            gain_r = (v.amplitude * g0u) * gain_r;
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) o->poly[u] = 0.0;
-    }
-    o->gain_l = gain_l;
-    o->gain_r = gain_r;
-    o->flags = flags;
-    // Other voices that can take the lean loop: a Sine carrier with a closed-form Sine LFO, and the plain waveforms without
-    // FM.  Their record folds amplitude and envelope into the gains like FL_FOLDED does (the general code is not told: its
-    // paths apply the amplitude themselves).
-    const bool lean_env = v.bias == 0.0 && !v.flip && (flags & FL_ENV_UNIFORM) && slu == 0.0 && !(flags & FL_SILENT);
-    const bool lean_fm = lean_env && v.kind == SH_SINE && v.fm_mode == SH_FM_SINE;
-    const bool lean_plain = lean_env && v.fm_mode == SH_FM_NONE &&
-                            (v.kind == SH_SINE || v.kind == SH_SAWTOOTH || v.kind == SH_SQUARE || v.kind == SH_TRIANGLE || v.kind == SH_PULSE);
-    info.kind = lean_fm ? LEAN_FM
-              : !lean_plain ? LEAN_HARM
-              : v.kind == SH_SINE ? LEAN_SINE : v.kind == SH_SAWTOOTH ? LEAN_SAW : v.kind == SH_SQUARE ? LEAN_SQUARE
-              : v.kind == SH_TRIANGLE ? LEAN_TRIANGLE : LEAN_PULSE;
-    info.amplitude = v.amplitude;
-    info.g0u = g0u;
-    info.pulsewidth = v.pulsewidth;
-    if (lean_fm || lean_plain) {
-        gain_l = (v.amplitude * g0u) * gain_l;
-        gain_r = (v.amplitude * g0u) * gain_r;
-    }
-    info.silent = (flags & FL_SILENT) != 0;
-    // lean: the launch lies on the current table piece, or on it and the next one
-    const bool one_piece = rem >= (uint64_t)nframes;
-    const bool two_pieces = !one_piece && lo + 1 < cnt && ((lo + 2 < cnt) ? (tab[lo + 2].n0 - start >= (uint64_t)nframes) : true);
-    bool lean_sloped = false;
-    info.slope_l = 0.0;
-    info.slope_r = 0.0;
-    if (SLOPED && (flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT | FL_ENV_UNIFORM)) == (FL_POLY | FL_ENV_UNIFORM) && v.bias == 0.0 && !v.flip) {
-        lean_sloped = true;                               // (not FL_FOLDED: slu != 0)
-        gain_l = (v.amplitude * g0u) * (double)v.gain_l;
-        gain_r = (v.amplitude * g0u) * (double)v.gain_r;
-        info.slope_l = (v.amplitude * slu) * (double)v.gain_l;
-        info.slope_r = (v.amplitude * slu) * (double)v.gain_r;
-    }
-    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm || lean_plain || lean_sloped) && (one_piece || two_pieces);
-    info.remain = one_piece ? 0xFFFFFFFFu : (uint32_t)rem;
-    info.t0_b = one_piece ? t_base : tab[lo + 1].t0;
-    info.dt_b = one_piece ? dt : tab[lo + 1].dt;
-    {
-        const double2 rb = B.seg_rot[off + (one_piece ? lo : lo + 1)];
-        info.rot_c_b = rb.x;
-        info.rot_s_b = rb.y;
-    }
-    info.t_base = t_base;
-    info.dt = dt;
-    info.gain_l = gain_l;
-    info.gain_r = gain_r;
-    info.rot_c = rc;
-    info.rot_s = rs;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) info.poly[u] = (flags & FL_POLY) ? harm[u] : 0.0;
-    if (fm) {
-        VoiceFM* __restrict__ f = out_fm + vi;
-        f->frequency = v.frequency;
-        f->phase0 = v.fm_phase0;
-        f->f_inc = v.frequency * v.fm_inc;
-        f->lfo_a_rel = fma((double)start - 0.5, v.lfo_d, v.lfo_a);     // arg(i) = a + (start + i - 0.5) * d
-        f->lfo_d = v.lfo_d;
-        f->lfo_K = v.lfo_K;
-        f->lfo_C0 = v.lfo_C0;
-        f->lfo_bias = v.lfo_bias;
-        const double2 lrot = B.lfo_rot[first + vi];
-        f->lfo_rot_c = lrot.x;
-        f->lfo_rot_s = lrot.y;
-        info.fmv[0] = v.frequency; info.fmv[1] = v.fm_phase0; info.fmv[2] = v.frequency * v.fm_inc;
-        info.fmv[3] = fma((double)start - 0.5, v.lfo_d, v.lfo_a);
-        info.fmv[4] = v.lfo_d; info.fmv[5] = v.lfo_K; info.fmv[6] = v.lfo_C0; info.fmv[7] = v.lfo_bias;
-        info.fmv[8] = lrot.x; info.fmv[9] = lrot.y; info.fmv[10] = (double)start;
-    }
-}
-#else
-// SLOPED (the record sets of a segmented transition launch): a polynomial-Harmonics voice on ONE envelope line of any slope is
-// lean too -- its record carries the line folded into the bus gains (gain + i * slope) -- not only one on a constant gain.
-template <bool SLOPED = false>
-__device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first, uint32_t vi, uint64_t start, uint32_t nframes,
+__device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first, uint32_t vi, uint64_t launch_start, uint32_t launch_nframes,
                                               VoiceLaunch* __restrict__ out, VoiceFM* __restrict__ out_fm, PrepInfo& info) {
     // Fields are stored straight to the record (no local struct: a 368-byte private array would give
     // every wave of the render kernel a scratch allocation).
@@ -395,6 +202,25 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     // latency, and in a stream the step runs inside every render launch (eight dependent round trips took 8 us; three take 3).
     const sh_voice& v = B.voices[first + vi];
     VoiceLaunch* __restrict__ o = out + vi;
+    // A voice with an onset (start_frame > 0) is silent before it and runs on its own sample index n - start_frame from there:
+    // launches behind the onset are resolved at start - start_frame like any other; the one launch that HOLDS the onset is
+    // resolved from the voice's sample 0 for the frames behind it (general code: the frames in front are zeros); launches in front
+    // of it get a silent record.
+    const uint64_t onset = v.start_frame;
+    if (launch_start + (uint64_t)launch_nframes <= onset) {
+        o->flags = (uint32_t)v.kind | FL_ENV_UNIFORM | FL_SILENT;
+        o->onset_i = 0;
+        o->start_rel = 0;
+        info.fast = false;
+        info.silent = true;
+        return;
+    }
+    const uint32_t onset_i = launch_start < onset ? (uint32_t)(onset - launch_start) : 0u;
+    const uint64_t start = launch_start < onset ? 0ull : launch_start - onset;
+    const uint32_t nframes = launch_nframes - onset_i;
+    o->onset_i = onset_i;
+    o->start_rel = start;
+    o->pad_ = 0;
     const bool fm = v.fm_mode != SH_FM_NONE;
     const uint32_t off = fm ? v.time_seg_offset : v.seg_offset;
     const uint32_t cnt = fm ? v.time_seg_count : v.seg_count;
@@ -478,7 +304,7 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         }
         o->nx_count = count;
     }
-    uint32_t flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) |
+    uint32_t flags = (uint32_t)v.kind | ((uint32_t)v.fm_mode << FL_FM_SHIFT) | (onset_i ? FL_ONSET : 0u) |
                      (v.harm_dense == 1 ? FL_DENSE : 0u) | (v.harm_dense == 2 ? FL_POLY : 0u) | (v.flip ? FL_FLIP : 0u);
     o->harm = harm;
     o->harm_cnt = v.harm_count;
@@ -588,7 +414,8 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         info.slope_l = (v.amplitude * slu) * (double)v.gain_l;
         info.slope_r = (v.amplitude * slu) * (double)v.gain_r;
     }
-    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm || lean_plain || lean_sloped) && (one_piece || two_pieces);
+    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm || lean_plain || lean_sloped) && (one_piece || two_pieces) &&
+                onset_i == 0;                                  // (the launch that holds the onset: general code)
     info.remain = one_piece ? 0xFFFFFFFFu : (uint32_t)rem;
     info.t0_b = one_piece ? t_base : p1_t0;
     info.dt_b = one_piece ? dt : p1_dt;
@@ -620,7 +447,6 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     }
 }
 
-#endif
 
 // One wavefront resolves the launch records of one chunk of 64 consecutive voices (lane = voice) and classifies them
 // (see LaunchSet); positions in the chunk's compacted lists come from wave ballots -- no inter-thread memory traffic,
@@ -728,11 +554,12 @@ typedef const shm::sc_pair* TrigTab;     // LDS
 
 // FPL samples per lane of one voice (frames i[j], launch-relative), float64.  Every argument except
 // i/di is wave-uniform, so the branches on kind / fm_mode / envelope do not diverge.
-//   tile_last: last frame index any lane of this wave touches (uniform)
+//   tile_first, tile_last: first / last frame index any lane of this wave touches (uniform); `start`: the voice's sample index at
+//   frame 0 (the record's start_rel)
 template <int FPL, bool BANK>
 __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* __restrict__ fmrec,
                                             const BankPtrs& B, const sh_voice* __restrict__ vfull,
-                                            uint64_t start, uint32_t tile_last,
+                                            uint64_t start, uint32_t tile_first, uint32_t tile_last,
                                             const uint32_t (&i)[FPL], const double (&di)[FPL],
                                             const double* __restrict__ fm_cumsum, const double* __restrict__ pwm,
                                             TrigTab trig, double (&x)[FPL]) {
@@ -749,7 +576,6 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
         // anything else looks its piece up in the voice's table: once per wave for the tile's first frame
         // (scalar binary search), then per lane only for the lanes past that piece's end.
         const VoiceLaunch SH_CONST_AS* q = r.rec;
-        const uint32_t tile_first = tile_last & ~(uint32_t)(64 * FPL - 1);
         // k = index of the following piece that holds the tile's first frame (uniform): the number of listed piece
         // ends at or before it
         uint32_t k = 0;
@@ -961,7 +787,6 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
     } else {                                   // this launch crosses attack/decay/sustain/release ends
         const VoiceLaunch SH_CONST_AS* q = r.rec;
         const uint32_t e0 = q->eb[0], e1 = q->eb[1], e2 = q->eb[2], e3 = q->eb[3], ti = q->tail_i;
-        const uint32_t tile_first = tile_last & ~(uint32_t)(64 * FPL - 1);
         const uint32_t p = (tile_first >= e0) + (tile_first >= e1) + (tile_first >= e2) + (tile_first >= e3);
         const uint32_t pend = p < 4 ? q->eb[p & 3] : 0xFFFFFFFFu;
         const bool tail_here = ti != NO_TAIL && ti >= tile_first && ti <= tile_last;
@@ -984,6 +809,43 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
             }
         }
     }
+}
+
+// voice_block for the launch-relative frames of a tile, whatever the voice's onset: the record's start_rel is the voice's sample
+// index at the launch's first sounding frame; in the launch that holds the onset (onset_i > 0) the frames in front of it are
+// zeros and the voice's own index is i - onset_i.  (Voices that read rows of the launch's matrix have no onset: sh_bank_create.)
+template <int FPL, bool BANK>
+__device__ __forceinline__ void voice_block_at(const VoiceRegs& r, const VoiceFM* __restrict__ fmrec, const BankPtrs& B,
+                                               const sh_voice* __restrict__ vfull, uint32_t tile_first, uint32_t tile_last,
+                                               const uint32_t (&i)[FPL], const double (&di)[FPL],
+                                               const double* __restrict__ fm_cumsum, const double* __restrict__ pwm,
+                                               TrigTab trig, double (&x)[FPL]) {
+    const uint64_t st = r.rec->start_rel;
+    if (!(r.flags & FL_ONSET)) {
+        voice_block<FPL, BANK>(r, fmrec, B, vfull, st, tile_first, tile_last, i, di, fm_cumsum, pwm, trig, x);
+        return;
+    }
+    const uint32_t d = r.rec->onset_i;                      // (uniform)
+    if (tile_last < d) {                                    // the whole tile lies in front of the onset
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) x[j] = 0.0;
+        return;
+    }
+    // the voice's own index of the lane's frames: integer form clamped at 0 for the frames in front of the onset (table walks,
+    // row indices); float form NOT clamped -- a lane's frames stay 64 apart, which the rotation shortcuts rely on (the values
+    // computed for negative indices are finite nonsense, and zeroed below)
+    uint32_t ii[FPL];
+    double dd[FPL];
+    const double dneg = (double)d;
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        ii[j] = i[j] >= d ? i[j] - d : 0u;
+        dd[j] = di[j] - dneg;
+    }
+    voice_block<FPL, BANK>(r, fmrec, B, vfull, st, tile_first > d ? tile_first - d : 0u, tile_last - d, ii, dd, fm_cumsum, pwm, trig, x);
+#pragma unroll
+    for (int j = 0; j < FPL; ++j)
+        if (i[j] < d) x[j] = 0.0;
 }
 
 // One voice through the general code, accumulated into the lane's partial bus.  With more than four frames per lane
@@ -1014,7 +876,7 @@ __device__ __forceinline__ void general_voice(const VoiceRegs& r, const VoiceFM*
         double dh[GF], x[GF];
 #pragma unroll
         for (int j = 0; j < GF; ++j) { ih[j] = i[h * GF + j]; dh[j] = di[h * GF + j]; }
-        voice_block<GF, true>(r, fmrec, B, vfull, start, last, ih, dh, fm_p, pwm_p, trig, x);
+        voice_block_at<GF, true>(r, fmrec, B, vfull, first, last, ih, dh, fm_p, pwm_p, trig, x);
 #pragma unroll
         for (int j = 0; j < GF; ++j) {
             accl[h * GF + j] = fma(r.gain_l, x[j], accl[h * GF + j]);

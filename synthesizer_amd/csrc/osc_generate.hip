@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
                 fm_p = fr >= 0 ? B.rows + (size_t)fr * B.row_stride : nullptr;
                 pwm_p = pr >= 0 ? B.rows + (size_t)pr * B.row_stride : nullptr;
             }
-            voice_block<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, start, tile_last, i, di, fm_p, pwm_p, trig, x);
+            voice_block_at<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, tile0, tile_last, i, di, fm_p, pwm_p, trig, x);
         }
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
         const uint32_t vi = idx[p];
         const VoiceRegs r = load_record(as_const(cur.launch) + vi);
         double x[FPL];
-        voice_block<FPL, false>(r, cur.fm + vi, B, B.voices + vi, start, tile_last, i, di, nullptr, nullptr, trig, x);
+        voice_block_at<FPL, false>(r, cur.fm + vi, B, B.voices + vi, tile0, tile_last, i, di, nullptr, nullptr, trig, x);
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
             const uint32_t raw = tile0 + j * 64 + lane;

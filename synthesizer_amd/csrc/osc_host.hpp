@@ -72,6 +72,7 @@ struct sh_bank {
     // whole launch, and no phase-table piece shorter than the launch ends after its start (a launch then crosses at most one
     // piece end per voice).  short_piece_end[k] = the largest end of any piece shorter than 2^k samples.
     bool        all_lean = false;          // every voice is a lean candidate (of any lean kind)
+    bool        has_onsets = false;        // some voice starts late (sh_voice::start_frame)
     uint64_t    env_flat_from = 0, env_flat_until = ~0ull;
     std::vector<uint64_t> env_corners;     // the distinct attack / decay / sustain / release ends of the voices, sorted (empty when there are many)
     uint64_t    short_piece_end[34] = {};

@@ -156,6 +156,7 @@ class VoiceSpec:
     flip: bool = False                                  # SawtoothH mirrors the wave around the bias
     noise_seed: int = 0                                 # WhiteNoise
     noise_hold: int = 0
+    start_frame: int = 0                                # onset: silent before, the voice's own sample 0 at this frame (DelayFilter)
 
 
 def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float, float]]] = None):
@@ -221,6 +222,7 @@ def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float
         v["flip"] = 1 if s.flip else 0
         v["noise_seed"] = s.noise_seed & 0xFFFFFFFFFFFFFFFF
         v["noise_hold"] = s.noise_hold
+        v["start_frame"] = s.start_frame
         if s.env is not None:
             e = v["env"]
             e["n_attack_end"], e["n_decay_end"] = s.env.n_attack_end, s.env.n_decay_end
@@ -811,6 +813,20 @@ class DelayFilter(_Filter):
     def __init__(self, source: Oscillator, seconds: float) -> None:
         super().__init__([source])
         self._seconds = seconds
+
+    def spec(self) -> VoiceSpec:
+        """A delayed single-record voice (a waveform, a fused envelope over one; no row-reading modulators) IS a single record:
+        the same voice with an onset (sh_voice::start_frame) -- silent before, its own sample 0 there.  So a bank can hold notes
+        that start at different times without rendering each into a row of its own."""
+        src = self._sources[0]
+        if self._seconds < 0.0:
+            raise NotImplementedError("a negative delay skips into the source: rendered block by block")
+        sp = src.spec()                              # NotImplementedError for filter graphs: rendered block by block
+        if sp.fm_mode == N.SH_FM_BUFFER or sp.needs_pwm or sp.kind == N.SH_BUFFER:
+            raise NotImplementedError("a delayed voice that reads modulator rows is rendered block by block")
+        if sp.env is not None and sp.env.stop_at_end:
+            raise NotImplementedError("a delayed finite stream is rendered block by block")
+        return replace(sp, start_frame=sp.start_frame + self._shift)
 
     @property
     def _shift(self) -> int:

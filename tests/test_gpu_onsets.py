@@ -1,0 +1,105 @@
+"""GPU parity: voices with an onset (sh_voice::start_frame) -- upstream's DelayFilter(voice, seconds) fused into the voice's
+record, so that a bank can hold notes that start at different times.  Oracle: oracle/synth_oracle.py DelayFilter over the same
+voices (zeros first, then the source from ITS sample 0), and the C oracle with zero-padded rows for the larger banks."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+from oracle import synth_oracle as O
+from tests.helpers import rms
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+RMS_TOL = 1e-6
+
+
+def _voices(m):
+    harm = [(k, 1.0 / k) for k in range(1, 17)]
+    env = lambda src: m.EnvelopeFilter(src, 0.01, 0.02, 0.05, 0.6, 0.03)
+    specs = [
+        (m.Sine(440.0, 0.2, samplerate=SR), 0.0),
+        (env(m.Harmonics(220.0, harm, 0.3, phase=0.3, samplerate=SR)), 1 / SR),
+        (env(m.Harmonics(330.0, harm, 0.3, phase=0.7, samplerate=SR)), 63 / SR),
+        (m.Square(1000.0, 0.2, samplerate=SR), 64 / SR),                     # an edge on every 24th sample of ITS time base
+        (m.Pulse(250.0, 0.2, pulsewidth=0.25, samplerate=SR), 100 / SR),
+        (env(m.Sawtooth(150.0, 0.3, samplerate=SR)), 511 / SR),
+        (m.Sine(330.0, 0.25, fm_lfo=m.Sine(5.0, 0.03, samplerate=SR), samplerate=SR), 512 / SR),     # closed-form FM restarts with the voice
+        (env(m.Triangle(90.0, 0.3, samplerate=SR)), 4095 / SR),
+        (m.WhiteNoise(800.0, 0.1, samplerate=SR, seed=5), 5000 / SR),
+        (m.Linear(0.0, 1e-4, samplerate=SR), 7777 / SR),
+        (env(m.Harmonics(110.0, harm, 0.3, samplerate=SR)), 9999 / SR),
+        (env(m.Harmonics(55.0, harm, 0.3, samplerate=SR)), 0.5),              # beyond the rendered range: never sounds
+    ]
+    return [m.DelayFilter(v, d) if d else v for v, d in specs]
+
+
+def test_voices_with_onsets_in_a_bank(gpu):
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    gv, ov = _voices(G), _voices(O)
+    rng = np.random.default_rng(9)
+    gains = [(float(np.float32(a)), float(np.float32(b))) for a, b in rng.uniform(0.2, 1.0, (len(gv), 2))]
+    n = 12000
+    want = np.array(O.mix_bus([v.take(n) for v in ov], gains), dtype=np.float64)
+    bank = VoiceBank(gv, gains=gains)
+    assert bank._rows is None                               # every delayed voice became ONE record with an onset: no rows
+    got = bank.render(n)
+    assert rms(got, want) <= RMS_TOL and np.max(np.abs(got - want)) < 5e-7
+    # block by block (onsets inside blocks, at block starts, blocks in front of onsets), and odd windows
+    for block in (1000, 512, 64):
+        parts = np.concatenate([bank.render(block, start=s) for s in range(0, 6144, block)])
+        assert rms(parts, want[:len(parts)]) <= RMS_TOL, block
+    for start, m in ((63, 2), (64, 1), (99, 3), (5000, 1), (4000, 4000), (9998, 1500)):
+        assert rms(bank.render(m, start=start), want[start:start + m]) <= RMS_TOL, (start, m)
+    # the reference-shaped two-step route: rows with leading zeros, exactly zero in front of the onset
+    rows = bank.generate(n)
+    for i, v in enumerate(ov):
+        w = np.array(v.take(n), dtype=np.float64)
+        assert np.max(np.abs(rows[i] - w)) < 2e-7, i
+        lead = int(SR * v._seconds) if isinstance(v, O.DelayFilter) else 0          # (upstream's own expression)
+        assert not rows[i][:min(lead, n)].any(), i
+    assert rms(bank.render_two_step(n), want) <= RMS_TOL
+    # Square / Pulse samples are EQUAL to float32(oracle): the accumulated phase restarts exactly at the onset
+    for i in (3, 4):
+        assert np.array_equal(rows[i], np.array(ov[i].take(n), dtype=np.float32)), i
+
+
+def test_notes_that_start_at_different_times(gpu):
+    """320 additive voices (several voice groups: split launches, segmented launches, the two-stream pipeline) whose notes start
+    anywhere in the first 30 000 frames and end (ADSR without a held sustain): long blocks from frame 0, the same frames block by
+    block in a pipelined run, against the C oracle's zero-padded rows."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    nv, n = 320, 49152
+    rng = np.random.default_rng(21)
+    f = np.exp(rng.uniform(np.log(55.0), np.log(3520.0), nv))
+    amp = rng.uniform(0.1, 1.0, nv) / np.sqrt(nv)
+    ph = rng.uniform(0, 1, nv)
+    onset = rng.integers(0, 30000, nv)
+    onset[:4] = (0, 16384, 16383, 512)
+    gains = [(float(np.float32(a)), float(np.float32(b))) for a, b in rng.uniform(0.0, 1.0, (nv, 2))]
+    harm = [(k, 1.0 / k) for k in range(1, 17)]
+
+    def build(m):
+        out = []
+        for i in range(nv):
+            v = m.EnvelopeFilter(m.Harmonics(float(f[i]), harm, float(amp[i]), phase=float(ph[i]), samplerate=SR), 0.01, 0.05, 0.2, 0.6, 0.1)
+            out.append(m.DelayFilter(v, int(onset[i]) / SR) if onset[i] else v)
+        return out
+    gv, ov = build(G), build(O)
+    rows = np.zeros((nv, n))
+    for i, v in enumerate(ov):
+        src = v._source if isinstance(v, O.DelayFilter) else v
+        d = int(SR * v._seconds) if isinstance(v, O.DelayFilter) else 0             # upstream's expression: may be onset - 1 after the division
+        rows[i, d:] = CO.render(src, n - d)
+    want = CO.mix_bus(rows, gains)
+    bank = VoiceBank(gv, gains=gains)
+    assert rms(bank.render(n), want) <= RMS_TOL
+    for block in (16384, 4096):
+        bufs = [N.DeviceBuffer(block * 8) for _ in range(n // block)]
+        for k in range(n // block):
+            bank.render_device(block, k * block, bus_f32=bufs[k])
+        parts = np.concatenate([b.download(np.float32, block * 2).reshape(block, 2) for b in bufs])
+        assert rms(parts, want[:len(parts)]) <= RMS_TOL, block
+    assert rms(bank.render_two_step(20000, start=10000), want[10000:30000]) <= RMS_TOL
