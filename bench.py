@@ -274,6 +274,36 @@ def config_roofline(prof, tag, voice_samples, ms, algorithmic_bytes):
             "source": prof.get("counters_source")}
 
 
+def staggered_row(N, F):
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd import workloads as W
+    from synthesizer_amd.mixer import VoiceBank
+    import ctypes
+    slots, notes, nblocks = VOICES_PER_GPU, 22, 20
+    t0 = time.perf_counter()
+    voices, gains = W.staggered_notes(G, slots, SR, seed=0, partials=PARTIALS, period=1.0, notes=notes)
+    bank = VoiceBank(voices, gains=gains)
+    build_s = time.perf_counter() - t0
+    ring = [N.DeviceBuffer(F * 8) for _ in range(4)]
+    pos = [0]
+
+    def step():                                     # blocks 1 .. 20 of the piece, over and over (block 0 has half its notes yet to start)
+        k = 1 + pos[0] % nblocks
+        bank.render_device(F, k * F, bus_f32=ring[pos[0] & 3])
+        pos[0] += 1
+    for _ in range(nblocks):
+        step()
+    ms = steady(N, step, min_seconds=0.2, reps=nblocks)      # every loop: the twenty blocks from a standing start (two cold launches among them)
+    nf, ng = ctypes.c_uint32(), ctypes.c_uint32()
+    return {"players": slots, "voices_in_the_table": len(voices), "ms_per_step": ms, "value": slots * F / (ms / 1e3) / 1e6, "unit": "Msamples/s",
+            "sounding_fraction": 0.76, "host_build_s": build_s,
+            "blocks_per_loop": nblocks,
+            "note": "1024 players x 22 rounds: every note a voice of its own with an onset (DelayFilter fused into the record), Harmonics x16 under "
+                    "the literal ADSR (attack 0.01, decay 0.05, sustain 0.5 at 0.6, release 0.2); blocks of one second, twenty of them per timed loop (each loop starts cold: its first two launches resolve their tile sets in front of the render), counted as "
+                    "1024 voice-samples per frame although a quarter of the players is between notes at any time; tile-classified launches "
+                    "(lean per (voice, 512-frame tile) pair, general code for the pairs with an onset, an envelope corner or a phase-table piece end)"}
+
+
 class _stdout_to_stderr:
     """File descriptor 1 points at stderr inside the block: what a native library prints on stdout (librccl's version banner
     at communicator creation) must not end up beside the ONE JSON line this script owes its caller."""
@@ -688,6 +718,11 @@ def main() -> int:
                                    "note": "ten consecutive blocks starting at frame 0 (first block of the notes included), best of 12"}
         for b_ in ring:
             b_.free()
+
+    # ---- notes that do not move in lock-step: 1024 players re-triggering SURVEY 8(d)'s literal note (0.76 s of sound) every second,
+    # onsets spread uniformly over the second; ten one-second blocks in the steady state of the piece ----
+    if world == 1 and not args.no_configs:
+        out["staggered_notes"] = staggered_row(N, F)
 
     # ---- two-step path on rank 0's shard: materialise (generate) + HBM-bound mix ----
     if not args.no_two_step:

@@ -57,6 +57,7 @@ struct State {
     hipEvent_t  ev_aux = nullptr;       // on stream2 after every launch there: `stream` waits for it when the run ends
     hipEvent_t  ev_prep = nullptr;      // on `stream` after a prepare kernel that a stream2 launch needs
     hipEvent_t  ev_sync = nullptr;      // join_streams: on `stream`, waited for by stream2
+    hipStream_t prep_stream = nullptr;  // the tile sets of tile-classified launches are resolved here, two launches ahead (osc_render.hip)
     bool        aux_busy = false;       // stream2 holds work `stream` has not waited for
 };
 
@@ -69,6 +70,7 @@ struct Knobs {
     bool no_overlap = false;       // SYNTHHIP_NO_OVERLAP=1: consecutive renders stay on one stream
     bool no_split = false;         // SYNTHHIP_NO_SPLIT=1: lean and general code in one kernel
     bool no_seg = false;           // SYNTHHIP_NO_SEG=1: transition launches / row heads are not cut into segments
+    bool no_tiles = false;         // SYNTHHIP_NO_TILES=1: banks whose notes do not move in lock-step are not classified tile by tile
     bool always_general = false;   // SYNTHHIP_ALWAYS_GENERAL=1: the general-lists kernel of a split launch is always launched
     bool no_small_pipeline = false;// SYNTHHIP_NO_SMALL_PIPELINE=1: single-group banks render on one stream (round-2 behaviour)
     bool prepare_in_tile = false;  // SYNTHHIP_PREPARE_IN_TILE=1: the next-but-one block's records are resolved by the first tile workgroups

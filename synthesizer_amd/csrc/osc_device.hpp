@@ -30,6 +30,71 @@ constexpr int SEG_MAX = 24;            // segments of a transition launch
 // record set set[k] (the lists launch skips the segments the host can prove free of general voices)
 struct SegTab { uint32_t n; uint32_t first[SEG_MAX]; uint32_t len[SEG_MAX]; uint32_t set[SEG_MAX]; };
 
+// A TILE-CLASSIFIED launch (banks whose notes do not move in lock-step: onsets and envelope corners of their own).  Whether a
+// voice can take the lean loop is decided per (voice, tile of TILE_FRAMES frames), not per launch.  A pair is LEAN when the voice
+// is a polynomial-Harmonics voice and the tile holds at most ONE corner of its envelope -- the onset counts as one: silence |
+// attack -- and at most two ends of pieces of its phase table; then 128 bytes and the voice's polynomial (a table by voice) say all the lean arithmetic needs:
+//   * the envelope over the tile is min or max of two lines (silence|attack: max; attack|decay: min; decay|sustain: max;
+//     sustain|release: min; release|silence: max; no corner: the same line twice) -- no select per frame, no list of corners;
+//     in front of an onset the attack's line is negative, the maximum with 0 is 0, and whatever the phase is there is multiplied by it;
+//   * piece ends inside the tile (the first tile of a note runs through several binades of its phase sum) make it a multi-piece
+//     tile: every frame is looked up from the piece that holds it (up to three compares), no recurrence across the ends.
+// A pair that sounds but holds two corners (or an onset without an attack) or more piece ends takes the general code for that
+// tile only; the rest is silent.  One bit per pair in two masks per (tile, chunk of 64 voices): the kernels walk set bits.
+constexpr uint32_t TILE_FRAMES = 512;         // = the lean render kernel's tile (four waves, eight frames per lane)
+constexpr uint32_t TILE_MAX_PIECES = 3;
+struct alignas(64) TileRec {
+    double t0, dt;                // t(i) = fma(i - tile0, dt, t0): the accumulated phase at the tile's first frame, its piece's step
+    double rc, rs;                // cos / sin of 64 dt
+    double ea0, ea1, eb0, eb1;    // envelope(i) = MIN of ea0 + (i - tile0) ea1 and eb0 + (i - tile0) eb1 -- a convex corner (the envelope is the
+                                  // maximum of its two lines) is stored with both lines AND the gains negated: max(a, b) g = min(-a, -b) (-g)
+    double GL, GR;                // amplitude * bus gain (negated at a convex corner)
+    double tb[2], db[2];          // pieces 1, 2: frames i - tile0 >= split[k] lie on piece k + 1, t = fma(i - tile0 - split[k], db[k], tb[k])
+    uint16_t split[2];            // 0xFFFF: no such piece
+    uint16_t npieces;
+    uint16_t corner;              // 1: the two lines differ
+    double pad_;
+};
+static_assert(sizeof(TileRec) == 128, "TileRec layout");
+// the position of the (p + 1)-th set bit of m (p < popcount(m)): wave-uniform scalar arithmetic, six halvings
+__device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t p) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const uint64_t low = m & ((1ull << w) - 1ull);
+        const uint32_t cnt = (uint32_t)__popcll(low);
+        if (p >= cnt) { p -= cnt; m >>= w; pos += (uint32_t)w; } else { m = low; }
+    }
+    return pos;
+}
+// the accumulated t of a lane's frame j (64 samples apart) in a multi-piece tile (by value members: see LaneTheta)
+struct TileTheta {
+    double   lane_d, t0, dt, tb0, tb1, db0, db1;
+    uint32_t lane, s1, s2;
+    __device__ __forceinline__ double operator()(int j) const {
+        const uint32_t i = lane + (uint32_t)j * 64u;
+        const double dd = lane_d + (double)(j * 64);
+        double t = fma(dd, dt, t0);
+        if (i >= s1) t = fma(dd - (double)s1, db0, tb0);
+        if (i >= s2) t = fma(dd - (double)s2, db1, tb1);
+        return t;
+    }
+};
+struct TileSet {
+    TileRec*  recs;               // [tile][slot]: the lean pairs of chunk c of a tile compacted at slots 64 c .. (their count: the bits of the mask)
+    // masks: [tile][group][k], chunk c = group + k * groups (a voice group of a tile-classified launch = every groups-th chunk:
+    // notes that sound together tend to be neighbours in the voice table, and a range of chunks would give one group all of
+    // them); mask_k = masks per (tile, group), a multiple of 8: a workgroup fetches its masks in batches of eight scalar loads
+    uint64_t* lean;               // bit b = voice 64 c + b is lean in this tile
+    uint64_t* gen;                // ... takes the general code in this tile
+    uint32_t  groups, mask_k;
+    uint32_t  gen_wgs;            // general workgroups per row of the render kernel's grid (RENDER_LEAN_TILES)
+};
+__host__ __device__ __forceinline__ uint32_t tile_mask_k(uint32_t nvoices, uint32_t groups) {
+    const uint32_t nchunks = (nvoices + 63) / 64;
+    return ((nchunks + groups - 1) / groups + 7) & ~7u;
+}
+
 struct BankPtrs {
     const sh_voice*   voices;
     const sh_segment* segs;
@@ -55,6 +120,9 @@ struct BankPtrs {
     // which k_seg_combine adds in order into the group's general parts.  Later segments: sub 0 alone, straight into the parts.
     uint32_t          gen_sub;
     double2*          gen_scratch;
+    // per launch (tile-classified launches, RENDER_*_TILES): the launch's tile set; polys = [slot][16] polynomial coefficients by voice
+    TileSet           tiles;
+    const double*     polys;
 };
 
 // Pointers to data that no thread of the running kernel writes are cast to the constant address space:

@@ -38,6 +38,17 @@ struct sh_bank {
     LaunchSet   seg_set[2] = {};
     uint32_t    seg_cap[2] = {0, 0};
     sh::Pooled  seg_scratch[2];            // ... and the slices of its first segment's general parts (BankPtrs::gen_scratch)
+    // The tile sets of tile-classified launches: a ring of four.  Launch n uses set n % 4; while it is being enqueued, the set of
+    // the block expected two launches on is resolved on the PREPARE stream (tile_spec says for which block; ev_tile_ready is
+    // recorded behind that kernel, ev_tile_free behind the last render that read a set) -- beside the renders, not in front of one.
+    static constexpr int NTILESETS = 4;
+    sh::Pooled  tile_block[NTILESETS];
+    TileSet     tile_set[NTILESETS] = {};
+    uint32_t    tile_carved[NTILESETS] = {0, 0, 0, 0};   // tiles the set was carved for
+    struct TileSpec { bool valid = false; uint64_t start = 0; uint32_t nframes = 0, groups = 0; } tile_spec[NTILESETS];
+    hipEvent_t  ev_tile_ready[NTILESETS] = {}, ev_tile_free[NTILESETS] = {};
+    bool        tile_ready_recorded[NTILESETS] = {false, false, false, false}, tile_free_recorded[NTILESETS] = {false, false, false, false};
+    uint32_t    tile_count = 0;            // tile-classified launches so far
     struct Range { const char* lo; const char* hi; };
     Range       last_direct[3] = {};       // what the last launch wrote itself (single-group launches: float32 / float64 / PCM bus)
     bool        overlaps_last_direct(const void* p, size_t bytes) const {
@@ -57,6 +68,7 @@ struct sh_bank {
     LaunchSet   gen_set = {};
     uint32_t    gen_segs = 0;
     double2*    d_seg_rot = nullptr;       // (cos, sin)(64*dt) per table piece
+    double*     d_polys = nullptr;         // [slot][16]: the polynomial of a polynomial-Harmonics voice, by voice
     double2*    d_lfo_rot = nullptr;       // (cos, sin)(64*lfo_d) per voice
     VoiceLaunch* d_launch = nullptr;       // the set the next kernel reads
     VoiceFM*    d_launch_fm = nullptr;
@@ -73,6 +85,7 @@ struct sh_bank {
     // piece end per voice).  short_piece_end[k] = the largest end of any piece shorter than 2^k samples.
     bool        all_lean = false;          // every voice is a lean candidate (of any lean kind)
     bool        has_onsets = false;        // some voice starts late (sh_voice::start_frame)
+    bool        own_envelopes = false;     // the voices' envelope corners are too many to cut launches at (more than 16 distinct ones)
     uint64_t    env_flat_from = 0, env_flat_until = ~0ull;
     std::vector<uint64_t> env_corners;     // the distinct attack / decay / sustain / release ends of the voices, sorted (empty when there are many)
     uint64_t    short_piece_end[34] = {};
@@ -99,6 +112,8 @@ uint32_t plan_segments(const sh_bank* b, uint64_t start, uint32_t nframes, uint6
 int bank_check_plain(const sh_bank* b, const char* who);
 // `nseg` record sets for `nvoices` voices carved out of one pool-backed block (grown when it is too small; *cap = sets it holds)
 int grow_segment_sets(sh::Pooled& block, LaunchSet& g, uint32_t& cap, uint32_t nseg, uint32_t nvoices);
+int launch_prepare_tiles(hipStream_t st, const BankPtrs& P, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes);
+int grow_tile_set(sh::Pooled& block, TileSet& T, uint32_t& carved_tiles, uint32_t ntiles, uint32_t nvoices, uint32_t groups, hipStream_t st);
 int launch_prepare_segments(hipStream_t st, const BankPtrs& P, const LaunchSet& base, uint32_t nvoices, uint32_t nseg, uint64_t start,
                             uint32_t nframes, uint32_t seg_frames);
 int launch_prepare_segments_var(hipStream_t st, bool sloped, const BankPtrs& P, const LaunchSet& base, uint32_t nvoices, uint32_t nseg, uint64_t start);

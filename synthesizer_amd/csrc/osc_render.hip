@@ -32,12 +32,55 @@ namespace {
 // over the tiles of all segments; a workgroup finds its segment first and from there on works in the segment's frame of
 // reference (records, tile, clamps); only its stores are launch-relative again.
 enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2, RENDER_LEAN_HARM_ONLY = 3, RENDER_GENERAL_ONLY = 4, RENDER_LEAN_ALL_ONLY = 5,
-       RENDER_LEAN_HARM_SEG = 6, RENDER_GENERAL_SEG = 7, RENDER_LEAN_ALL_SEG = 8 };
-constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_HARM_SEG; }
-constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY || mode == RENDER_LEAN_HARM_SEG || mode == RENDER_LEAN_ALL_SEG; }
-constexpr bool mode_general(int mode) { return mode == RENDER_GENERAL_ONLY || mode == RENDER_GENERAL_SEG; }
+       RENDER_LEAN_HARM_SEG = 6, RENDER_GENERAL_SEG = 7, RENDER_LEAN_ALL_SEG = 8,
+       // RENDER_LEAN_TILES / RENDER_GENERAL_TILES: the split launch of a TILE-CLASSIFIED block (see TileRec): the lean kernel walks the
+       // set bits of its tile's lean masks -- a 64-byte record per (voice, tile) + the voice's polynomial, the sloped lean arithmetic,
+       // no piece ends, no corners -- the general kernel the set bits of the general masks, through the launch records.
+       RENDER_LEAN_TILES = 9, RENDER_GENERAL_TILES = 10 };
+constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_HARM_SEG || mode == RENDER_LEAN_TILES; }
+constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY || mode == RENDER_LEAN_HARM_SEG || mode == RENDER_LEAN_ALL_SEG || mode == RENDER_LEAN_TILES; }
+constexpr bool mode_general(int mode) { return mode == RENDER_GENERAL_ONLY || mode == RENDER_GENERAL_SEG || mode == RENDER_GENERAL_TILES; }
 constexpr bool mode_seg(int mode) { return mode == RENDER_LEAN_HARM_SEG || mode == RENDER_GENERAL_SEG || mode == RENDER_LEAN_ALL_SEG; }
 constexpr bool mode_has_lean(int mode) { return mode != RENDER_DIRECT && !mode_general(mode); }
+constexpr uint32_t GEN_SPLIT = 2;      // general workgroups per tile of a tile-classified launch (each writes a plane of general parts; <= groups)
+
+// lean_harm_frames for a (voice, tile) pair of a tile-classified launch with a corner of the envelope inside: the envelope of
+// frame i is the minimum of two lines in the tile-relative index, applied to the sample before the (constant) bus gains.
+template <int FPL, typename Theta>
+__device__ __forceinline__ void lean_tile_frames(double s0, double c0, double s1, double c1, double k2, bool straddle, Theta theta,
+                                                 TrigTab trig, const double (&poly)[16], double GL, double GR,
+                                                 double ea0, double ea1, double eb0, double eb1, double dl,
+                                                 double (&accl)[FPL], double (&accr)[FPL]) {
+    static_assert(FPL % 2 == 0, "frames in pairs");
+#pragma unroll
+    for (int h = 0; h < FPL; h += 2) {
+        double p0 = fma(poly[0], c0, poly[1]), p1 = fma(poly[0], c1, poly[1]);
+#pragma unroll
+        for (int u = 2; u < 16; ++u) {
+            p0 = fma(p0, c0, poly[u]);
+            p1 = fma(p1, c1, poly[u]);
+        }
+        const double i0 = dl + (double)(h * 64), i1 = dl + (double)((h + 1) * 64);
+        const double a0 = fma(i0, ea1, ea0), b0 = fma(i0, eb1, eb0), a1 = fma(i1, ea1, ea0), b1 = fma(i1, eb1, eb0);
+        const double e0 = fmin(a0, b0), e1 = fmin(a1, b1);      // (a convex corner arrives negated, gains included: see TileRec)
+        const double x0 = (p0 * s0) * e0, x1 = (p1 * s1) * e1;
+        accl[h] = fma(GL, x0, accl[h]);
+        accr[h] = fma(GR, x0, accr[h]);
+        accl[h + 1] = fma(GL, x1, accl[h + 1]);
+        accr[h + 1] = fma(GR, x1, accr[h + 1]);
+        if (h + 2 < FPL) {
+            if (straddle) {
+                shm::sincos_tab(theta(h + 2), trig, s0, c0);
+                shm::sincos_tab(theta(h + 3), trig, s1, c1);
+            } else {
+                const double s2 = fma(k2, s1, -s0), c2 = fma(k2, c1, -c0);
+                const double s3 = fma(k2, s2, -s1), c3 = fma(k2, c2, -c1);
+                s0 = s2; c0 = c2; s1 = s3; c1 = c3;
+            }
+        }
+    }
+}
+
 template <int WAVES, int FPL, int MINW, int MODE>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                   uint32_t nvoices, uint32_t voices_per_group,
@@ -70,7 +113,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             return;
         }
     }
-    const uint32_t bx = blockIdx.x - (mode_general(MODE) ? 0u : prep_wgs);       // the tile (or, segmented: the tile counter) of this workgroup
+    // RENDER_GENERAL_TILES: workgroup (x, y) renders the general pairs of ONE tile of 64 FPL frames, ALL voice groups' -- part
+    // gen_part of GEN_SPLIT of them -- into plane gen_part of the general parts.
+    uint32_t gen_part = 0;
+    uint32_t bx_ = blockIdx.x - (mode_general(MODE) ? 0u : prep_wgs);
+    if constexpr (MODE == RENDER_GENERAL_TILES) {
+        bx_ = bx_ * gridDim.y + blockIdx.y;
+        gen_part = bx_ % GEN_SPLIT;
+        bx_ /= GEN_SPLIT;
+        if (bx_ * (64 * FPL) >= nframes) return;
+    }
+    const uint32_t bx = bx_;       // the tile (or, segmented: the tile counter) of this workgroup
     if constexpr (MODE == RENDER_GENERAL_ONLY) {       // (a segmented launch always writes its parts: see below)
         // a group without general voices in this launch: nothing to render, nothing to write (wave-uniform: scalar loads)
         const uint32_t c0g = (blockIdx.y * voices_per_group) / 64;
@@ -220,6 +273,37 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         }
     };
     if constexpr (!mode_has_lean(MODE)) build_frames(lane);        // (the lean loops work from the lane's first frame alone)
+    if constexpr (MODE == RENDER_GENERAL_TILES) {
+        // the (voice, tile) pairs of this tile that sound but are not lean, all voice groups': the masks of the classification tile
+        // are one contiguous row -- a lane fetches one mask per pass, the non-zero ones are handed round by ballot and readlane --
+        // and the pairs are dealt to the workgroups of the tile and their waves by their ordinal; each goes through the launch
+        // record and the general code
+        const uint32_t nmask = B.tiles.groups * B.tiles.mask_k;
+        const uint64_t* __restrict__ grow = B.tiles.gen + (size_t)(tile0 / TILE_FRAMES) * nmask;
+        if (tile_index == 0 && gen_part == 0 && threadIdx.x < B.tiles.groups) gen_valid[threadIdx.x] = threadIdx.x < GEN_SPLIT ? 1u : 0u;   // GEN_SPLIT general planes
+        uint32_t ord = 0;
+        for (uint32_t base = 0; base < nmask; base += 64) {
+            const uint32_t mi = base + lane;
+            const uint64_t mine = mi < nmask ? grow[mi] : 0ull;
+            uint64_t have = __ballot(mine != 0ull);
+            while (have) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(have);
+                have &= have - 1;
+                uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)src) << 32) |
+                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)src);
+                const uint32_t idx = base + src;                          // mask index in the row: (group, k)
+                const uint32_t c = idx / B.tiles.mask_k + (idx % B.tiles.mask_k) * B.tiles.groups;
+                while (m) {
+                    const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    if ((ord++ % (uint32_t)(WAVES * GEN_SPLIT)) != wave * GEN_SPLIT + gen_part) continue;
+                    const uint32_t vi = c * 64 + bit;
+                    const VoiceRegs r = load_record(as_const(curS.launch) + vi);
+                    general_voice<FPL>(r, curS.fm + vi, B, B.voices + vi, st0, tile0, nfr, i, di, trig, accl, accr);
+                }
+            }
+        }
+    }
     if constexpr (MODE == RENDER_DIRECT) {
         const uint32_t v0 = blockIdx.y * voices_per_group;
         uint32_t v1 = v0 + voices_per_group;
@@ -235,6 +319,78 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // Wave w takes every WAVES-th list entry; the offset carries over from chunk to chunk so that the waves'
     // shares of the whole group differ by at most one voice.
     uint32_t first = wave + sub * WAVES;                      // position in the current chunk's list this wave starts at
+    if constexpr (MODE == RENDER_LEAN_TILES) {
+        // this tile's lean pairs: per chunk of the group a compacted list of 256-byte records (the count: the bits of the chunk's
+        // mask), walked like the lean lists of an ordinary launch -- wave w takes every WAVES-th entry, the offset carries over
+        static_assert(64 * FPL == TILE_FRAMES, "the lean kernel's tile is the tile of the classification");
+        const size_t slots = set_slots(nvoices);
+        const TileRec SH_CONST_AS* trow = as_const(B.tiles.recs) + (size_t)tile_index * slots;
+        const double lane_d = (double)lane;
+        // The voice groups of a tile-classified launch do not partition the CHUNKS but every chunk's list: entry p of a list goes
+        // to group p / WAVES mod groups, wave p mod WAVES (the offset carries over from list to list) -- notes that sound together are
+        // neighbours in the voice table, whole chunks of them, and any deal of whole chunks leaves one group with twice the work of
+        // another.  The masks of the tile (one contiguous row) are fetched 64 at a time, one per lane; the lists that are not empty
+        // are handed round by ballot and readlane.
+        const uint32_t nmask = gridDim.y * B.tiles.mask_k, stride = gridDim.y * WAVES;
+        const uint64_t* __restrict__ lrow = B.tiles.lean + (size_t)tile_index * nmask;
+        uint32_t firstp = grp * WAVES + wave;
+        for (uint32_t base = 0; base < nmask; base += 64) {
+            const uint32_t mi = base + lane;
+            const uint64_t mymask = mi < nmask ? lrow[mi] : 0ull;
+            uint64_t have = __ballot(mymask != 0ull);
+            while (have) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(have);
+            have &= have - 1;
+            const uint64_t cmask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mymask >> 32), (int)src) << 32) |
+                                   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mymask, (int)src);
+            const uint32_t npairs = (uint32_t)__popcll(cmask);
+            const uint32_t idx = base + src;                              // mask index in the row: (group, k) of the prepare step's layout
+            const uint32_t c = idx / B.tiles.mask_k + (idx % B.tiles.mask_k) * gridDim.y;
+            const TileRec SH_CONST_AS* q = trow + c * 64 + firstp;
+            uint32_t p = firstp;
+            for (; p < npairs; p += stride, q += stride) {
+                const double t0 = q->t0, dt = q->dt, rc = q->rc, rs = q->rs, ea0 = q->ea0, ea1 = q->ea1, GL = q->GL, GR = q->GR;
+                const uint32_t pc = *reinterpret_cast<const uint32_t SH_CONST_AS*>(&q->npieces);      // npieces | corner << 16
+                // the voice of the list's entry p: the chunk's (p + 1)-th set bit -- its polynomial comes from the table by voice (read by
+                // every tile's workgroups: it lives in L2), at an address that does not wait for the record
+                const double SH_CONST_AS* pp = as_const(B.polys) + (size_t)(c * 64 + nth_set_bit(cmask, p)) * 16;
+                double poly[16];
+#pragma unroll
+                for (int v_ = 0; v_ < 16; ++v_) poly[v_] = pp[v_];
+                asm volatile("" :: "s"(t0), "s"(dt), "s"(rc), "s"(rs), "s"(ea0), "s"(ea1), "s"(GL), "s"(GR), "s"(pc),
+                             "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
+                             "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
+                             "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
+                const LaneTheta none{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0u, 0u, false};
+                if (pc == 1u) {
+                    // one piece, one line (seven pairs of eight): the lean arithmetic of an ordinary launch with the line folded into the gains
+                    double s0, c0s, s1, c1s;
+                    shm::sincos_tab(fma(lane_d, dt, t0), trig, s0, c0s);
+                    s1 = fma(s0, rc, c0s * rs);
+                    c1s = fma(c0s, rc, -(s0 * rs));
+                    lean_harm_frames<FPL, true>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL * ea0, GR * ea0, accl, accr, GL * ea1, GR * ea1, lane_d);
+                } else if ((pc & 0xFFFFu) == 1u) {
+                    // one piece, a corner: the envelope is the minimum of two lines
+                    const double eb0 = q->eb0, eb1 = q->eb1;
+                    double s0, c0s, s1, c1s;
+                    shm::sincos_tab(fma(lane_d, dt, t0), trig, s0, c0s);
+                    s1 = fma(s0, rc, c0s * rs);
+                    c1s = fma(c0s, rc, -(s0 * rs));
+                    lean_tile_frames<FPL>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL, GR, ea0, ea1, eb0, eb1, lane_d, accl, accr);
+                } else {
+                    // piece ends inside the tile: every frame by lookup from the piece that holds it
+                    const double eb0 = q->eb0, eb1 = q->eb1;
+                    const TileTheta theta{lane_d, t0, dt, q->tb[0], q->tb[1], q->db[0], q->db[1], lane, q->split[0], q->split[1]};
+                    double s0, c0s, s1, c1s;
+                    shm::sincos_tab(theta(0), trig, s0, c0s);
+                    shm::sincos_tab(theta(1), trig, s1, c1s);
+                    lean_tile_frames<FPL>(s0, c0s, s1, c1s, 0.0, true, theta, trig, poly, GL, GR, ea0, ea1, eb0, eb1, lane_d, accl, accr);
+                }
+            }
+            firstp = p - npairs;
+            }
+        }
+    } else
     if constexpr (!mode_general(MODE)) {
     for (uint32_t c = c0; c < c1; ++c) {
         const uint32_t nfast = as_const(curS.counts)[4 * c];
@@ -377,6 +533,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         asm volatile("" : "+v"(lane_late));       // defined here, after the loop above: the arrays cannot be built earlier
         build_frames(lane_late);
     }
+    if constexpr (MODE == RENDER_GENERAL_TILES) {
+        // (rendered above)
+    } else
     if constexpr (!mode_lean_only(MODE)) {
     for (uint32_t c = c0; c < c1; ++c) {
         const uint32_t ngen = as_const(curS.counts)[4 * c + 1];
@@ -415,7 +574,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             if (MODE == RENDER_GENERAL_SEG && to_scratch) {
                 B.gen_scratch[(size_t)(grp * nsub + sub) * nfr + raw] = make_double2(l, rr);
             } else if (parts) {
-                const uint32_t slot = mode_general(MODE) ? gridDim.y + grp : grp;
+                const uint32_t slot = MODE == RENDER_GENERAL_TILES ? B.tiles.groups + gen_part : (mode_general(MODE) ? gridDim.y + grp : grp);
                 parts[(size_t)slot * nframes + at] = make_double2(l, rr);
             } else {
                 if (bus32) bus32[at] = make_float2((float)l, (float)rr);
@@ -583,6 +742,11 @@ void free_render_buffers() {
         }
         release_pooled(b->gen_block);
         b->gen_segs = 0;
+        for (int k = 0; k < sh_bank::NTILESETS; ++k) {
+            release_pooled(b->tile_block[k]);
+            b->tile_carved[k] = 0;
+            b->tile_spec[k].valid = false;
+        }
     }
 }
 }  // namespace sh
@@ -691,9 +855,17 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // A transition launch (RENDER_*_SEG): cut where the envelopes become flat (every voice past its decay) and from there on
     // into segments no longer than their own distance from the note's start -- piece ends of the phase sum lie an octave apart,
     // so such a segment crosses at most one per voice; a cut, too, where the first voice leaves its sustain.  Tile-aligned cuts.
+    // A TILE-CLASSIFIED launch (RENDER_*_TILES): banks whose notes do not move in lock-step -- onsets, envelope corners of their
+    // own -- have no corners to cut a launch at, and nearly every voice holds a corner somewhere in a one-second block; but nearly
+    // every (voice, 512-frame tile) pair lies on one envelope line and one piece of the phase table.  Those pairs take the lean
+    // loop, the others the general code for that tile only (see TileRec).
+    bool tiled = false;
+    if (split && mode == RENDER_LEAN_HARM && var == 484 && b->all_lean && !K.no_tiles && !b->needs_rows &&
+        !b->no_general_voice(start, nframes) && (b->has_onsets || b->own_envelopes))
+        tiled = (uint64_t)sh::div_up(nframes, TILE_FRAMES) * set_slots(b->nvoices) * sizeof(TileRec) <= ((uint64_t)1 << 30);
     uint32_t seg_first[SEG_MAX + 1];
     uint32_t nseg = 0;
-    if (split && (mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_ALL) && var == 484 && b->all_lean && !K.no_seg && !b->needs_rows && !b->no_general_voice(start, nframes)) {
+    if (!tiled && split && (mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_ALL) && var == 484 && b->all_lean && !K.no_seg && !b->needs_rows && !b->no_general_voice(start, nframes)) {
         nseg = plan_segments(b, start, nframes, (uint64_t)(64 * F), ~0ull, true, seg_first);
         if (nseg < 2 || seg_first[nseg] != nframes) nseg = 0;        // nothing to cut, or more cuts than a launch carries
     }
@@ -741,7 +913,70 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // the workgroups that resolve those records: one per chunk of 64 voices, dispatched in front of the tiles' (prep_wgs per row of the grid)
     const uint32_t nchunks = sh::div_up(b->nvoices, 64);
     const uint32_t prep_wgs = (next.launch && !K.prepare_in_tile) ? sh::div_up(nchunks, groups) : 0u;
-    if (nseg) {
+    if (tiled) {
+        const uint32_t ntiles = sh::div_up(nframes, TILE_FRAMES);
+        const int ks = (int)(b->tile_count % sh_bank::NTILESETS);
+        if (!b->ev_tile_ready[0])
+            for (int k = 0; k < sh_bank::NTILESETS; ++k) {
+                SH_HIP(hipEventCreateWithFlags(&b->ev_tile_ready[k], hipEventDisableTiming));
+                SH_HIP(hipEventCreateWithFlags(&b->ev_tile_free[k], hipEventDisableTiming));
+            }
+        TileSet& T = b->tile_set[ks];
+        sh_bank::TileSpec& sp = b->tile_spec[ks];
+        BankPtrs P = ptrs(b);
+        if (sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups) {
+            // resolved on the prepare stream while the launch before last was being enqueued
+            SH_HIP(hipStreamWaitEvent(st, b->ev_tile_ready[ks], 0));
+        } else {
+            // not predicted (the first launches of a run, a jump): resolve it in front of the render -- behind whatever the
+            // prepare stream may still be writing into this set for a block that was not asked for
+            if (b->tile_ready_recorded[ks]) SH_HIP(hipStreamWaitEvent(st, b->ev_tile_ready[ks], 0));
+            rc = grow_tile_set(b->tile_block[ks], T, b->tile_carved[ks], ntiles, b->nvoices, groups, st);
+            if (rc) return rc;
+            P.tiles = T;
+            rc = launch_prepare_tiles(st, P, T, b->nvoices, start, nframes);
+            if (rc) return rc;
+        }
+        sp.valid = false;
+        P.tiles = T;
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(prep_wgs + tiles, groups), dim3(256), 0, st, P,
+                           trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
+        SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
+        {   // the general pairs: GEN_SPLIT workgroups per 256-frame tile, each all voice groups' pairs of it
+            LaunchSet none = cur;
+            none.launch = nullptr;
+            const uint32_t gen_wgs = sh::div_up(sh::div_up(nframes, 256) * GEN_SPLIT, groups);
+            // (on a stream of its own beside the lean kernel it was slower, 95 against 75 us per block: five streams share four
+            // hardware queues, and a kernel that waits for an event holds up whatever shares its queue)
+            hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs, groups), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, cur, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
+                               (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
+                               gen_valid, (const uint32_t*)nullptr, 0u);
+            SH_CHECK_LAUNCH("k_bank_render(general, tiles)");
+        }
+        SH_HIP(hipEventRecord(b->ev_tile_free[ks], st));
+        b->tile_free_recorded[ks] = true;
+        if (!K.no_speculation) {
+            // the tile set of the block expected two launches on (the set launch n - 2 read: its render must be over), on the
+            // prepare stream
+            const int k2 = (int)((b->tile_count + 2) % sh_bank::NTILESETS);
+            hipStream_t ps = S.prep_stream;
+            if (b->tile_free_recorded[k2]) SH_HIP(hipStreamWaitEvent(ps, b->ev_tile_free[k2], 0));
+            TileSet& T2 = b->tile_set[k2];
+            rc = grow_tile_set(b->tile_block[k2], T2, b->tile_carved[k2], ntiles, b->nvoices, groups, ps);
+            if (rc) return rc;
+            BankPtrs P2 = ptrs(b);
+            P2.tiles = T2;
+            rc = launch_prepare_tiles(ps, P2, T2, b->nvoices, next_start, nframes);
+            if (rc) return rc;
+            SH_HIP(hipEventRecord(b->ev_tile_ready[k2], ps));
+            b->tile_ready_recorded[k2] = true;
+            sh_bank::TileSpec& s2 = b->tile_spec[k2];
+            s2.valid = true; s2.start = next_start; s2.nframes = nframes; s2.groups = groups;
+        }
+        b->tile_count += 1;
+    } else if (nseg) {
         const int ks = use_aux ? 1 : 0;
         LaunchSet& g = b->seg_set[ks];
         rc = grow_segment_sets(b->seg_block[ks], g, b->seg_cap[ks], nseg, b->nvoices);

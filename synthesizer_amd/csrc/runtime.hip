@@ -32,6 +32,7 @@ void load_knobs() {
     k.no_overlap = flag("SYNTHHIP_NO_OVERLAP");
     k.no_split = flag("SYNTHHIP_NO_SPLIT");
     k.no_seg = flag("SYNTHHIP_NO_SEG");
+    k.no_tiles = flag("SYNTHHIP_NO_TILES");
     k.always_general = flag("SYNTHHIP_ALWAYS_GENERAL");
     k.no_small_pipeline = flag("SYNTHHIP_NO_SMALL_PIPELINE");
     k.prepare_in_tile = flag("SYNTHHIP_PREPARE_IN_TILE");
@@ -210,6 +211,7 @@ int sh_init(int device) {
     SH_HIP(hipSetDevice(device));
     SH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     SH_HIP(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+    SH_HIP(hipStreamCreateWithFlags(&s.prep_stream, hipStreamNonBlocking));
     SH_HIP(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
     SH_HIP(hipEventCreateWithFlags(&s.ev_aux, hipEventDisableTiming));
     SH_HIP(hipEventCreateWithFlags(&s.ev_prep, hipEventDisableTiming));
@@ -245,6 +247,7 @@ int sh_shutdown(void) {
     if (sh::has_pending()) sh::flush_pending();
     (void)hipStreamSynchronize(s.stream);
     (void)hipStreamSynchronize(s.stream2);
+    (void)hipStreamSynchronize(s.prep_stream);
     sh::free_render_buffers();
     if (s.scratch) sh::pool_free(s.scratch, s.scratch_bytes);
     sh::pool_trim();
@@ -253,6 +256,7 @@ int sh_shutdown(void) {
     (void)hipEventDestroy(s.ev_prep);
     (void)hipEventDestroy(s.ev_sync);
     (void)hipStreamDestroy(s.stream2);
+    (void)hipStreamDestroy(s.prep_stream);
     if (s.flag) (void)hipFree(s.flag);
     if (s.trig) (void)hipFree(s.trig);
     if (s.flag_host) (void)hipHostFree(s.flag_host);

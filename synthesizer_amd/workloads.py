@@ -48,3 +48,25 @@ def fm_voices(mod, n, samplerate, seed=0):
         lfo = mod.Sine(float(fm[i]), float(depth[i]), phase=float(pm[i]), samplerate=samplerate)
         voices.append(mod.Sine(float(f[i]), amplitude=float(amp[i]), phase=float(phase[i]), fm_lfo=lfo, samplerate=samplerate))
     return voices, gains
+
+
+def staggered_notes(mod, slots, samplerate, seed=0, partials=16, period=1.0, notes=11, adsr=None):
+    """Notes that do not move in lock-step: `slots` players, each re-triggering its note every `period` seconds; player s starts
+    its k-th note at (s / slots + k) * period -- the onsets are spread uniformly over the period -- and every note is a new voice
+    (phase and envelope start with it): Harmonics x `partials` under SURVEY 8(d)'s ADSR (attack 0.01, decay 0.05, sustain 0.5 at
+    level 0.6, release 0.2: 0.76 s of sound per note), delayed to its onset (DelayFilter).  slots * notes voices, in the order they
+    start within a round (all players' k-th notes are neighbours); gains[i] belongs to voices[i]."""
+    _, f, amp, phase, gains = _voice_params(slots, seed)
+    harm = [(k, 1.0 / k) for k in range(1, partials + 1)]
+    e = dict(ADSR)
+    if adsr:
+        e.update(adsr)
+    voices, vgains = [], []
+    for k in range(notes):
+        for s in range(slots):
+            onset = (s / slots + k) * period
+            osc = mod.Harmonics(float(f[s]), harm, amplitude=float(amp[s]), phase=float(phase[s]), samplerate=samplerate)
+            osc = mod.EnvelopeFilter(osc, e["attack"], e["decay"], e["sustain"], e["sustain_level"], e["release"])
+            voices.append(mod.DelayFilter(osc, onset) if onset else osc)
+            vgains.append(gains[s])
+    return voices, vgains

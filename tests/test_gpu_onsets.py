@@ -103,3 +103,68 @@ def test_notes_that_start_at_different_times(gpu):
         parts = np.concatenate([b.download(np.float32, block * 2).reshape(block, 2) for b in bufs])
         assert rms(parts, want[:len(parts)]) <= RMS_TOL, block
     assert rms(bank.render_two_step(20000, start=10000), want[10000:30000]) <= RMS_TOL
+
+
+_CHILD = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from synthesizer_amd import _native as N
+from synthesizer_amd import oscillators as G
+from synthesizer_amd.mixer import VoiceBank
+from synthesizer_amd.workloads import staggered_notes
+N.ensure_init(0)
+v, g = staggered_notes(G, 256, 48000, seed=4, period=0.5, notes=4)
+bank = VoiceBank(v, gains=g)
+out = [bank.render(24000, start=k * 24000) for k in range(4)]
+np.save(sys.argv[1], np.stack(out))
+'''
+
+
+def test_staggered_notes_tile_by_tile(gpu, tmp_path):
+    """The bench's staggered workload at a quarter of its size (256 players x 4 rounds, a note every half second): blocks of half a
+    second through the tile-classified launch (lean per (voice, tile) pair, general code for the pairs with an onset, a corner or a
+    piece end) against the C oracle -- and against the same blocks with the classification switched off (SYNTHHIP_NO_TILES=1: every
+    voice that holds a corner anywhere in the block goes through the general code)."""
+    import ctypes
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    from synthesizer_amd.workloads import staggered_notes
+    slots, notes, period, block = 256, 4, 0.5, 24000
+    gv, gains = staggered_notes(G, slots, SR, seed=4, period=period, notes=notes)
+    ov, _ = staggered_notes(O, slots, SR, seed=4, period=period, notes=notes)
+    n = 4 * block
+    rows = np.zeros((len(ov), n))
+    for i, v in enumerate(ov):
+        d = int(SR * v._seconds) if isinstance(v, O.DelayFilter) else 0
+        if d < n:
+            rows[i, d:] = CO.render(v._source if isinstance(v, O.DelayFilter) else v, n - d)
+    want = CO.mix_bus(rows, gains)
+    bank = VoiceBank(gv, gains=gains)
+    got = [bank.render(block, start=k * block) for k in range(4)]
+    for k in range(4):
+        assert rms(got[k], want[k * block:(k + 1) * block]) <= RMS_TOL, k
+    assert np.abs(want).max() > 0.05
+    # a pipelined run of the same blocks (records two launches ahead, folds taken over, tile sets per stream)
+    ring = [N.DeviceBuffer(block * 8) for _ in range(4)]
+    for k in range(4):
+        bank.render_device(block, k * block, bus_f32=ring[k])
+    for k in range(4):
+        assert np.array_equal(ring[k].download(np.float32, block * 2).reshape(block, 2), got[k]), k
+    # one long launch over everything (another tile count, a partial last tile)
+    whole = bank.render(n - 100)
+    assert rms(whole, want[:n - 100]) <= RMS_TOL
+    # the classification switched off: same buses up to float64 rounding (the lean pairs fold the envelope's line into the gains)
+    ref = tmp_path / "notiles.npy"
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SYNTHHIP_") or k in ("SYNTHHIP_LIB", "SYNTHHIP_DEVICE")}
+    p = subprocess.run([sys.executable, "-c", _CHILD % str(root), str(ref)], env=dict(env, SYNTHHIP_NO_TILES="1"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    other = np.load(ref)
+    for k in range(4):
+        assert rms(got[k], other[k]) <= 2e-8, k
