@@ -258,13 +258,14 @@ def config_roofline(prof, tag, voice_samples, ms, algorithmic_bytes):
     per dispatch against the algorithmic bytes."""
     best, name = None, None
     for k_, v_ in prof["counters"].items():
-        if k_.startswith(tag + ":") and "k_bank_render" in k_ and (best is None or v_.get("SQ_INSTS_VALU_FMA_F64", 0) > best.get("SQ_INSTS_VALU_FMA_F64", 0)):
-            best, name = v_, k_
+        m = re.match(re.escape(tag) + r":k_bank_render<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)>", k_)
+        if m and int(m.group(1)) < 6 and (best is None or v_.get("SQ_INSTS_VALU_FMA_F64", 0) > best.get("SQ_INSTS_VALU_FMA_F64", 0)):
+            best, name = v_, k_             # (modes 6 .. 8: the segmented transition launch of the loop's first block, not the steady state)
     if not best or not all(k in best for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")):
         return {"bound": "valu_f64", "note": "no counters for this config in profiles/ (tools/profile_round.sh writes them)"}
     ops = (best["SQ_INSTS_VALU_FMA_F64"] + best["SQ_INSTS_VALU_MUL_F64"] + best["SQ_INSTS_VALU_ADD_F64"]) * 64.0 / voice_samples
     achieved = voice_samples * ops / (ms / 1e3) / 1e12
-    traffic = sum(v_["hbm_bytes"] for k_, v_ in prof["traffic"].items() if k_.startswith(tag + ":") and "k_bank_render" in k_) or None
+    traffic = prof["traffic"].get(name, {}).get("hbm_bytes")
     return {"kernel": name.split(":", 1)[1], "bound": "valu_f64", "ops_per_voice_sample": ops, "achieved": achieved, "peak": FP64_PEAK_TOPS,
             "unit": "T f64 lane-ops/s", "frac": achieved / FP64_PEAK_TOPS, "avg_launch_ms": ms,
             "valu_busy_note": "all VALU wave-instructions x 4 cycles / 1024 SIMDs / launch time = %.2f" %
