@@ -57,7 +57,6 @@ struct State {
     hipEvent_t  ev_aux = nullptr;       // on stream2 after every launch there: `stream` waits for it when the run ends
     hipEvent_t  ev_prep = nullptr;      // on `stream` after a prepare kernel that a stream2 launch needs
     hipEvent_t  ev_sync = nullptr;      // join_streams: on `stream`, waited for by stream2
-    hipStream_t prep_stream = nullptr;  // the tile sets of tile-classified launches are resolved here, two launches ahead (osc_render.hip)
     bool        aux_busy = false;       // stream2 holds work `stream` has not waited for
 };
 

@@ -88,7 +88,7 @@ struct TileSet {
     uint64_t* lean;               // bit b = voice 64 c + b is lean in this tile
     uint64_t* gen;                // ... takes the general code in this tile
     uint32_t  groups, mask_k;
-    uint32_t  gen_wgs;            // general workgroups per row of the render kernel's grid (RENDER_LEAN_TILES)
+    uint32_t  gen_wgs;            // (unused)
 };
 __host__ __device__ __forceinline__ uint32_t tile_mask_k(uint32_t nvoices, uint32_t groups) {
     const uint32_t nchunks = (nvoices + 63) / 64;
@@ -123,6 +123,10 @@ struct BankPtrs {
     // per launch (tile-classified launches, RENDER_*_TILES): the launch's tile set; polys = [slot][16] polynomial coefficients by voice
     TileSet           tiles;
     const double*     polys;
+    // ... and the set that launch resolves for the block expected two launches on (next_tiles.recs = NULL: none): next_tile_wgs
+    // workgroups per row of the grid, behind the workgroups that resolve that block's launch records
+    TileSet           next_tiles;
+    uint32_t          next_tile_wgs, next_ntiles;
 };
 
 // Pointers to data that no thread of the running kernel writes are cast to the constant address space:
@@ -1018,5 +1022,177 @@ __device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1
         }
     }
 }
+
+// The tile set of a tile-classified launch (see TileRec): one wavefront, lane = voice of chunk c, walks run `run` of TILES_PER_WAVE tiles in order -- the piece of the phase table that holds a tile's first frame is the one of
+// the tile before or a later one (a binary search for the first tile that sounds, a forward walk from there) -- classifies each
+// (voice, tile) pair, writes the 64-byte record of the lean ones and, by two ballots per tile, the masks of the chunk.
+// (Four wavefronts per workgroup, a run of tiles each: the chunks whose voices are all silent in the launch -- most of a table of
+// notes -- cost four waves that leave after one load, not one per pair of tiles.)
+constexpr uint32_t TILES_PER_WAVE = 3;
+__device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes,
+                                                   uint32_t ntiles, uint32_t c, uint32_t run) {
+    const uint32_t lane = threadIdx.x & 63, vi = c * 64 + lane;
+    const size_t slots = set_slots(nvoices);
+    const uint32_t t_begin = run * TILES_PER_WAVE;
+    if (t_begin >= ntiles) return;
+    uint32_t t_end = t_begin + TILES_PER_WAVE;
+    if (t_end > ntiles) t_end = ntiles;
+    const bool valid = vi < nvoices;
+    const sh_voice& v = B.voices[valid ? vi : 0];
+    const bool lean_capable = valid && v.kind == SH_HARMONICS && v.harm_dense == 2 && v.fm_mode == SH_FM_NONE && v.bias == 0.0 && !v.flip;
+    const bool fm = v.fm_mode != SH_FM_NONE;
+    const uint32_t off = fm ? v.time_seg_offset : v.seg_offset;
+    const uint32_t cnt = fm ? v.time_seg_count : v.seg_count;
+    const sh_segment* tab = B.segs + off;
+    const uint64_t onset = v.start_frame;
+    const sh_envelope e = v.env;
+    const double amp = v.amplitude, bgl = (double)v.gain_l, bgr = (double)v.gain_r;
+    {   // a chunk whose voices are all silent throughout the launch (notes that have not started, notes that are over): empty masks
+        const bool sounds_in_launch = valid && start + (uint64_t)nframes > onset &&
+                                      !(e.enabled && start > onset + e.n_release_end);       // (>: the extra sample sits AT the release's end)
+        if (__ballot(sounds_in_launch) == 0) {
+            if (lane == 0)
+                for (uint32_t t = t_begin; t < t_end; ++t) {
+                    const size_t at = ((size_t)t * T.groups + c % T.groups) * T.mask_k + c / T.groups;
+                    T.lean[at] = 0;
+                    T.gen[at] = 0;
+                }
+            return;
+        }
+    }
+    uint32_t lo = 0;
+    bool lo_found = false;
+    uint64_t next_n0 = 0;                       // start of piece lo + 1 (2^64 - 1: none)
+    double p_t0 = 0.0, p_dt = 0.0;
+    uint64_t p_n0 = 0;
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+        const uint64_t abs0 = start + (uint64_t)t * TILE_FRAMES;
+        uint64_t abs1 = abs0 + TILE_FRAMES;
+        if (abs1 > start + (uint64_t)nframes) abs1 = start + (uint64_t)nframes;
+        bool is_lean = false, is_gen = false;
+        double rec_t0 = 0.0, rec_ea0 = 0.0, rec_ea1 = 0.0, rec_eb0 = 0.0, rec_eb1 = 0.0;
+        uint32_t rec_extra = 0, rec_env_max = 0;
+        uint16_t rec_split[2] = {0xFFFFu, 0xFFFFu};
+        if (valid && abs1 > onset) {
+            // the voice's own indices [n0, n1) of the tile; n0 < 0: the onset lies inside
+            const long long n0 = (long long)abs0 - (long long)onset, n1 = (long long)abs1 - (long long)onset;
+            const double dn0 = (double)n0;
+            // ---- envelope: the line that holds n0 (-1: the silence in front of the onset) and, if one corner lies inside the
+            // tile, the line behind it ----
+            double ea0 = 1.0, ea1 = 0.0, eb0 = 1.0, eb1 = 0.0;
+            uint32_t env_max = 0;
+            bool env_ok = true, sounds = true;
+            if (e.enabled) {
+                const long long cn[4] = {(long long)e.n_attack_end, (long long)e.n_decay_end, (long long)e.n_sustain_end, (long long)e.n_release_end};
+                const int p = (n0 >= 0) + (n0 >= cn[0]) + (n0 >= cn[1]) + (n0 >= cn[2]) + (n0 >= cn[3]) - 1;
+                const int p1 = (n1 - 1 >= 0) + (n1 - 1 >= cn[0]) + (n1 - 1 >= cn[1]) + (n1 - 1 >= cn[2]) + (n1 - 1 >= cn[3]) - 1;     // the tile's last frame
+                // line k at the voice's index n, as value at n0 and slope: -1 silence, 0 attack, 1 decay, 2 sustain, 3 release, 4 silence
+                auto line = [&](int k, double& v0, double& v1) {
+                    if (k == 0) { v0 = dn0 * e.attack_slope; v1 = e.attack_slope; }
+                    else if (k == 1) { v0 = fma(dn0 - (double)cn[0], e.decay_slope, 1.0); v1 = e.decay_slope; }
+                    else if (k == 2) { v0 = e.sustain_level; v1 = 0.0; }
+                    else if (k == 3) { v0 = fma(dn0 - (double)cn[2], e.release_slope, e.sustain_level); v1 = e.release_slope; }
+                    else { v0 = 0.0; v1 = 0.0; }
+                };
+                if (p == 4) {                                // behind the release: silent, but for the one extra sample at its end
+                    sounds = e.has_tail && n0 == cn[3];
+                    env_ok = false;
+                } else if (p1 == p) {
+                    line(p, ea0, ea1);
+                    eb0 = ea0; eb1 = ea1;
+                } else if (p1 == p + 1) {                    // one corner inside: convex (max) behind silence, decay and release; concave (min) behind attack and sustain
+                    line(p, ea0, ea1);
+                    line(p + 1, eb0, eb1);
+                    env_max = (uint32_t)(p & 1);             // p = -1, 1, 3
+                } else {
+                    env_ok = false;                          // two corners in one tile (lines of zero length included)
+                }
+            } else if (n0 < 0) {
+                env_ok = false;                              // an onset without an envelope is a step: not the meeting of two lines
+            }
+            if (sounds) {
+                // ---- phase table: the piece that holds max(n0, 0), and the ends of pieces inside the tile ----
+                const uint64_t nn0 = n0 > 0 ? (uint64_t)n0 : 0ull;
+                if (!lo_found) {
+                    // from the voice's hint (the piece of the last launch that was resolved for it: the same or a neighbour in a
+                    // stream of blocks; any value is safe -- it is walked into place)
+                    uint32_t a = B.hint[vi];
+                    if (a >= cnt) a = cnt - 1;
+                    uint32_t steps = 0;
+                    while (a > 0 && tab[a].n0 > nn0 && steps < 4) { --a; ++steps; }
+                    while (a + 1 < cnt && tab[a + 1].n0 <= nn0 && steps < 8) { ++a; ++steps; }
+                    if (tab[a].n0 > nn0 || (a + 1 < cnt && tab[a + 1].n0 <= nn0)) {     // far off: search
+                        a = 0;
+                        uint32_t hi = cnt - 1;
+                        while (a < hi) {
+                            const uint32_t mid = (a + hi + 1) >> 1;
+                            if (tab[mid].n0 <= nn0) a = mid; else hi = mid - 1;
+                        }
+                    }
+                    lo = a;
+                    lo_found = true;
+                    p_n0 = tab[lo].n0; p_t0 = tab[lo].t0; p_dt = tab[lo].dt;
+                    next_n0 = lo + 1 < cnt ? tab[lo + 1].n0 : ~0ull;
+                }
+                while (next_n0 <= nn0) {
+                    ++lo;
+                    p_n0 = next_n0; p_t0 = tab[lo].t0; p_dt = tab[lo].dt;
+                    next_n0 = lo + 1 < cnt ? tab[lo + 1].n0 : ~0ull;
+                }
+                // pieces lo + 1 .. that start inside the tile (at most TILE_MAX_PIECES - 1 for a lean pair)
+                uint32_t extra = 0;
+                uint64_t starts[TILE_MAX_PIECES];
+                starts[0] = next_n0;
+#pragma unroll
+                for (uint32_t k = 0; k < TILE_MAX_PIECES; ++k) {
+                    if (extra == k && starts[k] < (uint64_t)n1) {
+                        extra = k + 1;
+                        if (k + 1 < TILE_MAX_PIECES) starts[k + 1] = lo + 2 + k < cnt ? tab[lo + 2 + k].n0 : ~0ull;
+                    }
+                }
+                is_lean = lean_capable && env_ok && extra < TILE_MAX_PIECES;
+                is_gen = !is_lean;
+                if (is_lean) {
+                    rec_t0 = fma(dn0 - (double)p_n0, p_dt, p_t0);
+                    rec_ea0 = ea0; rec_ea1 = ea1; rec_eb0 = eb0; rec_eb1 = eb1;
+                    rec_extra = extra;
+                    rec_env_max = env_max;
+#pragma unroll
+                    for (uint32_t k = 0; k < 2; ++k) rec_split[k] = k < extra ? (uint16_t)((long long)starts[k] - n0) : (uint16_t)0xFFFFu;
+                }
+            }
+        }
+        const uint64_t ml = __ballot(is_lean), mg = __ballot(is_gen);
+        if (is_lean) {                                           // the chunk's lean pairs, compacted in voice order
+            TileRec* __restrict__ q = T.recs + (size_t)t * slots + c * 64 + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
+            const bool corner = !(rec_ea0 == rec_eb0 && rec_ea1 == rec_eb1);
+            const double sg = (corner && rec_env_max) ? -1.0 : 1.0;        // a convex corner: max(a, b) g = min(-a, -b) (-g)
+            const double2 rot = B.seg_rot[off + lo];
+            q->t0 = rec_t0;
+            q->dt = p_dt;
+            q->rc = rot.x;
+            q->rs = rot.y;
+            q->ea0 = sg * rec_ea0; q->ea1 = sg * rec_ea1; q->eb0 = sg * rec_eb0; q->eb1 = sg * rec_eb1;
+            q->GL = sg * (amp * bgl);
+            q->GR = sg * (amp * bgr);
+#pragma unroll
+            for (uint32_t k = 0; k < 2; ++k) {
+                const bool have = k < rec_extra;
+                q->tb[k] = have ? tab[lo + 1 + k].t0 : 0.0;
+                q->db[k] = have ? tab[lo + 1 + k].dt : 0.0;
+                q->split[k] = rec_split[k];
+            }
+            q->npieces = (uint16_t)(1 + rec_extra);
+            q->corner = corner ? 1 : 0;
+            q->pad_ = 0.0;
+        }
+        if (lane == 0) {
+            const size_t at = ((size_t)t * T.groups + c % T.groups) * T.mask_k + c / T.groups;
+            T.lean[at] = ml;
+            T.gen[at] = mg;
+        }
+    }
+}
+
 
 }  // namespace shosc

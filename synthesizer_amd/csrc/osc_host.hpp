@@ -38,16 +38,14 @@ struct sh_bank {
     LaunchSet   seg_set[2] = {};
     uint32_t    seg_cap[2] = {0, 0};
     sh::Pooled  seg_scratch[2];            // ... and the slices of its first segment's general parts (BankPtrs::gen_scratch)
-    // The tile sets of tile-classified launches: a ring of four.  Launch n uses set n % 4; while it is being enqueued, the set of
-    // the block expected two launches on is resolved on the PREPARE stream (tile_spec says for which block; ev_tile_ready is
-    // recorded behind that kernel, ev_tile_free behind the last render that read a set) -- beside the renders, not in front of one.
+    // The tile sets of tile-classified launches: a ring of four.  Launch n uses set n % 4 and resolves, in workgroups of its own
+    // render kernel, the set of the block expected two launches on (tile_spec says for which block): set (n + 2) % 4, last read by
+    // launch n - 2 -- the launch before on the same stream.
     static constexpr int NTILESETS = 4;
     sh::Pooled  tile_block[NTILESETS];
     TileSet     tile_set[NTILESETS] = {};
     uint32_t    tile_carved[NTILESETS] = {0, 0, 0, 0};   // tiles the set was carved for
     struct TileSpec { bool valid = false; uint64_t start = 0; uint32_t nframes = 0, groups = 0; } tile_spec[NTILESETS];
-    hipEvent_t  ev_tile_ready[NTILESETS] = {}, ev_tile_free[NTILESETS] = {};
-    bool        tile_ready_recorded[NTILESETS] = {false, false, false, false}, tile_free_recorded[NTILESETS] = {false, false, false, false};
     uint32_t    tile_count = 0;            // tile-classified launches so far
     struct Range { const char* lo; const char* hi; };
     Range       last_direct[3] = {};       // what the last launch wrote itself (single-group launches: float32 / float64 / PCM bus)

@@ -113,10 +113,24 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             return;
         }
     }
+    // RENDER_LEAN_TILES: behind the workgroups that resolve the launch records of the block two launches on come B.next_tile_wgs
+    // workgroups per row of the grid that resolve its TILE SET: four wavefronts each, a run of TILES_PER_WAVE tiles of one chunk per
+    // wavefront (prepare_tiles_wave) -- the chunks whose voices are all silent in that block leave after one load.  (As a kernel of
+    // its own on a third stream this step took 50 us beside the renders and, sharing a hardware queue with one of the render
+    // streams, sat in front of that stream's next launch.)
+    if constexpr (MODE == RENDER_LEAN_TILES) {
+        if (B.next_tile_wgs && blockIdx.x >= prep_wgs && blockIdx.x < prep_wgs + B.next_tile_wgs) {
+            const uint32_t runs = (B.next_ntiles + TILES_PER_WAVE - 1) / TILES_PER_WAVE, wgs_per_chunk = (runs + 3) / 4;
+            const uint32_t unit = blockIdx.y * B.next_tile_wgs + (blockIdx.x - prep_wgs);
+            const uint32_t c = unit / wgs_per_chunk, run = (unit % wgs_per_chunk) * 4 + (threadIdx.x >> 6);
+            if (c < (nvoices + 63) / 64) prepare_tiles_wave(B, B.next_tiles, nvoices, next_start, nframes, B.next_ntiles, c, run);
+            return;
+        }
+    }
     // RENDER_GENERAL_TILES: workgroup (x, y) renders the general pairs of ONE tile of 64 FPL frames, ALL voice groups' -- part
     // gen_part of GEN_SPLIT of them -- into plane gen_part of the general parts.
     uint32_t gen_part = 0;
-    uint32_t bx_ = blockIdx.x - (mode_general(MODE) ? 0u : prep_wgs);
+    uint32_t bx_ = blockIdx.x - (mode_general(MODE) ? 0u : prep_wgs) - (MODE == RENDER_LEAN_TILES ? B.next_tile_wgs : 0u);
     if constexpr (MODE == RENDER_GENERAL_TILES) {
         bx_ = bx_ * gridDim.y + blockIdx.y;
         gen_part = bx_ % GEN_SPLIT;
@@ -916,21 +930,11 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     if (tiled) {
         const uint32_t ntiles = sh::div_up(nframes, TILE_FRAMES);
         const int ks = (int)(b->tile_count % sh_bank::NTILESETS);
-        if (!b->ev_tile_ready[0])
-            for (int k = 0; k < sh_bank::NTILESETS; ++k) {
-                SH_HIP(hipEventCreateWithFlags(&b->ev_tile_ready[k], hipEventDisableTiming));
-                SH_HIP(hipEventCreateWithFlags(&b->ev_tile_free[k], hipEventDisableTiming));
-            }
         TileSet& T = b->tile_set[ks];
         sh_bank::TileSpec& sp = b->tile_spec[ks];
         BankPtrs P = ptrs(b);
-        if (sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups) {
-            // resolved on the prepare stream while the launch before last was being enqueued
-            SH_HIP(hipStreamWaitEvent(st, b->ev_tile_ready[ks], 0));
-        } else {
-            // not predicted (the first launches of a run, a jump): resolve it in front of the render -- behind whatever the
-            // prepare stream may still be writing into this set for a block that was not asked for
-            if (b->tile_ready_recorded[ks]) SH_HIP(hipStreamWaitEvent(st, b->ev_tile_ready[ks], 0));
+        if (!(sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups)) {
+            // not predicted (the first launches of a run, a jump): resolve it in front of the render
             rc = grow_tile_set(b->tile_block[ks], T, b->tile_carved[ks], ntiles, b->nvoices, groups, st);
             if (rc) return rc;
             P.tiles = T;
@@ -938,8 +942,22 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             if (rc) return rc;
         }
         sp.valid = false;
+        // the tile set of the block expected two launches on: set (n + 2) % 4 -- read last by launch n - 2, the launch before on
+        // this stream -- resolved by workgroups of this launch's render kernel
+        if (next.launch) {
+            const int k2 = (int)((b->tile_count + 2) % sh_bank::NTILESETS);
+            TileSet& T2 = b->tile_set[k2];
+            rc = grow_tile_set(b->tile_block[k2], T2, b->tile_carved[k2], ntiles, b->nvoices, groups, st);
+            if (rc) return rc;
+            P.next_tiles = T2;
+            P.next_ntiles = ntiles;
+            const uint32_t runs = sh::div_up(ntiles, TILES_PER_WAVE), units = nchunks * sh::div_up(runs, 4);
+            P.next_tile_wgs = sh::div_up(units, groups);
+            sh_bank::TileSpec& s2 = b->tile_spec[k2];
+            s2.valid = true; s2.start = next_start; s2.nframes = nframes; s2.groups = groups;
+        }
         P.tiles = T;
-        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(prep_wgs + tiles, groups), dim3(256), 0, st, P,
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(prep_wgs + P.next_tile_wgs + tiles, groups), dim3(256), 0, st, P,
                            trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
                            o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
         SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
@@ -954,26 +972,6 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
                                (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
                                gen_valid, (const uint32_t*)nullptr, 0u);
             SH_CHECK_LAUNCH("k_bank_render(general, tiles)");
-        }
-        SH_HIP(hipEventRecord(b->ev_tile_free[ks], st));
-        b->tile_free_recorded[ks] = true;
-        if (!K.no_speculation) {
-            // the tile set of the block expected two launches on (the set launch n - 2 read: its render must be over), on the
-            // prepare stream
-            const int k2 = (int)((b->tile_count + 2) % sh_bank::NTILESETS);
-            hipStream_t ps = S.prep_stream;
-            if (b->tile_free_recorded[k2]) SH_HIP(hipStreamWaitEvent(ps, b->ev_tile_free[k2], 0));
-            TileSet& T2 = b->tile_set[k2];
-            rc = grow_tile_set(b->tile_block[k2], T2, b->tile_carved[k2], ntiles, b->nvoices, groups, ps);
-            if (rc) return rc;
-            BankPtrs P2 = ptrs(b);
-            P2.tiles = T2;
-            rc = launch_prepare_tiles(ps, P2, T2, b->nvoices, next_start, nframes);
-            if (rc) return rc;
-            SH_HIP(hipEventRecord(b->ev_tile_ready[k2], ps));
-            b->tile_ready_recorded[k2] = true;
-            sh_bank::TileSpec& s2 = b->tile_spec[k2];
-            s2.valid = true; s2.start = next_start; s2.nframes = nframes; s2.groups = groups;
         }
         b->tile_count += 1;
     } else if (nseg) {

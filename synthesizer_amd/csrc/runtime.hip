@@ -211,7 +211,6 @@ int sh_init(int device) {
     SH_HIP(hipSetDevice(device));
     SH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     SH_HIP(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
-    SH_HIP(hipStreamCreateWithFlags(&s.prep_stream, hipStreamNonBlocking));
     SH_HIP(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
     SH_HIP(hipEventCreateWithFlags(&s.ev_aux, hipEventDisableTiming));
     SH_HIP(hipEventCreateWithFlags(&s.ev_prep, hipEventDisableTiming));
@@ -247,7 +246,6 @@ int sh_shutdown(void) {
     if (sh::has_pending()) sh::flush_pending();
     (void)hipStreamSynchronize(s.stream);
     (void)hipStreamSynchronize(s.stream2);
-    (void)hipStreamSynchronize(s.prep_stream);
     sh::free_render_buffers();
     if (s.scratch) sh::pool_free(s.scratch, s.scratch_bytes);
     sh::pool_trim();
@@ -256,7 +254,6 @@ int sh_shutdown(void) {
     (void)hipEventDestroy(s.ev_prep);
     (void)hipEventDestroy(s.ev_sync);
     (void)hipStreamDestroy(s.stream2);
-    (void)hipStreamDestroy(s.prep_stream);
     if (s.flag) (void)hipFree(s.flag);
     if (s.trig) (void)hipFree(s.trig);
     if (s.flag_host) (void)hipHostFree(s.flag_host);
