@@ -114,6 +114,7 @@ BankPtrs ptrs(const sh_bank* b) {
     p.next_tile_wgs = 0;
     p.next_ntiles = 0;
     p.polys = b->d_polys;
+    p.chunk_span = b->d_chunk_span;
     return p;
 }
 
@@ -146,10 +147,10 @@ int prepare_single(sh_bank* b, uint32_t first, uint32_t count, uint64_t start, u
 // that was predicted (sequential streaming), else run k_prepare.
 // `launch_stream`: the stream the consuming kernel goes to.  `in_run`: the previous render launch of this bank may still
 // be executing on the other stream -- its set (b->cur) and the set it is filling (b->last_target) must not be touched.
-int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t launch_stream, bool in_run) {
+int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t launch_stream, bool in_run, bool accept_sparse) {
     sh::State& S = sh::state();
     for (int k = 0; k < sh_bank::NSETS; ++k) {
-        if (b->spec[k].valid && b->spec[k].start == start && b->spec[k].nframes == nframes) {
+        if (b->spec[k].valid && b->spec[k].start == start && b->spec[k].nframes == nframes && (accept_sparse || !b->spec[k].sparse)) {
             b->spec[k].valid = false;                    // consumed: the set is this launch's from here on
             b->cur = k;
             b->d_launch = b->d_launch_buf[k];
@@ -372,6 +373,20 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             if (voices[i].kind == SH_HARMONICS && voices[i].harm_dense == 2)
                 for (int u = 0; u < 16; ++u) polys[(size_t)i * 16 + u] = coefs[voices[i].harm_offset + u];
         if (!rc) rc = upload_array(&b->d_polys, polys.data(), polys.size(), st);
+        // ... and per chunk of 64 voices the frames in which any of them sounds (the extra sample sits AT the release's end)
+        std::vector<uint64_t> span(2 * (size_t)sh::div_up(nvoices, 64));
+        for (uint32_t c = 0; c < sh::div_up(nvoices, 64); ++c) {
+            uint64_t lo = ~0ull, hi = 0;
+            for (uint32_t i = c * 64; i < nvoices && i < c * 64 + 64; ++i) {
+                const uint64_t on = voices[i].start_frame;
+                const uint64_t end = voices[i].env.enabled ? on + voices[i].env.n_release_end + 1 : ~0ull;
+                lo = on < lo ? on : lo;
+                hi = (end < on || end > hi) ? (end < on ? ~0ull : end) : hi;
+            }
+            span[2 * c] = lo;
+            span[2 * c + 1] = hi;
+        }
+        if (!rc) rc = upload_array(&b->d_chunk_span, span.data(), span.size(), st);
     }
     if (!rc) rc = upload_array(&b->d_seg_rot, seg_rot.data(), nsegs, st);
     if (!rc) rc = upload_array(&b->d_lfo_rot, lfo_rot.data(), nvoices, st);
@@ -433,6 +448,7 @@ int sh_bank_destroy(sh_bank* b) {
         if (b->d_pwm_row) (void)hipFree(b->d_pwm_row);
         if (b->d_seg_rot) (void)hipFree(b->d_seg_rot);
         if (b->d_polys) (void)hipFree(b->d_polys);
+        if (b->d_chunk_span) (void)hipFree(b->d_chunk_span);
         for (int k = 0; k < sh_bank::NTILESETS; ++k) sh::release_pooled(b->tile_block[k]);
         if (b->d_lfo_rot) (void)hipFree(b->d_lfo_rot);
     }

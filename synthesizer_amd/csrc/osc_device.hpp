@@ -55,7 +55,7 @@ struct alignas(64) TileRec {
     uint16_t corner;              // 1: the two lines differ
     double pad_;
 };
-static_assert(sizeof(TileRec) == 128, "TileRec layout");
+static_assert(sizeof(TileRec) == 128 && offsetof(TileRec, GL) == 64 && offsetof(TileRec, tb) == 80 && offsetof(TileRec, split) == 112, "TileRec layout");
 // the position of the (p + 1)-th set bit of m (p < popcount(m)): wave-uniform scalar arithmetic, six halvings
 __device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t p) {
     uint32_t pos = 0;
@@ -123,6 +123,9 @@ struct BankPtrs {
     // per launch (tile-classified launches, RENDER_*_TILES): the launch's tile set; polys = [slot][16] polynomial coefficients by voice
     TileSet           tiles;
     const double*     polys;
+    // per chunk of 64 voices: [first onset, last frame of sound + 1) of its voices (2^64 - 1: no end) -- a chunk silent throughout
+    // a launch costs the classification one scalar load
+    const uint64_t*   chunk_span;
     // ... and the set that launch resolves for the block expected two launches on (next_tiles.recs = NULL: none): next_tile_wgs
     // workgroups per row of the grid, behind the workgroups that resolve that block's launch records
     TileSet           next_tiles;
@@ -1023,12 +1026,29 @@ __device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1
     }
 }
 
-// The tile set of a tile-classified launch (see TileRec): one wavefront, lane = voice of chunk c, walks run `run` of TILES_PER_WAVE tiles in order -- the piece of the phase table that holds a tile's first frame is the one of
-// the tile before or a later one (a binary search for the first tile that sounds, a forward walk from there) -- classifies each
-// (voice, tile) pair, writes the 64-byte record of the lean ones and, by two ballots per tile, the masks of the chunk.
-// (Four wavefronts per workgroup, a run of tiles each: the chunks whose voices are all silent in the launch -- most of a table of
-// notes -- cost four waves that leave after one load, not one per pair of tiles.)
-constexpr uint32_t TILES_PER_WAVE = 3;
+// The tile set of a tile-classified launch (see TileRec): one wavefront, lane = voice of chunk c, walks run `run` of
+// TILES_PER_WAVE tiles in order, classifies each (voice, tile) pair, writes the 128-byte record of the lean ones and, by two
+// ballots per tile, the masks of the chunk.
+// A lane's chain of dependent round trips IS the time this step takes (nothing hides a lone wavefront's latency, and inside the
+// render kernel a prepare workgroup holds a slot the tiles' workgroups want): so the loads come in three batches -- the voice and
+// its hint; the starts of the pieces around the hint; a WINDOW of TILE_WIN pieces (start, t0, dt) from the piece that
+// holds the run's first frame -- and the tiles of the run are classified from registers: the piece of a tile and the ends of
+// pieces inside it are picks from the window, which slides (one more batch) only where a lane runs out of it -- the first
+// tiles of a note, whose phase sum runs through a binade every few frames.  (Round 3, first version: a dependent load per
+// piece end and tile, three tiles per wave: 32 us as a kernel of its own, and inside the render kernel its workgroups cost the
+// launch 28 us.)
+#ifndef SH_TPW
+#define SH_TPW 6
+#endif
+constexpr uint32_t TILES_PER_WAVE = SH_TPW;
+constexpr int TILE_WIN = 6;
+template <typename V>
+__device__ __forceinline__ V win_pick(const V (&a)[TILE_WIN], uint32_t r, V beyond) {
+    V x = beyond;
+#pragma unroll
+    for (int k = 0; k < TILE_WIN; ++k) x = r == (uint32_t)k ? a[k] : x;
+    return x;
+}
 __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes,
                                                    uint32_t ntiles, uint32_t c, uint32_t run) {
     const uint32_t lane = threadIdx.x & 63, vi = c * 64 + lane;
@@ -1038,19 +1058,10 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
     uint32_t t_end = t_begin + TILES_PER_WAVE;
     if (t_end > ntiles) t_end = ntiles;
     const bool valid = vi < nvoices;
-    const sh_voice& v = B.voices[valid ? vi : 0];
-    const bool lean_capable = valid && v.kind == SH_HARMONICS && v.harm_dense == 2 && v.fm_mode == SH_FM_NONE && v.bias == 0.0 && !v.flip;
-    const bool fm = v.fm_mode != SH_FM_NONE;
-    const uint32_t off = fm ? v.time_seg_offset : v.seg_offset;
-    const uint32_t cnt = fm ? v.time_seg_count : v.seg_count;
-    const sh_segment* tab = B.segs + off;
-    const uint64_t onset = v.start_frame;
-    const sh_envelope e = v.env;
-    const double amp = v.amplitude, bgl = (double)v.gain_l, bgr = (double)v.gain_r;
+    const uint64_t launch_end = start + (uint64_t)nframes;
     {   // a chunk whose voices are all silent throughout the launch (notes that have not started, notes that are over): empty masks
-        const bool sounds_in_launch = valid && start + (uint64_t)nframes > onset &&
-                                      !(e.enabled && start > onset + e.n_release_end);       // (>: the extra sample sits AT the release's end)
-        if (__ballot(sounds_in_launch) == 0) {
+        const uint64_t span_lo = as_const(B.chunk_span)[2 * c], span_hi = as_const(B.chunk_span)[2 * c + 1];
+        if (launch_end <= span_lo || start >= span_hi) {
             if (lane == 0)
                 for (uint32_t t = t_begin; t < t_end; ++t) {
                     const size_t at = ((size_t)t * T.groups + c % T.groups) * T.mask_k + c / T.groups;
@@ -1060,42 +1071,95 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             return;
         }
     }
-    uint32_t lo = 0;
-    bool lo_found = false;
-    uint64_t next_n0 = 0;                       // start of piece lo + 1 (2^64 - 1: none)
-    double p_t0 = 0.0, p_dt = 0.0;
-    uint64_t p_n0 = 0;
+    // ---- first batch: the voice, its hint ----
+    const sh_voice& v = B.voices[valid ? vi : 0];
+    const int32_t v_kind = v.kind, v_dense = v.harm_dense, v_fm = v.fm_mode, v_flip = v.flip;
+    const double v_bias = v.bias, amp = v.amplitude;
+    const uint32_t off_c = v.seg_offset, cnt_c = v.seg_count, off_t = v.time_seg_offset, cnt_t = v.time_seg_count;
+    const uint64_t onset = v.start_frame;
+    const uint64_t e_na = v.env.n_attack_end, e_nd = v.env.n_decay_end, e_ns = v.env.n_sustain_end, e_nr = v.env.n_release_end;
+    const double e_as = v.env.attack_slope, e_ds = v.env.decay_slope, e_sl = v.env.sustain_level, e_rs = v.env.release_slope;
+    const int32_t e_on = v.env.enabled, e_tail = v.env.has_tail;
+    const double bgl = (double)v.gain_l, bgr = (double)v.gain_r;
+    const uint32_t hint = B.hint[valid ? vi : 0];
+    asm volatile("" :: "v"(v_kind), "v"(v_dense), "v"(v_fm), "v"(v_flip), "v"(v_bias), "v"(amp), "v"(off_c), "v"(cnt_c), "v"(off_t), "v"(cnt_t),
+                 "v"(onset), "v"(e_na), "v"(e_nd), "v"(e_ns), "v"(e_nr), "v"(e_as), "v"(e_ds), "v"(e_sl), "v"(e_rs), "v"(e_on), "v"(e_tail),
+                 "v"(bgl), "v"(bgr), "v"(hint));
+    const bool lean_capable = valid && v_kind == SH_HARMONICS && v_dense == 2 && v_fm == SH_FM_NONE && v_bias == 0.0 && !v_flip;
+    const bool fm = v_fm != SH_FM_NONE;
+    const uint32_t off = fm ? off_t : off_c;
+    const uint32_t cnt = fm ? cnt_t : cnt_c;
+    const sh_segment* tab = B.segs + off;
+    const double2* rots = B.seg_rot + off;
+    // the voice's own index of the first frame of the run that it sounds in (0: its onset lies in the run or behind it)
+    const uint64_t run0 = start + (uint64_t)t_begin * TILE_FRAMES;
+    const uint64_t nn_first = run0 > onset ? run0 - onset : 0ull;
+    // ---- second batch: the starts of the pieces hint - 1 .. hint + 3: the one that holds nn_first is (nearly always) among them ----
+    uint32_t wb;                                  // the table index of the window's first piece
+    {
+        const uint32_t a = hint < cnt ? hint : cnt - 1;
+        const uint32_t a0 = a > 0 ? a - 1 : 0;
+        uint64_t s[5];
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) s[k] = a0 + k < cnt ? tab[a0 + k].n0 : ~0ull;
+        const uint32_t r = (uint32_t)(s[1] <= nn_first) + (uint32_t)(s[2] <= nn_first) + (uint32_t)(s[3] <= nn_first) + (uint32_t)(s[4] <= nn_first);
+        wb = a0 + r;
+        if (s[0] > nn_first || (r == 4 && a0 + 5 < cnt)) {     // not among them (a jump, a cold start): search
+            uint32_t lo_ = 0, hi = cnt - 1;
+            while (lo_ < hi) {
+                const uint32_t mid = (lo_ + hi + 1) >> 1;
+                if (tab[mid].n0 <= nn_first) lo_ = mid; else hi = mid - 1;
+            }
+            wb = lo_;
+        }
+    }
+    // ---- third batch: the window ----
+    uint64_t w_n0[TILE_WIN];
+    double w_t0[TILE_WIN], w_dt[TILE_WIN];
+    auto load_window = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)TILE_WIN; ++k) {
+            const bool have = wb + k < cnt;
+            const uint32_t at = have ? wb + k : cnt - 1;
+            const uint64_t n0_ = tab[at].n0;
+            w_n0[k] = have ? n0_ : ~0ull;
+            w_t0[k] = tab[at].t0;
+            w_dt[k] = tab[at].dt;
+        }
+    };
+    load_window();
     for (uint32_t t = t_begin; t < t_end; ++t) {
         const uint64_t abs0 = start + (uint64_t)t * TILE_FRAMES;
         uint64_t abs1 = abs0 + TILE_FRAMES;
-        if (abs1 > start + (uint64_t)nframes) abs1 = start + (uint64_t)nframes;
+        if (abs1 > launch_end) abs1 = launch_end;
         bool is_lean = false, is_gen = false;
         double rec_t0 = 0.0, rec_ea0 = 0.0, rec_ea1 = 0.0, rec_eb0 = 0.0, rec_eb1 = 0.0;
-        uint32_t rec_extra = 0, rec_env_max = 0;
+        uint32_t rec_extra = 0, rec_env_max = 0, r = 0;
         uint16_t rec_split[2] = {0xFFFFu, 0xFFFFu};
-        if (valid && abs1 > onset) {
-            // the voice's own indices [n0, n1) of the tile; n0 < 0: the onset lies inside
-            const long long n0 = (long long)abs0 - (long long)onset, n1 = (long long)abs1 - (long long)onset;
-            const double dn0 = (double)n0;
+        // the voice's own indices [n0, n1) of the tile; n0 < 0: the onset lies inside (or the voice has not started)
+        const long long n0 = (long long)abs0 - (long long)onset, n1 = (long long)abs1 - (long long)onset;
+        const double dn0 = (double)n0;
+        const uint64_t nn0 = n0 > 0 ? (uint64_t)n0 : 0ull;
+        bool env_ok = true, sounds = valid && abs1 > onset;
+        if (sounds) {
             // ---- envelope: the line that holds n0 (-1: the silence in front of the onset) and, if one corner lies inside the
             // tile, the line behind it ----
             double ea0 = 1.0, ea1 = 0.0, eb0 = 1.0, eb1 = 0.0;
             uint32_t env_max = 0;
-            bool env_ok = true, sounds = true;
-            if (e.enabled) {
-                const long long cn[4] = {(long long)e.n_attack_end, (long long)e.n_decay_end, (long long)e.n_sustain_end, (long long)e.n_release_end};
+            if (e_on) {
+                const long long cn[4] = {(long long)e_na, (long long)e_nd, (long long)e_ns, (long long)e_nr};
                 const int p = (n0 >= 0) + (n0 >= cn[0]) + (n0 >= cn[1]) + (n0 >= cn[2]) + (n0 >= cn[3]) - 1;
                 const int p1 = (n1 - 1 >= 0) + (n1 - 1 >= cn[0]) + (n1 - 1 >= cn[1]) + (n1 - 1 >= cn[2]) + (n1 - 1 >= cn[3]) - 1;     // the tile's last frame
                 // line k at the voice's index n, as value at n0 and slope: -1 silence, 0 attack, 1 decay, 2 sustain, 3 release, 4 silence
                 auto line = [&](int k, double& v0, double& v1) {
-                    if (k == 0) { v0 = dn0 * e.attack_slope; v1 = e.attack_slope; }
-                    else if (k == 1) { v0 = fma(dn0 - (double)cn[0], e.decay_slope, 1.0); v1 = e.decay_slope; }
-                    else if (k == 2) { v0 = e.sustain_level; v1 = 0.0; }
-                    else if (k == 3) { v0 = fma(dn0 - (double)cn[2], e.release_slope, e.sustain_level); v1 = e.release_slope; }
+                    if (k == 0) { v0 = dn0 * e_as; v1 = e_as; }
+                    else if (k == 1) { v0 = fma(dn0 - (double)cn[0], e_ds, 1.0); v1 = e_ds; }
+                    else if (k == 2) { v0 = e_sl; v1 = 0.0; }
+                    else if (k == 3) { v0 = fma(dn0 - (double)cn[2], e_rs, e_sl); v1 = e_rs; }
                     else { v0 = 0.0; v1 = 0.0; }
                 };
                 if (p == 4) {                                // behind the release: silent, but for the one extra sample at its end
-                    sounds = e.has_tail && n0 == cn[3];
+                    sounds = e_tail && n0 == cn[3];
                     env_ok = false;
                 } else if (p1 == p) {
                     line(p, ea0, ea1);
@@ -1110,81 +1174,62 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             } else if (n0 < 0) {
                 env_ok = false;                              // an onset without an envelope is a step: not the meeting of two lines
             }
-            if (sounds) {
-                // ---- phase table: the piece that holds max(n0, 0), and the ends of pieces inside the tile ----
-                const uint64_t nn0 = n0 > 0 ? (uint64_t)n0 : 0ull;
-                if (!lo_found) {
-                    // from the voice's hint (the piece of the last launch that was resolved for it: the same or a neighbour in a
-                    // stream of blocks; any value is safe -- it is walked into place)
-                    uint32_t a = B.hint[vi];
-                    if (a >= cnt) a = cnt - 1;
-                    uint32_t steps = 0;
-                    while (a > 0 && tab[a].n0 > nn0 && steps < 4) { --a; ++steps; }
-                    while (a + 1 < cnt && tab[a + 1].n0 <= nn0 && steps < 8) { ++a; ++steps; }
-                    if (tab[a].n0 > nn0 || (a + 1 < cnt && tab[a + 1].n0 <= nn0)) {     // far off: search
-                        a = 0;
-                        uint32_t hi = cnt - 1;
-                        while (a < hi) {
-                            const uint32_t mid = (a + hi + 1) >> 1;
-                            if (tab[mid].n0 <= nn0) a = mid; else hi = mid - 1;
-                        }
-                    }
-                    lo = a;
-                    lo_found = true;
-                    p_n0 = tab[lo].n0; p_t0 = tab[lo].t0; p_dt = tab[lo].dt;
-                    next_n0 = lo + 1 < cnt ? tab[lo + 1].n0 : ~0ull;
-                }
-                while (next_n0 <= nn0) {
-                    ++lo;
-                    p_n0 = next_n0; p_t0 = tab[lo].t0; p_dt = tab[lo].dt;
-                    next_n0 = lo + 1 < cnt ? tab[lo + 1].n0 : ~0ull;
-                }
-                // pieces lo + 1 .. that start inside the tile (at most TILE_MAX_PIECES - 1 for a lean pair)
-                uint32_t extra = 0;
-                uint64_t starts[TILE_MAX_PIECES];
-                starts[0] = next_n0;
+            rec_ea0 = ea0; rec_ea1 = ea1; rec_eb0 = eb0; rec_eb1 = eb1;
+            rec_env_max = env_max;
+        }
+        // ---- phase table: the piece that holds nn0 and the ends of pieces inside the tile, from the window; a lane whose window
+        // does not show the three pieces behind its own (and the table goes on) slides it -- with one batch of loads ----
+        for (;;) {
+            r = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < TILE_MAX_PIECES; ++k) {
-                    if (extra == k && starts[k] < (uint64_t)n1) {
-                        extra = k + 1;
-                        if (k + 1 < TILE_MAX_PIECES) starts[k + 1] = lo + 2 + k < cnt ? tab[lo + 2 + k].n0 : ~0ull;
-                    }
-                }
-                is_lean = lean_capable && env_ok && extra < TILE_MAX_PIECES;
-                is_gen = !is_lean;
-                if (is_lean) {
-                    rec_t0 = fma(dn0 - (double)p_n0, p_dt, p_t0);
-                    rec_ea0 = ea0; rec_ea1 = ea1; rec_eb0 = eb0; rec_eb1 = eb1;
-                    rec_extra = extra;
-                    rec_env_max = env_max;
+            for (int k = 1; k < TILE_WIN; ++k) r += (uint32_t)(w_n0[k] <= nn0);
+            const bool slide = sounds && r > (uint32_t)(TILE_WIN - 4) && wb + TILE_WIN < cnt;
+            if (__ballot(slide) == 0) break;
+            if (slide) {
+                wb += r;
+                load_window();
+            }
+        }
+        // (the piece's rotation: asked for here, needed at the record's stores)
+        const double2 rot = rots[wb + r < cnt ? wb + r : cnt - 1];
+        if (sounds) {
+            const uint64_t p_n0 = win_pick<uint64_t>(w_n0, r, 0ull);
+            const double p_t0 = win_pick<double>(w_t0, r, 0.0), p_dt = win_pick<double>(w_dt, r, 0.0);
+            uint64_t starts[TILE_MAX_PIECES];
 #pragma unroll
-                    for (uint32_t k = 0; k < 2; ++k) rec_split[k] = k < extra ? (uint16_t)((long long)starts[k] - n0) : (uint16_t)0xFFFFu;
-                }
+            for (uint32_t k = 0; k < TILE_MAX_PIECES; ++k) starts[k] = win_pick<uint64_t>(w_n0, r + 1 + k, ~0ull);
+            uint32_t extra = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < TILE_MAX_PIECES; ++k) extra += (uint32_t)(starts[k] < (uint64_t)n1);
+            is_lean = lean_capable && env_ok && extra < TILE_MAX_PIECES;
+            is_gen = !is_lean;
+            if (is_lean) {
+                rec_t0 = fma(dn0 - (double)p_n0, p_dt, p_t0);
+                rec_extra = extra;
+#pragma unroll
+                for (uint32_t k = 0; k < 2; ++k) rec_split[k] = k < extra ? (uint16_t)((long long)starts[k] - n0) : (uint16_t)0xFFFFu;
             }
         }
         const uint64_t ml = __ballot(is_lean), mg = __ballot(is_gen);
+#ifdef SH_X_NOSTORE
+        if (is_lean && rec_t0 == 1.2345e-300) {
+#else
         if (is_lean) {                                           // the chunk's lean pairs, compacted in voice order
+#endif
             TileRec* __restrict__ q = T.recs + (size_t)t * slots + c * 64 + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
             const bool corner = !(rec_ea0 == rec_eb0 && rec_ea1 == rec_eb1);
             const double sg = (corner && rec_env_max) ? -1.0 : 1.0;        // a convex corner: max(a, b) g = min(-a, -b) (-g)
-            const double2 rot = B.seg_rot[off + lo];
-            q->t0 = rec_t0;
-            q->dt = p_dt;
-            q->rc = rot.x;
-            q->rs = rot.y;
-            q->ea0 = sg * rec_ea0; q->ea1 = sg * rec_ea1; q->eb0 = sg * rec_eb0; q->eb1 = sg * rec_eb1;
-            q->GL = sg * (amp * bgl);
-            q->GR = sg * (amp * bgr);
-#pragma unroll
-            for (uint32_t k = 0; k < 2; ++k) {
-                const bool have = k < rec_extra;
-                q->tb[k] = have ? tab[lo + 1 + k].t0 : 0.0;
-                q->db[k] = have ? tab[lo + 1 + k].dt : 0.0;
-                q->split[k] = rec_split[k];
-            }
-            q->npieces = (uint16_t)(1 + rec_extra);
-            q->corner = corner ? 1 : 0;
-            q->pad_ = 0.0;
+            double2* __restrict__ q2 = reinterpret_cast<double2*>(q);      // eight 16-byte stores
+            q2[0] = make_double2(rec_t0, win_pick<double>(w_dt, r, 0.0));
+            q2[1] = rot;
+            q2[2] = make_double2(sg * rec_ea0, sg * rec_ea1);
+            q2[3] = make_double2(sg * rec_eb0, sg * rec_eb1);
+            q2[4] = make_double2(sg * (amp * bgl), sg * (amp * bgr));
+            q2[5] = make_double2(rec_extra > 0 ? win_pick<double>(w_t0, r + 1, 0.0) : 0.0, rec_extra > 1 ? win_pick<double>(w_t0, r + 2, 0.0) : 0.0);
+            q2[6] = make_double2(rec_extra > 0 ? win_pick<double>(w_dt, r + 1, 0.0) : 0.0, rec_extra > 1 ? win_pick<double>(w_dt, r + 2, 0.0) : 0.0);
+            union { uint16_t h[4]; double d; } tail;
+            tail.h[0] = rec_split[0]; tail.h[1] = rec_split[1]; tail.h[2] = (uint16_t)(1 + rec_extra); tail.h[3] = corner ? 1 : 0;
+            q2[7] = make_double2(tail.d, 0.0);
         }
         if (lane == 0) {
             const size_t at = ((size_t)t * T.groups + c % T.groups) * T.mask_k + c / T.groups;

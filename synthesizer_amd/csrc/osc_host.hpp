@@ -66,13 +66,16 @@ struct sh_bank {
     LaunchSet   gen_set = {};
     uint32_t    gen_segs = 0;
     double2*    d_seg_rot = nullptr;       // (cos, sin)(64*dt) per table piece
+    uint64_t*   d_chunk_span = nullptr;    // [chunk][2]: first onset, last frame of sound + 1 of the chunk's voices
     double*     d_polys = nullptr;         // [slot][16]: the polynomial of a polynomial-Harmonics voice, by voice
     double2*    d_lfo_rot = nullptr;       // (cos, sin)(64*lfo_d) per voice
     VoiceLaunch* d_launch = nullptr;       // the set the next kernel reads
     VoiceFM*    d_launch_fm = nullptr;
     int         cur = 0;                   // the set the last launch read
     int         last_target = -1;          // the set the last render launch is filling (-1: none)
-    struct Spec { bool valid = false; uint64_t start = 0; uint32_t nframes = 0; } spec[NSETS];   // what each set holds (or will)
+    // what each set holds (or will); sparse: resolved for a tile-classified launch -- the chunks whose voices are all silent in
+    // the block were skipped (nobody reads them there), so only such a launch may take the set
+    struct Spec { bool valid = false; uint64_t start = 0; uint32_t nframes = 0; bool sparse = false; } spec[NSETS];
     void        void_specs() { for (auto& q : spec) q.valid = false; last_target = -1; }
     uint32_t    lean_candidates = 0;      // voices that can take the lean loop in some launch (static properties)
     uint32_t    lean_fm_candidates = 0;   // ... of them other than polynomial Harmonics (FM Sine, plain waveforms)
@@ -105,7 +108,7 @@ std::vector<sh_bank*>& live_banks();
 const shm::sc_pair* trig_table();
 // osc_bank.hip
 int prepare_single(sh_bank* b, uint32_t first, uint32_t count, uint64_t start, uint32_t nframes);     // k_prepare: one voice (sh_osc_render)
-int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t launch_stream, bool in_run);
+int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t launch_stream, bool in_run, bool accept_sparse = false);
 uint32_t plan_segments(const sh_bank* b, uint64_t start, uint32_t nframes, uint64_t T, uint64_t max_len, bool corners, uint32_t* seg_first);
 int bank_check_plain(const sh_bank* b, const char* who);
 // `nseg` record sets for `nvoices` voices carved out of one pool-backed block (grown when it is too small; *cap = sets it holds)

@@ -108,29 +108,45 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         if (blockIdx.x < prep_wgs) {
             if (next.launch && threadIdx.x < 64) {
                 const uint32_t c = blockIdx.y * prep_wgs + blockIdx.x;
-                if (c < (nvoices + 63) / 64) prepare_chunk(B, next, c, nvoices, next_start, nframes);
+                if (c < (nvoices + 63) / 64) {
+                    if constexpr (MODE == RENDER_LEAN_TILES) {
+                        // a tile-classified launch reads the records of the voices in its masks only: a chunk whose voices are all
+                        // silent in that block is not resolved at all (a table of notes is mostly such chunks: 352 chunks, ~30
+                        // sounding, cost the launch 11 of 64 us) -- the set is marked sparse on the host
+                        const uint64_t span_lo = as_const(B.chunk_span)[2 * c], span_hi = as_const(B.chunk_span)[2 * c + 1];
+                        if (next_start + (uint64_t)nframes <= span_lo || next_start >= span_hi) {
+                            if (threadIdx.x == 0) {
+                                const uint32_t in_chunk = nvoices - c * 64 < 64u ? nvoices - c * 64 : 64u;
+                                next.counts[4 * c] = 0; next.counts[4 * c + 1] = 0; next.counts[4 * c + 2] = in_chunk; next.counts[4 * c + 3] = 0;
+                            }
+                            return;
+                        }
+                    }
+                    prepare_chunk(B, next, c, nvoices, next_start, nframes);
+                }
             }
             return;
         }
     }
-    // RENDER_LEAN_TILES: behind the workgroups that resolve the launch records of the block two launches on come B.next_tile_wgs
-    // workgroups per row of the grid that resolve its TILE SET: four wavefronts each, a run of TILES_PER_WAVE tiles of one chunk per
-    // wavefront (prepare_tiles_wave) -- the chunks whose voices are all silent in that block leave after one load.  (As a kernel of
-    // its own on a third stream this step took 50 us beside the renders and, sharing a hardware queue with one of the render
-    // streams, sat in front of that stream's next launch.)
-    if constexpr (MODE == RENDER_LEAN_TILES) {
-        if (B.next_tile_wgs && blockIdx.x >= prep_wgs && blockIdx.x < prep_wgs + B.next_tile_wgs) {
+    // RENDER_GENERAL_TILES: the first B.next_tile_wgs workgroups of every row of the grid resolve the TILE SET of the block two
+    // launches on: four wavefronts each, a run of TILES_PER_WAVE tiles of one chunk per wavefront (prepare_tiles_wave) -- the chunks
+    // whose voices are all silent in that block leave after one load.  They ride in the GENERAL kernel, which follows the lean one
+    // on its stream, is a few dozen latency-bound workgroups and runs beside the other stream's lean kernel: in the lean kernel
+    // (whose 752 workgroups want every slot of the chip at once) they cost the launch 16 of 69 us; as a kernel of its own on a third
+    // stream the step shared a hardware queue with one of the render streams and sat in front of that stream's next launch.
+    if constexpr (MODE == RENDER_GENERAL_TILES) {
+        if (blockIdx.x < B.next_tile_wgs) {
             const uint32_t runs = (B.next_ntiles + TILES_PER_WAVE - 1) / TILES_PER_WAVE, wgs_per_chunk = (runs + 3) / 4;
-            const uint32_t unit = blockIdx.y * B.next_tile_wgs + (blockIdx.x - prep_wgs);
+            const uint32_t unit = blockIdx.y * B.next_tile_wgs + blockIdx.x;
             const uint32_t c = unit / wgs_per_chunk, run = (unit % wgs_per_chunk) * 4 + (threadIdx.x >> 6);
             if (c < (nvoices + 63) / 64) prepare_tiles_wave(B, B.next_tiles, nvoices, next_start, nframes, B.next_ntiles, c, run);
             return;
         }
     }
-    // RENDER_GENERAL_TILES: workgroup (x, y) renders the general pairs of ONE tile of 64 FPL frames, ALL voice groups' -- part
+    // ... and workgroup (x, y) behind them renders the general pairs of ONE tile of 64 FPL frames, ALL voice groups' -- part
     // gen_part of GEN_SPLIT of them -- into plane gen_part of the general parts.
     uint32_t gen_part = 0;
-    uint32_t bx_ = blockIdx.x - (mode_general(MODE) ? 0u : prep_wgs) - (MODE == RENDER_LEAN_TILES ? B.next_tile_wgs : 0u);
+    uint32_t bx_ = blockIdx.x - (mode_general(MODE) ? 0u : prep_wgs) - (MODE == RENDER_GENERAL_TILES ? B.next_tile_wgs : 0u);
     if constexpr (MODE == RENDER_GENERAL_TILES) {
         bx_ = bx_ * gridDim.y + blockIdx.y;
         gen_part = bx_ % GEN_SPLIT;
@@ -884,7 +900,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         if (nseg < 2 || seg_first[nseg] != nframes) nseg = 0;        // nothing to cut, or more cuts than a launch carries
     }
     if (nseg == 0) {
-        rc = acquire_records(b, start, nframes, st, cont);
+        rc = acquire_records(b, start, nframes, st, cont, tiled);
         if (rc) return rc;
     }
     // partial buses: ring slot n % 4 (last read by the fold in launch n - 2, which is this stream's previous launch)
@@ -943,7 +959,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         }
         sp.valid = false;
         // the tile set of the block expected two launches on: set (n + 2) % 4 -- read last by launch n - 2, the launch before on
-        // this stream -- resolved by workgroups of this launch's render kernel
+        // this stream -- resolved by workgroups of this launch's general kernel
         if (next.launch) {
             const int k2 = (int)((b->tile_count + 2) % sh_bank::NTILESETS);
             TileSet& T2 = b->tile_set[k2];
@@ -957,7 +973,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             s2.valid = true; s2.start = next_start; s2.nframes = nframes; s2.groups = groups;
         }
         P.tiles = T;
-        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(prep_wgs + P.next_tile_wgs + tiles, groups), dim3(256), 0, st, P,
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(prep_wgs + tiles, groups), dim3(256), 0, st, P,
                            trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
                            o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
         SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
@@ -967,7 +983,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             const uint32_t gen_wgs = sh::div_up(sh::div_up(nframes, 256) * GEN_SPLIT, groups);
             // (on a stream of its own beside the lean kernel it was slower, 95 against 75 us per block: five streams share four
             // hardware queues, and a kernel that waits for an event holds up whatever shares its queue)
-            hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs, groups), dim3(256), 0, st, P,
+            hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(P.next_tile_wgs + gen_wgs, groups), dim3(256), 0, st, P,
                                trig_table(), b->nvoices, vpg, cur, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
                                (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
                                gen_valid, (const uint32_t*)nullptr, 0u);
@@ -1107,6 +1123,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         b->spec[target].valid = true;
         b->spec[target].start = next_start;
         b->spec[target].nframes = nframes;
+        b->spec[target].sparse = tiled;
     }
     return SH_OK;
 }
