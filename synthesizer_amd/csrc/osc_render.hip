@@ -97,17 +97,24 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                                                                   uint32_t* __restrict__ gen_valid,
                                                                   const uint32_t* __restrict__ prev_gen_valid,
                                                                   uint32_t prep_wgs) {
-    // prep_wgs > 0 (lean / direct / combined modes only): the first prep_wgs workgroups of every row of the grid do not render.
+    // prep_wgs > 0 (lean / direct / combined modes only): prep_wgs workgroups in rows of their own BEHIND the voice groups' rows do not render.
     // Sequential streaming is the common call pattern: a launch also resolves the launch records of the block expected two
     // launches on (next_start = start + 2 * nframes: the launch in between runs beside this one on the other stream and got
     // its records from this one's predecessor) into a free record set, so that launch needs no prepare kernel of its own
-    // (a 13 us kernel + a launch boundary per block otherwise).  One wavefront per chunk of 64 voices, each in a workgroup of
-    // its own that is dispatched FIRST and leaves: beside the rendering workgroups, not in front of one (as the first step of
-    // the first tiles' workgroups -- round 2 -- the step was the whole launch's critical path for small banks: 8 of 13 us).
+    // (a 13 us kernel + a launch boundary per block otherwise).  One wavefront per chunk of 64 voices, in workgroups of their own:
+    // beside the rendering workgroups, not in front of one (as the first step of the first tiles' workgroups -- round 2 -- the
+    // step was the whole launch's critical path for small banks: 8 of 13 us) -- and dispatched LAST: a workgroup that leaves at
+    // once between the rendering ones upsets their placement (the dispatcher does not refill the slot evenly: some CUs end up
+    // with four rendering workgroups where others hold two, and the launch lasts as long as its fullest CU -- 63 against 53 us
+    // for a bank of 352 chunks, most of them silent).
+    const uint32_t prep_rows = (!mode_general(MODE) && prep_wgs) ? (prep_wgs + gridDim.x - 1) / gridDim.x : 0u;
+    const uint32_t ngroups = gridDim.y - prep_rows;              // the voice groups of the launch
     if (!mode_general(MODE) && prep_wgs) {
-        if (blockIdx.x < prep_wgs) {
-            if (next.launch && threadIdx.x < 64) {
-                const uint32_t c = blockIdx.y * prep_wgs + blockIdx.x;
+        if (blockIdx.y >= ngroups) {
+            const uint32_t unit = (blockIdx.y - ngroups) * gridDim.x + blockIdx.x;
+            if (next.launch && unit < prep_wgs && threadIdx.x < 64) {       // (ONE wavefront per workgroup works: spread over the CUs)
+                __builtin_amdgcn_s_setprio(3);                               // (latency-bound, beside wavefronts that fill every issue slot)
+                const uint32_t c = unit;
                 if (c < (nvoices + 63) / 64) {
                     if constexpr (MODE == RENDER_LEAN_TILES) {
                         // a tile-classified launch reads the records of the voices in its masks only: a chunk whose voices are all
@@ -135,6 +142,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // (whose 752 workgroups want every slot of the chip at once) they cost the launch 16 of 69 us; as a kernel of its own on a third
     // stream the step shared a hardware queue with one of the render streams and sat in front of that stream's next launch.
     if constexpr (MODE == RENDER_GENERAL_TILES) {
+        // This kernel is a few hundred latency-bound wavefronts that run beside the other stream's lean kernel, whose wavefronts
+        // fill every issue slot they are given: without priority the two do not overlap at all -- the lean kernel runs at the speed
+        // it has alone and this one takes 60 us instead of 23 (rocprofv3 kernel trace of a stream of blocks).
+        __builtin_amdgcn_s_setprio(3);
         if (blockIdx.x < B.next_tile_wgs) {
             const uint32_t runs = (B.next_ntiles + TILES_PER_WAVE - 1) / TILES_PER_WAVE, wgs_per_chunk = (runs + 3) / 4;
             const uint32_t unit = blockIdx.y * B.next_tile_wgs + blockIdx.x;
@@ -146,9 +157,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // ... and workgroup (x, y) behind them renders the general pairs of ONE tile of 64 FPL frames, ALL voice groups' -- part
     // gen_part of GEN_SPLIT of them -- into plane gen_part of the general parts.
     uint32_t gen_part = 0;
-    uint32_t bx_ = blockIdx.x - (mode_general(MODE) ? 0u : prep_wgs) - (MODE == RENDER_GENERAL_TILES ? B.next_tile_wgs : 0u);
+    uint32_t bx_ = blockIdx.x - (MODE == RENDER_GENERAL_TILES ? B.next_tile_wgs : 0u);
     if constexpr (MODE == RENDER_GENERAL_TILES) {
-        bx_ = bx_ * gridDim.y + blockIdx.y;
+        bx_ = bx_ * ngroups + blockIdx.y;
         gen_part = bx_ % GEN_SPLIT;
         bx_ /= GEN_SPLIT;
         if (bx_ * (64 * FPL) >= nframes) return;
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                 const uint32_t n_s = B.seg_first[sidx + 1] - B.seg_first[sidx];
                 for (uint32_t f = threadIdx.x; f < 64 * FPL; f += WAVES * 64) {
                     const uint32_t raw = tidx * (64 * FPL) + f;
-                    if (raw < n_s) parts[(size_t)(gridDim.y + grp) * nframes + B.seg_first[sidx] + raw] = make_double2(0.0, 0.0);
+                    if (raw < n_s) parts[(size_t)(ngroups + grp) * nframes + B.seg_first[sidx] + raw] = make_double2(0.0, 0.0);
                 }
                 return;
             }
@@ -209,15 +220,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             const uint32_t raw = bx * (64 * FPL) + f;
             if (raw >= nframes) continue;
             double2 acc = prev_parts[raw];
-            for (uint32_t g = 1; g < gridDim.y; ++g) {
+            for (uint32_t g = 1; g < ngroups; ++g) {
                 const double2 pp = prev_parts[(size_t)g * nframes + raw];
                 acc.x += pp.x;
                 acc.y += pp.y;
             }
             if (prev_gen_valid) {                              // the general kernel's parts of that launch, where it wrote any
-                for (uint32_t g = 0; g < gridDim.y; ++g) {
+                for (uint32_t g = 0; g < ngroups; ++g) {
                     if (as_const(prev_gen_valid)[g]) {
-                        const double2 pp = prev_parts[(size_t)(gridDim.y + g) * nframes + raw];
+                        const double2 pp = prev_parts[(size_t)(ngroups + g) * nframes + raw];
                         acc.x += pp.x;
                         acc.y += pp.y;
                     }
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // (SYNTHHIP_PREPARE_IN_TILE=1, for A/B timings: the round-2 placement of the prepare step -- the chunks of 64 voices spread
     // over the first tile workgroups, one wavefront each, in front of their own work)
     if (!mode_general(MODE) && next.launch && !prep_wgs) {
-        const uint32_t nchunks = (nvoices + 63) / 64, nblocks = gridDim.x * gridDim.y;
+        const uint32_t nchunks = (nvoices + 63) / 64, nblocks = gridDim.x * ngroups;
         const uint32_t bid = blockIdx.y * gridDim.x + bx;
         if (threadIdx.x < 64) {
             for (uint32_t c = bid; c < nchunks; c += nblocks) prepare_chunk(B, next, c, nvoices, next_start, nframes);
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         // neighbours in the voice table, whole chunks of them, and any deal of whole chunks leaves one group with twice the work of
         // another.  The masks of the tile (one contiguous row) are fetched 64 at a time, one per lane; the lists that are not empty
         // are handed round by ballot and readlane.
-        const uint32_t nmask = gridDim.y * B.tiles.mask_k, stride = gridDim.y * WAVES;
+        const uint32_t nmask = ngroups * B.tiles.mask_k, stride = ngroups * WAVES;
         const uint64_t* __restrict__ lrow = B.tiles.lean + (size_t)tile_index * nmask;
         uint32_t firstp = grp * WAVES + wave;
         for (uint32_t base = 0; base < nmask; base += 64) {
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mymask, (int)src);
             const uint32_t npairs = (uint32_t)__popcll(cmask);
             const uint32_t idx = base + src;                              // mask index in the row: (group, k) of the prepare step's layout
-            const uint32_t c = idx / B.tiles.mask_k + (idx % B.tiles.mask_k) * gridDim.y;
+            const uint32_t c = idx / B.tiles.mask_k + (idx % B.tiles.mask_k) * ngroups;
             const TileRec SH_CONST_AS* q = trow + c * 64 + firstp;
             uint32_t p = firstp;
             for (; p < npairs; p += stride, q += stride) {
@@ -604,7 +615,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             if (MODE == RENDER_GENERAL_SEG && to_scratch) {
                 B.gen_scratch[(size_t)(grp * nsub + sub) * nfr + raw] = make_double2(l, rr);
             } else if (parts) {
-                const uint32_t slot = MODE == RENDER_GENERAL_TILES ? B.tiles.groups + gen_part : (mode_general(MODE) ? gridDim.y + grp : grp);
+                const uint32_t slot = MODE == RENDER_GENERAL_TILES ? B.tiles.groups + gen_part : (mode_general(MODE) ? ngroups + grp : grp);
                 parts[(size_t)slot * nframes + at] = make_double2(l, rr);
             } else {
                 if (bus32) bus32[at] = make_float2((float)l, (float)rr);
@@ -940,9 +951,9 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     }
     LaunchSet next = launch_set(b, target < 0 ? 0 : target);
     if (target < 0) next.launch = nullptr;
-    // the workgroups that resolve those records: one per chunk of 64 voices, dispatched in front of the tiles' (prep_wgs per row of the grid)
+    // the workgroups that resolve those records: one wavefront per chunk of 64 voices, in rows of the grid behind the voice groups'
     const uint32_t nchunks = sh::div_up(b->nvoices, 64);
-    const uint32_t prep_wgs = (next.launch && !K.prepare_in_tile) ? sh::div_up(nchunks, groups) : 0u;
+    const uint32_t prep_wgs = (next.launch && !K.prepare_in_tile) ? nchunks : 0u;
     if (tiled) {
         const uint32_t ntiles = sh::div_up(nframes, TILE_FRAMES);
         const int ks = (int)(b->tile_count % sh_bank::NTILESETS);
@@ -973,7 +984,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             s2.valid = true; s2.start = next_start; s2.nframes = nframes; s2.groups = groups;
         }
         P.tiles = T;
-        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(prep_wgs + tiles, groups), dim3(256), 0, st, P,
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups + sh::div_up(prep_wgs, tiles)), dim3(256), 0, st, P,
                            trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
                            o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
         SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
@@ -1006,11 +1017,11 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             tiles_gen += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 4);
         }
         if (mode == RENDER_LEAN_HARM)
-            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_HARM_SEG>), dim3(prep_wgs + tiles_lean, groups), dim3(256), 0, st, P,
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_HARM_SEG>), dim3(tiles_lean, groups + sh::div_up(prep_wgs, tiles_lean)), dim3(256), 0, st, P,
                                trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
                                o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
         else
-            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_ALL_SEG>), dim3(prep_wgs + tiles_lean, groups), dim3(256), 0, st, P,
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_ALL_SEG>), dim3(tiles_lean, groups + sh::div_up(prep_wgs, tiles_lean)), dim3(256), 0, st, P,
                                trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
                                o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
         SH_CHECK_LAUNCH("k_bank_render(lean, segments)");
@@ -1035,7 +1046,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         SH_CHECK_LAUNCH("k_seg_combine");
     } else {
 #define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
-    hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(prep_wgs + tiles, groups), dim3(W_ * 64), 0, st, ptrs(b),    \
+    hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups + sh::div_up(prep_wgs, tiles)), dim3(W_ * 64), 0, st, ptrs(b),    \
                        trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64, \
                        o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs)
 #define SH_LAUNCH_RENDER(W_, F_, M_)                                                 \
