@@ -47,7 +47,8 @@ __global__ __launch_bounds__(64) void k_prepare_segments_var(BankPtrs B, LaunchS
 // The tile set of a launch that was not predicted (the first launches of a run, a jump): a kernel in front of the render; in a stream
 // of blocks the same wavefronts run inside the render kernel of the launch before last (prepare_tiles_wave, osc_device.hpp).
 __global__ __launch_bounds__(256) void k_prepare_tiles(BankPtrs B, TileSet T, uint32_t nvoices, uint64_t start, uint32_t nframes, uint32_t ntiles) {
-    prepare_tiles_wave(B, T, nvoices, start, nframes, ntiles, blockIdx.x, blockIdx.y * 4 + (threadIdx.x >> 6));
+    const uint32_t c = T.k0 * T.groups + blockIdx.x;             // (the chunks of the set's range)
+    if (c < (nvoices + 63) / 64) prepare_tiles_wave(B, T, nvoices, start, nframes, ntiles, c, blockIdx.y * 4 + (threadIdx.x >> 6));
 }
 
 }  // namespace
@@ -56,7 +57,8 @@ namespace shosc {
 
 int launch_prepare_tiles(hipStream_t st, const BankPtrs& P, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes) {
     const uint32_t ntiles = sh::div_up(nframes, TILE_FRAMES);
-    hipLaunchKernelGGL(k_prepare_tiles, dim3(sh::div_up(nvoices, 64), sh::div_up(ntiles, 4 * TILES_PER_WAVE)), dim3(256), 0, st, P, T, nvoices, start, nframes, ntiles);
+    if (T.k1 == T.k0) return SH_OK;                            // no chunk sounds in the block
+    hipLaunchKernelGGL(k_prepare_tiles, dim3((T.k1 - T.k0) * T.groups, sh::div_up(ntiles, 4 * TILES_PER_WAVE)), dim3(256), 0, st, P, T, nvoices, start, nframes, ntiles);
     SH_CHECK_LAUNCH("k_prepare_tiles");
     return SH_OK;
 }
@@ -77,7 +79,8 @@ int grow_tile_set(sh::Pooled& block, TileSet& T, uint32_t& carved_tiles, uint32_
     T.gen = (uint64_t*)p;
     T.groups = groups;
     T.mask_k = mask_k;
-    T.gen_wgs = 0;
+    T.k0 = 0;
+    T.k1 = mask_k;
     if (((nvoices + 63) / 64) != groups * mask_k) SH_HIP(hipMemsetAsync(T.lean, 0, 2 * b_mask, st));     // (some slots have no chunk: they stay zero)
     return SH_OK;
 }
@@ -387,6 +390,7 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             span[2 * c + 1] = hi;
         }
         if (!rc) rc = upload_array(&b->d_chunk_span, span.data(), span.size(), st);
+        b->chunk_span = span;
     }
     if (!rc) rc = upload_array(&b->d_seg_rot, seg_rot.data(), nsegs, st);
     if (!rc) rc = upload_array(&b->d_lfo_rot, lfo_rot.data(), nvoices, st);

@@ -88,7 +88,10 @@ struct TileSet {
     uint64_t* lean;               // bit b = voice 64 c + b is lean in this tile
     uint64_t* gen;                // ... takes the general code in this tile
     uint32_t  groups, mask_k;
-    uint32_t  gen_wgs;            // (unused)
+    // the set is resolved (and read) for the chunks [k0 groups, k1 groups) only: the masks of a group are its slots k0 .. k1 - 1 --
+    // the chunks in front and behind are silent throughout the block (a table of notes in the order they start: a few dozen of
+    // several hundred chunks sound in any one block), nobody writes or reads their masks
+    uint32_t  k0, k1;
 };
 __host__ __device__ __forceinline__ uint32_t tile_mask_k(uint32_t nvoices, uint32_t groups) {
     const uint32_t nchunks = (nvoices + 63) / 64;

@@ -66,6 +66,7 @@ struct sh_bank {
     LaunchSet   gen_set = {};
     uint32_t    gen_segs = 0;
     double2*    d_seg_rot = nullptr;       // (cos, sin)(64*dt) per table piece
+    std::vector<uint64_t> chunk_span;      // (host copy)
     uint64_t*   d_chunk_span = nullptr;    // [chunk][2]: first onset, last frame of sound + 1 of the chunk's voices
     double*     d_polys = nullptr;         // [slot][16]: the polynomial of a polynomial-Harmonics voice, by voice
     double2*    d_lfo_rot = nullptr;       // (cos, sin)(64*lfo_d) per voice

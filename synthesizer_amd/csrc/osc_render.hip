@@ -114,7 +114,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             const uint32_t unit = (blockIdx.y - ngroups) * gridDim.x + blockIdx.x;
             if (next.launch && unit < prep_wgs && threadIdx.x < 64) {       // (ONE wavefront per workgroup works: spread over the CUs)
                 __builtin_amdgcn_s_setprio(3);                               // (latency-bound, beside wavefronts that fill every issue slot)
-                const uint32_t c = unit;
+                // (a tile-classified launch: the chunks of the next set's range only)
+                const uint32_t c = (MODE == RENDER_LEAN_TILES ? B.next_tiles.k0 * B.next_tiles.groups : 0u) + unit;
                 if (c < (nvoices + 63) / 64) {
                     if constexpr (MODE == RENDER_LEAN_TILES) {
                         // a tile-classified launch reads the records of the voices in its masks only: a chunk whose voices are all
@@ -146,10 +147,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         // fill every issue slot they are given: without priority the two do not overlap at all -- the lean kernel runs at the speed
         // it has alone and this one takes 60 us instead of 23 (rocprofv3 kernel trace of a stream of blocks).
         __builtin_amdgcn_s_setprio(3);
-        if (blockIdx.x < B.next_tile_wgs) {
+        // (a one-dimensional grid: the general workgroups first -- theirs is the longer job and the other stream's lean kernel
+        // leaves this one few slots -- then next_tile_wgs prepare workgroups over the chunks of the next set's range)
+        if (blockIdx.x >= gridDim.x - B.next_tile_wgs) {
             const uint32_t runs = (B.next_ntiles + TILES_PER_WAVE - 1) / TILES_PER_WAVE, wgs_per_chunk = (runs + 3) / 4;
-            const uint32_t unit = blockIdx.y * B.next_tile_wgs + blockIdx.x;
-            const uint32_t c = unit / wgs_per_chunk, run = (unit % wgs_per_chunk) * 4 + (threadIdx.x >> 6);
+            const uint32_t unit = blockIdx.x - (gridDim.x - B.next_tile_wgs);
+            const uint32_t c = B.next_tiles.k0 * B.next_tiles.groups + unit / wgs_per_chunk, run = (unit % wgs_per_chunk) * 4 + (threadIdx.x >> 6);
             if (c < (nvoices + 63) / 64) prepare_tiles_wave(B, B.next_tiles, nvoices, next_start, nframes, B.next_ntiles, c, run);
             return;
         }
@@ -157,9 +160,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // ... and workgroup (x, y) behind them renders the general pairs of ONE tile of 64 FPL frames, ALL voice groups' -- part
     // gen_part of GEN_SPLIT of them -- into plane gen_part of the general parts.
     uint32_t gen_part = 0;
-    uint32_t bx_ = blockIdx.x - (MODE == RENDER_GENERAL_TILES ? B.next_tile_wgs : 0u);
+    uint32_t bx_ = blockIdx.x;
     if constexpr (MODE == RENDER_GENERAL_TILES) {
-        bx_ = bx_ * ngroups + blockIdx.y;
         gen_part = bx_ % GEN_SPLIT;
         bx_ /= GEN_SPLIT;
         if (bx_ * (64 * FPL) >= nframes) return;
@@ -319,21 +321,21 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         // are one contiguous row -- a lane fetches one mask per pass, the non-zero ones are handed round by ballot and readlane --
         // and the pairs are dealt to the workgroups of the tile and their waves by their ordinal; each goes through the launch
         // record and the general code
-        const uint32_t nmask = B.tiles.groups * B.tiles.mask_k;
-        const uint64_t* __restrict__ grow = B.tiles.gen + (size_t)(tile0 / TILE_FRAMES) * nmask;
+        const uint32_t kw = B.tiles.k1 - B.tiles.k0, nmask = B.tiles.groups * kw;
+        const uint64_t* __restrict__ grow = B.tiles.gen + (size_t)(tile0 / TILE_FRAMES) * (B.tiles.groups * B.tiles.mask_k);
         if (tile_index == 0 && gen_part == 0 && threadIdx.x < B.tiles.groups) gen_valid[threadIdx.x] = threadIdx.x < GEN_SPLIT ? 1u : 0u;   // GEN_SPLIT general planes
         uint32_t ord = 0;
         for (uint32_t base = 0; base < nmask; base += 64) {
             const uint32_t mi = base + lane;
-            const uint64_t mine = mi < nmask ? grow[mi] : 0ull;
+            const uint64_t mine = mi < nmask ? grow[(mi / kw) * B.tiles.mask_k + B.tiles.k0 + mi % kw] : 0ull;
             uint64_t have = __ballot(mine != 0ull);
             while (have) {
                 const uint32_t src = (uint32_t)__builtin_ctzll(have);
                 have &= have - 1;
                 uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)src) << 32) |
                              (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)src);
-                const uint32_t idx = base + src;                          // mask index in the row: (group, k)
-                const uint32_t c = idx / B.tiles.mask_k + (idx % B.tiles.mask_k) * B.tiles.groups;
+                const uint32_t idx = base + src;                          // (group, k - k0)
+                const uint32_t c = idx / kw + (B.tiles.k0 + idx % kw) * B.tiles.groups;
                 while (m) {
                     const uint32_t bit = (uint32_t)__builtin_ctzll(m);
                     m &= m - 1;
@@ -372,12 +374,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         // neighbours in the voice table, whole chunks of them, and any deal of whole chunks leaves one group with twice the work of
         // another.  The masks of the tile (one contiguous row) are fetched 64 at a time, one per lane; the lists that are not empty
         // are handed round by ballot and readlane.
-        const uint32_t nmask = ngroups * B.tiles.mask_k, stride = ngroups * WAVES;
-        const uint64_t* __restrict__ lrow = B.tiles.lean + (size_t)tile_index * nmask;
+        // (only the masks k0 .. k1 - 1 of every group: the chunks of the set's range -- see TileSet)
+        const uint32_t kw = B.tiles.k1 - B.tiles.k0, nmask = ngroups * kw, stride = ngroups * WAVES;
+        const uint64_t* __restrict__ lrow = B.tiles.lean + (size_t)tile_index * (ngroups * B.tiles.mask_k);
         uint32_t firstp = grp * WAVES + wave;
         for (uint32_t base = 0; base < nmask; base += 64) {
             const uint32_t mi = base + lane;
-            const uint64_t mymask = mi < nmask ? lrow[mi] : 0ull;
+            const uint64_t mymask = mi < nmask ? lrow[(mi / kw) * B.tiles.mask_k + B.tiles.k0 + mi % kw] : 0ull;
             uint64_t have = __ballot(mymask != 0ull);
             while (have) {
             const uint32_t src = (uint32_t)__builtin_ctzll(have);
@@ -385,8 +388,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             const uint64_t cmask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mymask >> 32), (int)src) << 32) |
                                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mymask, (int)src);
             const uint32_t npairs = (uint32_t)__popcll(cmask);
-            const uint32_t idx = base + src;                              // mask index in the row: (group, k) of the prepare step's layout
-            const uint32_t c = idx / B.tiles.mask_k + (idx % B.tiles.mask_k) * ngroups;
+            const uint32_t idx = base + src;                              // (group, k - k0) of the prepare step's layout
+            const uint32_t c = idx / kw + (B.tiles.k0 + idx % kw) * ngroups;
             const TileRec SH_CONST_AS* q = trow + c * 64 + firstp;
             uint32_t p = firstp;
             for (; p < npairs; p += stride, q += stride) {
@@ -956,6 +959,16 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     const uint32_t prep_wgs = (next.launch && !K.prepare_in_tile) ? nchunks : 0u;
     if (tiled) {
         const uint32_t ntiles = sh::div_up(nframes, TILE_FRAMES);
+        // the chunks that can sound in a block, as a range of mask slots k (chunk c = group + k groups): [k0, k1)
+        auto k_range = [&](uint64_t s0, uint32_t& k0, uint32_t& k1) {
+            uint32_t c_lo = nchunks, c_hi = 0;
+            const uint64_t s1 = s0 + (uint64_t)nframes;
+            for (uint32_t c = 0; c < nchunks; ++c)
+                if (!(s1 <= b->chunk_span[2 * c] || s0 >= b->chunk_span[2 * c + 1])) { c_lo = c < c_lo ? c : c_lo; c_hi = c + 1; }
+            k0 = c_hi ? c_lo / groups : 0u;
+            k1 = c_hi ? sh::div_up(c_hi, groups) : 0u;
+        };
+        uint32_t tile_prep_chunks = 0;
         const int ks = (int)(b->tile_count % sh_bank::NTILESETS);
         TileSet& T = b->tile_set[ks];
         sh_bank::TileSpec& sp = b->tile_spec[ks];
@@ -964,6 +977,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             // not predicted (the first launches of a run, a jump): resolve it in front of the render
             rc = grow_tile_set(b->tile_block[ks], T, b->tile_carved[ks], ntiles, b->nvoices, groups, st);
             if (rc) return rc;
+            k_range(start, T.k0, T.k1);
             P.tiles = T;
             rc = launch_prepare_tiles(st, P, T, b->nvoices, start, nframes);
             if (rc) return rc;
@@ -976,25 +990,29 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             TileSet& T2 = b->tile_set[k2];
             rc = grow_tile_set(b->tile_block[k2], T2, b->tile_carved[k2], ntiles, b->nvoices, groups, st);
             if (rc) return rc;
+            k_range(next_start, T2.k0, T2.k1);
             P.next_tiles = T2;
             P.next_ntiles = ntiles;
-            const uint32_t runs = sh::div_up(ntiles, TILES_PER_WAVE), units = nchunks * sh::div_up(runs, 4);
-            P.next_tile_wgs = sh::div_up(units, groups);
+            uint32_t in_range = (T2.k1 - T2.k0) * groups;                 // chunks of the range (the last slot's may not all exist)
+            if (T2.k1 * groups > nchunks) in_range -= T2.k1 * groups - nchunks;
+            P.next_tile_wgs = in_range * sh::div_up(sh::div_up(ntiles, TILES_PER_WAVE), 4);
+            tile_prep_chunks = in_range;
             sh_bank::TileSpec& s2 = b->tile_spec[k2];
             s2.valid = true; s2.start = next_start; s2.nframes = nframes; s2.groups = groups;
         }
         P.tiles = T;
-        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups + sh::div_up(prep_wgs, tiles)), dim3(256), 0, st, P,
+        const uint32_t prep_t = next.launch ? tile_prep_chunks : 0u;          // record-prepare workgroups: the chunks of that range
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups + sh::div_up(prep_t, tiles)), dim3(256), 0, st, P,
                            trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
+                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_t);
         SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
         {   // the general pairs: GEN_SPLIT workgroups per 256-frame tile, each all voice groups' pairs of it
             LaunchSet none = cur;
             none.launch = nullptr;
-            const uint32_t gen_wgs = sh::div_up(sh::div_up(nframes, 256) * GEN_SPLIT, groups);
+            const uint32_t gen_wgs = sh::div_up(nframes, 256) * GEN_SPLIT;
             // (on a stream of its own beside the lean kernel it was slower, 95 against 75 us per block: five streams share four
             // hardware queues, and a kernel that waits for an event holds up whatever shares its queue)
-            hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(P.next_tile_wgs + gen_wgs, groups), dim3(256), 0, st, P,
+            hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs + P.next_tile_wgs), dim3(256), 0, st, P,
                                trig_table(), b->nvoices, vpg, cur, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
                                (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
                                gen_valid, (const uint32_t*)nullptr, 0u);
