@@ -51,11 +51,25 @@ struct alignas(64) TileRec {
     double GL, GR;                // amplitude * bus gain (negated at a convex corner)
     double tb[2], db[2];          // pieces 1, 2: frames i - tile0 >= split[k] lie on piece k + 1, t = fma(i - tile0 - split[k], db[k], tb[k])
     uint16_t split[2];            // 0xFFFF: no such piece
-    uint16_t npieces;
+    uint16_t npieces;             // 0: a WALK pair -- more piece ends than a record lists (the first tiles of a note: its phase sum runs
+                                  // through a binade every few frames) and / or an onset with the end of the attack behind it.  The lean
+                                  // kernel reads the pieces from the voice's table itself: tb[0] = the voice's own index of the tile's first
+                                  // frame (negative: the onset lies inside), tb[1] = (table index of the first piece | end of the voice's
+                                  // table << 32) as bits; the frames in front of the onset get the angle 0 -- sin 0 = 0 -- and the envelope
+                                  // is the minimum of the two lines behind the onset
     uint16_t corner;              // 1: the two lines differ
     double pad_;
 };
+constexpr uint32_t TILE_WALK_PIECES = 16;     // pieces a walk pair may touch (lanes 0 .. 15 fetch one each)
 static_assert(sizeof(TileRec) == 128 && offsetof(TileRec, GL) == 64 && offsetof(TileRec, tb) == 80 && offsetof(TileRec, split) == 112, "TileRec layout");
+// lane `src` (wave-uniform) of a float64 vector value
+__device__ __forceinline__ double readlane_f64(double v, uint32_t src) {
+    union { double d; int u[2]; } a, b;
+    a.d = v;
+    b.u[0] = __builtin_amdgcn_readlane(a.u[0], (int)src);
+    b.u[1] = __builtin_amdgcn_readlane(a.u[1], (int)src);
+    return b.d;
+}
 // the position of the (p + 1)-th set bit of m (p < popcount(m)): wave-uniform scalar arithmetic, six halvings
 __device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t p) {
     uint32_t pos = 0;
@@ -1135,7 +1149,7 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         const uint64_t abs0 = start + (uint64_t)t * TILE_FRAMES;
         uint64_t abs1 = abs0 + TILE_FRAMES;
         if (abs1 > launch_end) abs1 = launch_end;
-        bool is_lean = false, is_gen = false;
+        bool is_lean = false, is_gen = false, is_walk = false;
         double rec_t0 = 0.0, rec_ea0 = 0.0, rec_ea1 = 0.0, rec_eb0 = 0.0, rec_eb1 = 0.0;
         uint32_t rec_extra = 0, rec_env_max = 0, r = 0;
         uint16_t rec_split[2] = {0xFFFFu, 0xFFFFu};
@@ -1143,7 +1157,8 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         const long long n0 = (long long)abs0 - (long long)onset, n1 = (long long)abs1 - (long long)onset;
         const double dn0 = (double)n0;
         const uint64_t nn0 = n0 > 0 ? (uint64_t)n0 : 0ull;
-        bool env_ok = true, sounds = valid && abs1 > onset;
+        bool env_ok = true, walk_ok = true, sounds = valid && abs1 > onset;      // walk_ok: the envelope a WALK pair can carry (see TileRec)
+        double wa0 = 1.0, wa1 = 0.0, wb0 = 1.0, wb1 = 0.0;
         if (sounds) {
             // ---- envelope: the line that holds n0 (-1: the silence in front of the onset) and, if one corner lies inside the
             // tile, the line behind it ----
@@ -1164,6 +1179,14 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
                 if (p == 4) {                                // behind the release: silent, but for the one extra sample at its end
                     sounds = e_tail && n0 == cn[3];
                     env_ok = false;
+                    walk_ok = false;
+                } else if (p == -1 && p1 <= 1) {             // the onset inside: silence | attack [| decay]
+                    line(-1, ea0, ea1);
+                    line(0, eb0, eb1);
+                    env_max = 1;
+                    env_ok = p1 == 0;
+                    line(0, wa0, wa1);                       // (a walk pair: the attack, the decay -- or the attack twice; the frames in
+                    line(p1, wb0, wb1);                      //  front of the onset are silenced through their angle)
                 } else if (p1 == p) {
                     line(p, ea0, ea1);
                     eb0 = ea0; eb1 = ea1;
@@ -1173,12 +1196,14 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
                     env_max = (uint32_t)(p & 1);             // p = -1, 1, 3
                 } else {
                     env_ok = false;                          // two corners in one tile (lines of zero length included)
+                    walk_ok = false;
                 }
             } else if (n0 < 0) {
                 env_ok = false;                              // an onset without an envelope is a step: not the meeting of two lines
-            }
+            }                                                // (a walk pair carries it: the constant 1 behind the onset)
             rec_ea0 = ea0; rec_ea1 = ea1; rec_eb0 = eb0; rec_eb1 = eb1;
             rec_env_max = env_max;
+            if (!(e_on && n0 < 0)) { wa0 = ea0; wa1 = ea1; wb0 = eb0; wb1 = eb1; }
         }
         // ---- phase table: the piece that holds nn0 and the ends of pieces inside the tile, from the window; a lane whose window
         // does not show the three pieces behind its own (and the table goes on) slides it -- with one batch of loads ----
@@ -1205,7 +1230,17 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
 #pragma unroll
             for (uint32_t k = 0; k < TILE_MAX_PIECES; ++k) extra += (uint32_t)(starts[k] < (uint64_t)n1);
             is_lean = lean_capable && env_ok && extra < TILE_MAX_PIECES;
-            is_gen = !is_lean;
+            // more piece ends, or an onset with the attack's end behind it: a WALK pair, if the tile touches at most TILE_WALK_PIECES pieces
+            if (lean_capable && !is_lean && walk_ok) {
+                const uint32_t far = wb + r + TILE_WALK_PIECES;
+                is_walk = far >= cnt || tab[far].n0 >= (uint64_t)n1;
+            }
+            is_gen = !is_lean && !is_walk;
+            if (is_walk) {
+                // (the record's fields, re-used: see TileRec)
+                rec_ea0 = wa0; rec_ea1 = wa1; rec_eb0 = wb0; rec_eb1 = wb1;
+                if (n0 < 0) rec_env_max = 0;                 // behind an onset the two lines meet in a concave corner (or are one line)
+            }
             if (is_lean) {
                 rec_t0 = fma(dn0 - (double)p_n0, p_dt, p_t0);
                 rec_extra = extra;
@@ -1213,11 +1248,11 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
                 for (uint32_t k = 0; k < 2; ++k) rec_split[k] = k < extra ? (uint16_t)((long long)starts[k] - n0) : (uint16_t)0xFFFFu;
             }
         }
-        const uint64_t ml = __ballot(is_lean), mg = __ballot(is_gen);
+        const uint64_t ml = __ballot(is_lean || is_walk), mg = __ballot(is_gen);
 #ifdef SH_X_NOSTORE
         if (is_lean && rec_t0 == 1.2345e-300) {
 #else
-        if (is_lean) {                                           // the chunk's lean pairs, compacted in voice order
+        if (is_lean || is_walk) {                                // the chunk's lean pairs, compacted in voice order
 #endif
             TileRec* __restrict__ q = T.recs + (size_t)t * slots + c * 64 + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
             const bool corner = !(rec_ea0 == rec_eb0 && rec_ea1 == rec_eb1);
@@ -1228,10 +1263,13 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             q2[2] = make_double2(sg * rec_ea0, sg * rec_ea1);
             q2[3] = make_double2(sg * rec_eb0, sg * rec_eb1);
             q2[4] = make_double2(sg * (amp * bgl), sg * (amp * bgr));
-            q2[5] = make_double2(rec_extra > 0 ? win_pick<double>(w_t0, r + 1, 0.0) : 0.0, rec_extra > 1 ? win_pick<double>(w_t0, r + 2, 0.0) : 0.0);
+            union { uint64_t u; double d; } walk_bits;
+            walk_bits.u = (uint64_t)(off + wb + r) | ((uint64_t)(off + cnt) << 32);
+            q2[5] = is_walk ? make_double2(dn0, walk_bits.d)
+                            : make_double2(rec_extra > 0 ? win_pick<double>(w_t0, r + 1, 0.0) : 0.0, rec_extra > 1 ? win_pick<double>(w_t0, r + 2, 0.0) : 0.0);
             q2[6] = make_double2(rec_extra > 0 ? win_pick<double>(w_dt, r + 1, 0.0) : 0.0, rec_extra > 1 ? win_pick<double>(w_dt, r + 2, 0.0) : 0.0);
             union { uint16_t h[4]; double d; } tail;
-            tail.h[0] = rec_split[0]; tail.h[1] = rec_split[1]; tail.h[2] = (uint16_t)(1 + rec_extra); tail.h[3] = corner ? 1 : 0;
+            tail.h[0] = rec_split[0]; tail.h[1] = rec_split[1]; tail.h[2] = is_walk ? (uint16_t)0 : (uint16_t)(1 + rec_extra); tail.h[3] = corner ? 1 : 0;
             q2[7] = make_double2(tail.d, 0.0);
         }
         if (lane == 0) {

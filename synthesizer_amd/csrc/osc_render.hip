@@ -165,6 +165,25 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         gen_part = bx_ % GEN_SPLIT;
         bx_ /= GEN_SPLIT;
         if (bx_ * (64 * FPL) >= nframes) return;
+        if (bx_ == 0 && gen_part == 0 && threadIdx.x < B.tiles.groups) gen_valid[threadIdx.x] = threadIdx.x < GEN_SPLIT ? 1u : 0u;   // GEN_SPLIT general planes
+        {   // a tile without a general pair (nearly all of them, since the first tiles of a note are walk pairs of the lean kernel):
+            // zeros into this workgroup's share of the plane, and out -- before the table, the barrier, the reduction
+            const uint32_t kw = B.tiles.k1 - B.tiles.k0, nmask = B.tiles.groups * kw;
+            const uint64_t* __restrict__ grow = B.tiles.gen + (size_t)((bx_ * (64 * FPL)) / TILE_FRAMES) * (B.tiles.groups * B.tiles.mask_k);
+            bool any = false;
+            for (uint32_t base = 0; base < nmask; base += 64) {
+                const uint32_t mi = base + (threadIdx.x & 63);
+                const uint64_t mine = mi < nmask ? grow[(mi / kw) * B.tiles.mask_k + B.tiles.k0 + mi % kw] : 0ull;
+                any = any || __ballot(mine != 0ull) != 0ull;
+            }
+            if (!any) {
+                for (uint32_t f = threadIdx.x; f < 64 * FPL; f += WAVES * 64) {
+                    const uint32_t raw = bx_ * (64 * FPL) + f;
+                    if (raw < nframes) parts[(size_t)(B.tiles.groups + gen_part) * nframes + raw] = make_double2(0.0, 0.0);
+                }
+                return;
+            }
+        }
     }
     const uint32_t bx = bx_;       // the tile (or, segmented: the tile counter) of this workgroup
     if constexpr (MODE == RENDER_GENERAL_ONLY) {       // (a segmented launch always writes its parts: see below)
@@ -323,7 +342,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         // record and the general code
         const uint32_t kw = B.tiles.k1 - B.tiles.k0, nmask = B.tiles.groups * kw;
         const uint64_t* __restrict__ grow = B.tiles.gen + (size_t)(tile0 / TILE_FRAMES) * (B.tiles.groups * B.tiles.mask_k);
-        if (tile_index == 0 && gen_part == 0 && threadIdx.x < B.tiles.groups) gen_valid[threadIdx.x] = threadIdx.x < GEN_SPLIT ? 1u : 0u;   // GEN_SPLIT general planes
         uint32_t ord = 0;
         for (uint32_t base = 0; base < nmask; base += 64) {
             const uint32_t mi = base + lane;
@@ -421,6 +439,52 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                     s1 = fma(s0, rc, c0s * rs);
                     c1s = fma(c0s, rc, -(s0 * rs));
                     lean_tile_frames<FPL>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL, GR, ea0, ea1, eb0, eb1, lane_d, accl, accr);
+                } else if ((pc & 0xFFFFu) == 0u) {
+                    // a WALK pair (see TileRec): lanes 0 .. 15 fetch a piece of the voice's table each -- one round trip -- and every
+                    // frame takes the angle of the last piece that starts at or in front of it; a frame in front of them all (the
+                    // onset lies inside the tile) keeps the angle 0, whose sine is 0
+                    const double eb0 = q->eb0, eb1 = q->eb1, dn0 = q->tb[0];
+                    const uint64_t wbits = *reinterpret_cast<const uint64_t SH_CONST_AS*>(&q->tb[1]);
+                    const uint32_t seg_first = (uint32_t)wbits, seg_end = (uint32_t)(wbits >> 32);
+                    const uint32_t kidx = seg_first + (lane & (TILE_WALK_PIECES - 1));
+                    const bool have_piece = lane < TILE_WALK_PIECES && kidx < seg_end;
+                    const sh_segment* sp = B.segs + (have_piece ? kidx : seg_first);
+                    const uint64_t pn0 = sp->n0;
+                    const double pt0 = sp->t0, pdt = sp->dt;
+                    const double prel = (double)(long long)pn0 - dn0;             // the piece's first frame, relative to the tile's
+                    const uint32_t npc = (uint32_t)__popcll(__ballot(have_piece && prel < (double)TILE_FRAMES));
+                    double th[FPL];
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) th[j] = 0.0;
+                    for (uint32_t k = 0; k < npc; ++k) {
+                        const double rk = readlane_f64(prel, k), tk = readlane_f64(pt0, k), dk = readlane_f64(pdt, k);
+#pragma unroll
+                        for (int j = 0; j < FPL; ++j) {
+                            const double x = lane_d + (double)(j * 64);
+                            th[j] = x >= rk ? fma(x - rk, dk, tk) : th[j];
+                        }
+                    }
+                    // (the polynomial once more, behind the walk: its sixteen coefficients would sit in scalar registers through a loop
+                    // that needs those for the pieces -- and what the scalar file cannot hold costs vector registers this kernel lacks)
+                    const uint64_t pp_bits = (uint64_t)pp;
+                    const double SH_CONST_AS* pp2 = (const double SH_CONST_AS*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pp_bits >> 32)) << 32) |
+                                                                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pp_bits));
+                    double poly2[16];
+#pragma unroll
+                    for (int v_ = 0; v_ < 16; ++v_) poly2[v_] = pp2[v_];
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) {
+                        const double x = lane_d + (double)(j * 64);
+                        double sj, cj;
+                        shm::sincos_tab(th[j], trig, sj, cj);
+                        double pj = fma(poly2[0], cj, poly2[1]);
+#pragma unroll
+                        for (int u = 2; u < 16; ++u) pj = fma(pj, cj, poly2[u]);
+                        const double ej = fmin(fma(x, ea1, ea0), fma(x, eb1, eb0));
+                        const double xj = (pj * sj) * ej;
+                        accl[j] = fma(GL, xj, accl[j]);
+                        accr[j] = fma(GR, xj, accr[j]);
+                    }
                 } else {
                     // piece ends inside the tile: every frame by lookup from the piece that holds it
                     const double eb0 = q->eb0, eb1 = q->eb1;
