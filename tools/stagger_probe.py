@@ -25,6 +25,7 @@ for _ in range(10):
 out["headline_us"] = bench.steady(N, step, min_seconds=0.15, reps=20) * 1e3
 r = bench.staggered_row(N, 48000)
 out["staggered_us"] = r["ms_per_step"] * 1e3
+out["standing_start_us"] = r["from_a_standing_start_ms_per_step"] * 1e3
 out["ratio"] = out["staggered_us"] / out["headline_us"]
 out["host_build_s"] = r["host_build_s"]
 print(json.dumps(out))
