@@ -34,9 +34,11 @@ struct SegTab { uint32_t n; uint32_t first[SEG_MAX]; uint32_t len[SEG_MAX]; uint
 // voice can take the lean loop is decided per (voice, tile of TILE_FRAMES frames), not per launch.  A pair is LEAN when the voice
 // is a polynomial-Harmonics voice and the tile holds at most ONE corner of its envelope -- the onset counts as one: silence |
 // attack -- and at most two ends of pieces of its phase table; then 128 bytes and the voice's polynomial (a table by voice) say all the lean arithmetic needs:
-//   * the envelope over the tile is min or max of two lines (silence|attack: max; attack|decay: min; decay|sustain: max;
-//     sustain|release: min; release|silence: max; no corner: the same line twice) -- no select per frame, no list of corners;
-//     in front of an onset the attack's line is negative, the maximum with 0 is 0, and whatever the phase is there is multiplied by it;
+//   * the envelope over the tile is one line in front of the corner's frame and another from it on (no corner: the same line
+//     twice) -- one compare and select per frame in the tiles that hold a corner, no list of corners.  (First version: the minimum
+//     or maximum of the two lines, one operation -- wrong by up to one step of the slope in the corner's frame: the reference
+//     switches lines at an INTEGER frame, where the lines need not have met yet; found by a bank of notes with ADSR times that are
+//     no multiples of the sample period, tests/test_gpu_onsets.py.)  In front of an onset the line is the constant 0;
 //   * piece ends inside the tile (the first tile of a note runs through several binades of its phase sum) make it a multi-piece
 //     tile: every frame is looked up from the piece that holds it (up to three compares), no recurrence across the ends.
 // A pair that sounds but holds two corners (or an onset without an attack) or more piece ends takes the general code for that
@@ -46,9 +48,8 @@ constexpr uint32_t TILE_MAX_PIECES = 3;
 struct alignas(64) TileRec {
     double t0, dt;                // t(i) = fma(i - tile0, dt, t0): the accumulated phase at the tile's first frame, its piece's step
     double rc, rs;                // cos / sin of 64 dt
-    double ea0, ea1, eb0, eb1;    // envelope(i) = MIN of ea0 + (i - tile0) ea1 and eb0 + (i - tile0) eb1 -- a convex corner (the envelope is the
-                                  // maximum of its two lines) is stored with both lines AND the gains negated: max(a, b) g = min(-a, -b) (-g)
-    double GL, GR;                // amplitude * bus gain (negated at a convex corner)
+    double ea0, ea1, eb0, eb1;    // envelope(i) = ea0 + (i - tile0) ea1 for i - tile0 < corner, eb0 + (i - tile0) eb1 from there on
+    double GL, GR;                // amplitude * bus gain
     double tb[2], db[2];          // pieces 1, 2: frames i - tile0 >= split[k] lie on piece k + 1, t = fma(i - tile0 - split[k], db[k], tb[k])
     uint16_t split[2];            // 0xFFFF: no such piece
     uint16_t npieces;             // 0: a WALK pair -- more piece ends than a record lists (the first tiles of a note: its phase sum runs
@@ -57,7 +58,7 @@ struct alignas(64) TileRec {
                                   // frame (negative: the onset lies inside), tb[1] = (table index of the first piece | end of the voice's
                                   // table << 32) as bits; the frames in front of the onset get the angle 0 -- sin 0 = 0 -- and the envelope
                                   // is the minimum of the two lines behind the onset
-    uint16_t corner;              // 1: the two lines differ
+    uint16_t corner;              // the first frame (relative to the tile's) of the second line; 0: no corner in the tile
     double pad_;
 };
 constexpr uint32_t TILE_WALK_PIECES = 16;     // pieces a walk pair may touch (lanes 0 .. 15 fetch one each)
@@ -1151,7 +1152,7 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         if (abs1 > launch_end) abs1 = launch_end;
         bool is_lean = false, is_gen = false, is_walk = false;
         double rec_t0 = 0.0, rec_ea0 = 0.0, rec_ea1 = 0.0, rec_eb0 = 0.0, rec_eb1 = 0.0;
-        uint32_t rec_extra = 0, rec_env_max = 0, r = 0;
+        uint32_t rec_extra = 0, rec_corner = 0, r = 0;
         uint16_t rec_split[2] = {0xFFFFu, 0xFFFFu};
         // the voice's own indices [n0, n1) of the tile; n0 < 0: the onset lies inside (or the voice has not started)
         const long long n0 = (long long)abs0 - (long long)onset, n1 = (long long)abs1 - (long long)onset;
@@ -1159,11 +1160,12 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         const uint64_t nn0 = n0 > 0 ? (uint64_t)n0 : 0ull;
         bool env_ok = true, walk_ok = true, sounds = valid && abs1 > onset;      // walk_ok: the envelope a WALK pair can carry (see TileRec)
         double wa0 = 1.0, wa1 = 0.0, wb0 = 1.0, wb1 = 0.0;
+        uint32_t w_corner = 0;
         if (sounds) {
             // ---- envelope: the line that holds n0 (-1: the silence in front of the onset) and, if one corner lies inside the
             // tile, the line behind it ----
             double ea0 = 1.0, ea1 = 0.0, eb0 = 1.0, eb1 = 0.0;
-            uint32_t env_max = 0;
+            uint32_t corner_i = 0;                            // the first frame of the second line, relative to the tile's
             if (e_on) {
                 const long long cn[4] = {(long long)e_na, (long long)e_nd, (long long)e_ns, (long long)e_nr};
                 const int p = (n0 >= 0) + (n0 >= cn[0]) + (n0 >= cn[1]) + (n0 >= cn[2]) + (n0 >= cn[3]) - 1;
@@ -1183,17 +1185,18 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
                 } else if (p == -1 && p1 <= 1) {             // the onset inside: silence | attack [| decay]
                     line(-1, ea0, ea1);
                     line(0, eb0, eb1);
-                    env_max = 1;
+                    corner_i = (uint32_t)(-n0);
                     env_ok = p1 == 0;
                     line(0, wa0, wa1);                       // (a walk pair: the attack, the decay -- or the attack twice; the frames in
                     line(p1, wb0, wb1);                      //  front of the onset are silenced through their angle)
+                    w_corner = p1 == 1 ? (uint32_t)(cn[0] - n0) : 0u;
                 } else if (p1 == p) {
                     line(p, ea0, ea1);
                     eb0 = ea0; eb1 = ea1;
-                } else if (p1 == p + 1) {                    // one corner inside: convex (max) behind silence, decay and release; concave (min) behind attack and sustain
-                    line(p, ea0, ea1);
-                    line(p + 1, eb0, eb1);
-                    env_max = (uint32_t)(p & 1);             // p = -1, 1, 3
+                } else if (p1 == p + 1) {                    // one corner inside (p >= 0): the reference changes lines at frame cn[p] -- and plays
+                    line(p, ea0, ea1);                       // one more sample at the release's end if its accumulated amplitude is still
+                    line(p + 1, eb0, eb1);                   // positive (has_tail): the release's line, one frame longer
+                    corner_i = (uint32_t)(cn[p] - n0) + ((p == 3 && e_tail) ? 1u : 0u);
                 } else {
                     env_ok = false;                          // two corners in one tile (lines of zero length included)
                     walk_ok = false;
@@ -1202,8 +1205,8 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
                 env_ok = false;                              // an onset without an envelope is a step: not the meeting of two lines
             }                                                // (a walk pair carries it: the constant 1 behind the onset)
             rec_ea0 = ea0; rec_ea1 = ea1; rec_eb0 = eb0; rec_eb1 = eb1;
-            rec_env_max = env_max;
-            if (!(e_on && n0 < 0)) { wa0 = ea0; wa1 = ea1; wb0 = eb0; wb1 = eb1; }
+            rec_corner = corner_i;
+            if (!(e_on && n0 < 0)) { wa0 = ea0; wa1 = ea1; wb0 = eb0; wb1 = eb1; w_corner = corner_i; }
         }
         // ---- phase table: the piece that holds nn0 and the ends of pieces inside the tile, from the window; a lane whose window
         // does not show the three pieces behind its own (and the table goes on) slides it -- with one batch of loads ----
@@ -1239,7 +1242,7 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             if (is_walk) {
                 // (the record's fields, re-used: see TileRec)
                 rec_ea0 = wa0; rec_ea1 = wa1; rec_eb0 = wb0; rec_eb1 = wb1;
-                if (n0 < 0) rec_env_max = 0;                 // behind an onset the two lines meet in a concave corner (or are one line)
+                rec_corner = w_corner;
             }
             if (is_lean) {
                 rec_t0 = fma(dn0 - (double)p_n0, p_dt, p_t0);
@@ -1255,21 +1258,22 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         if (is_lean || is_walk) {                                // the chunk's lean pairs, compacted in voice order
 #endif
             TileRec* __restrict__ q = T.recs + (size_t)t * slots + c * 64 + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
-            const bool corner = !(rec_ea0 == rec_eb0 && rec_ea1 == rec_eb1);
-            const double sg = (corner && rec_env_max) ? -1.0 : 1.0;        // a convex corner: max(a, b) g = min(-a, -b) (-g)
+            // (a corner at the tile's end -- the tail sample of a release is its last frame -- is no corner of this tile)
+            const uint32_t corner = (rec_corner > 0 && rec_corner < TILE_FRAMES && !(rec_ea0 == rec_eb0 && rec_ea1 == rec_eb1)) ? rec_corner : 0u;
+            if (!corner) { rec_eb0 = rec_ea0; rec_eb1 = rec_ea1; }
             double2* __restrict__ q2 = reinterpret_cast<double2*>(q);      // eight 16-byte stores
             q2[0] = make_double2(rec_t0, win_pick<double>(w_dt, r, 0.0));
             q2[1] = rot;
-            q2[2] = make_double2(sg * rec_ea0, sg * rec_ea1);
-            q2[3] = make_double2(sg * rec_eb0, sg * rec_eb1);
-            q2[4] = make_double2(sg * (amp * bgl), sg * (amp * bgr));
+            q2[2] = make_double2(rec_ea0, rec_ea1);
+            q2[3] = make_double2(rec_eb0, rec_eb1);
+            q2[4] = make_double2(amp * bgl, amp * bgr);
             union { uint64_t u; double d; } walk_bits;
             walk_bits.u = (uint64_t)(off + wb + r) | ((uint64_t)(off + cnt) << 32);
             q2[5] = is_walk ? make_double2(dn0, walk_bits.d)
                             : make_double2(rec_extra > 0 ? win_pick<double>(w_t0, r + 1, 0.0) : 0.0, rec_extra > 1 ? win_pick<double>(w_t0, r + 2, 0.0) : 0.0);
             q2[6] = make_double2(rec_extra > 0 ? win_pick<double>(w_dt, r + 1, 0.0) : 0.0, rec_extra > 1 ? win_pick<double>(w_dt, r + 2, 0.0) : 0.0);
             union { uint16_t h[4]; double d; } tail;
-            tail.h[0] = rec_split[0]; tail.h[1] = rec_split[1]; tail.h[2] = is_walk ? (uint16_t)0 : (uint16_t)(1 + rec_extra); tail.h[3] = corner ? 1 : 0;
+            tail.h[0] = rec_split[0]; tail.h[1] = rec_split[1]; tail.h[2] = is_walk ? (uint16_t)0 : (uint16_t)(1 + rec_extra); tail.h[3] = (uint16_t)corner;
             q2[7] = make_double2(tail.d, 0.0);
         }
         if (lane == 0) {

@@ -45,11 +45,12 @@ constexpr bool mode_has_lean(int mode) { return mode != RENDER_DIRECT && !mode_g
 constexpr uint32_t GEN_SPLIT = 2;      // general workgroups per tile of a tile-classified launch (each writes a plane of general parts; <= groups)
 
 // lean_harm_frames for a (voice, tile) pair of a tile-classified launch with a corner of the envelope inside: the envelope of
-// frame i is the minimum of two lines in the tile-relative index, applied to the sample before the (constant) bus gains.
+// frame i is one line in front of frame ci (tile-relative) and another from there on, applied to the sample before the (constant)
+// bus gains.
 template <int FPL, typename Theta>
 __device__ __forceinline__ void lean_tile_frames(double s0, double c0, double s1, double c1, double k2, bool straddle, Theta theta,
                                                  TrigTab trig, const double (&poly)[16], double GL, double GR,
-                                                 double ea0, double ea1, double eb0, double eb1, double dl,
+                                                 double ea0, double ea1, double eb0, double eb1, double ci, double dl,
                                                  double (&accl)[FPL], double (&accr)[FPL]) {
     static_assert(FPL % 2 == 0, "frames in pairs");
 #pragma unroll
@@ -61,8 +62,7 @@ __device__ __forceinline__ void lean_tile_frames(double s0, double c0, double s1
             p1 = fma(p1, c1, poly[u]);
         }
         const double i0 = dl + (double)(h * 64), i1 = dl + (double)((h + 1) * 64);
-        const double a0 = fma(i0, ea1, ea0), b0 = fma(i0, eb1, eb0), a1 = fma(i1, ea1, ea0), b1 = fma(i1, eb1, eb0);
-        const double e0 = fmin(a0, b0), e1 = fmin(a1, b1);      // (a convex corner arrives negated, gains included: see TileRec)
+        const double e0 = i0 < ci ? fma(i0, ea1, ea0) : fma(i0, eb1, eb0), e1 = i1 < ci ? fma(i1, ea1, ea0) : fma(i1, eb1, eb0);
         const double x0 = (p0 * s0) * e0, x1 = (p1 * s1) * e1;
         accl[h] = fma(GL, x0, accl[h]);
         accr[h] = fma(GR, x0, accr[h]);
@@ -386,7 +386,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         static_assert(64 * FPL == TILE_FRAMES, "the lean kernel's tile is the tile of the classification");
         const size_t slots = set_slots(nvoices);
         const TileRec SH_CONST_AS* trow = as_const(B.tiles.recs) + (size_t)tile_index * slots;
-        const double lane_d = (double)lane;
         // The voice groups of a tile-classified launch do not partition the CHUNKS but every chunk's list: entry p of a list goes
         // to group p / WAVES mod groups, wave p mod WAVES (the offset carries over from list to list) -- notes that sound together are
         // neighbours in the voice table, whole chunks of them, and any deal of whole chunks leaves one group with twice the work of
@@ -413,6 +412,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             for (; p < npairs; p += stride, q += stride) {
                 const double t0 = q->t0, dt = q->dt, rc = q->rc, rs = q->rs, ea0 = q->ea0, ea1 = q->ea1, GL = q->GL, GR = q->GR;
                 const uint32_t pc = *reinterpret_cast<const uint32_t SH_CONST_AS*>(&q->npieces);      // npieces | corner << 16
+                uint32_t lane_again = lane;                               // (converted per entry: two registers less across the loop)
+                asm volatile("" : "+v"(lane_again));
+                const double lane_d = (double)lane_again;
                 // the voice of the list's entry p: the chunk's (p + 1)-th set bit -- its polynomial comes from the table by voice (read by
                 // every tile's workgroups: it lives in L2), at an address that does not wait for the record
                 const double SH_CONST_AS* pp = as_const(B.polys) + (size_t)(c * 64 + nth_set_bit(cmask, p)) * 16;
@@ -432,13 +434,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                     c1s = fma(c0s, rc, -(s0 * rs));
                     lean_harm_frames<FPL, true>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL * ea0, GR * ea0, accl, accr, GL * ea1, GR * ea1, lane_d);
                 } else if ((pc & 0xFFFFu) == 1u) {
-                    // one piece, a corner: the envelope is the minimum of two lines
+                    // one piece, a corner: the envelope changes lines at frame pc >> 16
                     const double eb0 = q->eb0, eb1 = q->eb1;
                     double s0, c0s, s1, c1s;
                     shm::sincos_tab(fma(lane_d, dt, t0), trig, s0, c0s);
                     s1 = fma(s0, rc, c0s * rs);
                     c1s = fma(c0s, rc, -(s0 * rs));
-                    lean_tile_frames<FPL>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL, GR, ea0, ea1, eb0, eb1, lane_d, accl, accr);
+                    lean_tile_frames<FPL>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL, GR, ea0, ea1, eb0, eb1, (double)(pc >> 16), lane_d, accl, accr);
                 } else if ((pc & 0xFFFFu) == 0u) {
                     // a WALK pair (see TileRec): lanes 0 .. 15 fetch a piece of the voice's table each -- one round trip -- and every
                     // frame takes the angle of the last piece that starts at or in front of it; a frame in front of them all (the
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                         double pj = fma(poly2[0], cj, poly2[1]);
 #pragma unroll
                         for (int u = 2; u < 16; ++u) pj = fma(pj, cj, poly2[u]);
-                        const double ej = fmin(fma(x, ea1, ea0), fma(x, eb1, eb0));
+                        const double ej = x < (double)(pc >> 16) ? fma(x, ea1, ea0) : fma(x, eb1, eb0);
                         const double xj = (pj * sj) * ej;
                         accl[j] = fma(GL, xj, accl[j]);
                         accr[j] = fma(GR, xj, accr[j]);
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                     double s0, c0s, s1, c1s;
                     shm::sincos_tab(theta(0), trig, s0, c0s);
                     shm::sincos_tab(theta(1), trig, s1, c1s);
-                    lean_tile_frames<FPL>(s0, c0s, s1, c1s, 0.0, true, theta, trig, poly, GL, GR, ea0, ea1, eb0, eb1, lane_d, accl, accr);
+                    lean_tile_frames<FPL>(s0, c0s, s1, c1s, 0.0, true, theta, trig, poly, GL, GR, ea0, ea1, eb0, eb1, (double)(pc >> 16), lane_d, accl, accr);
                 }
             }
             firstp = p - npairs;

@@ -168,3 +168,63 @@ def test_staggered_notes_tile_by_tile(gpu, tmp_path):
     other = np.load(ref)
     for k in range(4):
         assert rms(got[k], other[k]) <= 2e-8, k
+
+
+def _mixed_notes(m, n, seed):
+    """n polynomial-Harmonics notes with onsets over three seconds, in the order they start: a third under a short-attack ADSR of
+    their own (the attack ends inside the onset's tile), a third without any envelope (the onset is a step), a third under the
+    bench's ADSR; fundamentals up to 9 kHz (the phase sum of a high voice runs through a dozen binades in its first tile)."""
+    rng = np.random.default_rng(seed)
+    f = np.exp(rng.uniform(np.log(40.0), np.log(9000.0), n))
+    amp = rng.uniform(0.1, 1.0, n) / np.sqrt(n)
+    phase = rng.uniform(0.0, 1.0, n)
+    onsets = np.sort(rng.integers(0, 3 * SR, n))
+    onsets[:3] = (0, 1, 511)
+    kinds = rng.integers(0, 3, n)
+    gains = [(float(np.float32(g)), float(np.float32(1.0 - g))) for g in rng.uniform(0.0, 1.0, n)]
+    voices = []
+    for i in range(n):
+        nh = int(rng.integers(1, 17))
+        osc = m.Harmonics(float(f[i]), [(k, 1.0 / k) for k in range(1, nh + 1)], amplitude=float(amp[i]), phase=float(phase[i]), samplerate=SR)
+        if kinds[i] == 0:
+            osc = m.EnvelopeFilter(osc, float(rng.uniform(0.0002, 0.004)), float(rng.uniform(0.001, 0.02)), float(rng.uniform(0.0, 0.3)), 0.5,
+                                   float(rng.uniform(0.001, 0.3)))
+        elif kinds[i] == 2:
+            osc = m.EnvelopeFilter(osc, 0.01, 0.05, 0.5, 0.6, 0.2)
+        voices.append(m.DelayFilter(osc, int(onsets[i]) / SR) if onsets[i] else osc)
+    return voices, gains, onsets
+
+
+def test_walk_pairs_steps_and_chunk_ranges(gpu):
+    """Tile-classified launches over a table of 1500 notes (24 chunks, a few of which sound in any block): onset tiles as walk pairs
+    (many piece ends, the attack's end behind the onset, onsets without an envelope), the range of chunks per block, a stream of
+    blocks, a jump back, one long launch -- against the C oracle, block by block."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    n_voices, block, nblocks = 1500, 16384, 7
+    gv, gains, onsets = _mixed_notes(G, n_voices, 21)
+    ov, _, _ = _mixed_notes(O, n_voices, 21)
+    n = block * nblocks
+    rows = np.zeros((n_voices, n))
+    for i, v in enumerate(ov):
+        d = int(SR * v._seconds) if isinstance(v, O.DelayFilter) else 0      # (DelayFilter's own count of frames: onsets[i] or one less)
+        if d < n:
+            rows[i, d:] = CO.render(v._source if isinstance(v, O.DelayFilter) else v, n - d)
+    want = CO.mix_bus(rows, gains)
+    assert np.abs(want).max() > 0.02
+    bank = VoiceBank(gv, gains=gains)
+    ring = [N.DeviceBuffer(block * 8) for _ in range(4)]
+    read = lambda b: b.download(np.float32, block * 2).reshape(block, 2)
+    for k in list(range(nblocks)) + [2, 3, 4, 0, 1]:              # a stream, a jump back into it, the start again
+        bank.render_device(block, k * block, bus_f32=ring[k & 3])
+        assert rms(read(ring[k & 3]), want[k * block:(k + 1) * block]) <= RMS_TOL, k
+    # the stream without reading in between (the pipeline stays up: sets resolved two launches ahead, chunk ranges that move)
+    for rep in range(2):
+        for k in range(nblocks):
+            bank.render_device(block, k * block, bus_f32=ring[k & 3])
+    for k in range(nblocks - 4, nblocks):
+        assert rms(read(ring[k & 3]), want[k * block:(k + 1) * block]) <= RMS_TOL, k
+    whole = bank.render(n - 77)
+    assert rms(whole, want[:n - 77]) <= RMS_TOL
+    assert np.max(np.abs(whole - want[:n - 77])) < 5e-6
