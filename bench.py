@@ -109,6 +109,34 @@ def cpu_baseline(frames: int, all_cores: bool = True):
         out["c_port"] = {"value": VOICES_PER_GPU * frames / dtc / 1e6, "unit": "Msamples/s", "cores": 1, "wall_s": dtc}
     except Exception as e:                           # no C compiler on the box: the Python number stands alone
         out["c_port"] = {"error": str(e)}
+    # ... and the C restatement over all host cores (threads: ctypes drops the GIL around the C call; voices dealt to the threads,
+    # the partial buses of the threads added at the end -- timed): the yardstick a maintainer with a compiler and a many-core box
+    # would reach for first, and the honest denominator for "how much faster is the GPU than this host"
+    if all_cores and "error" not in out["c_port"]:
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            ncores = os.cpu_count() or 1
+            nthr = max(1, min(ncores, 64, VOICES_PER_GPU))
+            cframes = 8 * frames
+            shares = [voices[VOICES_PER_GPU * i // nthr:VOICES_PER_GPU * (i + 1) // nthr] for i in range(nthr)]
+            gshares = [gains[VOICES_PER_GPU * i // nthr:VOICES_PER_GPU * (i + 1) // nthr] for i in range(nthr)]
+
+            def share(k):
+                return CO.mix_bus(np.stack([CO.render(v, cframes) for v in shares[k]]), gshares[k])
+            with ThreadPoolExecutor(nthr) as ex:
+                list(ex.map(lambda k: CO.render(shares[k][0], 64), range(nthr)))      # threads up
+                t0 = time.perf_counter()
+                parts = list(ex.map(share, range(nthr)))
+                bus = parts[0]
+                for p_ in parts[1:]:
+                    bus = bus + p_
+                dtt = time.perf_counter() - t0
+            out["c_port_all_cores"] = {"value": VOICES_PER_GPU * cframes / dtt / 1e6, "unit": "Msamples/s", "cores": nthr, "host_cpu_count": ncores,
+                                       "wall_s": dtt, "frames": cframes,
+                                       "note": "oracle/oracle.c over %d threads (one share of the 1024 voices each, %d frames), partial buses added; "
+                                               "16 libm sin per voice-sample" % (nthr, cframes)}
+        except Exception as e:
+            out["c_port_all_cores"] = {"error": str(e)}
     # BASELINE.md's optional leg: the same pure-Python sample over all host cores (one process per core, voices split evenly)
     if all_cores:
         try:
