@@ -156,9 +156,13 @@ int  sh_sync(void);                       /* wait for the stream */
 /* What the library did behind the caller's back since sh_init: driver allocations (hipMalloc: pool misses, growing blocks),
  * driver frees, host-side stream synchronisations it inserted on its own (NOT the caller's sh_sync / downloads / timers), and
  * buffers served from the pool.  A streaming caller in its steady state -- blocks of lengths it has rendered before, buffers
- * of sizes it has used before -- must leave the first three unchanged (tests/test_gpu_bank.py asserts it). */
+ * of sizes it has used before -- must leave the first three unchanged (tests/test_gpu_pipeline.py asserts it).  Then which shape
+ * the bank renders took: launches cut into segments at shared envelope corners (RENDER_*_SEG), launches classified per (voice,
+ * tile) (RENDER_*_TILES: banks whose notes do not move in lock-step), and of those the ones whose tile set had been resolved
+ * two launches ahead -- so that a test can tell that the path it means to exercise is the one that ran. */
 typedef struct sh_counters {
     uint64_t device_allocs, device_frees, stream_syncs, pool_hits;
+    uint64_t segmented_launches, tiled_launches, tiled_predicted;
 } sh_counters;
 int  sh_debug_counters(sh_counters* out);
 

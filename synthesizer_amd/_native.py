@@ -58,7 +58,8 @@ assert VOICE_DTYPE.itemsize == 248, VOICE_DTYPE.itemsize
 
 
 class Counters(C.Structure):
-    _fields_ = [("device_allocs", C.c_uint64), ("device_frees", C.c_uint64), ("stream_syncs", C.c_uint64), ("pool_hits", C.c_uint64)]
+    _fields_ = [("device_allocs", C.c_uint64), ("device_frees", C.c_uint64), ("stream_syncs", C.c_uint64), ("pool_hits", C.c_uint64),
+                ("segmented_launches", C.c_uint64), ("tiled_launches", C.c_uint64), ("tiled_predicted", C.c_uint64)]
 
 
 class DevInfo(C.Structure):
@@ -240,7 +241,7 @@ def debug_counters() -> dict:
     """Driver allocations / frees / self-inserted stream synchronisations / pool hits since sh_init (sh_debug_counters)."""
     c = Counters()
     check(lib().sh_debug_counters(C.byref(c)))
-    return {"device_allocs": c.device_allocs, "device_frees": c.device_frees, "stream_syncs": c.stream_syncs, "pool_hits": c.pool_hits}
+    return {name: getattr(c, name) for name, _ in Counters._fields_}
 
 
 def sync() -> None:

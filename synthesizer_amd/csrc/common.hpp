@@ -94,6 +94,7 @@ struct Counters {
     uint64_t device_frees = 0;     // hipFree calls
     uint64_t stream_syncs = 0;     // host-side waits the library inserted on its own (growing a buffer; NOT the caller's sh_sync / downloads)
     uint64_t pool_hits = 0;        // buffers handed out again without touching the driver
+    uint64_t segmented_launches = 0, tiled_launches = 0, tiled_predicted = 0;     // which shape the bank renders took
 };
 Counters& counters();
 // Every extern "C" entry point holds this for its whole body: one stream, one scratch buffer, one pool and one pending

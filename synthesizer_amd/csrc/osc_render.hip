@@ -1039,6 +1039,8 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         TileSet& T = b->tile_set[ks];
         sh_bank::TileSpec& sp = b->tile_spec[ks];
         BankPtrs P = ptrs(b);
+        sh::counters().tiled_launches += 1;
+        if (sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups) sh::counters().tiled_predicted += 1;
         if (!(sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups)) {
             // not predicted (the first launches of a run, a jump): resolve it in front of the render
             rc = grow_tile_set(b->tile_block[ks], T, b->tile_carved[ks], ntiles, b->nvoices, groups, st);
@@ -1086,6 +1088,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         }
         b->tile_count += 1;
     } else if (nseg) {
+        sh::counters().segmented_launches += 1;
         const int ks = use_aux ? 1 : 0;
         LaunchSet& g = b->seg_set[ks];
         rc = grow_segment_sets(b->seg_block[ks], g, b->seg_cap[ks], nseg, b->nvoices);

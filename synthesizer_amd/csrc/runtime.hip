@@ -288,6 +288,9 @@ int sh_debug_counters(sh_counters* out) {
     out->device_frees = c.device_frees;
     out->stream_syncs = c.stream_syncs;
     out->pool_hits = c.pool_hits;
+    out->segmented_launches = c.segmented_launches;
+    out->tiled_launches = c.tiled_launches;
+    out->tiled_predicted = c.tiled_predicted;
     return SH_OK;
 }
 

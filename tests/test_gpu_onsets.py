@@ -146,7 +146,9 @@ def test_staggered_notes_tile_by_tile(gpu, tmp_path):
             rows[i, d:] = CO.render(v._source if isinstance(v, O.DelayFilter) else v, n - d)
     want = CO.mix_bus(rows, gains)
     bank = VoiceBank(gv, gains=gains)
+    before = N.debug_counters()["tiled_launches"]
     got = [bank.render(block, start=k * block) for k in range(4)]
+    assert N.debug_counters()["tiled_launches"] - before == 4
     for k in range(4):
         assert rms(got[k], want[k * block:(k + 1) * block]) <= RMS_TOL, k
     assert np.abs(want).max() > 0.05
@@ -216,6 +218,7 @@ def test_walk_pairs_steps_and_chunk_ranges(gpu):
     bank = VoiceBank(gv, gains=gains)
     ring = [N.DeviceBuffer(block * 8) for _ in range(4)]
     read = lambda b: b.download(np.float32, block * 2).reshape(block, 2)
+    before = N.debug_counters()
     for k in list(range(nblocks)) + [2, 3, 4, 0, 1]:              # a stream, a jump back into it, the start again
         bank.render_device(block, k * block, bus_f32=ring[k & 3])
         assert rms(read(ring[k & 3]), want[k * block:(k + 1) * block]) <= RMS_TOL, k
@@ -225,6 +228,9 @@ def test_walk_pairs_steps_and_chunk_ranges(gpu):
             bank.render_device(block, k * block, bus_f32=ring[k & 3])
     for k in range(nblocks - 4, nblocks):
         assert rms(read(ring[k & 3]), want[k * block:(k + 1) * block]) <= RMS_TOL, k
+    after = N.debug_counters()
+    assert after["tiled_launches"] - before["tiled_launches"] == nblocks + 5 + 2 * nblocks          # every one of them tile-classified
+    assert after["tiled_predicted"] - before["tiled_predicted"] >= 2 * nblocks - 4                  # ... the stream on sets resolved ahead
     whole = bank.render(n - 77)
     assert rms(whole, want[:n - 77]) <= RMS_TOL
     assert np.max(np.abs(whole - want[:n - 77])) < 5e-6
