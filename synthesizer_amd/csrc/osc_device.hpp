@@ -148,6 +148,7 @@ struct BankPtrs {
     // workgroups per row of the grid, behind the workgroups that resolve that block's launch records
     TileSet           next_tiles;
     uint32_t          next_tile_wgs, next_ntiles;
+    uint32_t          next_rec_wgs;        // RENDER_GENERAL_TILES: workgroups (four chunks each) that resolve that block's launch records
 };
 
 // Pointers to data that no thread of the running kernel writes are cast to the constant address space:

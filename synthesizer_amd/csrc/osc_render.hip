@@ -149,9 +149,28 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         __builtin_amdgcn_s_setprio(3);
         // (a one-dimensional grid: the general workgroups first -- theirs is the longer job and the other stream's lean kernel
         // leaves this one few slots -- then next_tile_wgs prepare workgroups over the chunks of the next set's range)
-        if (blockIdx.x >= gridDim.x - B.next_tile_wgs) {
+        // ... and next_rec_wgs workgroups that resolve the LAUNCH RECORDS of that block's chunks, one chunk per wavefront: in the lean
+        // kernel every such wavefront (3000 instructions at raised priority) held up the tile workgroups of its SIMD, and a launch
+        // lasts as long as its slowest SIMD (60 against 53 us); here there is slack
+        if (blockIdx.x >= gridDim.x - B.next_rec_wgs) {
+            const uint32_t c = B.next_tiles.k0 * B.next_tiles.groups + (blockIdx.x - (gridDim.x - B.next_rec_wgs)) * WAVES + (threadIdx.x >> 6);
+            if (next.launch && c < (nvoices + 63) / 64 && c < B.next_tiles.k1 * B.next_tiles.groups) {
+                // (a chunk whose voices are all silent in that block is not resolved at all: the set is marked sparse on the host)
+                const uint64_t span_lo = as_const(B.chunk_span)[2 * c], span_hi = as_const(B.chunk_span)[2 * c + 1];
+                if (next_start + (uint64_t)nframes <= span_lo || next_start >= span_hi) {
+                    if ((threadIdx.x & 63) == 0) {
+                        const uint32_t in_chunk = nvoices - c * 64 < 64u ? nvoices - c * 64 : 64u;
+                        next.counts[4 * c] = 0; next.counts[4 * c + 1] = 0; next.counts[4 * c + 2] = in_chunk; next.counts[4 * c + 3] = 0;
+                    }
+                } else {
+                    prepare_chunk(B, next, c, nvoices, next_start, nframes);
+                }
+            }
+            return;
+        }
+        if (blockIdx.x >= gridDim.x - B.next_rec_wgs - B.next_tile_wgs) {
             const uint32_t runs = (B.next_ntiles + TILES_PER_WAVE - 1) / TILES_PER_WAVE, wgs_per_chunk = (runs + 3) / 4;
-            const uint32_t unit = blockIdx.x - (gridDim.x - B.next_tile_wgs);
+            const uint32_t unit = blockIdx.x - (gridDim.x - B.next_rec_wgs - B.next_tile_wgs);
             const uint32_t c = B.next_tiles.k0 * B.next_tiles.groups + unit / wgs_per_chunk, run = (unit % wgs_per_chunk) * 4 + (threadIdx.x >> 6);
             if (c < (nvoices + 63) / 64) prepare_tiles_wave(B, B.next_tiles, nvoices, next_start, nframes, B.next_ntiles, c, run);
             return;
@@ -432,7 +451,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                     shm::sincos_tab(fma(lane_d, dt, t0), trig, s0, c0s);
                     s1 = fma(s0, rc, c0s * rs);
                     c1s = fma(c0s, rc, -(s0 * rs));
-                    lean_harm_frames<FPL, true>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL * ea0, GR * ea0, accl, accr, GL * ea1, GR * ea1, lane_d);
+                    if (ea1 == 0.0)          // a flat line (the sustain: two thirds of a note's life): the headline's loop, two operations per frame less
+                        lean_harm_frames<FPL>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL * ea0, GR * ea0, accl, accr);
+                    else
+                        lean_harm_frames<FPL, true>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL * ea0, GR * ea0, accl, accr, GL * ea1, GR * ea1, lane_d);
                 } else if ((pc & 0xFFFFu) == 1u) {
                     // one piece, a corner: the envelope changes lines at frame pc >> 16
                     const double eb0 = q->eb0, eb1 = q->eb1;
@@ -1069,19 +1091,20 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             s2.valid = true; s2.start = next_start; s2.nframes = nframes; s2.groups = groups;
         }
         P.tiles = T;
-        const uint32_t prep_t = next.launch ? tile_prep_chunks : 0u;          // record-prepare workgroups: the chunks of that range
-        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups + sh::div_up(prep_t, tiles)), dim3(256), 0, st, P,
-                           trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_t);
+        // (both prepare steps of the block two launches on -- launch records, tile set -- ride in the general kernel)
+        P.next_rec_wgs = next.launch ? sh::div_up(tile_prep_chunks, 4u) : 0u;
+        LaunchSet no_next = next;
+        no_next.launch = nullptr;
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups), dim3(256), 0, st, P,
+                           trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
         SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
         {   // the general pairs: GEN_SPLIT workgroups per 256-frame tile, each all voice groups' pairs of it
-            LaunchSet none = cur;
-            none.launch = nullptr;
             const uint32_t gen_wgs = sh::div_up(nframes, 256) * GEN_SPLIT;
             // (on a stream of its own beside the lean kernel it was slower, 95 against 75 us per block: five streams share four
             // hardware queues, and a kernel that waits for an event holds up whatever shares its queue)
-            hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs + P.next_tile_wgs), dim3(256), 0, st, P,
-                               trig_table(), b->nvoices, vpg, cur, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
+            hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs + P.next_tile_wgs + P.next_rec_wgs), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
                                (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
                                gen_valid, (const uint32_t*)nullptr, 0u);
             SH_CHECK_LAUNCH("k_bank_render(general, tiles)");
