@@ -993,7 +993,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // loop, the others the general code for that tile only (see TileRec).
     bool tiled = false;
     if (split && mode == RENDER_LEAN_HARM && var == 484 && b->all_lean && !K.no_tiles && !b->needs_rows &&
-        !b->no_general_voice(start, nframes) && (b->has_onsets || b->own_envelopes))
+        !b->no_general_voice(start, nframes) && (b->has_onsets || b->own_envelopes || K.tiles_for_all == 1))
         tiled = (uint64_t)sh::div_up(nframes, TILE_FRAMES) * set_slots(b->nvoices) * sizeof(TileRec) <= ((uint64_t)1 << 30);
     uint32_t seg_first[SEG_MAX + 1];
     uint32_t nseg = 0;
