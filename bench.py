@@ -518,7 +518,7 @@ def main() -> int:
     ap.add_argument("--no-pcm-rows", action="store_true", help="skip the resample / integer-mix rows")
     ap.add_argument("--no-two-step", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the rows of the other BASELINE configs")
-    ap.add_argument("--only-config", choices=("config2", "config3", "config4"), default=None,
+    ap.add_argument("--only-config", choices=("config2", "config3", "config4", "staggered"), default=None,
                     help="run ONLY that config's row and print it (tools/profile_round.sh: one rocprofv3 pass per config)")
     ap.add_argument("--reduce-batch", type=int, default=8, help="blocks per RCCL reduce when --gpus > 1 (also the length of a run of pipelined renders)")
     args = ap.parse_args()
@@ -546,6 +546,9 @@ def main() -> int:
         dist.init(rank, world, broadcast=gloo_broadcast)
 
     K, Wm, F = args.steps, args.warmup, args.frames
+    if args.only_config == "staggered":
+        print(json.dumps({"only_config": "staggered", "library": N.lib().sh_version().decode(), "configs": {"staggered_notes": staggered_row(N, F)}}), flush=True)
+        return 0
     if args.only_config:
         rows = config_rows(N, committed_profile(), only=args.only_config, K=K)
         print(json.dumps({"only_config": args.only_config, "library": N.lib().sh_version().decode(), "configs": rows}), flush=True)

@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ
     --output-format csv -d "$D" -o sq2 -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
 # the other BASELINE configs that fit one GPU, each in passes of its own (bench.py --only-config: that config's steady-state loop
 # and nothing else), so that its kernels' durations and counters are not averaged with the headline's launches of the same kernel
-for CFG in config2 config3; do
+for CFG in config2 config3 staggered; do
   CMD="python bench.py --only-config $CFG"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o ${CFG}_stats -- $CMD > gpurun_out/prof_${TAG}_${CFG}.json 2>> gpurun_out/prof_${TAG}_stats.err
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$D" -o ${CFG}_fetch -- $CMD > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err

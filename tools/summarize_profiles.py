@@ -112,7 +112,7 @@ for fname, title in (("sq1_counter_collection.csv", "SQ instruction mix"), ("sq2
 # ---- the other BASELINE configs: passes of their own (bench.py --only-config), keys "configN:<kernel>" ----
 import json
 cfg_traffic, cfg_counters = {}, {}
-for cfg in ("config2", "config3"):
+for cfg in ("config2", "config3", "staggered"):
     st = src / ("%s_stats_kernel_stats.csv" % cfg)
     if not st.exists():
         continue
@@ -126,9 +126,9 @@ for cfg in ("config2", "config3"):
     lines += ["", "## %s: `rocprofv3 ... -- python bench.py --only-config %s`" % (cfg, cfg), ""]
     if row:
         for name, r in row.get("configs", {}).items():
-            if "ms_per_1s_block" in r:
+            if "ms_per_1s_block" in r or "ms_per_step" in r:
                 lines.append("bench row under rocprofv3: **%s** %.2f us per 1-s block (HIP events), host enqueue %.1f us per block" %
-                             (name, r["ms_per_1s_block"] * 1e3, r.get("host_enqueue_us_per_block", float("nan"))))
+                             (name, r.get("ms_per_1s_block", r.get("ms_per_step")) * 1e3, r.get("host_enqueue_us_per_block", float("nan"))))
         lines.append("")
     lines += ["| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(st)):
