@@ -37,4 +37,5 @@ for CFG in config2 config3 staggered; do
       --output-format csv -d "$D" -o ${CFG}_sq2 -- $CMD > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
 done
 rm -f "$D"/*_kernel_trace.csv "$D"/*_domain_stats.csv          # large; the stats and counter tables are what is summarised
+python tools/reduce_counters.py "$D"                            # a row per (kernel, counter): the raw tables exceed what travels back
 ls -la "$D"
