@@ -100,6 +100,7 @@ struct sh_bank {
     float2*     d_gains = nullptr;
     uint32_t    nsegs = 0, ncoefs = 0, npartials = 0;
     std::vector<sh_voice> h_voices;    // for validation of per-call arguments
+    long long   first_row_voice = -1;  // the first voice that reads a modulation / sample row (SH_FM_BUFFER, SH_BUFFER); -1: none
 };
 
 namespace shosc {

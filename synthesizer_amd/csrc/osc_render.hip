@@ -911,6 +911,14 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // two FMAs of trigonometry (one table lookup per eight frames)
     if (var == 0) var = b->nvoices >= 128 ? (2 * b->lean_candidates >= b->nvoices ? (nframes >= 16384 ? 484 : 444) : 844)
                                           : (b->nvoices >= 64 ? 821 : (b->nvoices >= 8 ? 421 : 211));
+    // A bank whose notes do not move in lock-step takes the tile-classified launch (below) at EVERY block length: in real-time
+    // chunks (256 .. 4096 frames) the general code walked the whole table for every tile -- a table of 22 528 notes, ~780 of them
+    // sounding: 60 .. 85 us per chunk where the arithmetic is 2 us.  The lean tiles kernel has one shape (four waves, 512-frame
+    // tiles); a short launch is a few tiles of it, with more voice groups (but not hundreds: their partial buses are folded
+    // frame by frame).
+    const bool tile_candidate = K.variant == 0 && mode == RENDER_LEAN_HARM && b->nvoices >= 128 && b->all_lean && !K.no_tiles && !b->needs_rows &&
+                                (b->has_onsets || b->own_envelopes || K.tiles_for_all == 1) && !b->no_general_voice(start, nframes);
+    if (tile_candidate) var = 484;
     const int W = var / 100, F = (var / 10) % 10;
     // Voice groups: split the voices when the frame range alone gives too few tiles for 256 CUs -- up to ONE round of
     // resident workgroups (1024 slots of four waves), not beyond: 752 workgroups that all start at once beat 1504 whose
@@ -924,6 +932,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     } else {                                                 // the eight-wave shapes of small / non-lean banks: cover the chip several times over
         while (tiles * groups < 1024 && b->nvoices / (groups * 2) >= (uint32_t)(4 * W)) groups *= 2;
     }
+    if (tile_candidate && groups > 32) groups = 32;
     if (K.groups > 0) groups = (uint32_t)K.groups;
     uint32_t vpg = (b->nvoices + groups - 1) / groups;
     if (groups > 1) vpg = (vpg + 63) & ~63u;                // groups are made of whole 64-voice chunks (the lists' unit)

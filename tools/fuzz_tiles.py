@@ -1,7 +1,8 @@
 """Random banks of NOTES -- every voice with an onset and an ADSR of its own (zero-length phases, envelopes that end, voices without
-an envelope), fundamentals up to 12 kHz, 1 .. 16 partials -- rendered as streams of long launches, which take the tile-classified
-path (csrc/osc_render.hip RENDER_*_TILES: lean / corner / multi-piece / walk pairs, chunk ranges that move with the block), against
-the same frames rendered as launches of 8192 frames (never tile-classified: below the eight-frames-per-lane shape).
+an envelope), fundamentals up to 12 kHz, 1 .. 16 partials -- rendered as streams of launches of 256 .. 48 000 frames, which take the
+tile-classified path (csrc/osc_render.hip RENDER_*_TILES: lean / corner / multi-piece / walk pairs, chunk ranges that move with the
+block), against the float64 buses of the same frames rendered by sub-banks of 100 voices (never tile-classified: below 128 voices)
+added up in float64.
 usage: python tools/fuzz_tiles.py [seed] [cases]"""
 import sys
 
@@ -43,11 +44,13 @@ for case in range(cases):
         d = int(onsets[i])
         voices.append(G.DelayFilter(osc, d / SR) if d else osc)
         gains.append((float(rng.uniform(0, 1)), float(rng.uniform(0, 1))))
-    bank, ref = VoiceBank(voices, gains=gains), VoiceBank(voices, gains=gains)
-    n = int(rng.choice([16384, 20000, 32768, 48000]))
+    bank = VoiceBank(voices, gains=gains)
+    refs = [VoiceBank(voices[a:a + 100], gains=gains[a:a + 100]) for a in range(0, nv, 100)]
+    n = int(rng.choice([256, 1000, 4096, 16384, 20000, 48000]))
+    ref64 = N.DeviceBuffer(n * 16)
     first = int(rng.choice([0, 0, 1, 2]))
     ring = [N.DeviceBuffer(n * 8) for _ in range(4)]
-    nblocks = int(rng.integers(3, 7))
+    nblocks = int(rng.integers(3, 7)) if n >= 16384 else int(rng.integers(6, 40))
     plan = list(range(first, first + nblocks))
     if rng.random() < 0.3:
         plan += [first, first + 1]                                   # a jump back
@@ -55,7 +58,10 @@ for case in range(cases):
         bank.render_device(n, k * n, bus_f32=ring[k & 3])
         if k < plan[-1] - 3 or k == plan[-1] or rng.random() < 0.5:  # (not every block is read at once: the pipeline stays up)
             got = ring[k & 3].download(np.float32, n * 2).reshape(n, 2)
-            want = np.concatenate([ref.render(min(8192, n - o), start=k * n + o) for o in range(0, n, 8192)])
+            want = np.zeros((n, 2))
+            for r_ in refs:
+                r_.render_device(n, k * n, bus_f32=None, bus_f64=ref64)
+                want += ref64.download(np.float64, n * 2).reshape(n, 2)
             scale = max(1e-3, float(np.max(np.abs(want))))
             err = float(np.max(np.abs(got.astype(np.float64) - want))) / scale
             launches += 1
