@@ -115,7 +115,6 @@ BankPtrs ptrs(const sh_bank* b) {
     p.tiles = TileSet{nullptr, nullptr, nullptr, 0, 0, 0};
     p.next_tiles = p.tiles;
     p.next_tile_wgs = 0;
-    p.next_rec_wgs = 0;
     p.next_ntiles = 0;
     p.polys = b->d_polys;
     p.chunk_span = b->d_chunk_span;

@@ -148,7 +148,6 @@ struct BankPtrs {
     // workgroups per row of the grid, behind the workgroups that resolve that block's launch records
     TileSet           next_tiles;
     uint32_t          next_tile_wgs, next_ntiles;
-    uint32_t          next_rec_wgs;        // RENDER_GENERAL_TILES: workgroups (four chunks each) that resolve that block's launch records
 };
 
 // Pointers to data that no thread of the running kernel writes are cast to the constant address space:
@@ -1068,8 +1067,12 @@ __device__ __forceinline__ V win_pick(const V (&a)[TILE_WIN], uint32_t r, V beyo
     for (int k = 0; k < TILE_WIN; ++k) x = r == (uint32_t)k ? a[k] : x;
     return x;
 }
+// `recs` (a stream of blocks: the record set of that launch; NULL: the launch records have been resolved by a kernel of their own):
+// only the general pairs of a tile-classified launch read launch records, so a lane resolves its voice's record HERE, and only if
+// one of its tiles came out general -- for a table of notes that is next to never (as a step of its own, a wavefront per sounding
+// chunk, the records cost the general kernel its longest chain: 10 .. 19 us where the classification takes 8).
 __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes,
-                                                   uint32_t ntiles, uint32_t c, uint32_t run) {
+                                                   uint32_t ntiles, uint32_t c, uint32_t run, const LaunchSet* recs = nullptr) {
     const uint32_t lane = threadIdx.x & 63, vi = c * 64 + lane;
     const size_t slots = set_slots(nvoices);
     const uint32_t t_begin = run * TILES_PER_WAVE;
@@ -1147,6 +1150,8 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         }
     };
     load_window();
+    bool any_general = false, any_sound = false;
+    uint32_t last_piece = 0;
     for (uint32_t t = t_begin; t < t_end; ++t) {
         const uint64_t abs0 = start + (uint64_t)t * TILE_FRAMES;
         uint64_t abs1 = abs0 + TILE_FRAMES;
@@ -1252,6 +1257,8 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
                 for (uint32_t k = 0; k < 2; ++k) rec_split[k] = k < extra ? (uint16_t)((long long)starts[k] - n0) : (uint16_t)0xFFFFu;
             }
         }
+        any_general = any_general || is_gen;
+        if (sounds) { any_sound = true; last_piece = wb + r; }
         const uint64_t ml = __ballot(is_lean || is_walk), mg = __ballot(is_gen);
 #ifdef SH_X_NOSTORE
         if (is_lean && rec_t0 == 1.2345e-300) {
@@ -1281,6 +1288,17 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             const size_t at = ((size_t)t * T.groups + c % T.groups) * T.mask_k + c / T.groups;
             T.lean[at] = ml;
             T.gen[at] = mg;
+        }
+    }
+    if (recs) {
+        if (valid && any_general) {
+            PrepInfo info;
+            prepare_voice<false>(B, 0u, vi, start, nframes, recs->launch, recs->fm, info);       // (sets the voice's hint as well)
+        } else if (valid && any_sound) {
+            B.hint[vi] = last_piece;                             // where the next block's window starts looking
+        }
+        if (run == 0 && lane == 0) {                             // (sh_bank_launch_stats of a tile-classified launch: not by voice)
+            recs->counts[4 * c] = 0; recs->counts[4 * c + 1] = 0; recs->counts[4 * c + 2] = 0; recs->counts[4 * c + 3] = 0;
         }
     }
 }

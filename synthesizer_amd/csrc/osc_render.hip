@@ -149,30 +149,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         __builtin_amdgcn_s_setprio(3);
         // (a one-dimensional grid: the general workgroups first -- theirs is the longer job and the other stream's lean kernel
         // leaves this one few slots -- then next_tile_wgs prepare workgroups over the chunks of the next set's range)
-        // ... and next_rec_wgs workgroups that resolve the LAUNCH RECORDS of that block's chunks, one chunk per wavefront: in the lean
-        // kernel every such wavefront (3000 instructions at raised priority) held up the tile workgroups of its SIMD, and a launch
-        // lasts as long as its slowest SIMD (60 against 53 us); here there is slack
-        if (blockIdx.x >= gridDim.x - B.next_rec_wgs) {
-            const uint32_t c = B.next_tiles.k0 * B.next_tiles.groups + (blockIdx.x - (gridDim.x - B.next_rec_wgs)) * WAVES + (threadIdx.x >> 6);
-            if (next.launch && c < (nvoices + 63) / 64 && c < B.next_tiles.k1 * B.next_tiles.groups) {
-                // (a chunk whose voices are all silent in that block is not resolved at all: the set is marked sparse on the host)
-                const uint64_t span_lo = as_const(B.chunk_span)[2 * c], span_hi = as_const(B.chunk_span)[2 * c + 1];
-                if (next_start + (uint64_t)nframes <= span_lo || next_start >= span_hi) {
-                    if ((threadIdx.x & 63) == 0) {
-                        const uint32_t in_chunk = nvoices - c * 64 < 64u ? nvoices - c * 64 : 64u;
-                        next.counts[4 * c] = 0; next.counts[4 * c + 1] = 0; next.counts[4 * c + 2] = in_chunk; next.counts[4 * c + 3] = 0;
-                    }
-                } else {
-                    prepare_chunk(B, next, c, nvoices, next_start, nframes);
-                }
-            }
-            return;
-        }
-        if (blockIdx.x >= gridDim.x - B.next_rec_wgs - B.next_tile_wgs) {
+        // (the launch records of that block: resolved by the same wavefronts, for the voices that need one -- prepare_tiles_wave)
+        if (blockIdx.x >= gridDim.x - B.next_tile_wgs) {
             const uint32_t runs = (B.next_ntiles + TILES_PER_WAVE - 1) / TILES_PER_WAVE, wgs_per_chunk = (runs + 3) / 4;
-            const uint32_t unit = blockIdx.x - (gridDim.x - B.next_rec_wgs - B.next_tile_wgs);
+            const uint32_t unit = blockIdx.x - (gridDim.x - B.next_tile_wgs);
             const uint32_t c = B.next_tiles.k0 * B.next_tiles.groups + unit / wgs_per_chunk, run = (unit % wgs_per_chunk) * 4 + (threadIdx.x >> 6);
-            if (c < (nvoices + 63) / 64) prepare_tiles_wave(B, B.next_tiles, nvoices, next_start, nframes, B.next_ntiles, c, run);
+            if (c < (nvoices + 63) / 64) prepare_tiles_wave(B, B.next_tiles, nvoices, next_start, nframes, B.next_ntiles, c, run, next.launch ? &next : nullptr);
             return;
         }
     }
@@ -1065,7 +1047,6 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             k0 = c_hi ? c_lo / groups : 0u;
             k1 = c_hi ? sh::div_up(c_hi, groups) : 0u;
         };
-        uint32_t tile_prep_chunks = 0;
         const int ks = (int)(b->tile_count % sh_bank::NTILESETS);
         TileSet& T = b->tile_set[ks];
         sh_bank::TileSpec& sp = b->tile_spec[ks];
@@ -1095,13 +1076,12 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             uint32_t in_range = (T2.k1 - T2.k0) * groups;                 // chunks of the range (the last slot's may not all exist)
             if (T2.k1 * groups > nchunks) in_range -= T2.k1 * groups - nchunks;
             P.next_tile_wgs = in_range * sh::div_up(sh::div_up(ntiles, TILES_PER_WAVE), 4);
-            tile_prep_chunks = in_range;
             sh_bank::TileSpec& s2 = b->tile_spec[k2];
             s2.valid = true; s2.start = next_start; s2.nframes = nframes; s2.groups = groups;
         }
         P.tiles = T;
-        // (both prepare steps of the block two launches on -- launch records, tile set -- ride in the general kernel)
-        P.next_rec_wgs = next.launch ? sh::div_up(tile_prep_chunks, 4u) : 0u;
+        // (both prepare steps of the block two launches on -- tile set, and launch records where a voice needs one -- ride in the
+        // general kernel)
         LaunchSet no_next = next;
         no_next.launch = nullptr;
         hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups), dim3(256), 0, st, P,
@@ -1112,7 +1092,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             const uint32_t gen_wgs = sh::div_up(nframes, 256) * GEN_SPLIT;
             // (on a stream of its own beside the lean kernel it was slower, 95 against 75 us per block: five streams share four
             // hardware queues, and a kernel that waits for an event holds up whatever shares its queue)
-            hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs + P.next_tile_wgs + P.next_rec_wgs), dim3(256), 0, st, P,
+            hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs + P.next_tile_wgs), dim3(256), 0, st, P,
                                trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
                                (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
                                gen_valid, (const uint32_t*)nullptr, 0u);
