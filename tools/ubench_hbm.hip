@@ -46,6 +46,23 @@ __global__ __launch_bounds__(256) void k_fill(u4* __restrict__ out, size_t nvec,
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += step) __builtin_nontemporal_store(x, out + i);
 }
 
+// fills by other shapes (round 3: what is the most a write-only stream reaches?): ordinary (temporal) stores; a contiguous chunk
+// per workgroup instead of a grid stride; 4-byte stores (a wave instruction writes 256 contiguous bytes: the materialisation kernel's)
+__global__ __launch_bounds__(256) void k_fill_temporal(u4* __restrict__ out, size_t nvec, unsigned v) {
+    const size_t step = (size_t)gridDim.x * 256;
+    const u4 x = {v, v, v, v};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += step) out[i] = x;
+}
+__global__ __launch_bounds__(256) void k_fill_chunks(u4* __restrict__ out, size_t nvec, unsigned v) {
+    const size_t per = (nvec + gridDim.x - 1) / gridDim.x, lo = (size_t)blockIdx.x * per, hi = lo + per < nvec ? lo + per : nvec;
+    const u4 x = {v, v, v, v};
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) __builtin_nontemporal_store(x, out + i);
+}
+__global__ __launch_bounds__(256) void k_fill_dword(unsigned* __restrict__ out, size_t n, unsigned v) {
+    const size_t step = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += step) __builtin_nontemporal_store(v, out + i);
+}
+
 // one thread per vector, no loop (the shape of the elementwise PCM kernels)
 __global__ __launch_bounds__(256) void k_copy_flat(const u4* __restrict__ in, u4* __restrict__ out, size_t nvec) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -84,6 +101,9 @@ int main() {
         ROW("copy  1 in flight", 2.0 * bytes, hipLaunchKernelGGL(k_copy<1>, dim3(blocks), dim3(256), 0, 0, a, b, nvec))
         ROW("copy  4 in flight", 2.0 * bytes, hipLaunchKernelGGL(k_copy<4>, dim3(blocks), dim3(256), 0, 0, a, b, nvec))
         ROW("fill", (double)bytes, hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, 0, b, nvec, 7u))
+        ROW("fill temporal", (double)bytes, hipLaunchKernelGGL(k_fill_temporal, dim3(blocks), dim3(256), 0, 0, b, nvec, 7u))
+        ROW("fill chunk per workgroup", (double)bytes, hipLaunchKernelGGL(k_fill_chunks, dim3(blocks), dim3(256), 0, 0, b, nvec, 7u))
+        ROW("fill 4-byte stores", (double)bytes, hipLaunchKernelGGL(k_fill_dword, dim3(blocks), dim3(256), 0, 0, (unsigned*)b, nvec * 4, 7u))
     }
     {
         unsigned blocks = (unsigned)(nvec / 256);
@@ -92,6 +112,7 @@ int main() {
     {
         unsigned blocks = 0;
         ROW("hipMemcpyAsync D2D", 2.0 * bytes, hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0))
+        ROW("hipMemsetAsync", (double)bytes, hipMemsetAsync(b, 3, bytes, 0))
     }
     return 0;
 }
