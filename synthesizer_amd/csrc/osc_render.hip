@@ -234,11 +234,19 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             }
         }
     }
-    // The previous launch of the stream (same shape) left its voice groups' partial buses unfolded: the workgroups of
-    // group 0 fold their tile of it now, in group order, before their own work -- instead of a 5 us kernel between
-    // every two render launches.
-    if (!mode_general(MODE) && prev_parts && blockIdx.y == 0) {
-        for (uint32_t f = threadIdx.x; f < 64 * FPL; f += WAVES * 64) {
+    // The previous launch of the stream (same shape) left its voice groups' partial buses unfolded: this launch's workgroups
+    // fold it now, in group order, before their own work -- instead of a 5 us kernel between every two render launches.  With up
+    // to sixteen groups the workgroups of group 0 fold their tile (whole 4 KB runs of every plane per load instruction); a short
+    // launch of a table of notes -- 32 groups, a handful of tiles -- would leave 34 planes to eight workgroups: there the workgroups
+    // of ALL the groups share the tile's frames, a slice each (A/B in one call: 1024 frames 15.7 -> 13.7 us, 4096 frames 20.0 ->
+    // 18.8 us; but 16 384 frames -- 32 tiles -- 30.8 -> 36.3 us and the headline 37.5 -> 38.0 us: every workgroup then starts
+    // with a round trip of loads, and a load instruction moves 64 lanes' worth instead of 256).
+    const bool fold_shared = ngroups >= 32 && gridDim.x <= 8;          // (many groups, few tiles)
+    if (!mode_general(MODE) && prev_parts && (fold_shared || blockIdx.y == 0)) {
+        const bool shared = fold_shared;
+        const uint32_t slice = shared ? (64 * FPL + ngroups - 1) / ngroups : (uint32_t)(64 * FPL), f_lo = shared ? blockIdx.y * slice : 0u;
+        const uint32_t f_hi = f_lo + slice < (uint32_t)(64 * FPL) ? f_lo + slice : (uint32_t)(64 * FPL);
+        for (uint32_t f = f_lo + threadIdx.x; f < f_hi; f += WAVES * 64) {
             const uint32_t raw = bx * (64 * FPL) + f;
             if (raw >= nframes) continue;
             double2 acc = prev_parts[raw];
