@@ -69,6 +69,24 @@ def test_single_rank_rccl_reduce(gpu):
         N.sync()
         for s in range(5 * nslots + 2, 5 * nslots + 2 - 5 * (nslots - 1), -1):    # blocks whose slots have not been reused
             assert np.array_equal(blocks[s].download(np.float32, 6000).reshape(3000, 2), alone.render(3000, s * 3000)), s
+        # a table of notes (tile-classified launches, float64 partial bus out, blocks of real-time and of one-second length) down
+        # the same ring: the lagged reduce keeps the run of renders -- and the tile sets resolved two launches ahead -- alive
+        from synthesizer_amd.workloads import staggered_notes
+        nv, ng = staggered_notes(G, 256, 48000, seed=3, period=0.5, notes=4)
+        for blk in (2048, 24000):
+            notes = dist.DistVoiceBank(nv, ng, 0, 1, batch=4)
+            notes.world, notes.batch = 2, 4
+            ref_bank = dist.DistVoiceBank(nv, ng, 0, 1).local
+            before = N.debug_counters()
+            nblk = 4 * nslots + 2
+            got = [notes.render_device(blk, s * blk) for s in range(nblk)]
+            notes.flush()
+            N.sync()
+            after = N.debug_counters()
+            assert after["tiled_launches"] - before["tiled_launches"] == nblk
+            assert after["tiled_predicted"] - before["tiled_predicted"] >= nblk - 4
+            for s in range(nblk - 1, nblk - 1 - 4 * (nslots - 1), -1):
+                assert np.array_equal(got[s].download(np.float32, blk * 2).reshape(blk, 2), ref_bank.render(blk, s * blk)), (blk, s)
     finally:
         dist.shutdown()
     assert L.sh_dist_world() == 0
