@@ -331,6 +331,14 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
         }
     for (uint32_t i = 0; i < nvoices; ++i)
         if (voices[i].start_frame) b->has_onsets = true;
+    b->tile_all = true;
+    for (uint32_t i = 0; i < nvoices; ++i) {
+        const sh_voice& v = voices[i];
+        const bool wave = v.kind == SH_SAWTOOTH || v.kind == SH_SQUARE || v.kind == SH_TRIANGLE || v.kind == SH_PULSE;
+        const bool ok = v.bias == 0.0 && !v.flip && v.fm_mode == SH_FM_NONE && ((v.kind == SH_HARMONICS && v.harm_dense == 2) || v.kind == SH_SINE || wave);
+        if (!ok) b->tile_all = false;
+        if (wave) b->tile_waveforms = true;
+    }
     {
         b->all_lean = b->lean_candidates == nvoices;
         for (uint32_t i = 0; i < nvoices && b->all_lean; ++i) {
@@ -374,9 +382,13 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     for (uint32_t i = 0; i < nvoices; ++i) lfo_rot[i] = make_double2(cos(64.0 * voices[i].lfo_d), sin(64.0 * voices[i].lfo_d));
     {   // the polynomial of every polynomial-Harmonics voice by VOICE (tile-classified launches address it without a pointer chase)
         std::vector<double> polys(set_slots(nvoices) * 16, 0.0);
-        for (uint32_t i = 0; i < nvoices; ++i)
+        // (a plain Sine is the series with one partial: sin(t) P(cos t), P = 1; a Pulse keeps its width in the first slot)
+        for (uint32_t i = 0; i < nvoices; ++i) {
             if (voices[i].kind == SH_HARMONICS && voices[i].harm_dense == 2)
                 for (int u = 0; u < 16; ++u) polys[(size_t)i * 16 + u] = coefs[voices[i].harm_offset + u];
+            else if (voices[i].kind == SH_SINE) polys[(size_t)i * 16 + 15] = 1.0;
+            else if (voices[i].kind == SH_PULSE) polys[(size_t)i * 16] = voices[i].pulsewidth;
+        }
         if (!rc) rc = upload_array(&b->d_polys, polys.data(), polys.size(), st);
         // ... and per chunk of 64 voices the frames in which any of them sounds (the extra sample sits AT the release's end)
         std::vector<uint64_t> span(2 * (size_t)sh::div_up(nvoices, 64));

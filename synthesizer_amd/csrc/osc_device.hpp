@@ -59,7 +59,7 @@ struct alignas(64) TileRec {
                                   // table << 32) as bits; the frames in front of the onset get the angle 0 -- sin 0 = 0 -- and the envelope
                                   // is the minimum of the two lines behind the onset
     uint16_t corner;              // the first frame (relative to the tile's) of the second line; 0: no corner in the tile
-    double pad_;
+    double pad_;                  // low 32 bits: LEAN_HARM (a plain Sine too: the series with one partial) or the waveform LEAN_SAW .. LEAN_PULSE
 };
 constexpr uint32_t TILE_WALK_PIECES = 16;     // pieces a walk pair may touch (lanes 0 .. 15 fetch one each)
 static_assert(sizeof(TileRec) == 128 && offsetof(TileRec, GL) == 64 && offsetof(TileRec, tb) == 80 && offsetof(TileRec, split) == 112, "TileRec layout");
@@ -1107,7 +1107,10 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
     asm volatile("" :: "v"(v_kind), "v"(v_dense), "v"(v_fm), "v"(v_flip), "v"(v_bias), "v"(amp), "v"(off_c), "v"(cnt_c), "v"(off_t), "v"(cnt_t),
                  "v"(onset), "v"(e_na), "v"(e_nd), "v"(e_ns), "v"(e_nr), "v"(e_as), "v"(e_ds), "v"(e_sl), "v"(e_rs), "v"(e_on), "v"(e_tail),
                  "v"(bgl), "v"(bgr), "v"(hint));
-    const bool lean_capable = valid && v_kind == SH_HARMONICS && v_dense == 2 && v_fm == SH_FM_NONE && v_bias == 0.0 && !v_flip;
+    // (what a lean pair can be: polynomial Harmonics, a plain Sine -- the series with one partial -- or a plain waveform; see sh_bank::tile_all)
+    const bool v_wave = v_kind == SH_SAWTOOTH || v_kind == SH_SQUARE || v_kind == SH_TRIANGLE || v_kind == SH_PULSE;
+    const bool lean_capable = valid && ((v_kind == SH_HARMONICS && v_dense == 2) || v_kind == SH_SINE || v_wave) && v_fm == SH_FM_NONE && v_bias == 0.0 && !v_flip;
+    const uint32_t rec_kind = v_kind == SH_SAWTOOTH ? LEAN_SAW : v_kind == SH_SQUARE ? LEAN_SQUARE : v_kind == SH_TRIANGLE ? LEAN_TRIANGLE : v_kind == SH_PULSE ? LEAN_PULSE : LEAN_HARM;
     const bool fm = v_fm != SH_FM_NONE;
     const uint32_t off = fm ? off_t : off_c;
     const uint32_t cnt = fm ? cnt_t : cnt_c;
@@ -1282,7 +1285,9 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             q2[6] = make_double2(rec_extra > 0 ? win_pick<double>(w_dt, r + 1, 0.0) : 0.0, rec_extra > 1 ? win_pick<double>(w_dt, r + 2, 0.0) : 0.0);
             union { uint16_t h[4]; double d; } tail;
             tail.h[0] = rec_split[0]; tail.h[1] = rec_split[1]; tail.h[2] = is_walk ? (uint16_t)0 : (uint16_t)(1 + rec_extra); tail.h[3] = (uint16_t)corner;
-            q2[7] = make_double2(tail.d, 0.0);
+            union { uint32_t u[2]; double d; } kind_bits;
+            kind_bits.u[0] = rec_kind; kind_bits.u[1] = 0u;
+            q2[7] = make_double2(tail.d, kind_bits.d);
         }
         if (lane == 0) {
             const size_t at = ((size_t)t * T.groups + c % T.groups) * T.mask_k + c / T.groups;

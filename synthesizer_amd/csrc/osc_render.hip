@@ -36,9 +36,13 @@ enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2, RENDER_LEAN
        // RENDER_LEAN_TILES / RENDER_GENERAL_TILES: the split launch of a TILE-CLASSIFIED block (see TileRec): the lean kernel walks the
        // set bits of its tile's lean masks -- a 64-byte record per (voice, tile) + the voice's polynomial, the sloped lean arithmetic,
        // no piece ends, no corners -- the general kernel the set bits of the general masks, through the launch records.
-       RENDER_LEAN_TILES = 9, RENDER_GENERAL_TILES = 10 };
-constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_HARM_SEG || mode == RENDER_LEAN_TILES; }
-constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY || mode == RENDER_LEAN_HARM_SEG || mode == RENDER_LEAN_ALL_SEG || mode == RENDER_LEAN_TILES; }
+       RENDER_LEAN_TILES = 9, RENDER_GENERAL_TILES = 10,
+       // RENDER_LEAN_TILES_ALL: the lean tiles kernel of a bank that holds plain Sawtooth / Square / Triangle / Pulse voices too (the
+       // waveform branch costs the Harmonics loop registers: an instantiation of its own, as with RENDER_LEAN_ALL)
+       RENDER_LEAN_TILES_ALL = 11 };
+constexpr bool mode_tiles(int mode) { return mode == RENDER_LEAN_TILES || mode == RENDER_LEAN_TILES_ALL; }
+constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_HARM_SEG || mode_tiles(mode); }
+constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY || mode == RENDER_LEAN_HARM_SEG || mode == RENDER_LEAN_ALL_SEG || mode_tiles(mode); }
 constexpr bool mode_general(int mode) { return mode == RENDER_GENERAL_ONLY || mode == RENDER_GENERAL_SEG || mode == RENDER_GENERAL_TILES; }
 constexpr bool mode_seg(int mode) { return mode == RENDER_LEAN_HARM_SEG || mode == RENDER_GENERAL_SEG || mode == RENDER_LEAN_ALL_SEG; }
 constexpr bool mode_has_lean(int mode) { return mode != RENDER_DIRECT && !mode_general(mode); }
@@ -115,9 +119,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             if (next.launch && unit < prep_wgs && threadIdx.x < 64) {       // (ONE wavefront per workgroup works: spread over the CUs)
                 __builtin_amdgcn_s_setprio(3);                               // (latency-bound, beside wavefronts that fill every issue slot)
                 // (a tile-classified launch: the chunks of the next set's range only)
-                const uint32_t c = (MODE == RENDER_LEAN_TILES ? B.next_tiles.k0 * B.next_tiles.groups : 0u) + unit;
+                const uint32_t c = (mode_tiles(MODE) ? B.next_tiles.k0 * B.next_tiles.groups : 0u) + unit;
                 if (c < (nvoices + 63) / 64) {
-                    if constexpr (MODE == RENDER_LEAN_TILES) {
+                    if constexpr (mode_tiles(MODE)) {
                         // a tile-classified launch reads the records of the voices in its masks only: a chunk whose voices are all
                         // silent in that block is not resolved at all (a table of notes is mostly such chunks: 352 chunks, ~30
                         // sounding, cost the launch 11 of 64 us) -- the set is marked sparse on the host
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // Wave w takes every WAVES-th list entry; the offset carries over from chunk to chunk so that the waves'
     // shares of the whole group differ by at most one voice.
     uint32_t first = wave + sub * WAVES;                      // position in the current chunk's list this wave starts at
-    if constexpr (MODE == RENDER_LEAN_TILES) {
+    if constexpr (mode_tiles(MODE)) {
         // this tile's lean pairs: per chunk of the group a compacted list of 256-byte records (the count: the bits of the chunk's
         // mask), walked like the lean lists of an ordinary launch -- wave w takes every WAVES-th entry, the offset carries over
         static_assert(64 * FPL == TILE_FRAMES, "the lean kernel's tile is the tile of the classification");
@@ -448,6 +452,56 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                              "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
                              "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
                 const LaneTheta none{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0u, 0u, false};
+                if constexpr (MODE == RENDER_LEAN_TILES_ALL) {
+                    // a plain Sawtooth / Square / Triangle / Pulse (unit amplitude, t in turns: the amplitude lives in the gains): every
+                    // frame from its accumulated t on the piece that holds it -- the record's pieces, or a walk along the voice's
+                    // table -- the envelope's line of the frame, and nothing in front of an onset
+                    const uint32_t wkind = *reinterpret_cast<const uint32_t SH_CONST_AS*>(&q->pad_);
+                    if (wkind != LEAN_HARM) {
+                        const double eb0 = q->eb0, eb1 = q->eb1, ci = (double)(pc >> 16);
+                        double th[FPL], on = 0.0;
+                        if ((pc & 0xFFFFu) == 0u) {
+                            const double dn0 = q->tb[0];
+                            const uint64_t wbits = *reinterpret_cast<const uint64_t SH_CONST_AS*>(&q->tb[1]);
+                            const uint32_t seg_first = (uint32_t)wbits, seg_end = (uint32_t)(wbits >> 32);
+                            const uint32_t kidx = seg_first + (lane & (TILE_WALK_PIECES - 1));
+                            const bool have_piece = lane < TILE_WALK_PIECES && kidx < seg_end;
+                            const sh_segment* sp = B.segs + (have_piece ? kidx : seg_first);
+                            const uint64_t pn0 = sp->n0;
+                            const double pt0 = sp->t0, pdt = sp->dt;
+                            const double prel = (double)(long long)pn0 - dn0;
+                            const uint32_t npc = (uint32_t)__popcll(__ballot(have_piece && prel < (double)TILE_FRAMES));
+                            on = -dn0;                                    // (<= 0: the voice started before the tile)
+#pragma unroll
+                            for (int j = 0; j < FPL; ++j) th[j] = 0.0;
+                            for (uint32_t k = 0; k < npc; ++k) {
+                                const double rk = readlane_f64(prel, k), tk = readlane_f64(pt0, k), dk = readlane_f64(pdt, k);
+#pragma unroll
+                                for (int j = 0; j < FPL; ++j) {
+                                    const double x = lane_d + (double)(j * 64);
+                                    th[j] = x >= rk ? fma(x - rk, dk, tk) : th[j];
+                                }
+                            }
+                        } else {
+                            const TileTheta theta{lane_d, t0, dt, q->tb[0], q->tb[1], q->db[0], q->db[1], lane, q->split[0], q->split[1]};
+#pragma unroll
+                            for (int j = 0; j < FPL; ++j) th[j] = theta(j);
+                        }
+#pragma unroll
+                        for (int j = 0; j < FPL; ++j) {
+                            const double x = lane_d + (double)(j * 64);
+                            double w = wkind == LEAN_SAW ? shm::saw_value(th[j], 2.0, 0.0)
+                                     : wkind == LEAN_SQUARE ? shm::square_value(th[j], 1.0, 0.0)
+                                     : wkind == LEAN_TRIANGLE ? shm::triangle_value(th[j], 4.0, 0.0)
+                                     : shm::pulse_value(th[j], poly[0], 1.0, 0.0);
+                            const double ej = x < ci ? fma(x, ea1, ea0) : fma(x, eb1, eb0);
+                            w = x >= on ? w * ej : 0.0;
+                            accl[j] = fma(GL, w, accl[j]);
+                            accr[j] = fma(GR, w, accr[j]);
+                        }
+                        continue;
+                    }
+                }
                 if (pc == 1u) {
                     // one piece, one line (seven pairs of eight): the lean arithmetic of an ordinary launch with the line folded into the gains
                     double s0, c0s, s1, c1s;
@@ -919,7 +973,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // sounding: 60 .. 85 us per chunk where the arithmetic is 2 us.  The lean tiles kernel has one shape (four waves, 512-frame
     // tiles); a short launch is a few tiles of it, with more voice groups (but not hundreds: their partial buses are folded
     // frame by frame).
-    const bool tile_candidate = K.variant == 0 && mode == RENDER_LEAN_HARM && b->nvoices >= 128 && b->all_lean && !K.no_tiles && !b->needs_rows &&
+    const bool tile_candidate = K.variant == 0 && b->tile_all && b->nvoices >= 128 && b->all_lean && !K.no_tiles && !b->needs_rows &&
                                 (b->has_onsets || b->own_envelopes || K.tiles_for_all == 1) && !b->no_general_voice(start, nframes);
     if (tile_candidate) var = 484;
     const int W = var / 100, F = (var / 10) % 10;
@@ -1004,8 +1058,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // every (voice, 512-frame tile) pair lies on one envelope line and one piece of the phase table.  Those pairs take the lean
     // loop, the others the general code for that tile only (see TileRec).
     bool tiled = false;
-    if (split && mode == RENDER_LEAN_HARM && var == 484 && b->all_lean && !K.no_tiles && !b->needs_rows &&
-        !b->no_general_voice(start, nframes) && (b->has_onsets || b->own_envelopes || K.tiles_for_all == 1))
+    if (split && tile_candidate && var == 484)
         tiled = (uint64_t)sh::div_up(nframes, TILE_FRAMES) * set_slots(b->nvoices) * sizeof(TileRec) <= ((uint64_t)1 << 30);
     uint32_t seg_first[SEG_MAX + 1];
     uint32_t nseg = 0;
@@ -1105,9 +1158,15 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         // general kernel)
         LaunchSet no_next = next;
         no_next.launch = nullptr;
-        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups), dim3(256), 0, st, P,
-                           trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
+        if (b->tile_waveforms) {
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES_ALL>), dim3(tiles, groups), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
+        } else {
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
+        }
         SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
         {   // the general pairs: GEN_SPLIT workgroups per 256-frame tile, each all voice groups' pairs of it
             const uint32_t gen_wgs = sh::div_up(nframes, 256) * GEN_SPLIT;

@@ -234,3 +234,67 @@ def test_walk_pairs_steps_and_chunk_ranges(gpu):
     whole = bank.render(n - 77)
     assert rms(whole, want[:n - 77]) <= RMS_TOL
     assert np.max(np.abs(whole - want[:n - 77])) < 5e-6
+
+
+def _notes_of_every_kind(m, n, seed):
+    """n notes of the plain kinds -- Harmonics, Sine, Sawtooth, Square, Triangle, Pulse -- with onsets over two seconds in the order
+    they start, two thirds of them under ADSRs of their own."""
+    rng = np.random.default_rng(seed)
+    onsets = np.sort(rng.integers(0, 2 * SR, n))
+    onsets[:2] = (0, 300)
+    gains = [(float(np.float32(g)), float(np.float32(1.0 - g))) for g in rng.uniform(0.0, 1.0, n)]
+    voices = []
+    for i in range(n):
+        f = float(np.exp(rng.uniform(np.log(40.0), np.log(6000.0))))
+        amp = float(rng.uniform(0.1, 1.0)) / np.sqrt(n)
+        ph = float(rng.uniform(0.0, 1.0))
+        k = int(rng.integers(0, 6))
+        if k == 0:
+            nh = int(rng.integers(2, 17))
+            osc = m.Harmonics(f, [(q, 1.0 / q) for q in range(1, nh + 1)], amplitude=amp, phase=ph, samplerate=SR)
+        elif k == 1:
+            osc = m.Sine(f, amp, phase=ph, samplerate=SR)
+        elif k == 2:
+            osc = m.Sawtooth(f, amp, phase=ph, samplerate=SR)
+        elif k == 3:
+            osc = m.Square(f, amp, phase=ph, samplerate=SR)
+        elif k == 4:
+            osc = m.Triangle(f, amp, phase=ph, samplerate=SR)
+        else:
+            osc = m.Pulse(f, amp, phase=ph, pulsewidth=float(rng.uniform(0.05, 0.95)), samplerate=SR)
+        if rng.random() < 0.67:
+            osc = m.EnvelopeFilter(osc, float(rng.uniform(0.0005, 0.02)), float(rng.uniform(0.002, 0.08)), float(rng.uniform(0.0, 0.5)), 0.6,
+                                   float(rng.uniform(0.002, 0.3)))
+        voices.append(m.DelayFilter(osc, int(onsets[i]) / SR) if onsets[i] else osc)
+    return voices, gains
+
+
+def test_notes_of_every_plain_kind_tile_by_tile(gpu):
+    """A table of notes of all the plain kinds (the tiles kernel with the waveform branch): blocks of real-time length and of a
+    third of a second, as a stream and with a jump, against the C oracle; the launches are tile-classified."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    n_voices = 900
+    gv, gains = _notes_of_every_kind(G, n_voices, 33)
+    ov, _ = _notes_of_every_kind(O, n_voices, 33)
+    n = 6 * 16384
+    rows = np.zeros((n_voices, n))
+    for i, v in enumerate(ov):
+        d = int(SR * v._seconds) if isinstance(v, O.DelayFilter) else 0
+        if d < n:
+            rows[i, d:] = CO.render(v._source if isinstance(v, O.DelayFilter) else v, n - d)
+    want = CO.mix_bus(rows, gains)
+    bank = VoiceBank(gv, gains=gains)
+    for block in (16384, 2048):
+        nblocks = n // block if block == 16384 else 24
+        ring = [N.DeviceBuffer(block * 8) for _ in range(4)]
+        before = N.debug_counters()["tiled_launches"]
+        plan = list(range(nblocks)) + [1, 2]
+        for k in plan:
+            bank.render_device(block, k * block, bus_f32=ring[k & 3])
+            got = ring[k & 3].download(np.float32, block * 2).reshape(block, 2)
+            w = want[k * block:(k + 1) * block]
+            assert rms(got, w) <= RMS_TOL, (block, k)
+            assert np.max(np.abs(got - w)) < 2e-6, (block, k, float(np.max(np.abs(got - w))))
+        assert N.debug_counters()["tiled_launches"] - before == len(plan)

@@ -1,5 +1,5 @@
 """Random banks of NOTES -- every voice with an onset and an ADSR of its own (zero-length phases, envelopes that end, voices without
-an envelope), fundamentals up to 12 kHz, 1 .. 16 partials -- rendered as streams of launches of 256 .. 48 000 frames, which take the
+an envelope), fundamentals up to 12 kHz, Harmonics of 1 .. 16 partials or all the plain kinds -- rendered as streams of launches of 256 .. 48 000 frames, which take the
 tile-classified path (csrc/osc_render.hip RENDER_*_TILES: lean / corner / multi-piece / walk pairs, chunk ranges that move with the
 block), against the float64 buses of the same frames rendered by sub-banks of 100 voices (never tile-classified: below 128 voices)
 added up in float64.
@@ -23,6 +23,7 @@ for case in range(cases):
     nv = int(rng.choice([130, 200, 520, 1024, 2100]))
     span = float(rng.choice([0.2, 1.0, 3.0]))                       # the notes start within this many seconds
     order = rng.random() < 0.7                                       # in the order they start (chunk ranges) or shuffled
+    mixed_kinds = rng.random() < 0.5                                 # Harmonics only, or all the plain kinds (the waveform branch)
     onsets = rng.integers(0, int(span * SR), nv)
     if order:
         onsets = np.sort(onsets)
@@ -34,7 +35,20 @@ for case in range(cases):
         npart = int(rng.integers(1, 17))
         harm = [(k, 1.0 / k) for k in range(1, npart + 1)]
         phase = float(rng.uniform(-0.5, 1.0)) if rng.random() < 0.2 else float(rng.uniform(0.0, 1.0))
-        osc = G.Harmonics(f, harm, amplitude=float(rng.uniform(0.1, 1.0)) / np.sqrt(nv), phase=phase, samplerate=SR)
+        amp = float(rng.uniform(0.1, 1.0)) / np.sqrt(nv)
+        kind = int(rng.integers(0, 6)) if mixed_kinds else 0
+        if kind == 0:
+            osc = G.Harmonics(f, harm, amplitude=amp, phase=phase, samplerate=SR)
+        elif kind == 1:
+            osc = G.Sine(f, amp, phase=phase, samplerate=SR)
+        elif kind == 2:
+            osc = G.Sawtooth(f, amp, phase=phase, samplerate=SR)
+        elif kind == 3:
+            osc = G.Square(f, amp, phase=phase, samplerate=SR)
+        elif kind == 4:
+            osc = G.Triangle(f, amp, phase=phase, samplerate=SR)
+        else:
+            osc = G.Pulse(f, amp, phase=phase, pulsewidth=float(rng.uniform(0.02, 0.98)), samplerate=SR)
         r = rng.random()
         if r < 0.15:
             pass                                                     # no envelope: the onset is a step
