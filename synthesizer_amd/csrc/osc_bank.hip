@@ -335,9 +335,10 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     for (uint32_t i = 0; i < nvoices; ++i) {
         const sh_voice& v = voices[i];
         const bool wave = v.kind == SH_SAWTOOTH || v.kind == SH_SQUARE || v.kind == SH_TRIANGLE || v.kind == SH_PULSE;
-        const bool ok = v.bias == 0.0 && !v.flip && v.fm_mode == SH_FM_NONE && ((v.kind == SH_HARMONICS && v.harm_dense == 2) || v.kind == SH_SINE || wave);
+        const bool fm_sine = v.kind == SH_SINE && v.fm_mode == SH_FM_SINE;            // a Sine carrier with a closed-form Sine LFO
+        const bool ok = v.bias == 0.0 && !v.flip && (fm_sine || (v.fm_mode == SH_FM_NONE && ((v.kind == SH_HARMONICS && v.harm_dense == 2) || v.kind == SH_SINE || wave)));
         if (!ok) b->tile_all = false;
-        if (wave) b->tile_waveforms = true;
+        if (wave || fm_sine) b->tile_waveforms = true;
     }
     {
         b->all_lean = b->lean_candidates == nvoices;
@@ -386,6 +387,11 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
         for (uint32_t i = 0; i < nvoices; ++i) {
             if (voices[i].kind == SH_HARMONICS && voices[i].harm_dense == 2)
                 for (int u = 0; u < 16; ++u) polys[(size_t)i * 16 + u] = coefs[voices[i].harm_offset + u];
+            else if (voices[i].kind == SH_SINE && voices[i].fm_mode == SH_FM_SINE) {       // (the closed-form FM's constants by voice)
+                const sh_voice& v = voices[i];
+                const double row[8] = {v.frequency, v.fm_phase0, v.frequency * v.fm_inc, v.lfo_a, v.lfo_d, v.lfo_K, v.lfo_C0, v.lfo_bias};
+                for (int u = 0; u < 8; ++u) polys[(size_t)i * 16 + u] = row[u];
+            }
             else if (voices[i].kind == SH_SINE) polys[(size_t)i * 16 + 15] = 1.0;
             else if (voices[i].kind == SH_PULSE) polys[(size_t)i * 16] = voices[i].pulsewidth;
         }

@@ -47,7 +47,7 @@ constexpr uint32_t TILE_FRAMES = 512;         // = the lean render kernel's tile
 constexpr uint32_t TILE_MAX_PIECES = 3;
 struct alignas(64) TileRec {
     double t0, dt;                // t(i) = fma(i - tile0, dt, t0): the accumulated phase at the tile's first frame, its piece's step
-    double rc, rs;                // cos / sin of 64 dt
+    double rc, rs;                // cos / sin of 64 dt (LEAN_FM: rc = the voice's own index of the tile's first frame; t0, dt: its TIME table)
     double ea0, ea1, eb0, eb1;    // envelope(i) = ea0 + (i - tile0) ea1 for i - tile0 < corner, eb0 + (i - tile0) eb1 from there on
     double GL, GR;                // amplitude * bus gain
     double tb[2], db[2];          // pieces 1, 2: frames i - tile0 >= split[k] lie on piece k + 1, t = fma(i - tile0 - split[k], db[k], tb[k])
@@ -1109,8 +1109,10 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
                  "v"(bgl), "v"(bgr), "v"(hint));
     // (what a lean pair can be: polynomial Harmonics, a plain Sine -- the series with one partial -- or a plain waveform; see sh_bank::tile_all)
     const bool v_wave = v_kind == SH_SAWTOOTH || v_kind == SH_SQUARE || v_kind == SH_TRIANGLE || v_kind == SH_PULSE;
-    const bool lean_capable = valid && ((v_kind == SH_HARMONICS && v_dense == 2) || v_kind == SH_SINE || v_wave) && v_fm == SH_FM_NONE && v_bias == 0.0 && !v_flip;
-    const uint32_t rec_kind = v_kind == SH_SAWTOOTH ? LEAN_SAW : v_kind == SH_SQUARE ? LEAN_SQUARE : v_kind == SH_TRIANGLE ? LEAN_TRIANGLE : v_kind == SH_PULSE ? LEAN_PULSE : LEAN_HARM;
+    const bool v_fm_sine = v_kind == SH_SINE && v_fm == SH_FM_SINE;
+    const bool lean_capable = valid && v_bias == 0.0 && !v_flip &&
+                              (v_fm_sine || (v_fm == SH_FM_NONE && ((v_kind == SH_HARMONICS && v_dense == 2) || v_kind == SH_SINE || v_wave)));
+    const uint32_t rec_kind = v_fm_sine ? LEAN_FM : v_kind == SH_SAWTOOTH ? LEAN_SAW : v_kind == SH_SQUARE ? LEAN_SQUARE : v_kind == SH_TRIANGLE ? LEAN_TRIANGLE : v_kind == SH_PULSE ? LEAN_PULSE : LEAN_HARM;
     const bool fm = v_fm != SH_FM_NONE;
     const uint32_t off = fm ? off_t : off_c;
     const uint32_t cnt = fm ? cnt_t : cnt_c;
@@ -1274,7 +1276,7 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             if (!corner) { rec_eb0 = rec_ea0; rec_eb1 = rec_ea1; }
             double2* __restrict__ q2 = reinterpret_cast<double2*>(q);      // eight 16-byte stores
             q2[0] = make_double2(rec_t0, win_pick<double>(w_dt, r, 0.0));
-            q2[1] = rot;
+            q2[1] = rec_kind == LEAN_FM ? make_double2(dn0, 0.0) : rot;      // (an FM pair: the voice's own index of the tile's first frame)
             q2[2] = make_double2(rec_ea0, rec_ea1);
             q2[3] = make_double2(rec_eb0, rec_eb1);
             q2[4] = make_double2(amp * bgl, amp * bgr);

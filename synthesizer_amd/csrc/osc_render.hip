@@ -487,6 +487,26 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
 #pragma unroll
                             for (int j = 0; j < FPL; ++j) th[j] = theta(j);
                         }
+                        if (wkind == LEAN_FM) {
+                            // a Sine carrier with a closed-form Sine LFO: th[] is the accumulated TIME; the carrier's angle from the
+                            // running sum of the LFO, L(n) = K (C0 - cos(a + (n - 1/2) d)) + bias n, at the voice's own index n
+                            const double fr = poly[0], phase0 = poly[1], f_inc = poly[2], lfo_a = poly[3], lfo_d = poly[4];
+                            const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], n_first = rc;
+                            const double a_rel = fma(n_first - 0.5, lfo_d, lfo_a);
+#pragma unroll
+                            for (int j = 0; j < FPL; ++j) {
+                                const double x = lane_d + (double)(j * 64);
+                                double ls, lc, sj, cj;
+                                shm::sincos_tab(fma(x, lfo_d, a_rel), trig, ls, lc);
+                                const double Ln = fma(lfo_K, lfo_C0 - lc, lfo_bias * (n_first + x));
+                                shm::sincos_tab(fr * th[j] + fma(f_inc, Ln, phase0), trig, sj, cj);
+                                const double ej = x < ci ? fma(x, ea1, ea0) : fma(x, eb1, eb0);
+                                const double w = x >= on ? sj * ej : 0.0;
+                                accl[j] = fma(GL, w, accl[j]);
+                                accr[j] = fma(GR, w, accr[j]);
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int j = 0; j < FPL; ++j) {
                             const double x = lane_d + (double)(j * 64);

@@ -237,8 +237,8 @@ def test_walk_pairs_steps_and_chunk_ranges(gpu):
 
 
 def _notes_of_every_kind(m, n, seed):
-    """n notes of the plain kinds -- Harmonics, Sine, Sawtooth, Square, Triangle, Pulse -- with onsets over two seconds in the order
-    they start, two thirds of them under ADSRs of their own."""
+    """n notes of the plain kinds -- Harmonics, Sine, Sawtooth, Square, Triangle, Pulse -- and Sine carriers with a Sine LFO, with
+    onsets over two seconds in the order they start, two thirds of them under ADSRs of their own."""
     rng = np.random.default_rng(seed)
     onsets = np.sort(rng.integers(0, 2 * SR, n))
     onsets[:2] = (0, 300)
@@ -248,8 +248,11 @@ def _notes_of_every_kind(m, n, seed):
         f = float(np.exp(rng.uniform(np.log(40.0), np.log(6000.0))))
         amp = float(rng.uniform(0.1, 1.0)) / np.sqrt(n)
         ph = float(rng.uniform(0.0, 1.0))
-        k = int(rng.integers(0, 6))
-        if k == 0:
+        k = int(rng.integers(0, 7))
+        if k == 6:                                                   # a Sine carrier with a Sine LFO (closed-form FM: restarts with the note)
+            lfo = m.Sine(float(rng.uniform(0.5, 9.0)), float(rng.uniform(0.0, 0.05)), phase=float(rng.uniform(0.0, 1.0)), samplerate=SR)
+            osc = m.Sine(f, amp, phase=ph, fm_lfo=lfo, samplerate=SR)
+        elif k == 0:
             nh = int(rng.integers(2, 17))
             osc = m.Harmonics(f, [(q, 1.0 / q) for q in range(1, nh + 1)], amplitude=amp, phase=ph, samplerate=SR)
         elif k == 1:

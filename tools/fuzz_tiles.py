@@ -36,8 +36,11 @@ for case in range(cases):
         harm = [(k, 1.0 / k) for k in range(1, npart + 1)]
         phase = float(rng.uniform(-0.5, 1.0)) if rng.random() < 0.2 else float(rng.uniform(0.0, 1.0))
         amp = float(rng.uniform(0.1, 1.0)) / np.sqrt(nv)
-        kind = int(rng.integers(0, 6)) if mixed_kinds else 0
-        if kind == 0:
+        kind = int(rng.integers(0, 7)) if mixed_kinds else 0
+        if kind == 6:
+            lfo = G.Sine(float(rng.uniform(0.3, 12.0)), float(rng.uniform(0.0, 0.08)), phase=float(rng.uniform(0.0, 1.0)), samplerate=SR)
+            osc = G.Sine(f, amp, phase=phase, fm_lfo=lfo, samplerate=SR)
+        elif kind == 0:
             osc = G.Harmonics(f, harm, amplitude=amp, phase=phase, samplerate=SR)
         elif kind == 1:
             osc = G.Sine(f, amp, phase=phase, samplerate=SR)
