@@ -331,15 +331,18 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
         }
     for (uint32_t i = 0; i < nvoices; ++i)
         if (voices[i].start_frame) b->has_onsets = true;
-    b->tile_all = true;
+    uint32_t tile_capable = 0;
     for (uint32_t i = 0; i < nvoices; ++i) {
         const sh_voice& v = voices[i];
         const bool wave = v.kind == SH_SAWTOOTH || v.kind == SH_SQUARE || v.kind == SH_TRIANGLE || v.kind == SH_PULSE;
         const bool fm_sine = v.kind == SH_SINE && v.fm_mode == SH_FM_SINE;            // a Sine carrier with a closed-form Sine LFO
         const bool ok = v.bias == 0.0 && !v.flip && (fm_sine || (v.fm_mode == SH_FM_NONE && ((v.kind == SH_HARMONICS && v.harm_dense == 2) || v.kind == SH_SINE || wave)));
-        if (!ok) b->tile_all = false;
+        if (ok) tile_capable += 1;
         if (wave || fm_sine) b->tile_waveforms = true;
     }
+    // (a table of notes with the odd voice that only the general code can do -- noise, a bias, a sparse series -- is still a table of
+    // notes: those voices are general pairs of every tile they sound in)
+    b->tile_all = (uint64_t)tile_capable * 10 >= (uint64_t)nvoices * 9;
     {
         b->all_lean = b->lean_candidates == nvoices;
         for (uint32_t i = 0; i < nvoices && b->all_lean; ++i) {

@@ -100,7 +100,7 @@ struct sh_bank {
     float2*     d_gains = nullptr;
     uint32_t    nsegs = 0, ncoefs = 0, npartials = 0;
     std::vector<sh_voice> h_voices;    // for validation of per-call arguments
-    // every voice can be a lean pair of a tile-classified launch: polynomial Harmonics or a plain Sine / Sawtooth / Square /
+    // (nearly: nine in ten) every voice can be a lean pair of a tile-classified launch: polynomial Harmonics or a plain Sine / Sawtooth / Square /
     // Triangle / Pulse, no FM, no bias, not mirrored; tile_waveforms: some of them are no Harmonics / Sine (the tiles kernel with the
     // waveform branch)
     bool        tile_all = false, tile_waveforms = false;

@@ -993,7 +993,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // sounding: 60 .. 85 us per chunk where the arithmetic is 2 us.  The lean tiles kernel has one shape (four waves, 512-frame
     // tiles); a short launch is a few tiles of it, with more voice groups (but not hundreds: their partial buses are folded
     // frame by frame).
-    const bool tile_candidate = K.variant == 0 && b->tile_all && b->nvoices >= 128 && b->all_lean && !K.no_tiles && !b->needs_rows &&
+    const bool tile_candidate = K.variant == 0 && b->tile_all && b->nvoices >= 128 && mode != RENDER_DIRECT && !K.no_tiles && !b->needs_rows && b->first_row_voice < 0 &&
                                 (b->has_onsets || b->own_envelopes || K.tiles_for_all == 1) && !b->no_general_voice(start, nframes);
     if (tile_candidate) var = 484;
     const int W = var / 100, F = (var / 10) % 10;

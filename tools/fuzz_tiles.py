@@ -23,6 +23,7 @@ for case in range(cases):
     nv = int(rng.choice([130, 200, 520, 1024, 2100]))
     span = float(rng.choice([0.2, 1.0, 3.0]))                       # the notes start within this many seconds
     order = rng.random() < 0.7                                       # in the order they start (chunk ranges) or shuffled
+    odd_voices = rng.random() < 0.4                                  # a few voices that are no lean pairs at all
     mixed_kinds = rng.random() < 0.5                                 # Harmonics only, or all the plain kinds (the waveform branch)
     onsets = rng.integers(0, int(span * SR), nv)
     if order:
@@ -52,6 +53,11 @@ for case in range(cases):
             osc = G.Triangle(f, amp, phase=phase, samplerate=SR)
         else:
             osc = G.Pulse(f, amp, phase=phase, pulsewidth=float(rng.uniform(0.02, 0.98)), samplerate=SR)
+        if odd_voices and rng.random() < 0.06:                       # what only the general code can do: general pairs of every tile
+            which = int(rng.integers(0, 3))
+            osc = (G.Harmonics(f, harm, amplitude=amp, phase=phase, bias=0.01, samplerate=SR) if which == 0
+                   else G.Harmonics(min(f, 500.0), [(1, 1.0), (5, 0.3), (40, 0.1)], amplitude=amp, phase=phase, samplerate=SR) if which == 1
+                   else G.WhiteNoise(float(rng.uniform(200.0, 8000.0)), amp, samplerate=SR, seed=int(rng.integers(1, 1 << 30))))
         r = rng.random()
         if r < 0.15:
             pass                                                     # no envelope: the onset is a step
