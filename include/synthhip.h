@@ -216,7 +216,8 @@ int sh_bank_destroy(sh_bank* b);
 uint32_t sh_bank_nvoices(const sh_bank* b);
 /* How the last sh_bank_render launch classified the voices: *nfast took the lean loop (polynomial Harmonics, no FM,
  * constant envelope over the launch, one phase-table piece), *ngeneral the general code; voices released before the
- * launch are in neither count.  Synchronises the stream. */
+ * launch are in neither count.  Synchronises the stream.  (A tile-classified launch -- a table of notes -- classifies per (voice, tile),
+ * not per voice: both counts are 0; sh_debug_counters tells which shape a launch took.) */
 int sh_bank_launch_stats(sh_bank* bank, uint32_t* nfast, uint32_t* ngeneral);
 
 /* ---- oscillators: replaces Oscillator.blocks() of Sine/Sawtooth/Square/Pulse/Harmonics

@@ -494,6 +494,11 @@ int sh_bank_launch_stats(sh_bank* b, uint32_t* nfast, uint32_t* ngeneral) {
     SH_REQUIRE_INIT();
     if (!b) return sh::set_error(SH_ERR_INVALID, "sh_bank_launch_stats: NULL bank");
     if (!b->last_groups) return sh::set_error(SH_ERR_INVALID, "sh_bank_launch_stats: no sh_bank_render call yet");
+    if (b->last_tiled) {                                     // classified per (voice, tile), not per voice: see sh_debug_counters
+        if (nfast) *nfast = 0;
+        if (ngeneral) *ngeneral = 0;
+        return SH_OK;
+    }
     const uint32_t nchunks = (b->nvoices + 63) / 64;
     std::vector<uint32_t> c(4 * (size_t)nchunks);
     hipStream_t st = sh::state().stream;

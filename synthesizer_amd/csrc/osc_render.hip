@@ -1114,6 +1114,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     const double pv_scale = take_over ? prev.scale : 0.0;
     const uint32_t* pv_gen = take_over ? (const uint32_t*)prev.gen_valid : nullptr;
     b->last_groups = groups;
+    b->last_tiled = tiled;
     const LaunchSet cur = launch_set(b, b->cur);
     // the records of the block two launches on go to a set that is neither this launch's, nor its predecessor's (perhaps
     // still executing), nor the one holding the block in between
