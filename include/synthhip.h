@@ -183,6 +183,7 @@ int  sh_debug_counters(sh_counters* out);
  *   SYNTHHIP_VARIANT=WFM          render kernel shape: waves per workgroup, frames per lane, min waves per SIMD (e.g. 484)
  *   SYNTHHIP_GROUPS=n             voice groups of a render launch
  *   SYNTHHIP_GEN_LF=4|8|16        frames per lane of the lean materialisation kernel;  SYNTHHIP_GEN_ROWS=parts: the row-major walk (k_generate_lean_rows), parts per segment
+ *   SYNTHHIP_GEN_SPLIT=1|2|4|8    workgroups that share a chunk's lean records in the materialisation kernel (default 2)
  *   SYNTHHIP_GEN_SUB=1..16        split of a segmented launch's first segment;  SYNTHHIP_SEG_MIN=frames of its dense first segment
  *   SYNTHHIP_RESAMPLE_PK=0|1      the packed 16-bit mono resample kernel off / on
  *   SYNTHHIP_COMM_PRIORITY=-1|0|1 priority of the communication stream of the multi-GPU path (high / as the render streams / low)

@@ -77,6 +77,7 @@ struct Knobs {
                                    //   before their own work (round-2 behaviour) instead of by workgroups of their own
     int  variant = 0;              // SYNTHHIP_VARIANT=WFM: waves, frames per lane, min waves per SIMD of the render kernel
     int  groups = 0;               // SYNTHHIP_GROUPS: voice groups of a render launch
+    int  gen_split = 0;            // SYNTHHIP_GEN_SPLIT=1|2|4|8: workgroups that share a chunk's lean records in the materialisation kernel (0: default)
     int  gen_lf = 0;               // SYNTHHIP_GEN_LF=4|8|16: frames per lane of the lean materialisation kernel
     int  gen_sub = 4;              // SYNTHHIP_GEN_SUB=1..16: split of a segmented launch's first segment
     long seg_min = 0;              // SYNTHHIP_SEG_MIN: frames of a segmented launch's dense first segment

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 template <int FPL>
 __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
                                                                uint32_t total, uint32_t seg_frames,
-                                                               float* __restrict__ out32_all, size_t stride, SegTab tab) {
+                                                               float* __restrict__ out32_all, size_t stride, SegTab tab, uint32_t rec_split) {
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
     __syncthreads();
@@ -282,13 +282,16 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
     float* __restrict__ out32 = out32_all + seg_first;
     uint32_t tile_last = tile0 + 64 * FPL - 1;
     if (tile_last > n - 1) tile_last = n - 1;
-    const uint32_t c = blockIdx.y;
-    const uint32_t nfast = as_const(cur.counts)[4 * c];
-    const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64;
+    // (rec_split workgroups share a chunk's records: a wave that walks all 64 of them over 1024 frames lives a third of the launch --
+    // 7552 such waves on 5120 wave slots are a full round and a half-empty one)
+    const uint32_t c = blockIdx.y / rec_split, part = blockIdx.y % rec_split;
+    const uint32_t nfast_all = as_const(cur.counts)[4 * c];
+    const uint32_t p_lo = nfast_all * part / rec_split, nfast = nfast_all * (part + 1) / rec_split;
+    const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64 + p_lo;
     const uint32_t i0 = tile0 + lane;
     const double di0 = (double)i0;
     float* __restrict__ col = out32 + i0;                      // + vi * stride per record (uniform), + 64 * j per frame
-    for (uint32_t p = 0; p < nfast; ++p, ++q) {
+    for (uint32_t p = p_lo; p < nfast; ++p, ++q) {
         const uint32_t remain = q->remain, vi = q->vi;
         const double amp = q->amplitude, g0u = q->g0u;
         const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
@@ -512,6 +515,12 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
             if (forced == 4 || forced == 8 || forced == 16) lf = forced;
         }
         const int LF = lf;
+        // workgroups per chunk of records: enough waves for several rounds of the chip's wave slots (SYNTHHIP_GEN_SPLIT overrides)
+        uint32_t rsplit = 2;
+        {
+            const int forced = sh::knobs().gen_split;
+            if (forced == 1 || forced == 2 || forced == 4 || forced == 8) rsplit = (uint32_t)forced;
+        }
 #define SH_GEN_LEAN(GRID_, ...) do { \
             if (LF == 16) hipLaunchKernelGGL(k_generate_lean_harm<16>, GRID_, dim3(256), 0, st, __VA_ARGS__); \
             else if (LF == 8) hipLaunchKernelGGL(k_generate_lean_harm<8>, GRID_, dim3(256), 0, st, __VA_ARGS__); \
@@ -549,7 +558,7 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
                 for (uint32_t k = 0; k < ltab.n; ++k) list_groups += sh::div_up(ltab.len[k], 4 * 64 * 4);
                 rc = launch_prepare_segments_var(st, false, P, base, b->nvoices, tab.n, start);
                 if (rc) return rc;
-                SH_GEN_LEAN(dim3(sh::div_up(tiles, 4), nchunks), trig_table(), base, b->nvoices, head, SEG, o, stride, tab);
+                SH_GEN_LEAN(dim3(sh::div_up(tiles, 4), nchunks * rsplit), trig_table(), base, b->nvoices, head, SEG, o, stride, tab, rsplit);
                 SH_CHECK_LAUNCH("k_generate_lean_harm");
                 constexpr uint32_t VSPLIT = 8;
                 if (ltab.n) {
@@ -583,8 +592,8 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
             hipLaunchKernelGGL(k_generate_lean_rows<16>, dim3(nseg * parts, (unsigned)set_slots(b->nvoices)), dim3(256), 0, st, trig_table(), base, b->nvoices,
                                nframes, nseg == 1 ? (nframes + 1023u) / 1024u * 1024u : SEG, parts, o, stride);
         } else
-        SH_GEN_LEAN(dim3(sh::div_up(nframes, 256 * LF), nchunks), trig_table(), base, b->nvoices, nframes,
-                    nseg == 1 ? (nframes + 1023u) / 1024u * 1024u : SEG, o, stride, none);
+        SH_GEN_LEAN(dim3(sh::div_up(nframes, 256 * LF), nchunks * rsplit), trig_table(), base, b->nvoices, nframes,
+                    nseg == 1 ? (nframes + 1023u) / 1024u * 1024u : SEG, o, stride, none, rsplit);
 #undef SH_GEN_LEAN
         SH_CHECK_LAUNCH("k_generate_lean_harm");
         for (uint32_t sg = 0; sg < nseg; ++sg) {

@@ -40,6 +40,7 @@ void load_knobs() {
     k.variant = (int)num("SYNTHHIP_VARIANT", 0);
     k.groups = (int)num("SYNTHHIP_GROUPS", 0);
     k.gen_lf = (int)num("SYNTHHIP_GEN_LF", 0);
+    k.gen_split = (int)num("SYNTHHIP_GEN_SPLIT", 0);
     k.gen_sub = (int)num("SYNTHHIP_GEN_SUB", 4);
     if (k.gen_sub < 1 || k.gen_sub > 16) k.gen_sub = 4;
     k.seg_min = num("SYNTHHIP_SEG_MIN", 0);
