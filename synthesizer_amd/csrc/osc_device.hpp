@@ -1265,11 +1265,7 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         any_general = any_general || is_gen;
         if (sounds) { any_sound = true; last_piece = wb + r; }
         const uint64_t ml = __ballot(is_lean || is_walk), mg = __ballot(is_gen);
-#ifdef SH_X_NOSTORE
-        if (is_lean && rec_t0 == 1.2345e-300) {
-#else
         if (is_lean || is_walk) {                                // the chunk's lean pairs, compacted in voice order
-#endif
             TileRec* __restrict__ q = T.recs + (size_t)t * slots + c * 64 + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
             // (a corner at the tile's end -- the tail sample of a release is its last frame -- is no corner of this tile)
             const uint32_t corner = (rec_corner > 0 && rec_corner < TILE_FRAMES && !(rec_ea0 == rec_eb0 && rec_ea1 == rec_eb1)) ? rec_corner : 0u;
