@@ -46,19 +46,22 @@ __global__ __launch_bounds__(64) void k_prepare_segments_var(BankPtrs B, LaunchS
 
 // The tile set of a launch that was not predicted (the first launches of a run, a jump): a kernel in front of the render; in a stream
 // of blocks the same wavefronts run inside the render kernel of the launch before last (prepare_tiles_wave, osc_device.hpp).
-__global__ __launch_bounds__(256) void k_prepare_tiles(BankPtrs B, TileSet T, uint32_t nvoices, uint64_t start, uint32_t nframes, uint32_t ntiles) {
+__global__ __launch_bounds__(256) void k_prepare_tiles(BankPtrs B, TileSet T, uint32_t nvoices, uint64_t start, uint32_t nframes, uint32_t ntiles,
+                                                       LaunchSet recs, uint32_t with_recs) {
     const uint32_t c = T.k0 * T.groups + blockIdx.x;             // (the chunks of the set's range)
-    if (c < (nvoices + 63) / 64) prepare_tiles_wave(B, T, nvoices, start, nframes, ntiles, c, blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (c < (nvoices + 63) / 64)
+        prepare_tiles_wave(B, T, nvoices, start, nframes, ntiles, c, blockIdx.y * 4 + (threadIdx.x >> 6), with_recs ? &recs : nullptr);
 }
 
 }  // namespace
 
 namespace shosc {
 
-int launch_prepare_tiles(hipStream_t st, const BankPtrs& P, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes) {
+int launch_prepare_tiles(hipStream_t st, const BankPtrs& P, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes, const LaunchSet* recs) {
     const uint32_t ntiles = sh::div_up(nframes, TILE_FRAMES);
     if (T.k1 == T.k0) return SH_OK;                            // no chunk sounds in the block
-    hipLaunchKernelGGL(k_prepare_tiles, dim3((T.k1 - T.k0) * T.groups, sh::div_up(ntiles, 4 * TILES_PER_WAVE)), dim3(256), 0, st, P, T, nvoices, start, nframes, ntiles);
+    hipLaunchKernelGGL(k_prepare_tiles, dim3((T.k1 - T.k0) * T.groups, sh::div_up(ntiles, 4 * TILES_PER_WAVE)), dim3(256), 0, st, P, T, nvoices, start, nframes, ntiles,
+                       recs ? *recs : LaunchSet(), recs ? 1u : 0u);
     SH_CHECK_LAUNCH("k_prepare_tiles");
     return SH_OK;
 }
@@ -150,7 +153,13 @@ int prepare_single(sh_bank* b, uint32_t first, uint32_t count, uint64_t start, u
 // that was predicted (sequential streaming), else run k_prepare.
 // `launch_stream`: the stream the consuming kernel goes to.  `in_run`: the previous render launch of this bank may still
 // be executing on the other stream -- its set (b->cur) and the set it is filling (b->last_target) must not be touched.
-int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t launch_stream, bool in_run, bool accept_sparse) {
+int prepare_chunks_now(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t st) {
+    hipLaunchKernelGGL(k_prepare_chunks, sh::grid1d(b->nvoices, 64), dim3(64), 0, st, ptrs(b), launch_set(b, b->cur), b->nvoices, start, nframes);
+    SH_CHECK_LAUNCH("k_prepare_chunks");
+    return SH_OK;
+}
+
+int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t launch_stream, bool in_run, bool accept_sparse, bool* deferred) {
     sh::State& S = sh::state();
     for (int k = 0; k < sh_bank::NSETS; ++k) {
         if (b->spec[k].valid && b->spec[k].start == start && b->spec[k].nframes == nframes && (accept_sparse || !b->spec[k].sparse)) {
@@ -175,6 +184,13 @@ int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t la
             if (!(in_run && (c == b->cur || c == b->last_target))) k = c;
     }
     b->spec[k].valid = false;
+    if (deferred) {
+        *deferred = true;
+        b->cur = k;
+        b->d_launch = b->d_launch_buf[k];
+        b->d_launch_fm = b->d_launch_fm_buf[k];
+        return SH_OK;
+    }
     hipLaunchKernelGGL(k_prepare_chunks, sh::grid1d(b->nvoices, 64), dim3(64), 0, S.stream, ptrs(b), launch_set(b, k),
                        b->nvoices, start, nframes);
     SH_CHECK_LAUNCH("k_prepare_chunks");

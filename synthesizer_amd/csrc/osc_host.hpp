@@ -115,12 +115,15 @@ std::vector<sh_bank*>& live_banks();
 const shm::sc_pair* trig_table();
 // osc_bank.hip
 int prepare_single(sh_bank* b, uint32_t first, uint32_t count, uint64_t start, uint32_t nframes);     // k_prepare: one voice (sh_osc_render)
-int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t launch_stream, bool in_run, bool accept_sparse = false);
+// `deferred` (tile-classified launches): when no resolved set is found, one is chosen but NOT resolved -- *deferred = true -- because
+// the classification of such a launch resolves the records it needs itself (launch_prepare_tiles with the set)
+int acquire_records(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t launch_stream, bool in_run, bool accept_sparse = false, bool* deferred = nullptr);
+int prepare_chunks_now(sh_bank* b, uint64_t start, uint32_t nframes, hipStream_t st);     // the set b->cur, on stream st
 uint32_t plan_segments(const sh_bank* b, uint64_t start, uint32_t nframes, uint64_t T, uint64_t max_len, bool corners, uint32_t* seg_first);
 int bank_check_plain(const sh_bank* b, const char* who);
 // `nseg` record sets for `nvoices` voices carved out of one pool-backed block (grown when it is too small; *cap = sets it holds)
 int grow_segment_sets(sh::Pooled& block, LaunchSet& g, uint32_t& cap, uint32_t nseg, uint32_t nvoices);
-int launch_prepare_tiles(hipStream_t st, const BankPtrs& P, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes);
+int launch_prepare_tiles(hipStream_t st, const BankPtrs& P, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes, const LaunchSet* recs = nullptr);
 int grow_tile_set(sh::Pooled& block, TileSet& T, uint32_t& carved_tiles, uint32_t ntiles, uint32_t nvoices, uint32_t groups, hipStream_t st);
 int launch_prepare_segments(hipStream_t st, const BankPtrs& P, const LaunchSet& base, uint32_t nvoices, uint32_t nseg, uint64_t start,
                             uint32_t nframes, uint32_t seg_frames);

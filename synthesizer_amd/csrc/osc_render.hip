@@ -1086,8 +1086,9 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         nseg = plan_segments(b, start, nframes, (uint64_t)(64 * F), ~0ull, true, seg_first);
         if (nseg < 2 || seg_first[nseg] != nframes) nseg = 0;        // nothing to cut, or more cuts than a launch carries
     }
+    bool records_deferred = false;          // (a tile-classified launch without a resolved record set: its classification resolves what it needs)
     if (nseg == 0) {
-        rc = acquire_records(b, start, nframes, st, cont, tiled);
+        rc = acquire_records(b, start, nframes, st, cont, tiled, tiled ? &records_deferred : nullptr);
         if (rc) return rc;
     }
     // partial buses: ring slot n % 4 (last read by the fold in launch n - 2, which is this stream's previous launch)
@@ -1154,7 +1155,11 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
             if (rc) return rc;
             k_range(start, T.k0, T.k1);
             P.tiles = T;
-            rc = launch_prepare_tiles(st, P, T, b->nvoices, start, nframes);
+            const LaunchSet own = launch_set(b, b->cur);
+            rc = launch_prepare_tiles(st, P, T, b->nvoices, start, nframes, records_deferred ? &own : nullptr);
+            if (rc) return rc;
+        } else if (records_deferred) {
+            rc = prepare_chunks_now(b, start, nframes, st);      // (a predicted tile set without its records: not a state the pipeline produces)
             if (rc) return rc;
         }
         sp.valid = false;
