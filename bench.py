@@ -340,8 +340,20 @@ def staggered_row(N, F):
 
     ms = median_loop(3)             # blocks 3 .. 20: a stream of blocks, timed like the headline's (a pass of eighteen between two syncs)
     ms_cold = median_loop(1)        # ... and the twenty blocks from the standing start
+    # ... and the same table in real-time chunks: 4096 frames (85 ms of audio) per render call, eight seconds of the piece per loop
+    cf = 4096
+    cring = [N.DeviceBuffer(cf * 8) for _ in range(4)]
+    cpos = [0]
+
+    def chunk():
+        k = cpos[0] % (8 * SR // cf)
+        bank.render_device(cf, 3 * SR + k * cf, bus_f32=cring[k & 3])
+        cpos[0] += 1
+    ms_chunk = steady(N, chunk, min_seconds=0.05, reps=8 * SR // cf)
     return {"players": slots, "voices_in_the_table": len(voices), "ms_per_step": ms, "value": slots * F / (ms / 1e3) / 1e6, "unit": "Msamples/s",
             "from_a_standing_start_ms_per_step": ms_cold,
+            "realtime_chunks_4096": {"ms_per_chunk": ms_chunk, "x_real_time": cf / SR / (ms_chunk / 1e3),
+                                     "note": "the same table rendered 4096 frames per call (tile-classified launches at every block length)"},
             "sounding_fraction": 0.76, "host_build_s": build_s,
             "blocks_per_loop": nblocks,
             "note": "1024 players x 22 rounds: every note a voice of its own with an onset (DelayFilter fused into the record), Harmonics x16 under "
