@@ -39,8 +39,15 @@ enum { RENDER_DIRECT = 0, RENDER_LEAN_HARM = 1, RENDER_LEAN_ALL = 2, RENDER_LEAN
        RENDER_LEAN_TILES = 9, RENDER_GENERAL_TILES = 10,
        // RENDER_LEAN_TILES_ALL: the lean tiles kernel of a bank that holds plain Sawtooth / Square / Triangle / Pulse voices too (the
        // waveform branch costs the Harmonics loop registers: an instantiation of its own, as with RENDER_LEAN_ALL)
-       RENDER_LEAN_TILES_ALL = 11 };
-constexpr bool mode_tiles(int mode) { return mode == RENDER_LEAN_TILES || mode == RENDER_LEAN_TILES_ALL; }
+       RENDER_LEAN_TILES_ALL = 11,
+       // RENDER_TILES_MERGED: a SHORT tile-classified launch (real-time chunks: a handful of tiles) as ONE kernel -- the lean tiles'
+       // workgroups, and in rows behind them the general pairs' workgroups and the ones that resolve the tile set of the block two
+       // launches on.  The chip has room for all of them at once, the launch is latency-bound, and a second kernel costs the host
+       // and the stream more than its work; the general code in the same kernel costs the lean loop registers, which a long
+       // launch cannot afford (RENDER_LEAN_TILES + RENDER_GENERAL_TILES) and a short one does not notice.
+       RENDER_TILES_MERGED = 12 };
+constexpr bool mode_merged(int mode) { return mode == RENDER_TILES_MERGED; }
+constexpr bool mode_tiles(int mode) { return mode == RENDER_LEAN_TILES || mode == RENDER_LEAN_TILES_ALL || mode == RENDER_TILES_MERGED; }
 constexpr bool mode_lean_harm(int mode) { return mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_HARM_SEG || mode_tiles(mode); }
 constexpr bool mode_lean_only(int mode) { return mode == RENDER_LEAN_HARM_ONLY || mode == RENDER_LEAN_ALL_ONLY || mode == RENDER_LEAN_HARM_SEG || mode == RENDER_LEAN_ALL_SEG || mode_tiles(mode); }
 constexpr bool mode_general(int mode) { return mode == RENDER_GENERAL_ONLY || mode == RENDER_GENERAL_SEG || mode == RENDER_GENERAL_TILES; }
@@ -113,9 +120,26 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // for a bank of 352 chunks, most of them silent).
     const uint32_t prep_rows = (!mode_general(MODE) && prep_wgs) ? (prep_wgs + gridDim.x - 1) / gridDim.x : 0u;
     const uint32_t ngroups = gridDim.y - prep_rows;              // the voice groups of the launch
+    bool is_gen_wg = false;                   // RENDER_TILES_MERGED: this workgroup renders general pairs (a row behind the voice groups')
+    uint32_t gen_unit = 0;
     if (!mode_general(MODE) && prep_wgs) {
         if (blockIdx.y >= ngroups) {
             const uint32_t unit = (blockIdx.y - ngroups) * gridDim.x + blockIdx.x;
+            if constexpr (mode_merged(MODE)) {
+                // the rows behind the voice groups': GEN_SPLIT general workgroups per tile, then the tile-set prepare workgroups
+                const uint32_t gen_total = gridDim.x * GEN_SPLIT;
+                if (unit >= prep_wgs) return;
+                if (unit >= gen_total) {
+                    const uint32_t runs = (B.next_ntiles + TILES_PER_WAVE - 1) / TILES_PER_WAVE, wgs_per_chunk = (runs + 3) / 4;
+                    const uint32_t u = unit - gen_total;
+                    const uint32_t c = B.next_tiles.k0 * B.next_tiles.groups + u / wgs_per_chunk, run = (u % wgs_per_chunk) * 4 + (threadIdx.x >> 6);
+                    if (B.next_tile_wgs && c < (nvoices + 63) / 64)
+                        prepare_tiles_wave(B, B.next_tiles, nvoices, next_start, nframes, B.next_ntiles, c, run, next.launch ? &next : nullptr);
+                    return;
+                }
+                is_gen_wg = true;
+                gen_unit = unit;
+            } else
             if (next.launch && unit < prep_wgs && threadIdx.x < 64) {       // (ONE wavefront per workgroup works: spread over the CUs)
                 __builtin_amdgcn_s_setprio(3);                               // (latency-bound, beside wavefronts that fill every issue slot)
                 // (a tile-classified launch: the chunks of the next set's range only)
@@ -137,7 +161,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                     prepare_chunk(B, next, c, nvoices, next_start, nframes);
                 }
             }
-            return;
+            if (!mode_merged(MODE)) return;
         }
     }
     // RENDER_GENERAL_TILES: the first B.next_tile_wgs workgroups of every row of the grid resolve the TILE SET of the block two
@@ -166,7 +190,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // gen_part of GEN_SPLIT of them -- into plane gen_part of the general parts.
     uint32_t gen_part = 0;
     uint32_t bx_ = blockIdx.x;
-    if constexpr (MODE == RENDER_GENERAL_TILES) {
+    if constexpr (MODE == RENDER_GENERAL_TILES || mode_merged(MODE))
+    if (MODE == RENDER_GENERAL_TILES || is_gen_wg) {
+        if (mode_merged(MODE)) bx_ = gen_unit;
         gen_part = bx_ % GEN_SPLIT;
         bx_ /= GEN_SPLIT;
         if (bx_ * (64 * FPL) >= nframes) return;
@@ -246,7 +272,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // 18.8 us; but 16 384 frames -- 32 tiles -- 30.8 -> 36.3 us and the headline 37.5 -> 38.0 us: every workgroup then starts
     // with a round trip of loads, and a load instruction moves 64 lanes' worth instead of 256).
     const bool fold_shared = ngroups >= 32 && gridDim.x <= 8;          // (many groups, few tiles)
-    if (!mode_general(MODE) && prev_parts && (fold_shared || blockIdx.y == 0)) {
+    if (!mode_general(MODE) && prev_parts && !is_gen_wg && (fold_shared || blockIdx.y == 0)) {
         const bool shared = fold_shared;
         const uint32_t slice = shared ? (64 * FPL + ngroups - 1) / ngroups : (uint32_t)(64 * FPL), f_lo = shared ? blockIdx.y * slice : 0u;
         const uint32_t f_hi = f_lo + slice < (uint32_t)(64 * FPL) ? f_lo + slice : (uint32_t)(64 * FPL);
@@ -361,7 +387,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         }
     };
     if constexpr (!mode_has_lean(MODE)) build_frames(lane);        // (the lean loops work from the lane's first frame alone)
-    if constexpr (MODE == RENDER_GENERAL_TILES) {
+    if constexpr (mode_merged(MODE)) { if (is_gen_wg) build_frames(lane); }
+    if constexpr (MODE == RENDER_GENERAL_TILES || mode_merged(MODE))
+    if (MODE == RENDER_GENERAL_TILES || is_gen_wg) {
         // the (voice, tile) pairs of this tile that sound but are not lean, all voice groups': the masks of the classification tile
         // are one contiguous row -- a lane fetches one mask per pass, the non-zero ones are handed round by ballot and readlane --
         // and the pairs are dealt to the workgroups of the tile and their waves by their ordinal; each goes through the launch
@@ -407,6 +435,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // shares of the whole group differ by at most one voice.
     uint32_t first = wave + sub * WAVES;                      // position in the current chunk's list this wave starts at
     if constexpr (mode_tiles(MODE)) {
+        if (!is_gen_wg) {
         // this tile's lean pairs: per chunk of the group a compacted list of 256-byte records (the count: the bits of the chunk's
         // mask), walked like the lean lists of an ordinary launch -- wave w takes every WAVES-th entry, the offset carries over
         static_assert(64 * FPL == TILE_FRAMES, "the lean kernel's tile is the tile of the classification");
@@ -452,7 +481,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                              "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
                              "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
                 const LaneTheta none{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0u, 0u, false};
-                if constexpr (MODE == RENDER_LEAN_TILES_ALL) {
+                if constexpr (MODE == RENDER_LEAN_TILES_ALL || mode_merged(MODE)) {
                     // a plain Sawtooth / Square / Triangle / Pulse (unit amplitude, t in turns: the amplitude lives in the gains): every
                     // frame from its accumulated t on the piece that holds it -- the record's pieces, or a walk along the voice's
                     // table -- the envelope's line of the frame, and nothing in front of an onset
@@ -599,6 +628,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             firstp = p - npairs;
             }
         }
+        }   // (!is_gen_wg)
     } else
     if constexpr (!mode_general(MODE)) {
     for (uint32_t c = c0; c < c1; ++c) {
@@ -783,7 +813,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             if (MODE == RENDER_GENERAL_SEG && to_scratch) {
                 B.gen_scratch[(size_t)(grp * nsub + sub) * nfr + raw] = make_double2(l, rr);
             } else if (parts) {
-                const uint32_t slot = MODE == RENDER_GENERAL_TILES ? B.tiles.groups + gen_part : (mode_general(MODE) ? ngroups + grp : grp);
+                const uint32_t slot = (MODE == RENDER_GENERAL_TILES || is_gen_wg) ? B.tiles.groups + gen_part : (mode_general(MODE) ? ngroups + grp : grp);
                 parts[(size_t)slot * nframes + at] = make_double2(l, rr);
             } else {
                 if (bus32) bus32[at] = make_float2((float)l, (float)rr);
@@ -1184,6 +1214,13 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         // general kernel)
         LaunchSet no_next = next;
         no_next.launch = nullptr;
+        const bool merged = tiles <= 8 && !K.no_merged;                   // a short launch: ONE kernel (RENDER_TILES_MERGED)
+        if (merged) {
+            const uint32_t behind = tiles * GEN_SPLIT + P.next_tile_wgs;   // general workgroups, then the tile-set prepare workgroups
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_TILES_MERGED>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, behind);
+        } else
         if (b->tile_waveforms) {
             hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES_ALL>), dim3(tiles, groups), dim3(256), 0, st, P,
                                trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
@@ -1194,7 +1231,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
                                o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
         }
         SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
-        {   // the general pairs: GEN_SPLIT workgroups per 256-frame tile, each all voice groups' pairs of it
+        if (!merged) {   // the general pairs: GEN_SPLIT workgroups per 256-frame tile, each all voice groups' pairs of it
             const uint32_t gen_wgs = sh::div_up(nframes, 256) * GEN_SPLIT;
             // (on a stream of its own beside the lean kernel it was slower, 95 against 75 us per block: five streams share four
             // hardware queues, and a kernel that waits for an event holds up whatever shares its queue)
