@@ -1214,7 +1214,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         // general kernel)
         LaunchSet no_next = next;
         no_next.launch = nullptr;
-        const bool merged = tiles <= 8 && !K.no_merged;                   // a short launch: ONE kernel (RENDER_TILES_MERGED)
+        const bool merged = tiles <= 16 && !K.no_merged;                  // a short launch: ONE kernel (RENDER_TILES_MERGED)
         if (merged) {
             const uint32_t behind = tiles * GEN_SPLIT + P.next_tile_wgs;   // general workgroups, then the tile-set prepare workgroups
             hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_TILES_MERGED>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st, P,
