@@ -271,7 +271,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // of ALL the groups share the tile's frames, a slice each (A/B in one call: 1024 frames 15.7 -> 13.7 us, 4096 frames 20.0 ->
     // 18.8 us; but 16 384 frames -- 32 tiles -- 30.8 -> 36.3 us and the headline 37.5 -> 38.0 us: every workgroup then starts
     // with a round trip of loads, and a load instruction moves 64 lanes' worth instead of 256).
-    const bool fold_shared = ngroups >= 32 && gridDim.x <= 8;          // (many groups, few tiles)
+    const bool fold_shared = ngroups >= 32 && gridDim.x <= 12;         // (many groups, few tiles)
     if (!mode_general(MODE) && prev_parts && !is_gen_wg && (fold_shared || blockIdx.y == 0)) {
         const bool shared = fold_shared;
         const uint32_t slice = shared ? (64 * FPL + ngroups - 1) / ngroups : (uint32_t)(64 * FPL), f_lo = shared ? blockIdx.y * slice : 0u;
