@@ -31,3 +31,24 @@ for name, (voices, gains) in (("additive", additive_voices(G, 1024, SR, seed=0, 
             bad += 1
             print(name, "block", s, "differs: max", float(np.abs(got - ref).max()))
     print(name, "blocks checked", len(keep), "mismatches", bad)
+
+# a table of notes (tile-classified launches): a stream of one-second blocks and one of real-time chunks (sets resolved two launches
+# ahead, chunk ranges that move, the merged kernel) against random-access renders of sampled blocks (sets resolved in front)
+from synthesizer_amd.workloads import staggered_notes
+voices, gains = staggered_notes(G, 1024, SR, seed=0, period=1.0, notes=12)
+bank = VoiceBank(voices, gains=gains)
+for blk, n in ((48000, 11), (4096, 11 * 48000 // 4096)):
+    keep = sorted(set(rng.integers(0, n, 16).tolist() + [0, 1, 2, n - 1]))
+    bufs = {s: N.DeviceBuffer(blk * 8) for s in keep}
+    scratch = N.DeviceBuffer(blk * 8)
+    for s in range(n):
+        bank.render_device(blk, s * blk, bus_f32=bufs.get(s, scratch))
+    N.sync()
+    bad = 0
+    for s in keep:
+        got = bufs[s].download(np.float32, blk * 2)
+        ref = bank.render(blk, start=s * blk).reshape(-1)
+        if not np.array_equal(got, ref):
+            bad += 1
+            print("notes", blk, "block", s, "differs: max", float(np.abs(got - ref).max()))
+    print("notes, blocks of", blk, "checked", len(keep), "mismatches", bad, "tile-classified launches so far", N.debug_counters()["tiled_launches"])
