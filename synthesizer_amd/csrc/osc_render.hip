@@ -990,6 +990,223 @@ void free_render_buffers() {
 }
 }  // namespace sh
 
+// What the launches of one bank render have in common (bank_render works it out; the three shapes of a launch -- tile-classified,
+// segmented, plain -- enqueue their kernels from it).
+struct RenderLaunch {
+    sh_bank* b;
+    hipStream_t st;
+    const sh::Knobs& K;
+    uint64_t start, next_start;
+    uint32_t nframes, tiles, groups, vpg, nchunks, prep_wgs;
+    int mode, var;
+    bool split, with_general, use_aux;
+    LaunchSet cur, next;
+    float2* o32; double2* o64; uint32_t* o16;
+    double2* parts;
+    const double2* pv_parts; float2* pv32; double2* pv64; uint32_t* pv16;
+    double pcm_scale, pv_scale;
+    uint32_t* gen_valid; const uint32_t* pv_gen;
+};
+#define SH_RL_UNPACK(L)                                                                                                             \
+    sh_bank* b = (L).b; hipStream_t st = (L).st; const sh::Knobs& K = (L).K; const uint64_t start = (L).start, next_start = (L).next_start; \
+    const uint32_t nframes = (L).nframes, tiles = (L).tiles, groups = (L).groups, vpg = (L).vpg, nchunks = (L).nchunks, prep_wgs = (L).prep_wgs; \
+    const int mode = (L).mode, var = (L).var; const bool split = (L).split, with_general = (L).with_general, use_aux = (L).use_aux;    \
+    const LaunchSet cur = (L).cur, next = (L).next; float2* o32 = (L).o32; double2* o64 = (L).o64; uint32_t* o16 = (L).o16;          \
+    double2* parts = (L).parts; const double2* pv_parts = (L).pv_parts; float2* pv32 = (L).pv32; double2* pv64 = (L).pv64;            \
+    uint32_t* pv16 = (L).pv16; const double pcm_scale = (L).pcm_scale, pv_scale = (L).pv_scale; uint32_t* gen_valid = (L).gen_valid;  \
+    const uint32_t* pv_gen = (L).pv_gen; int rc = SH_OK;                                                                            \
+    (void)b; (void)st; (void)K; (void)start; (void)next_start; (void)nframes; (void)tiles; (void)groups; (void)vpg; (void)nchunks;    \
+    (void)prep_wgs; (void)mode; (void)var; (void)split; (void)with_general; (void)use_aux; (void)cur; (void)next; (void)o32; (void)o64; \
+    (void)o16; (void)parts; (void)pv_parts; (void)pv32; (void)pv64; (void)pv16; (void)pcm_scale; (void)pv_scale; (void)gen_valid;    \
+    (void)pv_gen; (void)rc
+
+// A TILE-CLASSIFIED launch: the lean tiles kernel and the general kernel behind it (which also resolves the tile set -- and the launch
+// records that will be needed -- of the block two launches on), or the merged kernel for a short launch.
+static int launch_tiled(const RenderLaunch& L, bool records_deferred) {
+    SH_RL_UNPACK(L);
+    const uint32_t ntiles = sh::div_up(nframes, TILE_FRAMES);
+    // the chunks that can sound in a block, as a range of mask slots k (chunk c = group + k groups): [k0, k1)
+    auto k_range = [&](uint64_t s0, uint32_t& k0, uint32_t& k1) {
+        uint32_t c_lo = nchunks, c_hi = 0;
+        const uint64_t s1 = s0 + (uint64_t)nframes;
+        for (uint32_t c = 0; c < nchunks; ++c)
+            if (!(s1 <= b->chunk_span[2 * c] || s0 >= b->chunk_span[2 * c + 1])) { c_lo = c < c_lo ? c : c_lo; c_hi = c + 1; }
+        k0 = c_hi ? c_lo / groups : 0u;
+        k1 = c_hi ? sh::div_up(c_hi, groups) : 0u;
+    };
+    const int ks = (int)(b->tile_count % sh_bank::NTILESETS);
+    TileSet& T = b->tile_set[ks];
+    sh_bank::TileSpec& sp = b->tile_spec[ks];
+    BankPtrs P = ptrs(b);
+    sh::counters().tiled_launches += 1;
+    if (sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups) sh::counters().tiled_predicted += 1;
+    if (!(sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups)) {
+        // not predicted (the first launches of a run, a jump): resolve it in front of the render
+        rc = grow_tile_set(b->tile_block[ks], T, b->tile_carved[ks], ntiles, b->nvoices, groups, st);
+        if (rc) return rc;
+        k_range(start, T.k0, T.k1);
+        P.tiles = T;
+        const LaunchSet own = launch_set(b, b->cur);
+        rc = launch_prepare_tiles(st, P, T, b->nvoices, start, nframes, records_deferred ? &own : nullptr);
+        if (rc) return rc;
+    } else if (records_deferred) {
+        rc = prepare_chunks_now(b, start, nframes, st);      // (a predicted tile set without its records: not a state the pipeline produces)
+        if (rc) return rc;
+    }
+    sp.valid = false;
+    // the tile set of the block expected two launches on: set (n + 2) % 4 -- read last by launch n - 2, the launch before on
+    // this stream -- resolved by workgroups of this launch's general kernel
+    if (next.launch) {
+        const int k2 = (int)((b->tile_count + 2) % sh_bank::NTILESETS);
+        TileSet& T2 = b->tile_set[k2];
+        rc = grow_tile_set(b->tile_block[k2], T2, b->tile_carved[k2], ntiles, b->nvoices, groups, st);
+        if (rc) return rc;
+        k_range(next_start, T2.k0, T2.k1);
+        P.next_tiles = T2;
+        P.next_ntiles = ntiles;
+        uint32_t in_range = (T2.k1 - T2.k0) * groups;                 // chunks of the range (the last slot's may not all exist)
+        if (T2.k1 * groups > nchunks) in_range -= T2.k1 * groups - nchunks;
+        P.next_tile_wgs = in_range * sh::div_up(sh::div_up(ntiles, TILES_PER_WAVE), 4);
+        sh_bank::TileSpec& s2 = b->tile_spec[k2];
+        s2.valid = true; s2.start = next_start; s2.nframes = nframes; s2.groups = groups;
+    }
+    P.tiles = T;
+    // (both prepare steps of the block two launches on -- tile set, and launch records where a voice needs one -- ride in the
+    // general kernel)
+    LaunchSet no_next = next;
+    no_next.launch = nullptr;
+    const bool merged = tiles <= 16 && !K.no_merged;                  // a short launch: ONE kernel (RENDER_TILES_MERGED)
+    if (merged) {
+        const uint32_t behind = tiles * GEN_SPLIT + P.next_tile_wgs;   // general workgroups, then the tile-set prepare workgroups
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_TILES_MERGED>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st, P,
+                           trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, behind);
+    } else
+    if (b->tile_waveforms) {
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES_ALL>), dim3(tiles, groups), dim3(256), 0, st, P,
+                           trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
+    } else {
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups), dim3(256), 0, st, P,
+                           trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
+    }
+    SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
+    if (!merged) {   // the general pairs: GEN_SPLIT workgroups per 256-frame tile, each all voice groups' pairs of it
+        const uint32_t gen_wgs = sh::div_up(nframes, 256) * GEN_SPLIT;
+        // (on a stream of its own beside the lean kernel it was slower, 95 against 75 us per block: five streams share four
+        // hardware queues, and a kernel that waits for an event holds up whatever shares its queue)
+        hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs + P.next_tile_wgs), dim3(256), 0, st, P,
+                           trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
+                           (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
+                           gen_valid, (const uint32_t*)nullptr, 0u);
+        SH_CHECK_LAUNCH("k_bank_render(general, tiles)");
+    }
+    b->tile_count += 1;
+    return SH_OK;
+}
+
+// A transition launch cut into SEGMENTS (RENDER_*_SEG): one batched prepare, the lean kernel over all segments, the general kernel
+// (the first segment's groups split SUB ways) and the combine of its slices.
+static int launch_segmented(const RenderLaunch& L, uint32_t nseg, const uint32_t* seg_first) {
+    SH_RL_UNPACK(L);
+    sh::counters().segmented_launches += 1;
+    const int ks = use_aux ? 1 : 0;
+    LaunchSet& g = b->seg_set[ks];
+    rc = grow_segment_sets(b->seg_block[ks], g, b->seg_cap[ks], nseg, b->nvoices);
+    if (rc) return rc;
+    BankPtrs P = ptrs(b);
+    P.nseg = nseg;
+    for (uint32_t k = 0; k <= nseg; ++k) P.seg_first[k] = seg_first[k];
+    rc = launch_prepare_segments_var(st, true, P, g, b->nvoices, nseg, start);
+    if (rc) return rc;
+    uint32_t tiles_lean = 0, tiles_gen = 0;
+    for (uint32_t k = 0; k < nseg; ++k) {
+        tiles_lean += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 8);
+        tiles_gen += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 4);
+    }
+    if (mode == RENDER_LEAN_HARM)
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_HARM_SEG>), dim3(tiles_lean, groups + sh::div_up(prep_wgs, tiles_lean)), dim3(256), 0, st, P,
+                           trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
+    else
+        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_ALL_SEG>), dim3(tiles_lean, groups + sh::div_up(prep_wgs, tiles_lean)), dim3(256), 0, st, P,
+                           trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
+    SH_CHECK_LAUNCH("k_bank_render(lean, segments)");
+    SH_HIP(hipMemsetAsync(gen_valid, 1, (size_t)groups * sizeof(uint32_t), st));         // every group's general parts are written
+    // the first segment's groups are split SUB ways (BankPtrs::gen_sub): with sixteen waves per workgroup a wave walks two
+    // or three of the 128 voices of its group
+    const uint32_t SUB = (uint32_t)K.gen_sub;
+    const uint32_t n0 = seg_first[1];
+    rc = sh::grow_pooled(b->seg_scratch[ks], (size_t)groups * SUB * n0 * sizeof(double2));
+    if (rc) return rc;
+    P.gen_sub = SUB;
+    P.gen_scratch = (double2*)b->seg_scratch[ks].ptr;
+    LaunchSet none = g;
+    none.launch = nullptr;
+    hipLaunchKernelGGL((k_bank_render<16, 4, 1, RENDER_GENERAL_SEG>), dim3(tiles_gen + (SUB - 1) * sh::div_up(n0, 64 * 4), groups), dim3(1024), 0, st, P,
+                       trig_table(), b->nvoices, vpg, g, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
+                       (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
+                       gen_valid, (const uint32_t*)nullptr, 0u);
+    SH_CHECK_LAUNCH("k_bank_render(general, segments)");
+    hipLaunchKernelGGL(k_seg_combine, dim3(sh::div_up(n0, 256), groups), dim3(256), 0, st, (const double2*)b->seg_scratch[ks].ptr, SUB, n0,
+                       parts + (size_t)groups * nframes, nframes);
+    SH_CHECK_LAUNCH("k_seg_combine");
+    return SH_OK;
+}
+
+// A plain launch: the render kernel of the bank's shape (lean + general lists in one kernel, or the split pair).
+static int launch_plain(const RenderLaunch& L) {
+    SH_RL_UNPACK(L);
+#define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
+hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups + sh::div_up(prep_wgs, tiles)), dim3(W_ * 64), 0, st, ptrs(b),    \
+                   trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64, \
+                   o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs)
+#define SH_LAUNCH_RENDER(W_, F_, M_)                                                 \
+do {                                                                             \
+    if (split && mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM_ONLY); \
+    else if (split) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_ALL_ONLY);            \
+    else if (mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM);  \
+    else if (mode == RENDER_LEAN_ALL) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_ALL); \
+    else SH_LAUNCH_MODE(W_, F_, M_, RENDER_DIRECT);                              \
+} while (0)
+switch (var) {
+case 1621: SH_LAUNCH_RENDER(16, 2, 1); break;
+case 1611: SH_LAUNCH_RENDER(16, 1, 1); break;
+case 826: SH_LAUNCH_RENDER(8, 2, 6); break;
+case 821: SH_LAUNCH_RENDER(8, 2, 1); break;
+case 828: SH_LAUNCH_RENDER(8, 2, 8); break;
+case 841: SH_LAUNCH_RENDER(8, 4, 1); break;
+case 844: SH_LAUNCH_RENDER(8, 4, 4); break;
+case 421: SH_LAUNCH_RENDER(4, 2, 1); break;
+case 411: SH_LAUNCH_RENDER(4, 1, 1); break;
+case 441: SH_LAUNCH_RENDER(4, 4, 1); break;
+case 444: SH_LAUNCH_RENDER(4, 4, 4); break;
+case 484: SH_LAUNCH_RENDER(4, 8, 4); break;
+case 884: SH_LAUNCH_RENDER(8, 8, 4); break;
+case 211: SH_LAUNCH_RENDER(2, 1, 1); break;
+case 221: SH_LAUNCH_RENDER(2, 2, 1); break;
+default: return sh::set_error(SH_ERR_INVALID, "sh_bank_render: unknown SYNTHHIP_VARIANT %d", var);
+}
+#undef SH_LAUNCH_RENDER
+#undef SH_LAUNCH_MODE
+SH_CHECK_LAUNCH("k_bank_render");
+if (with_general) {
+    // the general lists of the same launch: four waves x four frames per lane whatever the lean kernel's shape (the parts
+    // are indexed by frame), same voice groups, behind the lean kernel on the same stream
+    LaunchSet none = cur;
+    none.launch = nullptr;
+    hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_ONLY>), dim3(sh::div_up(nframes, 256), groups), dim3(256), 0, st, ptrs(b),
+                       trig_table(), b->nvoices, vpg, cur, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
+                       (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
+                       gen_valid, (const uint32_t*)nullptr, 0u);
+    SH_CHECK_LAUNCH("k_bank_render(general lists)");
+}
+    return SH_OK;
+}
+
+
 // the render behind sh_bank_render (float32 / float64 bus) and sh_bank_render_pcm (int16 PCM straight from the fold)
 static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64, sh_buf* pcm_i16, double pcm_scale) {
     SH_REQUIRE_INIT_KEEP_PENDING();          // a pending fold of the previous render is taken over by this launch (below)
@@ -1162,176 +1379,10 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // the workgroups that resolve those records: one wavefront per chunk of 64 voices, in rows of the grid behind the voice groups'
     const uint32_t nchunks = sh::div_up(b->nvoices, 64);
     const uint32_t prep_wgs = (next.launch && !K.prepare_in_tile) ? nchunks : 0u;
-    if (tiled) {
-        const uint32_t ntiles = sh::div_up(nframes, TILE_FRAMES);
-        // the chunks that can sound in a block, as a range of mask slots k (chunk c = group + k groups): [k0, k1)
-        auto k_range = [&](uint64_t s0, uint32_t& k0, uint32_t& k1) {
-            uint32_t c_lo = nchunks, c_hi = 0;
-            const uint64_t s1 = s0 + (uint64_t)nframes;
-            for (uint32_t c = 0; c < nchunks; ++c)
-                if (!(s1 <= b->chunk_span[2 * c] || s0 >= b->chunk_span[2 * c + 1])) { c_lo = c < c_lo ? c : c_lo; c_hi = c + 1; }
-            k0 = c_hi ? c_lo / groups : 0u;
-            k1 = c_hi ? sh::div_up(c_hi, groups) : 0u;
-        };
-        const int ks = (int)(b->tile_count % sh_bank::NTILESETS);
-        TileSet& T = b->tile_set[ks];
-        sh_bank::TileSpec& sp = b->tile_spec[ks];
-        BankPtrs P = ptrs(b);
-        sh::counters().tiled_launches += 1;
-        if (sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups) sh::counters().tiled_predicted += 1;
-        if (!(sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups)) {
-            // not predicted (the first launches of a run, a jump): resolve it in front of the render
-            rc = grow_tile_set(b->tile_block[ks], T, b->tile_carved[ks], ntiles, b->nvoices, groups, st);
-            if (rc) return rc;
-            k_range(start, T.k0, T.k1);
-            P.tiles = T;
-            const LaunchSet own = launch_set(b, b->cur);
-            rc = launch_prepare_tiles(st, P, T, b->nvoices, start, nframes, records_deferred ? &own : nullptr);
-            if (rc) return rc;
-        } else if (records_deferred) {
-            rc = prepare_chunks_now(b, start, nframes, st);      // (a predicted tile set without its records: not a state the pipeline produces)
-            if (rc) return rc;
-        }
-        sp.valid = false;
-        // the tile set of the block expected two launches on: set (n + 2) % 4 -- read last by launch n - 2, the launch before on
-        // this stream -- resolved by workgroups of this launch's general kernel
-        if (next.launch) {
-            const int k2 = (int)((b->tile_count + 2) % sh_bank::NTILESETS);
-            TileSet& T2 = b->tile_set[k2];
-            rc = grow_tile_set(b->tile_block[k2], T2, b->tile_carved[k2], ntiles, b->nvoices, groups, st);
-            if (rc) return rc;
-            k_range(next_start, T2.k0, T2.k1);
-            P.next_tiles = T2;
-            P.next_ntiles = ntiles;
-            uint32_t in_range = (T2.k1 - T2.k0) * groups;                 // chunks of the range (the last slot's may not all exist)
-            if (T2.k1 * groups > nchunks) in_range -= T2.k1 * groups - nchunks;
-            P.next_tile_wgs = in_range * sh::div_up(sh::div_up(ntiles, TILES_PER_WAVE), 4);
-            sh_bank::TileSpec& s2 = b->tile_spec[k2];
-            s2.valid = true; s2.start = next_start; s2.nframes = nframes; s2.groups = groups;
-        }
-        P.tiles = T;
-        // (both prepare steps of the block two launches on -- tile set, and launch records where a voice needs one -- ride in the
-        // general kernel)
-        LaunchSet no_next = next;
-        no_next.launch = nullptr;
-        const bool merged = tiles <= 16 && !K.no_merged;                  // a short launch: ONE kernel (RENDER_TILES_MERGED)
-        if (merged) {
-            const uint32_t behind = tiles * GEN_SPLIT + P.next_tile_wgs;   // general workgroups, then the tile-set prepare workgroups
-            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_TILES_MERGED>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st, P,
-                               trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, behind);
-        } else
-        if (b->tile_waveforms) {
-            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES_ALL>), dim3(tiles, groups), dim3(256), 0, st, P,
-                               trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
-        } else {
-            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups), dim3(256), 0, st, P,
-                               trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
-        }
-        SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
-        if (!merged) {   // the general pairs: GEN_SPLIT workgroups per 256-frame tile, each all voice groups' pairs of it
-            const uint32_t gen_wgs = sh::div_up(nframes, 256) * GEN_SPLIT;
-            // (on a stream of its own beside the lean kernel it was slower, 95 against 75 us per block: five streams share four
-            // hardware queues, and a kernel that waits for an event holds up whatever shares its queue)
-            hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs + P.next_tile_wgs), dim3(256), 0, st, P,
-                               trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
-                               (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
-                               gen_valid, (const uint32_t*)nullptr, 0u);
-            SH_CHECK_LAUNCH("k_bank_render(general, tiles)");
-        }
-        b->tile_count += 1;
-    } else if (nseg) {
-        sh::counters().segmented_launches += 1;
-        const int ks = use_aux ? 1 : 0;
-        LaunchSet& g = b->seg_set[ks];
-        rc = grow_segment_sets(b->seg_block[ks], g, b->seg_cap[ks], nseg, b->nvoices);
-        if (rc) return rc;
-        BankPtrs P = ptrs(b);
-        P.nseg = nseg;
-        for (uint32_t k = 0; k <= nseg; ++k) P.seg_first[k] = seg_first[k];
-        rc = launch_prepare_segments_var(st, true, P, g, b->nvoices, nseg, start);
-        if (rc) return rc;
-        uint32_t tiles_lean = 0, tiles_gen = 0;
-        for (uint32_t k = 0; k < nseg; ++k) {
-            tiles_lean += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 8);
-            tiles_gen += sh::div_up(seg_first[k + 1] - seg_first[k], 64 * 4);
-        }
-        if (mode == RENDER_LEAN_HARM)
-            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_HARM_SEG>), dim3(tiles_lean, groups + sh::div_up(prep_wgs, tiles_lean)), dim3(256), 0, st, P,
-                               trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
-        else
-            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_ALL_SEG>), dim3(tiles_lean, groups + sh::div_up(prep_wgs, tiles_lean)), dim3(256), 0, st, P,
-                               trig_table(), b->nvoices, vpg, g, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs);
-        SH_CHECK_LAUNCH("k_bank_render(lean, segments)");
-        SH_HIP(hipMemsetAsync(gen_valid, 1, (size_t)groups * sizeof(uint32_t), st));         // every group's general parts are written
-        // the first segment's groups are split SUB ways (BankPtrs::gen_sub): with sixteen waves per workgroup a wave walks two
-        // or three of the 128 voices of its group
-        const uint32_t SUB = (uint32_t)K.gen_sub;
-        const uint32_t n0 = seg_first[1];
-        rc = sh::grow_pooled(b->seg_scratch[ks], (size_t)groups * SUB * n0 * sizeof(double2));
-        if (rc) return rc;
-        P.gen_sub = SUB;
-        P.gen_scratch = (double2*)b->seg_scratch[ks].ptr;
-        LaunchSet none = g;
-        none.launch = nullptr;
-        hipLaunchKernelGGL((k_bank_render<16, 4, 1, RENDER_GENERAL_SEG>), dim3(tiles_gen + (SUB - 1) * sh::div_up(n0, 64 * 4), groups), dim3(1024), 0, st, P,
-                           trig_table(), b->nvoices, vpg, g, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
-                           (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
-                           gen_valid, (const uint32_t*)nullptr, 0u);
-        SH_CHECK_LAUNCH("k_bank_render(general, segments)");
-        hipLaunchKernelGGL(k_seg_combine, dim3(sh::div_up(n0, 256), groups), dim3(256), 0, st, (const double2*)b->seg_scratch[ks].ptr, SUB, n0,
-                           parts + (size_t)groups * nframes, nframes);
-        SH_CHECK_LAUNCH("k_seg_combine");
-    } else {
-#define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
-    hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups + sh::div_up(prep_wgs, tiles)), dim3(W_ * 64), 0, st, ptrs(b),    \
-                       trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64, \
-                       o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs)
-#define SH_LAUNCH_RENDER(W_, F_, M_)                                                 \
-    do {                                                                             \
-        if (split && mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM_ONLY); \
-        else if (split) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_ALL_ONLY);            \
-        else if (mode == RENDER_LEAN_HARM) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_HARM);  \
-        else if (mode == RENDER_LEAN_ALL) SH_LAUNCH_MODE(W_, F_, M_, RENDER_LEAN_ALL); \
-        else SH_LAUNCH_MODE(W_, F_, M_, RENDER_DIRECT);                              \
-    } while (0)
-    switch (var) {
-    case 1621: SH_LAUNCH_RENDER(16, 2, 1); break;
-    case 1611: SH_LAUNCH_RENDER(16, 1, 1); break;
-    case 826: SH_LAUNCH_RENDER(8, 2, 6); break;
-    case 821: SH_LAUNCH_RENDER(8, 2, 1); break;
-    case 828: SH_LAUNCH_RENDER(8, 2, 8); break;
-    case 841: SH_LAUNCH_RENDER(8, 4, 1); break;
-    case 844: SH_LAUNCH_RENDER(8, 4, 4); break;
-    case 421: SH_LAUNCH_RENDER(4, 2, 1); break;
-    case 411: SH_LAUNCH_RENDER(4, 1, 1); break;
-    case 441: SH_LAUNCH_RENDER(4, 4, 1); break;
-    case 444: SH_LAUNCH_RENDER(4, 4, 4); break;
-    case 484: SH_LAUNCH_RENDER(4, 8, 4); break;
-    case 884: SH_LAUNCH_RENDER(8, 8, 4); break;
-    case 211: SH_LAUNCH_RENDER(2, 1, 1); break;
-    case 221: SH_LAUNCH_RENDER(2, 2, 1); break;
-    default: return sh::set_error(SH_ERR_INVALID, "sh_bank_render: unknown SYNTHHIP_VARIANT %d", var);
-    }
-#undef SH_LAUNCH_RENDER
-#undef SH_LAUNCH_MODE
-    SH_CHECK_LAUNCH("k_bank_render");
-    if (with_general) {
-        // the general lists of the same launch: four waves x four frames per lane whatever the lean kernel's shape (the parts
-        // are indexed by frame), same voice groups, behind the lean kernel on the same stream
-        LaunchSet none = cur;
-        none.launch = nullptr;
-        hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_ONLY>), dim3(sh::div_up(nframes, 256), groups), dim3(256), 0, st, ptrs(b),
-                           trig_table(), b->nvoices, vpg, cur, none, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
-                           (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
-                           gen_valid, (const uint32_t*)nullptr, 0u);
-        SH_CHECK_LAUNCH("k_bank_render(general lists)");
-    }
-    }
+    const RenderLaunch L{b, st, K, start, next_start, nframes, tiles, groups, vpg, nchunks, prep_wgs, mode, var, split, with_general, use_aux,
+                         cur, next, o32, o64, o16, parts, pv_parts, pv32, pv64, pv16, pcm_scale, pv_scale, gen_valid, pv_gen};
+    rc = tiled ? launch_tiled(L, records_deferred) : nseg ? launch_segmented(L, nseg, seg_first) : launch_plain(L);
+    if (rc) return rc;
     if (use_aux) S.aux_busy = true;                         // (join_aux records the event the main stream waits for)
     const uint8_t stream_bit = use_aux ? 2u : 1u;
     if (take_over) {                                        // folded by this launch -- which may be running for a while yet: the
