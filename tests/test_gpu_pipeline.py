@@ -168,17 +168,27 @@ for nv in (64, 640):
     for s in range(9, 13):
         bank.render_device(6000, s * 6000, bus_f32=ring[s & 3])
     out["nv%%d" %% nv] = np.stack([ring[s & 3].download(np.float32, 12000) for s in range(9, 13)])
+# a table of notes (tile-classified launches): real-time chunks -- the merged kernel -- and longer blocks
+from synthesizer_amd.workloads import staggered_notes
+v, g = staggered_notes(G, 256, 48000, seed=2, period=0.5, notes=4)
+bank = VoiceBank(v, gains=g)
+for blk in (3000, 20000):
+    ring = [N.DeviceBuffer(blk * 8) for _ in range(4)]
+    for s in range(9):
+        bank.render_device(blk, s * blk, bus_f32=ring[s & 3])
+    out["notes%%d" %% blk] = np.stack([ring[s & 3].download(np.float32, blk * 2) for s in range(5, 9)])
 np.savez(sys.argv[1], **out)
 '''
 
 
 def test_knobs_change_no_result(gpu, tmp_path):
-    """SYNTHHIP_PREPARE_IN_TILE / SYNTHHIP_NO_SMALL_PIPELINE / SYNTHHIP_NO_OVERLAP select other schedules of the same work:
-    the buses are bit-identical with the default's."""
+    """SYNTHHIP_PREPARE_IN_TILE / SYNTHHIP_NO_SMALL_PIPELINE / SYNTHHIP_NO_OVERLAP / SYNTHHIP_NO_SPECULATION / SYNTHHIP_NO_MERGED select
+    other schedules of the same work: the buses -- of small and large lock-step banks and of a table of notes -- are bit-identical
+    with the default's."""
     outs = {}
     for name, env in (("default", {}), ("in_tile", {"SYNTHHIP_PREPARE_IN_TILE": "1"}),
                       ("no_small", {"SYNTHHIP_NO_SMALL_PIPELINE": "1"}), ("no_overlap", {"SYNTHHIP_NO_OVERLAP": "1"}),
-                      ("no_spec", {"SYNTHHIP_NO_SPECULATION": "1"})):
+                      ("no_spec", {"SYNTHHIP_NO_SPECULATION": "1"}), ("no_merged", {"SYNTHHIP_NO_MERGED": "1"})):
         path = tmp_path / (name + ".npz")
         clean = {k: v for k, v in os.environ.items() if not k.startswith("SYNTHHIP_") or k in ("SYNTHHIP_LIB", "SYNTHHIP_DEVICE")}
         p = subprocess.run([sys.executable, "-c", _CHILD % str(ROOT), str(path)], env=dict(clean, **env),
@@ -186,5 +196,5 @@ def test_knobs_change_no_result(gpu, tmp_path):
         assert p.returncode == 0, p.stderr[-2000:]
         outs[name] = np.load(path)
     for name in outs:
-        for key in ("nv64", "nv640"):
+        for key in ("nv64", "nv640", "notes3000", "notes20000"):
             assert np.array_equal(outs[name][key], outs["default"][key]), (name, key)
