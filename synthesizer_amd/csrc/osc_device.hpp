@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1
 // piece end and tile, three tiles per wave: 32 us as a kernel of its own, and inside the render kernel its workgroups cost the
 // launch 28 us.)
 #ifndef SH_TPW
-#define SH_TPW 6
+#define SH_TPW 3
 #endif
 constexpr uint32_t TILES_PER_WAVE = SH_TPW;
 constexpr int TILE_WIN = 6;
