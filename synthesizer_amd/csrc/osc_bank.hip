@@ -68,10 +68,15 @@ int launch_prepare_tiles(hipStream_t st, const BankPtrs& P, const TileSet& T, ui
 
 // The tile set of a launch of `ntiles` tiles and `groups` voice groups carved out of one pool-backed block (records, then the two
 // mask arrays; the masks of chunks that do not exist -- the padding of a group's row to a multiple of eight -- are zeroed here).
-int grow_tile_set(sh::Pooled& block, TileSet& T, uint32_t& carved_tiles, uint32_t ntiles, uint32_t nvoices, uint32_t groups, hipStream_t st) {
-    const size_t slots = set_slots(nvoices);
+int grow_tile_set(sh::Pooled& block, TileSet& T, uint32_t& carved_tiles, uint32_t ntiles, uint32_t nvoices, uint32_t groups, uint32_t range_chunks, hipStream_t st) {
     const uint32_t mask_k = tile_mask_k(nvoices, groups);
-    if (block.ptr && T.recs == (TileRec*)block.ptr && T.groups == groups && T.mask_k == mask_k && carved_tiles == ntiles) return SH_OK;
+    if (block.ptr && T.recs == (TileRec*)block.ptr && T.groups == groups && T.mask_k == mask_k && carved_tiles == ntiles && T.rec_chunks >= range_chunks) return SH_OK;
+    // (a quarter of headroom: the range of a stream of blocks breathes by a chunk or two)
+    uint32_t rec_chunks = ((range_chunks + range_chunks / 4 + 8) + 7) & ~7u;
+    const uint32_t all_chunks = (nvoices + 63) / 64 + groups;           // (a range is whole mask slots: up to groups - 1 chunks past the table)
+    if (rec_chunks > all_chunks) rec_chunks = all_chunks;
+    if (rec_chunks < range_chunks) rec_chunks = range_chunks;
+    const size_t slots = (size_t)rec_chunks * 64;
     const size_t b_recs = sizeof(TileRec) * ntiles * slots, b_mask = ((sizeof(uint64_t) * ntiles * groups * mask_k) + 255) & ~(size_t)255;
     int rc = sh::grow_pooled(block, b_recs + 2 * b_mask);
     if (rc) return rc;
@@ -83,7 +88,8 @@ int grow_tile_set(sh::Pooled& block, TileSet& T, uint32_t& carved_tiles, uint32_
     T.groups = groups;
     T.mask_k = mask_k;
     T.k0 = 0;
-    T.k1 = mask_k;
+    T.k1 = 0;
+    T.rec_chunks = rec_chunks;
     if (((nvoices + 63) / 64) != groups * mask_k) SH_HIP(hipMemsetAsync(T.lean, 0, 2 * b_mask, st));     // (some slots have no chunk: they stay zero)
     return SH_OK;
 }

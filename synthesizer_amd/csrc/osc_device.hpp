@@ -96,7 +96,9 @@ struct TileTheta {
     }
 };
 struct TileSet {
-    TileRec*  recs;               // [tile][slot]: the lean pairs of chunk c of a tile compacted at slots 64 c .. (their count: the bits of the mask)
+    TileRec*  recs;               // [tile][slot]: the lean pairs of chunk c of a tile compacted at slots 64 (c - k0 groups) .. (their count: the bits
+                                  // of the mask); a tile's row holds rec_chunks chunks -- the set's RANGE of chunks, not the table (a table of
+                                  // 22 528 notes of which 30 chunks sound: 30 MB of records per set instead of 271)
     // masks: [tile][group][k], chunk c = group + k * groups (a voice group of a tile-classified launch = every groups-th chunk:
     // notes that sound together tend to be neighbours in the voice table, and a range of chunks would give one group all of
     // them); mask_k = masks per (tile, group), a multiple of 8: a workgroup fetches its masks in batches of eight scalar loads
@@ -107,6 +109,7 @@ struct TileSet {
     // the chunks in front and behind are silent throughout the block (a table of notes in the order they start: a few dozen of
     // several hundred chunks sound in any one block), nobody writes or reads their masks
     uint32_t  k0, k1;
+    uint32_t  rec_chunks;         // chunks per tile row of recs (>= (k1 - k0) groups)
 };
 __host__ __device__ __forceinline__ uint32_t tile_mask_k(uint32_t nvoices, uint32_t groups) {
     const uint32_t nchunks = (nvoices + 63) / 64;
@@ -1074,7 +1077,7 @@ __device__ __forceinline__ V win_pick(const V (&a)[TILE_WIN], uint32_t r, V beyo
 __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes,
                                                    uint32_t ntiles, uint32_t c, uint32_t run, const LaunchSet* recs = nullptr) {
     const uint32_t lane = threadIdx.x & 63, vi = c * 64 + lane;
-    const size_t slots = set_slots(nvoices);
+    const size_t slots = (size_t)T.rec_chunks * 64;
     const uint32_t t_begin = run * TILES_PER_WAVE;
     if (t_begin >= ntiles) return;
     uint32_t t_end = t_begin + TILES_PER_WAVE;
@@ -1266,7 +1269,7 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         if (sounds) { any_sound = true; last_piece = wb + r; }
         const uint64_t ml = __ballot(is_lean || is_walk), mg = __ballot(is_gen);
         if (is_lean || is_walk) {                                // the chunk's lean pairs, compacted in voice order
-            TileRec* __restrict__ q = T.recs + (size_t)t * slots + c * 64 + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
+            TileRec* __restrict__ q = T.recs + (size_t)t * slots + (c - T.k0 * T.groups) * 64 + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
             // (a corner at the tile's end -- the tail sample of a release is its last frame -- is no corner of this tile)
             const uint32_t corner = (rec_corner > 0 && rec_corner < TILE_FRAMES && !(rec_ea0 == rec_eb0 && rec_ea1 == rec_eb1)) ? rec_corner : 0u;
             if (!corner) { rec_eb0 = rec_ea0; rec_eb1 = rec_ea1; }

@@ -124,7 +124,8 @@ int bank_check_plain(const sh_bank* b, const char* who);
 // `nseg` record sets for `nvoices` voices carved out of one pool-backed block (grown when it is too small; *cap = sets it holds)
 int grow_segment_sets(sh::Pooled& block, LaunchSet& g, uint32_t& cap, uint32_t nseg, uint32_t nvoices);
 int launch_prepare_tiles(hipStream_t st, const BankPtrs& P, const TileSet& T, uint32_t nvoices, uint64_t start, uint32_t nframes, const LaunchSet* recs = nullptr);
-int grow_tile_set(sh::Pooled& block, TileSet& T, uint32_t& carved_tiles, uint32_t ntiles, uint32_t nvoices, uint32_t groups, hipStream_t st);
+// (`range_chunks`: the chunks a tile's row of records has to hold -- the set's range, see TileSet; the rows grow with headroom, never shrink)
+int grow_tile_set(sh::Pooled& block, TileSet& T, uint32_t& carved_tiles, uint32_t ntiles, uint32_t nvoices, uint32_t groups, uint32_t range_chunks, hipStream_t st);
 int launch_prepare_segments(hipStream_t st, const BankPtrs& P, const LaunchSet& base, uint32_t nvoices, uint32_t nseg, uint64_t start,
                             uint32_t nframes, uint32_t seg_frames);
 int launch_prepare_segments_var(hipStream_t st, bool sloped, const BankPtrs& P, const LaunchSet& base, uint32_t nvoices, uint32_t nseg, uint64_t start);

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         // this tile's lean pairs: per chunk of the group a compacted list of 256-byte records (the count: the bits of the chunk's
         // mask), walked like the lean lists of an ordinary launch -- wave w takes every WAVES-th entry, the offset carries over
         static_assert(64 * FPL == TILE_FRAMES, "the lean kernel's tile is the tile of the classification");
-        const size_t slots = set_slots(nvoices);
+        const size_t slots = (size_t)B.tiles.rec_chunks * 64;
         const TileRec SH_CONST_AS* trow = as_const(B.tiles.recs) + (size_t)tile_index * slots;
         // The voice groups of a tile-classified launch do not partition the CHUNKS but every chunk's list: entry p of a list goes
         // to group p / WAVES mod groups, wave p mod WAVES (the offset carries over from list to list) -- notes that sound together are
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             const uint32_t npairs = (uint32_t)__popcll(cmask);
             const uint32_t idx = base + src;                              // (group, k - k0) of the prepare step's layout
             const uint32_t c = idx / kw + (B.tiles.k0 + idx % kw) * ngroups;
-            const TileRec SH_CONST_AS* q = trow + c * 64 + firstp;
+            const TileRec SH_CONST_AS* q = trow + (c - B.tiles.k0 * ngroups) * 64 + firstp;
             uint32_t p = firstp;
             for (; p < npairs; p += stride, q += stride) {
                 const double t0 = q->t0, dt = q->dt, rc = q->rc, rs = q->rs, ea0 = q->ea0, ea1 = q->ea1, GL = q->GL, GR = q->GR;
@@ -1042,9 +1042,11 @@ static int launch_tiled(const RenderLaunch& L, bool records_deferred) {
     if (sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups) sh::counters().tiled_predicted += 1;
     if (!(sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups)) {
         // not predicted (the first launches of a run, a jump): resolve it in front of the render
-        rc = grow_tile_set(b->tile_block[ks], T, b->tile_carved[ks], ntiles, b->nvoices, groups, st);
+        uint32_t k0 = 0, k1 = 0;
+        k_range(start, k0, k1);
+        rc = grow_tile_set(b->tile_block[ks], T, b->tile_carved[ks], ntiles, b->nvoices, groups, (k1 - k0) * groups, st);
         if (rc) return rc;
-        k_range(start, T.k0, T.k1);
+        T.k0 = k0; T.k1 = k1;
         P.tiles = T;
         const LaunchSet own = launch_set(b, b->cur);
         rc = launch_prepare_tiles(st, P, T, b->nvoices, start, nframes, records_deferred ? &own : nullptr);
@@ -1059,9 +1061,11 @@ static int launch_tiled(const RenderLaunch& L, bool records_deferred) {
     if (next.launch) {
         const int k2 = (int)((b->tile_count + 2) % sh_bank::NTILESETS);
         TileSet& T2 = b->tile_set[k2];
-        rc = grow_tile_set(b->tile_block[k2], T2, b->tile_carved[k2], ntiles, b->nvoices, groups, st);
+        uint32_t k0 = 0, k1 = 0;
+        k_range(next_start, k0, k1);
+        rc = grow_tile_set(b->tile_block[k2], T2, b->tile_carved[k2], ntiles, b->nvoices, groups, (k1 - k0) * groups, st);
         if (rc) return rc;
-        k_range(next_start, T2.k0, T2.k1);
+        T2.k0 = k0; T2.k1 = k1;
         P.next_tiles = T2;
         P.next_ntiles = ntiles;
         uint32_t in_range = (T2.k1 - T2.k0) * groups;                 // chunks of the range (the last slot's may not all exist)
@@ -1325,8 +1329,15 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // every (voice, 512-frame tile) pair lies on one envelope line and one piece of the phase table.  Those pairs take the lean
     // loop, the others the general code for that tile only (see TileRec).
     bool tiled = false;
-    if (split && tile_candidate && var == 484)
-        tiled = (uint64_t)sh::div_up(nframes, TILE_FRAMES) * set_slots(b->nvoices) * sizeof(TileRec) <= ((uint64_t)1 << 30);
+    if (split && tile_candidate && var == 484) {
+        // (a tile set holds records for the RANGE of chunks that can sound in the block; a block in which more than 2 GB worth of them
+        // do -- a million notes at once -- goes through the general code)
+        uint32_t c_lo = sh::div_up(b->nvoices, 64), c_hi = 0;
+        for (uint32_t c = 0; c < sh::div_up(b->nvoices, 64); ++c)
+            if (!(start + nframes <= b->chunk_span[2 * c] || start >= b->chunk_span[2 * c + 1])) { c_lo = c < c_lo ? c : c_lo; c_hi = c + 1; }
+        const uint64_t range = c_hi > c_lo ? (uint64_t)(c_hi - c_lo) + 2 * groups : 0;
+        tiled = (uint64_t)sh::div_up(nframes, TILE_FRAMES) * range * 64 * sizeof(TileRec) <= ((uint64_t)1 << 31);
+    }
     uint32_t seg_first[SEG_MAX + 1];
     uint32_t nseg = 0;
     if (!tiled && split && (mode == RENDER_LEAN_HARM || mode == RENDER_LEAN_ALL) && var == 484 && b->all_lean && !K.no_seg && !b->needs_rows && !b->no_general_voice(start, nframes)) {
