@@ -1006,6 +1006,7 @@ struct RenderLaunch {
     const double2* pv_parts; float2* pv32; double2* pv64; uint32_t* pv16;
     double pcm_scale, pv_scale;
     uint32_t* gen_valid; const uint32_t* pv_gen;
+    uint32_t c_lo, c_hi;              // (tile-classified launches) the chunks that can sound in this block: [c_lo, c_hi)
 };
 #define SH_RL_UNPACK(L)                                                                                                             \
     sh_bank* b = (L).b; hipStream_t st = (L).st; const sh::Knobs& K = (L).K; const uint64_t start = (L).start, next_start = (L).next_start; \
@@ -1042,8 +1043,7 @@ static int launch_tiled(const RenderLaunch& L, bool records_deferred) {
     if (sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups) sh::counters().tiled_predicted += 1;
     if (!(sp.valid && sp.start == start && sp.nframes == nframes && sp.groups == groups)) {
         // not predicted (the first launches of a run, a jump): resolve it in front of the render
-        uint32_t k0 = 0, k1 = 0;
-        k_range(start, k0, k1);
+        const uint32_t k0 = L.c_hi ? L.c_lo / groups : 0u, k1 = L.c_hi ? sh::div_up(L.c_hi, groups) : 0u;      // (found by bank_render)
         rc = grow_tile_set(b->tile_block[ks], T, b->tile_carved[ks], ntiles, b->nvoices, groups, (k1 - k0) * groups, st);
         if (rc) return rc;
         T.k0 = k0; T.k1 = k1;
@@ -1329,13 +1329,14 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // every (voice, 512-frame tile) pair lies on one envelope line and one piece of the phase table.  Those pairs take the lean
     // loop, the others the general code for that tile only (see TileRec).
     bool tiled = false;
+    uint32_t tile_c_lo = 0, tile_c_hi = 0;
     if (split && tile_candidate && var == 484) {
         // (a tile set holds records for the RANGE of chunks that can sound in the block; a block in which more than 2 GB worth of them
         // do -- a million notes at once -- goes through the general code)
-        uint32_t c_lo = sh::div_up(b->nvoices, 64), c_hi = 0;
+        tile_c_lo = sh::div_up(b->nvoices, 64);
         for (uint32_t c = 0; c < sh::div_up(b->nvoices, 64); ++c)
-            if (!(start + nframes <= b->chunk_span[2 * c] || start >= b->chunk_span[2 * c + 1])) { c_lo = c < c_lo ? c : c_lo; c_hi = c + 1; }
-        const uint64_t range = c_hi > c_lo ? (uint64_t)(c_hi - c_lo) + 2 * groups : 0;
+            if (!(start + nframes <= b->chunk_span[2 * c] || start >= b->chunk_span[2 * c + 1])) { tile_c_lo = c < tile_c_lo ? c : tile_c_lo; tile_c_hi = c + 1; }
+        const uint64_t range = tile_c_hi > tile_c_lo ? (uint64_t)(tile_c_hi - tile_c_lo) + 2 * groups : 0;
         tiled = (uint64_t)sh::div_up(nframes, TILE_FRAMES) * range * 64 * sizeof(TileRec) <= ((uint64_t)1 << 31);
     }
     uint32_t seg_first[SEG_MAX + 1];
@@ -1391,7 +1392,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     const uint32_t nchunks = sh::div_up(b->nvoices, 64);
     const uint32_t prep_wgs = (next.launch && !K.prepare_in_tile) ? nchunks : 0u;
     const RenderLaunch L{b, st, K, start, next_start, nframes, tiles, groups, vpg, nchunks, prep_wgs, mode, var, split, with_general, use_aux,
-                         cur, next, o32, o64, o16, parts, pv_parts, pv32, pv64, pv16, pcm_scale, pv_scale, gen_valid, pv_gen};
+                         cur, next, o32, o64, o16, parts, pv_parts, pv32, pv64, pv16, pcm_scale, pv_scale, gen_valid, pv_gen, tile_c_lo, tile_c_hi};
     rc = tiled ? launch_tiled(L, records_deferred) : nseg ? launch_segmented(L, nseg, seg_first) : launch_plain(L);
     if (rc) return rc;
     if (use_aux) S.aux_busy = true;                         // (join_aux records the event the main stream waits for)
