@@ -25,7 +25,10 @@ value = voice-samples mixed per second over all ranks / 1e6 ("Msamples/s"), inpu
 resident in HBM before the timed region.  The same run also times the other BASELINE configs
 (`configs`), the reference-shaped two-step path (voices materialised as float32 PCM in HBM, then the
 HBM-bound mixer kernel), the PCM rows (resample = configs[4], integer mixer chain, audioop.add ...) and
-the CPU oracle (pure-Python generators) on a bounded sample -- reported beside, never as `value`.
+the CPU oracle (pure-Python generators; its C restatement on one core and on all host cores) on a bounded sample -- reported
+beside, never as `value`.  Also beside: `staggered_notes` (a table of 22 528 notes that do not move in lock-step, one-second blocks
+and 4096-frame chunks), `config4` at N = 1 (the 8192-voice table; one rank's share through the RCCL ring) and `verified` (the last
+timed block against a fresh single render, bit for bit).
 """
 from __future__ import annotations
 
