@@ -183,3 +183,27 @@ def test_white_noise_spec():
     assert int(v["noise_seed"][0]) == 7 and int(v["noise_hold"][0]) == 80 and v["env"]["enabled"][0] == 1
     with pytest.raises(ValueError):
         WhiteNoise(10000.0, samplerate=8000).spec()
+
+
+def test_staggered_notes_workload_and_onset_records():
+    """workloads.staggered_notes on the host: slots * notes voices in the order they start, every note a DelayFilter over an
+    EnvelopeFilter over Harmonics whose record carries the onset (sh_voice::start_frame = int(samplerate * seconds), as the
+    oracle's DelayFilter counts) -- the same voices from both modules, so one seed gives the two sides of a parity check."""
+    from oracle import synth_oracle as O
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.oscillators import pack_voices
+    from synthesizer_amd.workloads import staggered_notes
+    sr, slots, notes = 48000, 32, 3
+    gv, gg = staggered_notes(G, slots, sr, seed=5, period=0.5, notes=notes)
+    ov, og = staggered_notes(O, slots, sr, seed=5, period=0.5, notes=notes)
+    assert len(gv) == len(ov) == slots * notes and gg == og
+    specs = [v.spec() for v in gv]
+    onsets = [s.start_frame for s in specs]
+    assert onsets == sorted(onsets) and onsets[0] == 0 and onsets[-1] < notes * 0.5 * sr
+    for s, o in zip(specs, ov):
+        want = int(sr * o._seconds) if isinstance(o, O.DelayFilter) else 0
+        assert s.start_frame == want
+        assert s.env is not None and s.harm_poly is not None                # a fused envelope, the polynomial form of the series
+    packed = pack_voices(specs, gg)
+    voices = packed[0]
+    assert [int(x) for x in voices["start_frame"]] == onsets
