@@ -177,6 +177,7 @@ int  sh_debug_counters(sh_counters* out);
  *   SYNTHHIP_NO_SEG=1             transition launches / the heads of materialised rows are not cut into segments
  *   SYNTHHIP_NO_TILES=1           banks whose notes do not move in lock-step (onsets, envelopes of their own) are not classified tile
  *                                 by tile: every voice that holds an onset or a corner in the launch takes the general code
+ *   SYNTHHIP_PREP_IN_GENERAL=1    long tile-classified launches resolve the next-but-one tile set in the general kernel, not the lean one
  *   SYNTHHIP_NO_MERGED=1          short tile-classified launches (up to sixteen tiles) as two kernels, like long ones
  *   SYNTHHIP_TILES_FOR_ALL=1     transition launches of lock-step banks tile-classified too instead of segmented (measured: the release
  *                                 block 80 -> 57 us, block 0 137 -> 174 us: not the default)

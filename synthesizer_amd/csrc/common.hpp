@@ -70,6 +70,7 @@ struct Knobs {
     bool no_split = false;         // SYNTHHIP_NO_SPLIT=1: lean and general code in one kernel
     bool no_seg = false;           // SYNTHHIP_NO_SEG=1: transition launches / row heads are not cut into segments
     int  tiles_for_all = -1;       // SYNTHHIP_TILES_FOR_ALL=0|1: transition launches of lock-step banks segmented (0) or tile-classified (1); -1: the default
+    bool prep_in_general = false;  // SYNTHHIP_PREP_IN_GENERAL=1: long tile-classified launches resolve the next-but-one tile set in the general kernel
     bool no_merged = false;        // SYNTHHIP_NO_MERGED=1: short tile-classified launches as two kernels, like long ones
     bool no_tiles = false;         // SYNTHHIP_NO_TILES=1: banks whose notes do not move in lock-step are not classified tile by tile
     bool always_general = false;   // SYNTHHIP_ALWAYS_GENERAL=1: the general-lists kernel of a split launch is always launched

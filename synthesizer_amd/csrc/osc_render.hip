@@ -125,16 +125,19 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     if (!mode_general(MODE) && prep_wgs) {
         if (blockIdx.y >= ngroups) {
             const uint32_t unit = (blockIdx.y - ngroups) * gridDim.x + blockIdx.x;
-            if constexpr (mode_merged(MODE)) {
-                // the rows behind the voice groups': GEN_SPLIT general workgroups per tile, then the tile-set prepare workgroups
-                const uint32_t gen_total = gridDim.x * GEN_SPLIT;
+            if constexpr (mode_tiles(MODE)) {
+                // the rows behind the voice groups': (merged kernel) GEN_SPLIT general workgroups per tile; then the workgroups that
+                // resolve the tile set of the block two launches on
+                const uint32_t gen_total = mode_merged(MODE) ? gridDim.x * GEN_SPLIT : 0u;
                 if (unit >= prep_wgs) return;
                 if (unit >= gen_total) {
                     const uint32_t runs = (B.next_ntiles + TILES_PER_WAVE - 1) / TILES_PER_WAVE, wgs_per_chunk = (runs + 3) / 4;
                     const uint32_t u = unit - gen_total;
                     const uint32_t c = B.next_tiles.k0 * B.next_tiles.groups + u / wgs_per_chunk, run = (u % wgs_per_chunk) * 4 + (threadIdx.x >> 6);
-                    if (B.next_tile_wgs && c < (nvoices + 63) / 64)
+                    if (B.next_tile_wgs && c < (nvoices + 63) / 64) {
+                        __builtin_amdgcn_s_setprio(3);                       // (latency-bound, beside wavefronts that fill every issue slot)
                         prepare_tiles_wave(B, B.next_tiles, nvoices, next_start, nframes, B.next_ntiles, c, run, next.launch ? &next : nullptr);
+                    }
                     return;
                 }
                 is_gen_wg = true;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         // (a one-dimensional grid: the general workgroups first -- theirs is the longer job and the other stream's lean kernel
         // leaves this one few slots -- then next_tile_wgs prepare workgroups over the chunks of the next set's range)
         // (the launch records of that block: resolved by the same wavefronts, for the voices that need one -- prepare_tiles_wave)
-        if (blockIdx.x >= gridDim.x - B.next_tile_wgs) {
+        if (prep_wgs && blockIdx.x >= gridDim.x - B.next_tile_wgs) {      // (prep_wgs = 0: the lean kernel of this launch resolves that set)
             const uint32_t runs = (B.next_ntiles + TILES_PER_WAVE - 1) / TILES_PER_WAVE, wgs_per_chunk = (runs + 3) / 4;
             const uint32_t unit = blockIdx.x - (gridDim.x - B.next_tile_wgs);
             const uint32_t c = B.next_tiles.k0 * B.next_tiles.groups + unit / wgs_per_chunk, run = (unit % wgs_per_chunk) * 4 + (threadIdx.x >> 6);
@@ -1085,25 +1088,32 @@ static int launch_tiled(const RenderLaunch& L, bool records_deferred) {
         hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_TILES_MERGED>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st, P,
                            trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
                            o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, behind);
-    } else
-    if (b->tile_waveforms) {
-        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES_ALL>), dim3(tiles, groups), dim3(256), 0, st, P,
-                           trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
     } else {
-        hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups), dim3(256), 0, st, P,
-                           trig_table(), b->nvoices, vpg, cur, no_next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
-                           o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, 0u);
+        // The tile set of the block two launches on is resolved in rows behind the lean kernel's voice groups (as in the merged
+        // kernel); the general kernel behind it is then the general pairs' alone.  With the classification in the general kernel
+        // (SYNTHHIP_PREP_IN_GENERAL=1: the shape this path had for most of round 3) the two kernels took 68 + 25 us on their stream, so
+        // 80 + 13: the sum is what the chip can do, but a block comes out at 48.4 instead of 50.4 us.
+        const uint32_t in_lean = K.prep_in_general ? 0u : P.next_tile_wgs;
+        const LaunchSet& nx = in_lean ? next : no_next;
+        if (b->tile_waveforms)
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES_ALL>), dim3(tiles, groups + sh::div_up(in_lean, tiles)), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, cur, nx, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, in_lean);
+        else
+            hipLaunchKernelGGL((k_bank_render<4, 8, 4, RENDER_LEAN_TILES>), dim3(tiles, groups + sh::div_up(in_lean, tiles)), dim3(256), 0, st, P,
+                               trig_table(), b->nvoices, vpg, cur, nx, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64,
+                               o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, in_lean);
     }
     SH_CHECK_LAUNCH("k_bank_render(lean, tiles)");
     if (!merged) {   // the general pairs: GEN_SPLIT workgroups per 256-frame tile, each all voice groups' pairs of it
         const uint32_t gen_wgs = sh::div_up(nframes, 256) * GEN_SPLIT;
         // (on a stream of its own beside the lean kernel it was slower, 95 against 75 us per block: five streams share four
         // hardware queues, and a kernel that waits for an event holds up whatever shares its queue)
-        hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs + P.next_tile_wgs), dim3(256), 0, st, P,
+        const uint32_t g_prep = K.prep_in_general ? P.next_tile_wgs : 0u;
+        hipLaunchKernelGGL((k_bank_render<4, 4, 4, RENDER_GENERAL_TILES>), dim3(gen_wgs + g_prep), dim3(256), 0, st, P,
                            trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, (float2*)nullptr, (double2*)nullptr, parts,
                            (const double2*)nullptr, (float2*)nullptr, (double2*)nullptr, (uint32_t*)nullptr, 0.0, (uint32_t*)nullptr, 0.0,
-                           gen_valid, (const uint32_t*)nullptr, 0u);
+                           gen_valid, (const uint32_t*)nullptr, g_prep);
         SH_CHECK_LAUNCH("k_bank_render(general, tiles)");
     }
     b->tile_count += 1;

@@ -34,6 +34,7 @@ void load_knobs() {
     k.no_seg = flag("SYNTHHIP_NO_SEG");
     k.no_tiles = flag("SYNTHHIP_NO_TILES");
     k.no_merged = flag("SYNTHHIP_NO_MERGED");
+    k.prep_in_general = flag("SYNTHHIP_PREP_IN_GENERAL");
     if (const char* e = getenv("SYNTHHIP_TILES_FOR_ALL")) k.tiles_for_all = atoi(e);
     k.always_general = flag("SYNTHHIP_ALWAYS_GENERAL");
     k.no_small_pipeline = flag("SYNTHHIP_NO_SMALL_PIPELINE");
