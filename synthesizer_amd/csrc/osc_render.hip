@@ -167,12 +167,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             if (!mode_merged(MODE)) return;
         }
     }
-    // RENDER_GENERAL_TILES: the first B.next_tile_wgs workgroups of every row of the grid resolve the TILE SET of the block two
-    // launches on: four wavefronts each, a run of TILES_PER_WAVE tiles of one chunk per wavefront (prepare_tiles_wave) -- the chunks
-    // whose voices are all silent in that block leave after one load.  They ride in the GENERAL kernel, which follows the lean one
-    // on its stream, is a few dozen latency-bound workgroups and runs beside the other stream's lean kernel: in the lean kernel
-    // (whose 752 workgroups want every slot of the chip at once) they cost the launch 16 of 69 us; as a kernel of its own on a third
-    // stream the step shared a hardware queue with one of the render streams and sat in front of that stream's next launch.
+    // RENDER_GENERAL_TILES with prep_wgs > 0 (SYNTHHIP_PREP_IN_GENERAL=1: where the step lived for most of round 3): the last
+    // B.next_tile_wgs workgroups of the grid resolve the TILE SET of the block two launches on: four wavefronts each, a run of
+    // TILES_PER_WAVE tiles of one chunk per wavefront (prepare_tiles_wave).  The step has been in four places: between the lean
+    // kernel's workgroups (it cost the launch 16 of 69 us: workgroups that leave at once upset the placement of the others), a
+    // kernel of its own on a third stream (which shared a hardware queue with a render stream), this kernel (68 + 25 us per launch
+    // on its stream), and -- the default -- rows of the lean kernel's grid BEHIND its voice groups (80 + 13 us: see above).
     if constexpr (MODE == RENDER_GENERAL_TILES) {
         // This kernel is a few hundred latency-bound wavefronts that run beside the other stream's lean kernel, whose wavefronts
         // fill every issue slot they are given: without priority the two do not overlap at all -- the lean kernel runs at the speed
