@@ -1458,8 +1458,14 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
 // which the shapes of small banks reach first: sixteen waves on 128 frames), and a bank with several voice groups keeps
 // 32 bytes of partial buses per frame and group.  Long renders are therefore a run of launches of RENDER_MAX_FRAMES (87 s
 // at 48 kHz; consecutive blocks of one shape: the two-stream pipeline applies) into views of the caller's buffers.
-constexpr uint32_t RENDER_MAX_FRAMES = 1u << 22;
+constexpr uint32_t RENDER_MAX_FRAMES_ANY = 1u << 22;
 static int bank_render_any(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32, sh_buf* bus_f64, sh_buf* pcm_i16, double pcm_scale) {
+    // A table of notes (tile-classified launches) is rendered in launches of at most 2^17 frames: a tile set holds a record per
+    // (tile, sounding voice), and a launch of minutes of audio would not get one (it would fall back to the general code for
+    // every voice of the table); everything else in launches of at most RENDER_MAX_FRAMES (the 32-bit work-item count of a dispatch).
+    const bool notes = b && b->tile_all && b->nvoices >= 128 && (b->has_onsets || b->own_envelopes) && !b->needs_rows && b->first_row_voice < 0 &&
+                       !sh::knobs().no_tiles;
+    const uint32_t RENDER_MAX_FRAMES = notes ? (1u << 17) : RENDER_MAX_FRAMES_ANY;
     if (nframes <= RENDER_MAX_FRAMES) return bank_render(b, start, nframes, bus_f32, bus_f64, pcm_i16, pcm_scale);
     SH_API_LOCK();                                           // (recursive) one call: nothing else gets between its launches
     if (bus_f32 && bus_f32->bytes < (size_t)nframes * 8) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f32 too small");

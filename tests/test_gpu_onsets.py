@@ -161,6 +161,9 @@ def test_staggered_notes_tile_by_tile(gpu, tmp_path):
     # one long launch over everything (another tile count, a partial last tile)
     whole = bank.render(n - 100)
     assert rms(whole, want[:n - 100]) <= RMS_TOL
+    # a call of several seconds is carried out as launches of 2^17 frames (a tile set per launch): the same frames as those launches
+    long_n = (1 << 17) + 40000
+    assert np.array_equal(bank.render(long_n), np.concatenate([bank.render(1 << 17), bank.render(40000, start=1 << 17)]))
     # the classification switched off: same buses up to float64 rounding (the lean pairs fold the envelope's line into the gains)
     ref = tmp_path / "notiles.npy"
     root = Path(__file__).resolve().parent.parent
