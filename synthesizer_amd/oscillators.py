@@ -563,6 +563,35 @@ class WhiteNoise(Oscillator):
                          carrier=_table(0.0, 0.0), noise_seed=int(self.seed), noise_hold=cycles)
 
 
+@lru_cache(maxsize=4096)
+def _harmonic_forms(harmonics):
+    """(polynomial, dense Clenshaw, sparse) form of a harmonic list [(k, amplitude)]: exactly one of them is not None."""
+    dense = None
+    sparse = None
+    poly = None
+    ks = [k for k, _ in harmonics]
+    integral = all(float(k) == int(k) for k in ks)
+    kmax = max((abs(int(k)) for k in ks), default=0) if integral else 0
+    if integral and 0 < kmax <= min(_DENSE_MAX_K, 8 * len(ks) + 64):
+        n = (kmax + 7) // 8 * 8
+        coef = [0.0] * (n + 1)                       # index k
+        for k, a in harmonics:
+            k = int(k)
+            if k > 0:
+                coef[k] += float(a)
+            elif k < 0:
+                coef[-k] -= float(a)                 # sin(-k t) = -sin(k t)
+        if kmax <= 16:
+            poly = series_polynomial(tuple((coef[1:] + [0.0] * 16)[:16]))
+        if poly is None:
+            dense = tuple(coef[n:0:-1])              # k = n .. 1
+    else:
+        sparse = tuple((float(k), float(a)) for k, a in harmonics)
+        if not sparse:
+            sparse = ((0.0, 0.0),)
+    return poly, dense, sparse
+
+
 class Harmonics(_Carrier):
     """Additive sine series sum_k a_k sin(k*t) (upstream: oscillators.py class Harmonics)."""
     KIND = N.SH_HARMONICS
@@ -575,29 +604,9 @@ class Harmonics(_Carrier):
         self.harmonics = list(harmonics)
 
     def _make_spec(self) -> VoiceSpec:
-        dense = None
-        sparse = None
-        poly = None
-        ks = [k for k, _ in self.harmonics]
-        integral = all(float(k) == int(k) for k in ks)
-        kmax = max((abs(int(k)) for k in ks), default=0) if integral else 0
-        if integral and 0 < kmax <= min(_DENSE_MAX_K, 8 * len(ks) + 64):
-            n = (kmax + 7) // 8 * 8
-            coef = [0.0] * (n + 1)                       # index k
-            for k, a in self.harmonics:
-                k = int(k)
-                if k > 0:
-                    coef[k] += float(a)
-                elif k < 0:
-                    coef[-k] -= float(a)                 # sin(-k t) = -sin(k t)
-            if kmax <= 16:
-                poly = series_polynomial(tuple((coef[1:] + [0.0] * 16)[:16]))
-            if poly is None:
-                dense = tuple(coef[n:0:-1])              # k = n .. 1
-        else:
-            sparse = tuple((float(k), float(a)) for k, a in self.harmonics)
-            if not sparse:
-                sparse = ((0.0, 0.0),)
+        # (the three forms of a harmonic list depend on the list alone: a table of notes shares a handful of lists among thousands
+        # of voices)
+        poly, dense, sparse = _harmonic_forms(tuple((k, a) for k, a in self.harmonics))
         return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias),
                          harm_poly=poly, harm_dense=dense, harm_sparse=sparse, **self._phase_fields())
 
