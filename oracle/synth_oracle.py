@@ -300,7 +300,7 @@ class EnvelopeFilter(Oscillator):
     """
 
     def __init__(self, source: Oscillator, attack: float, decay: float, sustain: float,
-                 sustain_level: float, release: float, stop_at_end: bool = False) -> None:
+                 sustain_level: float, release: float, stop_at_end: bool = False, cycle: bool = False) -> None:
         assert attack >= 0 and decay >= 0 and sustain >= 0 and release >= 0
         assert 0 <= sustain_level <= 1
         super().__init__(source.samplerate)
@@ -311,40 +311,46 @@ class EnvelopeFilter(Oscillator):
         self._sustain_level = sustain_level
         self._release = release
         self._stop_at_end = stop_at_end
+        # SURVEY.md 8(a) row a8 lists ``cycle=False`` in the signature [RECALL]: the phases start over after the release
+        # (``time`` and ``amp`` from zero), the source generator running on; the silence / stop_at_end tail is then never reached
+        self._cycle = cycle
 
     def _samples(self) -> Generator[float, None, None]:
         src = itertools.chain.from_iterable(self._source.blocks())
-        time = 0.0
         end_time_decay = self._attack + self._decay
         end_time_sustain = end_time_decay + self._sustain
         end_time_release = end_time_sustain + self._release
         increment = 1.0 / self.samplerate
-        if self._attack:
-            amp_change = 1.0 / self._attack * increment
-            amp = 0.0
-            while time < self._attack:
-                yield next(src) * amp
-                amp += amp_change
+        while True:
+            time = 0.0
+            if self._attack:
+                amp_change = 1.0 / self._attack * increment
+                amp = 0.0
+                while time < self._attack:
+                    yield next(src) * amp
+                    amp += amp_change
+                    time += increment
+            if self._decay:
+                amp = 1.0
+                amp_change = (self._sustain_level - 1.0) / self._decay * increment
+                while time < end_time_decay:
+                    yield next(src) * amp
+                    amp += amp_change
+                    time += increment
+            while time < end_time_sustain:
+                yield next(src) * self._sustain_level
                 time += increment
-        if self._decay:
-            amp = 1.0
-            amp_change = (self._sustain_level - 1.0) / self._decay * increment
-            while time < end_time_decay:
-                yield next(src) * amp
-                amp += amp_change
-                time += increment
-        while time < end_time_sustain:
-            yield next(src) * self._sustain_level
-            time += increment
-        if self._release:
-            amp = self._sustain_level
-            amp_change = (-self._sustain_level) / self._release * increment
-            while time < end_time_release:
-                yield next(src) * amp
-                amp += amp_change
-                time += increment
-            if amp > 0.0:
-                yield next(src) * amp
+            if self._release:
+                amp = self._sustain_level
+                amp_change = (-self._sustain_level) / self._release * increment
+                while time < end_time_release:
+                    yield next(src) * amp
+                    amp += amp_change
+                    time += increment
+                if amp > 0.0:
+                    yield next(src) * amp
+            if not self._cycle:
+                break
         if not self._stop_at_end:
             while True:
                 yield 0.0

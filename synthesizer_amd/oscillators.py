@@ -666,7 +666,7 @@ class EnvelopeFilter(Oscillator):
     exactly the reference's accumulated amplitude), one elementwise kernel."""
 
     def __init__(self, source: Oscillator, attack: float, decay: float, sustain: float, sustain_level: float,
-                 release: float, stop_at_end: bool = False) -> None:
+                 release: float, stop_at_end: bool = False, cycle: bool = False) -> None:
         assert attack >= 0 and decay >= 0 and sustain >= 0 and release >= 0
         assert 0 <= sustain_level <= 1
         super().__init__(source.samplerate)
@@ -677,11 +677,19 @@ class EnvelopeFilter(Oscillator):
         self._sustain_level = sustain_level
         self._release = release
         self._stop_at_end = stop_at_end
-        self._fused = isinstance(source, (_Carrier, Linear, WhiteNoise))
+        self._cycle = bool(cycle)
+        self._fused = isinstance(source, (_Carrier, Linear, WhiteNoise)) and not self._cycle
         self._gain: Optional["EnvelopeFilter"] = None
+        self._cycle_gain: Optional[N.DeviceBuffer] = None      # cycle=True: whole periods of the gain curve, kept in HBM
+        self._cycle_frames = 0
         if not self._fused:
+            # cycle=True (SURVEY 8(a) row a8's signature): the four phases start over when the release is done -- ``time`` and
+            # ``amp`` from zero, the source running on -- so the gain is ONE pass of the phases (stop_at_end: its length is the
+            # period) repeated; stop_at_end itself is never reached
             self._gain = EnvelopeFilter(Linear(1.0, samplerate=source.samplerate), attack, decay, sustain, sustain_level, release,
-                                        stop_at_end)
+                                        True if self._cycle else stop_at_end)
+            if self._cycle and self._gain.spec().env.length == 0:
+                raise ValueError("a cycling envelope needs a phase of at least one sample")
 
     def _fm_source(self):
         return self._source._fm_source() if self._fused else None
@@ -702,11 +710,39 @@ class EnvelopeFilter(Oscillator):
             return super().length
         # the envelope's own phases decide: attack .. release (+ the extra sample) with stop_at_end, endless silence
         # after them without -- the source is not consulted once the release is over
-        return self._gain.length
+        return None if self._cycle else self._gain.length
+
+    def _render_cycling(self, start: int, n: int) -> N.DeviceBuffer:
+        """cycle=True: source[start + i] * gain[(start + i) mod period].  One period of the gain comes from the fused path (the
+        envelope of a constant 1) once, laid out back to back until the buffer holds 65 536 frames, so a block is a few
+        multiplications of slices whatever the period."""
+        period = self._gain.spec().env.length
+        src_len = self._source.length
+        if src_len is not None and start + n > src_len:
+            raise _SourceExhausted("generator raised StopIteration")
+        if self._cycle_gain is None:
+            reps = max(1, -(-65536 // period))
+            one = self._gain._render_f64_device(0, period)
+            buf = N.DeviceBuffer(8 * period * reps)
+            for r in range(reps):
+                N.check(N.lib().sh_buf_copy(buf.handle, 8 * period * r, one.handle, 0, 8 * period))
+            one.free()
+            self._cycle_gain, self._cycle_frames = buf, period * reps
+        out = self._source._render_f64_device(start, n)
+        done = 0
+        while done < n:
+            pos = (start + done) % period
+            cnt = min(n - done, self._cycle_frames - pos)
+            N.check(N.lib().sh_ew_f64(N.SH_EW_MUL, out.handle, done, self._cycle_gain.handle, pos, cnt, 0.0, 0.0,
+                                      out.handle, done, None, 0, None))
+            done += cnt
+        return out
 
     def _render_f64_device(self, start: int, n: int) -> N.DeviceBuffer:
         if self._fused:
             return super()._render_f64_device(start, n)
+        if self._cycle:
+            return self._render_cycling(start, n)
         limit = self.length
         if limit is not None and start + n > limit:
             raise ValueError("stream ended before the requested range")

@@ -176,6 +176,44 @@ def test_envelope_filter(gpu, adsr):
     assert rms(got, want) <= RMS_TOL
 
 
+@pytest.mark.parametrize("adsr", [(0.01, 0.02, 0.03, 0.6, 0.04), (0.0, 0.005, 0.0, 0.3, 0.011), (0.002, 0.0, 0.001, 1.0, 0.0)])
+def test_envelope_filter_cycle(gpu, adsr):
+    """cycle=True (SURVEY 8(a) row a8's signature): the phases start over after the release, the source runs on.  Against the
+    oracle's generator over several periods, from frame 0, from the middle of a period, block by block, and as a bank voice."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    a, d, s, sl, r = adsr
+    period = G.envelope_spec(a, d, s, sl, r, SR, True).length
+    n = max(5 * period + 777, 8 * 512 + 5)
+    g = G.EnvelopeFilter(G.Sine(440, samplerate=SR), a, d, s, sl, r, cycle=True)
+    o = O.EnvelopeFilter(O.Sine(440, samplerate=SR), a, d, s, sl, r, cycle=True)
+    want = np.array(o.take(n))
+    assert g.length is None
+    got = g.render(n, start=0)
+    assert rms(got, want) <= RMS_TOL and np.max(np.abs(got - want)) < 2e-7
+    f64 = g.render_f64(n, start=0)
+    assert np.max(np.abs(f64 - want)) <= 1e-12
+    assert np.max(np.abs(want[period:2 * period])) > 0.0            # the second period sounds: this is not stop / silence
+    start = 2 * period + period // 3
+    assert np.array_equal(g.render(1000, start=start), got[start:start + 1000])
+    blocks = list(itertools.islice(g.blocks(), 8))
+    flat = np.array(list(itertools.chain.from_iterable(blocks)))
+    assert np.max(np.abs(flat - want[:flat.size])) <= 1e-12
+    # stop_at_end is never reached while cycling; a delayed cycling envelope goes block by block
+    g2 = G.EnvelopeFilter(G.Square(300, samplerate=SR), a, d, s, sl, r, stop_at_end=True, cycle=True)
+    o2 = O.EnvelopeFilter(O.Square(300, samplerate=SR), a, d, s, sl, r, stop_at_end=True, cycle=True)
+    assert rms(g2.render(n, start=0), np.array(o2.take(n))) <= RMS_TOL
+    # a voice of a bank (a row of the launch's matrix) beside a fused one
+    voices = [g, G.EnvelopeFilter(G.Sawtooth(220, samplerate=SR), a, d, s, sl, r)]
+    gains = [(0.25, 0.75), (0.5, 0.125)]
+    bus = VoiceBank(voices, gains=gains).render(n)
+    w1 = np.array(O.EnvelopeFilter(O.Sawtooth(220, samplerate=SR), a, d, s, sl, r).take(n))
+    ref = np.array(O.mix_bus([want, w1], gains))
+    assert rms(bus, ref) <= RMS_TOL
+    with pytest.raises(ValueError):
+        G.EnvelopeFilter(G.Sine(440, samplerate=SR), 0, 0, 0, 0.5, 0, cycle=True)
+
+
 def test_late_window_phase_precision(gpu):
     """Samples 600 s into the stream: float32 phase would be off by radians here, and the float64
     accumulation has drifted ~1e-5 rad from the ideal n*inc -- the tables follow the drift."""

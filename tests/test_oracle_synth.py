@@ -70,6 +70,23 @@ def test_envelope_shape_and_length():
     assert not any(tail)
 
 
+def test_envelope_cycle_repeats_the_gain_and_keeps_the_source_running():
+    """cycle=True: the phases start over after the release; the host side's period (envelope_spec(...).length) is the
+    generator's, the source is pulled once per sample throughout."""
+    from synthesizer_amd.oscillators import envelope_spec
+    sr = 8000
+    adsr = (0.01, 0.02, 0.03, 0.5, 0.04)
+    period = envelope_spec(*adsr, sr, True).length
+    one = np.array(list(itertools.chain.from_iterable(
+        O.EnvelopeFilter(O.Linear(1.0, samplerate=sr), *adsr, stop_at_end=True).blocks())))
+    assert one.size == period
+    gain = np.array(O.EnvelopeFilter(O.Linear(1.0, samplerate=sr), *adsr, cycle=True).take(3 * period + 17))
+    assert np.array_equal(gain, np.tile(one, 4)[:gain.size])
+    src = np.array(O.Sine(440, samplerate=sr).take(gain.size))
+    x = np.array(O.EnvelopeFilter(O.Sine(440, samplerate=sr), *adsr, stop_at_end=True, cycle=True).take(gain.size))
+    assert np.array_equal(x, src * gain)
+
+
 def test_quantise_rule():
     assert O.quantise([0.5, -0.5, 0.99999, -1.0, 1.0, 3.05e-5, -3.06e-5]) == [16383, -16383, 32766, -32767, 32767, 0, -1]
     assert O.quantise([1.0], 1) == [127] and O.quantise([-1.0], 4) == [-(2 ** 31 - 1)]
