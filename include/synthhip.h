@@ -188,6 +188,10 @@ int  sh_debug_counters(sh_counters* out);
  *   SYNTHHIP_GEN_SPLIT=1|2|4|8    workgroups that share a chunk's lean records in the materialisation kernel (default 2)
  *   SYNTHHIP_GEN_SUB=1..16        split of a segmented launch's first segment;  SYNTHHIP_SEG_MIN=frames of its dense first segment
  *   SYNTHHIP_RESAMPLE_PK=0|1      the packed 16-bit mono resample kernel off / on
+ *   SYNTHHIP_RESAMPLE_LANES=0|1   16-bit mono resample with the output frames dealt to the lanes (k_resample_mono16: no LDS bank conflicts,
+ *                                 16 instead of 20 instructions per sample -- and not faster; default off; bit-identical)
+ *   SYNTHHIP_RESAMPLE_SPLIT=0|1   16-bit mono resample: a thread's 16 output frames as two runs of 8, so that the 16-byte stores of
+ *                                 neighbouring lanes adjoin (default on; bit-identical either way)
  *   SYNTHHIP_COMM_PRIORITY=-1|0|1 priority of the communication stream of the multi-GPU path (high / as the render streams / low)
  * (SYNTHHIP_LIB, read by the Python binding, names another build of this library to load.) */
 

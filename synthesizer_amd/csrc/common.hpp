@@ -85,6 +85,8 @@ struct Knobs {
     long seg_min = 0;              // SYNTHHIP_SEG_MIN: frames of a segmented launch's dense first segment
     int  gen_rows = 0;             // SYNTHHIP_GEN_ROWS=1|2: rows per wave of the lean materialisation kernel
     int  resample_pk = -1;         // SYNTHHIP_RESAMPLE_PK=0|1: packed 16-bit mono resample kernel
+    int  resample_lanes = -1;      // SYNTHHIP_RESAMPLE_LANES=0|1: 16-bit mono resample with the frames dealt to the lanes (k_resample_mono16)
+    int  resample_split = -1;      // SYNTHHIP_RESAMPLE_SPLIT=0|1: 16-bit mono resample, a thread's 16 frames as two runs of 8 (stores of consecutive lanes adjoin)
     int  comm_priority = 0;        // SYNTHHIP_COMM_PRIORITY=-1|0|1: priority of the communication stream (high / as the render streams / low)
     int  pool_fill = -1;           // SYNTHHIP_POOL_FILL=0..255: blocks that grow are filled with this byte first (diagnostics)
 };

@@ -689,57 +689,23 @@ __global__ __launch_bounds__(256) void k_resample_lds(const T* __restrict__ in, 
     }
 }
 
-// 8/16-bit PCM, few channels, reduced rates below 65536 (the common Sample.resample case: 16-bit mono/stereo
-// between 44.1k/48k/96k).  The generic kernels above are VALU-issue-bound there (~55 instructions per output
-// sample at 2-4 bytes of traffic each), so this one strips the arithmetic to ~20 full-rate instructions:
-//  * the workgroup's input span goes through LDS (aligned 16-byte loads), positions are 32-bit LDS-relative;
-//  * output m sits at input position q + r/outr; with a = x[q], b = x[q+1] the reference's expression is
-//    M = a*(outr-r) + b*r for every r (r == 0 gives cur = x[q], weight outr), so there is no prev/cur select;
-//  * u = M + HALF*outr = (b-a)*r + (a+HALF)*outr in 24-bit multiplies (mod 2^32; 0 <= u < 2^32);
-//  * floor(u/outr) = trunc(fma(u, 1/outr, 1/(2 outr))) in float64, exact without a correction step.  See
-//    ratecv_small_int for why the floor equals audioop's float64 expression.
-// PK (16-bit mono, reduced rates below 65536): the interpolation's two products and their sum are ONE instruction -- the dword that
-// holds frames q and q + 1 (offset by HALF, as unsigned 16-bit halves) against the packed weights (outr - r, r):
-// u = ua (outr - r) + ub r = v_dot2_u32_u16 -- in place of two field extractions, a subtraction and two multiplies.
-template <typename T, int VEC, int FR, bool PK = false>
-__global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A,
-                                                        uint64_t in_frames, uint64_t out_frames, uint32_t span_vecs) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* lds = reinterpret_cast<T*>(smem);
-    typedef T vec_t __attribute__((ext_vector_type(VEC * FR)));
-    typedef T ld_t __attribute__((ext_vector_type(16 / sizeof(T))));
-    constexpr uint32_t EPV = 16 / sizeof(T);
+// One thread's FR output frames of k_resample_small, from the staged span (LDS element 0 = input element lo_elem).  GROUPS == 2:
+// the thread's frames are two runs of FR/2, 256*FR/2 frames apart, so that each of its stores is one 16-byte vector NEXT to its
+// neighbour lanes' (a wave's store instruction then writes 1 KB of consecutive bytes; with one run of 16 16-bit frames a lane's two
+// 16-byte stores interleave with its neighbours' at a 32-byte stride).
+template <typename T, int VEC, int FR, bool PK, int GROUPS = 1>
+__device__ __forceinline__ void resample_small_frames(const unsigned char* smem, T* __restrict__ out, const RatecvArgs& A, uint64_t m_first,
+                                                      uint64_t q0, uint32_t r0, uint64_t lo_elem, uint64_t out_frames) {
+    const T* lds = reinterpret_cast<const T*>(smem);
+    constexpr int FRG = FR / GROUPS;
+    typedef T vec_t __attribute__((ext_vector_type(VEC * FRG)));
     constexpr int HALF = 1 << (8 * (int)sizeof(T) - 1);
-    const uint64_t m_first = A.m_base + (uint64_t)blockIdx.x * (256 * FR);
-    if (m_first >= out_frames) return;
-    // position of the workgroup's first output frame: q0 + r0/outr   (uniform)
-    uint64_t q0;
-    uint32_t r0;
-    {
-        uint64_t jf;
-        uint32_t df;
-        ratecv_index(A, m_first, jf, df);
-        r0 = df ? A.outr - df : 0u;
-        q0 = jf - (r0 != 0);
-    }
-    const uint64_t lo_elem = (q0 * VEC) & ~(uint64_t)(EPV - 1);                  // 16-byte aligned start of the span
-    const uint64_t total_elems = in_frames * VEC;
-    for (uint32_t v = threadIdx.x; v < span_vecs; v += 256) {
-        const uint64_t e = lo_elem + (uint64_t)v * EPV;
-        if (e + EPV <= total_elems) {
-            // streaming on both sides (input read once per workgroup, output never re-read): +1..3 % on the 16-bit rows
-            reinterpret_cast<ld_t*>(lds)[v] = __builtin_nontemporal_load(reinterpret_cast<const ld_t*>(in + e));
-        } else {
-            for (uint32_t k = 0; k < EPV; ++k) lds[v * EPV + k] = (e + k < total_elems) ? in[e + k] : (T)0;
-        }
-    }
-    __syncthreads();
-    const uint64_t m0 = m_first + (uint64_t)threadIdx.x * FR;
+    uint64_t m0 = m_first + (uint64_t)threadIdx.x * FRG;
     if (m0 >= out_frames) return;
     // this thread's first frame: (q0, r0) advanced by threadIdx.x*FR output frames (host guarantees < 2^31)
     uint32_t r, qe_elem;
     {
-        const uint32_t tot = r0 + __umul24(threadIdx.x * FR, A.inr);
+        const uint32_t tot = r0 + __umul24(threadIdx.x * FRG, A.inr);
         const uint32_t dq = (uint32_t)fma((double)tot, A.inv_outr, 0.5 * A.inv_outr);   // floor(tot/outr), exact as below
         r = tot - dq * A.outr;
         qe_elem = (uint32_t)(q0 * VEC - lo_elem) + dq * VEC;                     // LDS element index of frame q
@@ -749,9 +715,11 @@ __global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in
     constexpr bool PAIR_IN_DWORD = 2 * VEC * sizeof(T) <= 4;
     constexpr uint32_t MASK = (1u << (8 * sizeof(T))) - 1u;
     constexpr uint32_t FLIP = sizeof(T) == 2 ? 0x80008000u : 0x80808080u;
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
     vec_t res;
 #pragma unroll
-    for (int f = 0; f < FR; ++f) {
+    for (int f = 0; f < FRG; ++f) {
         uint32_t pair = 0;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
@@ -791,11 +759,152 @@ __global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in
         r -= wrap ? A.outr : 0u;
         qe_elem += step_elem + (wrap ? (uint32_t)VEC : 0u);
     }
-    if (m0 + FR <= out_frames) {
+    if (m0 + FRG <= out_frames) {
         __builtin_nontemporal_store(res, reinterpret_cast<vec_t*>(out + m0 * VEC));
     } else {
-        for (int f = 0; f < FR && m0 + f < out_frames; ++f)
+        for (int f = 0; f < FRG && m0 + f < out_frames; ++f)
             for (int c = 0; c < VEC; ++c) out[(m0 + f) * VEC + c] = res[f * VEC + c];
+    }
+    if (g + 1 < GROUPS) {
+        // on to the thread's next run: 255 * FRG frames further (the loop above has moved FRG already)
+        m0 += 256 * FRG;
+        if (m0 >= out_frames) return;
+        const uint32_t tot = r + (uint32_t)(255 * FRG) * A.inr;
+        const uint32_t dq = (uint32_t)fma((double)tot, A.inv_outr, half_inv);
+        r = tot - dq * A.outr;
+        qe_elem += dq * VEC;
+    }
+    }
+}
+
+// 8/16-bit PCM, few channels, reduced rates below 65536 (the common Sample.resample case: 16-bit mono/stereo
+// between 44.1k/48k/96k).  The generic kernels above are VALU-issue-bound there (~55 instructions per output
+// sample at 2-4 bytes of traffic each), so this one strips the arithmetic to ~20 full-rate instructions:
+//  * the workgroup's input span goes through LDS (aligned 16-byte loads), positions are 32-bit LDS-relative;
+//  * output m sits at input position q + r/outr; with a = x[q], b = x[q+1] the reference's expression is
+//    M = a*(outr-r) + b*r for every r (r == 0 gives cur = x[q], weight outr), so there is no prev/cur select;
+//  * u = M + HALF*outr = (b-a)*r + (a+HALF)*outr in 24-bit multiplies (mod 2^32; 0 <= u < 2^32);
+//  * floor(u/outr) = trunc(fma(u, 1/outr, 1/(2 outr))) in float64, exact without a correction step.  See
+//    ratecv_small_int for why the floor equals audioop's float64 expression.
+// PK (16-bit mono, reduced rates below 65536): the interpolation's two products and their sum are ONE instruction -- the dword that
+// holds frames q and q + 1 (offset by HALF, as unsigned 16-bit halves) against the packed weights (outr - r, r):
+// u = ua (outr - r) + ub r = v_dot2_u32_u16 -- in place of two field extractions, a subtraction and two multiplies.
+template <typename T, int VEC, int FR, bool PK = false, int GROUPS = 1>
+__global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A,
+                                                        uint64_t in_frames, uint64_t out_frames, uint32_t span_vecs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* lds = reinterpret_cast<T*>(smem);
+    typedef T ld_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr uint32_t EPV = 16 / sizeof(T);
+    const uint64_t m_first = A.m_base + (uint64_t)blockIdx.x * (256 * FR);
+    if (m_first >= out_frames) return;
+    // position of the workgroup's first output frame: q0 + r0/outr   (uniform)
+    uint64_t q0;
+    uint32_t r0;
+    {
+        uint64_t jf;
+        uint32_t df;
+        ratecv_index(A, m_first, jf, df);
+        r0 = df ? A.outr - df : 0u;
+        q0 = jf - (r0 != 0);
+    }
+    const uint64_t lo_elem = (q0 * VEC) & ~(uint64_t)(EPV - 1);                  // 16-byte aligned start of the span
+    const uint64_t total_elems = in_frames * VEC;
+    for (uint32_t v = threadIdx.x; v < span_vecs; v += 256) {
+        const uint64_t e = lo_elem + (uint64_t)v * EPV;
+        if (e + EPV <= total_elems) {
+            // streaming on both sides (input read once per workgroup, output never re-read): +1..3 % on the 16-bit rows
+            reinterpret_cast<ld_t*>(lds)[v] = __builtin_nontemporal_load(reinterpret_cast<const ld_t*>(in + e));
+        } else {
+            for (uint32_t k = 0; k < EPV; ++k) lds[v * EPV + k] = (e + k < total_elems) ? in[e + k] : (T)0;
+        }
+    }
+    __syncthreads();
+    resample_small_frames<T, VEC, FR, PK, GROUPS>(smem, out, A, m_first, q0, r0, lo_elem, out_frames);
+}
+
+// 16-bit mono once more, the frames dealt to the LANES: a wave takes 1024 consecutive output frames as 8 steps of 128, lane i the
+// frames 2i and 2i + 1 of each step.  Neighbouring lanes then read neighbouring (or the same) dwords of the staged span -- no bank
+// conflicts, where a run of 16 frames per lane puts the lanes 7.35 dwords apart and every second LDS cycle of k_resample_small<short,
+// 1, 16> was a conflict cycle (rocprofv3: SQ_LDS_BANK_CONFLICT 44 M of SQ_LDS_IDX_ACTIVE 83 M) -- and a wave's store instruction
+// writes 256 consecutive bytes (one dword per lane).  The arithmetic is resample_small_frames' with the remainder kept BIASED, R = r -
+// outr (mod 2^32): the carry of R + step is the wrap (v_add_co / v_addc), max(R', R' - outr) restores the bias, and the low 24 bits of
+// R are -(outr - r), so u = ub*outr - (ub - ua)(outr - r) = ua (outr - r) + ub r needs no remainder of its own: 16 VALU instructions
+// per output sample instead of 20.  (SYNTHHIP_RESAMPLE_LANES; bit-identical: tools/resample_split_probe.py compares CRCs.)
+__global__ __launch_bounds__(256) void k_resample_mono16(const short* __restrict__ in, short* __restrict__ out, RatecvArgs A,
+                                                         uint64_t in_frames, uint64_t out_frames, uint32_t span_vecs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    short* lds = reinterpret_cast<short*>(smem);
+    typedef short ld_t __attribute__((ext_vector_type(8)));
+    constexpr uint32_t EPV = 8;
+    const uint64_t m_first = A.m_base + (uint64_t)blockIdx.x * 4096;
+    if (m_first >= out_frames) return;
+    uint64_t q0;
+    uint32_t r0;
+    {
+        uint64_t jf;
+        uint32_t df;
+        ratecv_index(A, m_first, jf, df);
+        r0 = df ? A.outr - df : 0u;
+        q0 = jf - (r0 != 0);
+    }
+    const uint64_t lo_elem = q0 & ~(uint64_t)(EPV - 1);
+    const uint64_t total_elems = in_frames;
+    for (uint32_t v = threadIdx.x; v < span_vecs; v += 256) {
+        const uint64_t e = lo_elem + (uint64_t)v * EPV;
+        if (e + EPV <= total_elems) {
+            reinterpret_cast<ld_t*>(lds)[v] = __builtin_nontemporal_load(reinterpret_cast<const ld_t*>(in + e));
+        } else {
+            for (uint32_t k = 0; k < EPV; ++k) lds[v * EPV + k] = (e + k < total_elems) ? in[e + k] : (short)0;
+        }
+    }
+    __syncthreads();
+    const uint32_t f0 = (threadIdx.x >> 6) * 1024u + 2u * (threadIdx.x & 63u);       // the lane's first frame within the workgroup
+    uint64_t m = m_first + f0;
+    if (m >= out_frames) return;
+    const double half_inv = 0.5 * A.inv_outr;
+    uint32_t R, qe;                                                                   // biased remainder, LDS element index of frame q
+    {
+        const uint32_t tot = r0 + __umul24(f0, A.inr);                                // < 2^29 (f0 < 4096, inr < 65536)
+        const uint32_t dq = (uint32_t)fma((double)tot, A.inv_outr, half_inv);
+        R = tot - dq * A.outr - A.outr;
+        qe = (uint32_t)(q0 - lo_elem) + dq;
+    }
+    const uint32_t t127 = 127u * A.inr;
+    const uint32_t q127 = (uint32_t)fma((double)t127, A.inv_outr, half_inv), r127 = t127 - q127 * A.outr;
+    auto sample = [&](uint32_t qel, uint32_t Rb) -> uint32_t {
+        const uint32_t* l32 = reinterpret_cast<const uint32_t*>(smem) + (qel >> 1);
+        const uint32_t pair = __builtin_amdgcn_alignbit(l32[1], l32[0], qel << 4) ^ 0x80008000u;      // the shift counts modulo 32
+        const uint32_t ua = pair & 0xffffu, ub = pair >> 16;
+        const uint32_t u = (uint32_t)__mul24((int)ub - (int)ua, (int)Rb) + __umul24(ub, A.outr);
+        return (uint32_t)fma((double)u, A.inv_outr, half_inv);                        // floor(u / outr) < 65536, exact (see above)
+    };
+    auto advance = [&](uint32_t& Rb, uint32_t& qel, uint32_t sr, uint32_t sq) {
+        uint32_t Rn;
+        const uint32_t c = __builtin_uadd_overflow(Rb, sr, &Rn) ? 1u : 0u;
+        qel += sq + c;
+        Rb = max(Rn, Rn - A.outr);
+    };
+    if (m_first + 4096 <= out_frames) {                                               // (uniform) every frame of the workgroup exists
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(out + m);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const uint32_t a = sample(qe, R);
+            advance(R, qe, A.step_r, A.step_q);
+            const uint32_t b = sample(qe, R);
+            if (s < 7) advance(R, qe, r127, q127);
+            __builtin_nontemporal_store((a | (b << 16)) ^ 0x80008000u, o32 + 64 * s);
+        }
+        return;
+    }
+    for (int s = 0; s < 8 && m < out_frames; ++s, m += 128) {                         // the last workgroup of the output
+        const uint32_t a = sample(qe, R);
+        advance(R, qe, A.step_r, A.step_q);
+        const uint32_t b = sample(qe, R);
+        advance(R, qe, r127, q127);
+        const uint32_t word = (a | (b << 16)) ^ 0x80008000u;
+        if (m + 1 < out_frames) *reinterpret_cast<uint32_t*>(out + m) = word;
+        else out[m] = (short)(word & 0xffffu);
     }
 }
 
@@ -1222,6 +1331,20 @@ static int resample_launch(const void* in, size_t in_frames, int nch, int width,
                 // 96 -> 44.1 kHz 0.238 vs 0.240): two VALU instructions fewer per sample do not move a kernel whose waves wait on LDS and memory;
                 // kept behind SYNTHHIP_RESAMPLE_PK=1 for the record
                 const bool pk = sh::knobs().resample_pk == 1 && A.outr < 65536u;
+                // 16 frames per thread as two runs of 8 (GROUPS = 2): bit-identical, +0.4 / +2.2 / +4 % on 44.1 -> 48, 96 -> 44.1, 48 -> 44.1 kHz
+                // (tools/resample_split_probe.py, two A/B pairs in one call); SYNTHHIP_RESAMPLE_SPLIT=0 for the single run
+                if (wide && !pk && sh::knobs().resample_lanes == 1) {
+                    hipLaunchKernelGGL(k_resample_mono16, g2, dim3(256), lds_bytes, st, (const short*)in, (short*)out, A,
+                                       (uint64_t)in_frames, (uint64_t)m_end, span_vecs);
+                    SH_CHECK_LAUNCH("k_resample_mono16");
+                    return SH_OK;
+                }
+                if (wide && !pk && sh::knobs().resample_split != 0) {
+                    hipLaunchKernelGGL((k_resample_small<short, 1, 16, false, 2>), g2, dim3(256), lds_bytes, st, (const short*)in, (short*)out, A,
+                                       (uint64_t)in_frames, (uint64_t)m_end, span_vecs);
+                    SH_CHECK_LAUNCH("k_resample_small");
+                    return SH_OK;
+                }
                 if (wide) { if (pk) SH_RMP(short, 1, 16); else SH_RM(short, 1, 16); }
                 else if (width == 2) { if (nch == 1) { if (pk) SH_RMP(short, 1, 8); else SH_RM(short, 1, 8); } else if (nch == 2) SH_RM(short, 2, 4); else SH_RM(short, 4, 2); }
                 else { if (nch == 1) SH_RM(signed char, 1, 8); else if (nch == 2) SH_RM(signed char, 2, 8); else SH_RM(signed char, 4, 4); }

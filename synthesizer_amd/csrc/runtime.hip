@@ -48,6 +48,8 @@ void load_knobs() {
     k.seg_min = num("SYNTHHIP_SEG_MIN", 0);
     k.gen_rows = (int)num("SYNTHHIP_GEN_ROWS", 0);
     k.resample_pk = (int)num("SYNTHHIP_RESAMPLE_PK", -1);
+    k.resample_split = (int)num("SYNTHHIP_RESAMPLE_SPLIT", -1);
+    k.resample_lanes = (int)num("SYNTHHIP_RESAMPLE_LANES", -1);
     k.pool_fill = (int)num("SYNTHHIP_POOL_FILL", -1);
     k.comm_priority = (int)num("SYNTHHIP_COMM_PRIORITY", 0);
     g_knobs = k;

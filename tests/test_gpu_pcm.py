@@ -300,3 +300,40 @@ def test_resample_sharded_float32(gpu):
     want = P.ratecv_f32(x, 96000, 44100)
     got = b"".join(dist.resample_shard(x.tobytes(), 4, 8, 96000, 44100, r, 4, is_float=True)[1] for r in range(4))
     assert np.array_equal(np.frombuffer(got, dtype=np.float32).reshape(-1, 8), want)
+
+
+_RESAMPLE_CHILD = r'''
+import audioop, sys
+sys.path.insert(0, %r)
+import numpy as np
+from synthesizer_amd import _native as N
+N.ensure_init(0)
+L = N.lib()
+rng = np.random.default_rng(11)
+for frames, inr, outr in ((100003, 44100, 48000), (250001, 96000, 44100), (77777, 48000, 44100), (40000, 8000, 48000), (4097, 44100, 48000)):
+    x = rng.integers(-32768, 32768, frames).astype(np.int16)
+    x[:64] = 32767
+    x[64:128] = -32768
+    src = N.DeviceBuffer.from_array(x)
+    nout = L.sh_resample_out_frames(frames, inr, outr)
+    dst = N.DeviceBuffer(nout * 2)
+    N.check(L.sh_resample(src.handle, frames, 1, 2, 0, inr, outr, dst.handle, None))
+    want, _ = audioop.ratecv(x.tobytes(), 2, 1, inr, outr, None)
+    got = dst.download_bytes(nout * 2)
+    assert len(want) == len(got) and got == want, (frames, inr, outr)
+print("ok")
+'''
+
+
+def test_resample_mono16_kernel_variants_vs_live_audioop(gpu):
+    """The 16-bit mono kernels behind SYNTHHIP_RESAMPLE_SPLIT / _LANES / _PK (two runs of 8 frames per thread -- the default --, one
+    run of 16, the frames dealt to the lanes, the packed dot product): each against live audioop.ratecv, tails and extremes included."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("SYNTHHIP_") or k in ("SYNTHHIP_LIB", "SYNTHHIP_DEVICE")}
+    for env in ({}, {"SYNTHHIP_RESAMPLE_SPLIT": "0"}, {"SYNTHHIP_RESAMPLE_LANES": "1"}, {"SYNTHHIP_RESAMPLE_PK": "1"}):
+        p = subprocess.run([sys.executable, "-c", _RESAMPLE_CHILD % str(root)], env=dict(clean, **env), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (env, p.stderr[-2000:])
