@@ -304,3 +304,34 @@ def test_notes_of_every_plain_kind_tile_by_tile(gpu):
             assert rms(got, w) <= RMS_TOL, (block, k)
             assert np.max(np.abs(got - w)) < 2e-6, (block, k, float(np.max(np.abs(got - w))))
         assert N.debug_counters()["tiled_launches"] - before == len(plan)
+
+
+def test_a_table_of_notes_is_the_same_nine_billion_frames_later(gpu):
+    """Shift invariance at positions beyond 2^32 frames (two days into a stream at 48 kHz): a table of notes whose onsets are all K
+    frames later, rendered K frames later, is the table itself bit for bit -- phases and envelopes count from a note's own first
+    frame, tiles and chunk ranges from the launch's; nothing on the way may keep an absolute frame in 32 bits.  Streams of one-second
+    blocks (the lean / general tile kernels) and of 2048-frame chunks (the merged kernel), and the counters say the tile path ran."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    from synthesizer_amd.workloads import staggered_notes
+    voices, gains = staggered_notes(G, 192, SR, seed=4, period=0.5, notes=4)
+    late_by = (2 ** 33 + 12345) / SR
+    late = [G.DelayFilter(v, late_by) for v in voices]
+    K = late[0]._shift
+    assert K > 2 ** 33 and all(v._shift == K for v in late)
+    assert late[5].spec().start_frame == voices[5].spec().start_frame + K
+    a, b = VoiceBank(voices, gains=gains), VoiceBank(late, gains=gains)
+    c0 = N.debug_counters()
+    for blk, count in ((SR, 3), (2048, 12)):
+        for s in range(count):
+            want = a.render(blk, start=s * blk)
+            got = b.render(blk, start=K + s * blk)
+            assert np.array_equal(got, want), (blk, s, float(np.max(np.abs(got - want))))
+            assert np.max(np.abs(want)) > 0.0
+    # a launch across K itself: silence in front of the first onset, then the table's first frames (another launch shape than
+    # the 96-frame render beside it: equal up to the order of the float64 sums)
+    edge, head = np.asarray(b.render(4096, start=K - 4000)).reshape(-1), np.asarray(a.render(96, start=0)).reshape(-1)
+    assert not edge[:8000].any() and np.max(np.abs(edge[8000:].astype(np.float64) - head)) < 1e-7 and head.any()
+    c1 = N.debug_counters()
+    assert c1["tiled_launches"] - c0["tiled_launches"] >= 2 * (3 + 12)
