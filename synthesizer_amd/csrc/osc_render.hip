@@ -730,26 +730,39 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
                 shm::sincos_tab(fma(di0, lfo_d, lfo_a_rel), trig, ls0, lc0);
                 double lc1 = fma(lc0, lrc, -(ls0 * lrs));
                 const double lk2 = lrc + lrc;
-#pragma unroll
-                for (int h = 0; h < FPL; h += 4) {            // four carriers at a time: their table reads are in flight together
-                    constexpr int Q = FPL < 4 ? FPL : 4;
-                    double th[Q], sn[Q], cs[Q];
-#pragma unroll
-                    for (int jj = 0; jj < Q; ++jj) {
-                        const int j = h + jj;
-                        const double Ln = fma(lfo_K, lfo_C0 - lc0, lfo_bias * (startd + (di0 + (double)(j * 64))));
-                        th[jj] = frequency * theta(j) + fma(f_inc, Ln, phase0);
-                        const double lc2 = fma(lk2, lc1, -lc0);
-                        lc0 = lc1;
-                        lc1 = lc2;
-                    }
-                    shm::sincos_tab_n<Q>(th, trig, sn, cs);
-#pragma unroll
-                    for (int jj = 0; jj < Q; ++jj) {
-                        accl[h + jj] = fma(gl, sn[jj], accl[h + jj]);
-                        accr[h + jj] = fma(gr, sn[jj], accr[h + jj]);
-                    }
+                // an LFO without bias (the usual modulator; BASELINE config 3): the linear term of L is 0 * (start + i) = +0, and
+                // fma(K, C0 - cos, +0) IS the rounded product -- three operations per frame less, the same bits.  (The two loops are
+                // written out: behind a lambda the accumulators are no longer scalarised -- they went to LDS and scratch.)
+#define SH_FM_FRAMES(LN_EXPR, THETA_EXPR)                                                                                \
+                _Pragma("unroll")                                                                                        \
+                for (int h = 0; h < FPL; h += 4) {            /* four carriers at a time: their table reads are in flight together */ \
+                    constexpr int Q = FPL < 4 ? FPL : 4;                                                                 \
+                    double th[Q], sn[Q], cs[Q];                                                                          \
+                    _Pragma("unroll")                                                                                    \
+                    for (int jj = 0; jj < Q; ++jj) {                                                                     \
+                        const int j = h + jj;                                                                            \
+                        const double Ln = LN_EXPR;                                                                       \
+                        th[jj] = frequency * (THETA_EXPR) + fma(f_inc, Ln, phase0);                                      \
+                        const double lc2 = fma(lk2, lc1, -lc0);                                                          \
+                        lc0 = lc1;                                                                                       \
+                        lc1 = lc2;                                                                                       \
+                    }                                                                                                    \
+                    shm::sincos_tab_n<Q>(th, trig, sn, cs);                                                              \
+                    _Pragma("unroll")                                                                                    \
+                    for (int jj = 0; jj < Q; ++jj) {                                                                     \
+                        accl[h + jj] = fma(gl, sn[jj], accl[h + jj]);                                                    \
+                        accr[h + jj] = fma(gr, sn[jj], accr[h + jj]);                                                    \
+                    }                                                                                                    \
                 }
+                // (Measured and dropped: the same split by `straddle` -- theta(j) asks it per frame, a uniform branch per frame -- with
+                // the one-piece tile's angle written out: straight-line code, four chains interleaved, and 58.8 instead of 51.6 us
+                // per block of BASELINE config 3.)
+                if (lfo_bias == 0.0) {
+                    SH_FM_FRAMES(lfo_K * (lfo_C0 - lc0), theta(j))
+                } else {
+                    SH_FM_FRAMES(fma(lfo_K, lfo_C0 - lc0, lfo_bias * (startd + (di0 + (double)(j * 64)))), theta(j))
+                }
+#undef SH_FM_FRAMES
                 continue;
             }
             // Sawtooth / Square / Triangle / Pulse at unit amplitude (the amplitude lives in the gains): t in turns, frame by frame
