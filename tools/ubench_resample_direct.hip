@@ -41,15 +41,16 @@ __device__ __forceinline__ void advance(uint32_t& Rb, uint32_t& qel, uint32_t sr
     Rb = max(Rn, Rn - outr);
 }
 
-// (A) as shipped: the workgroup's span through LDS
-__global__ __launch_bounds__(256) void k_staged(const short* __restrict__ in, short* __restrict__ out, Args A, uint32_t span_vecs) {
+// (A) as shipped (WAVES = 4): the workgroup's span through LDS; WAVES = 1 .. 16: the same with 1024 WAVES frames per workgroup
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_staged(const short* __restrict__ in, short* __restrict__ out, Args A, uint32_t span_vecs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef short ld_t __attribute__((ext_vector_type(8)));
-    const uint64_t m_first = (uint64_t)blockIdx.x * 4096;
+    const uint64_t m_first = (uint64_t)blockIdx.x * (1024 * WAVES);
     uint64_t q0; uint32_t r0;
     place(A, m_first, q0, r0);
     const uint64_t lo_elem = q0 & ~7ull;
-    for (uint32_t v = threadIdx.x; v < span_vecs; v += 256)
+    for (uint32_t v = threadIdx.x; v < span_vecs; v += 64 * WAVES)
         reinterpret_cast<ld_t*>(smem)[v] = __builtin_nontemporal_load(reinterpret_cast<const ld_t*>(in + lo_elem + (uint64_t)v * 8));
     __syncthreads();
     const uint32_t f0 = (threadIdx.x >> 6) * 1024u + 2u * (threadIdx.x & 63u);
@@ -134,23 +135,21 @@ int main() {
         size_t nout = (size_t)(((unsigned __int128)(in_frames - 1) * A.outr) / A.inr) + 1;
         nout &= ~(size_t)4095;                                     // whole workgroups only: the tails are not what is measured
         CK(hipMalloc(&oa, nout * 2)); CK(hipMalloc(&ob, nout * 2));
-        const uint64_t span_frames = ((uint64_t)4096 * A.inr + A.outr - 1) / A.outr + 3;
-        const uint32_t span_vecs = (uint32_t)((span_frames + 8 + 7) / 8 + 1);
-        float msa = 0, msb = 0, msb2 = 0;
+        float msa = 0, msb = 0, msb2 = 0, msw[5] = {0, 0, 0, 0, 0};
+        auto spanv = [&](uint32_t frames) { const uint64_t sf = ((uint64_t)frames * A.inr + A.outr - 1) / A.outr + 3; return (uint32_t)((sf + 8 + 7) / 8 + 1); };
+        nout &= ~(size_t)16383;
         for (int rep = 0; rep < 12; ++rep) {
-            CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k_staged, dim3((uint32_t)(nout / 4096)), dim3(256), span_vecs * 16, 0, in, oa, A, span_vecs);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-            float t; CK(hipEventElapsedTime(&t, e0, e1)); if (rep >= 4 && (msa == 0 || t < msa)) msa = t;
-            CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k_direct<4>, dim3((uint32_t)(nout / 4096)), dim3(256), 0, 0, in, ob, A);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-            CK(hipEventElapsedTime(&t, e0, e1)); if (rep >= 4 && (msb == 0 || t < msb)) msb = t;
-            CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k_direct<1>, dim3((uint32_t)(nout / 1024)), dim3(64), 0, 0, in, ob, A);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-            CK(hipEventElapsedTime(&t, e0, e1)); if (rep >= 4 && (msb2 == 0 || t < msb2)) msb2 = t;
+            float t;
+#define TIME(DST, ...) CK(hipEventRecord(e0)); __VA_ARGS__; CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&t, e0, e1)); if (rep >= 4 && (DST == 0 || t < DST)) DST = t;
+            TIME(msa, hipLaunchKernelGGL(k_staged<4>, dim3((uint32_t)(nout / 4096)), dim3(256), spanv(4096) * 16, 0, in, oa, A, spanv(4096)))
+            TIME(msb, hipLaunchKernelGGL(k_direct<4>, dim3((uint32_t)(nout / 4096)), dim3(256), 0, 0, in, ob, A))
+            TIME(msb2, hipLaunchKernelGGL(k_direct<1>, dim3((uint32_t)(nout / 1024)), dim3(64), 0, 0, in, ob, A))
+            TIME(msw[0], hipLaunchKernelGGL(k_staged<1>, dim3((uint32_t)(nout / 1024)), dim3(64), spanv(1024) * 16, 0, in, ob, A, spanv(1024)))
+            TIME(msw[1], hipLaunchKernelGGL(k_staged<2>, dim3((uint32_t)(nout / 2048)), dim3(128), spanv(2048) * 16, 0, in, ob, A, spanv(2048)))
+            TIME(msw[2], hipLaunchKernelGGL(k_staged<8>, dim3((uint32_t)(nout / 8192)), dim3(512), spanv(8192) * 16, 0, in, ob, A, spanv(8192)))
+            TIME(msw[3], hipLaunchKernelGGL(k_staged<16>, dim3((uint32_t)(nout / 16384)), dim3(1024), spanv(16384) * 16, 0, in, ob, A, spanv(16384)))
         }
+        printf("   staged with 1 / 2 / 8 / 16 waves per workgroup: %.3f / %.3f / %.3f / %.3f ms\n", msw[0], msw[1], msw[2], msw[3]);
         CK(hipMemset(bad, 0, 8));
         hipLaunchKernelGGL(k_diff, dim3(4096), dim3(256), 0, 0, (const uint32_t*)oa, (const uint32_t*)ob, nout / 2, bad);
         unsigned long long hb = 0;
