@@ -163,8 +163,7 @@ def _with(sp: VoiceSpec, **changes) -> VoiceSpec:
     """A copy of `sp` with some fields changed (dataclasses.replace re-runs __init__ with introspection: 10 us per call, two calls per
     note of a table of notes)."""
     new = VoiceSpec.__new__(VoiceSpec)
-    new.__dict__.update(sp.__dict__)
-    new.__dict__.update(changes)
+    new.__dict__ = {**sp.__dict__, **changes}
     return new
 
 
@@ -632,7 +631,7 @@ class Harmonics(_Carrier):
     def _make_spec(self) -> VoiceSpec:
         # (the three forms of a harmonic list depend on the list alone: a table of notes shares a handful of lists among thousands
         # of voices)
-        poly, dense, sparse = _harmonic_forms(tuple((k, a) for k, a in self.harmonics))
+        poly, dense, sparse = _harmonic_forms(tuple(map(tuple, self.harmonics)))
         return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias),
                          harm_poly=poly, harm_dense=dense, harm_sparse=sparse, **self._phase_fields())
 

@@ -207,3 +207,17 @@ def test_staggered_notes_workload_and_onset_records():
     packed = pack_voices(specs, gg)
     voices = packed[0]
     assert [int(x) for x in voices["start_frame"]] == onsets
+
+
+def test_every_module_of_the_package_imports_and_compiles():
+    """A syntax error in a module only the GPU tests import would otherwise wait for the GPU box: compile every source of the
+    package and the root scripts, and import the package's modules (importing loads no library and touches no device)."""
+    import importlib
+    import py_compile
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    files = sorted((root / "synthesizer_amd").glob("*.py")) + [root / "bench.py", root / "__graft_entry__.py"] + sorted((root / "tools").glob("*.py"))
+    for f in files:
+        py_compile.compile(str(f), doraise=True)
+    for name in ("_native", "build", "dist", "mixer", "oscillators", "params", "phasetable", "sample", "synth", "workloads"):
+        importlib.import_module("synthesizer_amd." + name)
