@@ -34,55 +34,55 @@ N_LIMIT = 1 << 62
 _TINY = 2.0 ** -1000
 
 
-def _binade(x: float) -> int:
-    """Signed binade id; 0 for zero/tiny values (never part of a run)."""
-    if x == 0.0 or abs(x) < _TINY:
-        return 0
-    e = frexp(x)[1]
-    return (e + 2000) if x > 0 else -(e + 2000)
-
-
-def _mant(x: float) -> Tuple[int, int]:
-    """x = M * 2**s with 2^52 <= |M| < 2^53 (normal x)."""
-    m, e = frexp(x)
-    return int(ldexp(m, 53)), e - 53
+_LO, _HI = 1 << 52, (1 << 53) - 1
+_MAX_PIECES = 1 << 16
 
 
 def build_phase_table(t0: float, inc: float, n_limit: int = N_LIMIT) -> List[Segment]:
-    """Pieces of the sequence t_0 = t0, t_{n+1} = fl(t_n + inc), covering [0, n_limit)."""
+    """Pieces of the sequence t_0 = t0, t_{n+1} = fl(t_n + inc), covering [0, n_limit).
+    (The binade tests are written out as comparisons against the binade's bounds: this loop is most of what creating a bank costs
+    on the host -- 150 pieces per distinct (phase, frequency) -- and calls of Python helpers were most of the loop.)"""
     segs: List[Segment] = []
+    append = segs.append
     n, t = 0, float(t0)
     inc = float(inc)
     while n < n_limit:
         t1 = t + inc
         if t1 == t:                       # inc == 0, or absorbed below half an ulp: constant forever
-            segs.append((n, t, 0.0))
+            append((n, t, 0.0))
             break
-        b = _binade(t)
-        if b != 0 and _binade(t1) == b:
-            t2 = t1 + inc
-            d = t1 - t                    # exact: same binade
-            if _binade(t2) == b and (t2 - t1) == d:
-                # regular run: t + j*d for j = 0..k stays inside the binade
-                T, s = _mant(t)
-                # d in units of 2**s: d is a multiple of the binade's ulp and |d| < 2**(s + 53), so the scaling is exact
-                D = int(ldexp(d, -s))
-                lo, hi = 1 << 52, (1 << 53) - 1
-                if T > 0:
-                    k = (hi - T) // D if D > 0 else (T - lo) // (-D)
-                else:
-                    k = (hi + T) // (-D) if D < 0 else (-T - lo) // D
-                segs.append((n, t, d))
-                tk = ldexp(float(T + k * D), s)       # exact: |T + k*D| < 2^53
-                t1 = tk + inc                          # the step out of the binade: a real addition
-                if t1 == tk:
-                    segs.append((n + k, tk, 0.0))
-                    break
-                n, t = n + k + 1, t1
-                continue
+        if t >= _TINY or t <= -_TINY:     # (zero and tiny values are never part of a run)
+            m, e = frexp(t)
+            hi = ldexp(1.0, e)            # the binade of t: lo <= |x| < hi, with t's sign
+            lo = 0.5 * hi
+            pos = t > 0
+            if (lo <= t1 < hi) if pos else (-hi < t1 <= -lo):
+                t2 = t1 + inc
+                d = t1 - t                # exact: same binade
+                if ((lo <= t2 < hi) if pos else (-hi < t2 <= -lo)) and (t2 - t1) == d:
+                    # regular run: t + j*d for j = 0..k stays inside the binade.  t = T * 2**s with 2^52 <= |T| < 2^53;
+                    # d in units of 2**s: d is a multiple of the binade's ulp and |d| < 2**(s + 53), so the scaling is exact
+                    s = e - 53
+                    T = int(ldexp(m, 53))
+                    D = int(ldexp(d, -s))
+                    if T > 0:
+                        k = (_HI - T) // D if D > 0 else (T - _LO) // (-D)
+                    else:
+                        k = (_HI + T) // (-D) if D < 0 else (-T - _LO) // D
+                    append((n, t, d))
+                    tk = ldexp(float(T + k * D), s)       # exact: |T + k*D| < 2^53
+                    t1 = tk + inc                          # the step out of the binade: a real addition
+                    if t1 == tk:
+                        append((n + k, tk, 0.0))
+                        break
+                    n, t = n + k + 1, t1
+                    continue
         # single step (entering/leaving a binade, crossing zero, irregular first step)
-        segs.append((n, t, t1 - t))
+        append((n, t, t1 - t))
         n, t = n + 1, t1
+        if len(segs) > _MAX_PIECES:
+            # (a denormal increment from a denormal start walks 2^70 single steps below the smallest binade this table keeps)
+            raise OverflowError("phase table of t0=%r, increment=%r does not close: the increment is denormal" % (t0, inc))
     return segs
 
 

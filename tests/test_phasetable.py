@@ -71,6 +71,14 @@ def test_constant_sequences():
     assert build_phase_table(1.0, 1e-30)[-1][2] == 0.0
 
 
+def test_a_denormal_walk_is_refused_not_followed():
+    """From 0 in steps of 5e-324 the sequence needs 2^74 single steps to reach the smallest binade the table keeps as a run: an
+    error, not a loop that eats the machine (a frequency of 1e-320 Hz is a typing mistake, not a patch)."""
+    with pytest.raises(OverflowError):
+        build_phase_table(0.0, 5e-324)
+    assert len(build_phase_table(0.0, 1e-290)) < 2500          # (tiny but normal: a piece or two per binade on the way up)
+
+
 def test_property_random_sequences():
     """Randomised check (seeded): any (t0, inc) -- negative, tiny, huge, zero-crossing -- is reproduced."""
     rng = random.Random(20260926)
