@@ -1,4 +1,4 @@
-"""Build libsynthhip.so (hipcc, gfx950) in-tree.
+"""Build libsynthhip.so (hipcc, gfx950) and libsynthhost.so (g++, host-side table building) in-tree.
 
     python -m synthesizer_amd.build [--force]
 
@@ -100,6 +100,52 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
+# ---- libsynthhost.so: host-side table building in native code (include/synthhost.h; plain C++, no HIP) ----------------------
+HOST_LIB = HERE / "libsynthhost.so"
+HOST_SOURCES = ["host_tables.cpp"]
+HOST_HEADERS = ["../../include/synthhost.h"]
+CXX = os.environ.get("CXX", "g++")
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall"]
+
+
+def host_source_hash() -> str:
+    h = hashlib.sha256()
+    for f in [CSRC / s for s in HOST_SOURCES] + [(CSRC / x).resolve() for x in HOST_HEADERS]:
+        h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
+    h.update(" ".join(HOST_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def host_built_hash() -> str:
+    if not HOST_LIB.exists():
+        return ""
+    m = re.search(rb"synthhost [0-9.]+ src:([0-9a-f]{16})", HOST_LIB.read_bytes())
+    return m.group(1).decode() if m else ""
+
+
+def build_host(force: bool = False, verbose: bool = False) -> Path:
+    """Compile libsynthhost.so when it is missing or its embedded source hash differs from the tree's (a second or two of g++)."""
+    if not force and host_built_hash() == host_source_hash():
+        return HOST_LIB
+    import fcntl
+    with open(HERE / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or host_built_hash() != host_source_hash():
+            tmp = HOST_LIB.with_suffix(".so.tmp%d" % os.getpid())
+            cmd = [CXX] + HOST_FLAGS + ['-DSHH_SOURCE_HASH="%s"' % host_source_hash()] + [str(CSRC / s) for s in HOST_SOURCES] + ["-o", str(tmp)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, HOST_LIB)
+            finally:
+                if tmp.exists():
+                    tmp.unlink()
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_host(force="--force" in sys.argv, verbose=True)
     print(LIB)
+    print(HOST_LIB)

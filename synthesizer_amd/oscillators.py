@@ -183,9 +183,7 @@ def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float
         nonlocal nsegs
         key = id(tab)
         if key not in seg_index:
-            arr = np.zeros(len(tab.segments), dtype=N.SEGMENT_DTYPE)
-            for i, (n0, t0, dt) in enumerate(tab.segments):
-                arr[i] = (n0, t0, dt)
+            arr = tab.records                       # (the C layout already: phasetable.phase_table_records)
             seg_index[key] = (nsegs, len(arr))
             seg_chunks.append(arr)
             nsegs += len(arr)

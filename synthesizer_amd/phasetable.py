@@ -19,14 +19,18 @@ what decides the side of a Square/Pulse edge and the 1e-5 rad drift of a
 long-running Sine.
 
 Host logic only.  tests/test_phasetable.py checks the table against brute-force
-accumulation.
+accumulation, and the native form of the same loop (libsynthhost.so, include/synthhost.h:
+what a PhaseTable is built by when the library can be had) against this one.
 """
 from __future__ import annotations
 
+import ctypes as C
 from bisect import bisect_right
 from fractions import Fraction
 from math import frexp, ceil, ldexp
-from typing import List, Tuple
+from typing import List, Optional, Tuple
+
+import numpy as np
 
 Segment = Tuple[int, float, float]      # (n0, t0, dt): t_n = t0 + (n-n0)*dt exactly, n0 <= n < next n0
 
@@ -86,17 +90,94 @@ def build_phase_table(t0: float, inc: float, n_limit: int = N_LIMIT) -> List[Seg
     return segs
 
 
+# ---- the same loop in native code (libsynthhost.so, include/synthhost.h): ~2 us per table instead of ~110 ------------------------
+_SEGMENT_DTYPE = np.dtype([("n0", "<u8"), ("t0", "<f8"), ("dt", "<f8")], align=True)      # = _native.SEGMENT_DTYPE = shh_segment
+_host = None           # None: not tried yet; False: unavailable (the Python loop is used, said once); else the CDLL
+
+
+def _host_lib():
+    global _host
+    if _host is None:
+        try:
+            from . import build as B
+            lib = C.CDLL(str(B.build_host()))
+            lib.shh_phase_table.restype = C.c_int
+            lib.shh_phase_table.argtypes = [C.c_double, C.c_double, C.c_uint64, C.c_void_p, C.c_int]
+            lib.shh_version.restype = C.c_char_p
+            _host = lib
+        except Exception as exc:      # no compiler, a read-only tree ...: host logic has a tested Python statement to fall back on
+            import warnings
+            warnings.warn("libsynthhost.so unavailable (%s): phase tables are built by the Python loop" % (exc,))
+            _host = False
+    return _host
+
+
+def phase_table_records(t0: float, inc: float, n_limit: int = N_LIMIT) -> np.ndarray:
+    """The pieces of build_phase_table as an array of (n0, t0, dt) records in the C layout, from the native loop when the host
+    library can be had (identical pieces: tests/test_phasetable.py), else from the Python one."""
+    lib = _host_lib()
+    if lib:
+        cap = 256
+        while True:
+            out = np.empty(cap, dtype=_SEGMENT_DTYPE)
+            cnt = lib.shh_phase_table(float(t0), float(inc), min(int(n_limit), (1 << 64) - 1), out.ctypes.data, cap)
+            if cnt >= 0:
+                return out[:cnt].copy()
+            if cnt == -2 or cap > (1 << 17):
+                raise OverflowError("phase table of t0=%r, increment=%r does not close: the increment is denormal" % (t0, inc))
+            cap *= 16
+    segs = build_phase_table(t0, inc, n_limit)
+    out = np.empty(len(segs), dtype=_SEGMENT_DTYPE)
+    for i, seg in enumerate(segs):
+        out[i] = seg
+    return out
+
+
 class PhaseTable:
-    """Host-side view used for envelope boundaries and by the tests."""
+    """Host-side view used for envelope boundaries, by the packing of a bank's tables (`records`) and by the tests."""
 
     def __init__(self, t0: float, inc: float, n_limit: int = N_LIMIT) -> None:
         self.t0 = float(t0)
         self.inc = float(inc)
-        self.segments = build_phase_table(t0, inc, n_limit)
-        self._starts = [s[0] for s in self.segments]
+        self._records: Optional[np.ndarray] = phase_table_records(t0, inc, n_limit)
+        self._segments: Optional[List[Segment]] = None
+        self._starts_cache: Optional[List[int]] = None
+
+    @property
+    def records(self) -> np.ndarray:
+        """(n0, t0, dt) records in the C layout (sh_segment)."""
+        if self._records is None:
+            out = np.empty(len(self._segments), dtype=_SEGMENT_DTYPE)
+            for i, seg in enumerate(self._segments):
+                out[i] = seg
+            self._records = out
+        return self._records
+
+    @property
+    def segments(self) -> List[Segment]:
+        if self._segments is None:
+            r = self._records
+            self._segments = list(zip(r["n0"].tolist(), r["t0"].tolist(), r["dt"].tolist()))
+        return self._segments
+
+    @segments.setter
+    def segments(self, value: List[Segment]) -> None:
+        self._segments = list(value)
+        self._records = None
+        self._starts_cache = None
+
+    @property
+    def _starts(self) -> List[int]:
+        if self._starts_cache is None:
+            self._starts_cache = [s[0] for s in self.segments]
+        return self._starts_cache
+
+    @_starts.setter
+    def _starts(self, value: List[int]) -> None:
+        self._starts_cache = list(value)
 
     def __len__(self) -> int:
-        return len(self.segments)
+        return len(self._records) if self._records is not None else len(self._segments)
 
     def value(self, n: int) -> float:
         """t_n, exactly (what the sequential loop holds when it emits sample n)."""

@@ -91,3 +91,26 @@ def test_product_never_imports_the_oracle():
         assert "import oracle" not in text and "from oracle" not in text, py
     for src in (ROOT / "synthesizer_amd" / "csrc").iterdir():
         assert "oracle" not in src.read_text().replace("the oracle", ""), src
+
+
+def test_host_library_exports_what_its_header_declares(tmp_path):
+    """include/synthhost.h / libsynthhost.so (host-side table building, plain C++): every declared function is exported, the header
+    is plain C, and shh_segment has sh_segment's layout -- the records go into a bank's table of pieces as they are."""
+    from synthesizer_amd import build as B
+    from synthesizer_amd import _native as N
+    header = ROOT / "include" / "synthhost.h"
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(shh_[a-z0-9_]+)\s*\(", text)))
+    assert names == ["shh_phase_table", "shh_version"]
+    lib = ctypes.CDLL(str(B.build_host()))
+    assert all(hasattr(lib, n) for n in names)
+    lib.shh_version.restype = ctypes.c_char_p
+    assert lib.shh_version().decode() == "synthhost 0.1 src:" + B.host_source_hash()
+    src = tmp_path / "sz.c"
+    src.write_text('#include "%s"\n#include "%s"\n#include <stdio.h>\n#include <stddef.h>\n'
+                   'int main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(shh_segment), sizeof(sh_segment), offsetof(shh_segment, t0),'
+                   'offsetof(sh_segment, t0), offsetof(shh_segment, dt), offsetof(sh_segment, dt));return 0;}\n' % (header, HEADER))
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c99", str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [24, 24, 8, 8, 16, 16] and N.SEGMENT_DTYPE.itemsize == 24

@@ -101,3 +101,46 @@ def test_property_random_sequences():
         pt = PhaseTable(t0, inc)
         for i in [0, 1, 2, 3, 5, 17, 100, 1023, 1024, 4095, n - 1] + [rng.randrange(n) for _ in range(40)]:
             assert pt.value(i) == ref[i], (t0, inc, i)
+
+
+def test_native_builder_gives_the_python_builders_pieces():
+    """libsynthhost.so (include/synthhost.h, csrc/host_tables.cpp) is the same loop in C++: identical pieces -- n0, t0 and dt bit
+    for bit -- on audio-shaped and on adversarial sequences, a table that needs a bigger buffer than the first try, the refusal of a
+    denormal walk; and the library is really there (a silent fallback to the Python loop would make this test vacuous)."""
+    from synthesizer_amd import phasetable as PT
+    lib = PT._host_lib()
+    assert lib, "libsynthhost.so was not built / loaded"
+    assert lib.shh_version().decode().startswith("synthhost ")
+    rng = random.Random(99)
+    cases = list(CASES)
+    for i in range(3000):
+        k = i % 7
+        if k == 0:
+            cases.append((rng.uniform(-10, 10), rng.uniform(-1, 1)))
+        elif k == 1:
+            cases.append((rng.uniform(0, 1), rng.uniform(20, 20000) / rng.choice([8000, 44100, 48000, 96000])))
+        elif k == 2:
+            cases.append((rng.uniform(0, 1) * 2 * math.pi, 2 * math.pi * rng.uniform(20, 20000) / 48000))
+        elif k == 3:
+            cases.append((0.0, 10.0 ** rng.uniform(-25, 5)))
+        elif k == 4:
+            cases.append((rng.uniform(-1e6, 1e6), rng.uniform(-1e3, 1e3)))
+        elif k == 5:
+            cases.append((rng.uniform(-1, 1) * 10.0 ** rng.uniform(-280, 280), rng.uniform(-1, 1) * 10.0 ** rng.uniform(-280, 280)))
+        else:
+            cases.append((float(rng.randrange(-5, 5)), rng.choice([0.0, 0.5, 0.25, 1.0, -1.0, 1 / 3, 2.0 ** -30, 1e-200])))
+    for t0, inc in cases:
+        want = build_phase_table(t0, inc)
+        rec = PT.phase_table_records(t0, inc)
+        got = list(zip(rec["n0"].tolist(), rec["t0"].tolist(), rec["dt"].tolist()))
+        assert got == want, (t0, inc)
+        assert [math.copysign(1.0, g[1]) for g in got] == [math.copysign(1.0, w[1]) for w in want]      # (-0.0 is 0.0 to ==)
+    small = np.empty(8, dtype=PT._SEGMENT_DTYPE)                             # a buffer too small: -1, not an overrun
+    assert lib.shh_phase_table(0.0, 440 / 48000, 1 << 62, small.ctypes.data, 8) == -1
+    assert PT.phase_table_records(0.0, 1e-290).tolist() == [tuple(s) for s in build_phase_table(0.0, 1e-290)]
+    with pytest.raises(OverflowError):
+        PT.phase_table_records(0.0, 5e-324)
+    # a limited table, and the view a PhaseTable gives of its records
+    assert PT.phase_table_records(0.3, 0.01, 1000).tolist() == [tuple(s) for s in build_phase_table(0.3, 0.01, 1000)]
+    pt = PhaseTable(0.25, 440 / 48000)
+    assert pt.segments == build_phase_table(0.25, 440 / 48000) and len(pt) == len(pt.segments) == len(pt.records)
