@@ -104,6 +104,8 @@ def oscillator_cases(quick: bool):
         ("Envelope ADSR", lambda m: m.EnvelopeFilter(m.Sine(440.0, samplerate=sr), 0.01, 0.02, 0.03, 0.6, 0.02)),
         ("Envelope stop_at_end", lambda m: m.EnvelopeFilter(m.Square(440.0, samplerate=sr), 0.005, 0.0, 0.01, 0.5, 0.01, stop_at_end=True)),
         ("Envelope no release", lambda m: m.EnvelopeFilter(m.Sawtooth(440.0, samplerate=sr), 0.0, 0.01, 0.02, 0.7, 0.0)),
+        # (SURVEY 8(a) row a8 recalls `cycle=False` in the signature: if the real class has no such keyword this case reports it)
+        ("Envelope cycle", lambda m: m.EnvelopeFilter(m.Sine(440.0, samplerate=sr), 0.005, 0.005, 0.01, 0.5, 0.01, cycle=True)),
         ("MixingFilter", lambda m: m.MixingFilter(m.Sine(440.0, 0.4, samplerate=sr), m.Square(220.0, 0.3, samplerate=sr), m.Triangle(110.0, 0.2, samplerate=sr))),
         ("AmpModulationFilter", lambda m: m.AmpModulationFilter(m.Sine(440.0, samplerate=sr), m.Sine(3.0, 0.5, bias=0.5, samplerate=sr))),
         ("ClipFilter", lambda m: m.ClipFilter(m.Sine(440.0, samplerate=sr), -0.3, 0.6)),
