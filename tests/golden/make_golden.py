@@ -121,6 +121,7 @@ def osc_vectors():
     out["harm"] = np.array(O.Harmonics(220, [(k, 1.0 / k) for k in range(1, 17)], 0.5, samplerate=sr).take(2048))
     out["fm_sine"] = np.array(O.Sine(440, fm_lfo=O.Sine(5, 0.03, samplerate=sr), samplerate=sr).take(2048))
     out["adsr"] = np.array(O.EnvelopeFilter(O.Sine(440, samplerate=sr), 0.01, 0.01, 0.01, 0.6, 0.01).take(2048))
+    out["adsr_cycle"] = np.array(O.EnvelopeFilter(O.Sine(440, samplerate=sr), 0.004, 0.003, 0.005, 0.6, 0.006, cycle=True).take(2048))
     out["quant"] = np.array(O.quantise(out["harm"] * 0.5), dtype=np.int16)
     np.savez_compressed(OUT / "osc_misc.npz", **out)
 

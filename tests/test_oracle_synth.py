@@ -19,6 +19,7 @@ def test_golden_vectors_reproduce():
     assert np.array_equal(g["harm"], O.Harmonics(220, [(k, 1.0 / k) for k in range(1, 17)], 0.5, samplerate=sr).take(2048))
     assert np.array_equal(g["fm_sine"], O.Sine(440, fm_lfo=O.Sine(5, 0.03, samplerate=sr), samplerate=sr).take(2048))
     assert np.array_equal(g["adsr"], O.EnvelopeFilter(O.Sine(440, samplerate=sr), 0.01, 0.01, 0.01, 0.6, 0.01).take(2048))
+    assert np.array_equal(g["adsr_cycle"], O.EnvelopeFilter(O.Sine(440, samplerate=sr), 0.004, 0.003, 0.005, 0.6, 0.006, cycle=True).take(2048))
     assert np.array_equal(g["quant"], O.quantise(g["harm"] * 0.5))
     s = np.array(O.Sine(440, samplerate=44100).take(44100))
     assert np.array_equal(np.load("tests/golden/osc_sine440_44k1.npy"), s[np.r_[0:4096, 40004:44100]])
