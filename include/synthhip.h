@@ -151,6 +151,11 @@ int  sh_device_count(void);               /* 0 when no GPU is visible; never fai
 int  sh_device_info(sh_devinfo* out);
 const char* sh_last_error(void);
 const char* sh_version(void);
+/* The binary interface this library was compiled with, so that a binding can refuse a library whose structs it would mis-pack
+ * (a stale .so loaded by path: same symbols, other layouts): out[0] = SH_ABI_VERSION, then sizeof of sh_segment, sh_partial,
+ * sh_envelope, sh_voice, sh_devinfo, sh_counters.  Writes min(n, 7) words, returns 7.  Callable before sh_init, without a GPU. */
+#define SH_ABI_VERSION 4
+int  sh_abi(uint32_t* out, int n);
 int  sh_sync(void);                       /* wait for the stream */
 
 /* What the library did behind the caller's back since sh_init: driver allocations (hipMalloc: pool misses, growing blocks),

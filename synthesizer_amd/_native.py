@@ -77,6 +77,7 @@ _SIGNATURES = {
     "sh_device_info": (C.c_int, [C.POINTER(DevInfo)]),
     "sh_last_error": (C.c_char_p, []),
     "sh_version": (C.c_char_p, []),
+    "sh_abi": (C.c_int, [C.POINTER(C.c_uint32), C.c_int]),
     "sh_sync": (C.c_int, []),
     "sh_debug_counters": (C.c_int, [C.POINTER(Counters)]),
     "sh_buf_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
@@ -152,8 +153,41 @@ _SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 
 
+SH_ABI_VERSION = 4           # include/synthhip.h; bumped with every change of a struct layout or of an entry point's meaning
+
+
+class NativeLibraryStale(ImportError):
+    pass
+
+
+def _abi_expected() -> list:
+    return [SH_ABI_VERSION, SEGMENT_DTYPE.itemsize, PARTIAL_DTYPE.itemsize, ENVELOPE_DTYPE.itemsize, VOICE_DTYPE.itemsize,
+            C.sizeof(DevInfo), C.sizeof(Counters)]
+
+
+def _check_abi(handle: C.CDLL, path) -> None:
+    """Refuse a library whose view of the structs differs from this binding's: Python would pack records it misreads."""
+    if not hasattr(handle, "sh_abi"):
+        raise NativeLibraryStale("%s exports no sh_abi: it predates this binding (ABI %d); rebuild it with "
+                                 "`python -m synthesizer_amd.build`" % (path, SH_ABI_VERSION))
+    handle.sh_abi.restype = C.c_int
+    handle.sh_abi.argtypes = [C.POINTER(C.c_uint32), C.c_int]
+    got = (C.c_uint32 * 7)()
+    n = handle.sh_abi(got, 7)
+    want = _abi_expected()
+    if n != 7 or list(got) != want:
+        raise NativeLibraryStale("%s was built for another binary interface: (ABI, sizeof sh_segment, sh_partial, sh_envelope, sh_voice, "
+                                 "sh_devinfo, sh_counters) = %s, this binding packs %s; rebuild it with `python -m synthesizer_amd.build`"
+                                 % (path, list(got), want))
+
+
 def lib() -> C.CDLL:
-    """Load libsynthhip.so (CDLL: the GIL is released around every call)."""
+    """Load libsynthhip.so (CDLL: the GIL is released around every call).
+
+    The in-tree library is rebuilt when its embedded source hash differs from the tree's.  A stale library is only ever loaded
+    when the COMPILER is absent (a shipped .so on a box without hipcc) or SYNTHHIP_ALLOW_STALE=1 says so -- a tree that no longer
+    compiles is an error, not a reason to run old code -- and in every case the library's binary interface (sh_abi: version and
+    struct sizes) must be this binding's."""
     global _lib
     if _lib is None:
         if "SYNTHHIP_LIB" not in os.environ:
@@ -165,15 +199,21 @@ def lib() -> C.CDLL:
                     raise NativeLibraryMissing(
                         "%s not found and building it failed (%s): run `python -m synthesizer_amd.build` "
                         "(hipcc, gfx950).  There is no CPU fallback." % (LIB_PATH, exc))
+                no_compiler = isinstance(exc, FileNotFoundError) and not Path(_build.HIPCC).exists()
+                if not (no_compiler or os.environ.get("SYNTHHIP_ALLOW_STALE") == "1"):
+                    raise NativeLibraryStale(
+                        "%s is stale (built from sources %s, the tree is %s) and rebuilding it FAILED (%s).  Fix the build, or set "
+                        "SYNTHHIP_ALLOW_STALE=1 to load the old library knowingly." % (LIB_PATH, _build.built_hash() or "?", _build.source_hash(), exc))
                 # a shipped library on a box without the compiler: use it, but say that it is not what the tree describes
                 import warnings
-                warnings.warn("%s is stale (built from sources %s, the tree is %s) and rebuilding it failed (%s): loading it as it is"
+                warnings.warn("%s is stale (built from sources %s, the tree is %s) and cannot be rebuilt here (%s): loading it as it is"
                               % (LIB_PATH, _build.built_hash() or "?", _build.source_hash(), exc), RuntimeWarning)
         if not LIB_PATH.exists():
             raise NativeLibraryMissing(
                 "%s not found: build it with `python -m synthesizer_amd.build` (hipcc, gfx950). "
                 "There is no CPU fallback." % LIB_PATH)
         handle = C.CDLL(str(LIB_PATH))
+        _check_abi(handle, LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             if "SYNTHHIP_LIB" in os.environ and not hasattr(handle, name):
                 continue                    # an older build named for an A/B timing (tools/): what it lacks cannot be called

@@ -88,6 +88,7 @@ struct Knobs {
     int  resample_lanes = -1;      // SYNTHHIP_RESAMPLE_LANES=0|1: 16-bit mono resample with the frames dealt to the lanes (k_resample_mono16)
     int  resample_split = -1;      // SYNTHHIP_RESAMPLE_SPLIT=0|1: 16-bit mono resample, a thread's 16 frames as two runs of 8 (stores of consecutive lanes adjoin)
     int  comm_priority = 0;        // SYNTHHIP_COMM_PRIORITY=-1|0|1: priority of the communication stream (high / as the render streams / low)
+    long lds_pad = 0;              // SYNTHHIP_LDS_PAD: bytes of unused dynamic LDS per workgroup of the plain render launch (occupancy experiments)
     int  pool_fill = -1;           // SYNTHHIP_POOL_FILL=0..255: blocks that grow are filled with this byte first (diagnostics)
 };
 const Knobs& knobs();

@@ -1000,11 +1000,57 @@ __device__ __forceinline__ uint32_t pcm16_frame(double l, double r, double scale
 // ulp worst case, ~2 ulp typically); the rounding of k2 itself shifts the step angle by <= 1.1e-16 / |sin(64 dt)| per
 // step: below 1e-9 relative for all but ~1e-6 of voices, orders of magnitude inside the 1e-6 RMS contract in any case.
 // SLOPED (segmented transition launches): the gains follow the envelope's line, gl + i * gls at the lane's frame i = dl + 64 j.
+#ifndef SH_LEAN_CH
+#define SH_LEAN_CH 4        // Horner chains of the lean Harmonics arithmetic in flight per wavefront (2: the pairs of rounds 2 and 3)
+#endif
 template <int FPL, bool SLOPED = false, typename Theta>
 __device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1, double c1, double k2, bool straddle, Theta theta,
                                                  TrigTab trig, const double (&poly)[16], double gl, double gr,
                                                  double (&accl)[FPL], double (&accr)[FPL],
                                                  double gls = 0.0, double grs = 0.0, double dl = 0.0) {
+    if constexpr (SH_LEAN_CH > 2 && FPL % SH_LEAN_CH == 0) {
+        // Round 4.  A float64 FMA's result is not there for the next instruction but one: with TWO chains per wavefront (the pairs
+        // below) a wavefront alone on its SIMD fills ~40 % of the FMA pipe, and the oldest wavefront of a SIMD is served first -- so
+        // a launch ended with SIMDs that held one or two wavefronts limping (profiles/r04_headline_phases.md: the voice loop of
+        // the last-dispatched voice groups took 41 us where the first took 26).  Same operations per frame, in the same order
+        // (bit-identical results): the sines and cosines of all frames first, then the Horner chains SH_LEAN_CH at a time.
+        double s[FPL], c[FPL];
+        s[0] = s0; c[0] = c0; s[1] = s1; c[1] = c1;
+        if (straddle) {
+#pragma unroll
+            for (int j = 2; j < FPL; ++j) shm::sincos_tab(theta(j), trig, s[j], c[j]);
+        } else {
+#pragma unroll
+            for (int j = 2; j < FPL; ++j) {
+                s[j] = fma(k2, s[j - 1], -s[j - 2]);
+                c[j] = fma(k2, c[j - 1], -c[j - 2]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < FPL; h += SH_LEAN_CH) {
+            double p[SH_LEAN_CH];
+#pragma unroll
+            for (int jj = 0; jj < SH_LEAN_CH; ++jj) p[jj] = fma(poly[0], c[h + jj], poly[1]);
+#pragma unroll
+            for (int u = 2; u < 16; ++u) {
+#pragma unroll
+                for (int jj = 0; jj < SH_LEAN_CH; ++jj) p[jj] = fma(p[jj], c[h + jj], poly[u]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < SH_LEAN_CH; ++jj) {
+                const double x = p[jj] * s[h + jj];
+                if (SLOPED) {
+                    const double ij = dl + (double)((h + jj) * 64);
+                    accl[h + jj] = fma(fma(ij, gls, gl), x, accl[h + jj]);
+                    accr[h + jj] = fma(fma(ij, grs, gr), x, accr[h + jj]);
+                } else {
+                    accl[h + jj] = fma(gl, x, accl[h + jj]);
+                    accr[h + jj] = fma(gr, x, accr[h + jj]);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < FPL; h += 2) {
         const bool two = h + 1 < FPL;                 // compile-time after unrolling (FPL = 1: a single frame)

@@ -55,6 +55,35 @@ constexpr bool mode_seg(int mode) { return mode == RENDER_LEAN_HARM_SEG || mode 
 constexpr bool mode_has_lean(int mode) { return mode != RENDER_DIRECT && !mode_general(mode); }
 constexpr uint32_t GEN_SPLIT = 2;      // general workgroups per tile of a tile-classified launch (each writes a plane of general parts; <= groups)
 
+// -DSH_DIAG (SYNTHHIP_BUILD_FLAGS, never the shipped library): every wavefront of a render launch leaves the 100 MHz timestamps of
+// its phases and the SIMD it ran on in g_diag (four banks by block number: launches of a stream of blocks overlap pairwise);
+// sh_debug_diag copies them out.  tools/headline_phases.py turns them into profiles/rNN_headline_phases.md.
+#ifdef SH_DIAG
+constexpr uint32_t DIAG_WAVES = 4096, DIAG_SLOTS = 10;
+__device__ uint64_t g_diag[4 * DIAG_WAVES * DIAG_SLOTS];
+__device__ __forceinline__ void diag_stamp(uint64_t start_, uint32_t nframes_, uint32_t slot) {
+    const uint32_t w = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && w < DIAG_WAVES) {
+        const uint32_t bank = (uint32_t)((double)start_ * __builtin_amdgcn_rcp((double)nframes_) + 0.5);     // the block's number (a stream of equal blocks)
+        uint64_t* d = g_diag + ((size_t)(bank & 3) * DIAG_WAVES + w) * DIAG_SLOTS;
+        d[slot] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 0) {
+            uint32_t hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            d[6] = (uint64_t)hw | ((uint64_t)xcc << 32);
+            d[7] = __builtin_amdgcn_s_memtime();
+            d[9] = ((uint64_t)gridDim.x << 32) | gridDim.y;
+        }
+        if (slot == 5) d[8] = __builtin_amdgcn_s_memtime();
+    }
+}
+__device__ uint64_t g_diag2[64 * 8];     // -DSH_DIAG2: s_memtime at five points of the first voices of one wavefront's lean loop
+#define SH_STAMP(slot) diag_stamp(start, nframes, slot)
+#else
+#define SH_STAMP(slot) ((void)0)
+#endif
+
 // lean_harm_frames for a (voice, tile) pair of a tile-classified launch with a corner of the envelope inside: the envelope of
 // frame i is one line in front of frame ci (tile-relative) and another from there on, applied to the sample before the (constant)
 // bus gains.
@@ -118,6 +147,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     // once between the rendering ones upsets their placement (the dispatcher does not refill the slot evenly: some CUs end up
     // with four rendering workgroups where others hold two, and the launch lasts as long as its fullest CU -- 63 against 53 us
     // for a bank of 352 chunks, most of them silent).
+    if constexpr (!mode_general(MODE)) SH_STAMP(0);
     const uint32_t prep_rows = (!mode_general(MODE) && prep_wgs) ? (prep_wgs + gridDim.x - 1) / gridDim.x : 0u;
     const uint32_t ngroups = gridDim.y - prep_rows;              // the voice groups of the launch
     bool is_gen_wg = false;                   // RENDER_TILES_MERGED: this workgroup renders general pairs (a row behind the voice groups')
@@ -315,6 +345,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             if (prev_pcm16) prev_pcm16[raw] = pcm16_frame(acc.x, acc.y, prev_pcm_scale);
         }
     }
+    if constexpr (!mode_general(MODE)) SH_STAMP(1);
     // (SYNTHHIP_PREPARE_IN_TILE=1, for A/B timings: the round-2 placement of the prepare step -- the chunks of 64 voices spread
     // over the first tile workgroups, one wavefront each, in front of their own work)
     if (!mode_general(MODE) && next.launch && !prep_wgs) {
@@ -328,6 +359,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += WAVES * 64) trig[k] = trig_g[k];
     __syncthreads();
+    if constexpr (!mode_general(MODE)) SH_STAMP(2);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // a segmented launch: this workgroup's segment and its tile there (uniform); everything below up to the stores is
@@ -639,6 +671,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
         const FastRec SH_CONST_AS* q = as_const(curS.fast) + c * 64 + first;
         uint32_t p = first;
         for (; p < nfast; p += WAVES, q += WAVES) {
+#ifdef SH_DIAG2
+            const bool d2on = blockIdx.x == 1 && blockIdx.y == 1 && wave == 0 && c == c0 + 1;
+            uint64_t d2t[5] = {0, 0, 0, 0, 0};
+            if (d2on) d2t[0] = __builtin_amdgcn_s_memtime();
+#endif
             // the common 192 bytes in ONE batch of scalar loads: the empty asm makes these fields live here, so the
             // compiler cannot sink their loads behind the tests below (it did: three dependent round trips per voice).
             // The second piece's fields are NOT in the list: their loads stay inside the rare crossing branches.
@@ -680,19 +717,39 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             if (mode_lean_harm(MODE) || kind == LEAN_HARM) {
                 // polynomial Harmonics: lookup + one rotation + the three-term recurrence (lean_harm_frames)
                 double s0, c0, s1, c1;
+#ifdef SH_DIAG2
+                { double th0 = theta(0); asm volatile("" : "+v"(th0)); if (d2on) d2t[1] = __builtin_amdgcn_s_memtime(); asm volatile("" : "+v"(th0)); }
+#endif
                 shm::sincos_tab(theta(0), trig, s0, c0);
+#ifdef SH_DIAG2
+                asm volatile("" : "+v"(s0), "+v"(c0)); if (d2on) d2t[2] = __builtin_amdgcn_s_memtime(); asm volatile("" : "+v"(s0), "+v"(c0));
+#endif
                 if (straddle) {
                     if (FPL > 1) shm::sincos_tab(theta(1), trig, s1, c1); else { s1 = s0; c1 = c0; }
                 } else {
                     s1 = fma(s0, rc, c0 * rs);
                     c1 = fma(c0, rc, -(s0 * rs));
                 }
+#ifdef SH_DIAG2
+                asm volatile("" : "+v"(s1), "+v"(c1)); if (d2on) d2t[3] = __builtin_amdgcn_s_memtime(); asm volatile("" : "+v"(s1), "+v"(c1));
+#endif
                 if constexpr (mode_seg(MODE)) {
                     const double gls = q->amplitude, grs = q->g0u;       // (a segmented launch's records: the gains' slopes per frame)
                     lean_harm_frames<FPL, true>(s0, c0, s1, c1, rc + rc, straddle, theta, trig, poly, gl, gr, accl, accr, gls, grs, di0);
                 } else {
                     lean_harm_frames<FPL>(s0, c0, s1, c1, rc + rc, straddle, theta, trig, poly, gl, gr, accl, accr);
                 }
+#ifdef SH_DIAG2
+                asm volatile("" : "+v"(accl[FPL - 1]), "+v"(accr[FPL - 1]), "+v"(accl[0]));
+                if (d2on) {
+                    d2t[4] = __builtin_amdgcn_s_memtime();
+                    const uint32_t it = (p - first) / WAVES;
+                    if (lane == 0 && it < 12) {
+#pragma unroll
+                        for (int k_ = 0; k_ < 5; ++k_) g_diag2[it * 8 + k_] = d2t[k_];
+                    }
+                }
+#endif
                 continue;
             }
             if constexpr (!mode_lean_harm(MODE)) {
@@ -808,12 +865,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
     }
     }
     }
+    if constexpr (!mode_general(MODE)) SH_STAMP(3);
 #pragma unroll
     for (int j = 0; j < FPL; ++j) {
         red[wave][0][j * 64 + lane] = accl[j];
         red[wave][1][j * 64 + lane] = accr[j];
     }
     __syncthreads();
+    if constexpr (!mode_general(MODE)) SH_STAMP(4);
     // each wave finishes 64-frame rows of the tile: rows wave, wave + WAVES, ...
     for (uint32_t row = wave; row < (uint32_t)FPL; row += WAVES) {
         const uint32_t f = row * 64 + lane;
@@ -838,6 +897,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_bank_render(BankPtrs B, co
             }
         }
     }
+    if constexpr (!mode_general(MODE)) SH_STAMP(5);
 }
 
 // The first segment of a general segmented launch: its nsub slices per group, added in order into the group's general parts.
@@ -1187,7 +1247,7 @@ static int launch_segmented(const RenderLaunch& L, uint32_t nseg, const uint32_t
 static int launch_plain(const RenderLaunch& L) {
     SH_RL_UNPACK(L);
 #define SH_LAUNCH_MODE(W_, F_, M_, MODE_)                                                                         \
-hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups + sh::div_up(prep_wgs, tiles)), dim3(W_ * 64), 0, st, ptrs(b),    \
+hipLaunchKernelGGL((k_bank_render<W_, F_, M_, MODE_>), dim3(tiles, groups + sh::div_up(prep_wgs, tiles)), dim3(W_ * 64), (size_t)K.lds_pad, st, ptrs(b),    \
                    trig_table(), b->nvoices, vpg, cur, next, next_start, start, nframes, o32, o64, parts, pv_parts, pv32, pv64, \
                    o16, pcm_scale, pv16, pv_scale, gen_valid, pv_gen, prep_wgs)
 #define SH_LAUNCH_RENDER(W_, F_, M_)                                                 \
@@ -1527,5 +1587,19 @@ int sh_bank_render_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_b
     b->launch_row_stride = 0;
     return rc;
 }
+
+#ifdef SH_DIAG
+int sh_debug_diag2(void* host, size_t bytes) {
+    if (hipDeviceSynchronize() != hipSuccess) return SH_ERR_HIP;
+    const size_t n = bytes < sizeof(g_diag2) ? bytes : sizeof(g_diag2);
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_diag2), n, 0, hipMemcpyDeviceToHost) == hipSuccess ? SH_OK : SH_ERR_HIP;
+}
+// (diagnostic builds only) the wavefronts' timestamps of the last launches: 4 banks x DIAG_WAVES x DIAG_SLOTS uint64
+int sh_debug_diag(void* host, size_t bytes) {
+    if (hipDeviceSynchronize() != hipSuccess) return SH_ERR_HIP;
+    const size_t n = bytes < sizeof(g_diag) ? bytes : sizeof(g_diag);
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_diag), n, 0, hipMemcpyDeviceToHost) == hipSuccess ? SH_OK : SH_ERR_HIP;
+}
+#endif
 
 }  // extern "C"

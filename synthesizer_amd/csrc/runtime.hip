@@ -36,6 +36,7 @@ void load_knobs() {
     k.no_merged = flag("SYNTHHIP_NO_MERGED");
     k.prep_in_general = flag("SYNTHHIP_PREP_IN_GENERAL");
     if (const char* e = getenv("SYNTHHIP_TILES_FOR_ALL")) k.tiles_for_all = atoi(e);
+    k.lds_pad = num("SYNTHHIP_LDS_PAD", 0);
     k.always_general = flag("SYNTHHIP_ALWAYS_GENERAL");
     k.no_small_pipeline = flag("SYNTHHIP_NO_SMALL_PIPELINE");
     k.prepare_in_tile = flag("SYNTHHIP_PREPARE_IN_TILE");
@@ -193,6 +194,13 @@ const char* sh_last_error(void) { return sh::g_err; }
 // "src:<hash>" = SHA-256 (first 16 hex digits) of csrc/ + include/synthhip.h + the compiler flags, embedded by
 // synthesizer_amd/build.py: a library whose hash differs from the tree's is stale and gets rebuilt.
 const char* sh_version(void) { return "synthhip 0.2 (gfx950) src:" SH_SOURCE_HASH; }
+
+int sh_abi(uint32_t* out, int n) {
+    const uint32_t v[7] = {SH_ABI_VERSION, (uint32_t)sizeof(sh_segment), (uint32_t)sizeof(sh_partial), (uint32_t)sizeof(sh_envelope),
+                           (uint32_t)sizeof(sh_voice), (uint32_t)sizeof(sh_devinfo), (uint32_t)sizeof(sh_counters)};
+    for (int k = 0; k < n && k < 7 && out; ++k) out[k] = v[k];
+    return 7;
+}
 
 int sh_device_count(void) {
     int n = 0;

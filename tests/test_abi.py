@@ -114,3 +114,65 @@ def test_host_library_exports_what_its_header_declares(tmp_path):
     subprocess.run(["gcc", "-std=c99", str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [24, 24, 8, 8, 16, 16] and N.SEGMENT_DTYPE.itemsize == 24
+
+
+def test_abi_guard_accepts_the_built_library():
+    from synthesizer_amd import _native as N
+    got = (ctypes.c_uint32 * 7)()
+    assert N.lib().sh_abi(got, 7) == 7
+    assert list(got) == N._abi_expected()
+    assert got[0] == N.SH_ABI_VERSION and got[4] == N.VOICE_DTYPE.itemsize
+
+
+def test_abi_guard_refuses_a_library_with_other_layouts(tmp_path):
+    """a stale .so with the same symbols but another sh_voice must not be loaded silently."""
+    from synthesizer_amd import _native as N
+    want = N._abi_expected()
+    for label, words in (("old_voice", [want[0], want[1], want[2], want[3], 240, want[5], want[6]]),
+                         ("old_abi", [want[0] - 1] + want[1:])):
+        src = tmp_path / (label + ".c")
+        src.write_text("#include <stdint.h>\nint sh_abi(uint32_t* out, int n){const uint32_t v[7]={%s};for(int k=0;k<n&&k<7;++k)out[k]=v[k];return 7;}\n"
+                       % ",".join(str(w) for w in words))
+        so = tmp_path / (label + ".so")
+        subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+        with pytest.raises(N.NativeLibraryStale):
+            N._check_abi(ctypes.CDLL(str(so)), so)
+    src = tmp_path / "none.c"
+    src.write_text("int sh_other(void){return 0;}\n")
+    so = tmp_path / "none.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+    with pytest.raises(N.NativeLibraryStale):
+        N._check_abi(ctypes.CDLL(str(so)), so)
+
+
+def test_a_tree_that_does_not_compile_is_an_error_not_a_stale_load(monkeypatch):
+    """A failing hipcc (the compiler IS there) must not fall back to the library of an older tree; a missing compiler may."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import build as B
+    N.lib()                                     # the real one is loaded and cached; work on a fresh cache below
+    saved = N._lib
+    try:
+        monkeypatch.delenv("SYNTHHIP_LIB", raising=False)
+        monkeypatch.delenv("SYNTHHIP_ALLOW_STALE", raising=False)
+
+        def fails(**kw):
+            raise subprocess.CalledProcessError(1, "hipcc -c osc_render.hip")
+        monkeypatch.setattr(B, "build", fails)
+        N._lib = None
+        with pytest.raises(N.NativeLibraryStale):
+            N.lib()
+        monkeypatch.setenv("SYNTHHIP_ALLOW_STALE", "1")
+        with pytest.warns(RuntimeWarning):
+            assert N.lib() is not None
+        # no compiler on the box: the shipped library is loaded with a warning
+        monkeypatch.delenv("SYNTHHIP_ALLOW_STALE")
+
+        def no_compiler(**kw):
+            raise FileNotFoundError(2, "No such file or directory", "/nonexistent/hipcc")
+        monkeypatch.setattr(B, "build", no_compiler)
+        monkeypatch.setattr(B, "HIPCC", "/nonexistent/hipcc")
+        N._lib = None
+        with pytest.warns(RuntimeWarning):
+            assert N.lib() is not None
+    finally:
+        N._lib = saved
