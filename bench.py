@@ -272,11 +272,28 @@ def pcm_rows(N):
     # Sample.mix: saturating add of two 900 MB int16 buffers (3 bytes moved per byte of output)
     n = 900_000_000
     row("pcm_add_i16_900MB", lambda: L.sh_pcm_add(chunks.handle, 0, chunks.handle, n, n, 2, src.handle, 0), 3 * n)
+    # ... and the METHOD a user calls: Sample.mix of two equal-length samples adds in place (3 bytes moved per
+    # output byte, as the kernel row above; rounds 1-3 allocated, copied self and added: 5) -- 900 MB, and the one-second stereo
+    # sample of SURVEY 8(a) row a10 (192 KB: a launch, not a bandwidth)
+    from synthesizer_amd.sample import Sample
+    sa = Sample(samplerate=48000, nchannels=2, samplewidth=2)
+    sa._set_device(src.view(0, n), n)
+    sb = Sample(samplerate=48000, nchannels=2, samplewidth=2)
+    sb._set_device(chunks.view(0, n), n)
+    row("sample_mix_method_i16_900MB", lambda: (sa.mix(sb), 0)[1], 3 * n, note="Sample.mix(other), equal lengths, both resident: in place")
+    n1s = 48000 * 2 * 2
+    s1 = Sample(samplerate=48000, nchannels=2, samplewidth=2)
+    s1._set_device(src.view(n, n1s), n1s)
+    s2 = Sample(samplerate=48000, nchannels=2, samplewidth=2)
+    s2._set_device(chunks.view(n, n1s), n1s)
+    rows["sample_mix_1s_stereo"] = {"ms": steady(N, lambda: s1.mix(s2), min_seconds=0.01, reps=50), "bytes": 3 * n1s,
+                                    "note": "Sample.mix of two one-second 48 kHz stereo int16 samples (192 KB each): one launch, latency-bound"}
     # Sample.amplify (audioop.mul), Sample.mono (audioop.tomono), peak/rms
     row("pcm_mul_i16_900MB", lambda: L.sh_pcm_mul(chunks.handle, 0, n, 2, 0.7071, src.handle, 0), 2 * n)
     row("pcm_tomono_i16_900MB", lambda: L.sh_pcm_tomono(chunks.handle, n // 4, 2, 0.5, 0.5, src.handle), n + n // 2)
     row("pcm_stats_i16_900MB", lambda: L.sh_pcm_stats(chunks.handle, n, 2, ctypes.byref(ctypes.c_uint32()), ctypes.byref(ctypes.c_double())), n)
     row("pcm_stats_stereo_i16_900MB", lambda: L.sh_pcm_stats_stereo(chunks.handle, n // 4, 2, (ctypes.c_uint32 * 2)(), (ctypes.c_double * 2)()), n)
+    del sa, sb, s1, s2                      # (their buffers are windows of src / chunks)
     for b in (src, dst, chunks, mixed):
         b.free()
     return rows
@@ -555,10 +572,24 @@ def main() -> int:
     from synthesizer_amd import _native as N
     from synthesizer_amd import build as B
     from synthesizer_amd import dist
-    N.ensure_init(local_rank)
+    N.ensure_init(dist.device_for_rank())          # the GPU ordinal = LOCAL_RANK (one process per GPU)
     info = N.device_info()
     if world > 1:
         dist.init(rank, world, broadcast=gloo_broadcast)
+    # what RCCL itself saw (ncclCommCount / ncclCommUserRank), read back BEFORE anything is timed: a line that claims N GPUs must
+    # come from a communicator of N ranks, each on a GPU of its own
+    rccl = dist.comm_info()
+    me = {"rank": rank, "local_rank": local_rank, "device": info["device"], "pci": N.device_pci(), "rccl_rank": rccl["rank"], "rccl_world": rccl["world"]}
+    if world > 1:
+        gathered_me = [None] * world
+        td.all_gather_object(gathered_me, me)
+    else:
+        gathered_me = [me]
+    bad = (rccl["world"] != world or rccl["rank"] != rank or info["device"] != dist.device_for_rank()
+           or len({g["pci"] for g in gathered_me}) != world)
+    if bad:
+        print("bench.py: RCCL / device check failed on rank %d: WORLD_SIZE %d, RCCL says %s, ranks %s" % (rank, world, rccl, gathered_me), file=sys.stderr)
+        return 3
 
     K, Wm, F = args.steps, args.warmup, args.frames
     if args.only_config == "staggered":
@@ -685,6 +716,11 @@ def main() -> int:
         "realtime_factor": F * K / wall / SR,
         "device": info["name"] or "AMD Instinct MI355X", "arch": info["arch"],
         "library": L.sh_version().decode(),
+        "rccl": {"world": rccl["world"], "rank": rccl["rank"], "version": rccl["version"], "communicator": rccl["communicator"],
+                 "ranks": gathered_me,
+                 "note": "world / rank: ncclCommCount / ncclCommUserRank of this process's communicator, read back before the timed region "
+                         "(no communicator at N = 1: world 1 by definition); ranks: every rank's GPU ordinal and PCI bus id -- the run "
+                         "aborts (exit 3) unless RCCL's world equals WORLD_SIZE and the PCI ids are distinct"},
         "verified": verified,
         "roofline": {
             "kernel": render_name or "k_bank_render<4, 8, 4, 3>", "bound": "valu_f64",
@@ -833,6 +869,8 @@ def main() -> int:
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_frames, all_cores=not args.no_cpu_all_cores)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    if out["rccl"]["version"] is None:
+        out["rccl"]["version"] = dist.comm_info()["version"]     # (N = 1: librccl.so is only loaded by the configs[3] row's 1-rank ring)
     if world > 1:
         barrier()
         dist.shutdown()

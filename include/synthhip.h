@@ -149,6 +149,7 @@ int  sh_shutdown(void);
 int  sh_is_initialized(void);
 int  sh_device_count(void);               /* 0 when no GPU is visible; never fails */
 int  sh_device_info(sh_devinfo* out);
+int  sh_device_pci(char* out, int n);     /* PCI bus id ("0000:c1:00.0") of the device sh_init selected, NUL-terminated */
 const char* sh_last_error(void);
 const char* sh_version(void);
 /* The binary interface this library was compiled with, so that a binding can refuse a library whose structs it would mis-pack
@@ -404,6 +405,10 @@ int sh_dist_init(int rank, int world, const void* id128); /* ncclCommInitRank on
 int sh_dist_shutdown(void);
 int sh_dist_rank(void);
 int sh_dist_world(void);
+/* What RCCL itself says about the communicator (not what the caller passed to sh_dist_init): out[0] = 1 when a communicator exists,
+ * out[1] = ncclCommCount, out[2] = ncclCommUserRank (-1 without a communicator), out[3] = ncclGetVersion (0 while librccl.so has not
+ * been loaded), out[4] = 1 when librccl.so is loaded.  Writes min(n, 5) words, returns 5; never loads the library by itself. */
+int sh_dist_comm_info(int32_t* out, int n);
 /* sum the ranks' float64 partial buses into root's buffer (ncclReduce, ncclDouble, in place) */
 int sh_dist_reduce_bus(sh_buf* bus_f64, size_t nvalues, int root);
 int sh_dist_allreduce_bus(sh_buf* bus_f64, size_t nvalues);

@@ -158,7 +158,9 @@ class RefSample:
         self.samplerate = samplerate
         return self
 
-    def chunked_frame_data(self, chunksize: int, repeat: bool = False):
+    def chunked_frame_data(self, chunksize: int, repeat: bool = False, stopcondition=lambda: False):
+        # (upstream's signature as recalled: a repeating generator also ends when stopcondition() turns true -- the mixer's
+        # "this sample was removed" test)
         if repeat:
             bdata = self.frames
             if len(bdata) < chunksize:
@@ -167,13 +169,13 @@ class RefSample:
             bdata += bdata[:chunksize]
             mdata = memoryview(bdata)
             i = 0
-            while True:
+            while not stopcondition():
                 yield mdata[i: i + chunksize]
                 i = (i + chunksize) % length
         else:
             mdata = memoryview(self.frames)
             i = 0
-            while i < len(mdata):
+            while i < len(mdata) and not stopcondition():
                 yield mdata[i: i + chunksize]
                 i += chunksize
 

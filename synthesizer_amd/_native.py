@@ -75,6 +75,7 @@ _SIGNATURES = {
     "sh_is_initialized": (C.c_int, []),
     "sh_device_count": (C.c_int, []),
     "sh_device_info": (C.c_int, [C.POINTER(DevInfo)]),
+    "sh_device_pci": (C.c_int, [C.c_char_p, C.c_int]),
     "sh_last_error": (C.c_char_p, []),
     "sh_version": (C.c_char_p, []),
     "sh_abi": (C.c_int, [C.POINTER(C.c_uint32), C.c_int]),
@@ -138,6 +139,7 @@ _SIGNATURES = {
     "sh_dist_shutdown": (C.c_int, []),
     "sh_dist_rank": (C.c_int, []),
     "sh_dist_world": (C.c_int, []),
+    "sh_dist_comm_info": (C.c_int, [C.POINTER(C.c_int32), C.c_int]),
     "sh_dist_reduce_bus": (C.c_int, [_P, C.c_size_t, C.c_int]),
     "sh_dist_allreduce_bus": (C.c_int, [_P, C.c_size_t]),
     "sh_dist_barrier": (C.c_int, []),
@@ -275,6 +277,14 @@ def device_info() -> dict:
     return {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": info.compute_units,
             "clock_mhz": info.clock_mhz, "hbm_bytes": info.hbm_bytes, "wavefront": info.wavefront,
             "device": info.device}
+
+
+def device_pci() -> str:
+    """PCI bus id of the GPU this process renders on (distinct per rank of a multi-GPU job: bench.py prints it per rank)."""
+    ensure_init()
+    buf = C.create_string_buffer(64)
+    check(lib().sh_device_pci(buf, 64))
+    return buf.value.decode()
 
 
 def debug_counters() -> dict:

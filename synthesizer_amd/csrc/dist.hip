@@ -22,6 +22,9 @@ struct Rccl {
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;          // (optional: sh_dist_comm_info)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     ncclComm_t comm = nullptr;
     int rank = -1, world = 0;
     double* token = nullptr;     // 1-element device buffer for the barrier
@@ -57,6 +60,9 @@ int load_rccl() {
     SH_SYM(AllReduce, "ncclAllReduce")
     SH_SYM(GetErrorString, "ncclGetErrorString")
 #undef SH_SYM
+    *(void**)(&r.CommCount) = dlsym(r.lib, "ncclCommCount");
+    *(void**)(&r.CommUserRank) = dlsym(r.lib, "ncclCommUserRank");
+    *(void**)(&r.GetVersion) = dlsym(r.lib, "ncclGetVersion");
     return SH_OK;
 }
 
@@ -147,6 +153,24 @@ int sh_dist_shutdown(void) {
 
 int sh_dist_rank(void) { return R().rank; }
 int sh_dist_world(void) { return R().world; }
+
+int sh_dist_comm_info(int32_t* out, int n) {
+    SH_API_LOCK();
+    Rccl& r = R();
+    int32_t v[5] = {r.comm ? 1 : 0, -1, -1, 0, r.lib ? 1 : 0};
+    if (r.comm) {
+        int x = -1;
+        if (r.CommCount && r.CommCount(r.comm, &x) == ncclSuccess) v[1] = x;
+        x = -1;
+        if (r.CommUserRank && r.CommUserRank(r.comm, &x) == ncclSuccess) v[2] = x;
+    }
+    if (r.lib && r.GetVersion) {
+        int x = 0;
+        if (r.GetVersion(&x) == ncclSuccess) v[3] = x;
+    }
+    for (int k = 0; k < n && k < 5 && out; ++k) out[k] = v[k];
+    return 5;
+}
 
 int sh_dist_reduce_bus(sh_buf* bus_f64, size_t nvalues, int root) {
     SH_REQUIRE_INIT();

@@ -1536,11 +1536,12 @@ static int bank_render_any(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf*
     // A table of notes (tile-classified launches) is rendered in launches of at most 2^17 frames: a tile set holds a record per
     // (tile, sounding voice), and a launch of minutes of audio would not get one (it would fall back to the general code for
     // every voice of the table); everything else in launches of at most RENDER_MAX_FRAMES (the 32-bit work-item count of a dispatch).
+    SH_API_LOCK();     // (recursive) taken BEFORE the bank is looked at -- sh_bank_set_rows on another thread changes needs_rows /
+                       // first_row_voice -- and held across the launches of one call: nothing else gets between them
     const bool notes = b && b->tile_all && b->nvoices >= 128 && (b->has_onsets || b->own_envelopes) && !b->needs_rows && b->first_row_voice < 0 &&
                        !sh::knobs().no_tiles;
     const uint32_t RENDER_MAX_FRAMES = notes ? (1u << 17) : RENDER_MAX_FRAMES_ANY;
     if (nframes <= RENDER_MAX_FRAMES) return bank_render(b, start, nframes, bus_f32, bus_f64, pcm_i16, pcm_scale);
-    SH_API_LOCK();                                           // (recursive) one call: nothing else gets between its launches
     if (bus_f32 && bus_f32->bytes < (size_t)nframes * 8) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f32 too small");
     if (bus_f64 && bus_f64->bytes < (size_t)nframes * 16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: bus_f64 too small");
     if (pcm_i16 && pcm_i16->bytes < (size_t)nframes * 4) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_pcm: PCM buffer too small");

@@ -278,6 +278,13 @@ int sh_shutdown(void) {
     return SH_OK;
 }
 
+int sh_device_pci(char* out, int n) {
+    SH_REQUIRE_INIT_KEEP_PENDING();
+    if (!out || n < 16) return sh::set_error(SH_ERR_INVALID, "sh_device_pci: buffer of at least 16 bytes");
+    SH_HIP(hipDeviceGetPCIBusId(out, n, sh::state().device));
+    return SH_OK;
+}
+
 int sh_device_info(sh_devinfo* out) {
     SH_REQUIRE_INIT();
     if (!out) return sh::set_error(SH_ERR_INVALID, "out is NULL");

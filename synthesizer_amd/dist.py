@@ -101,8 +101,7 @@ def init_from_env() -> Tuple[int, int]:
     """RANK / WORLD_SIZE / LOCAL_RANK as the launcher sets them (one process per GPU); selects GPU LOCAL_RANK."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    N.ensure_init(local)
+    N.ensure_init(device_for_rank())
     if world > 1:
         init(rank, world)
     return rank, world
@@ -110,6 +109,27 @@ def init_from_env() -> Tuple[int, int]:
 
 def shutdown() -> None:
     N.check(N.lib().sh_dist_shutdown())
+
+
+def device_for_rank(env=None) -> int:
+    """The GPU ordinal of this process: LOCAL_RANK as the launcher set it (one process per GPU on one node), else RANK, else 0.
+    Pure host logic (tests/test_host_logic.py maps eight ranks to eight distinct ordinals with it)."""
+    env = os.environ if env is None else env
+    return int(env.get("LOCAL_RANK", env.get("RANK", "0")))
+
+
+def comm_info() -> dict:
+    """What RCCL itself reports about this process's communicator (ncclCommCount / ncclCommUserRank / ncclGetVersion), beside
+    what the library was told: a bench line can show that RCCL SAW n ranks.  Without a communicator (single GPU): world 1, rank 0."""
+    L = N.lib()
+    v = (C.c_int32 * 5)()
+    L.sh_dist_comm_info(v, 5)
+    has = bool(v[0])
+    ver = int(v[3])
+    return {"communicator": has, "world": int(v[1]) if has else 1, "rank": int(v[2]) if has else 0,
+            "told_world": int(L.sh_dist_world()) if has else 1, "told_rank": int(L.sh_dist_rank()) if has else 0,
+            "version": ("%d.%d.%d" % (ver // 10000, (ver // 100) % 100, ver % 100)) if ver else None,
+            "librccl_loaded": bool(v[4])}
 
 
 class _HipBackend:
@@ -161,7 +181,9 @@ class DistVoiceBank:
     With several ranks the exchange is pipelined and batched: blocks are rendered into a ring of slots, each
     slot holding ``batch`` consecutive blocks; when a slot is full one ``ncclReduce`` (and, on root, the
     rounding to float32) is enqueued for it on the communication stream, overlapping the render of the
-    following blocks.  ``flush()`` sends a partly filled slot; ``sync()`` waits for everything.
+    following blocks.  ``flush()`` sends a partly filled slot; ``sync()`` releases every FULL slot whose reduce is still held
+    back and waits for everything enqueued -- a partly filled slot is only sent by ``flush()`` (call ``flush()`` then ``sync()``
+    before reading the last blocks).
 
     The reduce of a full slot is held back: a render's partial buses are folded into the slot's float64 bus by the render two
     launches on, so two renders later the slot is complete on the device without anybody having ended the run of pipelined
@@ -239,6 +261,11 @@ class DistVoiceBank:
             self._release_held(everything=True)
 
     def sync(self) -> None:
+        """Enqueue the reduces of the full slots that are still held back, then wait for the device: every block of a FULL slot
+        is final in its float32 view afterwards (before, a caller that rendered whole batches and called sync()
+        without flush() read views whose collective had never been enqueued)."""
+        if self.world > 1:
+            self._release_held(everything=True)
         self.backend.sync()
 
     def render_device(self, nframes: int, start: int = 0, root: int = 0):

@@ -721,9 +721,13 @@ class EnvelopeFilter(Oscillator):
             reps = max(1, -(-65536 // period))
             one = self._gain._render_f64_device(0, period)
             buf = N.DeviceBuffer(8 * period * reps)
-            for r in range(reps):
-                N.check(N.lib().sh_buf_copy(buf.handle, 8 * period * r, one.handle, 0, 8 * period))
+            N.check(N.lib().sh_buf_copy(buf.handle, 0, one.handle, 0, 8 * period))
             one.free()
+            have = 1                                  # periods laid out so far; doubled per copy: O(log reps) device copies, not
+            while have < reps:                        # reps of them (a period of a few samples made tens of thousands: ADVICE r03)
+                cnt = min(have, reps - have)
+                N.check(N.lib().sh_buf_copy(buf.handle, 8 * period * have, buf.handle, 0, 8 * period * cnt))
+                have += cnt
             self._cycle_gain, self._cycle_frames = buf, period * reps
         out = self._source._render_f64_device(start, n)
         done = 0
@@ -734,6 +738,18 @@ class EnvelopeFilter(Oscillator):
                                       out.handle, done, None, 0, None))
             done += cnt
         return out
+
+    def close(self) -> None:
+        """Give the periods of a cycling envelope's gain curve back to the buffer pool (also done when the object is collected)."""
+        if self._cycle_gain is not None:
+            self._cycle_gain.free()
+            self._cycle_gain, self._cycle_frames = None, 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown: the library may be gone
+            pass
 
     def _render_f64_device(self, start: int, n: int) -> N.DeviceBuffer:
         if self._fused:

@@ -57,7 +57,9 @@ def build_phase_table(t0: float, inc: float, n_limit: int = N_LIMIT) -> List[Seg
             break
         if t >= _TINY or t <= -_TINY:     # (zero and tiny values are never part of a run)
             m, e = frexp(t)
-            hi = ldexp(1.0, e)            # the binade of t: lo <= |x| < hi, with t's sign
+            # the binade of t: lo <= |x| < hi, with t's sign (|t| >= 2^1023: hi = 2^1024 is no float64 -- math.ldexp raises where C's
+            # ldexp returns inf; with inf, as in the native loop, no step stays "inside" and the table goes on by single steps)
+            hi = ldexp(1.0, e) if e < 1024 else float("inf")
             lo = 0.5 * hi
             pos = t > 0
             if (lo <= t1 < hi) if pos else (-hi < t1 <= -lo):
@@ -86,7 +88,8 @@ def build_phase_table(t0: float, inc: float, n_limit: int = N_LIMIT) -> List[Seg
         n, t = n + 1, t1
         if len(segs) > _MAX_PIECES:
             # (a denormal increment from a denormal start walks 2^70 single steps below the smallest binade this table keeps)
-            raise OverflowError("phase table of t0=%r, increment=%r does not close: the increment is denormal" % (t0, inc))
+            raise OverflowError("phase table of t0=%r, increment=%r does not close: more than %d single-step pieces (a denormal "
+                                "increment from a denormal start, or values that are not finite)" % (t0, inc, _MAX_PIECES))
     return segs
 
 
@@ -123,8 +126,11 @@ def phase_table_records(t0: float, inc: float, n_limit: int = N_LIMIT) -> np.nda
             cnt = lib.shh_phase_table(float(t0), float(inc), min(int(n_limit), (1 << 64) - 1), out.ctypes.data, cap)
             if cnt >= 0:
                 return out[:cnt].copy()
-            if cnt == -2 or cap > (1 << 17):
-                raise OverflowError("phase table of t0=%r, increment=%r does not close: the increment is denormal" % (t0, inc))
+            if cnt == -2:
+                raise OverflowError("phase table of t0=%r, increment=%r does not close: more than %d single-step pieces (a denormal "
+                                    "increment from a denormal start, or values that are not finite)" % (t0, inc, _MAX_PIECES))
+            if cap > (1 << 17):
+                raise OverflowError("phase table of t0=%r, increment=%r needs more than %d pieces" % (t0, inc, cap))
             cap *= 16
     segs = build_phase_table(t0, inc, n_limit)
     out = np.empty(len(segs), dtype=_SEGMENT_DTYPE)

@@ -2,7 +2,10 @@
 
     RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT in the environment; argv[1] = output directory.
 
-Every rank: synthesizer_amd.dist.init_from_env (TCP rendezvous of the ncclUniqueId, no torch), a DistVoiceBank with
+    python multi_gpu_worker.py --plumbing      prints what this process WOULD do (rank, world, GPU ordinal) and exits: no GPU touched
+
+This script is the one place of the multi-GPU test that picks a device: the ordinal is LOCAL_RANK (dist.device_for_rank), selected
+explicitly before anything else touches the library.  Every rank: TCP rendezvous of the ncclUniqueId (no torch), a DistVoiceBank with
 batch 8 over several wraps of the slot ring, the blocking render, and its share of a range-sharded resample.  Root
 writes the reduced buses (float32 and the float64 sums) for the parent to compare with the single-GPU render."""
 import os
@@ -30,13 +33,35 @@ def resample_input():
     return rng.integers(-32768, 32768, r["frames"] * r["nch"], dtype=np.int16).tobytes()
 
 
+def plumbing(env=None):
+    """(rank, world, GPU ordinal) from the launcher's environment -- host logic, no GPU."""
+    from synthesizer_amd import dist
+    env = os.environ if env is None else env
+    return {"rank": int(env.get("RANK", "0")), "world": int(env.get("WORLD_SIZE", "1")), "device": dist.device_for_rank(env)}
+
+
 def main():
+    if sys.argv[1] == "--plumbing":
+        import json
+        print(json.dumps(plumbing()))
+        return
     out = Path(sys.argv[1])
+    import json
     from synthesizer_amd import _native as N
     from synthesizer_amd import dist
-    rank, world = dist.init_from_env()
+    pl = plumbing()
+    rank, world, device = pl["rank"], pl["world"], pl["device"]
+    N.ensure_init(device)                             # THE device choice of this process
+    info = N.device_info()
+    assert info["device"] == device, (info, device)
+    if world > 1:
+        dist.init(rank, world)
     L = N.lib()
+    ci = dist.comm_info()
     assert world == 1 or (L.sh_dist_rank() == rank and L.sh_dist_world() == world)
+    assert world == 1 or (ci["communicator"] and ci["world"] == world and ci["rank"] == rank), ci     # what RCCL itself saw
+    (out / ("rank_%d.json" % rank)).write_text(json.dumps({"rank": rank, "world": world, "device": device, "pci": N.device_pci(),
+                                                           "name": info["name"], "rccl": ci}))
     voices, gains = workload(world)
     bank = dist.DistVoiceBank(voices, gains, rank, world, batch=BATCH)
     nslots = L.sh_dist_slots()

@@ -239,3 +239,58 @@ def test_resample_ranges_and_spans_cover_exactly():
                 assert lo + n - 1 == j_last and lo + n <= in_frames
     with pytest.raises(ValueError):
         dist.resample_span(1000, 48000, 44100, 900, 100)       # beyond the 919 output frames
+
+
+class _LaggedFakeBackend:
+    """The held-back reduce path of DistVoiceBank (reduce_lagged / mark_slot) without a GPU: records the calls."""
+
+    def __init__(self):
+        self.log = []
+
+    def nslots(self):
+        return 4
+
+    def alloc(self, nbytes):
+        return np.zeros(nbytes, dtype=np.uint8)
+
+    def view(self, buf, offset, nbytes):
+        return buf[offset:offset + nbytes]
+
+    def render(self, nframes, start, bus_f32, bus_f64):
+        self.log.append(("render", start))
+
+    def wait_slot(self, slot):
+        self.log.append(("wait", slot))
+
+    def mark_slot(self, slot):
+        self.log.append(("mark", slot))
+
+    def reduce_lagged(self, bus_f64, nvalues, root, bus_f32, slot):
+        self.log.append(("reduce", slot, nvalues))
+
+    def sync(self):
+        self.log.append(("sync",))
+
+
+def test_sync_releases_the_full_slots_whose_reduce_is_held_back():
+    """render whole batches, then sync() WITHOUT flush(): the held reduces must have been enqueued in front of the wait."""
+    from oracle import synth_oracle as O
+    from synthesizer_amd import dist
+    from synthesizer_amd.workloads import additive_voices
+    voices, gains = additive_voices(O, 4, 48000, seed=1, partials=2)
+    be = _LaggedFakeBackend()
+    bank = dist.DistVoiceBank(voices, gains, 0, 2, batch=2, backend=be)
+    for s in range(4):                                   # two full slots, nothing partly filled
+        bank.render_device(100, s * 100)
+    assert [e for e in be.log if e[0] == "reduce"] == [] or len([e for e in be.log if e[0] == "reduce"]) < 2     # (held back)
+    bank.sync()
+    reduces = [e for e in be.log if e[0] == "reduce"]
+    assert [e[1] for e in reduces] == [0, 1] and all(e[2] == 2 * 100 * 2 for e in reduces)
+    assert be.log[-1] == ("sync",) and be.log.index(reduces[-1]) < len(be.log) - 1
+    assert bank._held == []
+    # a partly filled slot is flush()'s business: sync() alone leaves it
+    bank.render_device(100, 400)
+    bank.sync()
+    assert len([e for e in be.log if e[0] == "reduce"]) == 2
+    bank.flush()
+    assert len([e for e in be.log if e[0] == "reduce"]) == 3

@@ -39,6 +39,9 @@ def test_worker_dry_run_on_one_gpu(gpu, tmp_path):
     p = subprocess.run([sys.executable, str(ROOT / "tests" / "multi_gpu_worker.py"), str(tmp_path)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    import json
+    me = json.loads((tmp_path / "rank_0.json").read_text())
+    assert me["device"] == 0 and me["world"] == 1 and me["rccl"]["world"] == 1 and not me["rccl"]["communicator"] and len(me["pci"]) >= 7, me
     got32, one = np.load(tmp_path / "bus32.npy"), np.load(tmp_path / "one.npy")
     voices, gains = W.workload(1)
     alone = VoiceBank(voices, gains=gains)
@@ -82,6 +85,12 @@ def test_voice_shards_reduced_by_rccl_across_gpus(gpu, tmp_path):
             logs.append(o)
         assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
         assert all((out / ("done_%d" % r)).exists() for r in range(world))
+        # every rank on a GPU of its own, and RCCL saw all of them
+        import json
+        ranks = [json.loads((out / ("rank_%d.json" % r)).read_text()) for r in range(world)]
+        assert [q["device"] for q in ranks] == list(range(world)), ranks
+        assert len({q["pci"] for q in ranks}) == world, ranks
+        assert all(q["rccl"]["communicator"] and q["rccl"]["world"] == world and q["rccl"]["rank"] == q["rank"] for q in ranks), ranks
         # the single-GPU render of the same voice table
         voices, gains = W.workload(world)
         alone = VoiceBank(voices, gains=gains)

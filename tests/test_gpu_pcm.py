@@ -73,6 +73,48 @@ def test_sample_mix_semantics(gpu):
         _sample(a, 2, 44100, 2).lock().mix(_sample(b, 2, 44100, 2))
 
 
+@pytest.mark.parametrize("width", [1, 2, 3, 4])
+def test_sample_mix_in_place(gpu, width):
+    """Round 4: when nothing grows Sample.mix / mix_at add IN PLACE (no allocate + copy).  Same bytes as audioop.add; the other operand
+    and earlier copies are untouched; the device buffer is the same object before and after; a sample mixed into itself doubles."""
+    from synthesizer_amd import _native as N
+    rng = np.random.default_rng(7 + width)
+    n = 4096 + 3
+    if width == 3:
+        a = rng.integers(0, 256, 3 * n, dtype=np.uint8)
+        b = rng.integers(0, 256, 3 * n, dtype=np.uint8)
+    else:
+        a, b = _rand(rng, width, n), _rand(rng, width, n)
+    ab, bb = a.tobytes(), b.tobytes()
+    s, o = _sample(a, width, 8000, 1).to_device(), _sample(b, width, 8000, 1).to_device()
+    keep = s.copy()
+    dev = s._device()
+    allocs = N.debug_counters()["device_allocs"]
+    s.mix(o)
+    assert s._device() is dev                                   # no new buffer
+    assert bytes(s.view_frame_data()) == audioop.add(ab, bb, width)
+    assert bytes(o.view_frame_data()) == bb and bytes(keep.view_frame_data()) == ab
+    # mix_at inside the sample
+    s2 = _sample(a, width, 8000, 1).to_device()
+    dev2 = s2._device()
+    part = _sample(b[: (1000 * (3 if width == 3 else 1))], width, 8000, 1)
+    s2.mix_at(0.125, part)
+    start = width * 1000
+    want = bytearray(ab)
+    want[start:start + 1000 * width] = audioop.add(ab[start:start + 1000 * width], bb[:1000 * width], width)
+    assert s2._device() is dev2 and bytes(s2.view_frame_data()) == bytes(want)
+    # a sample mixed into itself
+    s3 = _sample(a, width, 8000, 1)
+    s3.mix(s3)
+    assert bytes(s3.view_frame_data()) == audioop.add(ab, ab, width)
+    # the host copy is dropped, not served stale
+    s4 = _sample(a, width, 8000, 1)
+    assert bytes(s4.view_frame_data()) == ab
+    s4.mix(o)
+    assert bytes(s4.view_frame_data()) == audioop.add(ab, bb, width)
+    assert N.debug_counters()["device_allocs"] >= allocs         # (pool hits are not driver allocations; nothing to assert beyond sanity)
+
+
 def test_sample_mix_at(gpu):
     rng = np.random.default_rng(1)
     a = _rand(rng, 2, 4000)

@@ -221,3 +221,30 @@ def test_every_module_of_the_package_imports_and_compiles():
         py_compile.compile(str(f), doraise=True)
     for name in ("_native", "build", "dist", "mixer", "oscillators", "params", "phasetable", "sample", "synth", "workloads"):
         importlib.import_module("synthesizer_amd." + name)
+
+
+def test_eight_ranks_map_to_eight_distinct_gpu_ordinals(tmp_path):
+    """sh_init(device != 0) has never run anywhere, so at least the plumbing that picks the ordinal is pinned on
+    CPU: the launcher's environment of an 8-rank job (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE) gives ordinals
+    0 .. 7, through the function and through the worker script's own argv / env path; bench.py picks the same way."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "tests"))
+    import multi_gpu_worker as W
+    from synthesizer_amd import dist
+    envs = [{"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": "8", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29500"} for r in range(8)]
+    got = [W.plumbing(e) for e in envs]
+    assert [g["device"] for g in got] == list(range(8)) and all(g["world"] == 8 for g in got) and [g["rank"] for g in got] == list(range(8))
+    # two nodes of four: the ordinal is the LOCAL rank
+    assert [dist.device_for_rank({"RANK": str(r), "LOCAL_RANK": str(r % 4)}) for r in range(8)] == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert dist.device_for_rank({}) == 0 and dist.device_for_rank({"RANK": "3"}) == 3
+    for r in (0, 5, 7):
+        env = dict(os.environ, **envs[r])
+        env.pop("SYNTHHIP_DEVICE", None)
+        p = subprocess.run([sys.executable, str(root / "tests" / "multi_gpu_worker.py"), "--plumbing"], env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert json.loads(p.stdout.strip().splitlines()[-1]) == {"rank": r, "world": 8, "device": r}

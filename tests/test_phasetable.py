@@ -144,3 +144,25 @@ def test_native_builder_gives_the_python_builders_pieces():
     assert PT.phase_table_records(0.3, 0.01, 1000).tolist() == [tuple(s) for s in build_phase_table(0.3, 0.01, 1000)]
     pt = PhaseTable(0.25, 440 / 48000)
     assert pt.segments == build_phase_table(0.25, 440 / 48000) and len(pt) == len(pt.segments) == len(pt.records)
+
+
+def test_the_top_binade_is_walked_by_both_builders_alike():
+    """|t| >= 2^1023 -- math.ldexp(1.0, 1024) raises where C's ldexp returns inf.  Both loops now treat the top binade's
+    upper bound as inf (no run stays 'inside'): the same pieces, ending in the constant piece at +-inf."""
+    from synthesizer_amd import phasetable as PT
+    lib = PT._host_lib()
+    assert lib
+    for t0, inc in ((1e308, 1e308), (-1e308, -1e308), (8.0e307, 1.0e307), (2.0 ** 1023, 2.0 ** 1012), (1.0, 1.7e308)):
+        want = build_phase_table(t0, inc)
+        rec = PT.phase_table_records(t0, inc)
+        got = list(zip(rec["n0"].tolist(), rec["t0"].tolist(), rec["dt"].tolist()))
+        assert len(got) == len(want) and all(g[0] == w[0] and (g[1] == w[1]) and (g[2] == w[2] or (g[2] != g[2] and w[2] != w[2]))
+                                             for g, w in zip(got, want)), (t0, inc, got[:4], want[:4])
+        assert want[-1][2] == 0.0 and math.isinf(want[-1][1])          # the sum reached infinity and stays there
+    # the top binade is walked by single steps: a small increment there is refused by both loops alike
+    for build in (build_phase_table, PT.phase_table_records):
+        with pytest.raises(OverflowError, match="single-step pieces"):
+            build(1.7e308, 1e292)
+    # the cap on single-step pieces has a message of its own
+    with pytest.raises(OverflowError, match="single-step pieces"):
+        build_phase_table(5e-324, 5e-324)

@@ -2,6 +2,7 @@
 """Pin the oscillator / Sample oracle against the REAL synthplayer package -- the moment it is importable.
 
     python tools/pin_oracle.py [--regen] [--quick] [--json PATH]
+    python tools/pin_oracle.py --api [--json PATH]      signatures only: names, order, kinds, defaults of every public class / method
 
 The tree mounted at /root/reference holds a two-line relocation notice (README.md:1-2), so today this script
 finds nothing to diff against and exits 3 ("reference absent"); `parity: unpinned` stays in oracle/synth_oracle.py's
@@ -220,8 +221,99 @@ def regenerate_golden(ref):
     return ["osc_sine440_44k1.npy", "osc_misc.npz"]
 
 
+# ---- API audit: "drops in behind synthplayer.oscillators / Sample / the mixer" is a claim about SIGNATURES too ----
+API_MODULES = (("synthplayer.oscillators", "synthesizer_amd.oscillators", None),
+               ("synthplayer.sample", "synthesizer_amd.sample", ("Sample", "LevelMeter")),
+               ("synthplayer.synth", "synthesizer_amd.synth", ("WaveSynth",)),
+               ("synthplayer.playback", "synthesizer_amd.mixer", ("RealTimeMixer",)))
+
+
+def _sig(fn):
+    """(name, kind, default) per parameter -- names, order, kinds and defaults are what a caller's code depends on."""
+    import inspect
+    try:
+        sig = inspect.signature(fn)
+    except (TypeError, ValueError):
+        return None
+    out = []
+    for p_ in sig.parameters.values():
+        d = "<required>" if p_.default is inspect.Parameter.empty else repr(p_.default)
+        out.append((p_.name, p_.kind.name, d))
+    return out
+
+
+def _public_members(cls):
+    import inspect
+    names = ["__init__"] + sorted(n for n, v in vars(cls).items() if not n.startswith("_"))
+    out = {}
+    for n in names:
+        v = inspect.getattr_static(cls, n, None)
+        if v is None:
+            continue
+        if isinstance(v, property):
+            out[n] = ("property", None)
+        elif isinstance(v, (staticmethod, classmethod)):
+            out[n] = (type(v).__name__, _sig(v.__func__))
+        elif callable(v):
+            out[n] = ("method", _sig(v))
+        else:
+            out[n] = ("attribute", None)
+    return out
+
+
+def audit_api(ref_mod, our_mod, class_names=None, rename=None):
+    """One row per public class and per public member of it in `ref_mod`: status equal / differs / missing in `our_mod`.
+    `rename`: reference class name -> our class name (the oracle's RefSample stands for Sample in the self-test)."""
+    import inspect
+    rename = rename or {}
+    rows = []
+    if class_names is None:
+        class_names = sorted(n for n, v in vars(ref_mod).items()
+                             if inspect.isclass(v) and not n.startswith("_") and getattr(v, "__module__", None) == ref_mod.__name__)
+    for cname in class_names:
+        rc = getattr(ref_mod, cname, None)
+        if rc is None:
+            continue
+        oc = getattr(our_mod, rename.get(cname, cname), None)
+        if oc is None:
+            rows.append({"symbol": "%s.%s" % (ref_mod.__name__, cname), "status": "missing"})
+            continue
+        rm, om = _public_members(rc), _public_members(oc)
+        for mname, (kind, sig) in rm.items():
+            sym = "%s.%s.%s" % (ref_mod.__name__, cname, mname)
+            if mname not in om and not hasattr(oc, mname):
+                rows.append({"symbol": sym, "status": "missing", "ref": sig})
+                continue
+            if mname not in om:                      # inherited on our side: take it from the MRO
+                v = inspect.getattr_static(oc, mname)
+                okind = "property" if isinstance(v, property) else "method"
+                osig = None if isinstance(v, property) else _sig(v.__func__ if isinstance(v, (staticmethod, classmethod)) else v)
+            else:
+                okind, osig = om[mname]
+            same = (kind == okind or {kind, okind} <= {"method", "staticmethod", "classmethod"} and kind == okind) and sig == osig
+            rows.append({"symbol": sym, "status": "equal" if same else "differs", "ref": sig, "ours": osig,
+                         "ref_kind": kind, "our_kind": okind})
+    return rows
+
+
+def print_api_table(rows):
+    bad = [r for r in rows if r["status"] != "equal"]
+    print("API audit: %d symbols, %d equal, %d differ, %d missing" % (len(rows), len(rows) - len(bad),
+                                                                      sum(r["status"] == "differs" for r in bad), sum(r["status"] == "missing" for r in bad)))
+    for r in rows:
+        if r["status"] == "equal":
+            continue
+        print("  %-8s %s" % (r["status"], r["symbol"]))
+        if r.get("ref") is not None or r.get("ours") is not None:
+            print("           ref : %s" % (r.get("ref"),))
+            print("           ours: %s" % (r.get("ours"),))
+    return bad
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
+    ap.add_argument("--api", action="store_true", help="audit inspect.signature of every public class / method of synthplayer.oscillators, "
+                                                       "sample.Sample, synth.WaveSynth, playback.RealTimeMixer against synthesizer_amd's")
     ap.add_argument("--regen", action="store_true", help="rewrite tests/golden/osc_*.np* from the real package")
     ap.add_argument("--quick", action="store_true", help="one sample rate / phase, no late windows")
     ap.add_argument("--json", default=None, help="write the outcome here as JSON")
@@ -236,6 +328,20 @@ def main() -> int:
         if args.json:
             Path(args.json).write_text(json.dumps(outcome, indent=1) + "\n")
         return 3
+    if args.api:
+        import importlib
+        rows = []
+        for ref_name, our_name, classes in API_MODULES:
+            try:
+                rows += audit_api(importlib.import_module(ref_name), importlib.import_module(our_name), classes)
+            except ImportError as e:
+                rows.append({"symbol": ref_name, "status": "missing", "ref": repr(e)})
+        bad = print_api_table(rows)
+        outcome["status"] = "api equal" if not bad else "api differences"
+        outcome["api"] = rows
+        if args.json:
+            Path(args.json).write_text(json.dumps(outcome, indent=1) + "\n")
+        return 0 if not bad else 1
     from oracle import synth_oracle as O
     from oracle.sample_oracle import RefSample
     import synthplayer.oscillators as ref_osc
