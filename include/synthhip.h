@@ -172,34 +172,24 @@ typedef struct sh_counters {
 } sh_counters;
 int  sh_debug_counters(sh_counters* out);
 
-/* Measurement knobs: environment variables read ONCE, by sh_init.  None changes a result -- they choose between code paths
- * that produce the same buses, so that A/B timings can be taken with one library (tools/):
- *   SYNTHHIP_NO_SPECULATION=1     launch records by a prepare kernel in front of every render (no records two launches ahead)
+/* Measurement knobs: environment variables read ONCE, by sh_init.  None changes a result -- they choose between schedules of the same
+ * arithmetic, so that A/B timings can be taken with one library (tests/test_gpu_pipeline.py::test_knobs_change_no_result).  Nine of
+ * them; the fifteen others that rounds 1-3 accumulated selected paths that had lost their A/B and were removed with those paths in
+ * round 4 (CHANGELOG.md keeps what each measured):
  *   SYNTHHIP_NO_OVERLAP=1         consecutive renders of a bank stay on one stream
+ *   SYNTHHIP_NO_SPECULATION=1     launch records by a prepare kernel in front of every render (no records two launches ahead)
  *   SYNTHHIP_NO_SMALL_PIPELINE=1  single-group (small) banks render on one stream; several-group banks still alternate
- *   SYNTHHIP_PREPARE_IN_TILE=1    the records of the block two launches on are resolved by the first tile workgroups in front of
- *                                 their own work instead of by workgroups of their own
- *   SYNTHHIP_NO_SPLIT=1           lean and general code in one render kernel
+ *   SYNTHHIP_NO_SPLIT=1           lean and general code in one render kernel (k_render_combined) instead of k_render_lean + k_render_general
  *   SYNTHHIP_NO_SEG=1             transition launches / the heads of materialised rows are not cut into segments
  *   SYNTHHIP_NO_TILES=1           banks whose notes do not move in lock-step (onsets, envelopes of their own) are not classified tile
  *                                 by tile: every voice that holds an onset or a corner in the launch takes the general code
- *   SYNTHHIP_PREP_IN_GENERAL=1    long tile-classified launches resolve the next-but-one tile set in the general kernel, not the lean one
- *   SYNTHHIP_NO_MERGED=1          short tile-classified launches (up to sixteen tiles) as two kernels, like long ones
- *   SYNTHHIP_TILES_FOR_ALL=1     transition launches of lock-step banks tile-classified too instead of segmented (measured: the release
- *                                 block 80 -> 57 us, block 0 137 -> 174 us: not the default)
- *   SYNTHHIP_ALWAYS_GENERAL=1     the general-lists kernel of a split launch is launched even when provably idle
- *   SYNTHHIP_VARIANT=WFM          render kernel shape: waves per workgroup, frames per lane, min waves per SIMD (e.g. 484)
+ *   SYNTHHIP_VARIANT=WFM          render kernel shape: waves per workgroup, frames per lane, min waves per SIMD -- one of 484, 444,
+ *                                 844, 821, 421, 211 (the shapes the library chooses between by itself)
  *   SYNTHHIP_GROUPS=n             voice groups of a render launch
- *   SYNTHHIP_GEN_LF=4|8|16        frames per lane of the lean materialisation kernel;  SYNTHHIP_GEN_ROWS=parts: the row-major walk (k_generate_lean_rows), parts per segment
- *   SYNTHHIP_GEN_SPLIT=1|2|4|8    workgroups that share a chunk's lean records in the materialisation kernel (default 2)
- *   SYNTHHIP_GEN_SUB=1..16        split of a segmented launch's first segment;  SYNTHHIP_SEG_MIN=frames of its dense first segment
- *   SYNTHHIP_RESAMPLE_PK=0|1      the packed 16-bit mono resample kernel off / on
- *   SYNTHHIP_RESAMPLE_LANES=0|1   16-bit mono resample with the output frames dealt to the lanes (k_resample_mono16: no LDS bank conflicts,
- *                                 16 instead of 20 instructions per sample -- and not faster; default off; bit-identical)
- *   SYNTHHIP_RESAMPLE_SPLIT=0|1   16-bit mono resample: a thread's 16 output frames as two runs of 8, so that the 16-byte stores of
- *                                 neighbouring lanes adjoin (default on; bit-identical either way)
- *   SYNTHHIP_COMM_PRIORITY=-1|0|1 priority of the communication stream of the multi-GPU path (high / as the render streams / low)
- * (SYNTHHIP_LIB, read by the Python binding, names another build of this library to load.) */
+ *   SYNTHHIP_POOL_FILL=0..255     device blocks that grow are filled with this byte first (diagnostics: a kernel that reads what it
+ *                                 should have written shows)
+ * (SYNTHHIP_LIB, read by the Python binding, names another build of this library to load; SYNTHHIP_ALLOW_STALE=1 lets it load a
+ * library whose sources have changed when rebuilding fails.) */
 
 /* ---- device buffers ---------------------------------------------------------------- */
 int    sh_buf_alloc(size_t bytes, sh_buf** out);

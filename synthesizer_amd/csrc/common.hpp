@@ -69,26 +69,10 @@ struct Knobs {
     bool no_overlap = false;       // SYNTHHIP_NO_OVERLAP=1: consecutive renders stay on one stream
     bool no_split = false;         // SYNTHHIP_NO_SPLIT=1: lean and general code in one kernel
     bool no_seg = false;           // SYNTHHIP_NO_SEG=1: transition launches / row heads are not cut into segments
-    int  tiles_for_all = -1;       // SYNTHHIP_TILES_FOR_ALL=0|1: transition launches of lock-step banks segmented (0) or tile-classified (1); -1: the default
-    bool prep_in_general = false;  // SYNTHHIP_PREP_IN_GENERAL=1: long tile-classified launches resolve the next-but-one tile set in the general kernel
-    bool no_merged = false;        // SYNTHHIP_NO_MERGED=1: short tile-classified launches as two kernels, like long ones
     bool no_tiles = false;         // SYNTHHIP_NO_TILES=1: banks whose notes do not move in lock-step are not classified tile by tile
-    bool always_general = false;   // SYNTHHIP_ALWAYS_GENERAL=1: the general-lists kernel of a split launch is always launched
     bool no_small_pipeline = false;// SYNTHHIP_NO_SMALL_PIPELINE=1: single-group banks render on one stream (round-2 behaviour)
-    bool prepare_in_tile = false;  // SYNTHHIP_PREPARE_IN_TILE=1: the next-but-one block's records are resolved by the first tile workgroups
-                                   //   before their own work (round-2 behaviour) instead of by workgroups of their own
-    int  variant = 0;              // SYNTHHIP_VARIANT=WFM: waves, frames per lane, min waves per SIMD of the render kernel
+    int  variant = 0;              // SYNTHHIP_VARIANT=WFM: waves, frames per lane, min waves per SIMD of the render kernel (484, 444, 844, 821, 421, 211)
     int  groups = 0;               // SYNTHHIP_GROUPS: voice groups of a render launch
-    int  gen_split = 0;            // SYNTHHIP_GEN_SPLIT=1|2|4|8: workgroups that share a chunk's lean records in the materialisation kernel (0: default)
-    int  gen_lf = 0;               // SYNTHHIP_GEN_LF=4|8|16: frames per lane of the lean materialisation kernel
-    int  gen_sub = 4;              // SYNTHHIP_GEN_SUB=1..16: split of a segmented launch's first segment
-    long seg_min = 0;              // SYNTHHIP_SEG_MIN: frames of a segmented launch's dense first segment
-    int  gen_rows = 0;             // SYNTHHIP_GEN_ROWS=1|2: rows per wave of the lean materialisation kernel
-    int  resample_pk = -1;         // SYNTHHIP_RESAMPLE_PK=0|1: packed 16-bit mono resample kernel
-    int  resample_lanes = -1;      // SYNTHHIP_RESAMPLE_LANES=0|1: 16-bit mono resample with the frames dealt to the lanes (k_resample_mono16)
-    int  resample_split = -1;      // SYNTHHIP_RESAMPLE_SPLIT=0|1: 16-bit mono resample, a thread's 16 frames as two runs of 8 (stores of consecutive lanes adjoin)
-    int  comm_priority = 0;        // SYNTHHIP_COMM_PRIORITY=-1|0|1: priority of the communication stream (high / as the render streams / low)
-    long lds_pad = 0;              // SYNTHHIP_LDS_PAD: bytes of unused dynamic LDS per workgroup of the plain render launch (occupancy experiments)
     int  pool_fill = -1;           // SYNTHHIP_POOL_FILL=0..255: blocks that grow are filled with this byte first (diagnostics)
 };
 const Knobs& knobs();

@@ -106,17 +106,10 @@ int sh_dist_init(int rank, int world, const void* id128) {
     r.world = world;
     SH_HIP(hipMalloc((void**)&r.token, sizeof(double)));
     SH_HIP(hipMemsetAsync(r.token, 0, sizeof(double), sh::state().stream));
-    {
-        // The communication stream is created like the render streams.  A stream of another PRIORITY (SYNTHHIP_COMM_PRIORITY = -1
-        // high, 1 low) gets a hardware queue of its own, but with two priority levels active the render launches themselves slow
-        // down (rocprofv3 / tools/ring_probe.py, round 3, 1024 voices, 8 blocks per batch: 59 and 60 us per block against 46 in a
-        // cold single shot); what keeps the exchange off the renders' critical path is WHEN it is enqueued (sh_dist_mark_slot).
-        int lo_prio = 0, hi_prio = 0;
-        SH_HIP(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
-        const int want = sh::knobs().comm_priority;
-        if (want == 0) SH_HIP(hipStreamCreateWithFlags(&sh::state().comm_stream, hipStreamNonBlocking));
-        else SH_HIP(hipStreamCreateWithPriority(&sh::state().comm_stream, hipStreamNonBlocking, want < 0 ? hi_prio : lo_prio));
-    }
+    // The communication stream is created like the render streams.  (Measured in round 3: a stream of another PRIORITY gets a hardware
+    // queue of its own, but with two priority levels active the render launches themselves slow down -- 59 and 60 us per block against
+    // 46; what keeps the exchange off the renders' critical path is WHEN it is enqueued: sh_dist_mark_slot.)
+    SH_HIP(hipStreamCreateWithFlags(&sh::state().comm_stream, hipStreamNonBlocking));
     for (int k = 0; k < Rccl::SLOTS; ++k) {
         SH_HIP(hipEventCreateWithFlags(&r.ev_rendered[k], hipEventDisableTiming));
         SH_HIP(hipEventCreateWithFlags(&r.ev_rendered2[k], hipEventDisableTiming));

@@ -226,11 +226,9 @@ uint32_t plan_segments(const sh_bank* b, uint64_t start, uint32_t nframes, uint6
     const uint64_t flat = b->env_flat_from, rel = b->env_flat_until;       // last decay end, first sustain end
     const bool shared = corners && !b->env_corners.empty();
     if (!shared && pos < flat && flat < end && flat - pos <= max_len) { pos = flat; cuts[nc++] = pos; }
-    const long seg_min = sh::knobs().seg_min;
     while (pos < end && nc <= SEG_MAX) {
         uint64_t next = pos < T ? T : 2 * pos;
-        if (pos == start && start < (uint64_t)seg_min && (uint64_t)seg_min < end) next = (uint64_t)seg_min;   // the dense first segment
-        else if (shared) {
+        if (shared) {
             for (uint64_t c : b->env_corners)
                 if (c > pos && c < next) { next = c; break; }
         } else if (pos < rel && rel < next) {

@@ -358,96 +358,8 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
     }
 }
 
-// The same materialisation walked ROW by row: grid = (segments x parts, record slots) -- a workgroup takes ONE lean record (held in
-// SGPRs for its whole life: one batch of scalar loads per workgroup instead of one per (wave, record) pair), and its four waves
-// walk that voice's row through their part of the segment, tile after tile: consecutive waves write consecutive kilobytes, a
-// workgroup writes a contiguous run of a row for as long as it lives.  The kernel above sends every workgroup through 64 rows 1.9 MB
-// apart, 16 KB in each; this one keeps the writes of a workgroup in one DRAM neighbourhood (the lesson of the read-only kernels,
-// fewer, longer-lived workgroups whose accesses are adjacent).  Equal segments only (no head table).
-template <int FPL>
-__global__ __launch_bounds__(256, 4) void k_generate_lean_rows(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
-                                                              uint32_t total, uint32_t seg_frames, uint32_t parts,
-                                                              float* __restrict__ out32_all, size_t stride) {
-    const uint32_t seg = blockIdx.x / parts, part = blockIdx.x % parts;
-    const uint32_t c = blockIdx.y >> 6, pos = blockIdx.y & 63;
-    const LaunchSet cur = segment_set(base, seg, nvoices);
-    if (pos >= as_const(cur.counts)[4 * c]) return;                   // (uniform) no such record in this chunk's list
-    __shared__ shm::sc_pair trig[shm::TRIG_N];
-    for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t seg_first = seg * seg_frames;
-    const uint32_t n = total - seg_first < seg_frames ? total - seg_first : seg_frames;       // frames of this segment
-    const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64 + pos;
-    const uint32_t remain = q->remain, vi = q->vi;
-    const double amp = q->amplitude, g0u = q->g0u;
-    const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
-    const double tb = q->t0_b, db = q->dt_b, ob = q->off_b, rcb = q->rot_c_b, rsb = q->rot_s_b;
-    double poly[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
-    asm volatile("" :: "s"(amp), "s"(g0u), "s"(remain), "s"(vi), "s"(ta), "s"(da), "s"(rca), "s"(rsa), "s"(tb), "s"(db), "s"(ob), "s"(rcb), "s"(rsb),
-                 "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
-                 "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
-                 "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
-    const double ag = amp * g0u;
-    float* __restrict__ row = out32_all + (size_t)vi * stride + seg_first;
-    const uint32_t tiles = (n + 64 * FPL - 1) / (64 * FPL), per_part = (tiles + parts - 1) / parts;
-    const uint32_t t_begin = part * per_part;
-    uint32_t t_end = t_begin + per_part;
-    if (t_end > tiles) t_end = tiles;
-    for (uint32_t t = t_begin + wave; t < t_end; t += 4) {
-        const uint32_t tile0 = t * (64 * FPL);
-        uint32_t tile_last = tile0 + 64 * FPL - 1;
-        if (tile_last > n - 1) tile_last = n - 1;
-        const uint32_t i0 = tile0 + lane;
-        const double di0 = (double)i0;
-        double t_base = ta, dt = da, rc = rca, rs = rsa, off = 0.0;
-        bool straddle = false;
-        if (remain != 0xFFFFFFFFu && tile_last >= remain) {   // not wholly on the first piece
-            straddle = tile0 < remain;
-            if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
-        }
-        const LaneTheta theta{di0, t_base, dt, off, ta, da, tb, db, ob, i0, remain, straddle};
-        double s0, c0, s1, c1;
-        shm::sincos_tab(theta(0), trig, s0, c0);
-        if (straddle) {
-            shm::sincos_tab(theta(1), trig, s1, c1);
-        } else {
-            s1 = fma(s0, rc, c0 * rs);
-            c1 = fma(c0, rc, -(s0 * rs));
-        }
-        const double k2 = rc + rc;
-        s0 *= ag;
-        s1 *= ag;
-        float* __restrict__ col = row + i0;
-        const bool full = tile0 + 64 * FPL <= n;
-#pragma unroll
-        for (int h = 0; h < FPL; h += 2) {
-            double p0 = fma(poly[0], c0, poly[1]), p1 = fma(poly[0], c1, poly[1]);
-#pragma unroll
-            for (int u = 2; u < 16; ++u) {
-                p0 = fma(p0, c0, poly[u]);
-                p1 = fma(p1, c1, poly[u]);
-            }
-            if (full || i0 + (uint32_t)h * 64u < n) __builtin_nontemporal_store((float)(p0 * s0), col + h * 64);
-            if (full || i0 + (uint32_t)(h + 1) * 64u < n) __builtin_nontemporal_store((float)(p1 * s1), col + (h + 1) * 64);
-            if (h + 2 < FPL) {
-                if (straddle) {
-                    shm::sincos_tab(theta(h + 2), trig, s0, c0);
-                    shm::sincos_tab(theta(h + 3), trig, s1, c1);
-                    s0 *= ag;
-                    s1 *= ag;
-                } else {
-                    const double s2 = fma(k2, s1, -s0), c2 = fma(k2, c1, -c0);
-                    const double s3 = fma(k2, s2, -s1), c3 = fma(k2, c2, -c1);
-                    s0 = s2; c0 = c2; s1 = s3; c1 = c3;
-                }
-            }
-        }
-    }
-}
+// (Measured and dropped in round 3: the same materialisation walked ROW by row -- one record per workgroup held in SGPRs, contiguous runs
+// of a row per workgroup: 0.515 of HBM against 0.52; CHANGELOG item 38.)
 
 }  // namespace
 
@@ -510,17 +422,9 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
         // the chip short of workgroups (1024 x 48 000 at sixteen: 12 x 16 = 192 workgroups of four 1024-frame tiles)
         int lf = 16;
         while (lf > 4 && (uint64_t)sh::div_up(nframes, 256 * lf) * sh::div_up(b->nvoices, 64) < 512) lf /= 2;
-        {
-            const int forced = sh::knobs().gen_lf;
-            if (forced == 4 || forced == 8 || forced == 16) lf = forced;
-        }
         const int LF = lf;
-        // workgroups per chunk of records: enough waves for several rounds of the chip's wave slots (SYNTHHIP_GEN_SPLIT overrides)
-        uint32_t rsplit = 2;
-        {
-            const int forced = sh::knobs().gen_split;
-            if (forced == 1 || forced == 2 || forced == 4 || forced == 8) rsplit = (uint32_t)forced;
-        }
+        // workgroups per chunk of records: enough waves for several rounds of the chip's wave slots (1, 4, 8 measured: CHANGELOG item 38)
+        const uint32_t rsplit = 2;
 #define SH_GEN_LEAN(GRID_, ...) do { \
             if (LF == 16) hipLaunchKernelGGL(k_generate_lean_harm<16>, GRID_, dim3(256), 0, st, __VA_ARGS__); \
             else if (LF == 8) hipLaunchKernelGGL(k_generate_lean_harm<8>, GRID_, dim3(256), 0, st, __VA_ARGS__); \
@@ -586,12 +490,6 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
         }
         SegTab none;
         none.n = 0;
-        if (sh::knobs().gen_rows > 0 && LF == 16) {
-            // row-major walk (SYNTHHIP_GEN_ROWS = parts per segment): see k_generate_lean_rows
-            const uint32_t parts = (uint32_t)sh::knobs().gen_rows;
-            hipLaunchKernelGGL(k_generate_lean_rows<16>, dim3(nseg * parts, (unsigned)set_slots(b->nvoices)), dim3(256), 0, st, trig_table(), base, b->nvoices,
-                               nframes, nseg == 1 ? (nframes + 1023u) / 1024u * 1024u : SEG, parts, o, stride);
-        } else
         SH_GEN_LEAN(dim3(sh::div_up(nframes, 256 * LF), nchunks * rsplit), trig_table(), base, b->nvoices, nframes,
                     nseg == 1 ? (nframes + 1023u) / 1024u * 1024u : SEG, o, stride, none, rsplit);
 #undef SH_GEN_LEAN

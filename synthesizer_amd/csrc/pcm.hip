@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void k_resample_lds(const T* __restrict__ in, 
 // the thread's frames are two runs of FR/2, 256*FR/2 frames apart, so that each of its stores is one 16-byte vector NEXT to its
 // neighbour lanes' (a wave's store instruction then writes 1 KB of consecutive bytes; with one run of 16 16-bit frames a lane's two
 // 16-byte stores interleave with its neighbours' at a 32-byte stride).
-template <typename T, int VEC, int FR, bool PK, int GROUPS = 1>
+template <typename T, int VEC, int FR, int GROUPS = 1>
 __device__ __forceinline__ void resample_small_frames(const unsigned char* smem, T* __restrict__ out, const RatecvArgs& A, uint64_t m_first,
                                                       uint64_t q0, uint32_t r0, uint64_t lo_elem, uint64_t out_frames) {
     const T* lds = reinterpret_cast<const T*>(smem);
@@ -732,15 +732,6 @@ __device__ __forceinline__ void resample_small_frames(const unsigned char* smem,
                     const uint32_t byte_off = qe_elem * (uint32_t)sizeof(T);
                     const uint32_t* l32 = reinterpret_cast<const uint32_t*>(smem) + (byte_off >> 2);
                     pair = __builtin_amdgcn_alignbit(l32[1], l32[0], (byte_off & 3u) * 8u) ^ FLIP;
-                }
-                if constexpr (PK) {
-                    static_assert(!PK || (sizeof(T) == 2 && VEC == 1), "packed form: 16-bit mono");
-                    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-                    const uint32_t w = (A.outr - r) | (r << 16);
-                    const uint32_t u = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, pair), __builtin_bit_cast(ushort2v, w), 0u, false);
-                    const uint32_t q = (uint32_t)fma((double)u, A.inv_outr, half_inv);
-                    res[f * VEC + c] = (T)(q ^ (uint32_t)HALF);
-                    continue;
                 }
                 ua = (pair >> (8 * sizeof(T) * c)) & MASK;
                 ub = (pair >> (8 * sizeof(T) * (VEC + c))) & MASK;
@@ -786,10 +777,10 @@ __device__ __forceinline__ void resample_small_frames(const unsigned char* smem,
 //  * u = M + HALF*outr = (b-a)*r + (a+HALF)*outr in 24-bit multiplies (mod 2^32; 0 <= u < 2^32);
 //  * floor(u/outr) = trunc(fma(u, 1/outr, 1/(2 outr))) in float64, exact without a correction step.  See
 //    ratecv_small_int for why the floor equals audioop's float64 expression.
-// PK (16-bit mono, reduced rates below 65536): the interpolation's two products and their sum are ONE instruction -- the dword that
-// holds frames q and q + 1 (offset by HALF, as unsigned 16-bit halves) against the packed weights (outr - r, r):
-// u = ua (outr - r) + ub r = v_dot2_u32_u16 -- in place of two field extractions, a subtraction and two multiplies.
-template <typename T, int VEC, int FR, bool PK = false, int GROUPS = 1>
+// (Measured and dropped, bit-identical both: the interpolation as ONE v_dot2_u32_u16 on packed weights -- 0.395 vs 0.391 ms on 900 MB;
+// the output frames dealt to the lanes, no LDS bank conflicts and 16 instead of 20 instructions per sample -- not faster either:
+// CHANGELOG items 39 and 22; profiles/r03_summary.md.)
+template <typename T, int VEC, int FR, int GROUPS = 1>
 __global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in, T* __restrict__ out, RatecvArgs A,
                                                         uint64_t in_frames, uint64_t out_frames, uint32_t span_vecs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -820,92 +811,7 @@ __global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in
         }
     }
     __syncthreads();
-    resample_small_frames<T, VEC, FR, PK, GROUPS>(smem, out, A, m_first, q0, r0, lo_elem, out_frames);
-}
-
-// 16-bit mono once more, the frames dealt to the LANES: a wave takes 1024 consecutive output frames as 8 steps of 128, lane i the
-// frames 2i and 2i + 1 of each step.  Neighbouring lanes then read neighbouring (or the same) dwords of the staged span -- no bank
-// conflicts, where a run of 16 frames per lane puts the lanes 7.35 dwords apart and every second LDS cycle of k_resample_small<short,
-// 1, 16> was a conflict cycle (rocprofv3: SQ_LDS_BANK_CONFLICT 44 M of SQ_LDS_IDX_ACTIVE 83 M) -- and a wave's store instruction
-// writes 256 consecutive bytes (one dword per lane).  The arithmetic is resample_small_frames' with the remainder kept BIASED, R = r -
-// outr (mod 2^32): the carry of R + step is the wrap (v_add_co / v_addc), max(R', R' - outr) restores the bias, and the low 24 bits of
-// R are -(outr - r), so u = ub*outr - (ub - ua)(outr - r) = ua (outr - r) + ub r needs no remainder of its own: 16 VALU instructions
-// per output sample instead of 20.  (SYNTHHIP_RESAMPLE_LANES; bit-identical: tools/resample_split_probe.py compares CRCs.)
-__global__ __launch_bounds__(256) void k_resample_mono16(const short* __restrict__ in, short* __restrict__ out, RatecvArgs A,
-                                                         uint64_t in_frames, uint64_t out_frames, uint32_t span_vecs) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    short* lds = reinterpret_cast<short*>(smem);
-    typedef short ld_t __attribute__((ext_vector_type(8)));
-    constexpr uint32_t EPV = 8;
-    const uint64_t m_first = A.m_base + (uint64_t)blockIdx.x * 4096;
-    if (m_first >= out_frames) return;
-    uint64_t q0;
-    uint32_t r0;
-    {
-        uint64_t jf;
-        uint32_t df;
-        ratecv_index(A, m_first, jf, df);
-        r0 = df ? A.outr - df : 0u;
-        q0 = jf - (r0 != 0);
-    }
-    const uint64_t lo_elem = q0 & ~(uint64_t)(EPV - 1);
-    const uint64_t total_elems = in_frames;
-    for (uint32_t v = threadIdx.x; v < span_vecs; v += 256) {
-        const uint64_t e = lo_elem + (uint64_t)v * EPV;
-        if (e + EPV <= total_elems) {
-            reinterpret_cast<ld_t*>(lds)[v] = __builtin_nontemporal_load(reinterpret_cast<const ld_t*>(in + e));
-        } else {
-            for (uint32_t k = 0; k < EPV; ++k) lds[v * EPV + k] = (e + k < total_elems) ? in[e + k] : (short)0;
-        }
-    }
-    __syncthreads();
-    const uint32_t f0 = (threadIdx.x >> 6) * 1024u + 2u * (threadIdx.x & 63u);       // the lane's first frame within the workgroup
-    uint64_t m = m_first + f0;
-    if (m >= out_frames) return;
-    const double half_inv = 0.5 * A.inv_outr;
-    uint32_t R, qe;                                                                   // biased remainder, LDS element index of frame q
-    {
-        const uint32_t tot = r0 + __umul24(f0, A.inr);                                // < 2^29 (f0 < 4096, inr < 65536)
-        const uint32_t dq = (uint32_t)fma((double)tot, A.inv_outr, half_inv);
-        R = tot - dq * A.outr - A.outr;
-        qe = (uint32_t)(q0 - lo_elem) + dq;
-    }
-    const uint32_t t127 = 127u * A.inr;
-    const uint32_t q127 = (uint32_t)fma((double)t127, A.inv_outr, half_inv), r127 = t127 - q127 * A.outr;
-    auto sample = [&](uint32_t qel, uint32_t Rb) -> uint32_t {
-        const uint32_t* l32 = reinterpret_cast<const uint32_t*>(smem) + (qel >> 1);
-        const uint32_t pair = __builtin_amdgcn_alignbit(l32[1], l32[0], qel << 4) ^ 0x80008000u;      // the shift counts modulo 32
-        const uint32_t ua = pair & 0xffffu, ub = pair >> 16;
-        const uint32_t u = (uint32_t)__mul24((int)ub - (int)ua, (int)Rb) + __umul24(ub, A.outr);
-        return (uint32_t)fma((double)u, A.inv_outr, half_inv);                        // floor(u / outr) < 65536, exact (see above)
-    };
-    auto advance = [&](uint32_t& Rb, uint32_t& qel, uint32_t sr, uint32_t sq) {
-        uint32_t Rn;
-        const uint32_t c = __builtin_uadd_overflow(Rb, sr, &Rn) ? 1u : 0u;
-        qel += sq + c;
-        Rb = max(Rn, Rn - A.outr);
-    };
-    if (m_first + 4096 <= out_frames) {                                               // (uniform) every frame of the workgroup exists
-        uint32_t* o32 = reinterpret_cast<uint32_t*>(out + m);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const uint32_t a = sample(qe, R);
-            advance(R, qe, A.step_r, A.step_q);
-            const uint32_t b = sample(qe, R);
-            if (s < 7) advance(R, qe, r127, q127);
-            __builtin_nontemporal_store((a | (b << 16)) ^ 0x80008000u, o32 + 64 * s);
-        }
-        return;
-    }
-    for (int s = 0; s < 8 && m < out_frames; ++s, m += 128) {                         // the last workgroup of the output
-        const uint32_t a = sample(qe, R);
-        advance(R, qe, A.step_r, A.step_q);
-        const uint32_t b = sample(qe, R);
-        advance(R, qe, r127, q127);
-        const uint32_t word = (a | (b << 16)) ^ 0x80008000u;
-        if (m + 1 < out_frames) *reinterpret_cast<uint32_t*>(out + m) = word;
-        else out[m] = (short)(word & 0xffffu);
-    }
+    resample_small_frames<T, VEC, FR, GROUPS>(smem, out, A, m_first, q0, r0, lo_elem, out_frames);
 }
 
 uint64_t gcd_u64(uint64_t a, uint64_t b) {
@@ -1326,30 +1232,13 @@ static int resample_launch(const void* in, size_t in_frames, int nch, int width,
             if (svecs * 16 <= RS_LDS_BYTES) {
                 const uint32_t span_vecs = (uint32_t)svecs, lds_bytes = span_vecs * 16;
 #define SH_RM(T, V, F) hipLaunchKernelGGL((k_resample_small<T, V, F>), g2, dim3(256), lds_bytes, st, (const T*)in, (T*)out, A, (uint64_t)in_frames, (uint64_t)m_end, span_vecs)
-#define SH_RMP(T, V, F) hipLaunchKernelGGL((k_resample_small<T, V, F, true>), g2, dim3(256), lds_bytes, st, (const T*)in, (T*)out, A, (uint64_t)in_frames, (uint64_t)m_end, span_vecs)
-                // packed 16-bit mono form: bit-identical and not faster (round 3, 900 MB of mono input, same call: 44.1 -> 48 kHz 0.395 vs 0.391 ms,
-                // 96 -> 44.1 kHz 0.238 vs 0.240): two VALU instructions fewer per sample do not move a kernel whose waves wait on LDS and memory;
-                // kept behind SYNTHHIP_RESAMPLE_PK=1 for the record
-                const bool pk = sh::knobs().resample_pk == 1 && A.outr < 65536u;
-                // 16 frames per thread as two runs of 8 (GROUPS = 2): bit-identical, +0.4 / +2.2 / +4 % on 44.1 -> 48, 96 -> 44.1, 48 -> 44.1 kHz
-                // (tools/resample_split_probe.py, two A/B pairs in one call); SYNTHHIP_RESAMPLE_SPLIT=0 for the single run
-                if (wide && !pk && sh::knobs().resample_lanes == 1) {
-                    hipLaunchKernelGGL(k_resample_mono16, g2, dim3(256), lds_bytes, st, (const short*)in, (short*)out, A,
-                                       (uint64_t)in_frames, (uint64_t)m_end, span_vecs);
-                    SH_CHECK_LAUNCH("k_resample_mono16");
-                    return SH_OK;
-                }
-                if (wide && !pk && sh::knobs().resample_split != 0) {
-                    hipLaunchKernelGGL((k_resample_small<short, 1, 16, false, 2>), g2, dim3(256), lds_bytes, st, (const short*)in, (short*)out, A,
-                                       (uint64_t)in_frames, (uint64_t)m_end, span_vecs);
-                    SH_CHECK_LAUNCH("k_resample_small");
-                    return SH_OK;
-                }
-                if (wide) { if (pk) SH_RMP(short, 1, 16); else SH_RM(short, 1, 16); }
-                else if (width == 2) { if (nch == 1) { if (pk) SH_RMP(short, 1, 8); else SH_RM(short, 1, 8); } else if (nch == 2) SH_RM(short, 2, 4); else SH_RM(short, 4, 2); }
+                // 16-bit mono: 16 frames per thread as two runs of 8 (GROUPS = 2) -- a wave's store instruction then writes 1 KB of
+                // consecutive bytes: +0.4 / +2.2 / +4 % on 44.1 -> 48, 96 -> 44.1, 48 -> 44.1 kHz against one run of 16
+                if (wide) hipLaunchKernelGGL((k_resample_small<short, 1, 16, 2>), g2, dim3(256), lds_bytes, st, (const short*)in, (short*)out, A,
+                                             (uint64_t)in_frames, (uint64_t)m_end, span_vecs);
+                else if (width == 2) { if (nch == 1) SH_RM(short, 1, 8); else if (nch == 2) SH_RM(short, 2, 4); else SH_RM(short, 4, 2); }
                 else { if (nch == 1) SH_RM(signed char, 1, 8); else if (nch == 2) SH_RM(signed char, 2, 8); else SH_RM(signed char, 4, 4); }
 #undef SH_RM
-#undef SH_RMP
                 SH_CHECK_LAUNCH("k_resample_small");
                 return SH_OK;
             }

@@ -33,26 +33,10 @@ void load_knobs() {
     k.no_split = flag("SYNTHHIP_NO_SPLIT");
     k.no_seg = flag("SYNTHHIP_NO_SEG");
     k.no_tiles = flag("SYNTHHIP_NO_TILES");
-    k.no_merged = flag("SYNTHHIP_NO_MERGED");
-    k.prep_in_general = flag("SYNTHHIP_PREP_IN_GENERAL");
-    if (const char* e = getenv("SYNTHHIP_TILES_FOR_ALL")) k.tiles_for_all = atoi(e);
-    k.lds_pad = num("SYNTHHIP_LDS_PAD", 0);
-    k.always_general = flag("SYNTHHIP_ALWAYS_GENERAL");
     k.no_small_pipeline = flag("SYNTHHIP_NO_SMALL_PIPELINE");
-    k.prepare_in_tile = flag("SYNTHHIP_PREPARE_IN_TILE");
     k.variant = (int)num("SYNTHHIP_VARIANT", 0);
     k.groups = (int)num("SYNTHHIP_GROUPS", 0);
-    k.gen_lf = (int)num("SYNTHHIP_GEN_LF", 0);
-    k.gen_split = (int)num("SYNTHHIP_GEN_SPLIT", 0);
-    k.gen_sub = (int)num("SYNTHHIP_GEN_SUB", 4);
-    if (k.gen_sub < 1 || k.gen_sub > 16) k.gen_sub = 4;
-    k.seg_min = num("SYNTHHIP_SEG_MIN", 0);
-    k.gen_rows = (int)num("SYNTHHIP_GEN_ROWS", 0);
-    k.resample_pk = (int)num("SYNTHHIP_RESAMPLE_PK", -1);
-    k.resample_split = (int)num("SYNTHHIP_RESAMPLE_SPLIT", -1);
-    k.resample_lanes = (int)num("SYNTHHIP_RESAMPLE_LANES", -1);
     k.pool_fill = (int)num("SYNTHHIP_POOL_FILL", -1);
-    k.comm_priority = (int)num("SYNTHHIP_COMM_PRIORITY", 0);
     g_knobs = k;
 }
 

@@ -367,15 +367,15 @@ print("ok")
 '''
 
 
-def test_resample_mono16_kernel_variants_vs_live_audioop(gpu):
-    """The 16-bit mono kernels behind SYNTHHIP_RESAMPLE_SPLIT / _LANES / _PK (two runs of 8 frames per thread -- the default --, one
-    run of 16, the frames dealt to the lanes, the packed dot product): each against live audioop.ratecv, tails and extremes included."""
+def test_resample_mono16_kernel_vs_live_audioop(gpu):
+    """The 16-bit mono kernel (two runs of 8 frames per thread; rounds 2-3 kept three more bit-identical forms behind knobs -- removed
+    in round 4, CHANGELOG items 22 and 39) against live audioop.ratecv, tails and extremes included, in a process of its own."""
     import os
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     clean = {k: v for k, v in os.environ.items() if not k.startswith("SYNTHHIP_") or k in ("SYNTHHIP_LIB", "SYNTHHIP_DEVICE")}
-    for env in ({}, {"SYNTHHIP_RESAMPLE_SPLIT": "0"}, {"SYNTHHIP_RESAMPLE_LANES": "1"}, {"SYNTHHIP_RESAMPLE_PK": "1"}):
+    for env in ({},):
         p = subprocess.run([sys.executable, "-c", _RESAMPLE_CHILD % str(root)], env=dict(clean, **env), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (env, p.stderr[-2000:])
