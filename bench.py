@@ -100,6 +100,29 @@ def cpu_baseline(frames: int, all_cores: bool = True):
            "sample": "1024 voices (the bench's: Harmonics x16 + ADSR attack 0.01 / decay 0.05 / sustain spanning the run, level 0.6) "
                      "x the first %d frames (%.3f s of audio: attack, decay and the start of the sustain), pure-Python oracle "
                      "generators + float bus sum, %.1f s wall" % (frames, frames / SR, dt)}
+    # ... and a window that matches the phase the GPU's timed region sits in: the sustain plateau -- the generators
+    # run 3072 frames (attack and decay, untimed) and the NEXT `frames` frames are timed; same voices, same interpreter, one core
+    try:
+        skip_blocks = -(-3072 // O.norm_osc_blocksize)
+        gens = [v.blocks() for v in voices]
+        for g_ in gens:
+            for _ in range(skip_blocks):
+                next(g_)
+        t0 = time.perf_counter()
+        nb = -(-frames // O.norm_osc_blocksize)
+        blocks = []
+        for g_ in gens:
+            row = []
+            for _ in range(nb):
+                row.extend(next(g_))
+            blocks.append(row[:frames])
+        O.mix_bus(blocks, gains)
+        dtp = time.perf_counter() - t0
+        out["sustain_window"] = {"value": VOICES_PER_GPU * frames / dtp / 1e6, "unit": "Msamples/s", "cores": 1, "wall_s": dtp,
+                                 "sample": "the same voices, frames %d .. %d of the note (the constant-gain plateau the GPU's timed blocks lie on), "
+                                           "pure-Python generators + float bus sum" % (skip_blocks * O.norm_osc_blocksize, skip_blocks * O.norm_osc_blocksize + frames)}
+    except Exception as e:
+        out["sustain_window"] = {"error": str(e)}
     # the same sample through the C restatement of the oracle (oracle/oracle.c, one core): what a compiled single-threaded
     # CPU implementation of this arithmetic does -- a fairer yardstick than the interpreter
     try:
@@ -193,9 +216,9 @@ def _by_prefix(table, prefix):
     return None
 
 
-def steady(N, call, min_seconds=0.05, reps=5, max_loops=400):
+def steady(N, call, min_seconds=0.05, reps=5, max_loops=400, spread=None):
     """Average time (ms, HIP events on the library stream) of `call` once the clocks are up: loops of `reps` calls until
-    the loops add up to min_seconds; the median loop counts."""
+    the loops add up to min_seconds; the median loop counts (spread: a dict that receives min / max / loops)."""
     call()
     N.sync()
     loops, total = [], 0.0
@@ -206,6 +229,8 @@ def steady(N, call, min_seconds=0.05, reps=5, max_loops=400):
         ms = N.timer_stop()
         loops.append(ms / reps)
         total += ms / 1e3
+    if spread is not None:
+        spread.update({"min_ms": min(loops), "max_ms": max(loops), "loops": len(loops), "timed_s": total})
     return statistics.median(loops)
 
 
@@ -216,10 +241,14 @@ def pcm_rows(N):
     L = N.lib()
     rows = {}
 
-    def row(name, call, nbytes, **extra):
-        ms = steady(N, lambda: N.check(call()), min_seconds=0.02, reps=3)
+    def row(name, call, nbytes, min_seconds=0.02, **extra):
+        sp = {}
+        ms = steady(N, lambda: N.check(call()), min_seconds=min_seconds, reps=3, spread=sp)
         rows[name] = dict({"ms": ms, "bytes": nbytes, "GBps": nbytes / (ms / 1e3) / 1e9,
                            "frac_hbm": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}, **extra)
+        if min_seconds >= 0.1:      # a row timed like the headline: the spread says what a difference between two runs means
+            rows[name].update({"frac_hbm_min": nbytes / (sp["max_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, "frac_hbm_max": nbytes / (sp["min_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
+                               "loops": sp["loops"], "timed_s": sp["timed_s"]})
         return ms
 
     # configs[4]: 8-channel, 10-minute float32 PCM, 96 kHz -> 44.1 kHz (1.84 GB in, 0.85 GB out)
@@ -243,7 +272,8 @@ def pcm_rows(N):
         frames = 450_000_000 // nch_
         nout_m = L.sh_resample_out_frames(frames, inr, outr)
         big = N.DeviceBuffer(nout_m * 2 * nch_)
-        row(name, lambda: L.sh_resample(src.handle, frames, nch_, 2, 0, inr, outr, big.handle, None), (frames + nout_m) * 2 * nch_)
+        row(name, lambda: L.sh_resample(src.handle, frames, nch_, 2, 0, inr, outr, big.handle, None), (frames + nout_m) * 2 * nch_,
+            min_seconds=0.25 if nch_ == 1 else 0.02)
         big.free()
     # mixer chain: 1024 int16 voices x 10 s stereo (saturating fold in voice order), 2N+2 bytes per sample
     nv, nsamples = 1024, 48000 * 2 * 10
@@ -299,6 +329,21 @@ def pcm_rows(N):
     return rows
 
 
+def steady_render_kernel(name):
+    """Is this kernel name (as rocprofv3 prints it, shortened by tools/summarize_profiles.py) one of the render kernels of a STEADY block?
+    k_render_lean<W, F, M, KINDS, SEG> with SEG = false, k_render_general<W, F, M, KIND> with KIND != 1 (GEN_SEG), k_render_combined,
+    k_render_tiles -- not the kernels of a segmented transition launch (the first block of a profiled run)."""
+    m = re.match(r"k_render_(lean|general|combined|tiles)<([^>]*)>", name)
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(2).split(",")]
+    if m.group(1) == "lean":
+        return args[-1] in ("false", "0")
+    if m.group(1) == "general":
+        return args[-1] != "1"
+    return True
+
+
 def config_roofline(prof, tag, voice_samples, ms, algorithmic_bytes):
     """Roofline of a BASELINE config's render launch from the committed counters of ITS profiling pass (profiles/rNN_counters.json,
     key "<tag>:<kernel>"; tools/profile_round.sh runs bench.py --only-config <tag> under rocprofv3): float64 lane-operations per
@@ -306,9 +351,8 @@ def config_roofline(prof, tag, voice_samples, ms, algorithmic_bytes):
     per dispatch against the algorithmic bytes."""
     best, name = None, None
     for k_, v_ in prof["counters"].items():
-        m = re.match(re.escape(tag) + r":k_bank_render<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)>", k_)
-        if m and int(m.group(1)) < 6 and (best is None or v_.get("SQ_INSTS_VALU_FMA_F64", 0) > best.get("SQ_INSTS_VALU_FMA_F64", 0)):
-            best, name = v_, k_             # (modes 6 .. 8: the segmented transition launch of the loop's first block, not the steady state)
+        if k_.startswith(tag + ":") and steady_render_kernel(k_.split(":", 1)[1]) and (best is None or v_.get("SQ_INSTS_VALU_FMA_F64", 0) > best.get("SQ_INSTS_VALU_FMA_F64", 0)):
+            best, name = v_, k_             # (not the segmented transition launch of the loop's first block: that is not the steady state)
     if not best or not all(k in best for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")):
         return {"bound": "valu_f64", "note": "no counters for this config in profiles/ (tools/profile_round.sh writes them)"}
     ops = (best["SQ_INSTS_VALU_FMA_F64"] + best["SQ_INSTS_VALU_MUL_F64"] + best["SQ_INSTS_VALU_ADD_F64"]) * 64.0 / voice_samples
@@ -323,7 +367,40 @@ def config_roofline(prof, tag, voice_samples, ms, algorithmic_bytes):
             "source": prof.get("counters_source")}
 
 
-def staggered_row(N, F):
+def staggered_roofline(prof, sounding_voice_samples, ms):
+    """The literal-ADSR row's roofline: float64 lane-operations of BOTH kernels of a tile-classified launch
+    (k_render_tiles: the lean pairs; k_render_general<.., 2>: the general pairs) per SOUNDING voice-sample -- 0.76 of the players sound at
+    any time -- from the counters of the row's own profiling pass (profiles/rNN_counters.json, keys "staggered:<kernel>"), against the
+    issue peak; and the kernels' own durations from the same pass (two launches in flight: a kernel's duration is not the time per block)."""
+    ks = {k_.split(":", 1)[1]: v_ for k_, v_ in prof["counters"].items() if k_.startswith("staggered:") and steady_render_kernel(k_.split(":", 1)[1])}
+    need = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")
+    ks = {k_: v_ for k_, v_ in ks.items() if all(n in v_ for n in need)}
+    if not ks:
+        return {"bound": "valu_f64", "note": "no counters for this row in profiles/ (tools/profile_round.sh writes them)"}
+    f64 = sum(sum(v_[n] for n in need) for v_ in ks.values())
+    valu = sum(v_.get("SQ_INSTS_VALU", 0) for v_ in ks.values())
+    ops = f64 * 64.0 / sounding_voice_samples
+    achieved = sounding_voice_samples * ops / (ms / 1e3) / 1e12
+    durations = {}
+    try:
+        import csv
+        newest = sorted((ROOT / "profiles").glob("r*_staggered_kernel_stats.csv"))[-1]
+        for r in csv.DictReader(open(newest)):
+            m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", r["Name"])
+            if m and m.group(1).startswith("k_render_"):
+                durations[m.group(1)] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
+    except Exception:
+        pass
+    return {"kernels": sorted(ks), "bound": "valu_f64", "ops_per_sounding_voice_sample": ops,
+            "valu_instructions_per_sounding_voice_sample": valu * 64.0 / sounding_voice_samples if valu else None,
+            "achieved": achieved, "peak": FP64_PEAK_TOPS, "unit": "T f64 lane-ops/s", "frac": achieved / FP64_PEAK_TOPS,
+            "sounding_voice_samples_per_block": sounding_voice_samples, "avg_launch_ms": ms,
+            "kernel_durations_under_rocprofv3": durations, "source": prof.get("counters_source"),
+            "note": "frac counts the float64 operations of the SOUNDING voice-samples only (0.76 of 1024 players x frames); the counters are per "
+                    "dispatch of a steady block; kernel durations: two launches in flight, so a kernel's duration is about twice the time per block"}
+
+
+def staggered_row(N, F, prof=None):
     from synthesizer_amd import oscillators as G
     from synthesizer_amd import workloads as W
     from synthesizer_amd.mixer import VoiceBank
@@ -371,6 +448,7 @@ def staggered_row(N, F):
         cpos[0] += 1
     ms_chunk = steady(N, chunk, min_seconds=0.05, reps=8 * SR // cf)
     return {"players": slots, "voices_in_the_table": len(voices), "ms_per_step": ms, "value": slots * F / (ms / 1e3) / 1e6, "unit": "Msamples/s",
+            "roofline": staggered_roofline(prof if prof is not None else committed_profile(), slots * F * 0.76, ms),
             "from_a_standing_start_ms_per_step": ms_cold,
             "realtime_chunks_4096": {"ms_per_chunk": ms_chunk, "x_real_time": cf / SR / (ms_chunk / 1e3),
                                      "note": "the same table rendered 4096 frames per call (tile-classified launches at every block length)"},
@@ -671,11 +749,9 @@ def main() -> int:
     fused_bytes = 8.0 * F            # algorithmic: one float32 stereo frame written per output frame
     # float64 VALU lane-operations per voice-sample of the render kernel on this workload, from the committed rocprofv3
     # counters: (SQ_INSTS_VALU_FMA_F64 + MUL_F64 + ADD_F64) wave-instructions x 64 lanes / voice-samples per dispatch
-    # (the render kernel = the k_bank_render instantiation with the most float64 FMAs: the lean kernel of a split launch)
+    # (the render kernel = the k_render_* instantiation with the most float64 FMAs: the lean kernel of a split launch)
     # (the instantiations of a segmented transition launch -- MODE 6, 7, 8: block 0 of the profiled run -- are not the steady state)
-    def steady_render(name):
-        m = re.match(r"k_bank_render<\s*\d+,\s*\d+,\s*\d+,\s*(\d+)>", name)
-        return bool(m) and int(m.group(1)) < 6
+    steady_render = steady_render_kernel
     render_name, render_counters = None, None
     for k_, v_ in prof["counters"].items():
         if steady_render(k_) and (render_counters is None or v_.get("SQ_INSTS_VALU_FMA_F64", 0) > render_counters.get("SQ_INSTS_VALU_FMA_F64", 0)):
@@ -690,7 +766,7 @@ def main() -> int:
         lane_ops, flops_per_vs = 25.97, 25.97 + 16448494 * 64.0 / (VOICES_PER_GPU * SR)     # profiles/r01_summary.md
         ops_source = "profiles/r01_summary.md (literal: no rNN_counters.json committed)"
     valu_achieved = local_voices * F * lane_ops / kern_s / 1e12
-    # HBM traffic of one block: every k_bank_render dispatch of it (lean + general-lists kernel of a split launch)
+    # HBM traffic of one block: every render dispatch of it (lean + general-lists kernel of a split launch)
     render_traffic = [v_["hbm_bytes"] for k_, v_ in prof["traffic"].items() if steady_render(k_)]
     traffic_bytes = sum(render_traffic) if render_traffic else None
     out = {
@@ -723,10 +799,12 @@ def main() -> int:
                          "aborts (exit 3) unless RCCL's world equals WORLD_SIZE and the PCI ids are distinct"},
         "verified": verified,
         "roofline": {
-            "kernel": render_name or "k_bank_render<4, 8, 4, 3>", "bound": "valu_f64",
-            "kernel_note": "k_bank_render<WAVES, FPL, MINW, MODE>: <4, 8, 4, 3> = the lean Harmonics kernel of a split launch (table lookup + "
-                           "rotation + three-term recurrence, eight frames per lane); <4, 4, 4, 4> = the general-lists kernel that follows it "
-                           "on the same stream and leaves at once when no voice needs the general code",
+            "kernel": render_name or "k_render_lean<4, 8, 4, 0, false>", "bound": "valu_f64",
+            "kernel_note": "k_render_lean<WAVES, FPL, MINW, KINDS, SEG>: <4, 8, 4, 0, false> = the lean Harmonics kernel of a split launch (table lookup + "
+                           "rotation + three-term recurrence + four Horner chains at a time, eight frames per lane); k_render_general<4, 4, 4, 0> = the "
+                           "general-lists kernel that follows it on the same stream where a launch can hold a voice that needs the general code",
+            "clock_note": "peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz; under this load the chip holds 2.12-2.18 GHz (s_memtime / s_memrealtime per "
+                          "wavefront, profiles/r04_headline_phases.md): at that clock the stream of launches issues within 6-8 % of what the SIMDs can",
             "achieved": valu_achieved, "peak": FP64_PEAK_TOPS, "unit": "T f64 lane-ops/s", "frac": valu_achieved / FP64_PEAK_TOPS,
             "ops_per_voice_sample": lane_ops, "ops_source": ops_source,
             "flops": {"achieved_TFLOPs": local_voices * F * flops_per_vs / kern_s / 1e12, "peak_TFLOPs": 2 * FP64_PEAK_TOPS,
@@ -825,7 +903,7 @@ def main() -> int:
     # ---- notes that do not move in lock-step: 1024 players re-triggering SURVEY 8(d)'s literal note (0.76 s of sound) every second,
     # onsets spread uniformly over the second; one-second blocks 1 .. 20 of the piece ----
     if world == 1 and not args.no_configs:
-        out["staggered_notes"] = staggered_row(N, F)
+        out["staggered_notes"] = staggered_row(N, F, prof)
         out["staggered_notes"]["x_headline"] = out["staggered_notes"]["ms_per_step"] / out["ms_per_step"]     # (same run, same box, same protocol)
 
     # ---- two-step path on rank 0's shard: materialise (generate) + HBM-bound mix ----

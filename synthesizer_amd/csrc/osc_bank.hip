@@ -347,7 +347,8 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
              (voices[i].fm_mode == SH_FM_NONE && (voices[i].kind == SH_SINE || voices[i].kind == SH_SAWTOOTH || voices[i].kind == SH_SQUARE ||
                                                   voices[i].kind == SH_TRIANGLE || voices[i].kind == SH_PULSE)))) {
             b->lean_candidates += 1;
-            if (voices[i].kind != SH_HARMONICS) b->lean_fm_candidates += 1;       // needs the kernel with all record kinds
+            if (voices[i].kind != SH_HARMONICS) b->lean_fm_candidates += 1;       // needs a kernel with other record kinds
+            if (voices[i].kind == SH_SINE && voices[i].fm_mode == SH_FM_SINE) b->lean_fmsine_candidates += 1;
         }
     for (uint32_t i = 0; i < nvoices; ++i)
         if (voices[i].start_frame) b->has_onsets = true;

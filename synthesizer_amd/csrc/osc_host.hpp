@@ -80,6 +80,7 @@ struct sh_bank {
     void        void_specs() { for (auto& q : spec) q.valid = false; last_target = -1; }
     uint32_t    lean_candidates = 0;      // voices that can take the lean loop in some launch (static properties)
     uint32_t    lean_fm_candidates = 0;   // ... of them other than polynomial Harmonics (FM Sine, plain waveforms)
+    uint32_t    lean_fmsine_candidates = 0;   // ... of them FM Sine voices (all of the lean candidates: the FM-only lean kernel)
     bool        last_tiled = false;       // ... and whether it was tile-classified (no classification by voice then)
     uint32_t    last_groups = 0;          // voice groups of the last sh_bank_render launch (sh_bank_launch_stats)
     // When can a launch hold NO general voice (so that a split launch needs no general-lists kernel)?  Conservative, from

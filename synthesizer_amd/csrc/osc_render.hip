@@ -212,11 +212,19 @@ static int launch_tiled(const RenderLaunch& L, bool records_deferred) {
     // general pairs' and the ones that resolve the next-but-one tile set: the chip has room for all of them at once, the launch is
     // latency-bound, and a second kernel costs the host and the stream more than its work; the general code in the same kernel costs
     // the lean loop registers, which a long launch cannot afford and a short one does not notice.
+#ifdef SH_MERGE_ALWAYS
+    const bool merged = true;
+#else
     const bool merged = tiles <= 16;
+#endif
     if (merged) {
         const uint32_t behind = tiles * GEN_SPLIT + P.next_tile_wgs;   // general workgroups, then the tile-set prepare workgroups
-        hipLaunchKernelGGL((k_render_tiles<4, 8, 4, true, true>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st,
-                           A, L.next_args(L.next, behind), L.fold, L.parts, L.gen_valid);
+        if (b->tile_waveforms)
+            hipLaunchKernelGGL((k_render_tiles<4, 8, 4, true, true>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st,
+                               A, L.next_args(L.next, behind), L.fold, L.parts, L.gen_valid);
+        else
+            hipLaunchKernelGGL((k_render_tiles<4, 8, 4, false, true>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st,
+                               A, L.next_args(L.next, behind), L.fold, L.parts, L.gen_valid);
     } else {
         // (where the next-but-one tile set is resolved was moved three times in round 3 -- between the lean workgroups, a kernel of its
         // own on a third stream, the general kernel -- before it ended in rows behind the lean kernel's voice groups: CHANGELOG item 34)
@@ -272,8 +280,8 @@ static int launch_segmented(const RenderLaunch& L, uint32_t nseg, const uint32_t
     const LaunchArgs A = L.args(P, g);
     const NextArgs N = L.next_args(L.next, L.prep_wgs);
     const dim3 grid(tiles_lean, groups + sh::div_up(L.prep_wgs, tiles_lean));
-    if (L.mode == COMBINED_LEAN_HARM) hipLaunchKernelGGL((k_render_lean<4, 8, 4, false, true>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
-    else hipLaunchKernelGGL((k_render_lean<4, 8, 4, true, true>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
+    if (L.mode == COMBINED_LEAN_HARM) hipLaunchKernelGGL((k_render_lean<4, 8, 4, LEAN_K_HARM, true>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
+    else hipLaunchKernelGGL((k_render_lean<4, 8, 4, LEAN_K_ALL, true>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
     SH_CHECK_LAUNCH("k_render_lean(segments)");
     SH_HIP(hipMemsetAsync(L.gen_valid, 1, (size_t)groups * sizeof(uint32_t), st));         // every group's general parts are written
     hipLaunchKernelGGL((k_render_general<16, 4, 1, GEN_SEG>), dim3(tiles_gen + (SUB - 1) * sh::div_up(n0, 64 * 4), groups), dim3(1024), 0, st,
@@ -295,10 +303,12 @@ static int launch_plain(const RenderLaunch& L) {
     const NextArgs N = L.next_args(L.next, L.prep_wgs);
     const dim3 grid(L.tiles, L.groups + sh::div_up(L.prep_wgs, L.tiles));
     const bool lean_split = L.split;                     // (split implies lean candidates and several voice groups)
+    const bool fm_only = b->lean_fmsine_candidates == b->lean_candidates;     // every lean candidate an FM Sine voice (BASELINE config 3)
 #define SH_LAUNCH_SHAPE(W_, F_, M_)                                                                                                      \
     do {                                                                                                                                 \
-        if (lean_split && L.mode == COMBINED_LEAN_HARM) hipLaunchKernelGGL((k_render_lean<W_, F_, M_, false, false>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts); \
-        else if (lean_split) hipLaunchKernelGGL((k_render_lean<W_, F_, M_, true, false>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts); \
+        if (lean_split && L.mode == COMBINED_LEAN_HARM) hipLaunchKernelGGL((k_render_lean<W_, F_, M_, LEAN_K_HARM, false>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts); \
+        else if (lean_split && fm_only) hipLaunchKernelGGL((k_render_lean<W_, F_, M_, LEAN_K_FM, false>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts); \
+        else if (lean_split) hipLaunchKernelGGL((k_render_lean<W_, F_, M_, LEAN_K_ALL, false>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts); \
         else if (L.mode == COMBINED_LEAN_HARM) hipLaunchKernelGGL((k_render_combined<W_, F_, M_, COMBINED_LEAN_HARM>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts, L.out); \
         else if (L.mode == COMBINED_LEAN_ALL) hipLaunchKernelGGL((k_render_combined<W_, F_, M_, COMBINED_LEAN_ALL>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts, L.out); \
         else hipLaunchKernelGGL((k_render_combined<W_, F_, M_, COMBINED_DIRECT>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts, L.out); \

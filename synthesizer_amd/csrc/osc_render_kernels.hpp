@@ -333,13 +333,92 @@ __device__ __forceinline__ void lean_tile_frames(double s0, double c0, double s1
     }
 }
 
+// sin(t) for N angles in lockstep: shm::sincos_tab_n's sine, bit for bit (same operations in the same order; the cosine outputs are not
+// computed).  `magic` (1.5 * 2^52) and `s5` (1/120) arrive as VGPR-RESIDENT values: a float64 VALU instruction reads ONE scalar operand,
+// so fma(t, INV_STEP, MAGIC) and fma(z, 1/120, -1/6) cost a v_mov_b64 each, per angle, wherever the compiler lacks the registers to
+// keep the constants around -- 7 v_mov_b64 per frame in round 3's FM loop (profiles/r04_fm_isa.md).
+template <int N>
+__device__ __forceinline__ void sin_tab_n(const double (&t)[N], TrigTab tab, double magic, double s5, double (&s)[N]) {
+    double r[N], S[N], C[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        union { double d; uint64_t u; } m;
+        m.d = fma(t[j], shm::TRIG_INV_STEP, magic);
+        const double fk = m.d - magic;
+        const uint32_t k = (uint32_t)m.u & (uint32_t)(shm::TRIG_N - 1);
+        S[j] = tab[k].s;
+        C[j] = tab[k].c;
+        r[j] = fma(-fk, shm::TRIG_STEP_2, fma(-fk, shm::TRIG_STEP_1, t[j]));
+    }
+    double z[N], sr[N], cr[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = r[j] * r[j];
+#pragma unroll
+    for (int j = 0; j < N; ++j) sr[j] = fma(z[j], s5, -0.16666666666666666);
+#pragma unroll
+    for (int j = 0; j < N; ++j) cr[j] = fma(z[j], 0.041666666666666664, -0.5);
+#pragma unroll
+    for (int j = 0; j < N; ++j) sr[j] = fma(r[j] * z[j], sr[j], r[j]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) cr[j] = fma(z[j], cr[j], 1.0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) s[j] = fma(S[j], cr[j], C[j] * sr[j]);
+}
+
+// The lean FM arithmetic for FPL frames of one lane, 64 samples apart: a Sine carrier with a closed-form Sine LFO (the arithmetic of
+// voice_block's FM path).  The LFO angle a_rel + i*d is exactly linear in i, and only its COSINE enters L(i) = K (C0 - cos) + bias*(start+i):
+// one table lookup for the lane's first frame, one rotation for the second, then cos[j] = 2cos(64d) cos[j-1] - cos[j-2].  The carrier's
+// angle is not linear in i: one table lookup per frame, four carriers at a time so that their table reads are in flight together.
+// BIASED = false: an LFO without bias (the usual modulator; BASELINE config 3) -- the linear term of L is 0 * (start + i) = +0, and
+// fma(K, C0 - cos, +0) IS the rounded product: three operations per frame less, the same bits.
+// The accumulated TIME of the lane's frame j: LINEAR -- the tile lies on ONE phase-table piece, t_j = fma(i_j - off, dt, t_base): the
+// true value is a float64 by the table's construction, so t_first + j * t_step (t_step = 64 dt, a power-of-two multiple: exact) summed
+// step by step gives the same bits with ONE addition per frame and one scalar operand; else time(j) picks the piece per lane
+// (LaneTheta: the one tile per crossing that straddles a piece end).  The sines go to out[]: the caller accumulates them in ONE place
+// behind the four forms of this function (with the accumulation inside each, the compiler shuffled the accumulators between the forms'
+// register assignments: ~25 register copies per eight frames).
+template <int FPL, bool BIASED, bool LINEAR, typename TimeFn>
+__device__ __forceinline__ void lean_fm_frames(const double (&poly)[16], double di0, TimeFn time, double t_first, double t_step,
+                                               TrigTab trig, double (&out)[FPL]) {
+    const double frequency = poly[0], f_inc = poly[2], lfo_a_rel = poly[3], lfo_d = poly[4];
+    const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], lrc = poly[8], lrs = poly[9], startd = poly[10];
+    double magic = 6755399441055744.0, s5 = 0.008333333333333333, phase0 = poly[1];
+    asm volatile("" : "+v"(magic), "+v"(s5), "+v"(phase0));          // (VGPR-resident: see sin_tab_n)
+    double ls0, lc0;
+    shm::sincos_tab(fma(di0, lfo_d, lfo_a_rel), trig, ls0, lc0);
+    double lc1 = fma(lc0, lrc, -(ls0 * lrs));
+    const double lk2 = lrc + lrc;
+    double tj = t_first;
+    constexpr int Q = FPL < 4 ? FPL : 4;
+#pragma unroll
+    for (int h = 0; h < FPL; h += Q) {
+        double th[Q], sn[Q];
+#pragma unroll
+        for (int jj = 0; jj < Q; ++jj) {
+            const int j = h + jj;
+            const double Ln = BIASED ? fma(lfo_K, lfo_C0 - lc0, lfo_bias * (startd + (di0 + (double)(j * 64)))) : lfo_K * (lfo_C0 - lc0);
+            const double tt = LINEAR ? tj : time(j);
+            th[jj] = frequency * tt + fma(f_inc, Ln, phase0);
+            if (LINEAR) tj = tj + t_step;
+            const double lc2 = fma(lk2, lc1, -lc0);
+            lc0 = lc1;
+            lc1 = lc2;
+        }
+        sin_tab_n<Q>(th, trig, magic, s5, sn);
+#pragma unroll
+        for (int jj = 0; jj < Q; ++jj) out[h + jj] = sn[jj];
+    }
+}
+
 // ---- the lean lists ----------------------------------------------------------------------------------------------------------------
 // One table lookup, FPL-1 recurrence steps, the Horner chains, two accumulations per frame.  Wave w takes every WAVES-th list entry;
 // the offset carries over from chunk to chunk (`first`: in and out) so that the waves' shares of the whole group differ by at most one
-// voice.  HARM_ONLY: every lean record is a polynomial Harmonics voice (FM Sine and the plain waveforms are kept out of that
-// instantiation: the extra branches and code cost its loop 5 %).  SEG: the records of a segmented launch (sloped gains; the second
+// voice.  KINDS: LEAN_K_HARM -- every lean record is a polynomial Harmonics voice (FM Sine and the plain waveforms are kept out of that
+// instantiation: the extra branches and code cost its loop 5 %); LEAN_K_FM -- every one is an FM Sine voice (BASELINE config 3);
+// LEAN_K_ALL -- anything.  SEG: the records of a segmented launch (sloped gains; the second
 // piece's fields belong in the first batch of loads -- half the tiles lie behind the crossing).
-template <int WAVES, int FPL, bool HARM_ONLY, bool SEG>
+enum { LEAN_K_HARM = 0, LEAN_K_ALL = 1, LEAN_K_FM = 2 };     // which kinds of lean record a bank can hold (static)
+template <int WAVES, int FPL, int KINDS, bool SEG>
 __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, TrigTab trig, double (&accl)[FPL], double (&accr)[FPL]) {
     const uint32_t lane = T.lane, tile0 = T.tile0, tile_last = T.tile_last;
     for (uint32_t c = T.c0; c < T.c1; ++c) {
@@ -388,7 +467,26 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                 if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
             }
             const LaneTheta theta{di0, t_base, dt, off, ta, da, tb, db, ob, i0, remain, straddle};    // the accumulated t at frame j
-            if (HARM_ONLY || kind == LEAN_HARM) {
+            if constexpr (KINDS == LEAN_K_FM) {
+                // every lean record of the bank is an FM Sine voice: the FM code alone (no polynomial path, no waveform branches: the kernel
+                // with all kinds needs 128 VGPRs and spills; round 4)
+                double sn[FPL];
+                if (straddle) {
+                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, false>(poly, di0, theta, 0.0, 0.0, trig, sn);
+                    else lean_fm_frames<FPL, true, false>(poly, di0, theta, 0.0, 0.0, trig, sn);
+                } else {
+                    const double t_first = fma(di0 - off, dt, t_base), t_step = 64.0 * dt;
+                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, true>(poly, di0, theta, t_first, t_step, trig, sn);
+                    else lean_fm_frames<FPL, true, true>(poly, di0, theta, t_first, t_step, trig, sn);
+                }
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    accl[j] = fma(gl, sn[j], accl[j]);
+                    accr[j] = fma(gr, sn[j], accr[j]);
+                }
+                continue;
+            }
+            if (KINDS == LEAN_K_HARM || kind == LEAN_HARM) {
                 // polynomial Harmonics: lookup + one rotation + the three-term recurrence (lean_harm_frames)
                 double s0, c0, s1, c1;
 #ifdef SH_DIAG2
@@ -426,7 +524,7 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
 #endif
                 continue;
             }
-            if constexpr (!HARM_ONLY) {
+            if constexpr (KINDS == LEAN_K_ALL) {
             if (kind == LEAN_SINE) {
                 // a plain Sine: the same recurrence on the sine alone (the amplitude lives in the gains)
                 double s0, c0, s1, c1;
@@ -452,48 +550,14 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                 continue;
             }
             if (kind == LEAN_FM) {
-                // Sine carrier, closed-form Sine LFO (the arithmetic of voice_block's FM path).  theta(j) is the accumulated TIME;
-                // the LFO angle a_rel + i*d is exactly linear in i, and only its COSINE enters L(i) = K (C0 - cos) + bias*(start+i):
-                // one table lookup for the lane's first frame, one rotation for the second, then cos[j] = 2cos(64d) cos[j-1] - cos[j-2].
-                const double frequency = poly[0], phase0 = poly[1], f_inc = poly[2], lfo_a_rel = poly[3], lfo_d = poly[4];
-                const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], lrc = poly[8], lrs = poly[9], startd = poly[10];
-                double ls0, lc0;
-                shm::sincos_tab(fma(di0, lfo_d, lfo_a_rel), trig, ls0, lc0);
-                double lc1 = fma(lc0, lrc, -(ls0 * lrs));
-                const double lk2 = lrc + lrc;
-                // an LFO without bias (the usual modulator; BASELINE config 3): the linear term of L is 0 * (start + i) = +0, and
-                // fma(K, C0 - cos, +0) IS the rounded product -- three operations per frame less, the same bits.  (The two loops are
-                // written out: behind a lambda the accumulators are no longer scalarised -- they went to LDS and scratch.)
-#define SH_FM_FRAMES(LN_EXPR, THETA_EXPR)                                                                                \
-                _Pragma("unroll")                                                                                        \
-                for (int h = 0; h < FPL; h += 4) {            /* four carriers at a time: their table reads are in flight together */ \
-                    constexpr int Q = FPL < 4 ? FPL : 4;                                                                 \
-                    double th[Q], sn[Q], cs[Q];                                                                          \
-                    _Pragma("unroll")                                                                                    \
-                    for (int jj = 0; jj < Q; ++jj) {                                                                     \
-                        const int j = h + jj;                                                                            \
-                        const double Ln = LN_EXPR;                                                                       \
-                        th[jj] = frequency * (THETA_EXPR) + fma(f_inc, Ln, phase0);                                      \
-                        const double lc2 = fma(lk2, lc1, -lc0);                                                          \
-                        lc0 = lc1;                                                                                       \
-                        lc1 = lc2;                                                                                       \
-                    }                                                                                                    \
-                    shm::sincos_tab_n<Q>(th, trig, sn, cs);                                                              \
-                    _Pragma("unroll")                                                                                    \
-                    for (int jj = 0; jj < Q; ++jj) {                                                                     \
-                        accl[h + jj] = fma(gl, sn[jj], accl[h + jj]);                                                    \
-                        accr[h + jj] = fma(gr, sn[jj], accr[h + jj]);                                                    \
-                    }                                                                                                    \
+                double sn[FPL];
+                if (poly[7] == 0.0) lean_fm_frames<FPL, false, false>(poly, di0, theta, 0.0, 0.0, trig, sn);
+                else lean_fm_frames<FPL, true, false>(poly, di0, theta, 0.0, 0.0, trig, sn);
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    accl[j] = fma(gl, sn[j], accl[j]);
+                    accr[j] = fma(gr, sn[j], accr[j]);
                 }
-                // (Measured and dropped: the same split by `straddle` -- theta(j) asks it per frame, a uniform branch per frame -- with
-                // the one-piece tile's angle written out: straight-line code, four chains interleaved, and 58.8 instead of 51.6 us
-                // per block of BASELINE config 3.)
-                if (lfo_bias == 0.0) {
-                    SH_FM_FRAMES(lfo_K * (lfo_C0 - lc0), theta(j))
-                } else {
-                    SH_FM_FRAMES(fma(lfo_K, lfo_C0 - lc0, lfo_bias * (startd + (di0 + (double)(j * 64)))), theta(j))
-                }
-#undef SH_FM_FRAMES
                 continue;
             }
             // Sawtooth / Square / Triangle / Pulse at unit amplitude (the amplitude lives in the gains): t in turns, frame by frame
@@ -807,7 +871,7 @@ __device__ __forceinline__ void clear_acc(double (&accl)[FPL], double (&accr)[FP
 // =====================================================================================================================================
 // k_render_lean: grid = (tiles [of all segments], voice groups + rows that resolve the next-but-one block's records)
 // =====================================================================================================================================
-template <int WAVES, int FPL, int MINW, bool ALL, bool SEG>
+template <int WAVES, int FPL, int MINW, int KINDS, bool SEG>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_render_lean(LaunchArgs A, NextArgs N, FoldIn F, double2* __restrict__ parts) {
     SH_STAMP(A, 0);
     const uint32_t ngroups = groups_of_grid(N.prep_wgs);
@@ -823,7 +887,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_render_lean(LaunchArgs A, 
     double accl[FPL], accr[FPL];
     clear_acc(accl, accr);
     uint32_t first = T.wave;
-    lean_lists<WAVES, FPL, !ALL, SEG>(T, first, trig, accl, accr);
+    lean_lists<WAVES, FPL, KINDS, SEG>(T, first, trig, accl, accr);
     SH_STAMP(A, 3);
     SH_STAMP(A, 4);
     reduce_store<WAVES, FPL>(red, T, accl, accr, parts + (size_t)T.grp * A.nframes, T.seg_off, BusOut{});
@@ -980,7 +1044,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_render_combined(LaunchArgs
         }
     } else {
         uint32_t first = T.wave;
-        lean_lists<WAVES, FPL, MODE == COMBINED_LEAN_HARM, false>(T, first, trig, accl, accr);
+        lean_lists<WAVES, FPL, MODE == COMBINED_LEAN_HARM ? LEAN_K_HARM : LEAN_K_ALL, false>(T, first, trig, accl, accr);
         // The lean loops work from the lane's first frame alone, so the per-frame index arrays are only built behind them, for the
         // general code: they would cost 3 registers per frame for the whole lean loop.
         uint32_t lane_late = T.lane;

@@ -35,14 +35,14 @@ for r in csv.DictReader(open(src / "stats_kernel_stats.csv")):
 serial = src / "serial_kernel_stats.csv"
 if serial.exists():
     shutil.copy(serial, out / ("%s_kernel_stats_serial.csv" % tag))
-    lines += ["", "### k_bank_render: duration of a kernel vs time per launch", "",
-              "The default run pipelines consecutive `k_bank_render` launches over two HIP streams (DESIGN.md section 4 item 16): "
+    lines += ["", "### k_render_lean: duration of a kernel vs time per launch", "",
+              "The default run pipelines consecutive render launches over two HIP streams (CHANGELOG.md item 16): "
               "two kernels are in flight at any time, so the start-to-end duration of ONE kernel in the table above is about "
               "twice the time the stream of launches needs per launch -- the figure `bench.py` reports from HIP events over the "
               "timed region (`roofline.avg_launch_ms`) and the one that throughput follows.  With the launches serialised on one "
               "stream (`SYNTHHIP_NO_OVERLAP=1`, same command with `--no-pcm-rows --no-two-step`) the kernel-trace average IS the "
               "time per launch and agrees with that run's HIP-event figure:", "",
-              "| run | kernel-trace avg us (k_bank_render) | calls | bench.py HIP events, us per launch | Msamples/s |", "|---|---|---|---|---|"]
+              "| run | kernel-trace avg us (k_render_lean) | calls | bench.py HIP events, us per launch | Msamples/s |", "|---|---|---|---|---|"]
     import json as _json
 
     def bench_line(path):
@@ -54,7 +54,7 @@ if serial.exists():
 
     def render_row(csv_path):
         for r in csv.DictReader(open(csv_path)):
-            if "k_bank_render" in r["Name"]:
+            if "k_render_lean" in r["Name"] or "k_bank_render" in r["Name"]:
                 return float(r["AverageNs"]) / 1e3, r["Calls"]
         return float("nan"), "?"
     for label, csv_path, bpath in (("two streams (default)", src / "stats_kernel_stats.csv", src.parent / ("%s_bench.json" % src.name)),
@@ -148,7 +148,7 @@ for cfg in ("config2", "config3", "staggered"):
     for fname in ("%s_sq1_counter_collection.csv" % cfg, "%s_sq2_counter_collection.csv" % cfg):
         agg, meta = counters(fname)
         for k in sorted(agg):
-            if not k.startswith("k_bank_render"):
+            if not k.startswith("k_render_"):
                 continue
             cfg_counters.setdefault("%s:%s" % (cfg, k), {}).update({cn: sum(v) / len(v) for cn, v in agg[k].items()})
     for k in sorted(cfg_counters):
@@ -179,7 +179,7 @@ for fname in ("sq1_counter_collection.csv", "sq2_counter_collection.csv"):
             allc.setdefault(k, {}).update({cn: sum(v) / len(v) for cn, v in cs.items()})
 hash_file = src / "source_hash.txt"
 allc["_meta"] = {"source_hash": hash_file.read_text().strip() if hash_file.exists() else None,
-                 "dispatch": "bench.py default workload: 1024 voices x 48000 frames per k_bank_render dispatch"}
+                 "dispatch": "bench.py default workload: 1024 voices x 48000 frames per render dispatch"}
 (out / ("%s_counters.json" % tag)).write_text(json.dumps(allc, indent=1) + "\n")
 bench = src.parent / ("%s_bench.json" % src.name)
 if bench.exists():
