@@ -183,8 +183,9 @@ int  sh_debug_counters(sh_counters* out);
  *   SYNTHHIP_NO_SEG=1             transition launches / the heads of materialised rows are not cut into segments
  *   SYNTHHIP_NO_TILES=1           banks whose notes do not move in lock-step (onsets, envelopes of their own) are not classified tile
  *                                 by tile: every voice that holds an onset or a corner in the launch takes the general code
- *   SYNTHHIP_VARIANT=WFM          render kernel shape: waves per workgroup, frames per lane, min waves per SIMD -- one of 484, 444,
- *                                 844, 821, 421, 211 (the shapes the library chooses between by itself)
+ *   SYNTHHIP_VARIANT=WFM          render kernel shape: waves per workgroup, frames per lane, min waves per SIMD -- one of 4163, 484, 444,
+ *                                 844, 821, 421, 211 (the shapes the library chooses between by itself; 4163 -- sixteen frames per lane --
+ *                                 exists for split launches of polynomial-Harmonics banks only)
  *   SYNTHHIP_GROUPS=n             voice groups of a render launch
  *   SYNTHHIP_POOL_FILL=0..255     device blocks that grow are filled with this byte first (diagnostics: a kernel that reads what it
  *                                 should have written shows)

@@ -1009,43 +1009,65 @@ __device__ __forceinline__ void lean_harm_frames(double s0, double c0, double s1
                                                  double (&accl)[FPL], double (&accr)[FPL],
                                                  double gls = 0.0, double grs = 0.0, double dl = 0.0) {
     if constexpr (SH_LEAN_CH > 2 && FPL % SH_LEAN_CH == 0) {
-        // Round 4.  A float64 FMA's result is not there for the next instruction but one: with TWO chains per wavefront (the pairs
-        // below) a wavefront alone on its SIMD fills ~40 % of the FMA pipe, and the oldest wavefront of a SIMD is served first -- so
-        // a launch ended with SIMDs that held one or two wavefronts limping (profiles/r04_headline_phases.md: the voice loop of
-        // the last-dispatched voice groups took 41 us where the first took 26).  Same operations per frame, in the same order
-        // (bit-identical results): the sines and cosines of all frames first, then the Horner chains SH_LEAN_CH at a time.
-        double s[FPL], c[FPL];
-        s[0] = s0; c[0] = c0; s[1] = s1; c[1] = c1;
-        if (straddle) {
+        // Round 4: the Horner chains SH_LEAN_CH at a time instead of in pairs -- the same operations per frame in the same order
+        // (bit-identical results), 2 % faster (a dependent float64 FMA issues as fast as an independent one on this chip:
+        // profiles/r04_ubench_ilp.txt; what the wider interleave buys is slack for a wavefront that shares its SIMD with fewer
+        // others).  The sines and cosines of HB frames at a time, the recurrence running on from the previous batch's last two values.
+        constexpr int HB = FPL > 8 ? SH_LEAN_CH : (FPL < 8 ? FPL : 8);      // (sixteen frames per lane: the accumulators hold 64 registers -- four frames' sines at a time)
+        static_assert(FPL % HB == 0 && HB % SH_LEAN_CH == 0, "frames per lane: a multiple of the chains, in halves of eight");
+        double s[HB], c[HB];
 #pragma unroll
-            for (int j = 2; j < FPL; ++j) shm::sincos_tab(theta(j), trig, s[j], c[j]);
-        } else {
+        for (int h0 = 0; h0 < FPL; h0 += HB) {
+            if (h0 == 0) {
+                s[0] = s0; c[0] = c0;
+                if (HB > 1) { s[1] = s1; c[1] = c1; }
+                if (straddle) {
 #pragma unroll
-            for (int j = 2; j < FPL; ++j) {
-                s[j] = fma(k2, s[j - 1], -s[j - 2]);
-                c[j] = fma(k2, c[j - 1], -c[j - 2]);
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < FPL; h += SH_LEAN_CH) {
-            double p[SH_LEAN_CH];
-#pragma unroll
-            for (int jj = 0; jj < SH_LEAN_CH; ++jj) p[jj] = fma(poly[0], c[h + jj], poly[1]);
-#pragma unroll
-            for (int u = 2; u < 16; ++u) {
-#pragma unroll
-                for (int jj = 0; jj < SH_LEAN_CH; ++jj) p[jj] = fma(p[jj], c[h + jj], poly[u]);
-            }
-#pragma unroll
-            for (int jj = 0; jj < SH_LEAN_CH; ++jj) {
-                const double x = p[jj] * s[h + jj];
-                if (SLOPED) {
-                    const double ij = dl + (double)((h + jj) * 64);
-                    accl[h + jj] = fma(fma(ij, gls, gl), x, accl[h + jj]);
-                    accr[h + jj] = fma(fma(ij, grs, gr), x, accr[h + jj]);
+                    for (int j = 2; j < HB; ++j) shm::sincos_tab(theta(j), trig, s[j], c[j]);
                 } else {
-                    accl[h + jj] = fma(gl, x, accl[h + jj]);
-                    accr[h + jj] = fma(gr, x, accr[h + jj]);
+#pragma unroll
+                    for (int j = 2; j < HB; ++j) {
+                        s[j] = fma(k2, s[j - 1], -s[j - 2]);
+                        c[j] = fma(k2, c[j - 1], -c[j - 2]);
+                    }
+                }
+            } else {
+                if (straddle) {
+#pragma unroll
+                    for (int j = 0; j < HB; ++j) shm::sincos_tab(theta(h0 + j), trig, s[j], c[j]);
+                } else {
+                    const double sa = s[HB - 2], sb = s[HB - 1], ca = c[HB - 2], cb = c[HB - 1];
+                    s[0] = fma(k2, sb, -sa); c[0] = fma(k2, cb, -ca);
+                    s[1] = fma(k2, s[0], -sb); c[1] = fma(k2, c[0], -cb);
+#pragma unroll
+                    for (int j = 2; j < HB; ++j) {
+                        s[j] = fma(k2, s[j - 1], -s[j - 2]);
+                        c[j] = fma(k2, c[j - 1], -c[j - 2]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < HB; h += SH_LEAN_CH) {
+                double p[SH_LEAN_CH];
+#pragma unroll
+                for (int jj = 0; jj < SH_LEAN_CH; ++jj) p[jj] = fma(poly[0], c[h + jj], poly[1]);
+#pragma unroll
+                for (int u = 2; u < 16; ++u) {
+#pragma unroll
+                    for (int jj = 0; jj < SH_LEAN_CH; ++jj) p[jj] = fma(p[jj], c[h + jj], poly[u]);
+                }
+#pragma unroll
+                for (int jj = 0; jj < SH_LEAN_CH; ++jj) {
+                    const double x = p[jj] * s[h + jj];
+                    const int f = h0 + h + jj;
+                    if (SLOPED) {
+                        const double ij = dl + (double)(f * 64);
+                        accl[f] = fma(fma(ij, gls, gl), x, accl[f]);
+                        accr[f] = fma(fma(ij, grs, gr), x, accr[f]);
+                    } else {
+                        accl[f] = fma(gl, x, accl[f]);
+                        accr[f] = fma(gr, x, accr[f]);
+                    }
                 }
             }
         }

@@ -212,11 +212,10 @@ static int launch_tiled(const RenderLaunch& L, bool records_deferred) {
     // general pairs' and the ones that resolve the next-but-one tile set: the chip has room for all of them at once, the launch is
     // latency-bound, and a second kernel costs the host and the stream more than its work; the general code in the same kernel costs
     // the lean loop registers, which a long launch cannot afford and a short one does not notice.
-#ifdef SH_MERGE_ALWAYS
-    const bool merged = true;
-#else
+    // (Measured in round 4: the merged kernel for LONG launches too -- no general kernel between two lean kernels of a stream -- 50.7
+    // against 48.4 us per block of the staggered row; with the general workgroups' code behind a function call, so that it would not
+    // cost the lean pairs' loop registers, 530 us: the call's stack frame makes every wavefront of the dispatch a scratch user.)
     const bool merged = tiles <= 16;
-#endif
     if (merged) {
         const uint32_t behind = tiles * GEN_SPLIT + P.next_tile_wgs;   // general workgroups, then the tile-set prepare workgroups
         if (b->tile_waveforms)
@@ -314,13 +313,17 @@ static int launch_plain(const RenderLaunch& L) {
         else hipLaunchKernelGGL((k_render_combined<W_, F_, M_, COMBINED_DIRECT>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts, L.out); \
     } while (0)
     switch (L.var) {
+    case 4163:                                         // (chosen for split launches of polynomial-Harmonics banks only: bank_render)
+        if (!(lean_split && L.mode == COMBINED_LEAN_HARM)) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: shape 4163 needs a split launch of a Harmonics bank");
+        hipLaunchKernelGGL((k_render_lean<4, 16, 3, LEAN_K_HARM, false>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
+        break;
     case 484: SH_LAUNCH_SHAPE(4, 8, 4); break;
     case 444: SH_LAUNCH_SHAPE(4, 4, 4); break;
     case 844: SH_LAUNCH_SHAPE(8, 4, 4); break;
     case 821: SH_LAUNCH_SHAPE(8, 2, 1); break;
     case 421: SH_LAUNCH_SHAPE(4, 2, 1); break;
     case 211: SH_LAUNCH_SHAPE(2, 1, 1); break;
-    default: return sh::set_error(SH_ERR_INVALID, "sh_bank_render: SYNTHHIP_VARIANT %d is not one of 484, 444, 844, 821, 421, 211", L.var);
+    default: return sh::set_error(SH_ERR_INVALID, "sh_bank_render: SYNTHHIP_VARIANT %d is not one of 4163, 484, 444, 844, 821, 421, 211", L.var);
     }
 #undef SH_LAUNCH_SHAPE
     SH_CHECK_LAUNCH("k_render_lean / k_render_combined");
@@ -370,7 +373,21 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     const bool tile_candidate = K.variant == 0 && b->tile_all && b->nvoices >= 128 && mode != COMBINED_DIRECT && !K.no_tiles && !b->needs_rows && b->first_row_voice < 0 &&
                                 (b->has_onsets || b->own_envelopes) && !b->no_general_voice(start, nframes);
     if (tile_candidate) var = 484;
-    const int W = var / 100, F = (var / 10) % 10;
+    // SIXTEEN frames per lane (var 4163; round 4): what a (wave, voice) pair pays once -- the record's scalar loads, the table lookup,
+    // the rotation: ~40 of the ~190 VALU instructions of eight frames -- is paid once per sixteen, ~10 % fewer instructions per
+    // voice-sample.  The 32 float64 accumulator pairs do not fit 128 registers beside the loop (at 128 the compiler spills inside the
+    // Horner chains: 63 us per block), so the shape runs at THREE waves per SIMD (167 registers): 41.6 instead of 46 us for a launch
+    // alone, 35.4-35.7 instead of 35.8-35.9 us in a stream of launches (fewer instructions, but a CU holds three workgroups, not four:
+    // less of the neighbouring launch beside it).  Tiles of 1024 frames need twice the voice groups to fill the chip (47 tiles x 16
+    // groups of 64 voices for the headline: the same 752 workgroups), so: polynomial-Harmonics banks (the lean kernel of that kind is
+    // the one instantiated at this shape), a split launch, and enough 64-voice chunks for the groups.
+    if (K.variant == 0 && var == 484 && mode == COMBINED_LEAN_HARM && !tile_candidate && !K.no_split && K.groups == 0) {
+        const uint32_t tiles16 = sh::div_up(nframes, 1024u);
+        uint32_t g16 = 1;
+        while (tiles16 * g16 * 2 <= 1024u && b->nvoices / (g16 * 2) >= 64u) g16 *= 2;         // (whole chunks per group)
+        if (g16 >= 2 && tiles16 * g16 >= 640u) var = 4163;
+    }
+    const int W = var >= 1000 ? var / 1000 : var / 100, F = var >= 1000 ? (var / 10) % 100 : (var / 10) % 10;
     // Voice groups: split the voices when the frame range alone gives too few tiles for 256 CUs -- up to ONE round of
     // resident workgroups (1024 slots of four waves), not beyond: 752 workgroups that all start at once beat 1504 whose
     // second round runs half empty (MI355X, 1024 voices x 48 000 frames: 4 groups of 188 tiles 46.7 us, 8 groups 47.2, 16
@@ -464,7 +481,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     }
     uint32_t seg_first[SEG_MAX + 1];
     uint32_t nseg = 0;
-    if (!tiled && split && var == 484 && b->all_lean && !K.no_seg && !b->needs_rows && !b->no_general_voice(start, nframes)) {
+    if (!tiled && split && (var == 484 || var == 4163) && b->all_lean && !K.no_seg && !b->needs_rows && !b->no_general_voice(start, nframes)) {
         nseg = plan_segments(b, start, nframes, (uint64_t)(64 * F), ~0ull, true, seg_first);
         if (nseg < 2 || seg_first[nseg] != nframes) nseg = 0;        // nothing to cut, or more cuts than a launch carries
     }

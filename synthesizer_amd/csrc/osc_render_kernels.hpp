@@ -263,34 +263,42 @@ __device__ __forceinline__ void fold_previous(const FoldIn& F, uint32_t ngroups,
 }
 
 // ---- the sum across the waves of the workgroup, and the store ---------------------------------------------------------------------
-// dst: a plane of partial buses (launch-relative frames) -- or NULL: the final bus `out` (single-group launches)
+// dst: a plane of partial buses (launch-relative frames) -- or NULL: the final bus `out` (single-group launches).  The staging buffer
+// holds RED_ROWS(FPL) rows of 64 frames per wave and channel: eight at most (32 KB at four waves -- four workgroups per CU with the
+// trig table); sixteen frames per lane go through it in two passes.
+constexpr int red_rows(int fpl) { return fpl < 8 ? fpl : 8; }
 template <int WAVES, int FPL>
-__device__ __forceinline__ void reduce_store(double (*red)[2][64 * FPL], const TileCtx& T, const double (&accl)[FPL], const double (&accr)[FPL],
+__device__ __forceinline__ void reduce_store(double (*red)[2][64 * red_rows(FPL)], const TileCtx& T, const double (&accl)[FPL], const double (&accr)[FPL],
                                              double2* __restrict__ dst, size_t dst_off, const BusOut& out) {
+    constexpr int RR = red_rows(FPL);
 #pragma unroll
-    for (int j = 0; j < FPL; ++j) {
-        red[T.wave][0][j * 64 + T.lane] = accl[j];
-        red[T.wave][1][j * 64 + T.lane] = accr[j];
-    }
-    __syncthreads();
-    // each wave finishes 64-frame rows of the tile: rows wave, wave + WAVES, ...
-    for (uint32_t row = T.wave; row < (uint32_t)FPL; row += WAVES) {
-        const uint32_t f = row * 64 + T.lane;
-        const uint32_t raw = T.tile0 + f;
-        if (raw < T.nfr) {
-            double l = red[0][0][f], rr = red[0][1][f];
+    for (int r0 = 0; r0 < FPL; r0 += RR) {
+        if (r0) __syncthreads();                          // (the previous pass's rows have been read)
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) {
-                l += red[w][0][f];
-                rr += red[w][1][f];
-            }
-            const size_t at = dst_off + raw;
-            if (dst) {
-                dst[at] = make_double2(l, rr);
-            } else {
-                if (out.bus32) out.bus32[at] = make_float2((float)l, (float)rr);
-                if (out.bus64) out.bus64[at] = make_double2(l, rr);
-                if (out.pcm16) out.pcm16[at] = pcm16_frame(l, rr, out.pcm_scale);
+        for (int j = 0; j < RR; ++j) {
+            red[T.wave][0][j * 64 + T.lane] = accl[r0 + j];
+            red[T.wave][1][j * 64 + T.lane] = accr[r0 + j];
+        }
+        __syncthreads();
+        // each wave finishes 64-frame rows of the tile: rows wave, wave + WAVES, ...
+        for (uint32_t row = T.wave; row < (uint32_t)RR; row += WAVES) {
+            const uint32_t f = row * 64 + T.lane;
+            const uint32_t raw = T.tile0 + (uint32_t)r0 * 64 + f;
+            if (raw < T.nfr) {
+                double l = red[0][0][f], rr = red[0][1][f];
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) {
+                    l += red[w][0][f];
+                    rr += red[w][1][f];
+                }
+                const size_t at = dst_off + raw;
+                if (dst) {
+                    dst[at] = make_double2(l, rr);
+                } else {
+                    if (out.bus32) out.bus32[at] = make_float2((float)l, (float)rr);
+                    if (out.bus64) out.bus64[at] = make_double2(l, rr);
+                    if (out.pcm16) out.pcm16[at] = pcm16_frame(l, rr, out.pcm_scale);
+                }
             }
         }
     }
@@ -878,7 +886,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_render_lean(LaunchArgs A, 
     if (prep_rows_lists(A, N, ngroups)) return;
     fold_previous<WAVES, FPL>(F, ngroups, A.nframes, blockIdx.x);
     SH_STAMP(A, 1);
-    __shared__ double red[WAVES][2][64 * FPL];
+    __shared__ double red[WAVES][2][64 * red_rows(FPL)];
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     load_trig(trig, A.trig_g, WAVES * 64);
     SH_STAMP(A, 2);
@@ -946,7 +954,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_render_general(LaunchArgs 
             return;
         }
     }
-    __shared__ double red[WAVES][2][64 * FPL];
+    __shared__ double red[WAVES][2][64 * red_rows(FPL)];
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     load_trig(trig, A.trig_g, WAVES * 64);
     uint32_t i[FPL];
@@ -993,7 +1001,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_render_tiles(LaunchArgs A,
         }
     }
     if (!is_gen_wg) fold_previous<WAVES, FPL>(F, ngroups, A.nframes, bx);
-    __shared__ double red[WAVES][2][64 * FPL];
+    __shared__ double red[WAVES][2][64 * red_rows(FPL)];
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     load_trig(trig, A.trig_g, WAVES * 64);
     TileCtx T = plain_tile<FPL>(A, bx, blockIdx.y, ngroups);
@@ -1024,7 +1032,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_render_combined(LaunchArgs
     const uint32_t ngroups = groups_of_grid(N.prep_wgs);
     if (prep_rows_lists(A, N, ngroups)) return;
     fold_previous<WAVES, FPL>(F, ngroups, A.nframes, blockIdx.x);
-    __shared__ double red[WAVES][2][64 * FPL];
+    __shared__ double red[WAVES][2][64 * red_rows(FPL)];
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     load_trig(trig, A.trig_g, WAVES * 64);
     const TileCtx T = plain_tile<FPL>(A, blockIdx.x, blockIdx.y, ngroups);
