@@ -59,7 +59,8 @@ struct alignas(64) TileRec {
                                   // table << 32) as bits; the frames in front of the onset get the angle 0 -- sin 0 = 0 -- and the envelope
                                   // is the minimum of the two lines behind the onset
     uint16_t corner;              // the first frame (relative to the tile's) of the second line; 0: no corner in the tile
-    double pad_;                  // low 32 bits: LEAN_HARM (a plain Sine too: the series with one partial) or the waveform LEAN_SAW .. LEAN_PULSE
+    double pad_;                  // low 32 bits: LEAN_HARM (a plain Sine too: the series with one partial) or the waveform LEAN_SAW .. LEAN_PULSE;
+                                  // high 32 bits: the voice's position in its chunk of 64 (the lean kernel finds its polynomial by it)
 };
 constexpr uint32_t TILE_WALK_PIECES = 16;     // pieces a walk pair may touch (lanes 0 .. 15 fetch one each)
 static_assert(sizeof(TileRec) == 128 && offsetof(TileRec, GL) == 64 && offsetof(TileRec, tb) == 80 && offsetof(TileRec, split) == 112, "TileRec layout");
@@ -1355,7 +1356,7 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             union { uint16_t h[4]; double d; } tail;
             tail.h[0] = rec_split[0]; tail.h[1] = rec_split[1]; tail.h[2] = is_walk ? (uint16_t)0 : (uint16_t)(1 + rec_extra); tail.h[3] = (uint16_t)corner;
             union { uint32_t u[2]; double d; } kind_bits;
-            kind_bits.u[0] = rec_kind; kind_bits.u[1] = 0u;
+            kind_bits.u[0] = rec_kind; kind_bits.u[1] = lane;       // (high half: the voice's position in its chunk -- where its polynomial lives)
             q2[7] = make_double2(tail.d, kind_bits.d);
         }
         if (lane == 0) {

@@ -304,6 +304,45 @@ __device__ __forceinline__ void reduce_store(double (*red)[2][64 * red_rows(FPL)
     }
 }
 
+// The lean Harmonics arithmetic as VALUES: out[j] = P(cos) * sin of the lane's frame j (lean_harm_frames without the accumulation; same
+// operations, same order).  The tiles kernel's five kinds of pair all end in ONE accumulation (tiles_lean): with an accumulation inside
+// every kind the compiler shuffled the sixteen accumulators between the kinds' register assignments at every join -- ~34 register
+// copies per pair (profiles/r04_summary.md).
+template <int FPL, typename Theta>
+__device__ __forceinline__ void lean_harm_values(double s0, double c0, double s1, double c1, double k2, bool straddle, Theta theta,
+                                                 TrigTab trig, const double (&poly)[16], double (&out)[FPL]) {
+    static_assert(FPL % SH_LEAN_CH == 0 && FPL <= 8, "frames per lane");
+    double s[FPL], c[FPL];
+    s[0] = s0; c[0] = c0; s[1] = s1; c[1] = c1;
+    if (straddle) {
+#pragma unroll
+        for (int j = 2; j < FPL; ++j) shm::sincos_tab(theta(j), trig, s[j], c[j]);
+    } else {
+#pragma unroll
+        for (int j = 2; j < FPL; ++j) {
+            s[j] = fma(k2, s[j - 1], -s[j - 2]);
+            c[j] = fma(k2, c[j - 1], -c[j - 2]);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < FPL; h += SH_LEAN_CH) {
+        double p[SH_LEAN_CH];
+#pragma unroll
+        for (int jj = 0; jj < SH_LEAN_CH; ++jj) p[jj] = fma(poly[0], c[h + jj], poly[1]);
+#pragma unroll
+        for (int u = 2; u < 16; ++u) {
+#pragma unroll
+            for (int jj = 0; jj < SH_LEAN_CH; ++jj) p[jj] = fma(p[jj], c[h + jj], poly[u]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < SH_LEAN_CH; ++jj) out[h + jj] = p[jj] * s[h + jj];
+    }
+}
+// envelope of the lane's frame j of a tile: one line in front of frame ci (tile-relative), another from there on
+__device__ __forceinline__ double tile_envelope(double x, double ci, double ea0, double ea1, double eb0, double eb1) {
+    return x < ci ? fma(x, ea1, ea0) : fma(x, eb1, eb0);
+}
+
 // lean_harm_frames for a (voice, tile) pair of a tile-classified launch with a corner of the envelope inside: the envelope of
 // frame i is one line in front of frame ci (tile-relative) and another from there on, applied to the sample before the (constant)
 // bus gains.
@@ -631,11 +670,16 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
     // (only the masks k0 .. k1 - 1 of every group: the chunks of the set's range -- see TileSet)
     const uint32_t kw = B.tiles.k1 - B.tiles.k0, nmask = ngroups * kw, stride = ngroups * WAVES;
     const uint64_t* __restrict__ lrow = B.tiles.lean + (size_t)tile_index * (ngroups * B.tiles.mask_k);
-    uint32_t firstp = T.grp * WAVES + T.wave;
+    // (everything about WHICH pair comes next is wave-uniform -- ballots, set bits, popcounts -- and is kept in scalar registers by
+    // hand: left to itself the compiler did the arithmetic of nth_set_bit on the vector unit, ~50 VALU instructions per pair of the
+    // ~275: profiles/r04_summary.md, 44 % of the tiles kernel's VALU instructions were not float64)
+    uint32_t firstp = __builtin_amdgcn_readfirstlane(T.grp * WAVES + T.wave);
     for (uint32_t base = 0; base < nmask; base += 64) {
         const uint32_t mi = base + lane;
         const uint64_t mymask = mi < nmask ? lrow[(mi / kw) * B.tiles.mask_k + B.tiles.k0 + mi % kw] : 0ull;
-        uint64_t have = __ballot(mymask != 0ull);
+        const uint64_t have0 = __ballot(mymask != 0ull);
+        uint64_t have = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(have0 >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)have0);
         while (have) {
             const uint32_t src = (uint32_t)__builtin_ctzll(have);
             have &= have - 1;
@@ -652,9 +696,12 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                 uint32_t lane_again = lane;                               // (converted per entry: two registers less across the loop)
                 asm volatile("" : "+v"(lane_again));
                 const double lane_d = (double)lane_again;
-                // the voice of the list's entry p: the chunk's (p + 1)-th set bit -- its polynomial comes from the table by voice (read by
-                // every tile's workgroups: it lives in L2), at an address that does not wait for the record
-                const double SH_CONST_AS* pp = as_const(B.polys) + (size_t)(c * 64 + nth_set_bit(cmask, p)) * 16;
+                // the voice of the list's entry p: its position in the chunk rides in the record (round 3 found it as the chunk's (p + 1)-th
+                // set bit -- an address that did not wait for the record, at ~50 VALU instructions per pair: with the scalar registers this
+                // kernel has left, the compiler did that uniform arithmetic on the vector unit); its polynomial comes from the table by
+                // voice (read by every tile's workgroups: it lives in L2)
+                const uint32_t vbit = *reinterpret_cast<const uint32_t SH_CONST_AS*>(reinterpret_cast<const char SH_CONST_AS*>(&q->pad_) + 4);
+                const double SH_CONST_AS* pp = as_const(B.polys) + (size_t)(c * 64 + vbit) * 16;
                 double poly[16];
 #pragma unroll
                 for (int v_ = 0; v_ < 16; ++v_) poly[v_] = pp[v_];
@@ -733,29 +780,37 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                         continue;
                     }
                 }
+                // ---- a polynomial-Harmonics pair: w[j] = sample x envelope of the lane's frame j by the pair's kind, then ONE accumulation ----
+                double w[FPL], gl_e = GL, gr_e = GR;
                 if (pc == 1u) {
-                    // one piece, one line (seven pairs of eight): the lean arithmetic of an ordinary launch with the line folded into the gains
+                    // one piece, one line (seven pairs of eight): the lean arithmetic of an ordinary launch
                     double s0, c0s, s1, c1s;
                     shm::sincos_tab(fma(lane_d, dt, t0), trig, s0, c0s);
                     s1 = fma(s0, rc, c0s * rs);
                     c1s = fma(c0s, rc, -(s0 * rs));
-                    if (ea1 == 0.0)          // a flat line (the sustain: two thirds of a note's life): the headline's loop, two operations per frame less
-                        lean_harm_frames<FPL>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL * ea0, GR * ea0, accl, accr);
-                    else
-                        lean_harm_frames<FPL, true>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL * ea0, GR * ea0, accl, accr, GL * ea1, GR * ea1, lane_d);
+                    lean_harm_values<FPL>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, w);
+                    if (ea1 == 0.0) {        // a flat line (the sustain: two thirds of a note's life): the line folded into the gains
+                        gl_e = GL * ea0;
+                        gr_e = GR * ea0;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < FPL; ++j) w[j] = w[j] * fma(lane_d + (double)(j * 64), ea1, ea0);
+                    }
                 } else if ((pc & 0xFFFFu) == 1u) {
                     // one piece, a corner: the envelope changes lines at frame pc >> 16
-                    const double eb0 = q->eb0, eb1 = q->eb1;
+                    const double eb0 = q->eb0, eb1 = q->eb1, ci = (double)(pc >> 16);
                     double s0, c0s, s1, c1s;
                     shm::sincos_tab(fma(lane_d, dt, t0), trig, s0, c0s);
                     s1 = fma(s0, rc, c0s * rs);
                     c1s = fma(c0s, rc, -(s0 * rs));
-                    lean_tile_frames<FPL>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, GL, GR, ea0, ea1, eb0, eb1, (double)(pc >> 16), lane_d, accl, accr);
+                    lean_harm_values<FPL>(s0, c0s, s1, c1s, rc + rc, false, none, trig, poly, w);
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) w[j] = w[j] * tile_envelope(lane_d + (double)(j * 64), ci, ea0, ea1, eb0, eb1);
                 } else if ((pc & 0xFFFFu) == 0u) {
                     // a WALK pair (see TileRec): lanes 0 .. 15 fetch a piece of the voice's table each -- one round trip -- and every
                     // frame takes the angle of the last piece that starts at or in front of it; a frame in front of them all (the
                     // onset lies inside the tile) keeps the angle 0, whose sine is 0
-                    const double eb0 = q->eb0, eb1 = q->eb1, dn0 = q->tb[0];
+                    const double eb0 = q->eb0, eb1 = q->eb1, dn0 = q->tb[0], ci = (double)(pc >> 16);
                     const uint64_t wbits = *reinterpret_cast<const uint64_t SH_CONST_AS*>(&q->tb[1]);
                     const uint32_t seg_first = (uint32_t)wbits, seg_end = (uint32_t)(wbits >> 32);
                     const uint32_t kidx = seg_first + (lane & (TILE_WALK_PIECES - 1));
@@ -776,38 +831,33 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                             th[j] = x >= rk ? fma(x - rk, dk, tk) : th[j];
                         }
                     }
-                    // (the polynomial once more, behind the walk: its sixteen coefficients would sit in scalar registers through a loop
-                    // that needs those for the pieces -- and what the scalar file cannot hold costs vector registers this kernel lacks)
-                    const uint64_t pp_bits = (uint64_t)pp;
-                    const double SH_CONST_AS* pp2 = (const double SH_CONST_AS*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pp_bits >> 32)) << 32) |
-                                                                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pp_bits));
-                    double poly2[16];
-#pragma unroll
-                    for (int v_ = 0; v_ < 16; ++v_) poly2[v_] = pp2[v_];
 #pragma unroll
                     for (int j = 0; j < FPL; ++j) {
-                        const double x = lane_d + (double)(j * 64);
                         double sj, cj;
                         shm::sincos_tab(th[j], trig, sj, cj);
-                        double pj = fma(poly2[0], cj, poly2[1]);
+                        double pj = fma(poly[0], cj, poly[1]);
 #pragma unroll
-                        for (int u = 2; u < 16; ++u) pj = fma(pj, cj, poly2[u]);
-                        const double ej = x < (double)(pc >> 16) ? fma(x, ea1, ea0) : fma(x, eb1, eb0);
-                        const double xj = (pj * sj) * ej;
-                        accl[j] = fma(GL, xj, accl[j]);
-                        accr[j] = fma(GR, xj, accr[j]);
+                        for (int u = 2; u < 16; ++u) pj = fma(pj, cj, poly[u]);
+                        w[j] = (pj * sj) * tile_envelope(lane_d + (double)(j * 64), ci, ea0, ea1, eb0, eb1);
                     }
                 } else {
                     // piece ends inside the tile: every frame by lookup from the piece that holds it
-                    const double eb0 = q->eb0, eb1 = q->eb1;
+                    const double eb0 = q->eb0, eb1 = q->eb1, ci = (double)(pc >> 16);
                     const TileTheta theta{lane_d, t0, dt, q->tb[0], q->tb[1], q->db[0], q->db[1], lane, q->split[0], q->split[1]};
                     double s0, c0s, s1, c1s;
                     shm::sincos_tab(theta(0), trig, s0, c0s);
                     shm::sincos_tab(theta(1), trig, s1, c1s);
-                    lean_tile_frames<FPL>(s0, c0s, s1, c1s, 0.0, true, theta, trig, poly, GL, GR, ea0, ea1, eb0, eb1, (double)(pc >> 16), lane_d, accl, accr);
+                    lean_harm_values<FPL>(s0, c0s, s1, c1s, 0.0, true, theta, trig, poly, w);
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) w[j] = w[j] * tile_envelope(lane_d + (double)(j * 64), ci, ea0, ea1, eb0, eb1);
+                }
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    accl[j] = fma(gl_e, w[j], accl[j]);
+                    accr[j] = fma(gr_e, w[j], accr[j]);
                 }
             }
-            firstp = p - npairs;
+            firstp = __builtin_amdgcn_readfirstlane(p - npairs);
         }
     }
 }
