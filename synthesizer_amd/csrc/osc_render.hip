@@ -378,7 +378,10 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // voice-sample.  The 32 float64 accumulator pairs do not fit 128 registers beside the loop (at 128 the compiler spills inside the
     // Horner chains: 63 us per block), so the shape runs at THREE waves per SIMD (167 registers): 41.6 instead of 46 us for a launch
     // alone, 35.4-35.7 instead of 35.8-35.9 us in a stream of launches (fewer instructions, but a CU holds three workgroups, not four:
-    // less of the neighbouring launch beside it).  Tiles of 1024 frames need twice the voice groups to fill the chip (47 tiles x 16
+    // less of the neighbouring launch beside it).  TWELVE frames per lane fit 128 registers without a spill in the loop -- 7 % fewer
+    // instructions at four waves per SIMD -- and ran 36.5-36.7 us: slower than eight (36.0).  Fewer instructions do not buy time in
+    // the stream of launches; the clock the chip holds falls as the pipe fills (2.38 GHz with one wavefront per SIMD, 2.12-2.18 with
+    // two launches in flight: profiles/r04_headline_phases.md).  Tiles of 1024 frames need twice the voice groups to fill the chip (47 tiles x 16
     // groups of 64 voices for the headline: the same 752 workgroups), so: polynomial-Harmonics banks (the lean kernel of that kind is
     // the one instantiated at this shape), a split launch, and enough 64-voice chunks for the groups.
     if (K.variant == 0 && var == 484 && mode == COMBINED_LEAN_HARM && !tile_candidate && !K.no_split && K.groups == 0) {

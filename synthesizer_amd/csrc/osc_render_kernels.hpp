@@ -266,7 +266,7 @@ __device__ __forceinline__ void fold_previous(const FoldIn& F, uint32_t ngroups,
 // dst: a plane of partial buses (launch-relative frames) -- or NULL: the final bus `out` (single-group launches).  The staging buffer
 // holds RED_ROWS(FPL) rows of 64 frames per wave and channel: eight at most (32 KB at four waves -- four workgroups per CU with the
 // trig table); sixteen frames per lane go through it in two passes.
-constexpr int red_rows(int fpl) { return fpl < 8 ? fpl : 8; }
+constexpr int red_rows(int fpl) { return fpl <= 8 ? fpl : (fpl % 8 == 0 ? 8 : (fpl % 6 == 0 ? 6 : 4)); }
 template <int WAVES, int FPL>
 __device__ __forceinline__ void reduce_store(double (*red)[2][64 * red_rows(FPL)], const TileCtx& T, const double (&accl)[FPL], const double (&accr)[FPL],
                                              double2* __restrict__ dst, size_t dst_off, const BusOut& out) {
