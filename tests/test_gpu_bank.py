@@ -675,3 +675,50 @@ def test_banks_rendering_turn_by_turn_keep_their_pipelines(gpu):
     assert np.array_equal(read(shared), alone[0][3])
     for k in range(3):
         assert np.array_equal(read(outs[k]), alone[0][k]) and np.array_equal(read(outs[3 + k]), alone[2][k]), k
+
+
+def test_fm_only_lean_kernel_in_a_steady_window(gpu):
+    """Round 4: a bank whose lean candidates are ALL FM Sine voices renders its steady blocks through the lean kernel instantiated for
+    that kind alone (k_render_lean<.., LEAN_K_FM, false>): sines by sin_tab_n, the accumulated time of a one-piece tile by one addition
+    per frame, one accumulation behind the four forms (straddle x LFO bias).  256 voices, a third of the LFOs with a bias, a window of
+    two 16 384-frame blocks that holds the time table's piece end at n = 48 000 (t = 1.0: the tile there straddles it) against the C
+    oracle; and the same blocks as a pipelined run and through the general code (SYNTHHIP_VARIANT shapes are not needed: 444 split)."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    nv, blk, first = 256, 16384, 40000
+    rng = np.random.default_rng(11)
+    f = np.exp(rng.uniform(np.log(55.0), np.log(3520.0), nv))
+    amp = rng.uniform(0.1, 1.0, nv) / np.sqrt(nv)
+    ph = rng.uniform(0.0, 1.0, nv)
+    fm = rng.uniform(0.5, 8.0, nv)
+    depth = rng.uniform(0.0, 0.05, nv)
+    pm = rng.uniform(0.0, 1.0, nv)
+    gains = [(float(np.float32(g)), float(np.float32(1.0 - g))) for g in rng.uniform(0.0, 1.0, nv)]
+
+    def build(m):
+        out = []
+        for i in range(nv):
+            lfo = m.Sine(float(fm[i]), float(depth[i]), phase=float(pm[i]), bias=(0.01 if i % 3 == 0 else 0.0), samplerate=SR)
+            out.append(m.Sine(float(f[i]), amplitude=float(amp[i]), phase=float(ph[i]), fm_lfo=lfo, samplerate=SR))
+        return out
+    gv, ov = build(G), build(O)
+    want = _c_oracle_bus(ov, gains, first + 2 * blk)
+    bank = VoiceBank(gv, gains=gains)
+    for k in range(2):
+        got = bank.render(blk, start=first + k * blk)
+        w = want[first + k * blk: first + (k + 1) * blk]
+        assert rms(got, w) <= RMS_TOL and np.max(np.abs(got - w)) < 5e-7, k
+        assert np.abs(w).max() > 0.05
+    import ctypes as C
+    a, b = C.c_uint32(), C.c_uint32()
+    N.check(N.lib().sh_bank_launch_stats(bank._bank.handle, C.byref(a), C.byref(b)))
+    assert (a.value, b.value) == (nv, 0)                    # every voice took the lean lists in the steady window
+    # the pipelined run of the same blocks (records two launches ahead, folds taken over): bit-identical with the single renders
+    ring = [N.DeviceBuffer(blk * 8) for _ in range(4)]
+    singles = [bank.render(blk, start=first + k * blk) for k in range(4)]
+    for k in range(4):
+        bank.render_device(blk, first + k * blk, bus_f32=ring[k])
+    N.sync()
+    for k in range(4):
+        assert np.array_equal(ring[k].download(np.float32, blk * 2).reshape(blk, 2), singles[k]), k
