@@ -115,11 +115,16 @@ bool fold_owed_into(const void* p, size_t bytes);   // does any bank still owe a
 inline bool has_pending() { return state().pending_total != 0 || state().aux_busy || state().open_runs != 0; }
 int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* out);   // float64 bus -> float32 (osc.hip)
 
+// HIP's current device is a property of the HOST THREAD: a thread other than the one that called sh_init (the reference drives its
+// mixer from two) starts on device 0 -- on rank 3 of a multi-GPU job its allocations and launches would land on the wrong GPU.  Every
+// entry point binds its thread to the library's device once (round 4; sh_init(device != 0) has yet to run on hardware: DESIGN section 5).
+int bind_thread_to_device();           // runtime.hip
 #define SH_REQUIRE_INIT_KEEP_PENDING()                                                 \
     SH_API_LOCK();                                                                     \
     do {                                                                               \
         if (!sh::state().initialized)                                                  \
             return sh::set_error(SH_ERR_NOTINIT, "sh_init() has not been called");     \
+        { int rc_bind__ = sh::bind_thread_to_device(); if (rc_bind__) return rc_bind__; } \
     } while (0)
 
 #define SH_REQUIRE_INIT()                                                              \
@@ -127,6 +132,7 @@ int  bus_finalize_on(hipStream_t st, const double* in, size_t nvalues, float* ou
     do {                                                                               \
         if (!sh::state().initialized)                                                  \
             return sh::set_error(SH_ERR_NOTINIT, "sh_init() has not been called");     \
+        { int rc_bind__ = sh::bind_thread_to_device(); if (rc_bind__) return rc_bind__; } \
         if (sh::has_pending()) {                                                       \
             int rc_pending__ = sh::flush_pending();                                    \
             if (rc_pending__) return rc_pending__;                                     \

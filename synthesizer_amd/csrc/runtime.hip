@@ -40,6 +40,16 @@ void load_knobs() {
     g_knobs = k;
 }
 
+int bind_thread_to_device() {
+    thread_local int bound = -1;
+    const int want = state().device;
+    if (bound != want) {
+        SH_HIP(hipSetDevice(want));
+        bound = want;
+    }
+    return SH_OK;
+}
+
 std::recursive_mutex& api_mutex() {
     static std::recursive_mutex m;
     return m;
