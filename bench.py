@@ -655,7 +655,8 @@ def main() -> int:
     N.ensure_init(dist.device_for_rank())          # the GPU ordinal = LOCAL_RANK (one process per GPU)
     info = N.device_info()
     if world > 1:
-        dist.init(rank, world, broadcast=gloo_broadcast)
+        with _stdout_to_stderr():          # (librccl prints a version banner on stdout at communicator creation: not beside the JSON line)
+            dist.init(rank, world, broadcast=gloo_broadcast)
     # what RCCL itself saw (ncclCommCount / ncclCommUserRank), read back BEFORE anything is timed: a line that claims N GPUs must
     # come from a communicator of N ranks, each on a GPU of its own
     rccl = dist.comm_info()
