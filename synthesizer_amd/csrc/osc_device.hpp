@@ -271,7 +271,7 @@ struct LaunchSet {
     VoiceFM*     fm;
     FastRec*     fast;
     uint32_t*    gen_idx;
-    uint32_t*    counts;          // per chunk: [4c] = lean voices, [4c+1] = general voices, [4c+2] = silent voices
+    uint32_t*    counts;          // per chunk: [4c] = lean voices, [4c+1] = general voices, [4c+2] = silent voices, [4c+3] = Harmonics | FM Sine << 8 of the lean ones
 };
 
 struct PrepInfo {                 // what prepare_voice found, for the classification
@@ -561,8 +561,15 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
     const bool is_gen = vi < nvoices && !info.fast && !info.silent;
     const uint64_t mf = __ballot(is_fast), mg = __ballot(is_gen);
     const uint64_t below = (1ull << lane) - 1ull;
+    // the lean list in three runs -- polynomial Harmonics, FM Sine, the rest (plain Sine and the waveforms) -- so that a bank of mixed
+    // kinds is rendered by three loops one after the other, each as tight as the kernel of a bank of that kind alone (lean_lists)
+    const uint64_t mh = __ballot(is_fast && info.kind == LEAN_HARM), mm = __ballot(is_fast && info.kind == LEAN_FM);
+    const uint32_t n_harm = (uint32_t)__popcll(mh), n_fm = (uint32_t)__popcll(mm);
     if (is_fast) {
-        FastRec* __restrict__ f = S.fast + c * 64 + (uint32_t)__popcll(mf & below);
+        const uint32_t pos = info.kind == LEAN_HARM ? (uint32_t)__popcll(mh & below)
+                           : info.kind == LEAN_FM ? n_harm + (uint32_t)__popcll(mm & below)
+                           : n_harm + n_fm + (uint32_t)__popcll(mf & ~mh & ~mm & below);
+        FastRec* __restrict__ f = S.fast + c * 64 + pos;
         f->t_base = info.t_base; f->dt = info.dt;
         f->gain_l = info.gain_l; f->gain_r = info.gain_r;
         f->rot_c = info.rot_c; f->rot_s = info.rot_s;
@@ -597,7 +604,7 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         S.counts[4 * c] = (uint32_t)__popcll(mf);
         S.counts[4 * c + 1] = (uint32_t)__popcll(mg);
         S.counts[4 * c + 2] = (uint32_t)__popcll(ms);
-        S.counts[4 * c + 3] = 0;
+        S.counts[4 * c + 3] = n_harm | (n_fm << 8);       // the runs of the lean list
     }
 }
 

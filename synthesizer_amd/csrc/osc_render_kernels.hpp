@@ -21,6 +21,7 @@
 // block expected two launches on (prep_rows_*): a steady stream is ONE kernel per block.
 #pragma once
 #include "osc_device.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -464,15 +465,16 @@ __device__ __forceinline__ void lean_fm_frames(const double (&poly)[16], double 
 // instantiation: the extra branches and code cost its loop 5 %); LEAN_K_FM -- every one is an FM Sine voice (BASELINE config 3);
 // LEAN_K_ALL -- anything.  SEG: the records of a segmented launch (sloped gains; the second
 // piece's fields belong in the first batch of loads -- half the tiles lie behind the crossing).
-enum { LEAN_K_HARM = 0, LEAN_K_ALL = 1, LEAN_K_FM = 2 };     // which kinds of lean record a bank can hold (static)
+enum { LEAN_K_HARM = 0, LEAN_K_ALL = 1, LEAN_K_FM = 2, LEAN_K_REST = 3 };     // which kinds of lean record a bank can hold (static); _REST: a run of a list
 template <int WAVES, int FPL, int KINDS, bool SEG>
 __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, TrigTab trig, double (&accl)[FPL], double (&accr)[FPL]) {
     const uint32_t lane = T.lane, tile0 = T.tile0, tile_last = T.tile_last;
     for (uint32_t c = T.c0; c < T.c1; ++c) {
         const uint32_t nfast = as_const(T.set.counts)[4 * c];
-        const FastRec SH_CONST_AS* q = as_const(T.set.fast) + c * 64 + first;
-        uint32_t p = first;
-        for (; p < nfast; p += WAVES, q += WAVES) {
+        // (one list entry; CLS: the run of the list it lies in -- LEAN_K_HARM, LEAN_K_FM or LEAN_K_REST)
+        auto entry = [&](auto cls_, const FastRec SH_CONST_AS* q, uint32_t p) __attribute__((always_inline)) {
+            constexpr int CLS = decltype(cls_)::value;
+            (void)p;
 #ifdef SH_DIAG2
             const bool d2on = blockIdx.x == 1 && blockIdx.y == 1 && T.wave == 0 && c == T.c0 + 1;
             uint64_t d2t[5] = {0, 0, 0, 0, 0};
@@ -514,7 +516,7 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                 if (!straddle) { t_base = tb; dt = db; rc = rcb; rs = rsb; off = ob; }
             }
             const LaneTheta theta{di0, t_base, dt, off, ta, da, tb, db, ob, i0, remain, straddle};    // the accumulated t at frame j
-            if constexpr (KINDS == LEAN_K_FM) {
+            if constexpr (CLS == LEAN_K_FM) {
                 // every lean record of the bank is an FM Sine voice: the FM code alone (no polynomial path, no waveform branches: the kernel
                 // with all kinds needs 128 VGPRs and spills; round 4)
                 double sn[FPL];
@@ -531,9 +533,9 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                     accl[j] = fma(gl, sn[j], accl[j]);
                     accr[j] = fma(gr, sn[j], accr[j]);
                 }
-                continue;
+                return;
             }
-            if (KINDS == LEAN_K_HARM || kind == LEAN_HARM) {
+            if constexpr (CLS == LEAN_K_HARM) {
                 // polynomial Harmonics: lookup + one rotation + the three-term recurrence (lean_harm_frames)
                 double s0, c0, s1, c1;
 #ifdef SH_DIAG2
@@ -569,9 +571,9 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                     }
                 }
 #endif
-                continue;
+                return;
             }
-            if constexpr (KINDS == LEAN_K_ALL) {
+            if constexpr (CLS == LEAN_K_REST) {
             if (kind == LEAN_SINE) {
                 // a plain Sine: the same recurrence on the sine alone (the amplitude lives in the gains)
                 double s0, c0, s1, c1;
@@ -594,18 +596,7 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                         s1 = s2;
                     }
                 }
-                continue;
-            }
-            if (kind == LEAN_FM) {
-                double sn[FPL];
-                if (poly[7] == 0.0) lean_fm_frames<FPL, false, false>(poly, di0, theta, 0.0, 0.0, trig, sn);
-                else lean_fm_frames<FPL, true, false>(poly, di0, theta, 0.0, 0.0, trig, sn);
-#pragma unroll
-                for (int j = 0; j < FPL; ++j) {
-                    accl[j] = fma(gl, sn[j], accl[j]);
-                    accr[j] = fma(gr, sn[j], accr[j]);
-                }
-                continue;
+                return;
             }
             // Sawtooth / Square / Triangle / Pulse at unit amplitude (the amplitude lives in the gains): t in turns, frame by frame
 #pragma unroll
@@ -619,6 +610,19 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                 accr[j] = fma(gr, x, accr[j]);
             }
             }
+        };
+        const FastRec SH_CONST_AS* q = as_const(T.set.fast) + c * 64 + first;
+        uint32_t p = first;
+        if constexpr (KINDS == LEAN_K_ALL) {
+            // the list's three runs (prepare_chunk), one loop each: a loop over a switch of the kinds cost the Harmonics entries 16 % and
+            // the FM Sine entries 25-100 % of what the kernels of unmixed banks need (accumulator copies where the branches join, spills)
+            const uint32_t runs = as_const(T.set.counts)[4 * c + 3];
+            const uint32_t end_harm = runs & 0xFFu, end_fm = end_harm + ((runs >> 8) & 0xFFu);
+            for (; p < end_harm; p += WAVES, q += WAVES) entry(std::integral_constant<int, LEAN_K_HARM>{}, q, p);
+            for (; p < end_fm; p += WAVES, q += WAVES) entry(std::integral_constant<int, LEAN_K_FM>{}, q, p);
+            for (; p < nfast; p += WAVES, q += WAVES) entry(std::integral_constant<int, LEAN_K_REST>{}, q, p);
+        } else {
+            for (; p < nfast; p += WAVES, q += WAVES) entry(std::integral_constant<int, KINDS>{}, q, p);
         }
         first = p - nfast;                                    // 0 .. WAVES-1: where the stride lands in the next list
     }
