@@ -606,6 +606,19 @@ def config_rows(N, prof=None, only=None, K=20):
     if only in (None, "config3"):
         v, g = W.fm_voices(G, 1024, SR, seed=1)
         bank_row("config3_fm_1024v_48k_stereo", "config3", v, g, "1024 Sine carriers, each with a Sine fm_lfo (closed-form running sum), -> float32 stereo bus")
+    if only is None:
+        # not a BASELINE config: Harmonics and FM Sine voices in ONE bank (what a patch with both kinds of instrument asks for): the lean
+        # lists hold the kinds in runs, one loop per run (tools/mixed_kinds_probe.py has the other mixes)
+        va, ga = W.additive_voices(G, 512, SR, seed=0, partials=PARTIALS, adsr=ADSR_BENCH)
+        vf, gf = W.fm_voices(G, 512, SR, seed=1)
+        v = [x for pair in zip(va, vf) for x in pair]
+        g = [x for pair in zip(ga, gf) for x in pair]
+        bank_row("mixed_512_additive_512_fm_48k_stereo", "mixed", v, g,
+                 "512 Harmonics x16 voices + ADSR interleaved with 512 FM Sine voices in one bank -> float32 stereo bus")
+        r = rows["mixed_512_additive_512_fm_48k_stereo"]
+        r["roofline"] = {"bound": "valu_f64", "note": "no profiling pass of its own: between the headline's and config 3's operations per voice-sample"}
+        if "config3_fm_1024v_48k_stereo" in rows:
+            r["x_config3"] = r["ms_per_1s_block"] / rows["config3_fm_1024v_48k_stereo"]["ms_per_1s_block"]
     if only in (None, "config4"):
         rows["config4_8192v_8gpu"] = config4_rows(N, K)
     if only is None:
