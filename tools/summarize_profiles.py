@@ -23,8 +23,8 @@ def short(name):
 
 shutil.copy(src / "stats_kernel_stats.csv", out / ("%s_kernel_stats.csv" % tag))
 lines = ["# rocprofv3 summary %s" % tag, "",
-         "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 5 --cpu-frames 0` "
-         "(PMC passes: separate runs with `--pmc ...`, 10 steps).", "",
+         "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 5 --cpu-frames 0 --no-configs --min-seconds 0.25` "
+         "(PMC passes: separate runs with `--pmc ...`, `--steps 30 --warmup 100 --min-seconds 0`; tools/profile_round.sh).", "",
          "## Kernel durations (kernel-trace --stats)", "",
          "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
 for r in csv.DictReader(open(src / "stats_kernel_stats.csv")):
