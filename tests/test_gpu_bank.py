@@ -722,3 +722,74 @@ def test_fm_only_lean_kernel_in_a_steady_window(gpu):
     N.sync()
     for k in range(4):
         assert np.array_equal(ring[k].download(np.float32, blk * 2).reshape(blk, 2), singles[k]), k
+
+
+def test_lean_lists_in_runs_by_kind(gpu):
+    """Round 4: every chunk's lean list is written in three runs (polynomial Harmonics, FM Sine, the rest) and the all-kinds lean kernel
+    walks each run with a loop of its own.  Banks whose chunks hold every composition -- one kind only, runs of one entry, runs that a
+    wavefront's stride of four skips entirely, a last chunk that is not full -- against the C oracle in a steady window, and the float64
+    bus of the mixed bank against the sum of the buses of its three single-kind sub-banks (each rendered by another instantiation of
+    the kernel)."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    nv, blk, first = 333, 6000, 70000
+    rng = np.random.default_rng(21)
+    f = np.exp(rng.uniform(np.log(55.0), np.log(3520.0), nv))
+    amp = rng.uniform(0.1, 1.0, nv) / np.sqrt(nv)
+    ph = rng.uniform(0.0, 1.0, nv)
+    fm = rng.uniform(0.5, 8.0, nv)
+    depth = rng.uniform(0.0, 0.05, nv)
+    gains = [(float(np.float32(g)), float(np.float32(1.0 - g))) for g in rng.uniform(0.0, 1.0, nv)]
+    # chunk 0: Harmonics only; chunk 1: FM Sine only; chunk 2: waveforms only; chunk 3: one Harmonics, one FM Sine, the rest Sawtooth;
+    # chunk 4: random; chunk 5 (13 voices): random
+    kinds = np.concatenate([np.zeros(64, int), np.ones(64, int), 2 + rng.integers(0, 5, 64), [0, 1] + [2] * 62,
+                            rng.integers(0, 7, 64), rng.integers(0, 7, nv - 320)])
+
+    def build(m, only=None):
+        out = []
+        for i in range(nv):
+            k = int(kinds[i])
+            cls = 0 if k == 0 else 1 if k == 1 else 2
+            if only is not None and cls != only:
+                continue
+            fr, a, p = float(f[i]), float(amp[i]), float(ph[i])
+            if k == 0:
+                v = m.Harmonics(fr, [(j, 1.0 / j) for j in range(1, 1 + 1 + i % 16)], a, phase=p, samplerate=SR)
+            elif k == 1:
+                v = m.Sine(fr, a, phase=p, fm_lfo=m.Sine(float(fm[i]), float(depth[i]), samplerate=SR), samplerate=SR)
+            elif k == 2:
+                v = m.Sawtooth(fr, a, phase=p, samplerate=SR)
+            elif k == 3:
+                v = m.Square(fr, a, phase=p, samplerate=SR)
+            elif k == 4:
+                v = m.Triangle(fr, a, phase=p, samplerate=SR)
+            elif k == 5:
+                v = m.Pulse(fr, a, phase=p, pulsewidth=0.3, samplerate=SR)
+            else:
+                v = m.Sine(fr, a, phase=p, samplerate=SR)
+            out.append(v)
+        return out
+    cls_of = [0 if k == 0 else 1 if k == 1 else 2 for k in kinds]
+    bank = VoiceBank(build(G), gains=gains)
+    want = _c_oracle_bus(build(O), gains, first + 2 * blk)
+    for k in range(2):
+        got = bank.render(blk, start=first + k * blk)
+        w = want[first + k * blk: first + (k + 1) * blk]
+        assert rms(got, w) <= RMS_TOL and np.max(np.abs(got - w)) < 5e-7, k
+    import ctypes as C
+    a, b = C.c_uint32(), C.c_uint32()
+    N.check(N.lib().sh_bank_launch_stats(bank._bank.handle, C.byref(a), C.byref(b)))
+    assert (a.value, b.value) == (nv, 0)                    # every voice took the lean lists
+    whole = N.DeviceBuffer(blk * 16)
+    bank.render_device(blk, first, bus_f64=whole)
+    total = np.zeros(blk * 2)
+    for c in range(3):
+        sub = VoiceBank(build(G, only=c), gains=[g for g, cc in zip(gains, cls_of) if cc == c])
+        part = N.DeviceBuffer(blk * 16)
+        sub.render_device(blk, first, bus_f64=part)
+        total += part.download(np.float64, blk * 2)
+        part.free()
+    got64 = whole.download(np.float64, blk * 2)
+    whole.free()
+    assert np.max(np.abs(got64 - total)) < 1e-12
