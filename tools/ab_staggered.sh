@@ -1,4 +1,6 @@
-for L in synthesizer_amd/libsynthhip.so synthesizer_amd/build/libsynthhip_tpw2.so synthesizer_amd/build/libsynthhip_tpw4.so synthesizer_amd/build/libsynthhip_tpw6.so synthesizer_amd/build/libsynthhip_tpw8.so synthesizer_amd/build/libsynthhip_tpw12.so synthesizer_amd/libsynthhip.so; do
+#!/bin/bash
+# The staggered_notes row (us per block, from a standing start, per 4096-frame chunk) under each of the libraries named: A/B of build variants.
+for L in "$@"; do
   SYNTHHIP_ALLOW_STALE=1 SYNTHHIP_LIB=$L timeout 100 python bench.py --only-config staggered 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().splitlines()[-1]); s=d['configs']['staggered_notes'] if 'configs' in d and 'staggered_notes' in d['configs'] else d.get('staggered_notes', d)
