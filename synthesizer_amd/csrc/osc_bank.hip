@@ -415,6 +415,8 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
                 const sh_voice& v = voices[i];
                 const double row[8] = {v.frequency, v.fm_phase0, v.frequency * v.fm_inc, v.lfo_a, v.lfo_d, v.lfo_K, v.lfo_C0, v.lfo_bias};
                 for (int u = 0; u < 8; ++u) polys[(size_t)i * 16 + u] = row[u];
+                polys[(size_t)i * 16 + 8] = lfo_rot[i].x;                                  // (the LFO's rotation by 64 samples)
+                polys[(size_t)i * 16 + 9] = lfo_rot[i].y;
             }
             else if (voices[i].kind == SH_SINE) polys[(size_t)i * 16 + 15] = 1.0;
             else if (voices[i].kind == SH_PULSE) polys[(size_t)i * 16] = voices[i].pulsewidth;

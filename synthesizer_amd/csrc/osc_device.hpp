@@ -97,14 +97,14 @@ struct TileTheta {
     }
 };
 struct TileSet {
-    TileRec*  recs;               // [tile][slot]: the lean pairs of chunk c of a tile compacted at slots 64 (c - k0 groups) .. (their count: the bits
-                                  // of the mask); a tile's row holds rec_chunks chunks -- the set's RANGE of chunks, not the table (a table of
+    TileRec*  recs;               // [tile][slot]: the lean pairs of chunk c of a tile compacted at slots 64 (c - k0 groups) .. (their count: the low
+                                  // half of the chunk's word in `lean`); a tile's row holds rec_chunks chunks -- the set's RANGE of chunks, not the table (a table of
                                   // 22 528 notes of which 30 chunks sound: 30 MB of records per set instead of 271)
     // masks: [tile][group][k], chunk c = group + k * groups (a voice group of a tile-classified launch = every groups-th chunk:
     // notes that sound together tend to be neighbours in the voice table, and a range of chunks would give one group all of
     // them); mask_k = masks per (tile, group), a multiple of 8: a workgroup fetches its masks in batches of eight scalar loads
-    uint64_t* lean;               // bit b = voice 64 c + b is lean in this tile
-    uint64_t* gen;                // ... takes the general code in this tile
+    uint64_t* lean;               // the chunk's lean pairs in this tile: their number | the Harmonics pairs << 32 | the FM Sine pairs << 40 (the list's runs)
+    uint64_t* gen;                // bit b = voice 64 c + b takes the general code in this tile
     uint32_t  groups, mask_k;
     // the set is resolved (and read) for the chunks [k0 groups, k1 groups) only: the masks of a group are its slots k0 .. k1 - 1 --
     // the chunks in front and behind are silent throughout the block (a table of notes in the order they start: a few dozen of
@@ -1344,14 +1344,23 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         any_general = any_general || is_gen;
         if (sounds) { any_sound = true; last_piece = wb + r; }
         const uint64_t ml = __ballot(is_lean || is_walk), mg = __ballot(is_gen);
-        if (is_lean || is_walk) {                                // the chunk's lean pairs, compacted in voice order
-            TileRec* __restrict__ q = T.recs + (size_t)t * slots + (c - T.k0 * T.groups) * 64 + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
+        // the chunk's lean pairs in three runs, each in voice order -- polynomial Harmonics (plain Sines among them), FM Sine, the plain
+        // waveforms -- which the render kernel walks with a loop each (tiles_lean; the lean lists of an ordinary launch: prepare_chunk)
+        const uint64_t mh = __ballot((is_lean || is_walk) && rec_kind == LEAN_HARM), mm = __ballot((is_lean || is_walk) && rec_kind == LEAN_FM);
+        const uint32_t n_harm = (uint32_t)__popcll(mh), n_fm = (uint32_t)__popcll(mm);
+        if (is_lean || is_walk) {
+            const uint64_t below = (1ull << lane) - 1ull;
+            const uint32_t pos = rec_kind == LEAN_HARM ? (uint32_t)__popcll(mh & below)
+                               : rec_kind == LEAN_FM ? n_harm + (uint32_t)__popcll(mm & below)
+                               : n_harm + n_fm + (uint32_t)__popcll(ml & ~mh & ~mm & below);
+            TileRec* __restrict__ q = T.recs + (size_t)t * slots + (c - T.k0 * T.groups) * 64 + pos;
             // (a corner at the tile's end -- the tail sample of a release is its last frame -- is no corner of this tile)
             const uint32_t corner = (rec_corner > 0 && rec_corner < TILE_FRAMES && !(rec_ea0 == rec_eb0 && rec_ea1 == rec_eb1)) ? rec_corner : 0u;
             if (!corner) { rec_eb0 = rec_ea0; rec_eb1 = rec_ea1; }
             double2* __restrict__ q2 = reinterpret_cast<double2*>(q);      // eight 16-byte stores
             q2[0] = make_double2(rec_t0, win_pick<double>(w_dt, r, 0.0));
-            q2[1] = rec_kind == LEAN_FM ? make_double2(dn0, 0.0) : rot;      // (an FM pair: the voice's own index of the tile's first frame)
+            // (an FM pair: the voice's own index of the tile's first frame and the LFO's angle there, a + (n - 1/2) d)
+            q2[1] = rec_kind == LEAN_FM ? make_double2(dn0, fma(dn0 - 0.5, v.lfo_d, v.lfo_a)) : rot;
             q2[2] = make_double2(rec_ea0, rec_ea1);
             q2[3] = make_double2(rec_eb0, rec_eb1);
             q2[4] = make_double2(amp * bgl, amp * bgr);
@@ -1368,7 +1377,7 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         }
         if (lane == 0) {
             const size_t at = ((size_t)t * T.groups + c % T.groups) * T.mask_k + c / T.groups;
-            T.lean[at] = ml;
+            T.lean[at] = (uint64_t)(uint32_t)__popcll(ml) | ((uint64_t)n_harm << 32) | ((uint64_t)n_fm << 40);
             T.gen[at] = mg;
         }
     }

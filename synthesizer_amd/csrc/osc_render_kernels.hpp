@@ -425,11 +425,12 @@ __device__ __forceinline__ void sin_tab_n(const double (&t)[N], TrigTab tab, dou
 // (LaneTheta: the one tile per crossing that straddles a piece end).  The sines go to out[]: the caller accumulates them in ONE place
 // behind the four forms of this function (with the accumulation inside each, the compiler shuffled the accumulators between the forms'
 // register assignments: ~25 register copies per eight frames).
-template <int FPL, bool BIASED, bool LINEAR, typename TimeFn>
-__device__ __forceinline__ void lean_fm_frames(const double (&poly)[16], double di0, TimeFn time, double t_first, double t_step,
-                                               TrigTab trig, double (&out)[FPL]) {
-    const double frequency = poly[0], f_inc = poly[2], lfo_a_rel = poly[3], lfo_d = poly[4];
-    const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], lrc = poly[8], lrs = poly[9], startd = poly[10];
+template <int FPL, bool BIASED, bool LINEAR, int QMAX = 4, typename TimeFn>
+__device__ __forceinline__ void lean_fm_frames(const double (&poly)[16], double lfo_a_rel, double startd, double di0, TimeFn time,
+                                               double t_first, double t_step, TrigTab trig, double (&out)[FPL]) {
+    // (lfo_a_rel: the LFO's angle at the launch's -- or tile's -- frame 0; startd: the voice's own index of that frame)
+    const double frequency = poly[0], f_inc = poly[2], lfo_d = poly[4];
+    const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], lrc = poly[8], lrs = poly[9];
     double magic = 6755399441055744.0, s5 = 0.008333333333333333, phase0 = poly[1];
     asm volatile("" : "+v"(magic), "+v"(s5), "+v"(phase0));          // (VGPR-resident: see sin_tab_n)
     double ls0, lc0;
@@ -437,7 +438,7 @@ __device__ __forceinline__ void lean_fm_frames(const double (&poly)[16], double 
     double lc1 = fma(lc0, lrc, -(ls0 * lrs));
     const double lk2 = lrc + lrc;
     double tj = t_first;
-    constexpr int Q = FPL < 4 ? FPL : 4;
+    constexpr int Q = FPL < QMAX ? FPL : QMAX;      // (carriers looked up at a time: their temporaries are most of the loop's registers)
 #pragma unroll
     for (int h = 0; h < FPL; h += Q) {
         double th[Q], sn[Q];
@@ -521,12 +522,12 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                 // with all kinds needs 128 VGPRs and spills; round 4)
                 double sn[FPL];
                 if (straddle) {
-                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, false>(poly, di0, theta, 0.0, 0.0, trig, sn);
-                    else lean_fm_frames<FPL, true, false>(poly, di0, theta, 0.0, 0.0, trig, sn);
+                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, false>(poly, poly[3], poly[10], di0, theta, 0.0, 0.0, trig, sn);
+                    else lean_fm_frames<FPL, true, false>(poly, poly[3], poly[10], di0, theta, 0.0, 0.0, trig, sn);
                 } else {
                     const double t_first = fma(di0 - off, dt, t_base), t_step = 64.0 * dt;
-                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, true>(poly, di0, theta, t_first, t_step, trig, sn);
-                    else lean_fm_frames<FPL, true, true>(poly, di0, theta, t_first, t_step, trig, sn);
+                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, true>(poly, poly[3], poly[10], di0, theta, t_first, t_step, trig, sn);
+                    else lean_fm_frames<FPL, true, true>(poly, poly[3], poly[10], di0, theta, t_first, t_step, trig, sn);
                 }
 #pragma unroll
                 for (int j = 0; j < FPL; ++j) {
@@ -665,6 +666,7 @@ __device__ __forceinline__ uint32_t general_count(const uint32_t* counts, uint32
 // another.  The masks of the tile (one contiguous row) are fetched 64 at a time, one per lane; the lists that are not empty are handed
 // round by ballot and readlane.  WAVEFORMS: the bank holds plain Sawtooth / Square / Triangle / Pulse / FM Sine voices too (the
 // waveform branch costs the Harmonics loop registers: an instantiation of its own).
+enum { TILE_RUN_HARM = 0, TILE_RUN_FM = 1, TILE_RUN_REST = 2 };      // the runs of a (tile, chunk) list
 template <int WAVES, int FPL, bool WAVEFORMS>
 __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, TrigTab trig, double (&accl)[FPL], double (&accr)[FPL]) {
     static_assert(64 * FPL == TILE_FRAMES, "the lean kernel's tile is the tile of the classification");
@@ -689,12 +691,12 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
             have &= have - 1;
             const uint64_t cmask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mymask >> 32), (int)src) << 32) |
                                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mymask, (int)src);
-            const uint32_t npairs = (uint32_t)__popcll(cmask);
+            const uint32_t npairs = (uint32_t)cmask;                      // (the chunk's word: pairs | Harmonics pairs << 32 | FM Sine pairs << 40)
             const uint32_t idx = base + src;                              // (group, k - k0) of the prepare step's layout
             const uint32_t c = idx / kw + (B.tiles.k0 + idx % kw) * ngroups;
-            const TileRec SH_CONST_AS* q = trow + (c - B.tiles.k0 * ngroups) * 64 + firstp;
-            uint32_t p = firstp;
-            for (; p < npairs; p += stride, q += stride) {
+            // (one pair; CLS: the run of the chunk's list it lies in)
+            auto pair = [&](auto cls_, const TileRec SH_CONST_AS* q) __attribute__((always_inline)) {
+                constexpr int CLS = decltype(cls_)::value;
                 const double t0 = q->t0, dt = q->dt, rc = q->rc, rs = q->rs, ea0 = q->ea0, ea1 = q->ea1, GL = q->GL, GR = q->GR;
                 const uint32_t pc = *reinterpret_cast<const uint32_t SH_CONST_AS*>(&q->npieces);      // npieces | corner << 16
                 uint32_t lane_again = lane;                               // (converted per entry: two registers less across the loop)
@@ -714,12 +716,37 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                              "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
                              "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
                 const LaneTheta none{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0u, 0u, false};
-                if constexpr (WAVEFORMS) {
-                    // a plain Sawtooth / Square / Triangle / Pulse (unit amplitude, t in turns: the amplitude lives in the gains): every
-                    // frame from its accumulated t on the piece that holds it -- the record's pieces, or a walk along the voice's
-                    // table -- the envelope's line of the frame, and nothing in front of an onset
+                if constexpr (CLS != TILE_RUN_HARM) {
+                    if constexpr (CLS == TILE_RUN_FM) {
+                        if (pc == 1u) {
+                            // an FM Sine pair on one piece under one line (the sustain, the release): the arithmetic of the lean lists --
+                            // the time by one addition per frame, the LFO's cosine by recurrence (lean_fm_frames); the record's rc is the
+                            // voice's own index of the tile's first frame, rs the LFO's angle there
+                            double sn[FPL];
+                            const double t_first = fma(lane_d, dt, t0), t_step = 64.0 * dt;
+                            if (poly[7] == 0.0) lean_fm_frames<FPL, false, true, 2>(poly, rs, rc, lane_d, none, t_first, t_step, trig, sn);
+                            else lean_fm_frames<FPL, true, true, 2>(poly, rs, rc, lane_d, none, t_first, t_step, trig, sn);
+                            double gl_e = GL, gr_e = GR;
+                            if (ea1 == 0.0) {
+                                gl_e = GL * ea0;
+                                gr_e = GR * ea0;
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < FPL; ++j) sn[j] = sn[j] * fma(lane_d + (double)(j * 64), ea1, ea0);
+                            }
+#pragma unroll
+                            for (int j = 0; j < FPL; ++j) {
+                                accl[j] = fma(gl_e, sn[j], accl[j]);
+                                accr[j] = fma(gr_e, sn[j], accr[j]);
+                            }
+                            return;
+                        }
+                    }
+                    // an FM Sine pair of another form, or a plain Sawtooth / Square / Triangle / Pulse (unit amplitude, t in turns: the
+                    // amplitude lives in the gains): every frame from its accumulated t on the piece that holds it -- the record's
+                    // pieces, or a walk along the voice's table -- the envelope's line of the frame, and nothing in front of an onset
                     const uint32_t wkind = *reinterpret_cast<const uint32_t SH_CONST_AS*>(&q->pad_);
-                    if (wkind != LEAN_HARM) {
+                    {
                         const double eb0 = q->eb0, eb1 = q->eb1, ci = (double)(pc >> 16);
                         double th[FPL], on = 0.0;
                         if ((pc & 0xFFFFu) == 0u) {
@@ -749,9 +776,10 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
 #pragma unroll
                             for (int j = 0; j < FPL; ++j) th[j] = theta(j);
                         }
-                        if (wkind == LEAN_FM) {
+                        if constexpr (CLS == TILE_RUN_FM) {
                             // a Sine carrier with a closed-form Sine LFO: th[] is the accumulated TIME; the carrier's angle from the
                             // running sum of the LFO, L(n) = K (C0 - cos(a + (n - 1/2) d)) + bias n, at the voice's own index n
+                            // (a pair with a corner, further pieces or a walk: every frame by two lookups)
                             const double fr = poly[0], phase0 = poly[1], f_inc = poly[2], lfo_a = poly[3], lfo_d = poly[4];
                             const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], n_first = rc;
                             const double a_rel = fma(n_first - 0.5, lfo_d, lfo_a);
@@ -767,7 +795,7 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                                 accl[j] = fma(GL, w, accl[j]);
                                 accr[j] = fma(GR, w, accr[j]);
                             }
-                            continue;
+                            return;
                         }
 #pragma unroll
                         for (int j = 0; j < FPL; ++j) {
@@ -781,9 +809,10 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                             accl[j] = fma(GL, w, accl[j]);
                             accr[j] = fma(GR, w, accr[j]);
                         }
-                        continue;
+                        return;
                     }
                 }
+                if constexpr (CLS == TILE_RUN_HARM) {
                 // ---- a polynomial-Harmonics pair: w[j] = sample x envelope of the lane's frame j by the pair's kind, then ONE accumulation ----
                 double w[FPL], gl_e = GL, gr_e = GR;
                 if (pc == 1u) {
@@ -860,6 +889,18 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                     accl[j] = fma(gl_e, w[j], accl[j]);
                     accr[j] = fma(gr_e, w[j], accr[j]);
                 }
+                }
+            };
+            const TileRec SH_CONST_AS* q = trow + (c - B.tiles.k0 * ngroups) * 64 + firstp;
+            uint32_t p = firstp;
+            if constexpr (WAVEFORMS) {
+                // the list's three runs (prepare_tiles_wave), one loop each -- see lean_lists
+                const uint32_t end_harm = (uint32_t)(cmask >> 32) & 0xFFu, end_fm = end_harm + ((uint32_t)(cmask >> 40) & 0xFFu);
+                for (; p < end_harm; p += stride, q += stride) pair(std::integral_constant<int, TILE_RUN_HARM>{}, q);
+                for (; p < end_fm; p += stride, q += stride) pair(std::integral_constant<int, TILE_RUN_FM>{}, q);
+                for (; p < npairs; p += stride, q += stride) pair(std::integral_constant<int, TILE_RUN_REST>{}, q);
+            } else {
+                for (; p < npairs; p += stride, q += stride) pair(std::integral_constant<int, TILE_RUN_HARM>{}, q);
             }
             firstp = __builtin_amdgcn_readfirstlane(p - npairs);
         }

@@ -176,3 +176,17 @@ def test_a_tree_that_does_not_compile_is_an_error_not_a_stale_load(monkeypatch):
             assert N.lib() is not None
     finally:
         N._lib = saved
+
+
+def test_the_source_hash_covers_every_file_the_library_is_built_from():
+    """The hash embedded in libsynthhip.so decides whether the tree's library is stale (build.needs_build, the binding's guard): every
+    header a translation unit includes must be hashed (round 4: the render kernels' header was not, and an edit of it alone left the old
+    library in place)."""
+    import re
+    from synthesizer_amd import build as B
+    hashed = {Path(h).name for h in B.HEADERS} | set(B.SOURCES)
+    for f in list(B.CSRC.glob("*.hip")) + list(B.CSRC.glob("*.hpp")) + list(B.CSRC.glob("*.h")):
+        if f.suffix == ".hip":
+            assert f.name in B.SOURCES, f.name
+        for inc in re.findall(r'#include\s+"([^"]+)"', f.read_text()):
+            assert Path(inc).name in hashed, (f.name, inc)

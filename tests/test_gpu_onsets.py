@@ -335,3 +335,58 @@ def test_a_table_of_notes_is_the_same_nine_billion_frames_later(gpu):
     assert not edge[:8000].any() and np.max(np.abs(edge[8000:].astype(np.float64) - head)) < 1e-7 and head.any()
     c1 = N.debug_counters()
     assert c1["tiled_launches"] - c0["tiled_launches"] >= 2 * (3 + 12)
+
+
+def test_fm_notes_in_runs_of_a_tile_list(gpu):
+    """Round 4: the lean pairs of a (tile, chunk) list come in three runs -- Harmonics, FM Sine, plain waveforms -- walked by a loop each,
+    and an FM Sine pair on one piece under one line takes the lean lists' arithmetic (lean_fm_frames: time by addition, the LFO's cosine
+    by recurrence; every other LFO with a bias).  A table of 300 notes -- two thirds FM Sine, the rest Harmonics and Sawtooth, so that
+    chunks hold every composition of runs -- under ADSRs with sustains long enough for whole tiles of sustain and release, as a stream of
+    one-third-second blocks and of 2048-frame chunks, against the C oracle."""
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    n_voices, n = 300, 5 * 16384
+
+    def notes(m):
+        rng = np.random.default_rng(77)
+        onsets = np.sort(rng.integers(0, SR, n_voices))
+        onsets[0] = 0
+        out = []
+        for i in range(n_voices):
+            f = float(np.exp(rng.uniform(np.log(40.0), np.log(6000.0))))
+            amp = float(rng.uniform(0.1, 1.0)) / np.sqrt(n_voices)
+            ph = float(rng.uniform(0.0, 1.0))
+            k = int(rng.integers(0, 6))
+            lfo = m.Sine(float(rng.uniform(0.5, 9.0)), float(rng.uniform(0.0, 0.05)), phase=float(rng.uniform(0.0, 1.0)),
+                         bias=(0.02 if i % 2 else 0.0), samplerate=SR)
+            if k < 4:
+                osc = m.Sine(f, amp, phase=ph, fm_lfo=lfo, samplerate=SR)
+            elif k == 4:
+                osc = m.Harmonics(f, [(q, 1.0 / q) for q in range(1, 9)], amplitude=amp, phase=ph, samplerate=SR)
+            else:
+                osc = m.Sawtooth(f, amp, phase=ph, samplerate=SR)
+            if i % 5:
+                osc = m.EnvelopeFilter(osc, 0.005, 0.03, float(rng.uniform(0.2, 0.6)), 0.6, float(rng.uniform(0.05, 0.3)))
+            out.append(m.DelayFilter(osc, int(onsets[i]) / SR) if onsets[i] else osc)
+        return out
+    gains = [(float(np.float32(g)), float(np.float32(1.0 - g))) for g in np.random.default_rng(78).uniform(0.0, 1.0, n_voices)]
+    gv, ov = notes(G), notes(O)
+    rows = np.zeros((n_voices, n))
+    for i, v in enumerate(ov):
+        d = int(SR * v._seconds) if isinstance(v, O.DelayFilter) else 0
+        if d < n:
+            rows[i, d:] = CO.render(v._source if isinstance(v, O.DelayFilter) else v, n - d)
+    want = CO.mix_bus(rows, gains)
+    bank = VoiceBank(gv, gains=gains)
+    for block in (16384, 2048):
+        nblocks = n // block
+        ring = [N.DeviceBuffer(block * 8) for _ in range(4)]
+        before = N.debug_counters()["tiled_launches"]
+        for k in range(nblocks):
+            bank.render_device(block, k * block, bus_f32=ring[k & 3])
+            got = ring[k & 3].download(np.float32, block * 2).reshape(block, 2)
+            w = want[k * block:(k + 1) * block]
+            assert rms(got, w) <= RMS_TOL, (block, k)
+            assert np.max(np.abs(got - w)) < 2e-6, (block, k, float(np.max(np.abs(got - w))))
+        assert N.debug_counters()["tiled_launches"] - before == nblocks
