@@ -416,7 +416,7 @@ __device__ __forceinline__ void sin_tab_n(const double (&t)[N], TrigTab tab, dou
 // The lean FM arithmetic for FPL frames of one lane, 64 samples apart: a Sine carrier with a closed-form Sine LFO (the arithmetic of
 // voice_block's FM path).  The LFO angle a_rel + i*d is exactly linear in i, and only its COSINE enters L(i) = K (C0 - cos) + bias*(start+i):
 // one table lookup for the lane's first frame, one rotation for the second, then cos[j] = 2cos(64d) cos[j-1] - cos[j-2].  The carrier's
-// angle is not linear in i: one table lookup per frame, four carriers at a time so that their table reads are in flight together.
+// angle is not linear in i: one table lookup per frame, SH_FM_Q carriers at a time so that their table reads are in flight together.
 // BIASED = false: an LFO without bias (the usual modulator; BASELINE config 3) -- the linear term of L is 0 * (start + i) = +0, and
 // fma(K, C0 - cos, +0) IS the rounded product: three operations per frame less, the same bits.
 // The accumulated TIME of the lane's frame j: LINEAR -- the tile lies on ONE phase-table piece, t_j = fma(i_j - off, dt, t_base): the
@@ -425,7 +425,10 @@ __device__ __forceinline__ void sin_tab_n(const double (&t)[N], TrigTab tab, dou
 // (LaneTheta: the one tile per crossing that straddles a piece end).  The sines go to out[]: the caller accumulates them in ONE place
 // behind the four forms of this function (with the accumulation inside each, the compiler shuffled the accumulators between the forms'
 // register assignments: ~25 register copies per eight frames).
-template <int FPL, bool BIASED, bool LINEAR, int QMAX = 4, typename TimeFn>
+#ifndef SH_FM_Q
+#define SH_FM_Q 2        // carriers looked up at a time (four: 64 B of scratch in the FM-only lean kernel, 2 % slower; 260 B in the tiles kernel)
+#endif
+template <int FPL, bool BIASED, bool LINEAR, int QMAX = SH_FM_Q, typename TimeFn>
 __device__ __forceinline__ void lean_fm_frames(const double (&poly)[16], double lfo_a_rel, double startd, double di0, TimeFn time,
                                                double t_first, double t_step, TrigTab trig, double (&out)[FPL]) {
     // (lfo_a_rel: the LFO's angle at the launch's -- or tile's -- frame 0; startd: the voice's own index of that frame)
@@ -724,8 +727,8 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                             // voice's own index of the tile's first frame, rs the LFO's angle there
                             double sn[FPL];
                             const double t_first = fma(lane_d, dt, t0), t_step = 64.0 * dt;
-                            if (poly[7] == 0.0) lean_fm_frames<FPL, false, true, 2>(poly, rs, rc, lane_d, none, t_first, t_step, trig, sn);
-                            else lean_fm_frames<FPL, true, true, 2>(poly, rs, rc, lane_d, none, t_first, t_step, trig, sn);
+                            if (poly[7] == 0.0) lean_fm_frames<FPL, false, true>(poly, rs, rc, lane_d, none, t_first, t_step, trig, sn);
+                            else lean_fm_frames<FPL, true, true>(poly, rs, rc, lane_d, none, t_first, t_step, trig, sn);
                             double gl_e = GL, gr_e = GR;
                             if (ea1 == 0.0) {
                                 gl_e = GL * ea0;
