@@ -185,7 +185,7 @@ int  sh_debug_counters(sh_counters* out);
  *                                 by tile: every voice that holds an onset or a corner in the launch takes the general code
  *   SYNTHHIP_VARIANT=WFM          render kernel shape: waves per workgroup, frames per lane, min waves per SIMD -- one of 4163, 484, 444,
  *                                 844, 821, 421, 211 (the shapes the library chooses between by itself; 4163 -- sixteen frames per lane --
- *                                 exists for split launches of polynomial-Harmonics banks only)
+ *                                 exists for split launches of polynomial-Harmonics banks and of FM Sine banks only)
  *   SYNTHHIP_GROUPS=n             voice groups of a render launch
  *   SYNTHHIP_POOL_FILL=0..255     device blocks that grow are filled with this byte first (diagnostics: a kernel that reads what it
  *                                 should have written shows)

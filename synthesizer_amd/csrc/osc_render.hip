@@ -313,9 +313,10 @@ static int launch_plain(const RenderLaunch& L) {
         else hipLaunchKernelGGL((k_render_combined<W_, F_, M_, COMBINED_DIRECT>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts, L.out); \
     } while (0)
     switch (L.var) {
-    case 4163:                                         // (chosen for split launches of polynomial-Harmonics banks only: bank_render)
-        if (!(lean_split && L.mode == COMBINED_LEAN_HARM)) return sh::set_error(SH_ERR_INVALID, "sh_bank_render: shape 4163 needs a split launch of a Harmonics bank");
-        hipLaunchKernelGGL((k_render_lean<4, 16, 3, LEAN_K_HARM, false>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
+    case 4163:                                         // (chosen for split launches of polynomial-Harmonics or FM Sine banks only: bank_render)
+        if (lean_split && L.mode == COMBINED_LEAN_HARM) hipLaunchKernelGGL((k_render_lean<4, 16, 3, LEAN_K_HARM, false>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
+        else if (lean_split && fm_only) hipLaunchKernelGGL((k_render_lean<4, 16, 3, LEAN_K_FM, false>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
+        else return sh::set_error(SH_ERR_INVALID, "sh_bank_render: shape 4163 needs a split launch of a Harmonics or an FM Sine bank");
         break;
     case 484: SH_LAUNCH_SHAPE(4, 8, 4); break;
     case 444: SH_LAUNCH_SHAPE(4, 4, 4); break;
@@ -382,9 +383,11 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // instructions at four waves per SIMD -- and ran 36.5-36.7 us: slower than eight (36.0).  Fewer instructions do not buy time in
     // the stream of launches; the clock the chip holds falls as the pipe fills (2.38 GHz with one wavefront per SIMD, 2.12-2.18 with
     // two launches in flight: profiles/r04_headline_phases.md).  Tiles of 1024 frames need twice the voice groups to fill the chip (47 tiles x 16
-    // groups of 64 voices for the headline: the same 752 workgroups), so: polynomial-Harmonics banks (the lean kernel of that kind is
-    // the one instantiated at this shape), a split launch, and enough 64-voice chunks for the groups.
-    if (K.variant == 0 && var == 484 && mode == COMBINED_LEAN_HARM && !tile_candidate && !K.no_split && K.groups == 0) {
+    // groups of 64 voices for the headline: the same 752 workgroups), so: polynomial-Harmonics banks and FM Sine banks (the lean kernels
+    // of these kinds are the ones instantiated at this shape; config 3: 1.8 % faster than at eight frames, 72 B of scratch), a split
+    // launch, and enough 64-voice chunks for the groups.
+    const bool fm_bank = mode == COMBINED_LEAN_ALL && b->lean_candidates > 0 && b->lean_fmsine_candidates == b->lean_candidates;
+    if (K.variant == 0 && var == 484 && (mode == COMBINED_LEAN_HARM || fm_bank) && !tile_candidate && !K.no_split && K.groups == 0) {
         const uint32_t tiles16 = sh::div_up(nframes, 1024u);
         uint32_t g16 = 1;
         while (tiles16 * g16 * 2 <= 1024u && b->nvoices / (g16 * 2) >= 64u) g16 *= 2;         // (whole chunks per group)
