@@ -215,14 +215,17 @@ static int launch_tiled(const RenderLaunch& L, bool records_deferred) {
     // (Measured in round 4: the merged kernel for LONG launches too -- no general kernel between two lean kernels of a stream -- 50.7
     // against 48.4 us per block of the staggered row; with the general workgroups' code behind a function call, so that it would not
     // cost the lean pairs' loop registers, 530 us: the call's stack frame makes every wavefront of the dispatch a scratch user.)
+    // Waves per SIMD the kernels are compiled for (round 4, same-box A/Bs): the merged kernel 3 (168 registers: 116 B of scratch instead of
+    // 328; a 4096-frame chunk 10.9 -> 10.6 us; at 2 -- no scratch at all -- 10.8), the long-launch kernel with the waveform branch 3 (a
+    // staggered table of FM Sine notes 64.9 -> 63.0 us), the long-launch Harmonics kernel 4 (at 3: 45.5 instead of 41.0 us per block).
     const bool merged = tiles <= 16;
     if (merged) {
         const uint32_t behind = tiles * GEN_SPLIT + P.next_tile_wgs;   // general workgroups, then the tile-set prepare workgroups
         if (b->tile_waveforms)
-            hipLaunchKernelGGL((k_render_tiles<4, 8, 4, true, true>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st,
+            hipLaunchKernelGGL((k_render_tiles<4, 8, 3, true, true>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st,
                                A, L.next_args(L.next, behind), L.fold, L.parts, L.gen_valid);
         else
-            hipLaunchKernelGGL((k_render_tiles<4, 8, 4, false, true>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st,
+            hipLaunchKernelGGL((k_render_tiles<4, 8, 3, false, true>), dim3(tiles, groups + sh::div_up(behind, tiles)), dim3(256), 0, st,
                                A, L.next_args(L.next, behind), L.fold, L.parts, L.gen_valid);
     } else {
         // (where the next-but-one tile set is resolved was moved three times in round 3 -- between the lean workgroups, a kernel of its
@@ -232,7 +235,7 @@ static int launch_tiled(const RenderLaunch& L, bool records_deferred) {
         if (!behind) nx.launch = nullptr;
         const dim3 grid(tiles, groups + sh::div_up(behind, tiles));
         if (b->tile_waveforms)
-            hipLaunchKernelGGL((k_render_tiles<4, 8, 4, true, false>), grid, dim3(256), 0, st, A, L.next_args(nx, behind), L.fold, L.parts, L.gen_valid);
+            hipLaunchKernelGGL((k_render_tiles<4, 8, 3, true, false>), grid, dim3(256), 0, st, A, L.next_args(nx, behind), L.fold, L.parts, L.gen_valid);
         else
             hipLaunchKernelGGL((k_render_tiles<4, 8, 4, false, false>), grid, dim3(256), 0, st, A, L.next_args(nx, behind), L.fold, L.parts, L.gen_valid);
     }
