@@ -816,8 +816,9 @@ def main() -> int:
         "verified": verified,
         "roofline": {
             "kernel": render_name or "k_render_lean<4, 8, 4, 0, false>", "bound": "valu_f64",
-            "kernel_note": "k_render_lean<WAVES, FPL, MINW, KINDS, SEG>: <4, 8, 4, 0, false> = the lean Harmonics kernel of a split launch (table lookup + "
-                           "rotation + three-term recurrence + four Horner chains at a time, eight frames per lane); k_render_general<4, 4, 4, 0> = the "
+            "kernel_note": "k_render_lean<WAVES, FPL, MINW, KINDS, SEG>: <4, 16, 3, 0, false> = the lean Harmonics kernel of a split launch (table lookup + "
+                           "rotation + three-term recurrence + four Horner chains at a time, sixteen frames per lane, three waves per SIMD; <4, 8, 4, ..> for "
+                           "shorter blocks and smaller banks; KINDS 2: FM Sine banks); k_render_general<4, 4, 4, 0> = the "
                            "general-lists kernel that follows it on the same stream where a launch can hold a voice that needs the general code",
             "clock_note": "peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz; under this load the chip holds 2.12-2.18 GHz (s_memtime / s_memrealtime per "
                           "wavefront, profiles/r04_headline_phases.md): at that clock the stream of launches issues within 6-8 % of what the SIMDs can",
