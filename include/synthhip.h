@@ -98,7 +98,11 @@ typedef struct sh_voice {
     int32_t  kind;             /* sh_kind */
     int32_t  fm_mode;          /* sh_fm_mode */
     double   amplitude, bias, pulsewidth;
-    /* SH_FM_NONE: carrier phase table (t in radians for Sine/Harmonics, in turns otherwise) */
+    /* SH_FM_NONE: carrier phase table (t in radians for Sine/Harmonics, in turns otherwise).
+     * SH_FM_SINE with a Sine LFO that moves (lfo_K != 0): the table of the LFO's running sum, TWO records per piece of the LFO's own
+     * accumulated phase -- (n0, t0, dt) and (n0, K_p, C_p): on samples n0_p <= n < n0_{p+1},
+     * L(n) = K_p * (C_p - cos(t0_p + (n - n0_p - 1/2) * dt_p)) + lfo_bias * n  (oscillators.LfoTable: the prefix sums of the pieces in
+     * front are folded into C_p); seg_count = 0: a constant LFO, lfo_a .. lfo_C0 below are all there is. */
     uint32_t seg_offset, seg_count;
     /* Harmonics, by harm_dense:
      *   0 sparse  -> harm_count sh_partial at partial[harm_offset], summed term by term
@@ -113,7 +117,9 @@ typedef struct sh_voice {
      * (t += fm_inc from 0), L(n) = sum_{j<n} lfo_j */
     double   frequency, fm_phase0, fm_inc;
     uint32_t time_seg_offset, time_seg_count;
-    /* SH_FM_SINE: lfo_j = lfo_amp*sin(lfo_a + j*lfo_d) + lfo_bias;
+    /* SH_FM_SINE: lfo_j = lfo_amp*sin(phase_j) + lfo_bias, phase_j the LFO's accumulated phase (lfo_a, += lfo_d per sample in float64:
+     * piecewise exactly linear -- the table at seg_offset); on the ideal line phase_j = lfo_a + j*lfo_d (the first piece, and all
+     * there is for a library older than ABI 5):
      * L(n) = lfo_K*(lfo_C0 - cos(lfo_a + (n-0.5)*lfo_d)) + lfo_bias*n,
      * lfo_K = lfo_amp/(2 sin(lfo_d/2)), lfo_C0 = cos(lfo_a - lfo_d/2) */
     double   lfo_a, lfo_d, lfo_amp, lfo_bias, lfo_K, lfo_C0;
@@ -155,7 +161,7 @@ const char* sh_version(void);
 /* The binary interface this library was compiled with, so that a binding can refuse a library whose structs it would mis-pack
  * (a stale .so loaded by path: same symbols, other layouts): out[0] = SH_ABI_VERSION, then sizeof of sh_segment, sh_partial,
  * sh_envelope, sh_voice, sh_devinfo, sh_counters.  Writes min(n, 7) words, returns 7.  Callable before sh_init, without a GPU. */
-#define SH_ABI_VERSION 4
+#define SH_ABI_VERSION 5
 int  sh_abi(uint32_t* out, int n);
 int  sh_sync(void);                       /* wait for the stream */
 

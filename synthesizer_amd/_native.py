@@ -155,7 +155,7 @@ _SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 
 
-SH_ABI_VERSION = 4           # include/synthhip.h; bumped with every change of a struct layout or of an entry point's meaning
+SH_ABI_VERSION = 5           # include/synthhip.h; bumped with every change of a struct layout or of an entry point's meaning
 
 
 class NativeLibraryStale(ImportError):

@@ -215,8 +215,13 @@ struct alignas(16) VoiceFM {      // only read for FM voices
     double frequency, phase0, f_inc;      // theta = frequency*T + fma(f_inc, L, phase0)
     double lfo_a_rel, lfo_d, lfo_K, lfo_C0, lfo_bias;   // L(i) = K*(C0 - cos(a_rel + i*d)) + bias*(start+i)
     double lfo_rot_c, lfo_rot_s;          // cos / sin of 64*lfo_d: the LFO angle of a lane's next frame is one rotation away
+    // The LFO's own phase is an accumulated sum (oscillators.LfoTable): a_rel, d, K, C0 are those of the LFO's table piece that holds
+    // the launch's first frame; if that piece ends inside the launch, frames i >= lfo_split take the next piece's (further ends inside
+    // one launch exist only where t is small and an ulp of it with it: the second piece is followed beyond them)
+    double lfo2_a_rel, lfo2_d, lfo2_K, lfo2_C0;
+    uint32_t lfo_split, pad_[3];          // 0xFFFFFFFF: none
 };
-static_assert(sizeof(VoiceFM) == 80, "VoiceFM layout");
+static_assert(sizeof(VoiceFM) == 128, "VoiceFM layout");
 
 // The common voice of an additive bank in steady state -- polynomial Harmonics, no FM, amplitude and (constant)
 // envelope gain folded into the bus gains, the launch on one table piece or crossing one piece end -- needs only
@@ -231,7 +236,8 @@ struct alignas(64) FastRec {
     uint32_t remain;              // 0xFFFFFFFF: no crossing in this launch
     uint32_t kind;                // LEAN_HARM: the fields as described; LEAN_FM: Sine carrier with a closed-form Sine LFO --
                                   // t is the accumulated TIME table, poly[0..10] = frequency, phase0, f_inc, lfo_a_rel, lfo_d,
-                                  // lfo_K, lfo_C0, lfo_bias, lfo_rot_c, lfo_rot_s, (double)start (see VoiceFM)
+                                  // lfo_K, lfo_C0, lfo_bias, lfo_rot_c, lfo_rot_s, (double)start (see VoiceFM); poly[11..15], pad2 =
+                                  // the LFO's next table piece (a_rel, d, K, C0, rot_c, rot_s) for the frames i >= pad1
     double off_b;                 // (double)remain
     // ---- read only when the launch crosses ONE end of a phase-table piece (a binade of the running sum), at `remain` ----
     double t0_b, dt_b;            // frames i >= remain: t(i) = fma(i - remain, dt_b, t0_b)
@@ -281,7 +287,9 @@ struct PrepInfo {                 // what prepare_voice found, for the classific
     uint32_t remain;
     uint32_t kind;                // LEAN_HARM / LEAN_FM
     double   amplitude, g0u, pulsewidth;
-    double   fmv[11];             // LEAN_FM: the values that go to FastRec::poly[0..10]
+    double   fmv[16];             // LEAN_FM: the values that go to FastRec::poly[0..15]
+    double   lfo2_rot_s;          // ... and to pad2, pad1
+    uint32_t lfo_split;
     double   slope_l, slope_r;    // a record set of sloped lean records (SLOPED): gain(i) = gain + i * slope on the envelope's line
     double   poly[16];            // FL_POLY: the coefficients (read once, with the table pieces; the lean record is written from here)
 };
@@ -511,8 +519,46 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         info.slope_l = (v.amplitude * slu) * (double)v.gain_l;
         info.slope_r = (v.amplitude * slu) * (double)v.gain_r;
     }
-    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm || lean_plain || lean_sloped) && (one_piece || two_pieces) &&
-                onset_i == 0;                                  // (the launch that holds the onset: general code)
+    // the LFO of a closed-form FM voice: the piece of ITS table (pairs of records at seg_offset: oscillators.LfoTable) that holds the
+    // launch's first frame -- a scalar-free binary search per lane, ~6 dependent loads, FM voices only -- and the next one's start
+    double l_a = fma((double)start - 0.5, v.lfo_d, v.lfo_a), l_d = v.lfo_d, l_K = v.lfo_K, l_C0 = v.lfo_C0;      // (a constant LFO: no table)
+    double l2_a = l_a, l2_d = l_d, l2_K = l_K, l2_C0 = l_C0;
+    double2 l_rot = make_double2(1.0, 0.0), l2_rot = make_double2(1.0, 0.0);
+    uint32_t l_split = 0xFFFFFFFFu;
+    const bool lfo_pieces = v.fm_mode == SH_FM_SINE && v.seg_count >= 2;
+    if (lfo_pieces) {
+        const sh_segment* lt = B.segs + v.seg_offset;
+        const uint32_t np_ = v.seg_count / 2;
+        uint32_t lo_ = 0, hi_ = np_ - 1;
+        while (lo_ < hi_) {
+            const uint32_t mid = (lo_ + hi_ + 1) >> 1;
+            if (lt[2 * mid].n0 <= start) lo_ = mid; else hi_ = mid - 1;
+        }
+        const uint64_t q_n0 = lt[2 * lo_].n0;
+        const double q_t0 = lt[2 * lo_].t0, q_dt = lt[2 * lo_].dt;
+        l_a = fma((double)(start - q_n0) - 0.5, q_dt, q_t0);            // the angle at frame i: a + i d
+        l_d = q_dt;
+        l_K = lt[2 * lo_ + 1].t0;
+        l_C0 = lt[2 * lo_ + 1].dt;
+        l_rot = B.seg_rot[v.seg_offset + 2 * lo_];
+        l2_a = l_a; l2_d = l_d; l2_K = l_K; l2_C0 = l_C0;
+        if (lo_ + 1 < np_) {
+            const uint64_t e_n0 = lt[2 * lo_ + 2].n0;
+            if (e_n0 - start < (uint64_t)nframes) {
+                l_split = (uint32_t)(e_n0 - start);
+                const double e_t0 = lt[2 * lo_ + 2].t0, e_dt = lt[2 * lo_ + 2].dt;
+                l2_a = fma(-(double)(e_n0 - start) - 0.5, e_dt, e_t0);    // (start - n0' - 1/2) d' + t0': the same frame index i
+                l2_d = e_dt;
+                l2_K = lt[2 * lo_ + 3].t0;
+                l2_C0 = lt[2 * lo_ + 3].dt;
+                l2_rot = B.seg_rot[v.seg_offset + 2 * lo_ + 2];
+            }
+        }
+    } else if (fm) {
+        l_rot = B.lfo_rot[first + vi];
+    }
+    info.fast = ((flags & (FL_POLY | FL_FOLDED | FL_FM | FL_SILENT)) == (FL_POLY | FL_FOLDED) || lean_fm || lean_plain || lean_sloped) &&
+                (one_piece || two_pieces) && onset_i == 0;     // (the launch that holds the onset: general code)
     info.remain = one_piece ? 0xFFFFFFFFu : (uint32_t)rem;
     info.t0_b = one_piece ? t_base : p1_t0;
     info.dt_b = one_piece ? dt : p1_dt;
@@ -529,18 +575,30 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         f->frequency = v.frequency;
         f->phase0 = v.fm_phase0;
         f->f_inc = v.frequency * v.fm_inc;
-        f->lfo_a_rel = fma((double)start - 0.5, v.lfo_d, v.lfo_a);     // arg(i) = a + (start + i - 0.5) * d
-        f->lfo_d = v.lfo_d;
-        f->lfo_K = v.lfo_K;
-        f->lfo_C0 = v.lfo_C0;
+        f->lfo_a_rel = l_a;                   // arg(i) = a + (start + i - 0.5) * d on the LFO's piece
+        f->lfo_d = l_d;
+        f->lfo_K = l_K;
+        f->lfo_C0 = l_C0;
         f->lfo_bias = v.lfo_bias;
-        const double2 lrot = B.lfo_rot[first + vi];
-        f->lfo_rot_c = lrot.x;
-        f->lfo_rot_s = lrot.y;
+        f->lfo_rot_c = l_rot.x;
+        f->lfo_rot_s = l_rot.y;
+        f->lfo2_a_rel = l2_a; f->lfo2_d = l2_d; f->lfo2_K = l2_K; f->lfo2_C0 = l2_C0;
+        f->lfo_split = l_split;
+        f->pad_[0] = 0; f->pad_[1] = 0; f->pad_[2] = 0;
         info.fmv[0] = v.frequency; info.fmv[1] = v.fm_phase0; info.fmv[2] = v.frequency * v.fm_inc;
-        info.fmv[3] = fma((double)start - 0.5, v.lfo_d, v.lfo_a);
-        info.fmv[4] = v.lfo_d; info.fmv[5] = v.lfo_K; info.fmv[6] = v.lfo_C0; info.fmv[7] = v.lfo_bias;
-        info.fmv[8] = lrot.x; info.fmv[9] = lrot.y; info.fmv[10] = (double)start;
+        info.fmv[3] = l_a;
+        info.fmv[4] = l_d; info.fmv[5] = l_K; info.fmv[6] = l_C0; info.fmv[7] = v.lfo_bias;
+        info.fmv[8] = l_rot.x; info.fmv[9] = l_rot.y; info.fmv[10] = (double)start;
+        // (the LFO's next piece, should this one end inside the launch: frames i >= lfo_split)
+        info.fmv[11] = l2_a; info.fmv[12] = l2_d; info.fmv[13] = l2_K; info.fmv[14] = l2_C0; info.fmv[15] = l2_rot.x;
+        info.lfo2_rot_s = l2_rot.y;
+        // the lean loops change pieces at a TILE boundary: the first multiple of 1024 frames (a multiple of every shape's tile) at or
+        // behind the piece's end.  The up to 1023 frames in between follow the first piece's line: their phase is off by at most
+        // 1023 x (the difference of the two pieces' dt: an ulp of the LFO's t) -- 2e-9 rad at t = 8192, five minutes into a 5 Hz LFO --
+        // and the carrier's angle, transiently, by f_inc amp 1023^2 / 2 times that difference: 2e-7 rad at depth 0.5 under a 3.5 kHz
+        // carrier, below the rounding noise of the reference's own running sums by then (tools/fm_long_time_probe.py).  The general
+        // code (VoiceFM::lfo_split) changes at the exact frame.
+        info.lfo_split = l_split == 0xFFFFFFFFu ? l_split : ((l_split + 1023u) & ~1023u);
     }
 }
 
@@ -575,7 +633,7 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         f->rot_c = info.rot_c; f->rot_s = info.rot_s;
         if (info.kind == LEAN_FM) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) f->poly[u] = u < 11 ? info.fmv[u] : 0.0;
+            for (int u = 0; u < 16; ++u) f->poly[u] = info.fmv[u];
         } else if (info.kind != LEAN_HARM) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) f->poly[u] = u == 0 ? info.pulsewidth : 0.0;
@@ -591,8 +649,8 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         f->amplitude = SLOPED ? info.slope_l : info.amplitude;        // (SLOPED sets are read by the RENDER_LEAN_*_SEG kernels only)
         f->g0u = SLOPED ? info.slope_r : info.g0u;
         f->vi = vi;
-        f->pad1 = 0;
-        f->pad2 = 0.0;
+        f->pad1 = info.kind == LEAN_FM ? info.lfo_split : 0u;        // (LEAN_FM: where the LFO's table piece ends, 0xFFFFFFFF = not in this launch)
+        f->pad2 = info.kind == LEAN_FM ? info.lfo2_rot_s : 0.0;
     }
     if (is_gen) S.gen_idx[c * 64 + (uint32_t)__popcll(mg & below)] = vi;
     // silent voices: listed from the END of the chunk's index slots (the render kernel never looks there; k_generate_lists
@@ -735,12 +793,28 @@ __device__ __forceinline__ void voice_block(const VoiceRegs& r, const VoiceFM* _
         struct { double frequency, phase0, f_inc, lfo_a_rel, lfo_d, lfo_K, lfo_C0, lfo_bias; } f;
         f.frequency = fp->frequency; f.phase0 = fp->phase0; f.f_inc = fp->f_inc; f.lfo_a_rel = fp->lfo_a_rel;
         f.lfo_d = fp->lfo_d; f.lfo_K = fp->lfo_K; f.lfo_C0 = fp->lfo_C0; f.lfo_bias = fp->lfo_bias;
-        if (fm_mode == SH_FM_SINE) {
-            // LFO angle a_rel + i*d is exactly linear in i: table lookup for the lane's first frame, rotation
-            // by 64*d for the following ones
+        const uint32_t lfo_split = fp->lfo_split;
+        if (fm_mode == SH_FM_SINE && lfo_split > tile_first && lfo_split <= tile_last) {
+            // the LFO's table piece ends inside this tile: every frame from the piece that holds it, by lookup
+            const double a2 = fp->lfo2_a_rel, d2 = fp->lfo2_d, K2 = fp->lfo2_K, C2 = fp->lfo2_C0;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                const bool behind = i[j] >= lfo_split;
+                double ls, lc;
+                shm::sincos_tab(fma(di[j], behind ? d2 : f.lfo_d, behind ? a2 : f.lfo_a_rel), trig, ls, lc);
+                const double Ln = fma(behind ? K2 : f.lfo_K, (behind ? C2 : f.lfo_C0) - lc, f.lfo_bias * ((double)start + di[j]));
+                th[j] = f.frequency * th[j] + fma(f.f_inc, Ln, f.phase0);
+            }
+        } else if (fm_mode == SH_FM_SINE) {
+            // LFO angle a_rel + i*d is exactly linear in i (on one piece of the LFO's table: the first of the launch, or, behind
+            // lfo_split, the second): table lookup for the lane's first frame, rotation by 64*d for the following ones
+            double rc = fp->lfo_rot_c, rs = fp->lfo_rot_s;
+            if (tile_first >= lfo_split) {
+                f.lfo_a_rel = fp->lfo2_a_rel; f.lfo_d = fp->lfo2_d; f.lfo_K = fp->lfo2_K; f.lfo_C0 = fp->lfo2_C0;
+                shm::sincos_tab(64.0 * f.lfo_d, trig, rs, rc);
+            }
             double ls, lc;
             shm::sincos_tab(fma(di[0], f.lfo_d, f.lfo_a_rel), trig, ls, lc);
-            const double rc = fp->lfo_rot_c, rs = fp->lfo_rot_s;
 #pragma unroll
             for (int j = 0; j < FPL; ++j) {
                 if (j > 0) {
@@ -1234,6 +1308,19 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         }
     };
     load_window();
+    // an FM Sine voice's LFO has a table of its own (pairs of records at seg_offset: oscillators.LfoTable): the piece that holds the run's
+    // first frame by binary search (FM voices only), then forwards tile by tile
+    const uint32_t lnp = (v_fm_sine && cnt_c >= 2) ? cnt_c / 2 : 0u;
+    const sh_segment* ltab = B.segs + off_c;
+    uint32_t lp = 0;
+    if (lnp) {
+        uint32_t lo_ = 0, hi_ = lnp - 1;
+        while (lo_ < hi_) {
+            const uint32_t mid = (lo_ + hi_ + 1) >> 1;
+            if (ltab[2 * mid].n0 <= nn_first) lo_ = mid; else hi_ = mid - 1;
+        }
+        lp = lo_;
+    }
     bool any_general = false, any_sound = false;
     uint32_t last_piece = 0;
     for (uint32_t t = t_begin; t < t_end; ++t) {
@@ -1241,6 +1328,7 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
         uint64_t abs1 = abs0 + TILE_FRAMES;
         if (abs1 > launch_end) abs1 = launch_end;
         bool is_lean = false, is_gen = false, is_walk = false;
+        uint32_t lfo_split_rel = 0;
         double rec_t0 = 0.0, rec_ea0 = 0.0, rec_ea1 = 0.0, rec_eb0 = 0.0, rec_eb1 = 0.0;
         uint32_t rec_extra = 0, rec_corner = 0, r = 0;
         uint16_t rec_split[2] = {0xFFFFu, 0xFFFFu};
@@ -1322,6 +1410,12 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             uint32_t extra = 0;
 #pragma unroll
             for (uint32_t k = 0; k < TILE_MAX_PIECES; ++k) extra += (uint32_t)(starts[k] < (uint64_t)n1);
+            // (an FM Sine pair: the piece of the LFO's table that holds the tile's first frame rides in the record, and the frame at which
+            //  the next one takes over, should that lie inside the tile)
+            if (lnp) {
+                while (lp + 1 < lnp && ltab[2 * lp + 2].n0 <= nn0) ++lp;
+                lfo_split_rel = (lp + 1 < lnp && ltab[2 * lp + 2].n0 < (uint64_t)n1) ? (uint32_t)((long long)ltab[2 * lp + 2].n0 - n0) : 0u;
+            }
             is_lean = lean_capable && env_ok && extra < TILE_MAX_PIECES;
             // more piece ends, or an onset with the attack's end behind it: a WALK pair, if the tile touches at most TILE_WALK_PIECES pieces
             if (lean_capable && !is_lean && walk_ok) {
@@ -1359,8 +1453,11 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             if (!corner) { rec_eb0 = rec_ea0; rec_eb1 = rec_ea1; }
             double2* __restrict__ q2 = reinterpret_cast<double2*>(q);      // eight 16-byte stores
             q2[0] = make_double2(rec_t0, win_pick<double>(w_dt, r, 0.0));
-            // (an FM pair: the voice's own index of the tile's first frame and the LFO's angle there, a + (n - 1/2) d)
-            q2[1] = rec_kind == LEAN_FM ? make_double2(dn0, fma(dn0 - 0.5, v.lfo_d, v.lfo_a)) : rot;
+            // (an FM pair: the voice's own index of the tile's first frame and the LFO's angle there, t0 + (n - n0 - 1/2) d on the LFO's piece)
+            double lfo_angle = 0.0;
+            if (rec_kind == LEAN_FM)
+                lfo_angle = lnp ? fma(dn0 - (double)ltab[2 * lp].n0 - 0.5, ltab[2 * lp].dt, ltab[2 * lp].t0) : fma(dn0 - 0.5, v.lfo_d, v.lfo_a);
+            q2[1] = rec_kind == LEAN_FM ? make_double2(dn0, lfo_angle) : rot;
             q2[2] = make_double2(rec_ea0, rec_ea1);
             q2[3] = make_double2(rec_eb0, rec_eb1);
             q2[4] = make_double2(amp * bgl, amp * bgr);
@@ -1372,7 +1469,10 @@ __device__ __forceinline__ void prepare_tiles_wave(const BankPtrs& B, const Tile
             union { uint16_t h[4]; double d; } tail;
             tail.h[0] = rec_split[0]; tail.h[1] = rec_split[1]; tail.h[2] = is_walk ? (uint16_t)0 : (uint16_t)(1 + rec_extra); tail.h[3] = (uint16_t)corner;
             union { uint32_t u[2]; double d; } kind_bits;
-            kind_bits.u[0] = rec_kind; kind_bits.u[1] = lane;       // (high half: the voice's position in its chunk -- where its polynomial lives)
+            // (low byte: the kind; an FM pair: above it the index in `segs` of the LFO's piece, 0xFFFFFF = a constant LFO, none.
+            //  high half: the voice's position in its chunk -- where its polynomial lives)
+            kind_bits.u[0] = rec_kind | (rec_kind == LEAN_FM ? ((lnp ? off_c + 2 * lp : 0xFFFFFFu) << 8) : 0u);
+            kind_bits.u[1] = lane | (lfo_split_rel << 8);      // (above the position: an FM pair's frame at which the LFO's next piece takes over, 0 = none)
             q2[7] = make_double2(tail.d, kind_bits.d);
         }
         if (lane == 0) {

@@ -149,16 +149,23 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
                 for (int j = 0; j < FPL; ++j) T[j] = i[j] < remain ? fma(di[j], da, ta) : fma(di[j] - ob, db, tb);
             }
             double ls, lc, th[FPL], sn[FPL], cs[FPL];
-            shm::sincos_tab(fma(di[0], poly[4], poly[3]), trig, ls, lc);
+            // the LFO's table piece (FastRec: the launch's first in poly[3..9], the next one in poly[11..15], pad2 for the tiles from
+            // frame pad1 on -- a multiple of 1024, so of this kernel's tile: prepare_voice)
+            {
+                const bool second = tile0 >= q->pad1;
+                const double l_a = second ? poly[11] : poly[3], l_d = second ? poly[12] : poly[4], l_K = second ? poly[13] : poly[5];
+                const double l_C = second ? poly[14] : poly[6], l_rc = second ? poly[15] : poly[8], l_rs = second ? q->pad2 : poly[9];
+                shm::sincos_tab(fma(di[0], l_d, l_a), trig, ls, lc);
 #pragma unroll
-            for (int j = 0; j < FPL; ++j) {
-                if (j > 0) {
-                    const double ns = fma(ls, poly[8], lc * poly[9]), nc = fma(lc, poly[8], -(ls * poly[9]));
-                    ls = ns;
-                    lc = nc;
+                for (int j = 0; j < FPL; ++j) {
+                    if (j > 0) {
+                        const double ns = fma(ls, l_rc, lc * l_rs), nc = fma(lc, l_rc, -(ls * l_rs));
+                        ls = ns;
+                        lc = nc;
+                    }
+                    const double Ln = fma(l_K, l_C - lc, poly[7] * (poly[10] + di[j]));
+                    th[j] = poly[0] * T[j] + fma(poly[2], Ln, poly[1]);
                 }
-                const double Ln = fma(poly[5], poly[6] - lc, poly[7] * (poly[10] + di[j]));
-                th[j] = poly[0] * T[j] + fma(poly[2], Ln, poly[1]);
             }
             shm::sincos_tab_n<FPL>(th, trig, sn, cs);
 #pragma unroll

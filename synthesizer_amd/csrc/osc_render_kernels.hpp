@@ -429,11 +429,12 @@ __device__ __forceinline__ void sin_tab_n(const double (&t)[N], TrigTab tab, dou
 #define SH_FM_Q 2        // carriers looked up at a time (four: 64 B of scratch in the FM-only lean kernel, 2 % slower; 260 B in the tiles kernel)
 #endif
 template <int FPL, bool BIASED, bool LINEAR, int QMAX = SH_FM_Q, typename TimeFn>
-__device__ __forceinline__ void lean_fm_frames(const double (&poly)[16], double lfo_a_rel, double startd, double di0, TimeFn time,
+__device__ __forceinline__ void lean_fm_frames(const double (&poly)[16], double lfo_a_rel, double startd, double lfo_d, double lfo_K, double lfo_C0,
+                                               double lrc, double lrs, double di0, TimeFn time,
                                                double t_first, double t_step, TrigTab trig, double (&out)[FPL]) {
-    // (lfo_a_rel: the LFO's angle at the launch's -- or tile's -- frame 0; startd: the voice's own index of that frame)
-    const double frequency = poly[0], f_inc = poly[2], lfo_d = poly[4];
-    const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], lrc = poly[8], lrs = poly[9];
+    // (lfo_a_rel: the LFO's angle at the launch's -- or tile's -- frame 0; startd: the voice's own index of that frame; lfo_d, lfo_K,
+    //  lfo_C0, (lrc, lrs) = (cos, sin)(64 lfo_d): the constants of the piece of the LFO's table the frames lie on)
+    const double frequency = poly[0], f_inc = poly[2], lfo_bias = poly[7];
     double magic = 6755399441055744.0, s5 = 0.008333333333333333, phase0 = poly[1];
     asm volatile("" : "+v"(magic), "+v"(s5), "+v"(phase0));          // (VGPR-resident: see sin_tab_n)
     double ls0, lc0;
@@ -524,13 +525,17 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                 // every lean record of the bank is an FM Sine voice: the FM code alone (no polynomial path, no waveform branches: the kernel
                 // with all kinds needs 128 VGPRs and spills; round 4)
                 double sn[FPL];
+                // the LFO's table piece: the launch's first, or -- the tiles from FastRec::pad1 on, a multiple of 1024 frames and so of every
+                // shape's tile: the first tile boundary behind the piece's end -- the next one (prepare_voice says what that costs)
+                double l_a = poly[3], l_d = poly[4], l_K = poly[5], l_C = poly[6], l_rc = poly[8], l_rs = poly[9];
+                if (tile0 >= q->pad1) { l_a = poly[11]; l_d = poly[12]; l_K = poly[13]; l_C = poly[14]; l_rc = poly[15]; l_rs = q->pad2; }
                 if (straddle) {
-                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, false>(poly, poly[3], poly[10], di0, theta, 0.0, 0.0, trig, sn);
-                    else lean_fm_frames<FPL, true, false>(poly, poly[3], poly[10], di0, theta, 0.0, 0.0, trig, sn);
+                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, false>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, 0.0, 0.0, trig, sn);
+                    else lean_fm_frames<FPL, true, false>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, 0.0, 0.0, trig, sn);
                 } else {
                     const double t_first = fma(di0 - off, dt, t_base), t_step = 64.0 * dt;
-                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, true>(poly, poly[3], poly[10], di0, theta, t_first, t_step, trig, sn);
-                    else lean_fm_frames<FPL, true, true>(poly, poly[3], poly[10], di0, theta, t_first, t_step, trig, sn);
+                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, true>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, t_first, t_step, trig, sn);
+                    else lean_fm_frames<FPL, true, true>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, t_first, t_step, trig, sn);
                 }
 #pragma unroll
                 for (int j = 0; j < FPL; ++j) {
@@ -709,7 +714,8 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                 // set bit -- an address that did not wait for the record, at ~50 VALU instructions per pair: with the scalar registers this
                 // kernel has left, the compiler did that uniform arithmetic on the vector unit); its polynomial comes from the table by
                 // voice (read by every tile's workgroups: it lives in L2)
-                const uint32_t vbit = *reinterpret_cast<const uint32_t SH_CONST_AS*>(reinterpret_cast<const char SH_CONST_AS*>(&q->pad_) + 4);
+                const uint32_t vword = *reinterpret_cast<const uint32_t SH_CONST_AS*>(reinterpret_cast<const char SH_CONST_AS*>(&q->pad_) + 4);
+                const uint32_t vbit = vword & 0xFFu;
                 const double SH_CONST_AS* pp = as_const(B.polys) + (size_t)(c * 64 + vbit) * 16;
                 double poly[16];
 #pragma unroll
@@ -720,15 +726,33 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                              "s"(poly[13]), "s"(poly[14]), "s"(poly[15]));
                 const LaneTheta none{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0u, 0u, false};
                 if constexpr (CLS != TILE_RUN_HARM) {
+                    // (an FM pair: the constants of the piece of the LFO's table the tile lies on -- its index in `segs` rides above the kind;
+                    //  0xFFFFFF: a constant LFO, the voice's own constants)
+                    double lfo_d = 0.0, lfo_K = 0.0, lfo_C0 = 0.0, lrc = 1.0, lrs = 0.0, lfo2_a = 0.0, lfo2_d = 0.0, lfo2_K = 0.0, lfo2_C0 = 0.0;
+                    uint32_t lfo_split = 0;                          // (the LFO's next piece takes over at this frame of the tile; 0: not in this tile)
                     if constexpr (CLS == TILE_RUN_FM) {
-                        if (pc == 1u) {
+                        const uint32_t lfo_idx = *reinterpret_cast<const uint32_t SH_CONST_AS*>(&q->pad_) >> 8;
+                        const sh_segment SH_CONST_AS* lpc_ = as_const(B.segs) + (lfo_idx != 0xFFFFFFu ? lfo_idx : 0u);
+                        if (lfo_idx != 0xFFFFFFu) {
+                            const sh_segment SH_CONST_AS* lpc = lpc_;
+                            const double2 SH_CONST_AS* lro = as_const(B.seg_rot) + lfo_idx;
+                            lfo_d = lpc[0].dt; lfo_K = lpc[1].t0; lfo_C0 = lpc[1].dt; lrc = lro->x; lrs = lro->y;
+                        } else {
+                            lfo_d = poly[4]; lfo_K = poly[5]; lfo_C0 = poly[6]; lrc = poly[8]; lrs = poly[9];
+                        }
+                        lfo_split = vword >> 8;
+                        if (lfo_split) {
+                            // ... whose constants follow in `segs`; the angle of frame x on it: t0' + (x - split - 1/2) d'
+                            lfo2_d = lpc_[2].dt; lfo2_a = fma(-(double)lfo_split - 0.5, lfo2_d, lpc_[2].t0); lfo2_K = lpc_[3].t0; lfo2_C0 = lpc_[3].dt;
+                        }
+                        if (pc == 1u && lfo_split == 0u) {
                             // an FM Sine pair on one piece under one line (the sustain, the release): the arithmetic of the lean lists --
                             // the time by one addition per frame, the LFO's cosine by recurrence (lean_fm_frames); the record's rc is the
                             // voice's own index of the tile's first frame, rs the LFO's angle there
                             double sn[FPL];
                             const double t_first = fma(lane_d, dt, t0), t_step = 64.0 * dt;
-                            if (poly[7] == 0.0) lean_fm_frames<FPL, false, true>(poly, rs, rc, lane_d, none, t_first, t_step, trig, sn);
-                            else lean_fm_frames<FPL, true, true>(poly, rs, rc, lane_d, none, t_first, t_step, trig, sn);
+                            if (poly[7] == 0.0) lean_fm_frames<FPL, false, true>(poly, rs, rc, lfo_d, lfo_K, lfo_C0, lrc, lrs, lane_d, none, t_first, t_step, trig, sn);
+                            else lean_fm_frames<FPL, true, true>(poly, rs, rc, lfo_d, lfo_K, lfo_C0, lrc, lrs, lane_d, none, t_first, t_step, trig, sn);
                             double gl_e = GL, gr_e = GR;
                             if (ea1 == 0.0) {
                                 gl_e = GL * ea0;
@@ -748,7 +772,7 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                     // an FM Sine pair of another form, or a plain Sawtooth / Square / Triangle / Pulse (unit amplitude, t in turns: the
                     // amplitude lives in the gains): every frame from its accumulated t on the piece that holds it -- the record's
                     // pieces, or a walk along the voice's table -- the envelope's line of the frame, and nothing in front of an onset
-                    const uint32_t wkind = *reinterpret_cast<const uint32_t SH_CONST_AS*>(&q->pad_);
+                    const uint32_t wkind = *reinterpret_cast<const uint32_t SH_CONST_AS*>(&q->pad_) & 0xFFu;
                     {
                         const double eb0 = q->eb0, eb1 = q->eb1, ci = (double)(pc >> 16);
                         double th[FPL], on = 0.0;
@@ -783,15 +807,15 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                             // a Sine carrier with a closed-form Sine LFO: th[] is the accumulated TIME; the carrier's angle from the
                             // running sum of the LFO, L(n) = K (C0 - cos(a + (n - 1/2) d)) + bias n, at the voice's own index n
                             // (a pair with a corner, further pieces or a walk: every frame by two lookups)
-                            const double fr = poly[0], phase0 = poly[1], f_inc = poly[2], lfo_a = poly[3], lfo_d = poly[4];
-                            const double lfo_K = poly[5], lfo_C0 = poly[6], lfo_bias = poly[7], n_first = rc;
-                            const double a_rel = fma(n_first - 0.5, lfo_d, lfo_a);
+                            const double fr = poly[0], phase0 = poly[1], f_inc = poly[2], lfo_bias = poly[7], n_first = rc;
+                            const double a_rel = rs;             // (the LFO's angle at the tile's first frame, on its piece: prepare_tiles_wave)
 #pragma unroll
                             for (int j = 0; j < FPL; ++j) {
                                 const double x = lane_d + (double)(j * 64);
                                 double ls, lc, sj, cj;
-                                shm::sincos_tab(fma(x, lfo_d, a_rel), trig, ls, lc);
-                                const double Ln = fma(lfo_K, lfo_C0 - lc, lfo_bias * (n_first + x));
+                                const bool behind = lfo_split != 0u && x >= (double)lfo_split;
+                                shm::sincos_tab(behind ? fma(x, lfo2_d, lfo2_a) : fma(x, lfo_d, a_rel), trig, ls, lc);
+                                const double Ln = fma(behind ? lfo2_K : lfo_K, (behind ? lfo2_C0 : lfo_C0) - lc, lfo_bias * (n_first + x));
                                 shm::sincos_tab(fr * th[j] + fma(f_inc, Ln, phase0), trig, sj, cj);
                                 const double ej = x < ci ? fma(x, ea1, ea0) : fma(x, eb1, eb0);
                                 const double w = x >= on ? sj * ej : 0.0;

@@ -51,6 +51,52 @@ def _table(t0: float, inc: float) -> PhaseTable:
     return PhaseTable(t0, inc)
 
 
+class LfoTable:
+    """The running sum of a Sine LFO as the reference forms it, piece by piece.
+
+    The LFO is an oscillator of its own: its phase is the ACCUMULATED t += d (float64), which is piecewise exactly linear like every
+    running sum here (phasetable.py) -- and drifts away from a + j d as t grows (the rounding of an addition is half an ulp of t: after
+    300 s at 5 Hz the LFO's phase is 1.5e-5 rad off the ideal line, and the carrier's angle, f_inc * sum of the LFO, 1e-4 rad: a t^2 law).
+    On a piece p (samples n0_p .. n0_{p+1} - 1, phase t0_p + (j - n0_p) dt_p) the sum has the closed form
+
+        L(n) = S_p + K_p (cos(t0_p - dt_p / 2) - cos(t0_p + (n - n0_p - 1/2) dt_p)),   K_p = amp / (2 sin(dt_p / 2)),
+
+    S_p = L(n0_p).  `records`: two sh_segment-shaped records per piece -- (n0, t0, dt) and (n0, K_p, C_p) with
+    C_p = cos(t0_p - dt_p / 2) + S_p / K_p, so that L(n) = K_p (C_p - cos(...)) -- which a voice addresses through seg_offset /
+    seg_count (an FM voice's carrier runs on the TIME table; its own table slots are free).  S_p / K_p is summed from the pieces in
+    front, sum_q (K_q / K_p)(cos(b_q) - cos(e_q)), with the end angle e_q = (the piece's last t) + dt_q / 2 formed exactly in extended
+    precision (dt is a multiple of the ulp of t, so the sum has 54 significant bits)."""
+
+    def __init__(self, a: float, d: float, amp: float) -> None:
+        tab = PhaseTable(a, d)
+        segs = tab.segments
+        out = np.zeros(2 * len(segs), dtype=N.SEGMENT_DTYPE)
+        ld = np.longdouble
+        # per piece: begin angle b, end angle e (the last piece of the table has no end: nothing lies behind it)
+        terms: List[Tuple[float, "np.longdouble"]] = []         # (dt_q, cos(b_q) - cos(e_q)) of the pieces in front
+        for p, (n0, t0, dt) in enumerate(segs):
+            half = sin(dt / 2.0)
+            K = amp / (2.0 * half) if half != 0.0 else 0.0
+            acc = ld(0.0)
+            for dq, diff in terms:
+                rho = ld(dt) / ld(dq)
+                rho = rho * (ld(1.0) - (ld(dt) * ld(dt) - ld(dq) * ld(dq)) / ld(24.0))       # sin(dt/2) / sin(dq/2)
+                acc += rho * diff
+            C = float(np.cos(ld(t0) - ld(dt) / ld(2.0)) + acc)
+            out[2 * p] = (n0, t0, dt)
+            out[2 * p + 1] = (n0, K, C)
+            if p + 1 < len(segs):
+                last = tab.value(segs[p + 1][0] - 1)                                     # the piece's last t: a float64, exactly
+                terms.append((dt, np.cos(ld(t0) - ld(dt) / ld(2.0)) - np.cos(ld(last) + ld(dt) / ld(2.0))))
+        self.records = out
+        self.pieces = len(segs)
+
+
+@lru_cache(maxsize=4096)
+def _lfo_table(a: float, d: float, amp: float) -> LfoTable:
+    return LfoTable(a, d, amp)
+
+
 @lru_cache(maxsize=None)
 def _cheb_u(n: int) -> Tuple[Tuple[int, ...], ...]:
     """Monomial coefficients (ascending powers) of the Chebyshev polynomials U_0 .. U_n."""
@@ -148,6 +194,7 @@ class VoiceSpec:
     fm_phase0: float = 0.0
     fm_inc: float = 0.0
     lfo: Tuple[float, float, float, float, float, float] = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)  # a, d, amp, bias, K, C0
+    lfo_table: Optional[LfoTable] = None          # SH_FM_SINE with a Sine LFO that moves: its running sum piece by piece
     harm_poly: Optional[Tuple[float, ...]] = None       # 16 polynomial coefficients (all k <= 16), highest power first
     harm_dense: Optional[Tuple[float, ...]] = None      # Clenshaw coefficients, k = K..1, len % 8 == 0
     harm_sparse: Optional[Tuple[Tuple[float, float], ...]] = None
@@ -215,6 +262,8 @@ def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float
             seg_off[i], seg_cnt[i] = add_table(s.carrier)
         else:
             tseg_off[i], tseg_cnt[i] = add_table(s.time_table)
+            if s.lfo_table is not None:
+                seg_off[i], seg_cnt[i] = add_table(s.lfo_table)     # (the LFO's pieces, two records each: LfoTable)
             v = voices[i]
             v["frequency"] = s.frequency
             v["fm_phase0"] = s.fm_phase0
@@ -465,7 +514,8 @@ class _Carrier(Oscillator):
                     out.update(fm_mode=N.SH_FM_SINE, lfo=(a, d, 0.0, c, 0.0, 0.0))
                 else:
                     K = lfo.amplitude / (2.0 * half)
-                    out.update(fm_mode=N.SH_FM_SINE, lfo=(a, d, float(lfo.amplitude), float(lfo.bias), K, cos(a - d / 2.0)))
+                    out.update(fm_mode=N.SH_FM_SINE, lfo=(a, d, float(lfo.amplitude), float(lfo.bias), K, cos(a - d / 2.0)),
+                               lfo_table=_lfo_table(a, d, float(lfo.amplitude)))
             else:
                 out.update(fm_mode=N.SH_FM_BUFFER)
             return out

@@ -164,7 +164,9 @@ def test_segmented_transition_launches(gpu, tmp_path):
         scale = max(1e-3, float(np.max(np.abs(w))))
         # (naive Square / Pulse / Sawtooth voices: both paths evaluate the exact accumulated phase, edges included)
         assert np.max(np.abs(got.astype(np.float64) - w)) <= 1.3e-7 * scale, ("mixed", n, start)
-        assert np.mean(got != w) < 2e-3, ("mixed", n, start, float(np.mean(got != w)))
+        # (the FM Sine voices of this bank change pieces of their LFO's table at the first tile boundary behind the piece's end, and
+        # tiles count from the launch's -- here: the segment's -- first frame: a few float32 roundings more fall the other way)
+        assert np.mean(got != w) < 3e-3, ("mixed", n, start, float(np.mean(got != w)))
     pcm = bank.render_pcm_device(48000, 0).download(np.int16, 96000)
     assert np.max(np.abs(pcm.astype(np.int32) - want["pcm"].astype(np.int32))) <= 1 and np.mean(pcm != want["pcm"]) < 2e-3
     # a run that starts with the segmented launch and goes on: blocks 0 .. 5 pipelined == the blocks one by one

@@ -248,3 +248,36 @@ def test_eight_ranks_map_to_eight_distinct_gpu_ordinals(tmp_path):
         p = subprocess.run([sys.executable, str(root / "tests" / "multi_gpu_worker.py"), "--plumbing"], env=env, capture_output=True, text=True, timeout=120)
         assert p.returncode == 0, p.stderr[-2000:]
         assert json.loads(p.stdout.strip().splitlines()[-1]) == {"rank": r, "world": 8, "device": r}
+
+
+def test_lfo_table_reproduces_the_running_sum_of_an_accumulated_phase():
+    """oscillators.LfoTable: the running sum L(n) of amp * sin(t_j), t_j the ACCUMULATED t += d of the reference's LFO oscillator, from
+    per-piece closed forms with prefix sums -- against the sum formed sample by sample (math.fsum of the float sines over the accumulated
+    phases), for a slow and a fast LFO (the fast one walks through twenty binades in 2e6 samples: its phase ends 1e-4 rad off the ideal
+    line a + n d, which the single closed form of rounds 1-3 followed)."""
+    import math
+    from synthesizer_amd.oscillators import LfoTable
+    for a, d, amp, n_max in ((0.3 * 2 * math.pi, 2 * math.pi * 5.0 / 48000, 0.05, 600000), (1.25, 0.37, 0.5, 2000000), (0.0, 2 * math.pi * 0.01 / 48000, 0.5, 300000)):
+        tab = LfoTable(a, d, amp)
+        rec = tab.records
+        assert len(rec) == 2 * tab.pieces and tab.pieces >= 2
+        n0s = [int(rec["n0"][2 * p]) for p in range(tab.pieces)]
+        checks = sorted(set([1, 2, 3, 1000, n_max // 3, n_max // 2, n_max] + [n for n in n0s if 0 < n <= n_max] + [n + 1 for n in n0s if n + 1 <= n_max]))
+        t, j, sines, worst, drift = a, 0, [], 0.0, 0.0
+        for n in checks:
+            while j < n:
+                sines.append(amp * math.sin(t))
+                t += d
+                j += 1
+            want = math.fsum(sines)
+            p = max(q for q in range(tab.pieces) if n0s[q] <= n)
+            n0, t0, dt = int(rec["n0"][2 * p]), float(rec["t0"][2 * p]), float(rec["dt"][2 * p])
+            K, C = float(rec["t0"][2 * p + 1]), float(rec["dt"][2 * p + 1])
+            got = K * (C - math.cos(t0 + ((n - n0) - 0.5) * dt))
+            worst = max(worst, abs(got - want))
+            ideal = amp / (2 * math.sin(d / 2)) * (math.cos(a - d / 2) - math.cos(a + (n - 0.5) * d))
+            drift = max(drift, abs(ideal - want))
+        K0 = abs(amp / (2 * math.sin(d / 2)))
+        assert worst <= 4e-13 * max(K0, 1.0) + 3e-16 * n_max, (a, d, worst)
+        if d > 0.1:
+            assert drift > 1000 * worst, (drift, worst)             # the single closed form is off by the phase's drift

@@ -1,6 +1,6 @@
 """FM Sine voices whose LFO is very slow: the lean FM loop takes the LFO's cosine by the three-term recurrence cos[j] = 2cos(64 d) cos[j-1] - cos[j-2],
 whose error grows like j * 1.1e-16 / sin(64 d) and reaches the carrier's angle multiplied by f_inc * K, K ~ amplitude / d.  Max error of a
-256-voice bank and of single voices against the C oracle, LFO rates 10 Hz .. 0.0001 Hz.  usage (GPU box): python tools/slow_lfo_probe.py"""
+256-voice bank and of single voices against the C oracle, LFO rates 10 Hz .. 0.0001 Hz.  usage (GPU box): python tools/slow_lfo_probe.py [seconds into the notes = 30] [voices = 256]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,9 @@ from synthesizer_amd import _native as N
 from synthesizer_amd import oscillators as G
 from synthesizer_amd.mixer import VoiceBank
 N.ensure_init(0)
-SR, nv, blk, first = 48000, 256, 16384, 48000 * 30
+SR, blk = 48000, 16384
+nv = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+first = SR * (int(sys.argv[1]) if len(sys.argv) > 1 else 30)          # seconds into the notes
 rng = np.random.default_rng(5)
 f = np.exp(rng.uniform(np.log(55.0), np.log(3520.0), nv))
 ph = rng.uniform(0, 1, nv)
@@ -23,7 +25,7 @@ for rate in (10.0, 1.0, 0.1, 0.01, 0.001, 0.0001):
         gv, ov = build(G), build(O)
         want = CO.mix_bus(np.stack([CO.render(v, first + blk)[first:] for v in ov]), gains)
         got = VoiceBank(gv, gains=gains).render(blk, start=first)
-        one = gv[7].render(blk, start=first) if hasattr(gv[7], "render") else None
+        one = gv[7].render(blk, start=first) if hasattr(gv[7], "render") else None      # (a single oscillator: the general code)
         w1 = CO.render(ov[7], first + blk)[first:]
         e1 = float(np.max(np.abs(np.asarray(one, dtype=np.float64).reshape(-1)[:blk] - w1))) if one is not None else float("nan")
         print("lfo %8.4f Hz depth %.2f: bank max |err| %.3e rms %.3e   single voice (general path) max |err| %.3e" %
