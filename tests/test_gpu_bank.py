@@ -798,3 +798,52 @@ def test_lean_lists_in_runs_by_kind(gpu):
     got64 = whole.download(np.float64, blk * 2)
     whole.free()
     assert np.max(np.abs(got64 - total)) < 1e-12
+
+
+def test_fm_follows_the_lfos_accumulated_phase_late_in_a_note(gpu):
+    """Round 4: the LFO of an FM voice is an oscillator of its own in the reference -- its phase the accumulated t += d, which drifts from
+    a + n d by half an ulp of t per sample -- and the carrier's angle is f_inc times the running SUM of it: summed along the ideal line
+    (rounds 1-3) a 3.5 kHz carrier was 1e-5 off the oracle 30 s into a note and 1e-3 after 300 s.  The sum now follows the LFO's own
+    phase table (oscillators.LfoTable).  100 s into the note: a single oscillator (general code; the window holds the frame at which the
+    LFO's phase crosses 4096 rad for one of the rates) and a 160-voice bank (lean lists, the LFO's piece changing inside the launch for
+    some voices) against the C oracle; what is left is the rounding noise of the reference's own running sums."""
+    from oracle import c_oracle as CO
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    blk = 16384
+    for secs, f, rate, depth, tol in ((100, 3520.0, 5.0, 0.5, 2e-7), (130, 880.0, 5.0133, 0.05, 5e-8),
+                                      # (a very slow, deep LFO: the reference's own phase_correction sum -- 1.4e6 additions of slowly varying terms to a
+                                      #  number of ~1e5, their roundings correlated -- is 4e-7 off the exact sum by now: inside the contract, not below)
+                                      (30, 440.0, 0.01, 0.5, 1e-6)):
+        first = secs * SR
+        g = G.Sine(f, 1.0, phase=0.2, fm_lfo=G.Sine(rate, depth, phase=0.3, samplerate=SR), samplerate=SR)
+        o = O.Sine(f, 1.0, phase=0.2, fm_lfo=O.Sine(rate, depth, phase=0.3, samplerate=SR), samplerate=SR)
+        w = CO.render(o, first + blk)[first:]
+        got = g.render_f64(blk, start=first)
+        assert rms(got, w) <= tol, (secs, f, rate, float(rms(got, w)))
+    nv, first = 160, 40 * SR
+    rng = np.random.default_rng(3)
+    fr = np.exp(rng.uniform(np.log(55.0), np.log(3520.0), nv))
+    rate = rng.uniform(4.0, 17.0, nv)          # 40 s in: phases of 1000 .. 4300 rad -- some cross 1024, 2048 or 4096 in the window
+    gains = [(float(np.float32(a)), float(np.float32(1.0 - a))) for a in rng.uniform(0.0, 1.0, nv)]
+
+    def build(m):
+        return [m.Sine(float(fr[i]), 1.0 / np.sqrt(nv), phase=float(i % 7) / 7.0,
+                       fm_lfo=m.Sine(float(rate[i]), 0.3, phase=0.1, bias=(0.01 if i % 4 == 0 else 0.0), samplerate=SR), samplerate=SR) for i in range(nv)]
+    gv, ov = build(G), build(O)
+    n = 3 * blk
+    rows = np.stack([CO.render(v, first + n)[first:] for v in ov])
+    want = CO.mix_bus(rows, gains)
+    crossing = 0
+    for i in range(nv):
+        d = 2 * np.pi * rate[i] / SR
+        t0, t1 = 0.1 * 2 * np.pi + first * d, 0.1 * 2 * np.pi + (first + n) * d
+        crossing += int(np.floor(np.log2(t1)) > np.floor(np.log2(t0)))
+    assert crossing >= 3                                       # the window does hold ends of LFO table pieces
+    bank = VoiceBank(gv, gains=gains)
+    for k in range(3):
+        got = bank.render(blk, start=first + k * blk)
+        w = want[k * blk:(k + 1) * blk]
+        assert rms(got, w) <= 1e-7 and np.max(np.abs(got - w)) < 5e-7, (k, float(rms(got, w)))
+    whole = bank.render(n, start=first)                        # one launch over all of it: piece ends inside the launch
+    assert rms(whole, want) <= 1e-7
