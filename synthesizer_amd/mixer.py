@@ -26,7 +26,7 @@ from typing import Callable, Dict, Generator, List, Optional, Sequence, Tuple, U
 import numpy as np
 
 from . import _native as N
-from .oscillators import Oscillator, VoiceSpec, _table, pack_voices
+from .oscillators import Oscillator, VoiceSpec, _table, pack_voices, time_step_weights
 from .sample import Sample
 
 __all__ = ["VoiceBank", "RealTimeMixer", "mix_samples", "pan_gains"]
@@ -44,7 +44,7 @@ class _RowMatrix:
     modulated by an arbitrary oscillator, a filter graph -- renders into its row on its own."""
 
     def __init__(self, fm_sources: Sequence[Oscillator], other_sources: Sequence[Oscillator], samplerate: int,
-                 other_roles: Optional[Sequence[str]] = None) -> None:
+                 other_roles: Optional[Sequence[str]] = None, fm_incs: Optional[Sequence[float]] = None) -> None:
         self.nfm = len(fm_sources)
         self.nrows = len(fm_sources) + len(other_sources)
         self.samplerate = samplerate
@@ -79,6 +79,13 @@ class _RowMatrix:
             out_rows.extend(rows)
 
         place(fm_sources, 0, self.fm_rows, None)
+        # the time step inc of every fm row's CARRIER (2 pi / sr for Sine / Harmonics, 1 / sr for the turn-based kinds): the row is
+        # weighted with the accumulated time's actual steps over inc in front of the scan (oscillators.time_step_weights); runs of
+        # neighbouring rows with the same inc are weighted by one call
+        self._row_inc: List[float] = [0.0] * self.nfm
+        if fm_incs is not None:
+            for k, r in enumerate(self.fm_rows):
+                self._row_inc[r] = float(fm_incs[k])
         place(other_sources, self.nfm, self.other_rows, list(other_roles) if other_roles is not None else ["voice"] * len(other_sources))
         self._buf: Optional[N.DeviceBuffer] = None
         self._stride = 0
@@ -109,6 +116,26 @@ class _RowMatrix:
             if avail < n:
                 N.check(L.sh_ew_f64(N.SH_EW_FILL, None, 0, None, 0, n - avail, 0.0, 0.0, self._buf.handle, row * self._stride + avail, None, 0, None))
         if self.nfm:
+            r0 = 0
+            while r0 < self.nfm:
+                r1 = r0 + 1
+                while r1 < self.nfm and self._row_inc[r1] == self._row_inc[r0]:
+                    r1 += 1
+                if self._row_inc[r0] != 0.0:
+                    runs = time_step_weights(self._row_inc[r0], start, n)
+                    if len(runs) == 1 and runs[0][:2] == (0, n):          # one piece of the time table: rows r0 .. r1 - 1 in one call
+                        if runs[0][2] != 0.0:
+                            o = r0 * self._stride
+                            N.check(L.sh_ew_f64(N.SH_EW_AXPY, self._buf.handle, o, self._buf.handle, o, (r1 - r0 - 1) * self._stride + n,
+                                                runs[0][2], 0.0, self._buf.handle, o, None, 0, None))
+                    else:                                                  # a piece of the time table ends inside the block (rare)
+                        for r in range(r0, r1):
+                            for off, cnt, wm1 in runs:
+                                if wm1 != 0.0:
+                                    o = r * self._stride + off
+                                    N.check(L.sh_ew_f64(N.SH_EW_AXPY, self._buf.handle, o, self._buf.handle, o, cnt, wm1, 0.0,
+                                                        self._buf.handle, o, None, 0, None))
+                r0 = r1
             N.check(L.sh_scan_rows_f64(self._buf.handle, 0, self.nfm, n, self._stride, self._carry.handle))
             self._pos = start + n
 
@@ -152,6 +179,7 @@ class VoiceBank:
         # record at all -- a filter graph, an envelope over one -- whose samples are rendered into its row (SH_BUFFER).
         specs: List[VoiceSpec] = []
         fm_src: List[Tuple[int, Oscillator]] = []           # (voice, modulator): rows 0 .. nfm-1, scanned in place
+        fm_incs: List[float] = []                           # ... and the time step of the voice (the carrier) itself
         other_src: List[Tuple[str, int, Oscillator]] = []   # ("pwm" | "voice", voice, source): the rows after them
         # (the collector off while the records are made: a table of 200 000 notes is a million live objects, and every generation-2
         # pass walks them all -- 2.5 s with it, 1.35 s without; nothing in the loop makes a cycle)
@@ -167,6 +195,7 @@ class VoiceBank:
                 else:
                     if sp.fm_mode == N.SH_FM_BUFFER:
                         fm_src.append((i, v._fm_source()))
+                        fm_incs.append(sp.fm_inc)
                     if sp.needs_pwm:
                         other_src.append(("pwm", i, v._pwm_source()))
                 specs.append(sp)
@@ -181,7 +210,7 @@ class VoiceBank:
             fm_row = np.full(self.nvoices, -1, dtype=np.int32)
             pwm_row = np.full(self.nvoices, -1, dtype=np.int32)
             self._rows = _RowMatrix([m for _, m in fm_src], [m for _, _, m in other_src], self.samplerate,
-                                    other_roles=[what for what, _, _ in other_src])
+                                    other_roles=[what for what, _, _ in other_src], fm_incs=fm_incs)
             for (i, _m), r in zip(fm_src, self._rows.fm_rows):
                 fm_row[i] = r
             for (what, i, _m), r in zip(other_src, self._rows.other_rows):

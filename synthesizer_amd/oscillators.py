@@ -120,6 +120,34 @@ def _lfo_table(a: float, d: float, amp: float, bias: float, inc: float) -> LfoTa
     return LfoTable(a, d, amp, bias, inc)
 
 
+def time_step_weights(inc: float, start: int, n: int) -> List[Tuple[int, int, float]]:
+    """For the samples [start, start + n) of an FM carrier whose time is the accumulated t += inc: runs (offset, count, w - 1) with
+    w = (t_{j+1} - t_j) / inc, the ACTUAL step of the accumulated time over the ideal one -- constant on a piece of the time table,
+    another value for the one sample at a piece's end.  The reference's angle is sum freq_j (t_{j+1} - t_j) (LfoTable): a modulator
+    that is summed by a scan (the buffer path) is weighted with w first, so that f inc cumsum(w m) is that sum."""
+    tab = _table(0.0, inc)
+    rec = tab.records
+    n0s = rec["n0"]
+    ld = np.longdouble
+    out: List[Tuple[int, int, float]] = []
+    pos, end = start, start + n
+    q = int(np.searchsorted(n0s, np.uint64(pos), side="right") - 1)
+    while pos < end:
+        tau = ld(rec["dt"][q])
+        nxt = int(n0s[q + 1]) if q + 1 < len(n0s) else None
+        stop = end if nxt is None else min(end, nxt - 1)              # (the piece's last sample steps into the next piece)
+        if stop > pos:
+            out.append((pos - start, stop - pos, float((tau - ld(inc)) / ld(inc))))
+            pos = stop
+        if pos < end and nxt is not None and pos == nxt - 1:
+            t_last = ld(rec["t0"][q]) + ld(pos - int(n0s[q])) * tau
+            step = ld(rec["t0"][q + 1]) - t_last
+            out.append((pos - start, 1, float((step - ld(inc)) / ld(inc))))
+            pos += 1
+            q += 1
+    return out
+
+
 @lru_cache(maxsize=None)
 def _cheb_u(n: int) -> Tuple[Tuple[int, ...], ...]:
     """Monomial coefficients (ascending powers) of the Chebyshev polynomials U_0 .. U_n."""
@@ -390,6 +418,10 @@ class Oscillator:
 
     def _advance_fm(self, lfo: "Oscillator", start: int, n: int, keep: bool) -> Optional[N.DeviceBuffer]:
         mod = lfo._render_f64_device(start, n)
+        # the modulator's samples weighted with the accumulated time's actual steps over inc (time_step_weights): m += m (w - 1), in place
+        for off, cnt, wm1 in time_step_weights(self.spec().fm_inc, start, n):
+            if wm1 != 0.0:
+                N.check(N.lib().sh_ew_f64(N.SH_EW_AXPY, mod.handle, off, mod.handle, off, cnt, wm1, 0.0, mod.handle, off, None, 0, None))
         cum = N.DeviceBuffer(n * 8)
         carry = C.c_double()
         N.check(N.lib().sh_scan_f64(mod.handle, n, self._fm_carry, cum.handle, C.byref(carry)))
