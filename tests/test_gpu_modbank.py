@@ -201,3 +201,32 @@ def test_envelope_over_a_source_that_ends(gpu):
     assert bank.render(src_len, start=0)[:, 0].any()
     with pytest.raises(RuntimeError):
         bank.render(src_len + 10, start=0)
+
+
+def test_buffer_path_fm_sums_over_the_accumulated_time_steps(gpu):
+    """Round 4: the angle of an FM carrier is the sum of freq_j over the ACCUMULATED time steps; a modulator that is summed by
+    a scan is weighted with (t_{j+1} - t_j) / inc first (oscillators.time_step_weights).  Twenty seconds into the notes a bank whose fm
+    rows belong to carriers of both kinds of time step (Sine: 2 pi / sr; Sawtooth: 1 / sr) under biased non-Sine LFOs, whose block holds an
+    end of a time table's piece, against the pure-Python oracle: without the weights the biased rows are 1e-7 off by now (a t^2 law)."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    from synthesizer_amd.oscillators import time_step_weights
+
+    def voices(m):
+        return [m.Sine(3520.0, 0.3, phase=0.2, fm_lfo=m.Triangle(5.0, 0.05, bias=0.01, samplerate=SR), samplerate=SR),
+                m.Sawtooth(1760.0, 0.3, fm_lfo=m.Square(3.0, 0.02, bias=0.02, samplerate=SR), samplerate=SR),
+                m.Sine(2000.0, 0.3, fm_lfo=m.Sawtooth(2.0, 0.3, samplerate=SR), samplerate=SR),
+                m.Harmonics(880.0, [(1, 1.0), (2, 0.5)], 0.3, fm_lfo=m.Triangle(0.5, 0.2, bias=-0.01, samplerate=SR), samplerate=SR)]
+    gains = [(0.5, 0.25), (0.25, 0.5), (0.4, 0.4), (0.3, 0.6)]
+    # a block that holds the end of a piece of the time table t += 2 pi / sr (the accumulated time crosses 128 rad at sample 977 848)
+    ends = [int(n) for n in G._table(0.0, 2 * np.pi / SR).records["n0"] if 900000 < int(n) < 1100000]
+    assert ends
+    first, n = ends[0] - 5000, 12000
+    assert len(time_step_weights(2 * np.pi / SR, first, n)) >= 3
+    bank = VoiceBank(voices(G), gains=gains)
+    want = _oracle_bus(voices(O), gains, first + n)[first:]
+    got = bank.render(n, start=first)
+    assert rms(got, want) <= 2e-8, float(rms(got, want))              # (float32 rounding of the bus: ~1e-8)
+    again = bank.render(4096, start=first + n)                        # the carries go on from there
+    more = _oracle_bus(voices(O), gains, first + n + 4096)[first + n:]
+    assert rms(again, more) <= 2e-8
