@@ -386,14 +386,9 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
                 for (int q = 0; q < 34; ++q)
                     if (len < (1ull << q) && e + on > b->short_piece_end[q]) b->short_piece_end[q] = e + on;
             }
-            // ... and the pieces of an FM Sine voice's LFO (two records each): the lean loop follows ONE end of them per launch too
-            if (v.fm_mode == SH_FM_SINE)
-                for (uint32_t k = 0; k + 3 < v.seg_count; k += 2) {
-                    const uint64_t a = segs[v.seg_offset + k].n0, e = segs[v.seg_offset + k + 2].n0;
-                    const uint64_t len = e - a;
-                    for (int q = 0; q < 34; ++q)
-                        if (len < (1ull << q) && e + on > b->short_piece_end[q]) b->short_piece_end[q] = e + on;
-                }
+            // (the pieces of an FM Sine voice's LFO table -- oscillators.LfoTable -- do not count: the lean loop follows the first end
+            // of them inside a launch at a tile boundary and a second one, rare and late, along the line of the piece in front of it:
+            // never the general code)
         }
     }
     if (b->env_corners.size() > 16) {                              // voices with envelopes of their own: cut where they are all flat only
