@@ -111,6 +111,7 @@ BankPtrs ptrs(const sh_bank* b) {
     p.coefs = b->d_coefs;
     p.partials = b->d_partials;
     p.hint = b->d_hint;
+    p.lfo_hint = b->d_hint + b->nvoices;
     p.seg_rot = b->d_seg_rot;
     p.lfo_rot = b->d_lfo_rot;
     p.rows = b->launch_rows;
@@ -453,8 +454,8 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_gen_idx_buf[k], sizeof(uint32_t) * slots);
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_counts_buf[k], sizeof(uint32_t) * 4 * ((nvoices + 63) / 64));
         }
-        if (e == hipSuccess) e = hipMalloc((void**)&b->d_hint, sizeof(uint32_t) * nvoices);
-        if (e == hipSuccess) e = hipMemsetAsync(b->d_hint, 0, sizeof(uint32_t) * nvoices, st);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_hint, sizeof(uint32_t) * 2 * nvoices);      // (carrier / time table pieces, then LFO table pieces)
+        if (e == hipSuccess) e = hipMemsetAsync(b->d_hint, 0, sizeof(uint32_t) * 2 * nvoices, st);
         if (e != hipSuccess) rc = sh::hip_error(e, "hipMalloc(launch records)");
         b->d_launch = b->d_launch_buf[0];
         b->d_launch_fm = b->d_launch_fm_buf[0];

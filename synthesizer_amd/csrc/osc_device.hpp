@@ -123,6 +123,7 @@ struct BankPtrs {
     const double*     coefs;
     const sh_partial* partials;
     uint32_t*         hint;       // per voice: table piece of the last prepared launch (streaming: same or next piece)
+    uint32_t*         lfo_hint;   // ... and the piece of an FM Sine voice's LFO table (oscillators.LfoTable)
     const double2*    seg_rot;    // per table piece: (cos, sin)(64*dt), computed once on the host at bank creation
     const double2*    lfo_rot;    // per voice: (cos, sin)(64*lfo_d)
     // per launch (sh_bank_render_rows): float64 rows [row][row_stride], launch-relative -- the running LFO sum of an
@@ -529,11 +530,25 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     if (lfo_pieces) {
         const sh_segment* lt = B.segs + v.seg_offset;
         const uint32_t np_ = v.seg_count / 2;
-        uint32_t lo_ = 0, hi_ = np_ - 1;
-        while (lo_ < hi_) {
-            const uint32_t mid = (lo_ + hi_ + 1) >> 1;
-            if (lt[2 * mid].n0 <= start) lo_ = mid; else hi_ = mid - 1;
+        // (the piece of the last prepared launch, or the one behind it -- one batch of loads -- before the binary search's eight
+        // dependent ones: a lane's chain of round trips IS the time this step takes)
+        uint32_t lo_ = B.lfo_hint[first + vi];
+        if (lo_ >= np_) lo_ = np_ - 1;
+        {
+            const uint64_t h0 = lt[2 * lo_].n0, h1 = lo_ + 1 < np_ ? lt[2 * lo_ + 2].n0 : ~0ull, h2 = lo_ + 2 < np_ ? lt[2 * lo_ + 4].n0 : ~0ull;
+            if (h0 <= start && start < h1) {
+            } else if (h1 <= start && start < h2) {
+                lo_ += 1;
+            } else {
+                uint32_t hi_ = np_ - 1;
+                lo_ = 0;
+                while (lo_ < hi_) {
+                    const uint32_t mid = (lo_ + hi_ + 1) >> 1;
+                    if (lt[2 * mid].n0 <= start) lo_ = mid; else hi_ = mid - 1;
+                }
+            }
         }
+        B.lfo_hint[first + vi] = lo_;
         const uint64_t q_n0 = lt[2 * lo_].n0;
         const double q_t0 = lt[2 * lo_].t0, q_dt = lt[2 * lo_].dt;
         l_a = fma((double)(start - q_n0) - 0.5, q_dt, q_t0);            // the angle at frame i: a + i d

@@ -490,10 +490,12 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
             // The second piece's fields are NOT in the list: their loads stay inside the rare crossing branches.
             const double gl = q->gain_l, gr = q->gain_r;
             const uint32_t remain = q->remain, kind = q->kind;
+            const uint32_t lsplit = CLS == LEAN_K_FM ? q->pad1 : 0xFFFFFFFFu;      // (FM Sine: where the LFO's table piece ends; same batch of loads)
             const double ta = q->t_base, da = q->dt, rca = q->rot_c, rsa = q->rot_s;
             double poly[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) poly[u] = q->poly[u];
+            if constexpr (CLS == LEAN_K_FM) asm volatile("" :: "s"(lsplit));
             asm volatile("" :: "s"(gl), "s"(gr), "s"(remain), "s"(kind), "s"(ta), "s"(da), "s"(rca), "s"(rsa),
                          "s"(poly[0]), "s"(poly[1]), "s"(poly[2]), "s"(poly[3]), "s"(poly[4]), "s"(poly[5]),
                          "s"(poly[6]), "s"(poly[7]), "s"(poly[8]), "s"(poly[9]), "s"(poly[10]), "s"(poly[11]), "s"(poly[12]),
@@ -528,7 +530,7 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                 // the LFO's table piece: the launch's first, or -- the tiles from FastRec::pad1 on, a multiple of 1024 frames and so of every
                 // shape's tile: the first tile boundary behind the piece's end -- the next one (prepare_voice says what that costs)
                 double l_a = poly[3], l_d = poly[4], l_K = poly[5], l_C = poly[6], l_rc = poly[8], l_rs = poly[9];
-                if (tile0 >= q->pad1) { l_a = poly[11]; l_d = poly[12]; l_K = poly[13]; l_C = poly[14]; l_rc = poly[15]; l_rs = q->pad2; }
+                if (tile0 >= lsplit) { l_a = poly[11]; l_d = poly[12]; l_K = poly[13]; l_C = poly[14]; l_rc = poly[15]; l_rs = q->pad2; }
                 if (straddle) {
                     if (poly[7] == 0.0) lean_fm_frames<FPL, false, false>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, 0.0, 0.0, trig, sn);
                     else lean_fm_frames<FPL, true, false>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, 0.0, 0.0, trig, sn);
