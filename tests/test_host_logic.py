@@ -288,3 +288,39 @@ def test_lfo_table_reproduces_the_reference_fm_loop():
             tl += d
         assert worst <= tol, (f, rate, worst)
         assert worst_ideal > 20 * worst, (f, rate, worst_ideal, worst)
+
+
+def test_lfo_table_on_random_parameters():
+    """... and over a grid the fixed cases do not reach: four sample rates, both kinds of time step (radians / turns), LFO rates of
+    0.005 .. 400 Hz, depths to 0.9, biases of either sign, phases anywhere: relative error of the angle against the reference loop."""
+    import math
+    from synthesizer_amd.oscillators import LfoTable
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for _case in range(12):
+        sr = int(rng.choice([22050, 44100, 48000, 96000]))
+        inc = (1.0 / sr) if rng.integers(0, 2) else 2 * math.pi / sr
+        f = float(np.exp(rng.uniform(np.log(30), np.log(8000))))
+        rate = float(np.exp(rng.uniform(np.log(0.005), np.log(400))))
+        depth, bias, lph = float(rng.uniform(0.001, 0.9)), float(rng.choice([0.0, rng.uniform(-0.2, 0.2)])), float(rng.uniform(0, 1))
+        d, a = 2 * math.pi * rate / sr, lph * 2 * math.pi
+        rec = LfoTable(a, d, depth, bias, inc).records
+        n0s = rec["n0"][0::2]
+        n_max = int(rng.integers(5000, 120000))
+        marks = set(int(x) for x in rng.integers(1, n_max, 6)) | {n_max - 1}
+        T, tl, pc, fprev, feff = 0.0, a, 0.0, None, f * (1.0 + bias)
+        for n in range(n_max):
+            freq = f * (1.0 + (depth * math.sin(tl) + bias))
+            if fprev is None:
+                fprev = freq
+            pc += (fprev - freq) * T
+            fprev = freq
+            if n in marks:
+                want = T * freq + pc
+                g = int(np.searchsorted(n0s, n, side="right") - 1)
+                u, dl, Kp, Cp = float(rec["t0"][2 * g]), float(rec["dt"][2 * g]), float(rec["t0"][2 * g + 1]), float(rec["dt"][2 * g + 1])
+                got = feff * T + (feff * inc) * (Kp * (Cp - math.cos(u + ((n - int(n0s[g])) - 0.5) * dl)))
+                worst = max(worst, abs(got - want) / max(1.0, abs(want)))
+            T += inc
+            tl += d
+    assert worst <= 1e-13, worst
