@@ -324,3 +324,26 @@ def test_lfo_table_on_random_parameters():
             T += inc
             tl += d
     assert worst <= 1e-13, worst
+
+
+def test_time_step_weights_sum_to_the_accumulated_time():
+    """oscillators.time_step_weights: the runs (offset, count, w - 1) of a block cover it without gaps, and sum (w inc) over them is the
+    accumulated time's difference across the block to 1e-22 of it (rational arithmetic) -- pieces' ends and the one odd step in front of them
+    included; both kinds of time step."""
+    from fractions import Fraction
+    from synthesizer_amd.oscillators import _table, time_step_weights
+    for inc in (2 * np.pi / 48000, 1.0 / 44100):
+        tab = _table(0.0, inc)
+        ends = [int(n) for n in tab.records["n0"][1:40]]
+        for start, n in [(0, 5000), (ends[25] - 100, 300), (ends[30] - 1, 2), (ends[30], 1), (1440000, 50000), (ends[20] - 3, ends[22] - ends[20] + 7)]:
+            runs = time_step_weights(inc, start, n)
+            pos = 0
+            total = Fraction(0)
+            for off, cnt, wm1 in runs:
+                assert off == pos and cnt > 0
+                pos += cnt
+                total += cnt * (Fraction(wm1) + 1) * Fraction(inc)
+            assert pos == n
+            want = Fraction(tab.value(start + n)) - Fraction(tab.value(start))
+            # (w - 1 is a float64 of ~1e-10: its rounding is 1e-26 of the sum)
+            assert abs(total - want) <= Fraction(abs(float(want))) * Fraction(1, 10 ** 22), (inc, start, n, float(total - want))
