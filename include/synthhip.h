@@ -121,7 +121,8 @@ typedef struct sh_voice {
      * piecewise exactly linear -- the table at seg_offset); on the ideal line phase_j = lfo_a + j*lfo_d (the first piece, and all
      * there is for a library older than ABI 5):
      * L(n) = lfo_K*(lfo_C0 - cos(lfo_a + (n-0.5)*lfo_d)) + lfo_bias*n,
-     * lfo_K = lfo_amp/(2 sin(lfo_d/2)), lfo_C0 = cos(lfo_a - lfo_d/2) */
+     * lfo_K = lfo_amp/(2 sin(lfo_d/2)), lfo_C0 = cos(lfo_a - lfo_d/2).  ABI 5: lfo_bias must be 0 -- the bias rides in `frequency`
+     * (f * (1 + bias)) -- and lfo_K != 0 needs the table; sh_bank_create rejects anything else. */
     double   lfo_a, lfo_d, lfo_amp, lfo_bias, lfo_K, lfo_C0;
     sh_envelope env;
     float    gain_l, gain_r;   /* stereo bus gains (bank only) */

@@ -321,6 +321,15 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
         if (cnt == 0 || off > nsegs || cnt > nsegs - off)
             return sh::set_error(SH_ERR_INVALID, "voice %u: phase table [%u,+%u) outside %u pieces", i, off, cnt, nsegs);
         if (segs[off].n0 != 0) return sh::set_error(SH_ERR_INVALID, "voice %u: phase table does not start at sample 0", i);
+        if (v.fm_mode == SH_FM_SINE) {
+            // ABI 5: an LFO's bias rides in `frequency` (f (1 + bias): the angle's sum runs over the accumulated time), and an LFO that
+            // moves brings its table (two records per piece at seg_offset); the lean loops are instantiated for lfo_bias = 0 alone
+            if (v.lfo_bias != 0.0) return sh::set_error(SH_ERR_INVALID, "voice %u: lfo_bias must be 0 (fold it into frequency: f * (1 + bias))", i);
+            if (v.seg_count & 1u) return sh::set_error(SH_ERR_INVALID, "voice %u: an LFO table holds two records per piece (seg_count %u)", i, v.seg_count);
+            if (v.seg_count && (v.seg_offset > nsegs || v.seg_count > nsegs - v.seg_offset || segs[v.seg_offset].n0 != 0))
+                return sh::set_error(SH_ERR_INVALID, "voice %u: LFO table [%u,+%u) outside %u records or not starting at sample 0", i, v.seg_offset, v.seg_count, nsegs);
+            if (v.lfo_K != 0.0 && v.seg_count == 0) return sh::set_error(SH_ERR_INVALID, "voice %u: an LFO that moves (lfo_K != 0) needs its table", i);
+        }
         if (v.kind == SH_HARMONICS) {
             if (v.harm_dense < 0 || v.harm_dense > 2) return sh::set_error(SH_ERR_INVALID, "voice %u: harm_dense %d not in {0,1,2}", i, v.harm_dense);
             if (v.harm_dense == 2 && v.harm_count != 16) return sh::set_error(SH_ERR_INVALID, "voice %u: polynomial form needs 16 coefficients", i);

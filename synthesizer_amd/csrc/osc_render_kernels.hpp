@@ -532,12 +532,10 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
                 double l_a = poly[3], l_d = poly[4], l_K = poly[5], l_C = poly[6], l_rc = poly[8], l_rs = poly[9];
                 if (tile0 >= lsplit) { l_a = poly[11]; l_d = poly[12]; l_K = poly[13]; l_C = poly[14]; l_rc = poly[15]; l_rs = q->pad2; }
                 if (straddle) {
-                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, false>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, 0.0, 0.0, trig, sn);
-                    else lean_fm_frames<FPL, true, false>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, 0.0, 0.0, trig, sn);
+                    lean_fm_frames<FPL, false, false>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, 0.0, 0.0, trig, sn);
                 } else {
                     const double t_first = fma(di0 - off, dt, t_base), t_step = 64.0 * dt;
-                    if (poly[7] == 0.0) lean_fm_frames<FPL, false, true>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, t_first, t_step, trig, sn);
-                    else lean_fm_frames<FPL, true, true>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, t_first, t_step, trig, sn);
+                    lean_fm_frames<FPL, false, true>(poly, l_a, poly[10], l_d, l_K, l_C, l_rc, l_rs, di0, theta, t_first, t_step, trig, sn);
                 }
 #pragma unroll
                 for (int j = 0; j < FPL; ++j) {
@@ -753,8 +751,7 @@ __device__ __forceinline__ void tiles_lean(const BankPtrs& B, const TileCtx& T, 
                             // voice's own index of the tile's first frame, rs the LFO's angle there
                             double sn[FPL];
                             const double t_first = fma(lane_d, dt, t0), t_step = 64.0 * dt;
-                            if (poly[7] == 0.0) lean_fm_frames<FPL, false, true>(poly, rs, rc, lfo_d, lfo_K, lfo_C0, lrc, lrs, lane_d, none, t_first, t_step, trig, sn);
-                            else lean_fm_frames<FPL, true, true>(poly, rs, rc, lfo_d, lfo_K, lfo_C0, lrc, lrs, lane_d, none, t_first, t_step, trig, sn);
+                            lean_fm_frames<FPL, false, true>(poly, rs, rc, lfo_d, lfo_K, lfo_C0, lrc, lrs, lane_d, none, t_first, t_step, trig, sn);
                             double gl_e = GL, gr_e = GR;
                             if (ea1 == 0.0) {
                                 gl_e = GL * ea0;
