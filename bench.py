@@ -929,8 +929,11 @@ def main() -> int:
         F2 = F * 10 if nv * F * 10 * 4 <= (8 << 30) else F     # 10 s blocks: 1.97 GB of voices, far past the 256 MB L3
         vbuf = N.DeviceBuffer(nv * F2 * 4)
         bus = N.DeviceBuffer(F2 * 8)
-        gen_ms = steady(N, lambda: bank.local.generate_device(F2, Wm * F, out=vbuf), min_seconds=0.03, reps=3)
-        mix_ms = steady(N, lambda: bank.local.mix_device(vbuf, F2, bus_f32=bus), min_seconds=0.03, reps=3)
+        # (timed over 0.25 s each, with min / max, like the 16-bit mono resample row: 0.03 s x 3 launches said 0.49, 0.54 and 0.57 of HBM
+        #  for the same kernel on three occasions)
+        sp_gen, sp_mix = {}, {}
+        gen_ms = steady(N, lambda: bank.local.generate_device(F2, Wm * F, out=vbuf), min_seconds=0.25, reps=3, spread=sp_gen)
+        mix_ms = steady(N, lambda: bank.local.mix_device(vbuf, F2, bus_f32=bus), min_seconds=0.25, reps=3, spread=sp_mix)
         gen0_ms = steady(N, lambda: bank.local.generate_device(F2, 0, out=vbuf), min_seconds=0.03, reps=3)     # rows that start with the notes
         mix_bytes = (4.0 * nv + 8.0) * F2
         gen_bytes = 4.0 * nv * F2
@@ -947,10 +950,58 @@ def main() -> int:
             "roofline_generate": {"kernel": "k_generate_lean_harm<16> (+ k_prepare_segments; k_generate_lists<4, false> where a segment holds general or silent voices)", "bound": "hbm", "achieved": gen_bytes / (gen_ms / 1e3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gen_bytes / (gen_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                                   "traffic": tg["hbm_bytes"] if tg else None, "avg_launch_ms": gen_ms, "bytes_per_voice_sample": 4,
-                                  "algorithmic_bytes": gen_bytes},
+                                  "algorithmic_bytes": gen_bytes, "min_ms": sp_gen["min_ms"], "max_ms": sp_gen["max_ms"], "loops": sp_gen["loops"]},
         }
-        vbuf.free()
+        out["two_step"]["roofline_mix"].update({"min_ms": sp_mix["min_ms"], "max_ms": sp_mix["max_ms"], "loops": sp_mix["loops"]})
         bus.free()
+        # ---- the same pair in the reference's own sample format: every voice as int16 (Sample.from_osc_block's quantiser in the
+        # generate kernels' epilogue: 2 B per voice-sample reach HBM), then the mixer's saturating audioop.add chain over the rows --
+        # mono, and with every voice placed by Sample.stereo(l, r) (audioop.tostereo in registers: the stereo rows never exist) ----
+        stride16 = (F2 + 63) & ~63
+        rows16 = vbuf.view(0, nv * stride16 * 2) if nv * stride16 * 2 <= vbuf.nbytes else N.DeviceBuffer(nv * stride16 * 2)
+        mono16 = N.DeviceBuffer(F2 * 2)
+        st16 = N.DeviceBuffer(F2 * 4)
+        fac = bank.local.pan_factors_device()
+        sp_g16, sp_c16, sp_p16 = {}, {}, {}
+        g16_ms = steady(N, lambda: bank.local.generate_i16_device(F2, Wm * F, out=rows16, stride=stride16, check=False),
+                        min_seconds=0.25, reps=3, spread=sp_g16)
+        bank.local.overflow_check()
+        c16_ms = steady(N, lambda: N.check(N.lib().sh_mix_chain_i16(rows16.handle, nv, stride16, F2, mono16.handle)),
+                        min_seconds=0.25, reps=3, spread=sp_c16)
+        p16_ms = steady(N, lambda: N.check(N.lib().sh_mix_chain_pan_i16(rows16.handle, nv, stride16, F2, fac.handle, st16.handle)),
+                        min_seconds=0.25, reps=3, spread=sp_p16)
+        g16_bytes, c16_bytes, p16_bytes = 2.0 * nv * F2, (2.0 * nv + 2.0) * F2, (2.0 * nv + 4.0) * F2
+        tg16 = _by_prefix(prof["traffic"], "k_generate_lean_harm<16, short")
+        cg16 = _by_prefix(prof["counters"], "k_generate_lean_harm<16, short")
+        tc16, tp16 = _by_prefix(prof["traffic"], "k_mix_chain_direct"), _by_prefix(prof["traffic"], "k_mix_chain_pan_direct")
+
+        def hbm_roof(kernel, nbytes, ms, sp, traffic, per_unit_key, per_unit):
+            return {"kernel": kernel, "bound": "hbm", "achieved": nbytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic["hbm_bytes"] if traffic else None,
+                    "avg_launch_ms": ms, per_unit_key: per_unit, "algorithmic_bytes": nbytes,
+                    "min_ms": sp["min_ms"], "max_ms": sp["max_ms"], "loops": sp["loops"]}
+        rg16 = hbm_roof("k_generate_lean_harm<16, short> (+ k_prepare_segments; k_generate_lists<4, false, short> where a segment holds general or silent voices)",
+                        g16_bytes, g16_ms, sp_g16, tg16, "bytes_per_voice_sample", 2)
+        # the materialisation does the headline's arithmetic per voice-sample plus the quantiser: with 2 B per sample to store it is
+        # float64-VALU-bound, not HBM-bound -- the fraction of the issue peak beside the HBM figure the row is asked for
+        if cg16 and all(k in cg16 for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")):
+            ops16 = (cg16["SQ_INSTS_VALU_FMA_F64"] + cg16["SQ_INSTS_VALU_MUL_F64"] + cg16["SQ_INSTS_VALU_ADD_F64"]) * 64.0 / (nv * F2)
+            rg16["valu_f64"] = {"ops_per_voice_sample": ops16, "achieved": nv * F2 * ops16 / (g16_ms / 1e3) / 1e12, "peak": FP64_PEAK_TOPS,
+                                "unit": "T f64 lane-ops/s", "frac": nv * F2 * ops16 / (g16_ms / 1e3) / 1e12 / FP64_PEAK_TOPS,
+                                "all_valu_busy": (cg16.get("SQ_INSTS_VALU", 0) * 4.0 / 1024 / 2.4e9 / (g16_ms / 1e3)) or None}
+        out["two_step_i16"] = {
+            "frames_per_launch": F2, "voices": nv, "scale": 32767.0,
+            "value": nv * F2 / ((g16_ms + c16_ms) / 1e3) / 1e6, "unit": "Msamples/s",
+            "value_stereo": nv * F2 / ((g16_ms + p16_ms) / 1e3) / 1e6,
+            "x_float_two_step": (gen_ms + mix_ms) / (g16_ms + c16_ms),
+            "note": "the route upstream itself takes: oscillator block -> Sample.from_osc_block (int(32767 v)) -> [Sample.stereo(l, r)] -> "
+                    "the mixer's audioop.add chain in voice order; byte for byte against the oracle + live audioop in tests/test_gpu_int_mixdown.py",
+            "roofline_generate": rg16,
+            "roofline_mix": hbm_roof("k_mix_chain_direct<8,4>", c16_bytes, c16_ms, sp_c16, tc16, "bytes_per_sample", 2 * nv + 2),
+            "roofline_mix_stereo": hbm_roof("k_mix_chain_pan_direct<4,4>", p16_bytes, p16_ms, sp_p16, tp16, "bytes_per_frame", 2 * nv + 4),
+        }
+        for b_ in (mono16, st16, rows16, vbuf):       # (rows16 may be a window of vbuf: freed before it)
+            b_.free()
 
     # ---- the other BASELINE configs (rank 0, N = 1) ----
     if rank == 0 and world == 1 and not args.no_configs:

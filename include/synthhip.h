@@ -306,6 +306,23 @@ int sh_bank_render_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_b
 int sh_bank_generate_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
                           sh_buf* voices_out, size_t stride);
 
+/* The reference-shaped INTEGER route (upstream synthplayer/sample.py Sample.from_osc_block, [RECALL]: one oscillator block ->
+ * int(amplitude_scale * v) per sample through array('h'), OverflowError where a value does not fit): every voice of the bank as a
+ * row of int16 PCM, voices_out[v*stride + i] = int(scale * x_v[start + i]) -- the float64 sample, the float64 product, truncation
+ * toward zero -- made where the sample is made: 2 bytes per voice-sample reach HBM instead of a float row (4 written) that a
+ * quantise pass re-reads (4) and re-writes (2).  The rows are what sh_mix_chain_i16 / sh_mix_chain_pan_i16 fold (the mixer's
+ * audioop.add chain).  stride must be even (rows are written as 32-bit pairs).  SH_ERR_OVERFLOW when a sample of ANY voice does not
+ * fit (the rows are unspecified then); the call synchronises to learn it, like the quantisers.  _rows_: the same for a bank with
+ * modulation rows (sh_bank_set_rows). */
+int sh_bank_generate_i16(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* voices_out, size_t stride);
+/* The streaming form: enqueues the same work and returns; a sample that does not fit raises a flag on the device that stays up until
+ * sh_overflow_check() -- which waits for the stream, returns SH_ERR_OVERFLOW if any sh_bank_generate_i16_async since the last
+ * check met one, and lowers the flag -- is called: once per batch of blocks instead of a host round trip per block. */
+int sh_bank_generate_i16_async(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* voices_out, size_t stride);
+int sh_overflow_check(void);
+int sh_bank_generate_rows_i16(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
+                              double scale, sh_buf* voices_out, size_t stride);
+
 /* ---- mixer sum bus over materialised voices ------------------------------------------ */
 /* float32: bus[i] = sum_v gains[v] * voices[v*stride+i]; gains = device buffer of nvoices x (l, r) floats */
 int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32_t nframes,
@@ -313,6 +330,12 @@ int sh_mix_bus_f32(const sh_buf* voices, uint32_t nvoices, size_t stride, uint32
 /* integer: the reference mixer's fold, mixed = add(add(c0, c1), c2) ... in voice order,
  * saturating at every step (playback.py mixer loop -> audioop.add).  chunks[v*stride + i] int16. */
 int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint32_t nsamples, sh_buf* out);
+/* The same fold over MONO voice rows that enter it as Sample.stereo(left_factor, right_factor) of themselves (upstream
+ * synthplayer/sample.py Sample.stereo -> audioop.tostereo(frames, 2, lf, rf), [RECALL]): out frame i = (L, R) with
+ * L = add(add(tostereo_l(c0), tostereo_l(c1)), ...) -- per voice and channel fbound(sample * factor) (clamp, then floor), then the
+ * saturating chain in voice order.  The stereo rows are never materialised: 2 bytes are read per voice-sample, 4 written per frame.
+ * factors_lr: device buffer of nvoices x (left, right) doubles.  chunks[v*stride + i] int16 mono; out: nframes x 2 int16. */
+int sh_mix_chain_pan_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint32_t nframes, const sh_buf* factors_lr, sh_buf* out);
 /* The same fold with every chunk read where its sample lives (no staging copy): source v contributes
  * srcs[v][sample_offsets[v] .. +nsamples_each[v]) and silence after that, up to nsamples; the result goes to
  * out[out_sample_off ..).  This is one turn of the real-time mixer's chunk loop (upstream synthplayer/playback.py

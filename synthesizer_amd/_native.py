@@ -107,8 +107,13 @@ _SIGNATURES = {
     "sh_scan_rows_f64": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t, _P]),
     "sh_bank_render_rows": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t, _P, _P]),
     "sh_bank_generate_rows": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t, _P, C.c_size_t]),
+    "sh_bank_generate_i16": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_double, _P, C.c_size_t]),
+    "sh_bank_generate_i16_async": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_double, _P, C.c_size_t]),
+    "sh_overflow_check": (C.c_int, []),
+    "sh_bank_generate_rows_i16": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t, C.c_double, _P, C.c_size_t]),
     "sh_mix_bus_f32": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P, _P]),
     "sh_mix_chain_i16": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P]),
+    "sh_mix_chain_pan_i16": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P, _P]),
     "sh_mix_chain_gather_i16": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, _P, C.c_size_t]),
     "sh_mix_chain": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, C.c_int, _P]),
     "sh_mix_chain_gather": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, _P, C.c_size_t]),

@@ -328,6 +328,10 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             if (v.seg_count & 1u) return sh::set_error(SH_ERR_INVALID, "voice %u: an LFO table holds two records per piece (seg_count %u)", i, v.seg_count);
             if (v.seg_count && (v.seg_offset > nsegs || v.seg_count > nsegs - v.seg_offset || segs[v.seg_offset].n0 != 0))
                 return sh::set_error(SH_ERR_INVALID, "voice %u: LFO table [%u,+%u) outside %u records or not starting at sample 0", i, v.seg_offset, v.seg_count, nsegs);
+            // (a tile record addresses the LFO's piece by its index in `segs` packed into 24 bits, 0xFFFFFF = a constant LFO:
+            //  prepare_tiles in osc_device.hpp -- a table beyond that would be read at a truncated index, silently)
+            if (v.seg_count && (uint64_t)v.seg_offset + v.seg_count >= 0xFFFFFFull)
+                return sh::set_error(SH_ERR_INVALID, "voice %u: LFO table [%u,+%u) beyond the 2^24 - 1 records an FM voice's table may lie within (share LfoTables between voices)", i, v.seg_offset, v.seg_count);
             if (v.lfo_K != 0.0 && v.seg_count == 0) return sh::set_error(SH_ERR_INVALID, "voice %u: an LFO that moves (lfo_K != 0) needs its table", i);
         }
         if (v.kind == SH_HARMONICS) {

@@ -9,6 +9,24 @@
 
 namespace {
 
+// ---- the int16 forms (sh_bank_generate_i16): a row element is int(scale * v) of the float64 sample v -- Sample.from_osc_block's
+// quantiser (upstream synthplayer/sample.py; truncation toward zero, OverflowError where the value does not fit) applied where the
+// sample is made, so that a voice reaches HBM as 2 bytes instead of 4 (float32 row) + 4 read + 2 written by a quantise pass.
+template <typename OutT> struct RowOut;
+template <> struct RowOut<float> {
+    static constexpr bool I16 = false;
+    __device__ __forceinline__ static float make(double x, double, bool&) { return (float)x; }
+};
+template <> struct RowOut<short> {
+    static constexpr bool I16 = true;
+    __device__ __forceinline__ static short make(double x, double scale, bool& bad) {
+        const double t = trunc(scale * x);                   // float64 product, like the Python expression
+        const bool ok = t >= -32768.0 && t <= 32767.0;       // (false for NaN too)
+        bad |= !ok;
+        return ok ? (short)(int)t : (short)0;
+    }
+};
+
 // voice-major materialisation: out[v*stride + i].  grid = (groups of 4 tiles, voice groups); block = 4
 // waves on 4 consecutive tiles; each wave walks the voices of its group (so the 8 KB sin/cos table in LDS
 // is filled once per block, not once per voice) and stores one coalesced row segment per voice.
@@ -21,7 +39,8 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
                                                   const double* __restrict__ fm_cumsum,
                                                   const double* __restrict__ pwm,
                                                   float* __restrict__ out32, double* __restrict__ out64,
-                                                  size_t stride) {
+                                                  size_t stride, short* __restrict__ out16 = nullptr, double scale16 = 0.0,
+                                                  int* __restrict__ flag = nullptr) {
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
     __syncthreads();
@@ -65,6 +84,11 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
             if (raw < n) {
                 if (out32) out32[(size_t)vi * stride + raw] = (float)x[j];
                 if (out64) out64[(size_t)vi * stride + raw] = x[j];
+                if (out16) {
+                    bool bad = false;
+                    out16[(size_t)vi * stride + raw] = RowOut<short>::make(x[j], scale16, bad);
+                    if (bad) *flag = 1;
+                }
             }
         }
     }
@@ -75,11 +99,13 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
 // stored instead of accumulated), then the general list through voice_block, then zero-fills the rows of silent voices.
 // The lean arithmetic repeats the general code's order -- ((x * amplitude) + 0) * g0u.
 // LEAN = false: only the general and the silent list (the lean records went through k_generate_lean_harm).
-template <int FPL, bool LEAN>
+template <int FPL, bool LEAN, typename OutT = float>
 __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPtrs B, const shm::sc_pair* __restrict__ trig_g,
                                                                          uint32_t nvoices, LaunchSet cur, uint64_t start, uint32_t n,
-                                                                         float* __restrict__ out32, size_t stride,
-                                                                         SegTab tab = SegTab{0, {}, {}, {}}, uint32_t vsplit = 1) {
+                                                                         OutT* __restrict__ out32, size_t stride,
+                                                                         SegTab tab = SegTab{0, {}, {}, {}}, uint32_t vsplit = 1,
+                                                                         double scale = 0.0, int* __restrict__ flag = nullptr) {
+    bool bad = false;                          // (int16 rows: a sample that does not fit)
     // tab.n != 0: the unequal segments of a row's head in ONE launch -- grid.x runs over the groups of four tiles of all segments,
     // a workgroup finds its segment and from there on works relative to it (records, frames, output).  vsplit > 1: grid.y =
     // chunks x vsplit, the general and silent voices of a chunk dealt round robin to vsplit workgroups (rows are independent:
@@ -220,7 +246,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
             const uint32_t raw = tile0 + j * 64 + lane;
-            if (raw < n) out32[(size_t)vi * stride + raw] = (float)((x[j] * amp + 0.0) * g0u);
+            if (raw < n) out32[(size_t)vi * stride + raw] = RowOut<OutT>::make((x[j] * amp + 0.0) * g0u, scale, bad);
         }
     }
     const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
@@ -232,7 +258,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
             const uint32_t raw = tile0 + j * 64 + lane;
-            if (raw < n) out32[(size_t)vi * stride + raw] = (float)x[j];
+            if (raw < n) out32[(size_t)vi * stride + raw] = RowOut<OutT>::make(x[j], scale, bad);
         }
     }
     for (uint32_t p = vsub; p < nsilent; p += vsplit) {
@@ -240,9 +266,10 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
             const uint32_t raw = tile0 + j * 64 + lane;
-            if (raw < n) out32[(size_t)vi * stride + raw] = 0.0f;
+            if (raw < n) out32[(size_t)vi * stride + raw] = (OutT)0;
         }
     }
+    if (RowOut<OutT>::I16 && bad) *flag = 1;
 }
 
 // Materialisation of the lean polynomial-Harmonics records of a launch (banks whose lean candidates are all of that kind):
@@ -254,10 +281,20 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 // The sample repeats the general code's order, ((x * amplitude) + 0) * g0u, before its one rounding to float32.
 // A long row is cut into segments of seg_frames (a multiple of the tile) with a record set each (k_prepare_segments): a
 // record describes at most two phase-table pieces, and ten seconds of a high voice run through more.
-template <int FPL>
+//
+// OutT = short (sh_bank_generate_i16): the sample leaves as int(scale * v), two bytes.  A lane's frames lie 64 apart, so a lane's own
+// pair of consecutive values (frames h, h + 1 of its sixteen) are NOT neighbours in the row; lanes 2p and 2p + 1 hold the four frames
+// (2p, 2p + 1) + 64 h and (2p, 2p + 1) + 64 (h + 1).  They swap one packed pair (a DPP quad_perm within the register file, no LDS), a
+// v_perm_b32 with a per-lane selector picks the two int16 that are neighbours in memory, and every lane stores ONE 32-bit word: the
+// even lanes write the 128 bytes of frames [64 h, 64 h + 64), the odd lanes the 128 bytes behind them -- 256 contiguous bytes per
+// store instruction, as in the float32 form, for two frames per lane instead of one.  Per pair of samples: two products, two
+// conversions, the range check (min3 / max3), pack, swap, select -- against the 42 float64 operations that made the two samples.
+template <int FPL, typename OutT = float>
 __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
                                                                uint32_t total, uint32_t seg_frames,
-                                                               float* __restrict__ out32_all, size_t stride, SegTab tab, uint32_t rec_split) {
+                                                               OutT* __restrict__ out32_all, size_t stride, SegTab tab, uint32_t rec_split,
+                                                               double scale = 0.0, int* __restrict__ flag = nullptr) {
+    constexpr bool I16 = RowOut<OutT>::I16;
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
     __syncthreads();
@@ -286,7 +323,7 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
         tile0 = abs0 - seg_first;
     }
     const LaunchSet cur = segment_set(base, seg, nvoices);
-    float* __restrict__ out32 = out32_all + seg_first;
+    OutT* __restrict__ out32 = out32_all + seg_first;
     uint32_t tile_last = tile0 + 64 * FPL - 1;
     if (tile_last > n - 1) tile_last = n - 1;
     // (rec_split workgroups share a chunk's records: a wave that walks all 64 of them over 1024 frames lives a third of the launch --
@@ -297,7 +334,23 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
     const FastRec SH_CONST_AS* q = as_const(cur.fast) + c * 64 + p_lo;
     const uint32_t i0 = tile0 + lane;
     const double di0 = (double)i0;
-    float* __restrict__ col = out32 + i0;                      // + vi * stride per record (uniform), + 64 * j per frame
+    OutT* __restrict__ col = out32 + i0;                       // + vi * stride per record (uniform), + 64 * j per frame
+    // (int16 rows) the lane's word of a pair of frames: 32-bit index 64 (h / 2) + 32 (lane & 1) + (lane >> 1) from the tile's first frame
+    const uint32_t pair_word = ((lane & 1u) << 5) + (lane >> 1);
+    const uint32_t pair_sel = (lane & 1u) ? 0x07060302u : 0x01000504u;      // v_perm_b32(own, neighbour's): odd lanes (n.hi, own.hi), even (own.lo, n.lo)
+    int mx = 0, mn = 0;                                         // the largest / smallest integer any sample of this wave became
+    auto store_pair = [&](OutT* row_tile, int m, double v0, double v1) {     // frames 2m, 2m + 1 of the lane's FPL (a full tile: all lanes active)
+        if constexpr (I16) {
+            const int a = (int)(scale * v0), b = (int)(scale * v1);          // float64 product, truncation toward zero
+            mx = max(mx, max(a, b));
+            mn = min(mn, min(a, b));
+            typedef short short2p __attribute__((ext_vector_type(2)));
+            union { short2p v; uint32_t u; } w;
+            w.v = __builtin_amdgcn_cvt_pk_i16(a, b);
+            const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)w.u, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+            __builtin_nontemporal_store((int)__builtin_amdgcn_perm(w.u, nb, pair_sel), reinterpret_cast<int*>(row_tile) + 64 * m + pair_word);
+        }
+    };
     for (uint32_t p = p_lo; p < nfast; ++p, ++q) {
         const uint32_t remain = q->remain, vi = q->vi;
         const double amp = q->amplitude, g0u = q->g0u;
@@ -327,7 +380,8 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
             c1 = fma(c0, rc, -(s0 * rs));
         }
         const double k2 = rc + rc;
-        float* __restrict__ row = col + (size_t)vi * stride;
+        OutT* __restrict__ row = col + (size_t)vi * stride;
+        OutT* __restrict__ row_tile = row - lane;                  // (the tile's first frame in this record's row: 4-byte aligned, stride is even)
         // amplitude and (constant) envelope gain scale the sine ONCE: the recurrence is linear, so every later frame's sine
         // arrives scaled and the sample is one product, p * s (differs from the general code's ((x * amplitude) + 0) * g0u
         // by float64 rounding only)
@@ -345,8 +399,16 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
                     p1 = fma(p1, c1, poly[u]);
                 }
                 // streaming stores: the rows are not read again by this kernel (1.97 GB per launch of the benchmark shape)
-                if (FULL || i0 + (uint32_t)h * 64u < n) __builtin_nontemporal_store((float)(p0 * s0), row + h * 64);
-                if (FULL || i0 + (uint32_t)(h + 1) * 64u < n) __builtin_nontemporal_store((float)(p1 * s1), row + (h + 1) * 64);
+                if constexpr (!I16) {
+                    if (FULL || i0 + (uint32_t)h * 64u < n) __builtin_nontemporal_store((float)(p0 * s0), row + h * 64);
+                    if (FULL || i0 + (uint32_t)(h + 1) * 64u < n) __builtin_nontemporal_store((float)(p1 * s1), row + (h + 1) * 64);
+                } else if constexpr (FULL) {
+                    store_pair(row_tile, h / 2, p0 * s0, p1 * s1);
+                } else {                                           // the last tile of a row: frame by frame, two bytes each
+                    const int a = (int)(scale * (p0 * s0)), b = (int)(scale * (p1 * s1));
+                    if (i0 + (uint32_t)h * 64u < n) { row[h * 64] = (short)a; mx = max(mx, a); mn = min(mn, a); }
+                    if (i0 + (uint32_t)(h + 1) * 64u < n) { row[(h + 1) * 64] = (short)b; mx = max(mx, b); mn = min(mn, b); }
+                }
                 if (h + 2 < FPL) {
                     if (straddle) {
                         shm::sincos_tab(theta(h + 2), trig, s0, c0);
@@ -387,13 +449,19 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) pv[jj] = fma(pv[jj], cv[jj], poly[u]);
                 }
+                if constexpr (I16) {
+                    store_pair(row_tile, h / 2, pv[0] * sv[0], pv[1] * sv[1]);
+                    store_pair(row_tile, h / 2 + 1, pv[2] * sv[2], pv[3] * sv[3]);
+                } else {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) __builtin_nontemporal_store((float)(pv[jj] * sv[jj]), row + (h + jj) * 64);
+                    for (int jj = 0; jj < 4; ++jj) __builtin_nontemporal_store((float)(pv[jj] * sv[jj]), row + (h + jj) * 64);
+                }
             }
             continue;
         }
         if (tile0 + 64 * FPL <= n) frames(std::true_type()); else frames(std::false_type());
     }
+    if (I16 && (mx > 32767 || mn < -32768)) *flag = 1;
 }
 
 // (Measured and dropped in round 3: the same materialisation walked ROW by row -- one record per workgroup held in SGPRs, contiguous runs
@@ -438,19 +506,16 @@ int sh_osc_render(sh_bank* bank, uint32_t voice, const sh_buf* fm_cumsum, const 
     return SH_OK;
 }
 
-int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voices_out, size_t stride) {
-    SH_REQUIRE_INIT();
-    if (!b || !voices_out) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: NULL argument");
-    if (nframes == 0) return SH_OK;
-    if (nframes > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: at most 2^32 - 65536 frames per call");
-    if (stride < nframes) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: stride < nframes");
-    if (voices_out->bytes / 4 < (size_t)(b->nvoices - 1) * stride + nframes)
-        return sh::set_error(SH_ERR_INVALID, "sh_bank_generate: output buffer too small");
-    int rc = bank_check_plain(b, "sh_bank_generate");
-    if (rc) return rc;
+}  // extern "C"
+
+namespace {
+
+// every voice of the bank as a row of OutT (float: the sample rounded to float32; short: int(scale * sample), *flag set where one does not fit)
+template <typename OutT>
+int generate_rows(sh_bank* b, uint64_t start, uint32_t nframes, OutT* o, size_t stride, double scale, int* flag) {
+    int rc;
     // frames per lane: 4 for long rows (one sin/cos lookup + three rotations per voice, as in k_bank_render), else 2 / 1
     const int fpl = nframes >= 8192 ? 4 : (nframes >= 2048 ? 2 : 1);
-    float* o = (float*)voices_out->ptr;
     const bool with_rows = b->launch_rows != nullptr;             // sh_bank_generate_rows: every voice through the general kernel, which reads the rows
     if (!with_rows && fpl == 4 && b->lean_candidates != 0 && b->lean_fm_candidates == 0) {
         // Long rows, every lean candidate a polynomial Harmonics voice: the lean records by the recurrence kernel at sixteen frames
@@ -464,9 +529,9 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
         // workgroups per chunk of records: enough waves for several rounds of the chip's wave slots (1, 4, 8 measured: CHANGELOG item 38)
         const uint32_t rsplit = 2;
 #define SH_GEN_LEAN(GRID_, ...) do { \
-            if (LF == 16) hipLaunchKernelGGL(k_generate_lean_harm<16>, GRID_, dim3(256), 0, st, __VA_ARGS__); \
-            else if (LF == 8) hipLaunchKernelGGL(k_generate_lean_harm<8>, GRID_, dim3(256), 0, st, __VA_ARGS__); \
-            else hipLaunchKernelGGL(k_generate_lean_harm<4>, GRID_, dim3(256), 0, st, __VA_ARGS__); } while (0)
+            if (LF == 16) hipLaunchKernelGGL((k_generate_lean_harm<16, OutT>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); \
+            else if (LF == 8) hipLaunchKernelGGL((k_generate_lean_harm<8, OutT>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); \
+            else hipLaunchKernelGGL((k_generate_lean_harm<4, OutT>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); } while (0)
         constexpr uint32_t SEG = 65536;                      // frames per segment (a multiple of the 1024-frame tile)
         hipStream_t st = sh::state().stream;
         const uint32_t nchunks = sh::div_up(b->nvoices, 64);
@@ -504,13 +569,12 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
                 SH_CHECK_LAUNCH("k_generate_lean_harm");
                 constexpr uint32_t VSPLIT = 8;
                 if (ltab.n) {
-                    hipLaunchKernelGGL((k_generate_lists<4, false>), dim3(list_groups, nchunks * VSPLIT), dim3(256), 0, st,
-                                       ptrs(b), trig_table(), b->nvoices, base, start, head, o, stride, ltab, VSPLIT);
+                    hipLaunchKernelGGL((k_generate_lists<4, false, OutT>), dim3(list_groups, nchunks * VSPLIT), dim3(256), 0, st,
+                                       ptrs(b), trig_table(), b->nvoices, base, start, head, o, stride, ltab, VSPLIT, scale, flag);
                     SH_CHECK_LAUNCH("k_generate_lists");
                 }
                 if (head == nframes) return SH_OK;
-                sh_buf rest{(char*)voices_out->ptr + (size_t)head * 4, voices_out->bytes - (size_t)head * 4, false, 0};
-                return sh_bank_generate(b, start + head, nframes - head, &rest, stride);
+                return generate_rows<OutT>(b, start + head, nframes - head, o + head, stride, scale, flag);
             }
         }
         const uint32_t nseg = sh::div_up(nframes, SEG);
@@ -541,8 +605,10 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
                 cur.launch += (size_t)sg * stride; cur.fm += (size_t)sg * stride; cur.fast += (size_t)sg * stride;
                 cur.gen_idx += (size_t)sg * stride; cur.counts += (size_t)sg * 4 * nchunks;
             }
-            hipLaunchKernelGGL((k_generate_lists<4, false>), dim3(sh::div_up(n, 1024), nchunks), dim3(256), 0, st,
-                               ptrs(b), trig_table(), b->nvoices, cur, start + first, n, o + first, stride);
+            SegTab no_tab;
+            no_tab.n = 0;
+            hipLaunchKernelGGL((k_generate_lists<4, false, OutT>), dim3(sh::div_up(n, 1024), nchunks), dim3(256), 0, st,
+                               ptrs(b), trig_table(), b->nvoices, cur, start + first, n, o + first, stride, no_tab, 1u, scale, flag);
             SH_CHECK_LAUNCH("k_generate_lists");
         }
         return SH_OK;
@@ -555,17 +621,70 @@ int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voice
     while (vpg < 64 && (uint64_t)tile_groups * ((b->nvoices + 2 * vpg - 1) / (2 * vpg)) >= 4096) vpg *= 2;
     while ((b->nvoices + vpg - 1) / vpg > 65535) vpg *= 2;
     const uint32_t groups = (b->nvoices + vpg - 1) / vpg;
+    float* o32 = nullptr;
+    short* o16 = nullptr;
+    if constexpr (RowOut<OutT>::I16) o16 = o; else o32 = o;
 #define SH_GEN(F_) hipLaunchKernelGGL(k_generate<F_>, dim3(tile_groups, groups), dim3(256), 0, sh::state().stream,            \
                                       ptrs(b), trig_table(), 0u, b->nvoices, vpg, b->d_launch, b->d_launch_fm, start, nframes, \
-                                      (const double*)nullptr, (const double*)nullptr, o, (double*)nullptr, stride)
+                                      (const double*)nullptr, (const double*)nullptr, o32, (double*)nullptr, stride, o16, scale, flag)
     if (!with_rows && fpl == 4 && b->lean_candidates != 0) {
         // long rows of a bank with lean candidates: one workgroup column per 64-voice chunk, walking the launch's lists
-        hipLaunchKernelGGL((k_generate_lists<4, true>), dim3(tile_groups, sh::div_up(b->nvoices, 64)), dim3(256), 0, sh::state().stream,
-                           ptrs(b), trig_table(), b->nvoices, launch_set(b, b->cur), start, nframes, o, stride);
+        SegTab no_tab;
+        no_tab.n = 0;
+        hipLaunchKernelGGL((k_generate_lists<4, true, OutT>), dim3(tile_groups, sh::div_up(b->nvoices, 64)), dim3(256), 0, sh::state().stream,
+                           ptrs(b), trig_table(), b->nvoices, launch_set(b, b->cur), start, nframes, o, stride, no_tab, 1u, scale, flag);
     } else if (fpl == 4) SH_GEN(4); else if (fpl == 2) SH_GEN(2); else SH_GEN(1);
 #undef SH_GEN
     SH_CHECK_LAUNCH("k_generate");
     return SH_OK;
+}
+
+int generate_check(const char* who, sh_bank* b, uint32_t nframes, const sh_buf* voices_out, size_t stride, size_t elem) {
+    if (!b || !voices_out) return sh::set_error(SH_ERR_INVALID, "%s: NULL argument", who);
+    if (nframes > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "%s: at most 2^32 - 65536 frames per call", who);
+    if (stride < nframes) return sh::set_error(SH_ERR_INVALID, "%s: stride < nframes", who);
+    if (nframes && voices_out->bytes / elem < (size_t)(b->nvoices - 1) * stride + nframes)
+        return sh::set_error(SH_ERR_INVALID, "%s: output buffer too small", who);
+    return bank_check_plain(b, who);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sh_bank_generate(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* voices_out, size_t stride) {
+    SH_REQUIRE_INIT();
+    int rc = generate_check("sh_bank_generate", b, nframes, voices_out, stride, 4);
+    if (rc || nframes == 0) return rc;
+    return generate_rows<float>(b, start, nframes, (float*)voices_out->ptr, stride, 0.0, nullptr);
+}
+
+int sh_bank_generate_i16_async(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* voices_out, size_t stride) {
+    SH_REQUIRE_INIT();
+    int rc = generate_check("sh_bank_generate_i16", b, nframes, voices_out, stride, 2);
+    if (rc || nframes == 0) return rc;
+    if ((stride & 1u) || ((uintptr_t)voices_out->ptr & 3u))
+        return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_i16: stride must be even (rows are written as 32-bit pairs of samples)");
+    return generate_rows<short>(b, start, nframes, (short*)voices_out->ptr, stride, scale, sh::state().flag + 1);     // (word 0: the quantisers of pcm.hip)
+}
+
+int sh_overflow_check(void) {
+    SH_REQUIRE_INIT();
+    sh::State& st = sh::state();
+    SH_HIP(hipMemcpyAsync(st.flag_host + 1, st.flag + 1, sizeof(int), hipMemcpyDeviceToHost, st.stream));
+    SH_HIP(hipStreamSynchronize(st.stream));
+    if (st.flag_host[1]) {
+        SH_HIP(hipMemsetAsync(st.flag + 1, 0, sizeof(int), st.stream));
+        return sh::set_error(SH_ERR_OVERFLOW, "signed integer out of range for sample width 2");
+    }
+    return SH_OK;
+}
+
+int sh_bank_generate_i16(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* voices_out, size_t stride) {
+    SH_API_LOCK();
+    const int rc = sh_bank_generate_i16_async(b, start, nframes, scale, voices_out, stride);
+    if (rc || nframes == 0) return rc;
+    return sh_overflow_check();
 }
 
 int sh_bank_generate_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
@@ -579,6 +698,22 @@ int sh_bank_generate_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh
     b->launch_rows = (const double*)rows_f64->ptr;
     b->launch_row_stride = row_stride;
     const int rc = sh_bank_generate(b, start, nframes, voices_out, stride);
+    b->launch_rows = nullptr;
+    b->launch_row_stride = 0;
+    return rc;
+}
+
+int sh_bank_generate_rows_i16(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
+                              double scale, sh_buf* voices_out, size_t stride) {
+    if (!b || !rows_f64) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_rows_i16: NULL argument");
+    SH_API_LOCK();
+    if (!b->d_fm_row) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_rows_i16: sh_bank_set_rows has not been called");
+    if (row_stride < nframes) return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_rows_i16: row_stride < nframes");
+    if (b->fm_row_max >= 0 && rows_f64->bytes / 8 < (size_t)b->fm_row_max * row_stride + nframes)
+        return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_rows_i16: rows buffer too small for row %d", b->fm_row_max);
+    b->launch_rows = (const double*)rows_f64->ptr;
+    b->launch_row_stride = row_stride;
+    const int rc = sh_bank_generate_i16(b, start, nframes, scale, voices_out, stride);
     b->launch_rows = nullptr;
     b->launch_row_stride = 0;
     return rc;

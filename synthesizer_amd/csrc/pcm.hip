@@ -9,6 +9,8 @@
 #include "common.hpp"
 #include <new>
 
+#define SH_PCM_CONST __attribute__((address_space(4)))
+
 namespace {
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -157,11 +159,37 @@ struct ChainFold {
     __device__ __forceinline__ int hi(int j) const { return any ? (int)U[j >> 1][j & 1] : CH_BIG; }
 };
 
+// PAN forms of the two chain kernels below (sh_mix_chain_pan_i16): the rows are MONO voices and every voice enters the fold as
+// Sample.stereo(lf, rf) of itself -- audioop.tostereo: (fbound(v * lf), fbound(v * rf)) per frame, fbound = clamp to the sample
+// range, then floor -- made in registers from the 8 bytes of four mono frames; the fold is the same chain over the eight
+// stereo samples.  For every finite product fbound(p) == clamp(floor(p), -32768, 32767) (the "val < minval + 1 -> minval" branch
+// selects values whose floor is minval anyway), so a frame costs: one int -> float64 conversion, two products, two floors, two
+// conversions (saturating at the int32 range) and ONE v_cvt_pk_i16_i32, whose saturation is the clamp and whose packed result is
+// the interleaved (L, R) pair.  The factors of a voice are wave-uniform: scalar loads.
+typedef short short4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ short8v pan4(const short4v m, const double lf, const double rf) {
+    union { short8v v; short2v p[4]; } r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double x = (double)m[j];
+        r.p[j] = __builtin_amdgcn_cvt_pk_i16((int)floor(x * lf), (int)floor(x * rf));
+    }
+    return r.v;
+}
+template <bool NT>
+__device__ __forceinline__ short8v load_row8(const short* __restrict__ chunks, size_t v, size_t stride, uint32_t s0, const double2* __restrict__ pan) {
+    if (pan) {                                           // (uniform) s0 = the first of eight STEREO samples: four mono frames from s0 / 2
+        const double2 f = pan[v];
+        return pan4(sh::load_vec<NT, short4v>(chunks + v * stride + (s0 >> 1)), f.x, f.y);
+    }
+    return sh::load_vec<NT, short8v>(chunks + v * stride + s0);
+}
+
 // WAVES waves = (WAVES / COLS) voice ranges x COLS adjacent 1 KB columns: a workgroup visits COLS KB of a row at a time.
 template <int WAVES, int COLS, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __restrict__ chunks, uint32_t nvoices,
                                                               size_t stride, uint32_t nsamples,
-                                                              short* __restrict__ out) {
+                                                              short* __restrict__ out, const double2* __restrict__ pan = nullptr) {
     constexpr int S = 8;                                  // samples per lane: one 16-byte load per voice row
     constexpr int VG = WAVES / COLS;
     __shared__ int red[WAVES][3][S][64];
@@ -175,26 +203,35 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __res
     if (v1 > nvoices) v1 = nvoices;
     ChainFold f;
     f.init();
-    const bool vec = (s0 + S - 1 < nsamples) && ((stride & (S - 1)) == 0);
+    const bool vec = (s0 + S - 1 < nsamples) && ((stride & (pan ? 3 : S - 1)) == 0);
     if (s0 < nsamples && v0 < v1) {
         if (vec) {
             uint32_t v = v0;
-            f.first(sh::load_vec<NT, short8v>(chunks + (size_t)v * stride + s0));
+            f.first(load_row8<NT>(chunks, v, stride, s0, pan));
             ++v;
             for (; v + 3 < v1; v += 4) {                  // four voice rows in flight
-                const short8v x0 = sh::load_vec<NT, short8v>(chunks + (size_t)v * stride + s0);
-                const short8v x1 = sh::load_vec<NT, short8v>(chunks + (size_t)(v + 1) * stride + s0);
-                const short8v x2 = sh::load_vec<NT, short8v>(chunks + (size_t)(v + 2) * stride + s0);
-                const short8v x3 = sh::load_vec<NT, short8v>(chunks + (size_t)(v + 3) * stride + s0);
+                const short8v x0 = load_row8<NT>(chunks, v, stride, s0, pan);
+                const short8v x1 = load_row8<NT>(chunks, v + 1, stride, s0, pan);
+                const short8v x2 = load_row8<NT>(chunks, v + 2, stride, s0, pan);
+                const short8v x3 = load_row8<NT>(chunks, v + 3, stride, s0, pan);
                 f.add(x0); f.add(x1); f.add(x2); f.add(x3);
             }
-            for (; v < v1; ++v) f.add(sh::load_vec<NT, short8v>(chunks + (size_t)v * stride + s0));
+            for (; v < v1; ++v) f.add(load_row8<NT>(chunks, v, stride, s0, pan));
         } else {
             for (uint32_t v = v0; v < v1; ++v) {
-                const short* row = chunks + (size_t)v * stride + s0;
                 short8v x;
+                if (pan) {
+                    const short* row = chunks + (size_t)v * stride + (s0 >> 1);
+                    short4v m;
 #pragma unroll
-                for (int j = 0; j < S; ++j) x[j] = (s0 + j < nsamples) ? row[j] : (short)0;
+                    for (int j = 0; j < 4; ++j) m[j] = (s0 + 2 * j < nsamples) ? row[j] : (short)0;
+                    const double2 fac = pan[v];
+                    x = pan4(m, fac.x, fac.y);
+                } else {
+                    const short* row = chunks + (size_t)v * stride + s0;
+#pragma unroll
+                    for (int j = 0; j < S; ++j) x[j] = (s0 + j < nsamples) ? row[j] : (short)0;
+                }
                 if (v == v0) f.first(x); else f.add(x);
             }
         }
@@ -232,7 +269,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_i16(const short* __res
 template <int WAVES, int INFLIGHT, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_direct(const short* __restrict__ chunks, uint32_t nvoices, size_t stride,
                                                                  uint32_t nsamples, short* __restrict__ out) {
-    const uint32_t s0 = (blockIdx.x * (WAVES * 64) + threadIdx.x) * 8;
+    const uint32_t s0 = (uint32_t)(sh::block_id() * (WAVES * 64) + threadIdx.x) * 8;
     if (s0 >= nsamples) return;
     const short* col = chunks + s0;
     if (s0 + 8 <= nsamples) {
@@ -252,6 +289,57 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_direct(const short* __
             short acc = col[j];
             for (uint32_t v = 1; v < nvoices; ++v) acc = __builtin_elementwise_add_sat(acc, col[(size_t)v * stride + j]);
             out[s0 + j] = acc;
+        }
+    }
+}
+
+// The direct loop over MONO rows that enter the chain as Sample.stereo(lf, rf) of themselves (see pan4): a lane owns eight frames --
+// one 16-byte load per row, sixteen stereo samples in two packed accumulators, two 16-byte stores.
+template <int WAVES, int INFLIGHT, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_pan_direct(const short* __restrict__ chunks, uint32_t nvoices, size_t stride,
+                                                                     uint32_t nframes, const double2* __restrict__ pan, short* __restrict__ out) {
+    const uint32_t f0 = (uint32_t)(sh::block_id() * (WAVES * 64) + threadIdx.x) * 8;
+    if (f0 >= nframes) return;
+    const short* col = chunks + f0;
+    const double SH_PCM_CONST* fac = (const double SH_PCM_CONST*)pan;     // (lf, rf) per voice: wave-uniform, scalar loads
+    if (f0 + 8 <= nframes) {
+        short8v a0, a1;
+        {
+            const short8v x = *reinterpret_cast<const short8v*>(col);
+            const double lf = fac[0], rf = fac[1];
+            a0 = pan4(__builtin_shufflevector(x, x, 0, 1, 2, 3), lf, rf);
+            a1 = pan4(__builtin_shufflevector(x, x, 4, 5, 6, 7), lf, rf);
+        }
+        uint32_t v = 1;
+        for (; v + INFLIGHT <= nvoices; v += INFLIGHT) {
+            short8v x[INFLIGHT];
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) x[k] = sh::load_vec<NT, short8v>(col + (size_t)(v + k) * stride);
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) {
+                const double lf = fac[2 * (v + k)], rf = fac[2 * (v + k) + 1];
+                a0 = __builtin_elementwise_add_sat(a0, pan4(__builtin_shufflevector(x[k], x[k], 0, 1, 2, 3), lf, rf));
+                a1 = __builtin_elementwise_add_sat(a1, pan4(__builtin_shufflevector(x[k], x[k], 4, 5, 6, 7), lf, rf));
+            }
+        }
+        for (; v < nvoices; ++v) {
+            const short8v x = *reinterpret_cast<const short8v*>(col + (size_t)v * stride);
+            const double lf = fac[2 * v], rf = fac[2 * v + 1];
+            a0 = __builtin_elementwise_add_sat(a0, pan4(__builtin_shufflevector(x, x, 0, 1, 2, 3), lf, rf));
+            a1 = __builtin_elementwise_add_sat(a1, pan4(__builtin_shufflevector(x, x, 4, 5, 6, 7), lf, rf));
+        }
+        __builtin_nontemporal_store(a0, reinterpret_cast<short8v*>(out + 2 * (size_t)f0));
+        __builtin_nontemporal_store(a1, reinterpret_cast<short8v*>(out + 2 * (size_t)f0 + 8));
+    } else {
+        for (uint32_t j = 0; f0 + j < nframes; ++j) {
+            short2v acc = {0, 0};
+            for (uint32_t v = 0; v < nvoices; ++v) {
+                const double x = (double)col[(size_t)v * stride + j];
+                const short2v p = __builtin_amdgcn_cvt_pk_i16((int)floor(x * fac[2 * v]), (int)floor(x * fac[2 * v + 1]));
+                acc = v == 0 ? p : __builtin_elementwise_add_sat(acc, p);
+            }
+            out[2 * (size_t)(f0 + j)] = acc[0];
+            out[2 * (size_t)(f0 + j) + 1] = acc[1];
         }
     }
 }
@@ -1038,6 +1126,35 @@ int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint
     else SH_CHAIN(8, 1);
 #undef SH_CHAIN
     SH_CHECK_LAUNCH("k_mix_chain_i16");
+    return SH_OK;
+}
+
+int sh_mix_chain_pan_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint32_t nframes, const sh_buf* factors_lr, sh_buf* out) {
+    SH_REQUIRE_INIT();
+    if (!chunks || !out || !factors_lr || nvoices == 0) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_pan_i16: NULL argument");
+    if (nvoices > 32768) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_pan_i16: at most 32768 voices");
+    if (nframes > 0x7FFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_pan_i16: at most 2^31 - 65536 frames per call");
+    if (!nframes) return SH_OK;
+    if (stride < nframes || chunks->bytes / 2 < (size_t)(nvoices - 1) * stride + nframes)
+        return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_pan_i16: chunk buffer too small");
+    if (factors_lr->bytes / 16 < nvoices) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_pan_i16: one (left, right) pair of doubles per voice");
+    if (out->bytes / 4 < nframes) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_pan_i16: output too small");
+    hipStream_t st = sh::state().stream;
+    const short* in = (const short*)chunks->ptr;
+    const double2* fac = (const double2*)factors_lr->ptr;
+    const uint32_t nsamples = 2 * nframes;
+    const uint32_t columns = (uint32_t)sh::div_up(nframes, 512);                      // 1 KB of a mono row
+    const bool aligned = (stride & 7) == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out->ptr & 15) == 0 && ((uintptr_t)fac & 15) == 0;
+    const bool stream = (size_t)nvoices * nframes * 2 > sh::STREAM_BYTES;
+    if (columns >= 1536 && aligned) {
+        if (stream) hipLaunchKernelGGL((k_mix_chain_pan_direct<4, 4, true>), sh::grid1d(nframes, 256 * 8), dim3(256), 0, st, in, nvoices, stride, nframes, fac, (short*)out->ptr);
+        else hipLaunchKernelGGL((k_mix_chain_pan_direct<4, 4, false>), sh::grid1d(nframes, 256 * 8), dim3(256), 0, st, in, nvoices, stride, nframes, fac, (short*)out->ptr);
+    } else if (nvoices < 64) {
+        hipLaunchKernelGGL((k_mix_chain_i16<2, 1, false>), sh::grid1d(nsamples, 512), dim3(128), 0, st, in, nvoices, stride, nsamples, (short*)out->ptr, fac);
+    } else {
+        hipLaunchKernelGGL((k_mix_chain_i16<8, 1, false>), sh::grid1d(nsamples, 512), dim3(512), 0, st, in, nvoices, stride, nsamples, (short*)out->ptr, fac);
+    }
+    SH_CHECK_LAUNCH("k_mix_chain_pan");
     return SH_OK;
 }
 

@@ -41,12 +41,11 @@ void load_knobs() {
 }
 
 int bind_thread_to_device() {
-    thread_local int bound = -1;
+    // (asked of the runtime every time, not remembered: another HIP user on this host thread -- a library, the caller's own
+    //  hipSetDevice -- may have moved the thread's current device between two calls of ours; hipGetDevice is a thread-local read)
     const int want = state().device;
-    if (bound != want) {
-        SH_HIP(hipSetDevice(want));
-        bound = want;
-    }
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != want) SH_HIP(hipSetDevice(want));
     return SH_OK;
 }
 

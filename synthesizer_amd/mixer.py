@@ -205,6 +205,7 @@ class VoiceBank:
                 gc.enable()
         self._bank = N.Bank(*self._packed)
         self._gains_dev: Optional[N.DeviceBuffer] = None
+        self._pan_dev: Optional[N.DeviceBuffer] = None
         self._rows: Optional[_RowMatrix] = None
         if fm_src or other_src:
             fm_row = np.full(self.nvoices, -1, dtype=np.int32)
@@ -286,6 +287,73 @@ class VoiceBank:
         buf = self.generate_device(nframes, start)
         out = buf.download(np.float32, self.nvoices * nframes).reshape(self.nvoices, nframes)
         buf.free()
+        return out
+
+    # -- two-step, integer: the route upstream itself takes (oscillator block -> Sample.from_osc_block -> mixer) ---------------
+    def generate_i16_device(self, nframes: int, start: int = 0, scale: float = 32767.0, out: Optional[N.DeviceBuffer] = None,
+                            stride: Optional[int] = None, check: bool = True) -> Tuple[N.DeviceBuffer, int]:
+        """Every voice as int16 PCM in HBM, voice-major: out[v*stride + i] = int(scale * sample) -- ``Sample.from_osc_block`` of
+        every voice's block in one launch (OverflowError where a sample does not fit).  Returns (buffer, stride); the stride is
+        ``nframes`` rounded up to a multiple of 64 unless given (it must be even).  ``check=False`` (a stream of blocks): the
+        call only enqueues; ``VoiceBank.overflow_check()`` raises for every block since the last check at once."""
+        stride = (nframes + 63) & ~63 if stride is None else stride
+        if out is None:
+            out = N.DeviceBuffer(max(self.nvoices * stride * 2, 4))
+        if nframes == 0:
+            return out, stride
+        if self._rows is not None:
+            rows, rstride = self._rows.fill(start, nframes)
+            N.check(N.lib().sh_bank_generate_rows_i16(self._bank.handle, start, nframes, rows.handle, rstride, float(scale), out.handle, stride))
+        else:
+            fn = N.lib().sh_bank_generate_i16 if check else N.lib().sh_bank_generate_i16_async
+            N.check(fn(self._bank.handle, start, nframes, float(scale), out.handle, stride))
+        return out, stride
+
+    @staticmethod
+    def overflow_check() -> None:
+        """OverflowError if a ``generate_i16_device(..., check=False)`` since the last check met a sample that does not fit."""
+        N.check(N.lib().sh_overflow_check())
+
+    def voice_samples(self, nframes: int, start: int = 0, scale: float = 32767.0) -> List[Sample]:
+        """The voices as mono int16 Samples (views of one matrix in HBM): ``[Sample.from_osc_block(voice block) ...]``."""
+        buf, stride = self.generate_i16_device(nframes, start, scale)
+        out = []
+        for v in range(self.nvoices):
+            s = Sample(samplerate=self.samplerate, nchannels=1, samplewidth=2)
+            if nframes:
+                s._set_device(buf.view(v * stride * 2, nframes * 2), nframes * 2)
+                s._share_device()                              # (a window of the shared matrix: never written in place)
+            out.append(s)
+        return out
+
+    def mixdown_i16_device(self, nframes: int, start: int = 0, scale: float = 32767.0,
+                           out: Optional[N.DeviceBuffer] = None) -> N.DeviceBuffer:
+        """The mono mixdown the reference's mixer makes of the voices: every voice quantised (``from_osc_block``), then
+        ``mixed = audioop.add(mixed, voice, 2)`` down the voices in order.  nframes int16 samples."""
+        rows, stride = self.generate_i16_device(nframes, start, scale)
+        if out is None:
+            out = N.DeviceBuffer(max(nframes * 2, 4))
+        if nframes:
+            N.check(N.lib().sh_mix_chain_i16(rows.handle, self.nvoices, stride, nframes, out.handle))
+        rows.free()
+        return out
+
+    def pan_factors_device(self) -> N.DeviceBuffer:
+        if self._pan_dev is None:
+            self._pan_dev = N.DeviceBuffer.from_array(np.asarray(self.gains, dtype=np.float64).reshape(-1))
+        return self._pan_dev
+
+    def mixdown_stereo_i16_device(self, nframes: int, start: int = 0, scale: float = 32767.0,
+                                  out: Optional[N.DeviceBuffer] = None) -> N.DeviceBuffer:
+        """The stereo mixdown the reference's mixer makes: every voice quantised (``from_osc_block``), placed with
+        ``Sample.stereo(left, right)`` (``audioop.tostereo`` with the voice's gains as factors), then the saturating
+        ``audioop.add`` chain in voice order.  nframes x 2 int16, interleaved."""
+        rows, stride = self.generate_i16_device(nframes, start, scale)
+        if out is None:
+            out = N.DeviceBuffer(max(nframes * 4, 4))
+        if nframes:
+            N.check(N.lib().sh_mix_chain_pan_i16(rows.handle, self.nvoices, stride, nframes, self.pan_factors_device().handle, out.handle))
+        rows.free()
         return out
 
     def gains_device(self) -> N.DeviceBuffer:
@@ -412,7 +480,9 @@ class RealTimeMixer:
             N.check(N.lib().sh_buf_copy(buf.handle, loop, buf.handle, 0, self.chunksize))
             source = _MixSource(sample.name, buf, loop, loop, chunk_delay)
         else:
-            source = _MixSource(sample.name, sample._device(), nbytes, 0, chunk_delay)     # Sample never writes a buffer in place
+            # the Sample's own buffer, read in place: _share_device() tells the Sample never to write it in place from now on
+            # (Sample.mix adds in place when nothing grows -- it would change, and race with, the audio being streamed)
+            source = _MixSource(sample.name, sample._share_device(), nbytes, 0, chunk_delay)
         with self.add_lock:
             self.sample_counter += 1
             sid = sid or self.sample_counter

@@ -559,7 +559,9 @@ class _Carrier(Oscillator):
             lfo = self.fm
             if lfo is None:
                 out.update(fm_mode=N.SH_FM_SINE, lfo=(0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
-            elif _closed_form_lfo(lfo):
+            elif _closed_form_lfo(lfo) and abs(1.0 + float(lfo.bias)) >= 2.0 ** -10:
+                # (a bias at or next to -1 leaves nothing to fold it into -- the closed form carries f (1 + bias) as its frequency and
+                # divides the sine part by it: such an LFO takes the buffer path below, which needs no division)
                 a = lfo._phase * 2.0 * pi
                 d = 2.0 * pi * lfo.frequency / lfo.samplerate
                 half = sin(d / 2.0)

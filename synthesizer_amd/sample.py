@@ -55,6 +55,7 @@ class Sample:
         self.__samplewidth = samplewidth or params.norm_samplewidth
         self.__frames: Optional[bytes] = b""
         self.__dev: Optional[N.DeviceBuffer] = None
+        self.__dev_shared = False      # somebody else (a playing mixer source) reads __dev: never write it in place
         self.__nbytes = 0
         self.filename = None
         if wave_file:
@@ -66,12 +67,22 @@ class Sample:
     def _set_host(self, frames: bytes) -> None:
         self.__frames = bytes(frames)
         self.__dev = None
+        self.__dev_shared = False
         self.__nbytes = len(self.__frames)
 
     def _set_device(self, buf: N.DeviceBuffer, nbytes: int) -> None:
+        if buf is not self.__dev:
+            self.__dev_shared = False  # a fresh buffer is this Sample's own again
         self.__frames = None
         self.__dev = buf
         self.__nbytes = nbytes
+
+    def _share_device(self) -> N.DeviceBuffer:
+        """The device buffer, handed to a reader that keeps it (RealTimeMixer.add_sample streams from it): from now on every
+        operation of this Sample writes a buffer of its own -- the in-place form of mix / mix_at is off until the data moves."""
+        buf = self._device()
+        self.__dev_shared = True
+        return buf
 
     def _host(self) -> bytes:
         if self.__frames is None:
@@ -522,11 +533,13 @@ class Sample:
         """self[start:start+n2] = sat_add(self[start:start+n2] (zero-extended), other[:n2]); length -> total."""
         L = N.lib()
         n1 = self.__nbytes
-        if total == n1 and n1 and self._device().nbytes >= n1:
+        aliased = other is self and start != 0              # overlapping source and destination at shifted offsets inside one kernel
+        if total == n1 and n1 and self._device().nbytes >= n1 and not self.__dev_shared and not aliased:
             # nothing grows (the mixer's common case: equal lengths, or mix_at inside the sample): add in place -- the kernel is
             # elementwise and declared without __restrict__ for exactly this -- 3 bytes moved per output byte instead of 5 (allocate,
             # copy self, add).  A Sample's device buffer is its own (copy() copies), so nobody else sees the write; a lock()ed
-            # sample never gets here (_check_writable).
+            # sample never gets here (_check_writable); one that a mixer streams from (_share_device) and a mix_at of the sample
+            # into itself at an offset take the copying form below.
             if n2:
                 N.check(L.sh_pcm_add(self.__dev.handle, start, other._device().handle, 0, n2, self.__samplewidth, self.__dev.handle, start))
             self._set_device(self.__dev, n1)            # (drops the host copy: it is stale now)

@@ -27,6 +27,22 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t c) {
 #define ALIGNBIT(j) asm volatile("v_alignbit_b32 %0, %1, %2, %2" : "=v"(u[j]) : "v"(u[j]), "v"(c));
 #define ADD_U32(j) asm volatile("v_add_u32 %0, %1, %2" : "=v"(u[j]) : "v"(u[j]), "v"(c));
 #define XOR3(j) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(u[j]) : "v"(u[j]), "v"(c));
+// (round 5: what the int16 materialisation's epilogue and the pan chain are made of)
+#define FLOOR_F64(j) asm volatile("v_floor_f64 %0, %1" : "=v"(d[j]) : "v"(d[j]));
+#define TRUNC_F64(j) asm volatile("v_trunc_f64 %0, %1" : "=v"(d[j]) : "v"(d[j]));
+#define CVT_I32_F64(j) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(u[j]) : "v"(d[j]));
+#define CVT_F64_I32(j) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(d[j]) : "v"(u[j]));
+#define MUL_F64(j) asm volatile("v_mul_f64 %0, %1, %1" : "=v"(d[j]) : "v"(d[j]));
+#define ADD_F64(j) asm volatile("v_add_f64 %0, %1, %1" : "=v"(d[j]) : "v"(d[j]));
+#define MAX_F64(j) asm volatile("v_max_f64 %0, %1, %1" : "=v"(d[j]) : "v"(d[j]));
+#define CVT_PK(j) asm volatile("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(u[j]) : "v"(u[j]), "v"(c));
+#define PK_ADD(j) asm volatile("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(u[j]) : "v"(u[j]), "v"(c));
+#define PERM(j) asm volatile("v_perm_b32 %0, %1, %2, %2" : "=v"(u[j]) : "v"(u[j]), "v"(c));
+#define DPP(j) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(u[j]) : "v"(u[j]));
+#define MAX3(j) asm volatile("v_max3_i32 %0, %1, %2, %2" : "=v"(u[j]) : "v"(u[j]), "v"(c));
+#define BFE(j) asm volatile("v_bfe_i32 %0, %1, 0, 16" : "=v"(u[j]) : "v"(u[j]));
+#define CMP_CND(j) asm volatile("v_cmp_lt_f64 vcc, %1, %1\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(u[j]) : "v"(d[j]), "v"(c) : "vcc");
+#define DOT2(j) asm volatile("v_dot2_i32_i16 %0, %1, %2, %1" : "=v"(u[j]) : "v"(u[j]), "v"(c));
         if (MODE == 0) { REP8(CVT_F64_U32) }
         else if (MODE == 1) { REP8(CVT_U32_F64) }
         else if (MODE == 2) { REP8(CVT_F32_U32) }
@@ -40,6 +56,21 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t c) {
         else if (MODE == 10) { REP8(ALIGNBIT) }
         else if (MODE == 11) { REP8(ADD_U32) }
         else if (MODE == 12) { REP8(XOR3) }
+        else if (MODE == 13) { REP8(FLOOR_F64) }
+        else if (MODE == 14) { REP8(TRUNC_F64) }
+        else if (MODE == 15) { REP8(CVT_I32_F64) }
+        else if (MODE == 16) { REP8(CVT_F64_I32) }
+        else if (MODE == 17) { REP8(MUL_F64) }
+        else if (MODE == 18) { REP8(ADD_F64) }
+        else if (MODE == 19) { REP8(MAX_F64) }
+        else if (MODE == 20) { REP8(CVT_PK) }
+        else if (MODE == 21) { REP8(PK_ADD) }
+        else if (MODE == 22) { REP8(PERM) }
+        else if (MODE == 23) { REP8(DPP) }
+        else if (MODE == 24) { REP8(MAX3) }
+        else if (MODE == 25) { REP8(BFE) }
+        else if (MODE == 26) { REP8(CMP_CND) }
+        else if (MODE == 27) { REP8(DOT2) }
     }
     uint32_t s = 0;
     for (int j = 0; j < 8; ++j) s += u[j] + (uint32_t)d[j] + (uint32_t)f[j];
@@ -81,5 +112,20 @@ int main() {
     run<10>("v_alignbit_b32", blocks, it);
     run<11>("v_add_u32", blocks, it);
     run<12>("v_xor_b32", blocks, it);
+    run<13>("v_floor_f64", blocks, it);
+    run<14>("v_trunc_f64", blocks, it);
+    run<15>("v_cvt_i32_f64", blocks, it);
+    run<16>("v_cvt_f64_i32", blocks, it);
+    run<17>("v_mul_f64", blocks, it);
+    run<18>("v_add_f64", blocks, it);
+    run<19>("v_max_f64", blocks, it);
+    run<20>("v_cvt_pk_i16_i32", blocks, it);
+    run<21>("v_pk_add_i16", blocks, it);
+    run<22>("v_perm_b32", blocks, it);
+    run<23>("v_mov_b32_dpp", blocks, it);
+    run<24>("v_max3_i32", blocks, it);
+    run<25>("v_bfe_i32", blocks, it);
+    run<26>("v_cmp_f64+cndmask", blocks, it);
+    run<27>("v_dot2_i32_i16", blocks, it);
     return 0;
 }
