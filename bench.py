@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1.  Started by a launcher (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) this process IS a
+rank; started plainly with --gpus N > 1 it becomes the launcher: it starts N copies of itself, one per GPU ordinal, with that
+environment, and rank 0 prints the one JSON line.  Either way the ranks talk through synthesizer_amd.dist.Rendezvous (a TCP star
+next to MASTER_PORT for data, a page of /dev/shm for the barriers that bracket the timed passes): no torch anywhere.
+
 Workload (BASELINE.json metric): 1024 additive voices PER GPU -- each a
 Harmonics oscillator with 16 partials a_k = 1/k under an ADSR envelope, f log-uniform in [55, 3520] Hz,
 random phase/pan, seed 0 -- mixed to one float32 stereo bus at 48 kHz.  One step = one block of 48 000
@@ -54,16 +59,103 @@ FP64_PEAK_TOPS = 256 * 4 * 16 * 2.4 / 1e3   # float64 VALU issue peak: 256 CU x 
 ADSR_BENCH = {"sustain": 1.0e6}             # attack 0.01, decay 0.05, release 0.2 as SURVEY 8(d); the sustain spans any run
 
 
-def gloo_broadcast(payload, rank: int, world: int, nbytes: int) -> bytes:
-    """The rendezvous channel bench.py hands to synthesizer_amd.dist.init under torchrun: 128 opaque bytes from rank 0
-    over the (gloo) process group that the launcher plumbing already has.  torch never enters the product package."""
-    import torch
-    import torch.distributed as td
-    t = torch.zeros(nbytes, dtype=torch.uint8)
-    if rank == 0:
-        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
-    td.broadcast(t, src=0)
-    return bytes(t.numpy().tobytes())
+def launch_ranks(argv, n: int, dry: bool = False) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks -- this file again, rank r on GPU ordinal r
+    (synthesizer_amd.dist.rank_env: RANK = LOCAL_RANK = r, WORLD_SIZE = N, MASTER_ADDR 127.0.0.1, a free MASTER_PORT) -- and wait for
+    them.  stdout / stderr are inherited: rank 0's JSON line is this process's output.  The first rank that fails takes the others
+    with it (exactly the processes started here); the exit status is that rank's."""
+    import subprocess
+    from synthesizer_amd import dist
+    port = dist.free_port()
+    procs = []
+    for r in range(n):
+        env = dist.rank_env(r, n, port)
+        env["SYNTHHIP_BENCH_LAUNCHED"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc, alive = 0, list(procs)
+    try:
+        while alive:
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print("bench.py: rank %d exited with status %d; stopping the other ranks" % (procs.index(p), code), file=sys.stderr)
+                    for q in alive:
+                        q.terminate()
+            time.sleep(0.02)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+class _DryNative:
+    """SYNTHHIP_BENCH_DRY_RUN=1 (tests/test_bench_launch.py, no GPU): what main() needs of synthesizer_amd._native to walk the launch /
+    rendezvous / device check / timed passes / gather plumbing of an N-rank run on CPU.  Renders nothing; the line it leads to says
+    "data": "dry-run" and is no measurement."""
+
+    class _Lib:
+        @staticmethod
+        def sh_version():
+            return b"dry-run (no GPU)"
+
+    def __init__(self):
+        self._dev = 0
+        self._t0 = 0.0
+
+    def ensure_init(self, device=0):
+        self._dev = int(device)
+
+    def device_info(self):
+        return {"name": "dry-run", "arch": "none", "device": self._dev}
+
+    def device_pci(self):
+        if os.environ.get("SYNTHHIP_BENCH_DRY_SAME_PCI") == "1":      # (the test of the device check: two ranks on ONE GPU must not pass)
+            return "dry0:00:00.0"
+        return "dry0:%02x:00.0" % self._dev
+
+    def lib(self):
+        return self._Lib
+
+    def sync(self):
+        pass
+
+    def timer_start(self):
+        self._t0 = time.perf_counter()
+
+    def timer_stop(self):
+        return (time.perf_counter() - self._t0) * 1e3
+
+
+class _DryBackend:
+    """DistVoiceBank's device side for the dry run: buffers are labels, a render is a 20-us pause, a reduce is nothing."""
+
+    def nslots(self):
+        return 4
+
+    def alloc(self, nbytes):
+        return ("buf", nbytes)
+
+    def view(self, buf, offset, nbytes):
+        return ("view", offset, nbytes)
+
+    def render(self, nframes, start, bus_f32, bus_f64):
+        t = time.perf_counter() + 20e-6
+        while time.perf_counter() < t:
+            pass
+
+    def wait_slot(self, slot):
+        pass
+
+    def reduce_async(self, bus_f64, nvalues, root, bus_f32, slot):
+        pass
+
+    def sync(self):
+        pass
 
 
 def build_voices(n_total: int):
@@ -550,7 +642,7 @@ def config4_rows(N, K):
             dist.shutdown()
         except Exception:
             pass
-    out["note"] = "the 8-GPU run itself: python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 [--scaling strong]"
+    out["note"] = "the 8-GPU run itself: python bench.py --gpus 8 [--scaling strong] (or the same under torch.distributed.run / any launcher that sets RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*)"
     return out
 
 
@@ -648,37 +740,47 @@ def main() -> int:
     ap.add_argument("--reduce-batch", type=int, default=8, help="blocks per RCCL reduce when --gpus > 1 (also the length of a run of pipelined renders)")
     args = ap.parse_args()
 
+    dry = os.environ.get("SYNTHHIP_BENCH_DRY_RUN") == "1"
+    if dry:
+        args.no_two_step = args.no_configs = args.no_pcm_rows = True
+        args.cpu_frames = 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes one (the ranks are copies of this command with the launcher's environment)
+        if not dry:
+            from synthesizer_amd import _native as N0
+            seen = N0.lib().sh_device_count()            # (0 without a GPU; never fails)
+            if seen < args.gpus:
+                print("bench.py: --gpus %d, but this node shows %d GPU%s" % (args.gpus, seen, "" if seen == 1 else "s"), file=sys.stderr)
+                return 3
+        return launch_ranks(sys.argv[1:], args.gpus, dry)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs one process per GPU (torch.distributed.run)" % args.gpus, file=sys.stderr)
-            return 2
-    td = None
+        print("bench.py: --gpus %d but WORLD_SIZE is %d (one process per GPU: start it plainly, or under a launcher with "
+              "--nproc-per-node %d)" % (args.gpus, world, args.gpus), file=sys.stderr)
+        return 2
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as td      # plumbing only: barrier + max over ranks + id broadcast
-        td.init_process_group("gloo", rank=rank, world_size=world)
 
-    from synthesizer_amd import _native as N
     from synthesizer_amd import build as B
     from synthesizer_amd import dist
+    if dry:
+        N = _DryNative()
+    else:
+        from synthesizer_amd import _native as N
+    # the ranks' control channel: data over a TCP star beside MASTER_PORT, barriers through a page of shared memory
+    rdzv = dist.Rendezvous(rank, world)
     N.ensure_init(dist.device_for_rank())          # the GPU ordinal = LOCAL_RANK (one process per GPU)
     info = N.device_info()
-    if world > 1:
+    if world > 1 and not dry:
         with _stdout_to_stderr():          # (librccl prints a version banner on stdout at communicator creation: not beside the JSON line)
-            dist.init(rank, world, broadcast=gloo_broadcast)
+            dist.init(rank, world, broadcast=rdzv.as_broadcast())
     # what RCCL itself saw (ncclCommCount / ncclCommUserRank), read back BEFORE anything is timed: a line that claims N GPUs must
     # come from a communicator of N ranks, each on a GPU of its own
-    rccl = dist.comm_info()
+    rccl = dist.comm_info() if not dry else {"communicator": world > 1, "world": world, "rank": rank, "version": "dry-run", "librccl_loaded": False}
     me = {"rank": rank, "local_rank": local_rank, "device": info["device"], "pci": N.device_pci(), "rccl_rank": rccl["rank"], "rccl_world": rccl["world"]}
-    if world > 1:
-        gathered_me = [None] * world
-        td.all_gather_object(gathered_me, me)
-    else:
-        gathered_me = [me]
+    gathered_me = rdzv.gather(me)
     bad = (rccl["world"] != world or rccl["rank"] != rank or info["device"] != dist.device_for_rank()
            or len({g["pci"] for g in gathered_me}) != world)
     if bad:
@@ -695,21 +797,15 @@ def main() -> int:
         return 0
     total_voices = STRONG_VOICES if args.scaling == "strong" else VOICES_PER_GPU * world
     voices, gains = build_voices(total_voices)
-    bank = dist.DistVoiceBank(voices, gains, rank, world, batch=args.reduce_batch)
+    bank = dist.DistVoiceBank(voices, gains, rank, world, batch=args.reduce_batch, backend=_DryBackend() if dry else None)
     local_voices = bank.hi - bank.lo
     L = N.lib()
 
     def barrier():
         N.sync()
-        if td is not None:
-            td.barrier()
+        rdzv.barrier()
 
-    def allmax(*vals):
-        if td is None:
-            return vals
-        t = torch.tensor(list(vals), dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        return tuple(float(x) for x in t)
+    allmax = rdzv.allmax
 
     # ---- fused path (headline) ----
     for s in range(Wm):
@@ -739,7 +835,7 @@ def main() -> int:
     # self-check: the last block of the last timed pass (left in the bank's bus buffer by the pipelined run) against a fresh
     # single render of the same block (records by a prepare kernel, fold by k_bus_combine: none of the run's machinery)
     verified = None
-    if world == 1:
+    if world == 1 and not dry:
         import numpy as np
         last = (step0 - 1) * F
         got = bank._bus32[0].download(np.float32, F * 2)
@@ -789,7 +885,7 @@ def main() -> int:
         "metric": "Msamples/sec mixed to stereo bus, 1024-voice additive @48kHz",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic" if not dry else "dry-run (no GPU: launch / rendezvous / timing plumbing only -- not a measurement)",
         "config": {"workload": "%d-voice additive (Harmonics x%d partials + ADSR) -> float32 stereo bus, 48 kHz, "
                                "fused generate-and-mix, block %d frames" % (total_voices, PARTIALS, F),
                    "voices_total": total_voices, "voices_this_rank": local_voices, "frames_per_step": F, "samplerate": SR,
@@ -852,7 +948,7 @@ def main() -> int:
     }
 
     # ---- multi-GPU: what each rank spends on rendering and what the exchange adds ----
-    if world > 1:
+    if world > 1 and not dry:
         ring = [N.DeviceBuffer(F * 16) for _ in range(4)]
         pos = [step0]
 
@@ -869,9 +965,7 @@ def main() -> int:
             N.check(L.sh_dist_reduce_bus(msg.handle, nval, 0))
         reduce_ms = N.timer_stop() / 20
         barrier()
-        t = torch.tensor([render_ms, reduce_ms], dtype=torch.float64)
-        gathered = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
-        td.all_gather(gathered, t)
+        gathered = rdzv.gather([float(render_ms), float(reduce_ms)])
         out["per_rank"] = {"render_us_per_step": [float(g[0]) * 1e3 for g in gathered],
                            "blocking_reduce_us_per_call": [float(g[1]) * 1e3 for g in gathered],
                            "reduce_message_bytes": nval * 8, "blocks_per_reduce": bank.batch,
@@ -1015,12 +1109,17 @@ def main() -> int:
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_frames, all_cores=not args.no_cpu_all_cores)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-    if out["rccl"]["version"] is None:
+    if out["rccl"]["version"] is None and not dry:
         out["rccl"]["version"] = dist.comm_info()["version"]     # (N = 1: librccl.so is only loaded by the configs[3] row's 1-rank ring)
+    out["launcher"] = ("bench.py itself (python bench.py --gpus %d)" % world) if os.environ.get("SYNTHHIP_BENCH_LAUNCHED") == "1" else \
+                      ("an external launcher (RANK / WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "none (one process)")
+    out["control_channel"] = {"data": "TCP star beside MASTER_PORT" if world > 1 else None,
+                              "barrier": ("shared memory (/dev/shm), spin" if rdzv._slots is not None else "TCP") if world > 1 else None}
     if world > 1:
         barrier()
-        dist.shutdown()
-        td.destroy_process_group()
+        if not dry:
+            dist.shutdown()
+    rdzv.close()
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)          # C stdio of the loaded libraries (RCCL's banner) goes out first
