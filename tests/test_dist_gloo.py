@@ -38,10 +38,13 @@ def _worker(rank, world, port, nvoices, nframes, q):
     part = np.array(O.mix_bus([v.take(nframes) for v in voices[lo:hi]], gains[lo:hi]), dtype=np.float64)
     t = torch.from_numpy(part.copy())
     td.reduce(t, dst=0, op=td.ReduceOp.SUM)            # float64 partial buses summed to rank 0
-    # the rendezvous used for the RCCL unique id: 128 opaque bytes broadcast from rank 0 (bench.py's callable)
-    sys.path.insert(0, str(ROOT))
-    import bench
-    ident = bench.gloo_broadcast(bytes(range(128)) if rank == 0 else None, rank, world, 128)
+    # the rendezvous used for the RCCL unique id: 128 opaque bytes broadcast from rank 0 (the channel bench.py hands to dist.init:
+    # synthesizer_amd.dist.Rendezvous, the TCP star beside MASTER_PORT -- gloo's own store sits ON MASTER_PORT)
+    from synthesizer_amd.dist import Rendezvous
+    rdzv = Rendezvous(rank, world)
+    ident = rdzv.as_broadcast()(bytes(range(128)) if rank == 0 else None, rank, world, 128)
+    rdzv.barrier()
+    rdzv.close()
     td.barrier()
     if rank == 0:
         q.put((t.numpy().copy(), ident, (lo, hi)))
