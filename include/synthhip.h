@@ -287,6 +287,17 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
  * the run with a quantise kernel after every block.  The same rule about reading the buffer applies. */
 int sh_bank_render_pcm(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* pcm_i16);
 
+/* A run of blocks per call: blocks k = 0 .. nblocks - 1 of nframes frames each, block k = frames [start + k nframes, +nframes),
+ * into bus_f32[k % nring] (float32 stereo) and / or pcm_i16[k % nring] (saturated int16 stereo, as sh_bank_render_pcm) -- what a
+ * caller streaming blocks through a ring of buffers does with one sh_bank_render per block, with ONE crossing of the ABI, one
+ * acquisition of the library's lock, and ONE LAUNCH for every stretch of blocks whose ring buffers lie back to back in memory
+ * (windows of one allocation, sh_buf_view): a launch costs the host 2-4 us whatever it renders, and a small bank's one-second block
+ * costs the device less (BASELINE config 2: 64 voices).  Blocks of a merged stretch are one render of the whole stretch: the same
+ * samples as block-by-block renders up to the float64 summation order of the voice groups (a longer launch may use fewer groups).
+ * Either ring may be NULL (not both).  The rule about reading the buffers is sh_bank_render's. */
+int sh_bank_render_run(sh_bank* b, uint64_t start, uint32_t nframes, uint32_t nblocks, sh_buf* const* bus_f32, sh_buf* const* pcm_i16,
+                       uint32_t nring, double pcm_scale);
+
 /* ---- banks whose voices are modulated by arbitrary oscillators (fm_lfo= / pwm_lfo= any Oscillator, upstream oscillators.py)
  *      or ARE arbitrary oscillator graphs (filters): the modulators / sources are rendered as float64 rows of one matrix
  *      [row][row_stride] (launch-relative: element i = frame start + i) and the bank's general code reads them.

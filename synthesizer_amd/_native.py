@@ -102,6 +102,7 @@ _SIGNATURES = {
     "sh_bank_generate": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t]),
     "sh_bank_render": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, _P]),
     "sh_bank_render_pcm": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_double, _P]),
+    "sh_bank_render_run": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(_P), C.c_uint32, C.c_double]),
     "sh_bank_set_rows": (C.c_int, [_P, _P, _P]),
     "sh_bank_generate_f64": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t, C.c_size_t]),
     "sh_scan_rows_f64": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t, _P]),

@@ -240,6 +240,20 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 #pragma unroll
                 for (int j = 0; j < FPL; ++j) pv[j] = fma(pv[j], cs[j], poly[u]);
             }
+            if (RowOut<OutT>::I16 && kind == LEAN_SINE) {
+                // Where int16 parity hangs on ONE ulp: a Sine whose frequency divides the sample rate has samples on its peaks; the
+                // reference's accumulated t lies some delta (1e-13 early in a note, 1e-6 minutes in) beside pi/2 + 2 pi k there and
+                // math.sin returns the correctly rounded 1 - delta^2 / 2: exactly 1.0 while delta <= 1.05e-8, an ulp or two less just
+                // beyond.  With amplitude x scale an integer -- the oscillators' default amplitude 1.0 at scale 32767 -- the sample lies
+                // ON a truncation boundary: 32767 if the sine is 1.0, 32766 if it is 1 - 2^-53.  A sine rotated from its neighbour is an
+                // ulp off either way about half the time.  But the cosine beside it IS delta (to 1e-16 absolute, 1e-8 of itself), so
+                // next to a peak the sine is taken from it: +-fma(-c / 2, c, 1), ONE rounding of 1 - c^2 / 2 (c^4 / 8 < 5e-22 inside
+                // |c| < 2^-17; beyond, the sample is 1e-6 of a step away from the boundary and an ulp cannot carry it across).
+                // (The table lookup of a lane's first frame, and of every frame of the per-oscillator path, does the same by
+                // construction: its node at pi/2 is (1, 6e-17) and the residual enters as 1 - r^2 / 2.)
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) sn[j] = fabs(cs[j]) < 0x1p-17 ? copysign(fma(-0.5 * cs[j], cs[j], 1.0), sn[j]) : sn[j];
+            }
 #pragma unroll
             for (int j = 0; j < FPL; ++j) x[j] = kind == LEAN_SINE ? sn[j] : pv[j] * sn[j];
         }

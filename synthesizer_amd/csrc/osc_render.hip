@@ -369,6 +369,11 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     // two FMAs of trigonometry (one table lookup per eight frames)
     if (var == 0) var = b->nvoices >= 128 ? (2 * b->lean_candidates >= b->nvoices ? (nframes >= 16384 ? 484 : 444) : 844)
                                           : (b->nvoices >= 64 ? 821 : (b->nvoices >= 8 ? 421 : 211));
+    // a LONG launch of a small, mostly lean bank (a run of blocks in one launch: sh_bank_render_run; a whole piece rendered at once) is
+    // throughput work, not a latency problem: 64 voices x 480 000 frames at two frames per lane are 3750 workgroups of eight waves that
+    // each pay a table lookup per two frames -- at eight frames per lane the recurrences carry six of them (46.7 -> us per run of ten
+    // one-second blocks of BASELINE config 2)
+    if (K.variant == 0 && b->nvoices < 128 && b->nvoices >= 16 && nframes >= (1u << 18) && 2 * b->lean_candidates >= b->nvoices) var = 484;
     // A bank whose notes do not move in lock-step takes the tile-classified launch (below) at EVERY block length: in real-time
     // chunks (256 .. 4096 frames) the general code walked the whole table for every tile -- a table of 22 528 notes, ~780 of them
     // sounding: 60 .. 85 us per chunk where the arithmetic is 2 us.  The lean tiles kernel has one shape (four waves, 512-frame
@@ -637,6 +642,39 @@ int sh_bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus_f32
 int sh_bank_render_pcm(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* pcm_i16) {
     if (!pcm_i16) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_pcm: NULL PCM buffer");
     return bank_render_any(b, start, nframes, nullptr, nullptr, pcm_i16, scale);
+}
+
+int sh_bank_render_run(sh_bank* b, uint64_t start, uint32_t nframes, uint32_t nblocks, sh_buf* const* bus_f32, sh_buf* const* pcm_i16,
+                       uint32_t nring, double pcm_scale) {
+    if (!b || (!bus_f32 && !pcm_i16) || nring == 0) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_run: NULL argument");
+    if (nframes == 0 || nblocks == 0) return SH_OK;
+    for (uint32_t k = 0; k < nring && k < nblocks; ++k) {
+        if (bus_f32 && (!bus_f32[k] || bus_f32[k]->bytes < (size_t)nframes * 8)) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_run: bus_f32[%u] missing or too small", k);
+        if (pcm_i16 && (!pcm_i16[k] || pcm_i16[k]->bytes < (size_t)nframes * 4)) return sh::set_error(SH_ERR_INVALID, "sh_bank_render_run: pcm_i16[%u] missing or too small", k);
+    }
+    SH_API_LOCK();                                            // one acquisition for the whole run
+    // Blocks whose buffers lie back to back in memory (windows of one allocation: the usual shape of a ring) are ONE launch: a
+    // launch costs the host 2-4 us whatever it renders, a small bank's block less than that on the device.  At most
+    // RUN_MAX_FRAMES per launch, and never across the ring's wrap (slot nring - 1 is followed by slot 0 somewhere else).
+    constexpr uint64_t RUN_MAX_FRAMES = 1u << 20;
+    int rc = SH_OK;
+    uint32_t k = 0;
+    while (k < nblocks && !rc) {
+        const uint32_t slot = k % nring;
+        uint32_t m = 1;
+        while (k + m < nblocks && slot + m < nring && (uint64_t)(m + 1) * nframes <= RUN_MAX_FRAMES) {
+            const bool adj32 = !bus_f32 || (char*)bus_f32[slot + m]->ptr == (char*)bus_f32[slot]->ptr + (size_t)m * nframes * 8;
+            const bool adj16 = !pcm_i16 || (char*)pcm_i16[slot + m]->ptr == (char*)pcm_i16[slot]->ptr + (size_t)m * nframes * 4;
+            if (!adj32 || !adj16) break;
+            ++m;
+        }
+        sh_buf v32{nullptr, 0, false, 0}, v16{nullptr, 0, false, 0};
+        if (bus_f32) { v32.ptr = bus_f32[slot]->ptr; v32.bytes = (size_t)m * nframes * 8; }
+        if (pcm_i16) { v16.ptr = pcm_i16[slot]->ptr; v16.bytes = (size_t)m * nframes * 4; }
+        rc = bank_render_any(b, start + (uint64_t)k * nframes, m * nframes, bus_f32 ? &v32 : nullptr, nullptr, pcm_i16 ? &v16 : nullptr, pcm_scale);
+        k += m;
+    }
+    return rc;
 }
 
 int sh_bank_render_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,

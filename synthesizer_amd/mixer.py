@@ -235,6 +235,33 @@ class VoiceBank:
                                        bus_f64.handle if bus_f64 is not None else None))
         return bus_f32 if bus_f32 is not None else bus_f64
 
+    def render_run(self, nframes: int, nblocks: int, start: int = 0, ring: Optional[Sequence[N.DeviceBuffer]] = None,
+                   pcm_ring: Optional[Sequence[N.DeviceBuffer]] = None, scale: float = 32767.0) -> Sequence[N.DeviceBuffer]:
+        """``nblocks`` consecutive blocks of ``nframes`` frames in ONE call: block k goes to ``ring[k % len(ring)]`` (float32 stereo)
+        and / or ``pcm_ring[k % len(pcm_ring)]`` (saturated int16 stereo).  Ring buffers that are consecutive windows of one
+        allocation (``VoiceBank.make_ring``) are filled by one launch per stretch: a run of blocks of a small bank costs one
+        launch, not one per block.  Without a ring: a fresh contiguous one of ``nblocks`` float32 buffers.  Returns the ring."""
+        if self._rows is not None:
+            raise NotImplementedError("render_run: a bank with modulation rows renders block by block (render_device)")
+        if ring is None and pcm_ring is None:
+            ring = self.make_ring(nframes, nblocks)
+        n32 = len(ring) if ring is not None else 0
+        n16 = len(pcm_ring) if pcm_ring is not None else 0
+        if n32 and n16 and n32 != n16:
+            raise ValueError("the float32 and the PCM ring must have the same number of slots")
+        nring = n32 or n16
+        a32 = (C.c_void_p * nring)(*[b.handle for b in ring]) if n32 else None
+        a16 = (C.c_void_p * nring)(*[b.handle for b in pcm_ring]) if n16 else None
+        N.check(N.lib().sh_bank_render_run(self._bank.handle, start, nframes, nblocks, a32, a16, nring, float(scale)))
+        return ring if ring is not None else pcm_ring
+
+    @staticmethod
+    def make_ring(nframes: int, nslots: int, bytes_per_frame: int = 8) -> Sequence[N.DeviceBuffer]:
+        """``nslots`` bus buffers of ``nframes`` frames that are consecutive windows of ONE allocation (8 bytes per frame: float32
+        stereo; 4: int16 stereo PCM): ``render_run`` fills neighbouring slots with one launch."""
+        whole = N.DeviceBuffer(nslots * nframes * bytes_per_frame)
+        return [whole.view(k * nframes * bytes_per_frame, nframes * bytes_per_frame) for k in range(nslots)]
+
     def render(self, nframes: int, start: int = 0) -> np.ndarray:
         """Stereo bus as a [nframes, 2] float32 array."""
         if nframes == 0:

@@ -739,6 +739,10 @@ class Harmonics(_Carrier):
     def _make_spec(self) -> VoiceSpec:
         # (the three forms of a harmonic list depend on the list alone: a table of notes shares a handful of lists among thousands
         # of voices)
+        if type(self) in (Harmonics, SquareH) and len(self.harmonics) == 1 and tuple(self.harmonics[0]) == (1, 1.0):
+            # one partial, k = 1, a = 1.0: the reference's sum is 0 + sin(t * 1) * 1.0 -- a Sine, bit for bit; as a Sine record it takes
+            # the exact treatment of the peaks (tests/test_gpu_int_mixdown.py::test_sine_peaks_on_rational_frequencies)
+            return VoiceSpec(kind=N.SH_SINE, amplitude=float(self.amplitude), bias=float(self.bias), **self._phase_fields())
         poly, dense, sparse = _harmonic_forms(tuple(map(tuple, self.harmonics)))
         return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias),
                          harm_poly=poly, harm_dense=dense, harm_sparse=sparse, **self._phase_fields())

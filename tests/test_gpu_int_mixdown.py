@@ -179,7 +179,7 @@ def test_generate_i16_overflow_odd_lengths_and_windows(gpu):
     from synthesizer_amd.sample import Sample
     harm = [(k, 1.0 / k) for k in range(1, 17)]
     voices = [G.Harmonics(220.0 * (1 + 0.37 * i), harm, amplitude=0.4, phase=0.1 * i, samplerate=SR) for i in range(70)]
-    voices += [G.Sine(330.0, 0.37, samplerate=SR), G.Square(100.0, 0.25, samplerate=SR), G.Sawtooth(441.0, 0.3, bias=0.1, samplerate=SR),
+    voices += [G.Sine(330.0, 0.3713, samplerate=SR), G.Square(100.0, 0.25, samplerate=SR), G.Sawtooth(441.0, 0.3, bias=0.1, samplerate=SR),
                G.Sine(500.0, 0.4, fm_lfo=G.Sine(3.0, 0.2, samplerate=SR), samplerate=SR),
                G.EnvelopeFilter(G.Triangle(120.0, 0.6, samplerate=SR), 0.01, 0.02, 0.1, 0.5, 0.1)]
     bank = VoiceBank(voices)
@@ -202,7 +202,7 @@ def test_generate_i16_overflow_odd_lengths_and_windows(gpu):
     with pytest.raises(OverflowError):
         VoiceBank.overflow_check()                               # ... the flag stays up until it is asked for
     VoiceBank.overflow_check()                                   # and is down again afterwards
-    with pytest.raises(N.SynthHipError):
+    with pytest.raises(ValueError):
         loud.generate_i16_device(100, stride=101)                # rows are written as 32-bit pairs
 
 
@@ -211,8 +211,9 @@ def test_sine_peaks_on_rational_frequencies(gpu):
     the reference's accumulated t is within 1e-12 of pi/2 + 2 pi k, math.sin returns exactly +-1.0 (the true value is 1 - 1e-24), and with
     amplitude * scale an integer (the oscillators' default amplitude 1.0 at scale 32767) the sample sits ON a truncation boundary:
     32767 if the sine is 1.0, 32766 if it is one ulp short.  A sine made by rotating a neighbour's (the bank kernels' frames 2 .. of a
-    lane) is one ulp short about half the time -- so those paths snap |sin| to 1 where |cos| <= 1.05e-8 (the zone in which the
-    correctly rounded sine IS 1).  Both routes, against the oracle."""
+    lane) is an ulp off about half the time -- so next to a peak those paths take the sine from the cosine, +-fma(-c / 2, c, 1): one
+    rounding of 1 - c^2 / 2, which is what math.sin returns there.  Both routes, against the oracle, early and minutes into the notes
+    (where the accumulated t has drifted up to 1e-6 rad off the peak)."""
     from oracle import c_oracle as CO
     from oracle import synth_oracle as O
     from synthesizer_amd import oscillators as G
@@ -220,9 +221,10 @@ def test_sine_peaks_on_rational_frequencies(gpu):
     from synthesizer_amd.sample import Sample
     n = 60000
     freqs = [1000.0, 1500.0, 750.0, 250.0, 3000.0, 125.0, 6000.0, 2000.0, 12000.0, 375.0, 4000.0, 500.0]
-    for start in (0, 7 * SR):
+    for start in (0, 7 * SR, 200 * SR):
         want = np.stack([CO.quantise(CO.render(O.Sine(f, samplerate=SR), start + n)[start:]).astype(np.int16) for f in freqs])
-        assert int(np.count_nonzero(np.abs(want.astype(np.int32)) == 32767)) > 1000       # the peaks are there
+        if start < 100 * SR:        # the peaks are there (minutes in, the accumulated t has drifted 1e-4 rad off them: none reaches 32767)
+            assert int(np.count_nonzero(np.abs(want.astype(np.int32)) == 32767)) > 1000
         gv = [G.Sine(f, samplerate=SR) for f in freqs]
         got_a = np.stack([np.frombuffer(Sample.from_osc_device(v._render_f64_device(start, n), n, SR).view_frame_data(), dtype=np.int16) for v in gv])
         assert np.array_equal(got_a, want), ("route A", start, np.argwhere(got_a != want)[:5])
