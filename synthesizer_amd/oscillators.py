@@ -23,7 +23,7 @@ import ctypes as C
 from dataclasses import dataclass, field
 from fractions import Fraction
 from functools import lru_cache
-from math import pi, sin, cos
+from math import pi, sin, cos, sqrt
 from typing import Dict, Generator, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -590,6 +590,32 @@ class _Carrier(Oscillator):
     def _make_spec(self) -> VoiceSpec:
         return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias), **self._phase_fields())
 
+    # What "held to the 1e-6 contract" means for an FM voice (not upstream: INTEGRATION.md).  The reference forms the carrier's angle
+    # as t * freq + phase_correction with phase_correction += (freq_previous - freq) * t per sample: a running float64 sum whose every
+    # addition rounds at ulp(f * depth * t) -- a random walk no closed form can retrace.  Measured against the C
+    # oracle (tests/test_gpu_fm_contract.py; profiles/r04_late_parity.txt): RMS error <= FM_WALK_C * ulp(f depth t) * sqrt(n), n = t * sr
+    # samples into the note, ulp(x) = 2^-52 x (the smooth envelope of the binade steps).
+    FM_WALK_C = 0.5
+
+    def fm_error_bound(self, seconds: float) -> float:
+        """Bound on the RMS distance of this voice from the reference's samples ``seconds`` into the note: the random walk of the
+        reference's own phase_correction roundings for an FM voice (grows like t^1.5), 0.0 for one without an fm_lfo (whose
+        accumulated phase is reproduced bit for bit)."""
+        lfo = self.fm
+        if lfo is None or seconds <= 0.0:
+            return 0.0
+        depth = abs(float(getattr(lfo, "amplitude", 1.0))) + abs(float(getattr(lfo, "bias", 0.0)))
+        x = abs(float(self.frequency)) * depth * (2.0 * pi if self.RADIANS else 1.0) * seconds     # the size phase_correction has grown to
+        rad = (1.0 if self.RADIANS else 2.0 * pi)                                                   # error of the angle in radians
+        return self.FM_WALK_C * (2.0 ** -52) * x * sqrt(seconds * self.samplerate) * rad * abs(float(self.amplitude))
+
+    def fm_contract_horizon(self, tolerance: float = 1.0e-6) -> float:
+        """Seconds into a note until ``fm_error_bound`` reaches ``tolerance`` (the 1e-6 RMS float contract): how long an FM voice can
+        sound before its distance from the reference's own rounding walk may exceed the contract; ``inf`` without an fm_lfo."""
+        if self.fm is None or self.fm_error_bound(1.0) == 0.0:
+            return float("inf")
+        return (tolerance / self.fm_error_bound(1.0)) ** (2.0 / 3.0)                                # the bound grows like t^1.5
+
 
 class Sine(_Carrier):
     """Sine wave oscillator (upstream: oscillators.py class Sine)."""
@@ -697,13 +723,14 @@ class WhiteNoise(Oscillator):
 
 
 @lru_cache(maxsize=4096)
-def _harmonic_forms(harmonics):
-    """(polynomial, dense Clenshaw, sparse) form of a harmonic list [(k, amplitude)]: exactly one of them is not None."""
+def _harmonic_forms(harmonics, exact=False):
+    """(polynomial, dense Clenshaw, sparse) form of a harmonic list [(k, amplitude)]: exactly one of them is not None.
+    exact (params.exact_harmonics): the term-by-term form whatever the list -- the reference's own loop, sin(fl(t k)) a_k in order."""
     dense = None
     sparse = None
     poly = None
     ks = [k for k, _ in harmonics]
-    integral = all(float(k) == int(k) for k in ks)
+    integral = not exact and all(float(k) == int(k) for k in ks)
     kmax = max((abs(int(k)) for k in ks), default=0) if integral else 0
     if integral and 0 < kmax <= min(_DENSE_MAX_K, 8 * len(ks) + 64):
         n = (kmax + 7) // 8 * 8
@@ -743,7 +770,7 @@ class Harmonics(_Carrier):
             # one partial, k = 1, a = 1.0: the reference's sum is 0 + sin(t * 1) * 1.0 -- a Sine, bit for bit; as a Sine record it takes
             # the exact treatment of the peaks (tests/test_gpu_int_mixdown.py::test_sine_peaks_on_rational_frequencies)
             return VoiceSpec(kind=N.SH_SINE, amplitude=float(self.amplitude), bias=float(self.bias), **self._phase_fields())
-        poly, dense, sparse = _harmonic_forms(tuple(map(tuple, self.harmonics)))
+        poly, dense, sparse = _harmonic_forms(tuple(map(tuple, self.harmonics)), bool(params.exact_harmonics))
         return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias),
                          harm_poly=poly, harm_dense=dense, harm_sparse=sparse, **self._phase_fields())
 
