@@ -199,6 +199,16 @@ int  sh_debug_counters(sh_counters* out);
  * (SYNTHHIP_LIB, read by the Python binding, names another build of this library to load; SYNTHHIP_ALLOW_STALE=1 lets it load a
  * library whose sources have changed when rebuilding fails.) */
 
+/* Readings of the recalled reference arithmetic that the DEVICE has to know about (the others are host-side choices of
+ * synthesizer_amd/params.py `variants`: increments, Square as a Pulse record, pulse widths, envelope boundaries -- they change the records,
+ * not the kernels).  SH_OPT_QUANTISE_ROUND: 0 (default) Sample.from_osc_block quantises int(scale * v), truncation toward zero;
+ * 1: round(scale * v), half to even (Python 3's round) -- sh_quantize_f32 / sh_quantize_f64 follow it (the saturating [SPEC] forms,
+ * sh_quantize_clip_f32 and sh_bank_render_pcm, and the fused sh_bank_generate_i16 do not: under 1 the latter refuses and the caller
+ * quantises float64 rows).  Process-wide, like the stream.  Returns SH_ERR_INVALID for an unknown option. */
+typedef enum sh_option { SH_OPT_QUANTISE_ROUND = 1 } sh_option;
+int  sh_set_option(int option, int value);
+int  sh_get_option(int option);
+
 /* ---- device buffers ---------------------------------------------------------------- */
 int    sh_buf_alloc(size_t bytes, sh_buf** out);
 int    sh_buf_free(sh_buf* b);
@@ -252,7 +262,8 @@ int sh_osc_render(sh_bank* bank, uint32_t voice,
  *      AmpModulationFilter (a*b), ClipFilter (max(min(a, p1), p0)), AbsFilter (|a|), copy / constant fill.
  *      a, b, out_f64: float64 device buffers; out_f32 (+ element offset) / out_host: optional float32 copies */
 typedef enum sh_ew_op { SH_EW_ADD = 0, SH_EW_MUL = 1, SH_EW_CLIP = 2, SH_EW_ABS = 3, SH_EW_COPY = 4, SH_EW_FILL = 5,
-                        SH_EW_AXPY = 6 /* a + b*p0 (product rounded first): EchoFilter */ } sh_ew_op;
+                        SH_EW_AXPY = 6 /* a + b*p0 (product rounded first): EchoFilter */,
+                        SH_EW_NEXTUP = 7 /* the float64 successor of a: pulse widths under the `<=` reading (below) */ } sh_ew_op;
 int sh_ew_f64(int op, const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, size_t n, double p0, double p1,
               sh_buf* out_f64, size_t out64_off, sh_buf* out_f32, size_t out32_off, float* out_host);
 

@@ -39,7 +39,23 @@ def _dp(a):
     return a.ctypes.data_as(_D)
 
 
+def _c_code_knows_the_variants(osc) -> bool:
+    """oracle.c restates the DEFAULT readings of synth_oracle.VARIANTS (the increment is computed here, so both of its readings are
+    served); a case that touches another reading goes through the Python generators."""
+    v = O.VARIANTS
+    inner = osc._source if isinstance(osc, O.EnvelopeFilter) else osc
+    if isinstance(osc, O.EnvelopeFilter) and v["envelope"] != "lt":
+        return False
+    if isinstance(inner, O.Square) and v["square"] != "int2":
+        return False
+    if isinstance(inner, O.Pulse) and v["pulse"] != "lt":
+        return False
+    return True
+
+
 def render(osc, n: int) -> np.ndarray:
+    if not _c_code_knows_the_variants(osc):
+        return np.array(osc.take(n), dtype=np.float64)
     env = None
     if isinstance(osc, O.EnvelopeFilter):
         env, osc = osc, osc._source
@@ -68,10 +84,8 @@ def render(osc, n: int) -> np.ndarray:
     pw = float(getattr(osc, "pulsewidth", 0.0))
     L = lib()
     if osc.fm is None and getattr(osc, "pwm", None) is None:
-        if radians:
-            inc, t0 = 2.0 * pi * osc.frequency / sr, osc._phase * 2.0 * pi
-        else:
-            inc, t0 = osc.frequency / sr, osc._phase
+        inc = O._increment(osc.frequency, sr, radians)
+        t0 = osc._phase * 2.0 * pi if radians else osc._phase
         L.or_osc_plain(kind, C.c_double(t0), C.c_double(inc), C.c_double(osc.amplitude), C.c_double(osc.bias),
                        C.c_double(pw), _dp(hk), _dp(ha), nh, C.c_size_t(n), _dp(out))
     else:
@@ -83,7 +97,7 @@ def render(osc, n: int) -> np.ndarray:
             phase0, inc = osc._phase, 1.0 / sr
         L.or_osc_fm_sine(kind, C.c_double(osc.frequency), C.c_double(phase0), C.c_double(inc), C.c_double(osc.amplitude),
                          C.c_double(osc.bias), C.c_double(pw), _dp(hk), _dp(ha), nh,
-                         C.c_double(lfo._phase * 2.0 * pi), C.c_double(2.0 * pi * lfo.frequency / lfo.samplerate),
+                         C.c_double(lfo._phase * 2.0 * pi), C.c_double(O._increment(lfo.frequency, lfo.samplerate, True)),
                          C.c_double(lfo.amplitude), C.c_double(lfo.bias), C.c_size_t(n), _dp(out))
     if env is not None:
         L.or_envelope(C.c_double(env._attack), C.c_double(env._decay), C.c_double(env._sustain),
@@ -131,6 +145,8 @@ def ratecv_f32(x: np.ndarray, inrate: int, outrate: int) -> np.ndarray:
 
 
 def quantise(v: np.ndarray, scale: float = 32767.0, width: int = 2) -> np.ndarray:
+    if O.VARIANTS["quantise"] != "trunc":
+        return np.array(O.quantise(np.asarray(v, dtype=np.float64).tolist(), width, scale), dtype=np.int32)
     v = np.ascontiguousarray(v, dtype=np.float64)
     out = np.empty(len(v), dtype=np.int32)
     bad = lib().or_quantise(_dp(v), C.c_size_t(len(v)), C.c_double(scale), width, out.ctypes.data_as(C.POINTER(C.c_int32)))

@@ -51,6 +51,51 @@ norm_nchannels = 2
 norm_samplewidth = 2
 norm_osc_blocksize = 512
 
+# ---- host-side VARIANTS of the recalled arithmetic (tools/pin_oracle.py --variants) ---------------------------------------------
+# Where the recollection could be off by a last bit or a comparison operator, both readings exist, here and -- under the same names
+# and values -- in the product (synthesizer_amd/params.py `variants`): the day the real package is importable, tools/pin_oracle.py
+# re-runs every failing case under each reading and prints the one that matches; adopting it is a change of these defaults.
+#   increment  "mul": 2 pi f / sr (f / sr for the turn-based kinds)       "div": rate = sr / f; 2 pi / rate (1 / rate)
+#   square     "int2": -a if int(t * 2) % 2 else a                        "mod1": a if t % 1.0 < 0.5 else -a
+#   pulse      "lt": a if t % 1.0 < pulsewidth else -a                    "le": ... <= pulsewidth
+#   quantise   "trunc": int(scale * v)                                    "round": round(scale * v) (Python 3: half to even)
+#   envelope   "lt": while time < phase_end                               "le": while time <= phase_end
+VARIANT_CHOICES = {"increment": ("mul", "div"), "square": ("int2", "mod1"), "pulse": ("lt", "le"), "quantise": ("trunc", "round"),
+                   "envelope": ("lt", "le")}
+VARIANTS = {k: v[0] for k, v in VARIANT_CHOICES.items()}
+
+
+def set_variants(**kw) -> dict:
+    """Change readings (returns the previous table, for a try / finally); unknown names or values raise."""
+    old = dict(VARIANTS)
+    for k, v in kw.items():
+        if k not in VARIANT_CHOICES or v not in VARIANT_CHOICES[k]:
+            raise ValueError("variant %s=%r: choose from %r" % (k, v, VARIANT_CHOICES.get(k)))
+        VARIANTS[k] = v
+    return old
+
+
+def _increment(frequency: float, samplerate: int, radians: bool) -> float:
+    """The per-sample phase step of the non-FM branch of blocks()."""
+    if VARIANTS["increment"] == "div":
+        rate = samplerate / frequency
+        return 2.0 * pi / rate if radians else 1.0 / rate
+    return 2.0 * pi * frequency / samplerate if radians else frequency / samplerate
+
+
+def _square(t: float, a: float) -> float:
+    if VARIANTS["square"] == "mod1":
+        return a if t % 1.0 < 0.5 else -a
+    return -a if int(t * 2) % 2 else a
+
+
+def _pulse_high(m: float, pw: float) -> bool:
+    return m <= pw if VARIANTS["pulse"] == "le" else m < pw
+
+
+def _env_before(time: float, end: float) -> bool:
+    return time <= end if VARIANTS["envelope"] == "le" else time < end
+
 
 class Oscillator:
     """upstream: oscillators.py class Oscillator (ABC with blocks())."""
@@ -106,7 +151,7 @@ class Sine(Oscillator):
                     t += increment
                 yield block
         else:
-            increment = 2.0 * pi * self.frequency / self.samplerate
+            increment = _increment(self.frequency, self.samplerate, True)
             t = self._phase * 2.0 * pi
             while True:
                 block = []
@@ -146,7 +191,7 @@ class Sawtooth(Oscillator):
                     t += increment
                 yield block
         else:
-            increment = self.frequency / self.samplerate
+            increment = _increment(self.frequency, self.samplerate, False)
             t = self._phase
             while True:
                 block = []
@@ -182,16 +227,16 @@ class Square(Oscillator):
                     phase_correction += (freq_previous - freq) * t
                     freq_previous = freq
                     tt = t * freq + phase_correction
-                    block.append((-self.amplitude if int(tt * 2) % 2 else self.amplitude) + self.bias)
+                    block.append(_square(tt, self.amplitude) + self.bias)
                     t += increment
                 yield block
         else:
-            increment = self.frequency / self.samplerate
+            increment = _increment(self.frequency, self.samplerate, False)
             t = self._phase
             while True:
                 block = []
                 for _ in range(norm_osc_blocksize):
-                    block.append((-self.amplitude if int(t * 2) % 2 else self.amplitude) + self.bias)
+                    block.append(_square(t, self.amplitude) + self.bias)
                     t += increment
                 yield block
 
@@ -228,16 +273,16 @@ class Pulse(Oscillator):
                     phase_correction += (freq_previous - freq) * t
                     freq_previous = freq
                     tt = t * freq + phase_correction
-                    block.append((self.amplitude if tt % 1.0 < pw else -self.amplitude) + self.bias)
+                    block.append((self.amplitude if _pulse_high(tt % 1.0, pw) else -self.amplitude) + self.bias)
                     t += increment
                 yield block
         else:
-            increment = self.frequency / self.samplerate
+            increment = _increment(self.frequency, self.samplerate, False)
             t = self._phase
             while True:
                 block = []
                 for _ in range(norm_osc_blocksize):
-                    block.append((self.amplitude if t % 1.0 < self.pulsewidth else -self.amplitude) + self.bias)
+                    block.append((self.amplitude if _pulse_high(t % 1.0, self.pulsewidth) else -self.amplitude) + self.bias)
                     t += increment
                 yield block
 
@@ -277,7 +322,7 @@ class Harmonics(Oscillator):
                     t += increment
                 yield block
         else:
-            increment = 2.0 * pi * self.frequency / self.samplerate
+            increment = _increment(self.frequency, self.samplerate, True)
             t = self._phase * 2.0 * pi
             while True:
                 block = []
@@ -326,24 +371,24 @@ class EnvelopeFilter(Oscillator):
             if self._attack:
                 amp_change = 1.0 / self._attack * increment
                 amp = 0.0
-                while time < self._attack:
+                while _env_before(time, self._attack):
                     yield next(src) * amp
                     amp += amp_change
                     time += increment
             if self._decay:
                 amp = 1.0
                 amp_change = (self._sustain_level - 1.0) / self._decay * increment
-                while time < end_time_decay:
+                while _env_before(time, end_time_decay):
                     yield next(src) * amp
                     amp += amp_change
                     time += increment
-            while time < end_time_sustain:
+            while _env_before(time, end_time_sustain):
                 yield next(src) * self._sustain_level
                 time += increment
             if self._release:
                 amp = self._sustain_level
                 amp_change = (-self._sustain_level) / self._release * increment
-                while time < end_time_release:
+                while _env_before(time, end_time_release):
                     yield next(src) * amp
                     amp += amp_change
                     time += increment
@@ -376,7 +421,7 @@ def quantise(block: Iterable[float], samplewidth: int = norm_samplewidth,
     lo, hi = -(2 ** (8 * samplewidth - 1)), 2 ** (8 * samplewidth - 1) - 1
     out = []
     for v in block:
-        i = int(amplitude_scale * v)
+        i = round(amplitude_scale * v) if VARIANTS["quantise"] == "round" else int(amplitude_scale * v)
         if i < lo or i > hi:
             raise OverflowError("signed integer out of range for sample width %d" % samplewidth)
         out.append(i)
@@ -435,7 +480,7 @@ class Triangle(Oscillator):
                     t += increment
                 yield block
         else:
-            increment = self.frequency / self.samplerate
+            increment = _increment(self.frequency, self.samplerate, False)
             t = self._phase
             while True:
                 block = []

@@ -18,7 +18,8 @@ LIB_PATH = Path(os.environ.get("SYNTHHIP_LIB", HERE / "libsynthhip.so"))
 SH_OK = 0
 SH_ERR_INVALID, SH_ERR_HIP, SH_ERR_NOMEM, SH_ERR_NOTINIT, SH_ERR_OVERFLOW, SH_ERR_RCCL, SH_ERR_LENGTH = -1, -2, -3, -4, -5, -6, -7
 SH_SINE, SH_SAWTOOTH, SH_SQUARE, SH_PULSE, SH_HARMONICS, SH_TRIANGLE, SH_LINEAR, SH_NOISE, SH_BUFFER = range(9)
-SH_EW_ADD, SH_EW_MUL, SH_EW_CLIP, SH_EW_ABS, SH_EW_COPY, SH_EW_FILL, SH_EW_AXPY = range(7)
+SH_EW_ADD, SH_EW_MUL, SH_EW_CLIP, SH_EW_ABS, SH_EW_COPY, SH_EW_FILL, SH_EW_AXPY, SH_EW_NEXTUP = range(8)
+SH_OPT_QUANTISE_ROUND = 1
 SH_FM_NONE, SH_FM_SINE, SH_FM_BUFFER = range(3)
 SH_DIST_ID_BYTES = 128
 
@@ -80,6 +81,8 @@ _SIGNATURES = {
     "sh_version": (C.c_char_p, []),
     "sh_abi": (C.c_int, [C.POINTER(C.c_uint32), C.c_int]),
     "sh_sync": (C.c_int, []),
+    "sh_set_option": (C.c_int, [C.c_int, C.c_int]),
+    "sh_get_option": (C.c_int, [C.c_int]),
     "sh_debug_counters": (C.c_int, [C.POINTER(Counters)]),
     "sh_buf_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
     "sh_buf_free": (C.c_int, [_P]),
@@ -248,6 +251,11 @@ def check(rc: int) -> None:
         if rc == SH_ERR_NOMEM:
             raise MemoryError(msg)
         raise SynthHipError(rc, msg)
+
+
+def set_quantise_round(on: bool) -> None:
+    """params.variants["quantise"]: "round" -> the library's quantisers round half to even (sh_set_option); "trunc" -> int()'s rule."""
+    check(lib().sh_set_option(SH_OPT_QUANTISE_ROUND, 1 if on else 0))
 
 
 _initialized = False

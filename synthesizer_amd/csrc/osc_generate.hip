@@ -679,6 +679,8 @@ int sh_bank_generate_i16_async(sh_bank* b, uint64_t start, uint32_t nframes, dou
     if (rc || nframes == 0) return rc;
     if ((stride & 1u) || ((uintptr_t)voices_out->ptr & 3u))
         return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_i16: stride must be even (rows are written as 32-bit pairs of samples)");
+    if (sh::state().quantise_round)
+        return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_i16: the fused quantiser truncates; under SH_OPT_QUANTISE_ROUND quantise float64 rows (sh_bank_generate_f64 + sh_quantize_f64)");
     return generate_rows<short>(b, start, nframes, (short*)voices_out->ptr, stride, scale, sh::state().flag + 1);     // (word 0: the quantisers of pcm.hip)
 }
 

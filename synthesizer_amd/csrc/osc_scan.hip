@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void k_ew_f64(int op, const double* a, const d
     case SH_EW_ABS: v = fabs(a[i]); break;
     case SH_EW_COPY: v = a[i]; break;
     case SH_EW_AXPY: { const double e = b[i] * p0; v = a[i] + e; } break;
+    case SH_EW_NEXTUP: v = nextafter(a[i], INFINITY); break;
     default: v = p0; break;
     }
     if (out64) out64[i] = v;
@@ -159,7 +160,7 @@ extern "C" {
 int sh_ew_f64(int op, const sh_buf* a, size_t a_off, const sh_buf* b, size_t b_off, size_t n, double p0, double p1,
               sh_buf* out_f64, size_t out64_off, sh_buf* out_f32, size_t out32_off, float* out_host) {
     SH_REQUIRE_INIT();
-    if (op < SH_EW_ADD || op > SH_EW_AXPY) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: unknown op %d", op);
+    if (op < SH_EW_ADD || op > SH_EW_NEXTUP) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: unknown op %d", op);
     const bool need_a = op != SH_EW_FILL, need_b = op == SH_EW_ADD || op == SH_EW_MUL || op == SH_EW_AXPY;
     if (need_a && (!a || a_off > a->bytes / 8 || n > a->bytes / 8 - a_off)) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: operand a too small");
     if (need_b && (!b || b_off > b->bytes / 8 || n > b->bytes / 8 - b_off)) return sh::set_error(SH_ERR_INVALID, "sh_ew_f64: operand b too small");

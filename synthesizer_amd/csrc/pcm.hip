@@ -20,14 +20,16 @@ typedef int   int4v   __attribute__((ext_vector_type(4)));
 typedef char  char16v __attribute__((ext_vector_type(16)));
 
 // ---- quantise: int(scale*v), truncation toward zero (sample.py Sample.from_osc_block) -------
+// rnd (sh_set_option(SH_OPT_QUANTISE_ROUND)): the other reading of the reference's rule, round(scale*v) -- half to even, rint -- in
+// place of int()'s truncation toward zero; never with clip (the saturating forms are this build's own: [SPEC]).
 template <typename OutT, typename InT = float>
 __global__ __launch_bounds__(256) void k_quantize(const InT* __restrict__ in, size_t n, double scale,
                                                   double lo, double hi, OutT* __restrict__ out,
-                                                  int* __restrict__ flag, int clip) {
+                                                  int* __restrict__ flag, int clip, int rnd = 0) {
     size_t i = sh::block_id() * 256 + threadIdx.x;
     if (i >= n) return;
     double v = scale * (double)in[i];          // float64 product, like the Python expression
-    double t = trunc(v);
+    double t = rnd ? rint(v) : trunc(v);
     if (!(t >= lo && t <= hi)) {               // also catches NaN
         if (clip) {
             t = (t > hi) ? hi : lo;
@@ -45,8 +47,8 @@ __global__ __launch_bounds__(256) void k_quantize(const InT* __restrict__ in, si
 // 256 / 512 bytes.  tools/ubench_quant.hip: float64 6.3 TB/s this way, 5.8 with eight consecutive samples per thread and a
 // 16-byte store, 4.4 with those loads marked non-temporal, 4.9 one sample per thread.
 template <bool CLIP>
-__device__ __forceinline__ short quantize16(double p, bool& bad) {
-    double t = trunc(p);
+__device__ __forceinline__ short quantize16(double p, bool& bad, bool rnd = false) {
+    double t = rnd ? rint(p) : trunc(p);
     if (!(t >= -32768.0 && t <= 32767.0)) {                  // also catches NaN
         if (CLIP) { t = (t > 32767.0) ? 32767.0 : -32768.0; if (p != p) t = 0.0; }
         else { bad = true; t = 0.0; }
@@ -57,7 +59,7 @@ __device__ __forceinline__ short quantize16(double p, bool& bad) {
 // float32 -> int16, four samples per 16-byte vector
 typedef float float4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_quantize_f32_i16_vec(const float4v* __restrict__ in, size_t nvec, double scale,
-                                                              short4v* __restrict__ out, int* __restrict__ flag, int clip) {
+                                                              short4v* __restrict__ out, int* __restrict__ flag, int clip, int rnd = 0) {
     const size_t base = sh::block_id() * 512 + threadIdx.x;
     float4v v[2];
 #pragma unroll
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void k_quantize_f32_i16_vec(const float4v* __r
         if (base + u * 256 >= nvec) break;
         short4v r;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = clip ? quantize16<true>(scale * (double)v[u][j], bad) : quantize16<false>(scale * (double)v[u][j], bad);
+        for (int j = 0; j < 4; ++j) r[j] = clip ? quantize16<true>(scale * (double)v[u][j], bad) : quantize16<false>(scale * (double)v[u][j], bad, rnd != 0);
         __builtin_nontemporal_store(r, out + base + u * 256);       // streaming store: +3.5 %
     }
     if (bad) *flag = 1;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void k_quantize_f32_i16_vec(const float4v* __r
 typedef double double2v __attribute__((ext_vector_type(2)));
 typedef short short2v __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_quantize_f64_i16_vec(const double2v* __restrict__ in, size_t nvec, double scale,
-                                                              short2v* __restrict__ out, int* __restrict__ flag) {
+                                                              short2v* __restrict__ out, int* __restrict__ flag, int rnd = 0) {
     const size_t base = sh::block_id() * 512 + threadIdx.x;
     double2v v[2];
 #pragma unroll
@@ -88,8 +90,8 @@ __global__ __launch_bounds__(256) void k_quantize_f64_i16_vec(const double2v* __
     for (int u = 0; u < 2; ++u) {
         if (base + u * 256 >= nvec) break;
         short2v r;
-        r[0] = quantize16<false>(scale * v[u][0], bad);
-        r[1] = quantize16<false>(scale * v[u][1], bad);
+        r[0] = quantize16<false>(scale * v[u][0], bad, rnd != 0);
+        r[1] = quantize16<false>(scale * v[u][1], bad, rnd != 0);
         __builtin_nontemporal_store(r, out + base + u * 256);       // streaming store: +3.5 %
     }
     if (bad) *flag = 1;
@@ -939,15 +941,16 @@ int sh_quantize_f32(const sh_buf* in_f32, size_t in_off, size_t n, double scale,
     const dim3 grid = sh::grid1d(n, 256);
     hipStream_t st = sh::state().stream;
     int* flag = sh::state().flag;
+    const int rnd = sh::state().quantise_round;
     if (width == 2) {
         short* o = (short*)out_pcm->ptr + out_off;
         const bool aligned = ((uintptr_t)in & 15) == 0 && ((uintptr_t)o & 7) == 0;
         const size_t nvec = aligned ? n / 4 : 0, done = nvec * 4;
-        if (nvec) hipLaunchKernelGGL(k_quantize_f32_i16_vec, sh::grid1d(nvec, 512), dim3(256), 0, st, (const float4v*)in, nvec, scale, (short4v*)o, flag, 0);
-        if (n > done) hipLaunchKernelGGL(k_quantize<short>, sh::grid1d(n - done, 256), dim3(256), 0, st, in + done, n - done, scale, lo, hi, o + done, flag, 0);
+        if (nvec) hipLaunchKernelGGL(k_quantize_f32_i16_vec, sh::grid1d(nvec, 512), dim3(256), 0, st, (const float4v*)in, nvec, scale, (short4v*)o, flag, 0, rnd);
+        if (n > done) hipLaunchKernelGGL(k_quantize<short>, sh::grid1d(n - done, 256), dim3(256), 0, st, in + done, n - done, scale, lo, hi, o + done, flag, 0, rnd);
     }
-    else if (width == 1) hipLaunchKernelGGL(k_quantize<signed char>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (signed char*)out_pcm->ptr + out_off, flag, 0);
-    else hipLaunchKernelGGL(k_quantize<int>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (int*)out_pcm->ptr + out_off, flag, 0);
+    else if (width == 1) hipLaunchKernelGGL(k_quantize<signed char>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (signed char*)out_pcm->ptr + out_off, flag, 0, rnd);
+    else hipLaunchKernelGGL(k_quantize<int>, grid, dim3(256), 0, st, in, n, scale, lo, hi, (int*)out_pcm->ptr + out_off, flag, 0, rnd);
     SH_CHECK_LAUNCH("k_quantize");
     int overflow = 0;
     int rc = fetch_flag(&overflow);
@@ -969,14 +972,15 @@ int sh_quantize_f64(const sh_buf* in_f64, size_t in_off, size_t n, double scale,
     const dim3 grid = sh::grid1d(n, 256);
     hipStream_t st = sh::state().stream;
     int* flag = sh::state().flag;
+    const int rnd = sh::state().quantise_round;
     if (width == 2) {
         short* out = (short*)out_pcm->ptr + out_off;
         const bool aligned = ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 3) == 0;
         const size_t nvec = aligned ? n / 2 : 0, done = nvec * 2;
-        if (nvec) hipLaunchKernelGGL(k_quantize_f64_i16_vec, sh::grid1d(nvec, 512), dim3(256), 0, st, (const double2v*)in, nvec, scale, (short2v*)out, flag);
-        if (n > done) hipLaunchKernelGGL((k_quantize<short, double>), sh::grid1d(n - done, 256), dim3(256), 0, st, in + done, n - done, scale, lo, hi, out + done, flag, 0);
-    } else if (width == 1) hipLaunchKernelGGL((k_quantize<signed char, double>), grid, dim3(256), 0, st, in, n, scale, lo, hi, (signed char*)out_pcm->ptr + out_off, flag, 0);
-    else hipLaunchKernelGGL((k_quantize<int, double>), grid, dim3(256), 0, st, in, n, scale, lo, hi, (int*)out_pcm->ptr + out_off, flag, 0);
+        if (nvec) hipLaunchKernelGGL(k_quantize_f64_i16_vec, sh::grid1d(nvec, 512), dim3(256), 0, st, (const double2v*)in, nvec, scale, (short2v*)out, flag, rnd);
+        if (n > done) hipLaunchKernelGGL((k_quantize<short, double>), sh::grid1d(n - done, 256), dim3(256), 0, st, in + done, n - done, scale, lo, hi, out + done, flag, 0, rnd);
+    } else if (width == 1) hipLaunchKernelGGL((k_quantize<signed char, double>), grid, dim3(256), 0, st, in, n, scale, lo, hi, (signed char*)out_pcm->ptr + out_off, flag, 0, rnd);
+    else hipLaunchKernelGGL((k_quantize<int, double>), grid, dim3(256), 0, st, in, n, scale, lo, hi, (int*)out_pcm->ptr + out_off, flag, 0, rnd);
     SH_CHECK_LAUNCH("k_quantize");
     int overflow = 0;
     int rc = fetch_flag(&overflow);

@@ -308,6 +308,19 @@ int sh_debug_counters(sh_counters* out) {
     return SH_OK;
 }
 
+// Options are plain host state (no device work): callable before sh_init, without a GPU.
+int sh_set_option(int option, int value) {
+    SH_API_LOCK();
+    if (option == SH_OPT_QUANTISE_ROUND) { state().quantise_round = value ? 1 : 0; return SH_OK; }
+    return sh::set_error(SH_ERR_INVALID, "sh_set_option: unknown option %d", option);
+}
+
+int sh_get_option(int option) {
+    SH_API_LOCK();
+    if (option == SH_OPT_QUANTISE_ROUND) return state().quantise_round;
+    return sh::set_error(SH_ERR_INVALID, "sh_get_option: unknown option %d", option);
+}
+
 int sh_sync(void) {
     SH_REQUIRE_INIT();
     SH_HIP(hipStreamSynchronize(state().stream));

@@ -26,7 +26,8 @@ from typing import Callable, Dict, Generator, List, Optional, Sequence, Tuple, U
 import numpy as np
 
 from . import _native as N
-from .oscillators import Oscillator, VoiceSpec, _table, pack_voices, time_step_weights
+from . import params
+from .oscillators import Oscillator, VoiceSpec, _pwm_widths, _table, pack_voices, time_step_weights
 from .sample import Sample
 
 __all__ = ["VoiceBank", "RealTimeMixer", "mix_samples", "pan_gains"]
@@ -51,6 +52,7 @@ class _RowMatrix:
         self.fm_rows: List[int] = []
         self.other_rows: List[int] = []
         self._banks: List[Tuple[N.Bank, int, bool]] = []        # (bank of closed-form sources, first row, fm rows?)
+        self._pwm_bank_rows: List[int] = []                     # rows of pulse widths among them (params.variants["pulse"])
         self._singles: List[Tuple[Oscillator, int, str]] = []   # (source, row, "fm" | "pwm" | "voice")
 
         def place(sources, first_row, out_rows, roles):
@@ -71,6 +73,8 @@ class _RowMatrix:
                 self._banks.append((N.Bank(*pack_voices([sp for _, _, sp in bankable])), r, is_fm))
                 for k, _m, _sp in bankable:
                     rows[k] = r
+                    if not is_fm and roles[k] == "pwm":
+                        self._pwm_bank_rows.append(r)
                     r += 1
             for k, m, _sp in single:
                 rows[k] = r
@@ -102,6 +106,9 @@ class _RowMatrix:
         for bank, row0, is_fm in self._banks:
             if is_fm or not fm_only:
                 N.check(L.sh_bank_generate_f64(bank.handle, start, n, self._buf.handle, row0, self._stride))
+        if not fm_only:
+            for row in self._pwm_bank_rows:                         # (closed-form pwm sources rendered by the bank launch above)
+                _pwm_widths(self._buf, row * self._stride, n)
         for m, row, role in self._singles:
             if fm_only and role != "fm":
                 continue
@@ -113,6 +120,8 @@ class _RowMatrix:
                 avail = max(0, min(n, m.length - start))
             if avail:
                 m._render_device(start, avail, out_f64=self._buf.view(row * self._stride * 8, avail * 8))
+                if role == "pwm":
+                    _pwm_widths(self._buf, row * self._stride, avail)
             if avail < n:
                 N.check(L.sh_ew_f64(N.SH_EW_FILL, None, 0, None, 0, n - avail, 0.0, 0.0, self._buf.handle, row * self._stride + avail, None, 0, None))
         if self.nfm:
@@ -327,6 +336,19 @@ class VoiceBank:
         if out is None:
             out = N.DeviceBuffer(max(self.nvoices * stride * 2, 4))
         if nframes == 0:
+            return out, stride
+        if params.variants["quantise"] == "round":
+            # the other reading of the quantiser (round half to even): the fused epilogue truncates, so every voice goes through
+            # float64 rows and the library's quantiser, which follows the option (a contingency path: 8 B per voice-sample on the way)
+            if self._rows is not None:
+                raise NotImplementedError("generate_i16_device under the round() quantise variant: banks with modulation rows")
+            r64 = N.DeviceBuffer(self.nvoices * stride * 8)
+            N.check(N.lib().sh_bank_generate_f64(self._bank.handle, start, nframes, r64.handle, 0, stride))
+            try:
+                for v in range(self.nvoices):
+                    N.check(N.lib().sh_quantize_f64(r64.handle, v * stride, nframes, float(scale), 2, out.handle, v * stride))
+            finally:
+                r64.free()
             return out, stride
         if self._rows is not None:
             rows, rstride = self._rows.fill(start, nframes)

@@ -199,15 +199,24 @@ class EnvelopeSpec:
         return self.n_release_end + (1 if self.has_tail else 0)
 
 
-@lru_cache(maxsize=4096)          # a bank's voices usually share one ADSR: the four boundary searches are done once
 def envelope_spec(attack: float, decay: float, sustain: float, sustain_level: float, release: float,
                   samplerate: int, stop_at_end: bool = False) -> EnvelopeSpec:
     """Replay EnvelopeFilter's accumulated ``time`` exactly and return the sample indices at which
     its four ``while time < ...`` loops end (upstream: oscillators.py EnvelopeFilter)."""
+    return _envelope_spec(attack, decay, sustain, sustain_level, release, samplerate, stop_at_end, params.variants["envelope"] == "le")
+
+
+@lru_cache(maxsize=4096)          # a bank's voices usually share one ADSR: the four boundary searches are done once
+def _envelope_spec(attack: float, decay: float, sustain: float, sustain_level: float, release: float,
+                   samplerate: int, stop_at_end: bool, inclusive: bool) -> EnvelopeSpec:
     increment = 1.0 / samplerate
     tt = _table(0.0, increment)
 
     def first_ge(x: float) -> int:
+        # the number of samples a loop `while time < x` delivers: the first index whose accumulated time is >= x; inclusive (the other
+        # reading, `while time <= x`): the first index whose time is > x, i.e. >= the successor of x
+        if inclusive:
+            return 0 if x < 0.0 else tt.first_index_ge(float(np.nextafter(x, np.inf)))
         return 0 if x <= 0.0 else tt.first_index_ge(x)
 
     end_time_decay = attack + decay
@@ -441,6 +450,7 @@ class Oscillator:
         pwm_buf = None
         if s.needs_pwm:
             pwm_buf = self._pwm_source()._render_f64_device(start, n)
+            _pwm_widths(pwm_buf, 0, n)
         N.check(N.lib().sh_osc_render(
             bank.handle, 0,
             fm_buf.handle if fm_buf else None, pwm_buf.handle if pwm_buf else None,
@@ -528,6 +538,21 @@ class Oscillator:
         return self.blocks()
 
 
+def _increment(frequency: float, samplerate: int, radians: bool) -> float:
+    """The per-sample phase step of the non-FM branch of the reference's blocks(), under params.variants["increment"]."""
+    if params.variants["increment"] == "div":
+        rate = samplerate / frequency
+        return 2.0 * pi / rate if radians else 1.0 / rate
+    return 2.0 * pi * frequency / samplerate if radians else frequency / samplerate
+
+
+def _pwm_widths(buf: N.DeviceBuffer, offset: int, n: int) -> None:
+    """Per-sample pulse widths (a rendered pwm_lfo) as the device's strict comparison needs them: under params.variants["pulse"] ==
+    "le" every width becomes its float64 successor, in place."""
+    if params.variants["pulse"] == "le" and n:
+        N.check(N.lib().sh_ew_f64(N.SH_EW_NEXTUP, buf.handle, offset, None, 0, n, 0.0, 0.0, buf.handle, offset, None, 0, None))
+
+
 def _closed_form_lfo(lfo: Optional[Oscillator]) -> bool:
     return type(lfo) is Sine and lfo.fm is None
 
@@ -563,7 +588,7 @@ class _Carrier(Oscillator):
                 # (a bias at or next to -1 leaves nothing to fold it into -- the closed form carries f (1 + bias) as its frequency and
                 # divides the sine part by it: such an LFO takes the buffer path below, which needs no division)
                 a = lfo._phase * 2.0 * pi
-                d = 2.0 * pi * lfo.frequency / lfo.samplerate
+                d = _increment(lfo.frequency, lfo.samplerate, True)
                 half = sin(d / 2.0)
                 if half == 0.0 or lfo.amplitude == 0.0:
                     # a constant LFO, lfo_j = c: the angle is f (1 + c) t_n (the sum of freq_j over the ACCUMULATED time steps)
@@ -579,12 +604,8 @@ class _Carrier(Oscillator):
             else:
                 out.update(fm_mode=N.SH_FM_BUFFER)
             return out
-        if self.RADIANS:
-            increment = 2.0 * pi * self.frequency / sr
-            t0 = self._phase * 2.0 * pi
-        else:
-            increment = self.frequency / sr
-            t0 = self._phase
+        increment = _increment(self.frequency, sr, self.RADIANS)
+        t0 = self._phase * 2.0 * pi if self.RADIANS else self._phase
         return dict(fm_mode=N.SH_FM_NONE, carrier=_table(t0, increment))
 
     def _make_spec(self) -> VoiceSpec:
@@ -637,6 +658,13 @@ class Square(_Carrier):
     """Perfect square wave (upstream: oscillators.py class Square)."""
     KIND = N.SH_SQUARE
 
+    def _make_spec(self) -> VoiceSpec:
+        if params.variants["square"] == "mod1":
+            # the other reading, a if t % 1.0 < 0.5 else -a (equal for t >= 0, not for a negative phase: int() truncates toward zero):
+            # literally a Pulse of width 0.5 -- the record the device already knows
+            return VoiceSpec(kind=N.SH_PULSE, amplitude=float(self.amplitude), bias=float(self.bias), pulsewidth=0.5, **self._phase_fields())
+        return super()._make_spec()
+
 
 class Pulse(_Carrier):
     """Pulse of a given width, optionally pulse-width modulated (upstream: oscillators.py class Pulse)."""
@@ -653,8 +681,11 @@ class Pulse(_Carrier):
     def _make_spec(self) -> VoiceSpec:
         # with a pwm_lfo (and no fm_lfo) the reference still runs its modulated loop: t += 1/sr, tt = t*f + phase
         fields = self._phase_fields(force_fm=self.pwm is not None)
+        pw = float(self.pulsewidth)
+        if params.variants["pulse"] == "le":
+            pw = float(np.nextafter(pw, np.inf))      # m <= w  <=>  m < successor(w) for float64 m, w (pwm rows: _pwm_widths)
         return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias),
-                         pulsewidth=float(self.pulsewidth), needs_pwm=self.pwm is not None, **fields)
+                         pulsewidth=pw, needs_pwm=self.pwm is not None, **fields)
 
 
 class _StoppedTable(PhaseTable):

@@ -72,3 +72,75 @@ def test_api_audit_exits_3_here_and_its_code_runs_against_the_oracle():
     bad = [r for r in methods if r["status"] == "missing" or (r["status"] == "differs" and names(r.get("ref")) != names(r.get("ours")))]
     assert not bad, bad
     assert P.print_api_table(rows) is not None
+
+
+def _oracle_copy(name, **variants):
+    """A second instance of oracle/synth_oracle.py (its own VARIANTS table) standing in for a reference that follows other readings."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, str(ROOT / "oracle" / "synth_oracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    mod.set_variants(**variants)
+    return mod
+
+
+def test_variants_recipe_names_the_reading_a_reference_follows():
+    """--variants: against a stand-in reference that computes increments as 2 pi / (sr / f), compares Pulse with <= and quantises with
+    round(), the recipe must report differences AND say which readings make the oracle equal -- per case and in the verdict."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import pin_oracle as P
+    from oracle import synth_oracle as O
+    assert O.VARIANTS == {k: v[0] for k, v in O.VARIANT_CHOICES.items()}
+    assert len(P.variant_flips(O)) == 5 + 10
+    ref = _oracle_copy("ref_like_div", increment="div", pulse="le")
+    report = []
+    P.diff_oscillators(ref, O, True, report, variants=True)
+    assert report, "a reference with other increments must differ somewhere"
+    assert O.VARIANTS == {k: v[0] for k, v in O.VARIANT_CHOICES.items()}          # the recipe restores the table
+    by_case = {r["case"]: r for r in report}
+    # a plain Sine from phase 0 differs through its increment alone (from phase 0.3 the two increments, one ulp apart, round to the same
+    # running sums for thousands of samples: the grid's phase-0 cases are the ones that see it) ...
+    sine = by_case["NullFilter"]
+    assert {"increment": "div"} in sine["variants_that_match"] and {"pulse": "le"} not in sine["variants_that_match"]
+    assert {"pulse": "le"} in by_case["Pulse width on a sample"]["variants_that_match"]
+    # ... every differing case is explained by increment=div, alone or with pulse=le
+    for r in report:
+        assert any(f.get("increment") == "div" for f in r["variants_that_match"]) or any(f == {"pulse": "le"} for f in r["variants_that_match"]), r
+    verdict = P.variant_verdict(report)
+    assert verdict["adopt"].get("increment") == "div" and not verdict["unexplained"], verdict
+    # the quantiser: a stand-in that rounds
+    class RoundingSample:
+        @staticmethod
+        def from_osc_block(block, rate, samplewidth=2):
+            class R:
+                def get_frame_array(self_inner):
+                    return [round((2 ** (8 * samplewidth - 1) - 1) * v) for v in block]
+            return R()
+    block = [0.9999 * __import__("math").sin(0.01 * i) for i in range(3000)] + [1.0, -1.0, 0.0, 1234.0 / 32767.0]
+    want = list(RoundingSample.from_osc_block(block, 22050, 2).get_frame_array())
+    assert want != list(O.quantise(block, 2))
+    assert {"quantise": "round"} in P.explain_by_variants(None, None, O, None, quantise_block=(block, 2, want))
+
+
+def test_every_variant_reading_changes_some_case_of_the_grid():
+    """A reading no case of the grid can tell from the default would make the recipe blind to it."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import pin_oracle as P
+    from oracle import synth_oracle as O
+    for k, v in (("increment", "div"), ("envelope", "le")):
+        ref = _oracle_copy("ref_like_%s" % k, **{k: v})
+        report = []
+        P.diff_oscillators(ref, O, True, report)
+        assert report, (k, v)
+    # Square int2 / mod1 differ for negative t only; Pulse < / <= where t % 1 lands ON the width: cases made for them
+    import numpy as np
+    for flip, make in (({"square": "mod1"}, lambda m: m.Square(440.0, 0.8, -0.3, samplerate=48000)),
+                       ({"pulse": "le"}, lambda m: m.Pulse(375.0, 0.8, 0.0, 0.25, samplerate=48000))):
+        a = np.array(P.take(make(O), 2048))
+        old = O.set_variants(**flip)
+        try:
+            b = np.array(P.take(make(O), 2048))
+        finally:
+            O.set_variants(**old)
+        assert not np.array_equal(a, b), flip

@@ -81,7 +81,7 @@ def oscillator_cases(quick: bool):
     cases = []
     for sr, ph in itertools.product(rates, phases):
         for kind in ("Sine", "Triangle", "Square", "Sawtooth"):
-            for f in (440.0, 1000.0, 55.5):
+            for f in (440.0, 1000.0, 55.5, 441.0):          # (441 Hz at 48 kHz: f / sr != 1 / (sr / f) -- the turn-based kinds' increment readings part)
                 cases.append(("%s f=%g sr=%d ph=%g" % (kind, f, sr, ph),
                               lambda m, kind=kind, f=f, sr=sr, ph=ph: getattr(m, kind)(f, 0.8, ph, 0.1, samplerate=sr)))
                 cases.append(("%s f=%g sr=%d ph=%g fm" % (kind, f, sr, ph),
@@ -102,6 +102,11 @@ def oscillator_cases(quick: bool):
     cases += [
         ("Linear up", lambda m: m.Linear(-0.5, 1e-4, -1.0, 0.25, samplerate=sr)),
         ("Linear const", lambda m: m.Linear(0.3, samplerate=sr)),
+        # cases made to tell the readings of oracle.synth_oracle.VARIANTS apart (--variants): phase boundaries that fall ON a sample
+        # (1 / 32768 is a float64: the accumulated time is exact), a Square on a negative phase, a Pulse whose t % 1 lands on its width
+        ("Envelope boundaries on samples", lambda m: m.EnvelopeFilter(m.Sine(512.0, samplerate=32768), 1.0 / 64, 1.0 / 128, 1.0 / 64, 0.5, 1.0 / 128)),
+        ("Square negative phase", lambda m: m.Square(440.0, 0.8, -0.3, 0.0, samplerate=sr)),
+        ("Pulse width on a sample", lambda m: m.Pulse(375.0, 0.8, 0.0, 0.25, 0.0, samplerate=sr)),
         ("Envelope ADSR", lambda m: m.EnvelopeFilter(m.Sine(440.0, samplerate=sr), 0.01, 0.02, 0.03, 0.6, 0.02)),
         ("Envelope stop_at_end", lambda m: m.EnvelopeFilter(m.Square(440.0, samplerate=sr), 0.005, 0.0, 0.01, 0.5, 0.01, stop_at_end=True)),
         ("Envelope no release", lambda m: m.EnvelopeFilter(m.Sawtooth(440.0, samplerate=sr), 0.0, 0.01, 0.02, 0.7, 0.0)),
@@ -119,7 +124,43 @@ def oscillator_cases(quick: bool):
     return cases
 
 
-def diff_oscillators(ref, O, quick, report, very_late=False):
+def variant_flips(O):
+    """Every single alternative reading of oracle.synth_oracle.VARIANTS, then every pair of them: [{name: value, ...}, ...]."""
+    singles = [{k: v} for k, choices in O.VARIANT_CHOICES.items() for v in choices[1:]]
+    pairs = [dict(a, **b) for a, b in itertools.combinations(singles, 2) if set(a) != set(b)]
+    return singles + pairs
+
+
+def explain_by_variants(make, ref, O, windows, quantise_block=None):
+    """A case whose values differ: re-run the ORACLE side under every alternative reading (and pair of readings) and return those
+    under which it equals the reference -- "which variant" instead of "different".  make(module) builds the case; windows =
+    [(skip, count)].  quantise_block: instead of an oscillator case, (block, width) through Sample.from_osc_block / O.quantise."""
+    import numpy as np
+    matching = []
+    for flip in variant_flips(O):
+        old = O.set_variants(**flip)
+        try:
+            ok = True
+            if quantise_block is not None:
+                block, width, want = quantise_block
+                ok = want == list(O.quantise(block, width))
+            else:
+                a, b = make(ref), make(O)
+                for skip, cnt in windows:
+                    x, y = np.array(take(a, cnt, skip), dtype=np.float64), np.array(take(b, cnt, skip), dtype=np.float64)
+                    if x.shape != y.shape or not np.array_equal(x, y):
+                        ok = False
+                        break
+        except Exception:
+            ok = False
+        finally:
+            O.set_variants(**old)
+        if ok:
+            matching.append(flip)
+    return matching
+
+
+def diff_oscillators(ref, O, quick, report, very_late=False, variants=False):
     import numpy as np
     n = 2048
     late = (1 << 20) - 1024                     # a window that straddles sample 2**20
@@ -137,6 +178,7 @@ def diff_oscillators(ref, O, quick, report, very_late=False):
         # round 4 found the product's closed form there).  Minutes of pure-Python generator per case: only when asked for
         if very_late and name.endswith(" fm") and ("f=440 " in name or "f=1000 " in name) and "sr=48000 ph=0.3" in name:
             windows.append(((1 << 22) - 1024, n))
+        failed = []
         for skip, cnt in windows:
             try:
                 x, y = np.array(take(a, cnt, skip), dtype=np.float64), np.array(take(b, cnt, skip), dtype=np.float64)
@@ -145,13 +187,20 @@ def diff_oscillators(ref, O, quick, report, very_late=False):
                 continue
             if x.shape != y.shape:
                 report.append({"case": name, "window": skip, "len_ref": int(x.size), "len_oracle": int(y.size)})
+                failed.append(report[-1])
             elif not np.array_equal(x, y):
                 d = np.abs(x - y)
                 report.append({"case": name, "window": skip, "differing": int(np.sum(x != y)), "max_abs": float(d.max()),
                                "first": int(np.argmax(x != y))})
+                failed.append(report[-1])
+        if variants and failed:
+            # which reading of the recalled arithmetic makes the oracle EQUAL the reference on every window of this case?
+            match = explain_by_variants(make, ref, O, windows)
+            for row in failed:
+                row["variants_that_match"] = match
 
 
-def diff_samples(refS, RefSample, O, report):
+def diff_samples(refS, RefSample, O, report, variants=False):
     import numpy as np
     rng = np.random.default_rng(2024)
 
@@ -198,6 +247,27 @@ def diff_samples(refS, RefSample, O, report):
         want = list(refS.from_osc_block(block, 22050, samplewidth=width).get_frame_array())
         if want != list(O.quantise(block, width)):
             report.append({"case": "from_osc_block width %d" % width, "differs": True})
+            if variants:
+                report[-1]["variants_that_match"] = explain_by_variants(None, None, O, None, quantise_block=(block, width, want))
+
+
+def variant_verdict(report):
+    """What the differing cases say together: the readings that appear in EVERY differing case's list of matching flips (adopt these:
+    oracle.synth_oracle.VARIANTS and synthesizer_amd/params.py variants), and the cases no reading explains."""
+    rows = [r for r in report if "variants_that_match" in r]
+    unexplained = sorted({r["case"] for r in rows if not r["variants_that_match"]})
+    votes = {}
+    for r in rows:
+        for flip in r["variants_that_match"]:
+            if len(flip) == 1:
+                (k, v), = flip.items()
+                votes.setdefault((k, v), set()).add(r["case"])
+    adopt = {k: v for (k, v), cases in votes.items()}
+    summary = ("no value differences" if not rows else
+               "%d differing case(s); single readings that make cases equal: %s; unexplained by any reading or pair: %s"
+               % (len({r["case"] for r in rows}), ", ".join("%s=%s (%d cases)" % (k, v, len(c)) for (k, v), c in sorted(votes.items())) or "none",
+                  ", ".join(unexplained) or "none"))
+    return {"adopt": adopt, "unexplained": unexplained, "summary": summary}
 
 
 def diff_params(refP, O, report):
@@ -322,6 +392,10 @@ def main() -> int:
     ap.add_argument("--regen", action="store_true", help="rewrite tests/golden/osc_*.np* from the real package")
     ap.add_argument("--quick", action="store_true", help="one sample rate / phase, no late windows")
     ap.add_argument("--very-late", action="store_true", help="FM cases also in a window at sample 2^22 (minutes of generator time per case)")
+    ap.add_argument("--variants", action="store_true",
+                    help="for every case whose values differ, re-run the oracle under each alternative reading of oracle.synth_oracle.VARIANTS "
+                         "(increment mul / div, Square int2 / mod1, Pulse < / <=, quantise int / round, envelope < / <=; singly and in pairs) and "
+                         "print the readings under which it EQUALS the reference; ends with the readings that explain every such case")
     ap.add_argument("--json", default=None, help="write the outcome here as JSON")
     args = ap.parse_args()
     where = find_reference()
@@ -355,8 +429,11 @@ def main() -> int:
     import synthplayer.sample as ref_sample
     report = outcome["differences"]
     diff_params(ref_params, O, report)
-    diff_oscillators(ref_osc, O, args.quick, report, very_late=args.very_late)
-    diff_samples(ref_sample.Sample, RefSample, O, report)
+    diff_oscillators(ref_osc, O, args.quick, report, very_late=args.very_late, variants=args.variants)
+    diff_samples(ref_sample.Sample, RefSample, O, report, variants=args.variants)
+    if args.variants:
+        outcome["variant_verdict"] = variant_verdict(report)
+        print("variants: %s" % outcome["variant_verdict"]["summary"])
     if args.regen:
         outcome["regenerated"] = regenerate_golden(ref_osc)
     outcome["status"] = "pinned" if not report else "differences"
