@@ -17,7 +17,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libsynthhip.so"
-SOURCES = ["runtime.hip", "osc_bank.hip", "osc_render.hip", "osc_generate.hip", "osc_mixbus.hip", "osc_scan.hip", "pcm.hip", "pcm_ops.hip", "dist.hip"]
+SOURCES = ["runtime.hip", "osc_bank.hip", "osc_render.hip", "osc_render_lean.hip", "osc_render_combined.hip", "osc_generate.hip", "osc_mixbus.hip", "osc_scan.hip", "pcm.hip", "pcm_ops.hip", "dist.hip"]
 HEADERS = sorted(p.name for p in CSRC.glob("*.hpp")) + ["../../include/synthhip.h"]      # (every header of csrc/: a header left out of the hash is a stale library unnoticed)
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -282,9 +282,8 @@ static int launch_segmented(const RenderLaunch& L, uint32_t nseg, const uint32_t
     const LaunchArgs A = L.args(P, g);
     const NextArgs N = L.next_args(L.next, L.prep_wgs);
     const dim3 grid(tiles_lean, groups + sh::div_up(L.prep_wgs, tiles_lean));
-    if (L.mode == COMBINED_LEAN_HARM) hipLaunchKernelGGL((k_render_lean<4, 8, 4, LEAN_K_HARM, true>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
-    else hipLaunchKernelGGL((k_render_lean<4, 8, 4, LEAN_K_ALL, true>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
-    SH_CHECK_LAUNCH("k_render_lean(segments)");
+    rc = launch_render_lean(484, L.mode == COMBINED_LEAN_HARM ? LEAN_K_HARM : LEAN_K_ALL, true, grid, st, A, N, L.fold, L.parts);
+    if (rc) return rc;
     SH_HIP(hipMemsetAsync(L.gen_valid, 1, (size_t)groups * sizeof(uint32_t), st));         // every group's general parts are written
     hipLaunchKernelGGL((k_render_general<16, 4, 1, GEN_SEG>), dim3(tiles_gen + (SUB - 1) * sh::div_up(n0, 64 * 4), groups), dim3(1024), 0, st,
                        A, L.parts, L.gen_valid);
@@ -306,31 +305,13 @@ static int launch_plain(const RenderLaunch& L) {
     const dim3 grid(L.tiles, L.groups + sh::div_up(L.prep_wgs, L.tiles));
     const bool lean_split = L.split;                     // (split implies lean candidates and several voice groups)
     const bool fm_only = b->lean_fmsine_candidates == b->lean_candidates;     // every lean candidate an FM Sine voice (BASELINE config 3)
-#define SH_LAUNCH_SHAPE(W_, F_, M_)                                                                                                      \
-    do {                                                                                                                                 \
-        if (lean_split && L.mode == COMBINED_LEAN_HARM) hipLaunchKernelGGL((k_render_lean<W_, F_, M_, LEAN_K_HARM, false>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts); \
-        else if (lean_split && fm_only) hipLaunchKernelGGL((k_render_lean<W_, F_, M_, LEAN_K_FM, false>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts); \
-        else if (lean_split) hipLaunchKernelGGL((k_render_lean<W_, F_, M_, LEAN_K_ALL, false>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts); \
-        else if (L.mode == COMBINED_LEAN_HARM) hipLaunchKernelGGL((k_render_combined<W_, F_, M_, COMBINED_LEAN_HARM>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts, L.out); \
-        else if (L.mode == COMBINED_LEAN_ALL) hipLaunchKernelGGL((k_render_combined<W_, F_, M_, COMBINED_LEAN_ALL>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts, L.out); \
-        else hipLaunchKernelGGL((k_render_combined<W_, F_, M_, COMBINED_DIRECT>), grid, dim3(W_ * 64), 0, st, A, N, L.fold, L.parts, L.out); \
-    } while (0)
-    switch (L.var) {
-    case 4163:                                         // (chosen for split launches of polynomial-Harmonics or FM Sine banks only: bank_render)
-        if (lean_split && L.mode == COMBINED_LEAN_HARM) hipLaunchKernelGGL((k_render_lean<4, 16, 3, LEAN_K_HARM, false>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
-        else if (lean_split && fm_only) hipLaunchKernelGGL((k_render_lean<4, 16, 3, LEAN_K_FM, false>), grid, dim3(256), 0, st, A, N, L.fold, L.parts);
-        else return sh::set_error(SH_ERR_INVALID, "sh_bank_render: shape 4163 needs a split launch of a Harmonics or an FM Sine bank");
-        break;
-    case 484: SH_LAUNCH_SHAPE(4, 8, 4); break;
-    case 444: SH_LAUNCH_SHAPE(4, 4, 4); break;
-    case 844: SH_LAUNCH_SHAPE(8, 4, 4); break;
-    case 821: SH_LAUNCH_SHAPE(8, 2, 1); break;
-    case 421: SH_LAUNCH_SHAPE(4, 2, 1); break;
-    case 211: SH_LAUNCH_SHAPE(2, 1, 1); break;
-    default: return sh::set_error(SH_ERR_INVALID, "sh_bank_render: SYNTHHIP_VARIANT %d is not one of 4163, 484, 444, 844, 821, 421, 211", L.var);
+    if (lean_split) {                                    // every k_render_lean lives in osc_render_lean.hip
+        const int rc = launch_render_lean(L.var, L.mode == COMBINED_LEAN_HARM ? LEAN_K_HARM : (fm_only ? LEAN_K_FM : LEAN_K_ALL), false, grid, st, A, N, L.fold, L.parts);
+        if (rc) return rc;
+    } else {                                             // ... and every k_render_combined in osc_render_combined.hip
+        const int rc = launch_render_combined(L.var, L.mode, grid, st, A, N, L.fold, L.parts, L.out);
+        if (rc) return rc;
     }
-#undef SH_LAUNCH_SHAPE
-    SH_CHECK_LAUNCH("k_render_lean / k_render_combined");
     if (L.with_general) {
         // the general lists of the same launch: four waves x four frames per lane whatever the lean kernel's shape (the parts
         // are indexed by frame), same voice groups, behind the lean kernel on the same stream
@@ -474,7 +455,9 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     const int prev_cur = b->cur;
     // a bank with lean candidates + several voice groups: the launch is split into a lean and a general kernel
     // (k_render_lean + k_render_general); SYNTHHIP_NO_SPLIT=1 keeps the combined kernel
-    const bool split = mode != COMBINED_DIRECT && groups > 1 && !K.no_split;
+    // (the shapes of banks of fewer than 64 voices -- 421, 211 -- have no lean kernel: such banks never have two voice groups by
+    //  themselves; forced on a larger bank by SYNTHHIP_VARIANT they render through the combined kernel)
+    const bool split = mode != COMBINED_DIRECT && groups > 1 && !K.no_split && var != 421 && var != 211;
     // A transition launch (segmented): cut where the envelopes become flat (every voice past its decay) and from there on
     // into segments no longer than their own distance from the note's start -- piece ends of the phase sum lie an octave apart,
     // so such a segment crosses at most one per voice; a cut, too, where the first voice leaves its sustain.  Tile-aligned cuts.

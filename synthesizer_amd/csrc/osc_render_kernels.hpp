@@ -23,10 +23,10 @@
 #include "osc_device.hpp"
 #include <type_traits>
 
-namespace {
-
-constexpr uint32_t GEN_SPLIT = 2;      // general workgroups per tile of a tile-classified launch (each writes a plane of general parts; <= groups)
-
+// The launch structures are shared by the two translation units that instantiate these kernels (osc_render.hip: combined / general /
+// tiles / the folds; osc_render_lean.hip: every k_render_lean -- compiled side by side, the lean kernels are half of the ISA), so they
+// have names with linkage; everything else in this header stays local to the unit that includes it.
+namespace shosc {
 // A final bus: float32 and / or float64 frames, and / or saturated int16 PCM (any may be NULL).
 struct BusOut {
     float2*   bus32;
@@ -56,6 +56,17 @@ struct NextArgs {
     uint64_t  next_start;
     uint32_t  prep_wgs;
 };
+enum { LEAN_K_HARM = 0, LEAN_K_ALL = 1, LEAN_K_FM = 2, LEAN_K_REST = 3 };     // which kinds of lean record a bank can hold (static); _REST: a run of a list
+// osc_render_lean.hip: k_render_lean<W, F, M, kinds, seg> of shape var = W F M (4163, 484, 444, 844, 821) on `st`; SH_ERR_INVALID for a
+// shape that has no lean kernel (421, 211: banks of fewer than 64 voices never split a launch)
+int launch_render_lean(int var, int kinds, bool seg, dim3 grid, hipStream_t st, const LaunchArgs& A, const NextArgs& N, const FoldIn& F, double2* parts);
+// osc_render_combined.hip: k_render_combined<W, F, M, mode> of shape var (484, 444, 844, 821, 421, 211), mode = COMBINED_DIRECT / _LEAN_HARM / _LEAN_ALL
+int launch_render_combined(int var, int mode, dim3 grid, hipStream_t st, const LaunchArgs& A, const NextArgs& N, const FoldIn& F, double2* parts, const BusOut& out);
+}  // namespace shosc
+
+namespace {
+
+constexpr uint32_t GEN_SPLIT = 2;      // general workgroups per tile of a tile-classified launch (each writes a plane of general parts; <= groups)
 
 // -DSH_DIAG (tools/build_variant.py; never the shipped library): every wavefront of a render launch leaves the 100 MHz timestamps of
 // its phases and the SIMD it ran on in g_diag (four banks by block number: launches of a stream of blocks overlap pairwise);
@@ -470,7 +481,6 @@ __device__ __forceinline__ void lean_fm_frames(const double (&poly)[16], double 
 // instantiation: the extra branches and code cost its loop 5 %); LEAN_K_FM -- every one is an FM Sine voice (BASELINE config 3);
 // LEAN_K_ALL -- anything.  SEG: the records of a segmented launch (sloped gains; the second
 // piece's fields belong in the first batch of loads -- half the tiles lie behind the crossing).
-enum { LEAN_K_HARM = 0, LEAN_K_ALL = 1, LEAN_K_FM = 2, LEAN_K_REST = 3 };     // which kinds of lean record a bank can hold (static); _REST: a run of a list
 template <int WAVES, int FPL, int KINDS, bool SEG>
 __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, TrigTab trig, double (&accl)[FPL], double (&accr)[FPL]) {
     const uint32_t lane = T.lane, tile0 = T.tile0, tile_last = T.tile_last;
