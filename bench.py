@@ -726,7 +726,7 @@ def config_rows(N, prof=None, only=None, K=20):
         bank_row("config3_fm_1024v_48k_stereo", "config3", v, g, "1024 Sine carriers, each with a Sine fm_lfo (closed-form running sum), -> float32 stereo bus")
     if only is None:
         # not a BASELINE config: Harmonics and FM Sine voices in ONE bank (what a patch with both kinds of instrument asks for): the lean
-        # lists hold the kinds in runs, one loop per run (tools/mixed_kinds_probe.py has the other mixes)
+        # lists hold the kinds in runs, one loop per run (tools/probe.py kinds has the other mixes)
         va, ga = W.additive_voices(G, 512, SR, seed=0, partials=PARTIALS, adsr=ADSR_BENCH)
         vf, gf = W.fm_voices(G, 512, SR, seed=1)
         v = [x for pair in zip(va, vf) for x in pair]

@@ -170,7 +170,7 @@ __device__ __forceinline__ size_t block_id() { return (size_t)blockIdx.y * gridD
 
 // Rows that are read exactly once: streaming (non-temporal) loads are worth +10..13 % once the data no longer fits the 256 MB
 // Infinity Cache (mixers: 6.4 -> 7.2 TB/s on 2 GB) and cost 11 % when it does (36 MB: 8.9 -> 7.9 TB/s) -- the entry points
-// choose by the bytes a call reads (tools/mix_probe.py).
+// choose by the bytes a call reads (CHANGELOG.md item 28).
 constexpr size_t STREAM_BYTES = (size_t)128 << 20;
 template <bool NT, typename V>
 __device__ __forceinline__ V load_vec(const void* p) {

@@ -611,7 +611,7 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
         // behind the piece's end.  The up to 1023 frames in between follow the first piece's line: their phase is off by at most
         // 1023 x (the difference of the two pieces' dt: an ulp of the LFO's t) -- 2e-9 rad at t = 8192, five minutes into a 5 Hz LFO --
         // and the carrier's angle, transiently, by f_inc amp 1023^2 / 2 times that difference: 2e-7 rad at depth 0.5 under a 3.5 kHz
-        // carrier, below the rounding noise of the reference's own running sums by then (tools/fm_long_time_probe.py).  The general
+        // carrier, below the rounding noise of the reference's own running sums by then (tools/probe.py fm-long).  The general
         // code (VoiceFM::lfo_split) changes at the exact frame.
         info.lfo_split = l_split == 0xFFFFFFFFu ? l_split : ((l_split + 1023u) & ~1023u);
     }

@@ -68,7 +68,7 @@ namespace {
 
 constexpr uint32_t GEN_SPLIT = 2;      // general workgroups per tile of a tile-classified launch (each writes a plane of general parts; <= groups)
 
-// -DSH_DIAG (tools/build_variant.py; never the shipped library): every wavefront of a render launch leaves the 100 MHz timestamps of
+// -DSH_DIAG (tools/ab.py build; never the shipped library): every wavefront of a render launch leaves the 100 MHz timestamps of
 // its phases and the SIMD it ran on in g_diag (four banks by block number: launches of a stream of blocks overlap pairwise);
 // sh_debug_diag copies them out.  tools/headline_phases.py turns them into profiles/r04_headline_phases.md.
 #ifdef SH_DIAG

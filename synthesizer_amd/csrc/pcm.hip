@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_quantize(const InT* __restrict__ in, si
 
 // The vector forms: a workgroup covers 512 vectors of 16 bytes, each thread two of them 256 apart -- every load instruction
 // of a wave reads one contiguous kilobyte (streaming: nothing is read twice) and every store instruction writes a contiguous
-// 256 / 512 bytes.  tools/ubench_quant.hip: float64 6.3 TB/s this way, 5.8 with eight consecutive samples per thread and a
+// 256 / 512 bytes.  round 3 microbenchmark (profiles/r03_summary.md): float64 6.3 TB/s this way, 5.8 with eight consecutive samples per thread and a
 // 16-byte store, 4.4 with those loads marked non-temporal, 4.9 one sample per thread.
 template <bool CLIP>
 __device__ __forceinline__ short quantize16(double p, bool& bad, bool rnd = false) {

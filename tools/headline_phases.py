@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where does one launch of the headline render kernel spend its time?  (measure first.)
 
-    python tools/build_variant.py diag -DSH_DIAG
+    python tools/ab.py build diag -DSH_DIAG
     SYNTHHIP_LIB=synthesizer_amd/build/libsynthhip_diag.so python tools/headline_phases.py [--serial] [--tag NAME] > out.json
 
 A -DSH_DIAG library leaves, per wavefront of the render kernel, the 100 MHz timestamps of its phases (entry, fold of the launch two
@@ -94,7 +94,7 @@ def main():
     N.ensure_init(0)
     L = N.lib()
     if not hasattr(L, "sh_debug_diag"):
-        sys.exit("this library was not built with -DSH_DIAG (tools/build_variant.py diag -DSH_DIAG; SYNTHHIP_LIB=...)")
+        sys.exit("this library was not built with -DSH_DIAG (tools/ab.py build diag -DSH_DIAG; SYNTHHIP_LIB=...)")
     L.sh_debug_diag.restype = C.c_int
     L.sh_debug_diag.argtypes = [C.c_void_p, C.c_size_t]
     voices, gains = W.additive_voices(G, args.voices, 48000, seed=0, partials=16, adsr={"sustain": 1.0e6})

@@ -2,7 +2,7 @@
 // bench.py (mixer bus, saturating mix, resample, elementwise PCM) sit at 66-78 % of the 8 TB/s data-sheet figure; this
 // is the yardstick they should be read against: read-only reduction, copy, and write-only fill over 2 GiB, 16-byte
 // accesses, with 1 / 2 / 4 / 8 independent loads in flight per lane and grid sizes from "one wave per SIMD" upward.
-// build: hipcc --offload-arch=gfx950 -O3 tools/ubench_hbm.hip -o tools/ubench_hbm.bin
+// build: hipcc --offload-arch=gfx950 -O3 tools/ubench/hbm.hip -o tools/ubench/hbm.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>

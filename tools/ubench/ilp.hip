@@ -4,7 +4,7 @@
 // wavefronts -- does a lone wavefront with two chains stall?)
 //   grid = 256 * W workgroups of 256 threads (one wavefront per SIMD each), dynamic LDS sized so that at most W workgroups fit a CU;
 //   every wavefront runs ITERS iterations of CHAINS chains x = fma(x, a, b) and reports its s_memtime cycles.
-// build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/ubench_ilp.hip -o tools/ubench_ilp.bin
+// build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/ubench/ilp.hip -o tools/ubench/ilp.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
