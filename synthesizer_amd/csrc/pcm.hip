@@ -295,43 +295,75 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_chain_direct(const short* __
     }
 }
 
-// The direct loop over MONO rows that enter the chain as Sample.stereo(lf, rf) of themselves (see pan4): a lane owns eight frames --
-// one 16-byte load per row, sixteen stereo samples in two packed accumulators, two 16-byte stores.
-template <int WAVES, int INFLIGHT, bool NT>
-__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_pan_direct(const short* __restrict__ chunks, uint32_t nvoices, size_t stride,
-                                                                     uint32_t nframes, const double2* __restrict__ pan, short* __restrict__ out) {
-    const uint32_t f0 = (uint32_t)(sh::block_id() * (WAVES * 64) + threadIdx.x) * 8;
-    if (f0 >= nframes) return;
-    const short* col = chunks + f0;
-    const double SH_PCM_CONST* fac = (const double SH_PCM_CONST*)pan;     // (lf, rf) per voice: wave-uniform, scalar loads
-    if (f0 + 8 <= nframes) {
-        short8v a0, a1;
-        {
-            const short8v x = *reinterpret_cast<const short8v*>(col);
-            const double lf = fac[0], rf = fac[1];
-            a0 = pan4(__builtin_shufflevector(x, x, 0, 1, 2, 3), lf, rf);
-            a1 = pan4(__builtin_shufflevector(x, x, 4, 5, 6, 7), lf, rf);
-        }
+// The direct loops with S samples (F frames) per lane: for rows of MIDDLING length (a few hundred thousand samples: too few 1 KB
+// columns to fill the chip with eight samples per lane, more than the split kernels like) four samples per lane -- 8-byte loads,
+// twice the wavefronts, eight row loads in flight -- run the mono chain at 0.87 of the HBM peak where the split kernel reaches 0.74
+// (1024 rows x 480 000 samples: 166 -> 142 us).  The PAN chain -- mono rows that enter as Sample.stereo(lf, rf) of themselves, see pan4
+// -- is bound by its float64 arithmetic (ten operations per frame), not by HBM: four frames per lane at every length from ~300 000
+// frames (480 000: 290 -> 202 us, 0.61 of HBM; 960 000: 392 -> 358 us, 0.69); eight frames per lane were slower at both.
+template <int S> struct ShortVec;
+template <> struct ShortVec<8> { typedef short8v type; };
+template <> struct ShortVec<4> { typedef short4v type; };
+template <> struct ShortVec<2> { typedef short2v type; };
+
+template <int S, int WAVES, int INFLIGHT, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_direct_s(const short* __restrict__ chunks, uint32_t nvoices, size_t stride,
+                                                                   uint32_t nsamples, short* __restrict__ out) {
+    typedef typename ShortVec<S>::type vec;
+    const uint32_t s0 = (uint32_t)(sh::block_id() * (WAVES * 64) + threadIdx.x) * S;
+    if (s0 >= nsamples) return;
+    const short* col = chunks + s0;
+    if (s0 + S <= nsamples) {
+        vec acc = *reinterpret_cast<const vec*>(col);
         uint32_t v = 1;
         for (; v + INFLIGHT <= nvoices; v += INFLIGHT) {
-            short8v x[INFLIGHT];
+            vec x[INFLIGHT];
 #pragma unroll
-            for (int k = 0; k < INFLIGHT; ++k) x[k] = sh::load_vec<NT, short8v>(col + (size_t)(v + k) * stride);
+            for (int k = 0; k < INFLIGHT; ++k) x[k] = sh::load_vec<NT, vec>(col + (size_t)(v + k) * stride);
 #pragma unroll
-            for (int k = 0; k < INFLIGHT; ++k) {
-                const double lf = fac[2 * (v + k)], rf = fac[2 * (v + k) + 1];
-                a0 = __builtin_elementwise_add_sat(a0, pan4(__builtin_shufflevector(x[k], x[k], 0, 1, 2, 3), lf, rf));
-                a1 = __builtin_elementwise_add_sat(a1, pan4(__builtin_shufflevector(x[k], x[k], 4, 5, 6, 7), lf, rf));
-            }
+            for (int k = 0; k < INFLIGHT; ++k) acc = __builtin_elementwise_add_sat(acc, x[k]);
         }
-        for (; v < nvoices; ++v) {
-            const short8v x = *reinterpret_cast<const short8v*>(col + (size_t)v * stride);
-            const double lf = fac[2 * v], rf = fac[2 * v + 1];
-            a0 = __builtin_elementwise_add_sat(a0, pan4(__builtin_shufflevector(x, x, 0, 1, 2, 3), lf, rf));
-            a1 = __builtin_elementwise_add_sat(a1, pan4(__builtin_shufflevector(x, x, 4, 5, 6, 7), lf, rf));
+        for (; v < nvoices; ++v) acc = __builtin_elementwise_add_sat(acc, *reinterpret_cast<const vec*>(col + (size_t)v * stride));
+        __builtin_nontemporal_store(acc, reinterpret_cast<vec*>(out + s0));
+    } else {
+        for (uint32_t j = 0; s0 + j < nsamples; ++j) {
+            short acc = col[j];
+            for (uint32_t v = 1; v < nvoices; ++v) acc = __builtin_elementwise_add_sat(acc, col[(size_t)v * stride + j]);
+            out[s0 + j] = acc;
         }
-        __builtin_nontemporal_store(a0, reinterpret_cast<short8v*>(out + 2 * (size_t)f0));
-        __builtin_nontemporal_store(a1, reinterpret_cast<short8v*>(out + 2 * (size_t)f0 + 8));
+    }
+}
+
+template <int F, int WAVES, int INFLIGHT, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_chain_pan_direct_s(const short* __restrict__ chunks, uint32_t nvoices, size_t stride,
+                                                                       uint32_t nframes, const double2* __restrict__ pan, short* __restrict__ out) {
+    typedef typename ShortVec<F>::type vin;                       // F mono frames in, 2 F stereo samples out
+    typedef typename ShortVec<2 * F>::type vout;
+    const uint32_t f0 = (uint32_t)(sh::block_id() * (WAVES * 64) + threadIdx.x) * F;
+    if (f0 >= nframes) return;
+    const short* col = chunks + f0;
+    const double SH_PCM_CONST* fac = (const double SH_PCM_CONST*)pan;
+    auto stereo = [](const vin m, const double lf, const double rf) {
+        union { vout v; short2v p[F]; } r;
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            const double x = (double)m[j];
+            r.p[j] = __builtin_amdgcn_cvt_pk_i16((int)floor(x * lf), (int)floor(x * rf));
+        }
+        return r.v;
+    };
+    if (f0 + F <= nframes) {
+        vout acc = stereo(*reinterpret_cast<const vin*>(col), fac[0], fac[1]);
+        uint32_t v = 1;
+        for (; v + INFLIGHT <= nvoices; v += INFLIGHT) {
+            vin x[INFLIGHT];
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) x[k] = sh::load_vec<NT, vin>(col + (size_t)(v + k) * stride);
+#pragma unroll
+            for (int k = 0; k < INFLIGHT; ++k) acc = __builtin_elementwise_add_sat(acc, stereo(x[k], fac[2 * (v + k)], fac[2 * (v + k) + 1]));
+        }
+        for (; v < nvoices; ++v) acc = __builtin_elementwise_add_sat(acc, stereo(*reinterpret_cast<const vin*>(col + (size_t)v * stride), fac[2 * v], fac[2 * v + 1]));
+        __builtin_nontemporal_store(acc, reinterpret_cast<vout*>(out + 2 * (size_t)f0));
     } else {
         for (uint32_t j = 0; f0 + j < nframes; ++j) {
             short2v acc = {0, 0};
@@ -1119,12 +1151,17 @@ int sh_mix_chain_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint
     // (the split kernel keeps plain loads: 1024 x 96 000 samples = 197 MB ran 13 % slower with streaming ones)
 #define SH_CHAIN(W_, C_) hipLaunchKernelGGL((k_mix_chain_i16<W_, C_, false>), sh::grid1d(nsamples, 512 * C_), dim3(W_ * 64), 0, st, \
                                             (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr)
-    if (columns >= 1536 && aligned) {
+#define SH_DIRECT_S(S_, INF_) do { \
+        if (stream) hipLaunchKernelGGL((k_mix_chain_direct_s<S_, 4, INF_, true>), sh::grid1d(nsamples, 256 * S_), dim3(256), 0, st, (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr); \
+        else hipLaunchKernelGGL((k_mix_chain_direct_s<S_, 4, INF_, false>), sh::grid1d(nsamples, 256 * S_), dim3(256), 0, st, (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr); } while (0)
+    if (columns >= 640 && columns < 1536 && aligned) SH_DIRECT_S(4, 8);      // (measured at 937 columns; 187 columns: the split kernel, 31 against 86 us)
+    else if (columns >= 1536 && aligned) {
         if (stream) hipLaunchKernelGGL((k_mix_chain_direct<8, 4, true>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
                                        (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
         else hipLaunchKernelGGL((k_mix_chain_direct<8, 4, false>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
                                 (const short*)chunks->ptr, nvoices, stride, nsamples, (short*)out->ptr);
     }
+#undef SH_DIRECT_S
     else if (nvoices < 64) SH_CHAIN(2, 1);
     else if (columns >= 512) SH_CHAIN(8, 2);
     else SH_CHAIN(8, 1);
@@ -1150,9 +1187,9 @@ int sh_mix_chain_pan_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, 
     const uint32_t columns = (uint32_t)sh::div_up(nframes, 512);                      // 1 KB of a mono row
     const bool aligned = (stride & 7) == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out->ptr & 15) == 0 && ((uintptr_t)fac & 15) == 0;
     const bool stream = (size_t)nvoices * nframes * 2 > sh::STREAM_BYTES;
-    if (columns >= 1536 && aligned) {
-        if (stream) hipLaunchKernelGGL((k_mix_chain_pan_direct<4, 4, true>), sh::grid1d(nframes, 256 * 8), dim3(256), 0, st, in, nvoices, stride, nframes, fac, (short*)out->ptr);
-        else hipLaunchKernelGGL((k_mix_chain_pan_direct<4, 4, false>), sh::grid1d(nframes, 256 * 8), dim3(256), 0, st, in, nvoices, stride, nframes, fac, (short*)out->ptr);
+    if (columns >= 640 && aligned) {
+        if (stream) hipLaunchKernelGGL((k_mix_chain_pan_direct_s<4, 4, 8, true>), sh::grid1d(nframes, 256 * 4), dim3(256), 0, st, in, nvoices, stride, nframes, fac, (short*)out->ptr);
+        else hipLaunchKernelGGL((k_mix_chain_pan_direct_s<4, 4, 8, false>), sh::grid1d(nframes, 256 * 4), dim3(256), 0, st, in, nvoices, stride, nframes, fac, (short*)out->ptr);
     } else if (nvoices < 64) {
         hipLaunchKernelGGL((k_mix_chain_i16<2, 1, false>), sh::grid1d(nsamples, 512), dim3(128), 0, st, in, nvoices, stride, nsamples, (short*)out->ptr, fac);
     } else {
