@@ -555,6 +555,55 @@ def staggered_row(N, F, prof=None):
                     "walk along the voice's table for the first tiles of a note -- general code for what is left)"}
 
 
+def job_row(N, local, F, step0, prof):
+    """BASELINE's job taken literally -- 10 s from frame 0 in blocks of F, the first block being the notes' attack, decay and a dozen
+    binades of the phase sum (a segmented launch) -- best of 12, other frames rendered in between (the clocks stay up, block 0's records
+    go cold).  roofline: the float64 lane-operations of ALL the job's kernels (profiles/rNN_counters.json, keys "job:<kernel>", from
+    tools/profile_round.sh's `--only-config job` pass: block 0's four kernels once, the steady kernel nine times) over the job's time,
+    and what block 0's kernels take one by one (profiles/rNN_job_kernel_stats.csv)."""
+    import csv
+    ring = [N.DeviceBuffer(F * 8) for _ in range(4)]
+    job_ms = float("inf")
+    for rep in range(12):
+        N.sync()
+        N.timer_start()
+        for k in range(10):
+            local.render_device(F, k * F, bus_f32=ring[k & 3])
+        job_ms = min(job_ms, N.timer_stop())
+        for k in range(30):
+            local.render_device(F, (step0 + k) * F, bus_f32=ring[k & 3])
+    N.sync()
+    for b_ in ring:
+        b_.free()
+    nv = local.nvoices
+    row = {"blocks": 10, "ms": job_ms, "value": nv * 10.0 * F / (job_ms / 1e3) / 1e6, "unit": "Msamples/s", "us_per_block": job_ms * 100.0,
+           "note": "ten consecutive blocks starting at frame 0 (first block of the notes included), best of 12"}
+    ops = {k.split(":", 1)[1]: (v.get("SQ_INSTS_VALU_FMA_F64", 0) + v.get("SQ_INSTS_VALU_MUL_F64", 0) + v.get("SQ_INSTS_VALU_ADD_F64", 0)) * 64.0
+           for k, v in prof["counters"].items() if k.startswith("job:")}
+    steady_k = [k for k in ops if steady_render_kernel(k)]
+    block0_k = [k for k in ops if k.startswith("k_render_") and not steady_render_kernel(k)]
+    roof = {"bound": "valu_f64"}
+    if steady_k and block0_k:
+        total = 9.0 * max(ops[k] for k in steady_k) + sum(ops[k] for k in block0_k)
+        roof.update({"lane_ops_per_job": total, "ops_per_voice_sample": total / (nv * 10.0 * F), "achieved": total / (job_ms / 1e3) / 1e12,
+                     "peak": FP64_PEAK_TOPS, "unit": "T f64 lane-ops/s", "frac": total / (job_ms / 1e3) / 1e12 / FP64_PEAK_TOPS,
+                     "kernels": {"steady (x9)": steady_k, "block 0 (x1)": block0_k}, "source": prof.get("counters_source")})
+    else:
+        roof["note"] = "no counters of a job pass in profiles/ (tools/profile_round.sh: bench.py --only-config job)"
+    stats = sorted((ROOT / "profiles").glob("r*_job_kernel_stats.csv"))
+    if stats:
+        split = {}
+        for r in csv.DictReader(open(stats[-1])):
+            m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", r["Name"])
+            name = m.group(1) if m else r["Name"][:40]
+            if not steady_render_kernel(name) and (name.startswith("k_render_") or name.startswith("k_prepare") or name.startswith("k_seg") or name.startswith("k_bus")):
+                split[name] = {"avg_us": float(r["AverageNs"]) / 1e3, "calls": int(r["Calls"])}
+        roof["block0_kernels"] = split
+        roof["block0_source"] = stats[-1].name
+    row["roofline"] = roof
+    return row
+
+
 class _stdout_to_stderr:
     """File descriptor 1 points at stderr inside the block: what a native library prints on stdout (librccl's version banner
     at communicator creation) must not end up beside the ONE JSON line this script owes its caller."""
@@ -724,7 +773,7 @@ def config_rows(N, prof=None, only=None, K=20):
     if only in (None, "config3"):
         v, g = W.fm_voices(G, 1024, SR, seed=1)
         bank_row("config3_fm_1024v_48k_stereo", "config3", v, g, "1024 Sine carriers, each with a Sine fm_lfo (closed-form running sum), -> float32 stereo bus")
-    if only is None:
+    if only in (None, "mixed"):
         # not a BASELINE config: Harmonics and FM Sine voices in ONE bank (what a patch with both kinds of instrument asks for): the lean
         # lists hold the kinds in runs, one loop per run (tools/probe.py kinds has the other mixes)
         va, ga = W.additive_voices(G, 512, SR, seed=0, partials=PARTIALS, adsr=ADSR_BENCH)
@@ -734,7 +783,6 @@ def config_rows(N, prof=None, only=None, K=20):
         bank_row("mixed_512_additive_512_fm_48k_stereo", "mixed", v, g,
                  "512 Harmonics x16 voices + ADSR interleaved with 512 FM Sine voices in one bank -> float32 stereo bus")
         r = rows["mixed_512_additive_512_fm_48k_stereo"]
-        r["roofline"] = {"bound": "valu_f64", "note": "no profiling pass of its own: between the headline's and config 3's operations per voice-sample"}
         if "config3_fm_1024v_48k_stereo" in rows:
             r["x_config3"] = r["ms_per_1s_block"] / rows["config3_fm_1024v_48k_stereo"]["ms_per_1s_block"]
     if only in (None, "config4"):
@@ -761,7 +809,7 @@ def main() -> int:
     ap.add_argument("--no-pcm-rows", action="store_true", help="skip the resample / integer-mix rows")
     ap.add_argument("--no-two-step", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the rows of the other BASELINE configs")
-    ap.add_argument("--only-config", choices=("config2", "config3", "config4", "staggered"), default=None,
+    ap.add_argument("--only-config", choices=("config2", "config3", "config4", "staggered", "mixed", "job"), default=None,
                     help="run ONLY that config's row and print it (tools/profile_round.sh: one rocprofv3 pass per config)")
     ap.add_argument("--reduce-batch", type=int, default=8, help="blocks per RCCL reduce when --gpus > 1 (also the length of a run of pipelined renders)")
     args = ap.parse_args()
@@ -816,6 +864,16 @@ def main() -> int:
     K, Wm, F = args.steps, args.warmup, args.frames
     if args.only_config == "staggered":
         print(json.dumps({"only_config": "staggered", "library": N.lib().sh_version().decode(), "configs": {"staggered_notes": staggered_row(N, F)}}), flush=True)
+        return 0
+    if args.only_config == "job":
+        voices, gains = build_voices(VOICES_PER_GPU)
+        from synthesizer_amd.mixer import VoiceBank
+        local = VoiceBank(voices, gains=gains)
+        warm = [N.DeviceBuffer(F * 8) for _ in range(4)]
+        for k in range(60):                                    # (clocks up, on the frames the job's in-between renders use)
+            local.render_device(F, (Wm + k) * F, bus_f32=warm[k & 3])
+        print(json.dumps({"only_config": "job", "library": N.lib().sh_version().decode(),
+                          "configs": {"job_from_frame_0": job_row(N, local, F, Wm, committed_profile())}}), flush=True)
         return 0
     if args.only_config:
         rows = config_rows(N, committed_profile(), only=args.only_config, K=K)
@@ -1020,22 +1078,9 @@ def main() -> int:
 
     # ---- BASELINE's job taken literally: 10 s from frame 0 in blocks of F -- block 0 is the notes' attack, decay and a dozen
     # binades of the phase sum (a segmented launch); the passes above measure the steady state
-    if world == 1:
-        ring = [N.DeviceBuffer(F * 8) for _ in range(4)]
-        job_ms = float("inf")
-        for rep in range(12):
-            N.sync()
-            N.timer_start()
-            for k in range(10):
-                bank.local.render_device(F, k * F, bus_f32=ring[k & 3])
-            job_ms = min(job_ms, N.timer_stop())
-            for k in range(30):                     # other frames in between: the clocks stay up, the records of block 0 go cold
-                bank.local.render_device(F, (step0 + k) * F, bus_f32=ring[k & 3])
-        N.sync()
-        out["job_from_frame_0"] = {"blocks": 10, "ms": job_ms, "value": local_voices * 10.0 * F / (job_ms / 1e3) / 1e6, "unit": "Msamples/s",
-                                   "note": "ten consecutive blocks starting at frame 0 (first block of the notes included), best of 12"}
-        for b_ in ring:
-            b_.free()
+    if world == 1 and not dry:
+        out["job_from_frame_0"] = job_row(N, bank.local, F, step0, prof)
+        out["job_from_frame_0"]["x_steady"] = out["job_from_frame_0"]["ms"] / 10.0 / out["ms_per_step"]
 
     # ---- the same stream asked for K blocks per call (sh_bank_render_run into a ring of K windows of one allocation: one crossing
     # of the ABI and one launch per K blocks): what a latency-bound caller gains, and what the host then spends per block ----
@@ -1082,7 +1127,8 @@ def main() -> int:
         gen0_ms = steady(N, lambda: bank.local.generate_device(F2, 0, out=vbuf), min_seconds=0.03, reps=3)     # rows that start with the notes
         mix_bytes = (4.0 * nv + 8.0) * F2
         gen_bytes = 4.0 * nv * F2
-        tm, tg = _by_prefix(prof["traffic"], "k_mix_bus"), _by_prefix(prof["traffic"], "k_generate")
+        tm = _by_prefix(prof["traffic"], "k_mix_bus")
+        tg = _by_prefix(prof["traffic"], "k_generate_lean_harm<16, float") or _by_prefix(prof["traffic"], "k_generate_lean_harm<16>")
         out["two_step"] = {
             "frames_per_launch": F2, "voices": nv,
             "value": nv * F2 / ((gen_ms + mix_ms) / 1e3) / 1e6, "unit": "Msamples/s",
@@ -1092,7 +1138,7 @@ def main() -> int:
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mix_bytes / (mix_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                              "traffic": tm["hbm_bytes"] if tm else None, "avg_launch_ms": mix_ms, "bytes_per_frame": 4 * nv + 8,
                              "algorithmic_bytes": mix_bytes},
-            "roofline_generate": {"kernel": "k_generate_lean_harm<16> (+ k_prepare_segments; k_generate_lists<4, false> where a segment holds general or silent voices)", "bound": "hbm", "achieved": gen_bytes / (gen_ms / 1e3) / 1e9,
+            "roofline_generate": {"kernel": "k_generate_lean_harm<16, float> (+ k_prepare_segments; k_generate_lists<4, false> where a segment holds general or silent voices)", "bound": "hbm", "achieved": gen_bytes / (gen_ms / 1e3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gen_bytes / (gen_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                                   "traffic": tg["hbm_bytes"] if tg else None, "avg_launch_ms": gen_ms, "bytes_per_voice_sample": 4,
                                   "algorithmic_bytes": gen_bytes, "min_ms": sp_gen["min_ms"], "max_ms": sp_gen["max_ms"], "loops": sp_gen["loops"]},

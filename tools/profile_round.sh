@@ -3,7 +3,7 @@
 # (run through gpurun from the repo root; afterwards, here: python tools/summarize_profiles.py gpurun_out/prof_r01 r01)
 # Kernel durations and counters are separate runs: --pmc is never combined with a runtime / sys trace.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 D=gpurun_out/prof_$TAG
@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ
     --output-format csv -d "$D" -o sq2 -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
 # the other BASELINE configs that fit one GPU, each in passes of its own (bench.py --only-config: that config's steady-state loop
 # and nothing else), so that its kernels' durations and counters are not averaged with the headline's launches of the same kernel
-for CFG in config2 config3 staggered; do
+for CFG in config2 config3 staggered mixed job; do
   CMD="python bench.py --only-config $CFG"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o ${CFG}_stats -- $CMD > gpurun_out/prof_${TAG}_${CFG}.json 2>> gpurun_out/prof_${TAG}_stats.err
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$D" -o ${CFG}_fetch -- $CMD > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err

@@ -112,7 +112,7 @@ for fname, title in (("sq1_counter_collection.csv", "SQ instruction mix"), ("sq2
 # ---- the other BASELINE configs: passes of their own (bench.py --only-config), keys "configN:<kernel>" ----
 import json
 cfg_traffic, cfg_counters = {}, {}
-for cfg in ("config2", "config3", "staggered"):
+for cfg in ("config2", "config3", "staggered", "mixed", "job"):
     st = src / ("%s_stats_kernel_stats.csv" % cfg)
     if not st.exists():
         continue
@@ -126,7 +126,9 @@ for cfg in ("config2", "config3", "staggered"):
     lines += ["", "## %s: `rocprofv3 ... -- python bench.py --only-config %s`" % (cfg, cfg), ""]
     if row:
         for name, r in row.get("configs", {}).items():
-            if "ms_per_1s_block" in r or "ms_per_step" in r:
+            if "us_per_block" in r:
+                lines.append("bench row under rocprofv3: **%s** %.2f us per block over the ten blocks of the job (HIP events)" % (name, r["us_per_block"]))
+            elif "ms_per_1s_block" in r or "ms_per_step" in r:
                 lines.append("bench row under rocprofv3: **%s** %.2f us per 1-s block (HIP events), host enqueue %.1f us per block" %
                              (name, r.get("ms_per_1s_block", r.get("ms_per_step")) * 1e3, r.get("host_enqueue_us_per_block", float("nan"))))
         lines.append("")
