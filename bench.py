@@ -1164,7 +1164,7 @@ def main() -> int:
         g16_bytes, c16_bytes, p16_bytes = 2.0 * nv * F2, (2.0 * nv + 2.0) * F2, (2.0 * nv + 4.0) * F2
         tg16 = _by_prefix(prof["traffic"], "k_generate_lean_harm<16, short")
         cg16 = _by_prefix(prof["counters"], "k_generate_lean_harm<16, short")
-        tc16, tp16 = _by_prefix(prof["traffic"], "k_mix_chain_direct"), _by_prefix(prof["traffic"], "k_mix_chain_pan_direct")
+        tc16, tp16 = _by_prefix(prof["traffic"], "k_mix_chain_direct_s"), _by_prefix(prof["traffic"], "k_mix_chain_pan_direct_s")
 
         def hbm_roof(kernel, nbytes, ms, sp, traffic, per_unit_key, per_unit):
             return {"kernel": kernel, "bound": "hbm", "achieved": nbytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1188,8 +1188,8 @@ def main() -> int:
             "note": "the route upstream itself takes: oscillator block -> Sample.from_osc_block (int(32767 v)) -> [Sample.stereo(l, r)] -> "
                     "the mixer's audioop.add chain in voice order; byte for byte against the oracle + live audioop in tests/test_gpu_int_mixdown.py",
             "roofline_generate": rg16,
-            "roofline_mix": hbm_roof("k_mix_chain_direct<8,4>", c16_bytes, c16_ms, sp_c16, tc16, "bytes_per_sample", 2 * nv + 2),
-            "roofline_mix_stereo": hbm_roof("k_mix_chain_pan_direct<4,4>", p16_bytes, p16_ms, sp_p16, tp16, "bytes_per_frame", 2 * nv + 4),
+            "roofline_mix": hbm_roof("k_mix_chain_direct_s<4, 4, 8> (four samples per lane, eight row loads in flight)", c16_bytes, c16_ms, sp_c16, tc16, "bytes_per_sample", 2 * nv + 2),
+            "roofline_mix_stereo": hbm_roof("k_mix_chain_pan_direct_s<4, 4, 8> (audioop.tostereo per voice in registers: ten float64-rate operations per frame -- VALU-bound, not HBM-bound)", p16_bytes, p16_ms, sp_p16, tp16, "bytes_per_frame", 2 * nv + 4),
         }
         for b_ in (mono16, st16, rows16, vbuf):       # (rows16 may be a window of vbuf: freed before it)
             b_.free()
