@@ -1161,6 +1161,10 @@ def main() -> int:
                         min_seconds=0.25, reps=3, spread=sp_c16)
         p16_ms = steady(N, lambda: N.check(N.lib().sh_mix_chain_pan_i16(rows16.handle, nv, stride16, F2, fac.handle, st16.handle)),
                         min_seconds=0.25, reps=3, spread=sp_p16)
+        sp_f16 = {}
+        f16_ms = steady(N, lambda: bank.local.mixdown_i16_device(F2, Wm * F, out=mono16, check=False), min_seconds=0.25, reps=3, spread=sp_f16)
+        bank.local.overflow_check()
+        fused_stretches = N.lib().sh_get_option(N.SH_INFO_LAST_MIXDOWN_FUSED)
         g16_bytes, c16_bytes, p16_bytes = 2.0 * nv * F2, (2.0 * nv + 2.0) * F2, (2.0 * nv + 4.0) * F2
         tg16 = _by_prefix(prof["traffic"], "k_generate_lean_harm<16, short")
         cg16 = _by_prefix(prof["counters"], "k_generate_lean_harm<16, short")
@@ -1180,6 +1184,25 @@ def main() -> int:
             rg16["valu_f64"] = {"ops_per_voice_sample": ops16, "achieved": nv * F2 * ops16 / (g16_ms / 1e3) / 1e12, "peak": FP64_PEAK_TOPS,
                                 "unit": "T f64 lane-ops/s", "frac": nv * F2 * ops16 / (g16_ms / 1e3) / 1e12 / FP64_PEAK_TOPS,
                                 "all_valu_busy": (cg16.get("SQ_INSTS_VALU", 0) * 4.0 / 1024 / 2.4e9 / (g16_ms / 1e3)) or None}
+        # the mono mixdown without the rows (sh_bank_mixdown_i16): the samples enter the chain where they are made; what reaches HBM is one
+        # (a, L | U) map per frame and (64-voice chunk, half) -- 16 B x planes per frame, written once, read once -- and 2 B per frame of result
+        cf16 = _by_prefix(prof["counters"], "k_generate_lean_harm<16, short, true")
+        tf16 = _by_prefix(prof["traffic"], "k_generate_lean_harm<16, short, true")
+        tcomb = _by_prefix(prof["traffic"], "k_mixdown_combine")
+        fused_row = {"kernel": "k_generate_lean_harm<16, short, true> + k_mixdown_combine", "ms": f16_ms, "min_ms": sp_f16["min_ms"], "max_ms": sp_f16["max_ms"],
+                     "loops": sp_f16["loops"], "value": nv * F2 / (f16_ms / 1e3) / 1e6, "unit": "Msamples/s", "fused_stretches_of_last_call": fused_stretches,
+                     "x_two_step_i16": (g16_ms + c16_ms) / f16_ms,
+                     "hbm": {"bound": "hbm", "algorithmic_bytes": 2.0 * F2, "achieved": 2.0 * F2 / (f16_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": 2.0 * F2 / (f16_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": (tf16["hbm_bytes"] + tcomb["hbm_bytes"]) if tf16 and tcomb else None,
+                             "note": "2 B per output sample is all the route owes HBM: like the fused float path it is bound by float64 issue, below"}}
+        if cf16 and all(k in cf16 for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")):
+            opsf = (cf16["SQ_INSTS_VALU_FMA_F64"] + cf16["SQ_INSTS_VALU_MUL_F64"] + cf16["SQ_INSTS_VALU_ADD_F64"]) * 64.0 / (nv * F2)
+            fused_row["roofline"] = {"bound": "valu_f64", "ops_per_voice_sample": opsf, "achieved": nv * F2 * opsf / (f16_ms / 1e3) / 1e12, "peak": FP64_PEAK_TOPS,
+                                     "unit": "T f64 lane-ops/s", "frac": nv * F2 * opsf / (f16_ms / 1e3) / 1e12 / FP64_PEAK_TOPS,
+                                     "all_valu_busy": (cf16.get("SQ_INSTS_VALU", 0) * 4.0 / 1024 / 2.4e9 / (f16_ms / 1e3)) or None}
+        else:
+            fused_row["roofline"] = {"bound": "valu_f64", "note": "no counters for the fold kernel in profiles/ yet"}
         out["two_step_i16"] = {
             "frames_per_launch": F2, "voices": nv, "scale": 32767.0,
             "value": nv * F2 / ((g16_ms + c16_ms) / 1e3) / 1e6, "unit": "Msamples/s",
@@ -1189,6 +1212,7 @@ def main() -> int:
                     "the mixer's audioop.add chain in voice order; byte for byte against the oracle + live audioop in tests/test_gpu_int_mixdown.py",
             "roofline_generate": rg16,
             "roofline_mix": hbm_roof("k_mix_chain_direct_s<4, 4, 8> (four samples per lane, eight row loads in flight)", c16_bytes, c16_ms, sp_c16, tc16, "bytes_per_sample", 2 * nv + 2),
+            "fused_mono_mixdown": fused_row,
             "roofline_mix_stereo": hbm_roof("k_mix_chain_pan_direct_s<4, 4, 8> (audioop.tostereo per voice in registers: ten float64-rate operations per frame -- VALU-bound, not HBM-bound)", p16_bytes, p16_ms, sp_p16, tp16, "bytes_per_frame", 2 * nv + 4),
         }
         for b_ in (mono16, st16, rows16, vbuf):       # (rows16 may be a window of vbuf: freed before it)

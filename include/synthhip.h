@@ -205,7 +205,10 @@ int  sh_debug_counters(sh_counters* out);
  * 1: round(scale * v), half to even (Python 3's round) -- sh_quantize_f32 / sh_quantize_f64 follow it (the saturating [SPEC] forms,
  * sh_quantize_clip_f32 and sh_bank_render_pcm, and the fused sh_bank_generate_i16 do not: under 1 the latter refuses and the caller
  * quantises float64 rows).  Process-wide, like the stream.  Returns SH_ERR_INVALID for an unknown option. */
-typedef enum sh_option { SH_OPT_QUANTISE_ROUND = 1 } sh_option;
+typedef enum sh_option { SH_OPT_QUANTISE_ROUND = 1,
+                         SH_INFO_LAST_MIXDOWN_FUSED = 2   /* read-only (sh_get_option): how many stretches of the last sh_bank_mixdown_i16
+                                                           * call were folded where the samples are made (0: all through int16 rows) */
+} sh_option;
 int  sh_set_option(int option, int value);
 int  sh_get_option(int option);
 
@@ -342,6 +345,14 @@ int sh_bank_generate_i16(sh_bank* b, uint64_t start, uint32_t nframes, double sc
  * check met one, and lowers the flag -- is called: once per batch of blocks instead of a host round trip per block. */
 int sh_bank_generate_i16_async(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* voices_out, size_t stride);
 int sh_overflow_check(void);
+/* The MONO mixdown the reference's mixer makes of the bank -- every voice quantised like sh_bank_generate_i16, then mixed =
+ * audioop.add(mixed, voice, 2) down the voices in order -- without the rows: out[i], nframes int16 samples, equal byte for byte to
+ * sh_mix_chain_i16 of sh_bank_generate_i16's rows.  Where every voice of a 65 536-frame stretch takes the lean polynomial-Harmonics loop
+ * the samples enter the chain where they are made (a saturating chain over a range of voices is the map x -> clamp(x + a, L, U); such
+ * maps compose in voice order: the kernel leaves one per frame and (64-voice chunk, half), a second small kernel applies them); the
+ * other stretches go through int16 rows in a temporary and the chain kernel.  SH_ERR_OVERFLOW / _async / sh_overflow_check: as above. */
+int sh_bank_mixdown_i16(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* out_i16);
+int sh_bank_mixdown_i16_async(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* out_i16);
 int sh_bank_generate_rows_i16(sh_bank* b, uint64_t start, uint32_t nframes, const sh_buf* rows_f64, size_t row_stride,
                               double scale, sh_buf* voices_out, size_t stride);
 

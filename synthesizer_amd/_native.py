@@ -20,6 +20,7 @@ SH_ERR_INVALID, SH_ERR_HIP, SH_ERR_NOMEM, SH_ERR_NOTINIT, SH_ERR_OVERFLOW, SH_ER
 SH_SINE, SH_SAWTOOTH, SH_SQUARE, SH_PULSE, SH_HARMONICS, SH_TRIANGLE, SH_LINEAR, SH_NOISE, SH_BUFFER = range(9)
 SH_EW_ADD, SH_EW_MUL, SH_EW_CLIP, SH_EW_ABS, SH_EW_COPY, SH_EW_FILL, SH_EW_AXPY, SH_EW_NEXTUP = range(8)
 SH_OPT_QUANTISE_ROUND = 1
+SH_INFO_LAST_MIXDOWN_FUSED = 2
 SH_FM_NONE, SH_FM_SINE, SH_FM_BUFFER = range(3)
 SH_DIST_ID_BYTES = 128
 
@@ -114,6 +115,8 @@ _SIGNATURES = {
     "sh_bank_generate_i16": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_double, _P, C.c_size_t]),
     "sh_bank_generate_i16_async": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_double, _P, C.c_size_t]),
     "sh_overflow_check": (C.c_int, []),
+    "sh_bank_mixdown_i16": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_double, _P]),
+    "sh_bank_mixdown_i16_async": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_double, _P]),
     "sh_bank_generate_rows_i16": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_size_t, C.c_double, _P, C.c_size_t]),
     "sh_mix_bus_f32": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P, _P]),
     "sh_mix_chain_i16": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, _P]),

@@ -43,6 +43,7 @@ struct State {
     // grow-only scratch used by kernels that need a second pass (partial buses, scan sums, flags)
     void*       scratch = nullptr;
     size_t      scratch_bytes = 0;
+    int         last_mixdown_fused = 0;   // stretches of the last sh_bank_mixdown_i16 call that were folded where the samples are made (sh_get_option)
     int         quantise_round = 0;    // sh_set_option(SH_OPT_QUANTISE_ROUND): 1 = round half to even instead of truncation
     int*        flag = nullptr;        // device int: overflow flag for quantise
     int*        flag_host = nullptr;   // pinned host mirror

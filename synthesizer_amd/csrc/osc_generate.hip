@@ -9,6 +9,8 @@
 
 namespace {
 
+typedef int int2v __attribute__((ext_vector_type(2)));     // a plane element of the fused mixdown: (a, L | U << 16)
+
 // ---- the int16 forms (sh_bank_generate_i16): a row element is int(scale * v) of the float64 sample v -- Sample.from_osc_block's
 // quantiser (upstream synthplayer/sample.py; truncation toward zero, OverflowError where the value does not fit) applied where the
 // sample is made, so that a voice reaches HBM as 2 bytes instead of 4 (float32 row) + 4 read + 2 written by a quantise pass.
@@ -303,12 +305,23 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 // even lanes write the 128 bytes of frames [64 h, 64 h + 64), the odd lanes the 128 bytes behind them -- 256 contiguous bytes per
 // store instruction, as in the float32 form, for two frames per lane instead of one.  Per pair of samples: two products, two
 // conversions, the range check (min3 / max3), pack, swap, select -- against the 42 float64 operations that made the two samples.
-template <int FPL, typename OutT = float>
-__global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
+//
+// FOLD (sh_bank_mixdown_i16): the int16 samples are not stored at all -- they enter the reference mixer's chain, mixed =
+// audioop.add(mixed, voice, 2) down the voices in order, where they are made.  A saturating chain over a RANGE of voices is the map
+// x -> clamp(x + a, L, U) (a: the exact sum, L / U: what the rails have done to the bounds), and such maps compose in voice order:
+// a wave keeps (a, L, U) for its sixteen frames per lane in registers (a += s; L = add_sat(L, s); U = add_sat(U, s): one packed
+// instruction per two frames for each bound), walks its share of a chunk's records, and leaves ONE (a, L | U) pair per frame --
+// 8 bytes -- in plane blockIdx.y of `parts`; k_mixdown_combine applies the planes in order.  Where the int16 rows and the chain
+// kernel move 2 B + 2 B per voice-sample through HBM this moves 16 B per frame and plane (32 planes for 1024 voices: 0.5 B per
+// voice-sample) -- and the launch is bound by the same float64 arithmetic as the materialisation, so the chain pass disappears.
+template <int FPL, typename OutT = float, bool FOLD = false>
+__global__ __launch_bounds__(256, FOLD ? 3 : 4) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
                                                                uint32_t total, uint32_t seg_frames,
                                                                OutT* __restrict__ out32_all, size_t stride, SegTab tab, uint32_t rec_split,
-                                                               double scale = 0.0, int* __restrict__ flag = nullptr) {
+                                                               double scale = 0.0, int* __restrict__ flag = nullptr,
+                                                               int2v* __restrict__ parts = nullptr, size_t plane = 0) {
     constexpr bool I16 = RowOut<OutT>::I16;
+    static_assert(!FOLD || I16, "the fold is over int16 samples");
     __shared__ shm::sc_pair trig[shm::TRIG_N];
     for (uint32_t k = threadIdx.x; k < shm::TRIG_N; k += 256) trig[k] = trig_g[k];
     __syncthreads();
@@ -353,12 +366,31 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
     const uint32_t pair_word = ((lane & 1u) << 5) + (lane >> 1);
     const uint32_t pair_sel = (lane & 1u) ? 0x07060302u : 0x01000504u;      // v_perm_b32(own, neighbour's): odd lanes (n.hi, own.hi), even (own.lo, n.lo)
     int mx = 0, mn = 0;                                         // the largest / smallest integer any sample of this wave became
+    // (FOLD) the chain over this wave's records as x -> clamp(x + fa, fL, fU), per frame of the lane: the identity on int16 to begin with
+    typedef short short2p __attribute__((ext_vector_type(2)));
+    int fa[FOLD ? FPL : 1];
+    short2p fL[FOLD ? FPL / 2 : 1], fU[FOLD ? FPL / 2 : 1];
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) fa[j] = 0;
+#pragma unroll
+        for (int m = 0; m < FPL / 2; ++m) { fL[m] = (short2p){-32768, -32768}; fU[m] = (short2p){32767, 32767}; }
+    }
+    auto fold_pair = [&](int m, int a, int b) {                // frames 2m, 2m + 1 of the lane: one more voice in the chain
+        if constexpr (FOLD) {
+            const short2p s2 = __builtin_amdgcn_cvt_pk_i16(a, b);
+            fa[2 * m] += a;
+            fa[2 * m + 1] += b;
+            fL[m] = __builtin_elementwise_add_sat(fL[m], s2);
+            fU[m] = __builtin_elementwise_add_sat(fU[m], s2);
+        }
+    };
     auto store_pair = [&](OutT* row_tile, int m, double v0, double v1) {     // frames 2m, 2m + 1 of the lane's FPL (a full tile: all lanes active)
         if constexpr (I16) {
             const int a = (int)(scale * v0), b = (int)(scale * v1);          // float64 product, truncation toward zero
             mx = max(mx, max(a, b));
             mn = min(mn, min(a, b));
-            typedef short short2p __attribute__((ext_vector_type(2)));
+            if constexpr (FOLD) { fold_pair(m, a, b); return; }
             union { short2p v; uint32_t u; } w;
             w.v = __builtin_amdgcn_cvt_pk_i16(a, b);
             const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)w.u, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
@@ -420,8 +452,14 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
                     store_pair(row_tile, h / 2, p0 * s0, p1 * s1);
                 } else {                                           // the last tile of a row: frame by frame, two bytes each
                     const int a = (int)(scale * (p0 * s0)), b = (int)(scale * (p1 * s1));
-                    if (i0 + (uint32_t)h * 64u < n) { row[h * 64] = (short)a; mx = max(mx, a); mn = min(mn, a); }
-                    if (i0 + (uint32_t)(h + 1) * 64u < n) { row[(h + 1) * 64] = (short)b; mx = max(mx, b); mn = min(mn, b); }
+                    if constexpr (FOLD) {                          // (frames behind the row's end are folded too and never written; not range-checked)
+                        if (i0 + (uint32_t)h * 64u < n) { mx = max(mx, a); mn = min(mn, a); }
+                        if (i0 + (uint32_t)(h + 1) * 64u < n) { mx = max(mx, b); mn = min(mn, b); }
+                        fold_pair(h / 2, a, b);
+                    } else {
+                        if (i0 + (uint32_t)h * 64u < n) { row[h * 64] = (short)a; mx = max(mx, a); mn = min(mn, a); }
+                        if (i0 + (uint32_t)(h + 1) * 64u < n) { row[(h + 1) * 64] = (short)b; mx = max(mx, b); mn = min(mn, b); }
+                    }
                 }
                 if (h + 2 < FPL) {
                     if (straddle) {
@@ -476,6 +514,43 @@ __global__ __launch_bounds__(256, 4) void k_generate_lean_harm(const shm::sc_pai
         if (tile0 + 64 * FPL <= n) frames(std::true_type()); else frames(std::false_type());
     }
     if (I16 && (mx > 32767 || mn < -32768)) *flag = 1;
+    if constexpr (FOLD) {
+        // this wave's map for its tile, into the plane of its (chunk, part): frame f of the launch at parts[plane_index * plane + f]
+        int2v* __restrict__ dst = parts + (size_t)blockIdx.y * plane + seg_first + i0;
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            if (i0 + (uint32_t)j * 64u < n) {
+                const uint32_t lu = (uint32_t)(uint16_t)fL[j / 2][j & 1] | ((uint32_t)(uint16_t)fU[j / 2][j & 1] << 16);
+                __builtin_nontemporal_store((int2v){fa[j], (int)lu}, dst + j * 64);
+            }
+        }
+    }
+}
+
+// The planes of k_generate_lean_harm<.., FOLD> applied in order (plane = 64-voice chunk x part: voice order): out[f] = the chain's result.
+__global__ __launch_bounds__(256) void k_mixdown_combine(const int2v* __restrict__ parts, uint32_t nplanes, size_t plane, uint32_t first, uint32_t n,
+                                                         short* __restrict__ out) {
+    const uint32_t f = (uint32_t)(sh::block_id() * 256 + threadIdx.x);
+    if (f >= n) return;
+    const int2v* __restrict__ p = parts + first + f;
+    int x = 0;
+    uint32_t k = 0;
+    for (; k + 4 <= nplanes; k += 4) {                          // four planes in flight
+        int2v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(p + (size_t)(k + u) * plane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int L = (int)(short)(uint16_t)((uint32_t)v[u].y & 0xFFFFu), U = (int)(short)(uint16_t)((uint32_t)v[u].y >> 16);
+            x = min(max(x + v[u].x, L), U);
+        }
+    }
+    for (; k < nplanes; ++k) {
+        const int2v v = p[(size_t)k * plane];
+        const int L = (int)(short)(uint16_t)((uint32_t)v.y & 0xFFFFu), U = (int)(short)(uint16_t)((uint32_t)v.y >> 16);
+        x = min(max(x + v.x, L), U);
+    }
+    out[first + f] = (short)x;
 }
 
 // (Measured and dropped in round 3: the same materialisation walked ROW by row -- one record per workgroup held in SGPRs, contiguous runs
@@ -699,6 +774,104 @@ int sh_overflow_check(void) {
 int sh_bank_generate_i16(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* voices_out, size_t stride) {
     SH_API_LOCK();
     const int rc = sh_bank_generate_i16_async(b, start, nframes, scale, voices_out, stride);
+    if (rc || nframes == 0) return rc;
+    return sh_overflow_check();
+}
+
+// ---- the reference's mono mixdown without the rows (see k_generate_lean_harm, FOLD) ---------------------------------------------------
+namespace {
+
+// frames [f0, f0 + len) of the call through int16 rows in a temporary and the chain kernel: where a voice needs the general code (the
+// attack and decay of the notes, voices of other kinds), whose rows the fold would have to take in voice order between the lean ones
+int mixdown_two_step(sh_bank* b, uint64_t start, uint32_t len, double scale, short* out, int* flag) {
+    const size_t stride = ((size_t)len + 63) & ~(size_t)63;
+    sh::Temp rows;
+    int rc = rows.alloc((size_t)b->nvoices * stride * 2);
+    if (rc) return rc;
+    rc = generate_rows<short>(b, start, len, (short*)rows.buf.ptr, stride, scale, flag);
+    if (rc) return rc;
+    sh_buf o{out, (size_t)len * 2, false, 0};
+    return sh_mix_chain_i16(&rows.buf, b->nvoices, stride, len, &o);
+}
+
+int mixdown_fused(sh_bank* b, uint64_t start, uint32_t len, double scale, short* out, int* flag) {
+    constexpr uint32_t SEG = 65536;
+    hipStream_t st = sh::state().stream;
+    const uint32_t nchunks = sh::div_up(b->nvoices, 64), rsplit = 2, nplanes = nchunks * rsplit;
+    int lf = 16;
+    while (lf > 4 && (uint64_t)sh::div_up(len, 256 * lf) * nchunks < 512) lf /= 2;
+    const uint32_t nseg = sh::div_up(len, SEG);
+    LaunchSet base;
+    int rc;
+    if (nseg == 1) {
+        rc = acquire_records(b, start, len, st, false);
+        if (rc) return rc;
+        base = launch_set(b, b->cur);
+    } else {
+        rc = grow_segment_sets(b->gen_block, b->gen_set, b->gen_segs, nseg, b->nvoices);
+        if (rc) return rc;
+        base = b->gen_set;
+        rc = launch_prepare_segments(st, ptrs(b), base, b->nvoices, nseg, start, len, SEG);
+        if (rc) return rc;
+    }
+    sh::Temp parts;
+    rc = parts.alloc((size_t)nplanes * len * sizeof(int2v));
+    if (rc) return rc;
+    SegTab none;
+    none.n = 0;
+    const dim3 grid(sh::div_up(len, 256 * lf), nplanes);
+    const uint32_t seg_frames = nseg == 1 ? (len + 1023u) / 1024u * 1024u : SEG;
+#define SH_MIXDOWN(F_) hipLaunchKernelGGL((k_generate_lean_harm<F_, short, true>), grid, dim3(256), 0, st, trig_table(), base, b->nvoices, len, seg_frames, \
+                                          (short*)nullptr, (size_t)0, none, rsplit, scale, flag, (int2v*)parts.buf.ptr, (size_t)len)
+    if (lf == 16) SH_MIXDOWN(16); else if (lf == 8) SH_MIXDOWN(8); else SH_MIXDOWN(4);
+#undef SH_MIXDOWN
+    SH_CHECK_LAUNCH("k_generate_lean_harm(fold)");
+    hipLaunchKernelGGL(k_mixdown_combine, sh::grid1d(len, 256), dim3(256), 0, st, (const int2v*)parts.buf.ptr, nplanes, (size_t)len, 0u, len, out);
+    SH_CHECK_LAUNCH("k_mixdown_combine");
+    return SH_OK;
+}
+
+}  // namespace
+
+int sh_bank_mixdown_i16_async(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* out_i16) {
+    SH_REQUIRE_INIT();
+    if (!b || !out_i16) return sh::set_error(SH_ERR_INVALID, "sh_bank_mixdown_i16: NULL argument");
+    if (nframes > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_bank_mixdown_i16: at most 2^32 - 65536 frames per call");
+    if (out_i16->bytes / 2 < nframes) return sh::set_error(SH_ERR_INVALID, "sh_bank_mixdown_i16: output buffer too small");
+    int rc = bank_check_plain(b, "sh_bank_mixdown_i16");
+    if (rc || nframes == 0) return rc;
+    if (b->nvoices > 32768) return sh::set_error(SH_ERR_INVALID, "sh_bank_mixdown_i16: at most 32768 voices");
+    if (sh::state().quantise_round)
+        return sh::set_error(SH_ERR_INVALID, "sh_bank_mixdown_i16: the fused quantiser truncates; under SH_OPT_QUANTISE_ROUND quantise float64 rows and fold them (sh_mix_chain_i16)");
+    int* flag = sh::state().flag + 1;
+    short* out = (short*)out_i16->ptr;
+    // Stretches of whole 65 536-frame segments in which every voice takes the lean polynomial-Harmonics loop (its records then hold the
+    // bank in voice order, silent voices -- which add nothing to a chain -- left out) are folded where the samples are made; the others
+    // (the notes' attack and decay, banks with other kinds of voice, short calls) go through int16 rows and the chain kernel.
+    constexpr uint32_t SEG = 65536;
+    const bool lean_bank = !b->launch_rows && b->lean_candidates != 0 && b->lean_fm_candidates == 0 && b->all_lean && nframes >= 8192;
+    uint32_t f0 = 0;
+    sh::state().last_mixdown_fused = 0;
+    while (f0 < nframes && !rc) {
+        const uint32_t n0 = nframes - f0 < SEG ? nframes - f0 : SEG;
+        const bool fused = lean_bank && b->no_general_voice(start + f0, n0);
+        uint32_t f1 = f0 + n0;
+        while (f1 < nframes) {                                // extend the stretch while the next segment is of the same sort
+            const uint32_t n1 = nframes - f1 < SEG ? nframes - f1 : SEG;
+            if ((lean_bank && b->no_general_voice(start + f1, n1)) != fused) break;
+            if (!fused && f1 - f0 >= 4 * SEG) break;          // (two-step stretches: a temporary of nvoices x 2 B per frame each)
+            f1 += n1;
+        }
+        rc = fused ? mixdown_fused(b, start + f0, f1 - f0, scale, out + f0, flag) : mixdown_two_step(b, start + f0, f1 - f0, scale, out + f0, flag);
+        if (fused) sh::state().last_mixdown_fused += 1;
+        f0 = f1;
+    }
+    return rc;
+}
+
+int sh_bank_mixdown_i16(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* out_i16) {
+    SH_API_LOCK();
+    const int rc = sh_bank_mixdown_i16_async(b, start, nframes, scale, out_i16);
     if (rc || nframes == 0) return rc;
     return sh_overflow_check();
 }

@@ -318,6 +318,7 @@ int sh_set_option(int option, int value) {
 int sh_get_option(int option) {
     SH_API_LOCK();
     if (option == SH_OPT_QUANTISE_ROUND) return state().quantise_round;
+    if (option == SH_INFO_LAST_MIXDOWN_FUSED) return state().last_mixdown_fused;
     return sh::set_error(SH_ERR_INVALID, "sh_get_option: unknown option %d", option);
 }
 

@@ -376,15 +376,22 @@ class VoiceBank:
         return out
 
     def mixdown_i16_device(self, nframes: int, start: int = 0, scale: float = 32767.0,
-                           out: Optional[N.DeviceBuffer] = None) -> N.DeviceBuffer:
+                           out: Optional[N.DeviceBuffer] = None, check: bool = True, two_step: bool = False) -> N.DeviceBuffer:
         """The mono mixdown the reference's mixer makes of the voices: every voice quantised (``from_osc_block``), then
-        ``mixed = audioop.add(mixed, voice, 2)`` down the voices in order.  nframes int16 samples."""
-        rows, stride = self.generate_i16_device(nframes, start, scale)
+        ``mixed = audioop.add(mixed, voice, 2)`` down the voices in order.  nframes int16 samples.  The library folds the samples
+        into the chain where they are made wherever it can (``sh_bank_mixdown_i16``); ``two_step=True`` materialises the int16 rows
+        and runs the chain kernel over them -- the same bytes."""
         if out is None:
             out = N.DeviceBuffer(max(nframes * 2, 4))
-        if nframes:
+        if nframes == 0:
+            return out
+        if two_step or self._rows is not None or params.variants["quantise"] == "round":
+            rows, stride = self.generate_i16_device(nframes, start, scale, check=check)
             N.check(N.lib().sh_mix_chain_i16(rows.handle, self.nvoices, stride, nframes, out.handle))
-        rows.free()
+            rows.free()
+            return out
+        fn = N.lib().sh_bank_mixdown_i16 if check else N.lib().sh_bank_mixdown_i16_async
+        N.check(fn(self._bank.handle, start, nframes, float(scale), out.handle))
         return out
 
     def pan_factors_device(self) -> N.DeviceBuffer:

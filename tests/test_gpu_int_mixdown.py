@@ -235,3 +235,59 @@ def test_sine_peaks_on_rational_frequencies(gpu):
         rows, stride = VoiceBank(gv).generate_i16_device(1000, start)
         got_c = rows.download(np.int16, len(gv) * stride).reshape(len(gv), stride)[:, :1000]
         assert np.array_equal(got_c, want[:, :1000]), ("route B, short rows", start, np.argwhere(got_c != want[:, :1000])[:5])
+
+
+def test_fused_mixdown_equals_rows_plus_chain(gpu):
+    """sh_bank_mixdown_i16 folds the int16 samples into the mixer's chain where they are made (stretches in which every voice takes the
+    lean Harmonics loop) -- the bytes are those of sh_bank_generate_i16's rows folded by sh_mix_chain_i16, and of audioop.add over them."""
+    N = gpu
+    from oracle import c_oracle as CO
+    from oracle import synth_oracle as O
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    from synthesizer_amd.workloads import additive_voices
+
+    def fused_stretches():
+        return N.lib().sh_get_option(N.SH_INFO_LAST_MIXDOWN_FUSED)
+    # the bench's bank on its plateau: three 65 536-frame segments, a ragged end
+    gv, gains = additive_voices(G, 1024, SR, seed=0, partials=16, adsr={"sustain": 1.0e6})
+    bank = VoiceBank(gv, gains=gains)
+    start, n = 3 * SR + 11, 150001
+    fused = bank.mixdown_i16_device(n, start).download_bytes(n * 2)
+    assert fused_stretches() == 1
+    two = bank.mixdown_i16_device(n, start, two_step=True).download_bytes(n * 2)
+    assert fused == two
+    # from frame 0: the attack and decay go through the rows (general voices), the plateau behind them is folded -- one result
+    n0 = 3 * 65536 + 777
+    a = bank.mixdown_i16_device(n0, 0).download_bytes(n0 * 2)
+    assert fused_stretches() == 1
+    assert a == bank.mixdown_i16_device(n0, 0, two_step=True).download_bytes(n0 * 2)
+    # short calls and other kinds of bank: the rows route, same entry point
+    for m in (1, 100, 8191, 8192, 12345):
+        assert bank.mixdown_i16_device(m, start).download_bytes(m * 2) == bank.mixdown_i16_device(m, start, two_step=True).download_bytes(m * 2), m
+    fm = VoiceBank(_gpu_voices("fm", 80, 2)[0])
+    assert fm.mixdown_i16_device(20000, 1000).download_bytes(40000) == fm.mixdown_i16_device(20000, 1000, two_step=True).download_bytes(40000)
+    assert fused_stretches() == 0
+    # loud voices on their plateau: the chain saturates on the way and later voices pull it back -- against the oracle's samples
+    # quantised and folded by the live audioop
+    rng = np.random.default_rng(8)
+    nv, start, n = 70, SR, 70001
+    f, ph = rng.uniform(150.0, 1200.0, nv), rng.uniform(0.0, 1.0, nv)
+    harm = [(1, 1.0), (2, 0.3), (5, 0.1)]
+
+    def make(mod):
+        return [mod.EnvelopeFilter(mod.Harmonics(float(f[i]), harm, amplitude=0.6, phase=float(ph[i]), samplerate=SR), 0.01, 0.05, 30.0, 0.8, 0.1)
+                for i in range(nv)]
+    want_rows = np.stack([CO.quantise(CO.render(v, start + n)[start:]).astype(np.int16) for v in make(O)])
+    want = audioop_chain([r.tobytes() for r in want_rows])
+    assert want != np.clip(want_rows.astype(np.int64).sum(axis=0), -32768, 32767).astype(np.int16).tobytes()      # order matters here
+    loud = VoiceBank(make(G))
+    got = loud.mixdown_i16_device(n, start).download_bytes(n * 2)
+    assert fused_stretches() == 1
+    rows, stride = loud.generate_i16_device(n, start)
+    got_rows = rows.download(np.int16, nv * stride).reshape(nv, stride)[:, :n]
+    assert got == audioop_chain([r.tobytes() for r in got_rows])
+    if np.array_equal(got_rows, want_rows):
+        assert got == want
+    with pytest.raises(OverflowError):
+        VoiceBank([G.EnvelopeFilter(G.Harmonics(300.0, harm, amplitude=1.3, samplerate=SR), 0.01, 0.05, 30.0, 0.9, 0.1) for _ in range(64)]).mixdown_i16_device(70000, SR)
