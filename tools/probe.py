@@ -3,6 +3,7 @@
 
     python tools/probe.py <name> [args]
 
+    run-lengths us per block of ONE launch that renders B blocks (sh_bank_render_run), next to the two-stream pipeline of one-block launches
     staggered  bench.py's staggered_notes table (1024 players x 22 rounds, literal ADSR, tile-classified launches) with the players' instruments
     kinds      Fused render of a 1024-voice bank of MIXED lean kinds (Harmonics x16, FM Sine, Sine, Sawtooth, Square, Pulse; one-second blocks, steady
     late       Every oscillator kind far into a note (300 s at 48 kHz: 1.4e7 samples of accumulated phase) against the C oracle's float64 values: the plain
@@ -222,7 +223,47 @@ attack, decay and a dozen binades of the phase sum), timed as a whole -- next to
     print("10 s job from frame 0: %.1f us  = %.3f T voice-samples/s" % (best * 1e3, 1024 * 10 * SR / best / 1e9))
 
 
-PROBES = {"staggered": probe_staggered, "kinds": probe_kinds, "late": probe_late, "fm-long": probe_fm_long, "job": probe_job}
+def probe_run_lengths(argv):
+    """What ONE launch costs per block when it renders B blocks (sh_bank_render_run into a contiguous ring), launches one at a time -- a
+    caller that does not stream -- next to the two-stream pipeline of one-block launches.  The headline's bank; also config 3's FM bank."""
+    import statistics
+    import numpy as np
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd import workloads as W
+    from synthesizer_amd.mixer import VoiceBank
+    N.ensure_init(0)
+    SR = 48000
+    for name, (v, g) in (("1024 x Harmonics16 + ADSR (headline)", W.additive_voices(G, 1024, SR, seed=0, partials=16, adsr={"sustain": 1e6})),
+                         ("1024 x FM Sine (config 3)", W.fm_voices(G, 1024, SR, seed=1)),
+                         ("64 x Harmonics16 + ADSR (config 2)", W.additive_voices(G, 64, SR, seed=0, partials=16, adsr={"sustain": 1e6}))):
+        bank = VoiceBank(v, gains=g)
+        ring4 = [N.DeviceBuffer(SR * 8) for _ in range(4)]
+        pos = [100]
+        for _ in range(300):                                     # clocks up
+            bank.render_device(SR, pos[0] * SR, bus_f32=ring4[pos[0] & 3]); pos[0] += 1
+        N.sync()
+        N.timer_start()
+        for _ in range(400):
+            bank.render_device(SR, pos[0] * SR, bus_f32=ring4[pos[0] & 3]); pos[0] += 1
+        streamed = N.timer_stop() / 400 * 1e3
+        row = ["%-38s streamed, one block per launch on two streams: %6.2f us per block;  one launch at a time, B blocks per launch:" % (name, streamed)]
+        for B in (1, 2, 4, 8, 16):
+            ring = bank.make_ring(SR, B)
+            got = []
+            for rep in range(40):
+                for _ in range(3):                               # (keeps the clocks up; on other frames, pipelined)
+                    bank.render_device(SR, pos[0] * SR, bus_f32=ring4[pos[0] & 3]); pos[0] += 1
+                N.sync()
+                N.timer_start()
+                bank.render_run(SR, B, pos[0] * SR, ring=ring)
+                got.append(N.timer_stop() / B * 1e3)
+                pos[0] += B
+            row.append("  B = %2d: %6.2f us per block" % (B, statistics.median(got)))
+        print("\n".join(row), flush=True)
+
+
+PROBES = {"run-lengths": probe_run_lengths, "staggered": probe_staggered, "kinds": probe_kinds, "late": probe_late, "fm-long": probe_fm_long, "job": probe_job}
 
 if __name__ == "__main__":
     if len(sys.argv) < 2 or sys.argv[1] not in PROBES:
