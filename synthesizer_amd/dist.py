@@ -329,11 +329,22 @@ def shutdown() -> None:
     N.check(N.lib().sh_dist_shutdown())
 
 
-def device_for_rank(env=None) -> int:
-    """The GPU ordinal of this process: LOCAL_RANK as the launcher set it (one process per GPU on one node), else RANK, else 0.
-    Pure host logic (tests/test_host_logic.py maps eight ranks to eight distinct ordinals with it)."""
+def device_for_rank(env=None, visible: Optional[int] = None) -> int:
+    """The GPU ordinal of this process: LOCAL_RANK as the launcher set it (one process per GPU on one node), else RANK, else 0 -- unless
+    the launcher shows every rank exactly ONE GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set per process): then that one, ordinal 0.
+    ``visible``: how many GPUs this process sees (asked of the library for the real environment when it matters: LOCAL_RANK >= 1).
+    Pure host logic otherwise (tests/test_host_logic.py maps eight ranks to eight distinct ordinals with it)."""
+    real = env is None
     env = os.environ if env is None else env
-    return int(env.get("LOCAL_RANK", env.get("RANK", "0")))
+    r = int(env.get("LOCAL_RANK", env.get("RANK", "0")))
+    if visible is None and real and r > 0:
+        try:
+            visible = int(N.lib().sh_device_count())
+        except Exception:
+            visible = None
+    if visible == 1 and r > 0:
+        return 0
+    return r
 
 
 def comm_info() -> dict:

@@ -53,6 +53,10 @@ def test_rank_env_maps_eight_ranks_to_eight_ordinals():
     assert all(e["WORLD_SIZE"] == "8" and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == str(port) for e in envs)
     assert all(e["RANK"] == e["LOCAL_RANK"] == str(r) for r, e in enumerate(envs))
     assert all("SYNTHHIP_DEVICE" not in e and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+    # a launcher that shows every rank one GPU of its own (HIP_VISIBLE_DEVICES per process): each rank's device is ordinal 0
+    assert [dist.device_for_rank(e, visible=1) for e in envs] == [0] * 8
+    assert [dist.device_for_rank(e, visible=8) for e in envs] == list(range(8))
+    assert dist.device_for_rank(envs[5], visible=4) == 5            # fewer GPUs than ranks, more than one: sh_init refuses ordinal 5 loudly
 
 
 def _check_two_rank_line(d, launcher_prefix):
