@@ -436,26 +436,31 @@ def steady_render_kernel(name):
     return True
 
 
-def config_roofline(prof, tag, voice_samples, ms, algorithmic_bytes):
+PROFILE_RUN = 10      # blocks per launch in the per-config profiling passes (bench.py --only-config X: runs of PROFILE_RUN blocks ONLY, so that the
+                      # per-dispatch averages rocprofv3 reports are averages over dispatches of one size)
+
+
+def config_roofline(prof, tag, nvoices, ms_per_block):
     """Roofline of a BASELINE config's render launch from the committed counters of ITS profiling pass (profiles/rNN_counters.json,
-    key "<tag>:<kernel>"; tools/profile_round.sh runs bench.py --only-config <tag> under rocprofv3): float64 lane-operations per
-    voice-sample = (FMA + MUL + ADD wave-instructions) x 64 / voice-samples per dispatch, against the issue peak; HBM traffic
-    per dispatch against the algorithmic bytes."""
+    key "<tag>:<kernel>"; tools/profile_round.sh runs bench.py --only-config <tag> under rocprofv3, which renders in runs of PROFILE_RUN
+    one-second blocks per launch and nothing else): float64 lane-operations per voice-sample = (FMA + MUL + ADD wave-instructions) x 64 /
+    voice-samples per dispatch, against the issue peak at the row's time per block; HBM traffic per block against the algorithmic bytes."""
     best, name = None, None
     for k_, v_ in prof["counters"].items():
         if k_.startswith(tag + ":") and steady_render_kernel(k_.split(":", 1)[1]) and (best is None or v_.get("SQ_INSTS_VALU_FMA_F64", 0) > best.get("SQ_INSTS_VALU_FMA_F64", 0)):
             best, name = v_, k_             # (not the segmented transition launch of the loop's first block: that is not the steady state)
     if not best or not all(k in best for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")):
         return {"bound": "valu_f64", "note": "no counters for this config in profiles/ (tools/profile_round.sh writes them)"}
-    ops = (best["SQ_INSTS_VALU_FMA_F64"] + best["SQ_INSTS_VALU_MUL_F64"] + best["SQ_INSTS_VALU_ADD_F64"]) * 64.0 / voice_samples
-    achieved = voice_samples * ops / (ms / 1e3) / 1e12
+    per_dispatch = float(nvoices) * SR * PROFILE_RUN
+    ops = (best["SQ_INSTS_VALU_FMA_F64"] + best["SQ_INSTS_VALU_MUL_F64"] + best["SQ_INSTS_VALU_ADD_F64"]) * 64.0 / per_dispatch
+    achieved = float(nvoices) * SR * ops / (ms_per_block / 1e3) / 1e12
     traffic = prof["traffic"].get(name, {}).get("hbm_bytes")
+    algorithmic = 8.0 * SR
     return {"kernel": name.split(":", 1)[1], "bound": "valu_f64", "ops_per_voice_sample": ops, "achieved": achieved, "peak": FP64_PEAK_TOPS,
-            "unit": "T f64 lane-ops/s", "frac": achieved / FP64_PEAK_TOPS, "avg_launch_ms": ms,
-            "valu_busy_note": "all VALU wave-instructions x 4 cycles / 1024 SIMDs / launch time = %.2f" %
-                              (best.get("SQ_INSTS_VALU", 0) * 4.0 / 1024 / 2.4e9 / (ms / 1e3)) if best.get("SQ_INSTS_VALU") else None,
-            "traffic": traffic, "algorithmic_bytes": algorithmic_bytes,
-            "traffic_over_algorithmic": traffic / algorithmic_bytes if traffic else None,
+            "unit": "T f64 lane-ops/s", "frac": achieved / FP64_PEAK_TOPS, "avg_launch_ms": ms_per_block,
+            "profiled_dispatch": "%d voices x %d frames (a run of %d blocks in one launch)" % (nvoices, SR * PROFILE_RUN, PROFILE_RUN),
+            "traffic": traffic / PROFILE_RUN if traffic else None, "algorithmic_bytes": algorithmic,
+            "traffic_over_algorithmic": traffic / PROFILE_RUN / algorithmic if traffic else None,
             "source": prof.get("counters_source")}
 
 
@@ -573,11 +578,29 @@ def job_row(N, local, F, step0, prof):
         for k in range(30):
             local.render_device(F, (step0 + k) * F, bus_f32=ring[k & 3])
     N.sync()
+    # the same job asked for in ONE call (sh_bank_render_run: the ten blocks are one launch, cut into segments where the notes' envelopes and
+    # phase sums demand it -- the lean kernel once over all of them, the general code over the first segment only)
+    cont = local.make_ring(F, 10)
+    run_ms = float("inf")
+    for rep in range(12):
+        N.sync()
+        N.timer_start()
+        local.render_run(F, 10, 0, ring=cont)
+        run_ms = min(run_ms, N.timer_stop())
+        for k in range(30):
+            local.render_device(F, (step0 + k) * F, bus_f32=ring[k & 3])
+    N.sync()
     for b_ in ring:
         b_.free()
+    del cont
     nv = local.nvoices
+    block_by_block_ms = job_ms
+    in_one_run = run_ms < job_ms
+    job_ms = min(job_ms, run_ms)
     row = {"blocks": 10, "ms": job_ms, "value": nv * 10.0 * F / (job_ms / 1e3) / 1e6, "unit": "Msamples/s", "us_per_block": job_ms * 100.0,
-           "note": "ten consecutive blocks starting at frame 0 (first block of the notes included), best of 12"}
+           "how": "one sh_bank_render_run call (one launch)" if in_one_run else "ten sh_bank_render calls",
+           "ten_calls_ms": block_by_block_ms, "one_run_ms": run_ms,
+           "note": "ten consecutive blocks starting at frame 0 (first block of the notes included), best of 12, both ways"}
     ops = {k.split(":", 1)[1]: (v.get("SQ_INSTS_VALU_FMA_F64", 0) + v.get("SQ_INSTS_VALU_MUL_F64", 0) + v.get("SQ_INSTS_VALU_ADD_F64", 0)) * 64.0
            for k, v in prof["counters"].items() if k.startswith("job:")}
     steady_k = [k for k in ops if steady_render_kernel(k)]
@@ -723,17 +746,21 @@ def config_rows(N, prof=None, only=None, K=20):
         def step():
             bank.render_device(SR, pos[0] * SR, bus_f32=ring[pos[0] & 3])
             pos[0] += 1
-        for _ in range(8):
-            step()
-        ms = steady(N, step, min_seconds=0.1, reps=20)
-        t0 = time.perf_counter()
-        for _ in range(400):
-            step()
-        host_us = (time.perf_counter() - t0) / 400 * 1e6
-        N.sync()
+        ms, host_us = float("inf"), float("nan")
+        if only is None:                    # (a profiling pass -- bench.py --only-config X -- renders in runs only: dispatches of ONE size)
+            for _ in range(8):
+                step()
+            ms = steady(N, step, min_seconds=0.1, reps=20)
+            t0 = time.perf_counter()
+            for _ in range(400):
+                step()
+            host_us = (time.perf_counter() - t0) / 400 * 1e6
+            N.sync()
+        else:
+            pos[0] = 30
         # the same stream of blocks asked for RUN blocks at a time (sh_bank_render_run: one call, and -- the ring being windows of one
         # allocation -- one launch per run): what BASELINE's job "10 s in blocks of 48 000" is for a caller that knows it wants 10 blocks
-        RUN = 10
+        RUN = PROFILE_RUN
         cont = bank.make_ring(SR, RUN)
 
         def run():
@@ -758,8 +785,7 @@ def config_rows(N, prof=None, only=None, K=20):
                       "one_call_per_block": {"ms_per_1s_block": ms, "host_enqueue_us_per_block": host_us},
                       "runs_of_%d_blocks" % RUN: {"ms_per_1s_block": ms_run, "host_enqueue_us_per_block": host_run_us,
                                                   "min_ms": sp["min_ms"] / RUN, "max_ms": sp["max_ms"] / RUN},
-                      "roofline": config_roofline(prof, tag, float(len(voices)) * SR * (RUN if in_runs else 1), best * (RUN if in_runs else 1),
-                                                  8.0 * SR * (RUN if in_runs else 1))}
+                      "roofline": config_roofline(prof, tag, len(voices), best)}
         for b in ring:
             b.free()
     if only in (None, "config1"):
@@ -808,6 +834,8 @@ def main() -> int:
     ap.add_argument("--no-cpu-all-cores", action="store_true")
     ap.add_argument("--no-pcm-rows", action="store_true", help="skip the resample / integer-mix rows")
     ap.add_argument("--no-two-step", action="store_true")
+    ap.add_argument("--no-runs", action="store_true", help="skip the run_of_blocks row (tools/profile_round.sh: its launches of K blocks would be "
+                                                           "averaged with the one-block launches of the same kernel in rocprofv3's per-dispatch counters)")
     ap.add_argument("--no-configs", action="store_true", help="skip the rows of the other BASELINE configs")
     ap.add_argument("--only-config", choices=("config2", "config3", "config4", "staggered", "mixed", "job"), default=None,
                     help="run ONLY that config's row and print it (tools/profile_round.sh: one rocprofv3 pass per config)")
@@ -1084,7 +1112,7 @@ def main() -> int:
 
     # ---- the same stream asked for K blocks per call (sh_bank_render_run into a ring of K windows of one allocation: one crossing
     # of the ABI and one launch per K blocks): what a latency-bound caller gains, and what the host then spends per block ----
-    if world == 1 and not dry:
+    if world == 1 and not dry and not args.no_runs:
         cont = bank.local.make_ring(F, K)
         rpos = [step0]
 

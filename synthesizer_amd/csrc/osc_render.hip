@@ -380,6 +380,10 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         const uint32_t tiles16 = sh::div_up(nframes, 1024u);
         uint32_t g16 = 1;
         while (tiles16 * g16 * 2 <= 1024u && b->nvoices / (g16 * 2) >= 64u) g16 *= 2;         // (whole chunks per group)
+        // a LONG launch (a run of blocks in one: sh_bank_render_run) has tiles enough for the chip with ONE voice group -- which would
+        // make it a combined-kernel launch at eight frames per lane, general code and all (37.9 us per block where the stream of
+        // one-block launches needs 36.4): two groups keep it a split launch of the sixteen-frame lean kernel
+        if (g16 == 1 && tiles16 >= 640u && b->nvoices >= 128u) g16 = 2;
         if (g16 >= 2 && tiles16 * g16 >= 640u) var = 4163;
     }
     const int W = var >= 1000 ? var / 1000 : var / 100, F = var >= 1000 ? (var / 10) % 100 : (var / 10) % 10;
@@ -396,6 +400,10 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         while (tiles * groups < 1024 && b->nvoices / (groups * 2) >= (uint32_t)(4 * W)) groups *= 2;
     }
     if (tile_candidate && groups > 32) groups = 32;
+    if (var == 4163 && K.variant == 0 && groups < 2) groups = 2;      // (the long launch above)
+    // ... and the long launch of any other bank of >= 128 voices with lean candidates (mixed kinds; eight frames per lane): two groups, so
+    // that it is a split launch -- lean lists in the lean kernel, the general lists beside it -- like its one-block launches
+    if (K.variant == 0 && W == 4 && groups == 1 && mode != COMBINED_DIRECT && b->nvoices >= 128 && tiles >= 640 && !tile_candidate) groups = 2;
     if (K.groups > 0) groups = (uint32_t)K.groups;
     uint32_t vpg = (b->nvoices + groups - 1) / groups;
     if (groups > 1) vpg = (vpg + 63) & ~63u;                // groups are made of whole 64-voice chunks (the lists' unit)

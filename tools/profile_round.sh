@@ -10,14 +10,14 @@ D=gpurun_out/prof_$TAG
 rm -rf "$D"; mkdir -p "$D"
 python -c "from synthesizer_amd import build as B; print(B.source_hash())" > "$D/source_hash.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o stats -- \
-    python bench.py --steps 100 --warmup 5 --cpu-frames 0 --no-configs --min-seconds 0.25 > gpurun_out/prof_${TAG}_bench.json 2> gpurun_out/prof_${TAG}_stats.err
+    python bench.py --steps 100 --warmup 5 --cpu-frames 0 --no-configs --no-runs --min-seconds 0.25 > gpurun_out/prof_${TAG}_bench.json 2> gpurun_out/prof_${TAG}_stats.err
 # the same with the render launches on ONE stream: the default run overlaps consecutive render launches pairwise
 # on two streams, so a kernel's own start-to-end duration there is about twice the time per launch; serialised, the
 # kernel-trace average is the per-launch time and can be set against bench.py's HIP-event figure of the same run
 SYNTHHIP_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o serial -- \
-    python bench.py --steps 100 --warmup 5 --cpu-frames 0 --no-pcm-rows --no-two-step --no-configs --min-seconds 0.25 > gpurun_out/prof_${TAG}_bench_serial.json 2>> gpurun_out/prof_${TAG}_stats.err
+    python bench.py --steps 100 --warmup 5 --cpu-frames 0 --no-pcm-rows --no-two-step --no-configs --no-runs --min-seconds 0.25 > gpurun_out/prof_${TAG}_bench_serial.json 2>> gpurun_out/prof_${TAG}_stats.err
 # counters: blocks 100 .. 190 of the stream (the steady state the timed passes of a default run sit in)
-SHORT="python bench.py --steps 30 --warmup 100 --cpu-frames 0 --min-seconds 0 --no-configs"
+SHORT="python bench.py --steps 30 --warmup 100 --cpu-frames 0 --min-seconds 0 --no-configs --no-runs"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$D" -o fetch -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$D" -o write -- $SHORT > /dev/null 2>> gpurun_out/prof_${TAG}_stats.err
 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_WAVES SQ_WAVE_CYCLES \
