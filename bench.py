@@ -560,7 +560,7 @@ def staggered_row(N, F, prof=None):
                     "walk along the voice's table for the first tiles of a note -- general code for what is left)"}
 
 
-def job_row(N, local, F, step0, prof):
+def job_row(N, local, F, step0, prof, with_run=True):
     """BASELINE's job taken literally -- 10 s from frame 0 in blocks of F, the first block being the notes' attack, decay and a dozen
     binades of the phase sum (a segmented launch) -- best of 12, other frames rendered in between (the clocks stay up, block 0's records
     go cold).  roofline: the float64 lane-operations of ALL the job's kernels (profiles/rNN_counters.json, keys "job:<kernel>", from
@@ -582,7 +582,7 @@ def job_row(N, local, F, step0, prof):
     # phase sums demand it -- the lean kernel once over all of them, the general code over the first segment only)
     cont = local.make_ring(F, 10)
     run_ms = float("inf")
-    for rep in range(12):
+    for rep in range(12 if with_run else 0):       # (not in the profiling pass: its launch would be averaged with block 0's kernels of the same name)
         N.sync()
         N.timer_start()
         local.render_run(F, 10, 0, ring=cont)
@@ -901,7 +901,7 @@ def main() -> int:
         for k in range(60):                                    # (clocks up, on the frames the job's in-between renders use)
             local.render_device(F, (Wm + k) * F, bus_f32=warm[k & 3])
         print(json.dumps({"only_config": "job", "library": N.lib().sh_version().decode(),
-                          "configs": {"job_from_frame_0": job_row(N, local, F, Wm, committed_profile())}}), flush=True)
+                          "configs": {"job_from_frame_0": job_row(N, local, F, Wm, committed_profile(), with_run=False)}}), flush=True)
         return 0
     if args.only_config:
         rows = config_rows(N, committed_profile(), only=args.only_config, K=K)
