@@ -291,3 +291,28 @@ def test_fused_mixdown_equals_rows_plus_chain(gpu):
         assert got == want
     with pytest.raises(OverflowError):
         VoiceBank([G.EnvelopeFilter(G.Harmonics(300.0, harm, amplitude=1.3, samplerate=SR), 0.01, 0.05, 30.0, 0.9, 0.1) for _ in range(64)]).mixdown_i16_device(70000, SR)
+
+
+def test_int16_rows_and_mixdown_of_a_table_of_notes(gpu):
+    """Notes with onsets and envelopes of their own (DelayFilter fused into the records; silent voices, attacks, releases inside the
+    range): the int16 rows equal quantise(every voice's float64 block), and the mixdown -- rows route and fused route alike -- is
+    audioop's chain over them."""
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    from synthesizer_amd.sample import Sample
+    from synthesizer_amd.workloads import staggered_notes
+    voices, gains = staggered_notes(G, 48, SR, seed=4, partials=16, period=0.5, notes=4)
+    bank = VoiceBank(voices, gains=gains)
+    for start, n in ((0, 70000), (30000, 24001), (SR, 2 * 65536 + 100)):
+        rows, stride = bank.generate_i16_device(n, start)
+        got = rows.download(np.int16, len(voices) * stride).reshape(len(voices), stride)[:, :n]
+        for i in range(0, len(voices), 7):
+            want = np.frombuffer(Sample.from_osc_device(voices[i]._render_f64_device(start, n), n, SR).view_frame_data(), dtype=np.int16)
+            bad = np.nonzero(got[i] != want)[0]
+            assert len(bad) <= 1 and all(abs(int(got[i, j]) - int(want[j])) == 1 for j in bad), (start, n, i, bad[:4])
+        want_mono = audioop_chain([r.tobytes() for r in got])
+        assert bank.mixdown_i16_device(n, start).download_bytes(n * 2) == want_mono
+        assert bank.mixdown_i16_device(n, start, two_step=True).download_bytes(n * 2) == want_mono
+        want_st = audioop_chain([audioop.tostereo(r.tobytes(), 2, gl, gr) for r, (gl, gr) in zip(got, gains)])
+        assert bank.mixdown_stereo_i16_device(n, start).download_bytes(n * 4) == want_st
+        rows.free()
