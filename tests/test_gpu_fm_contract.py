@@ -128,3 +128,23 @@ def test_long_launch_over_several_lfo_piece_ends(gpu):
           % (start, rms(got_bus, want_bus), float(per_voice.max())))
     assert rms(got_bus, want_bus) <= 1e-6 / 3
     assert per_voice.max() <= 1e-6 / 3
+
+
+@pytest.mark.gpu
+def test_lfo_with_bias_minus_one(gpu):
+    """the closed form folds the LFO's bias into the carrier's frequency, f (1 + bias), and divides the sine part by it -- a
+    bias of -1 (the carrier sweeps through 0 Hz) or next to it takes the buffer path, which divides by nothing."""
+    from oracle import synth_oracle as O
+    from synthesizer_amd import _native as N
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    n = 6000
+    for bias in (-1.0, -1.0 + 2.0 ** -12, -0.999):
+        o = O.Sine(440.0, 0.8, phase=0.1, fm_lfo=O.Sine(5.0, 1.0, bias=bias, samplerate=SR), samplerate=SR)
+        g = G.Sine(440.0, 0.8, phase=0.1, fm_lfo=G.Sine(5.0, 1.0, bias=bias, samplerate=SR), samplerate=SR)
+        assert (g.spec().fm_mode == N.SH_FM_BUFFER) == (abs(1.0 + bias) < 2.0 ** -10)
+        assert rms(g.render_f64(n), np.array(o.take(n))) <= 1e-9, bias
+    gv = [G.Sine(300.0 + 10 * k, 0.5, fm_lfo=G.Sine(4.0 + k, 1.0, bias=-1.0, samplerate=SR), samplerate=SR) for k in range(4)]
+    ov = [O.Sine(300.0 + 10 * k, 0.5, fm_lfo=O.Sine(4.0 + k, 1.0, bias=-1.0, samplerate=SR), samplerate=SR) for k in range(4)]
+    want = np.array(O.mix_bus([v.take(n) for v in ov], [(0.5, 0.25)] * 4))
+    assert rms(VoiceBank(gv, gains=[(0.5, 0.25)] * 4).render(n), want) <= 1e-7

@@ -254,3 +254,28 @@ def test_mixer_of_every_sample_width(gpu, width):
     for r in rows[1:]:
         acc = audioop.add(acc, r, width)
     assert out.download_bytes(ns * width) == acc
+
+
+def test_a_sample_the_mixer_streams_from_is_never_mixed_into_in_place(gpu):
+    """Sample.mix adds in place when nothing grows -- but not into a buffer a RealTimeMixer reads (add_sample keeps the
+    Sample's device buffer by reference), and not when a sample is mixed into itself at an offset."""
+    import audioop
+    from synthesizer_amd.mixer import RealTimeMixer
+    from synthesizer_amd.sample import Sample
+    rng = np.random.default_rng(3)
+    a = rng.integers(-9000, 9000, 4096, dtype=np.int16)
+    b = rng.integers(-9000, 9000, 4096, dtype=np.int16)
+    s = Sample.from_raw_frames(a.tobytes(), 2, 8000, 1).to_device()
+    mixer = RealTimeMixer(2048)
+    mixer.add_sample(s)
+    s.mix(Sample.from_raw_frames(b.tobytes(), 2, 8000, 1))            # the Sample changes ...
+    assert bytes(s.view_frame_data()) == audioop.add(a.tobytes(), b.tobytes(), 2)
+    chunks = mixer.chunks()
+    got = bytes(next(chunks)) + bytes(next(chunks))
+    assert got == a.tobytes()[:4096]                                   # ... what the mixer plays does not (two chunks of 2048 bytes)
+    # a sample mixed into itself at an offset: source and destination overlap at shifted positions
+    t = Sample.from_raw_frames(a.tobytes(), 2, 8000, 1).to_device()
+    t.mix_at(0.1, t, other_seconds=0.2)                                # frames 800 .. 2400 += frames 0 .. 1600
+    want = a.copy().astype(np.int32)
+    want[800:2400] = np.clip(want[800:2400] + a[:1600].astype(np.int32), -32768, 32767)
+    assert np.array_equal(np.frombuffer(t.view_frame_data(), dtype=np.int16), want.astype(np.int16))
