@@ -69,9 +69,8 @@ def test_voice_shards_reduced_by_rccl_across_gpus(gpu, tmp_path):
         port = _free_port()
         procs = []
         for r in range(world):
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-            env.pop("SYNTHHIP_DEVICE", None)
+            from synthesizer_amd import dist
+            env = dist.rank_env(r, world, port)               # (what bench.py's own launcher gives its ranks)
             procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "multi_gpu_worker.py"), str(out)], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         logs = []
