@@ -28,7 +28,7 @@ def _run(cmd, env_extra=None, timeout=300):
 def _line(p):
     lines = [x for x in p.stdout.splitlines() if x.strip()]
     assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])        # ONE JSON line, from rank 0
-    return json.loads(lines[0])
+    return _check_compact(lines[0])
 
 
 def test_more_gpus_than_the_node_has_is_a_one_line_refusal():
@@ -69,6 +69,83 @@ def _check_two_rank_line(d, launcher_prefix):
     assert d["launcher"].startswith(launcher_prefix), d["launcher"]
     assert d["control_channel"]["barrier"].startswith("shared memory") or d["control_channel"]["barrier"] == "TCP"
     assert d["data"].startswith("dry-run") and d["passes"]["count"] >= 3 and d["value"] > 0
+    assert d["config"]["voice_shards"] == [[0, 1024], [1024, 2048]]
+
+
+def _check_compact(text):
+    """the one stdout line is <= 4 KB and json.loads()-able with the contract's keys."""
+    assert len(text.encode()) <= 4096, len(text.encode())
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    for k in ("workload", "voices_total", "frames_per_step", "samplerate"):
+        assert k in d["config"], k
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    return d
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_eight_rank_dry_run_prints_the_compact_line(scaling, tmp_path):
+    """The first real N = 8 run's plumbing: 8 ranks, voice shards tiling the table, one compact line from rank 0."""
+    detail = tmp_path / "detail.json"
+    p = _run([sys.executable, "bench.py", "--gpus", "8", "--scaling", scaling, "--steps", "10", "--warmup", "2", "--min-seconds", "0.05", "--detail", str(detail)],
+             {"SYNTHHIP_BENCH_DRY_RUN": "1"}, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [x for x in p.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = _check_compact(lines[0])
+    total = 8192
+    assert d["n_gpus"] == 8 and d["scaling"] == scaling and d["config"]["voices_total"] == total and d["config"]["voices_this_rank"] == 1024
+    shards = d["config"]["voice_shards"]
+    assert len(shards) == 8 and shards[0][0] == 0 and shards[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(shards, shards[1:])) and all(hi - lo == 1024 for lo, hi in shards)
+    ranks = d["rccl"]["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8)) and [r["device"] for r in ranks] == list(range(8))
+    assert len({r["pci"] for r in ranks}) == 8 and all(r["rccl_world"] == 8 for r in ranks) and d["rccl"]["world"] == 8
+    full = json.loads(detail.read_text())
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5) and "passes" in full and full["config"]["voice_shards"] == shards
+
+
+def test_compact_line_of_a_full_single_gpu_record_fits():
+    """A record with every side row a real N = 1 run produces (synthetic numbers, the r05 run's shapes and its long notes) still gives a
+    line of <= 4 KB that carries roofline.frac, cpu_baseline.value and the HBM-regime pair."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    note = "x" * 700
+    row = {"ms": 0.44, "bytes": 2689920000, "GBps": 6096.39, "frac_hbm": 0.762, "note": note}
+    out = {
+        "metric": "Msamples/sec mixed to stereo bus, 1024-voice additive @48kHz", "value": 1327000.123456789, "unit": "Msamples/s", "n_gpus": 1, "steps": 20,
+        "warmup": 5, "ms_per_step": 0.037, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "1024-voice additive (Harmonics x16 partials + ADSR) -> float32 stereo bus, 48 kHz, fused generate-and-mix, block 48000 frames",
+                   "voices_total": 1024, "voices_this_rank": 1024, "frames_per_step": 48000, "samplerate": 48000, "voice_shards": [[0, 1024]], "adsr": note, "parallelism": "single GPU"},
+        "passes": {"count": 7000, "steps_per_pass": 20, "timed_region_s": 5.5, "median_ms_per_step": 0.037, "min_ms_per_step": 0.0365, "max_ms_per_step": 0.05, "note": note},
+        "roofline": {"kernel": "k_render_lean<4, 16, 3, 0, false>", "bound": "valu_f64", "kernel_note": note, "clock_note": note, "achieved": 28.5, "peak": 39.3216,
+                     "unit": "T f64 lane-ops/s", "frac": 0.7251234, "ops_per_voice_sample": 21.25, "traffic": 29024800.0, "avg_launch_ms": 0.0366, "launches_in_flight": 2,
+                     "why": note, "hbm": {"bound": "hbm", "achieved": 10.4, "peak": 8000.0, "unit": "GB/s", "frac": 0.0013, "algorithmic_bytes": 384000.0,
+                                          "traffic_over_algorithmic": 75.6, "note": note}, "profile_stale": False, "profile_note": note, "timing_note": note},
+        "two_step": {"value": 700000.0, "roofline_mix": {"frac": 0.90, "achieved": 7200.0, "note": note}, "roofline_generate": {"frac": 0.55, "achieved": 4400.0}},
+        "two_step_i16": {"note": note, "rows": [row] * 8},
+        "configs": {"config1_sine_440Hz_1s_44k1_mono_to_host": {"ms": 0.043, "note": note}, "config2_additive_64v_adsr_48k_stereo": {"ms_per_1s_block": 0.0033, "note": note},
+                    "config3_fm_1024v_48k_stereo": {"ms_per_1s_block": 0.037, "note": note}, "config4_8192v_8gpu": {"note": note}},
+        "pcm_rows": dict({"resample_f32_8ch_600s_96k_to_44k1": row, "resample_i16_mono_44k1_to_48k_900MB": row, "mix_chain_i16_1024v_10s_stereo": row},
+                         **{"row%d" % k: row for k in range(30)}),
+        "int16_stream": {"ms_per_step": 0.037, "note": note}, "run_of_blocks": {"ms_per_step": 0.0366, "note": note}, "staggered_notes": {"ms_per_step": 0.043, "note": note},
+        "job_from_frame_0": {"ms": 0.5, "note": note},
+        "cpu_baseline": {"value": 1.0208, "unit": "Msamples/s", "cores": 1, "kind": "port", "sample": note, "sustain_window": {"note": note},
+                         "c_port": {"value": 8.02, "cores": 1}, "c_port_all_cores": {"value": 118.8, "cores": 64, "note": note}, "all_cores": {"note": note}},
+        "speedup_vs_cpu_baseline": 1300089.5, "verified": {"ok": True, "block_start_frame": 1, "abs_max": 0.5, "checksum_f64": 1.25, "note": note},
+        "rccl": {"world": 1, "rank": 0, "version": "2.27.7", "communicator": False, "ranks": [{"rank": 0, "local_rank": 0, "device": 0, "pci": "0000:05:00.0", "rccl_rank": 0, "rccl_world": 1}], "note": note},
+        "library": "synthhip 0.6 (gfx950) src:0123456789abcdef", "launcher": "none (one process)", "control_channel": {"data": None, "barrier": None},
+    }
+    assert len(json.dumps(out)) > 20000
+    d = _check_compact(bench.compact_line(out, "bench_detail.json"))
+    assert d["roofline"]["frac"] == pytest.approx(0.725123, rel=1e-5) and d["cpu_baseline"]["value"] == pytest.approx(1.0208)
+    assert d["cpu_baseline"]["c_port_all_cores"] == {"value": 118.8, "cores": 64} and d["speedup_vs_cpu_baseline"] > 1e6
+    assert d["roofline_hbm_regime"]["mix_frac"] == 0.9 and d["roofline_hbm_regime"]["generate_frac"] == 0.55
+    assert d["verified"]["ok"] is True and d["rccl"]["world"] == 1 and d["roofline"]["hbm"]["frac"] == 0.0013
+    assert d["side"]["config5_resample_f32_frac_hbm"] == 0.762 and "no reference oracle" in d["side"]["config5_oracle"]
+    assert "note" not in json.dumps(d["roofline"]) and d["detail"] == "bench_detail.json"
 
 
 def test_two_rank_dry_run_started_plainly():
