@@ -342,7 +342,10 @@ int sh_bank_generate_rows(sh_bank* b, uint64_t start, uint32_t nframes, const sh
 int sh_bank_generate_i16(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* voices_out, size_t stride);
 /* The streaming form: enqueues the same work and returns; a sample that does not fit raises a flag on the device that stays up until
  * sh_overflow_check() -- which waits for the stream, returns SH_ERR_OVERFLOW if any sh_bank_generate_i16_async since the last
- * check met one, and lowers the flag -- is called: once per batch of blocks instead of a host round trip per block. */
+ * check met one, and lowers the flag -- is called: once per batch of blocks instead of a host round trip per block.  The flag is
+ * ONE word per process: the synchronous forms (sh_bank_generate_i16, sh_bank_mixdown_i16) read and lower it too, so a synchronous
+ * call consumes -- and reports as its own -- an overflow still pending from an _async call of any bank; a synchronous call that
+ * fails with another error lowers it as well, so that nothing it raised is left for the next call. */
 int sh_bank_generate_i16_async(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* voices_out, size_t stride);
 int sh_overflow_check(void);
 /* The MONO mixdown the reference's mixer makes of the bank -- every voice quantised like sh_bank_generate_i16, then mixed =

@@ -314,8 +314,11 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 // 8 bytes -- in plane blockIdx.y of `parts`; k_mixdown_combine applies the planes in order.  Where the int16 rows and the chain
 // kernel move 2 B + 2 B per voice-sample through HBM this moves 16 B per frame and plane (32 planes for 1024 voices: 0.5 B per
 // voice-sample) -- and the launch is bound by the same float64 arithmetic as the materialisation, so the chain pass disappears.
+#ifndef SH_GEN_MINW
+#define SH_GEN_MINW 4              // wavefronts per SIMD the compiler budgets registers for (tools/ab.py build NAME -DSH_GEN_MINW=3: the A/B of round 6)
+#endif
 template <int FPL, typename OutT = float, bool FOLD = false>
-__global__ __launch_bounds__(256, FOLD ? 3 : 4) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
+__global__ __launch_bounds__(256, FOLD ? 3 : SH_GEN_MINW) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
                                                                uint32_t total, uint32_t seg_frames,
                                                                OutT* __restrict__ out32_all, size_t stride, SegTab tab, uint32_t rec_split,
                                                                double scale = 0.0, int* __restrict__ flag = nullptr,
@@ -771,10 +774,22 @@ int sh_overflow_check(void) {
     return SH_OK;
 }
 
+namespace {
+// A synchronous call that fails part-way (kernels already enqueued may have raised the flag) must not leave the process-wide word up
+// for the next, unrelated call: lower it on the stream, behind those kernels.  (The word is shared with the _async calls: a synchronous
+// call consumes whatever overflow is pending -- include/synthhip.h says so.)
+int sync_call_failed(int rc) {
+    sh::State& st = sh::state();
+    if (st.flag) (void)hipMemsetAsync(st.flag + 1, 0, sizeof(int), st.stream);
+    return rc;
+}
+}  // namespace
+
 int sh_bank_generate_i16(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* voices_out, size_t stride) {
     SH_API_LOCK();
     const int rc = sh_bank_generate_i16_async(b, start, nframes, scale, voices_out, stride);
-    if (rc || nframes == 0) return rc;
+    if (rc) return sync_call_failed(rc);
+    if (nframes == 0) return rc;
     return sh_overflow_check();
 }
 
@@ -860,6 +875,7 @@ int sh_bank_mixdown_i16_async(sh_bank* b, uint64_t start, uint32_t nframes, doub
             const uint32_t n1 = nframes - f1 < SEG ? nframes - f1 : SEG;
             if ((lean_bank && b->no_general_voice(start + f1, n1)) != fused) break;
             if (!fused && f1 - f0 >= 4 * SEG) break;          // (two-step stretches: a temporary of nvoices x 2 B per frame each)
+            if (fused && f1 - f0 >= 16 * SEG) break;          // (fused stretches: planes of 16 B per frame each -- 1024 voices: 0.5 GB per 2^20 frames; the chain is per frame, so cutting changes nothing)
             f1 += n1;
         }
         rc = fused ? mixdown_fused(b, start + f0, f1 - f0, scale, out + f0, flag) : mixdown_two_step(b, start + f0, f1 - f0, scale, out + f0, flag);
@@ -872,7 +888,8 @@ int sh_bank_mixdown_i16_async(sh_bank* b, uint64_t start, uint32_t nframes, doub
 int sh_bank_mixdown_i16(sh_bank* b, uint64_t start, uint32_t nframes, double scale, sh_buf* out_i16) {
     SH_API_LOCK();
     const int rc = sh_bank_mixdown_i16_async(b, start, nframes, scale, out_i16);
-    if (rc || nframes == 0) return rc;
+    if (rc) return sync_call_failed(rc);
+    if (nframes == 0) return rc;
     return sh_overflow_check();
 }
 
