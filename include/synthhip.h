@@ -135,6 +135,14 @@ typedef struct sh_voice {
      * envelope boundaries, FM sums and noise counters all count from the onset): upstream's DelayFilter(voice, seconds) with
      * seconds >= 0, start_frame = int(samplerate * seconds), fused into the voice.  0 for voices that read rows. */
     uint64_t start_frame;
+    /* ABI 6 -- the int16 boundary guard of a Harmonics voice in the polynomial or Clenshaw form (harm_dense 2 / 1).  Those forms sum
+     * a_k sin(k t) of the EXACT products k t where the reference rounds every `t * k` before its sine: the float64 samples part
+     * ways by up to guard_t * |t| + guard_c (t: the accumulated phase), far inside the float contract -- but where int(scale * v)
+     * of such a sample lies that close to an integer, the int16 routes (sh_bank_generate_i16, sh_bank_mixdown_i16) recompute it
+     * term by term from the voice's own list, guard_count sh_partial at partial[guard_offset] in the order of the reference's
+     * loop: equal integers whatever the time into the note.  guard_count = 0: no guard (the sample is quantised as it is). */
+    double   guard_t, guard_c;
+    uint32_t guard_offset, guard_count;
 } sh_voice;
 
 typedef struct sh_devinfo {
@@ -162,7 +170,7 @@ const char* sh_version(void);
 /* The binary interface this library was compiled with, so that a binding can refuse a library whose structs it would mis-pack
  * (a stale .so loaded by path: same symbols, other layouts): out[0] = SH_ABI_VERSION, then sizeof of sh_segment, sh_partial,
  * sh_envelope, sh_voice, sh_devinfo, sh_counters.  Writes min(n, 7) words, returns 7.  Callable before sh_init, without a GPU. */
-#define SH_ABI_VERSION 5
+#define SH_ABI_VERSION 6
 int  sh_abi(uint32_t* out, int n);
 int  sh_sync(void);                       /* wait for the stream */
 

@@ -105,6 +105,34 @@ def render(osc, n: int) -> np.ndarray:
     return out
 
 
+def render_window(osc, start: int, n: int) -> np.ndarray:
+    """Samples [start, start + n) of a non-FM waveform oscillator, optionally inside an EnvelopeFilter whose SUSTAIN holds the whole
+    window: the generator's loop entered at sample `start` -- its accumulated phase brought there by `start` additions (or_advance),
+    the envelope's sustain loop (`next(src) * sustain_level`) applied -- instead of `start` samples rendered and thrown away."""
+    env = None
+    if isinstance(osc, O.EnvelopeFilter):
+        env, osc = osc, osc._source
+        sr = osc.samplerate
+        assert (start - 2) / sr > env._attack + env._decay and (start + n + 2) / sr < env._attack + env._decay + env._sustain, "window outside the sustain"
+        assert not env._cycle
+    assert osc.fm is None and getattr(osc, "pwm", None) is None and O.VARIANTS["increment"] in ("mul", "div")
+    kind = _KIND[type(osc)]
+    radians = kind in (0, 4)
+    L = lib()
+    L.or_advance.restype = C.c_double
+    inc = O._increment(osc.frequency, osc.samplerate, radians)
+    t0 = osc._phase * 2.0 * pi if radians else osc._phase
+    t = L.or_advance(C.c_double(t0), C.c_double(inc), C.c_size_t(start))
+    hk = np.array([float(k) for k, _ in getattr(osc, "harmonics", [])] or [0.0], dtype=np.float64)
+    ha = np.array([float(a) for _, a in getattr(osc, "harmonics", [])] or [0.0], dtype=np.float64)
+    out = np.empty(n, dtype=np.float64)
+    L.or_osc_plain(kind, C.c_double(t), C.c_double(inc), C.c_double(osc.amplitude), C.c_double(osc.bias),
+                   C.c_double(float(getattr(osc, "pulsewidth", 0.0))), _dp(hk), _dp(ha), len(getattr(osc, "harmonics", [])), C.c_size_t(n), _dp(out))
+    if env is not None:
+        out *= env._sustain_level
+    return out
+
+
 def mix_bus(voices: np.ndarray, gains) -> np.ndarray:
     voices = np.ascontiguousarray(voices, dtype=np.float64)
     nv, n = voices.shape

@@ -56,6 +56,13 @@ void or_osc_plain(int kind, double t0, double inc, double amp, double bias, doub
     }
 }
 
+/* the accumulated phase after n samples: the `t += inc` of blocks(), n times, from t0 (what or_osc_plain holds when it reaches sample n) */
+double or_advance(double t0, double inc, size_t n) {
+    volatile double t = t0;
+    for (size_t i = 0; i < n; ++i) t = t + inc;
+    return t;
+}
+
 /* FM branch with a plain Sine LFO (lfo_t0, lfo_inc, lfo_amp, lfo_bias) */
 void or_osc_fm_sine(int kind, double frequency, double phase0, double inc, double amp, double bias, double pw,
                     const double* hk, const double* ha, int nh,

@@ -52,11 +52,12 @@ VOICE_DTYPE = np.dtype([
     ("lfo_a", "<f8"), ("lfo_d", "<f8"), ("lfo_amp", "<f8"), ("lfo_bias", "<f8"), ("lfo_K", "<f8"), ("lfo_C0", "<f8"),
     ("env", ENVELOPE_DTYPE),
     ("gain_l", "<f4"), ("gain_r", "<f4"),
-    ("noise_seed", "<u8"), ("noise_hold", "<u4"), ("reserved0", "<u4"), ("start_frame", "<u8")], align=True)
+    ("noise_seed", "<u8"), ("noise_hold", "<u4"), ("reserved0", "<u4"), ("start_frame", "<u8"),
+    ("guard_t", "<f8"), ("guard_c", "<f8"), ("guard_offset", "<u4"), ("guard_count", "<u4")], align=True)
 
 # sizes the C side must agree with (checked against the library's view in tests via sh_bank_create)
 assert SEGMENT_DTYPE.itemsize == 24 and PARTIAL_DTYPE.itemsize == 16 and ENVELOPE_DTYPE.itemsize == 80
-assert VOICE_DTYPE.itemsize == 248, VOICE_DTYPE.itemsize
+assert VOICE_DTYPE.itemsize == 272, VOICE_DTYPE.itemsize
 
 
 class Counters(C.Structure):
@@ -167,7 +168,7 @@ _SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 
 
-SH_ABI_VERSION = 5           # include/synthhip.h; bumped with every change of a struct layout or of an entry point's meaning
+SH_ABI_VERSION = 6           # include/synthhip.h; bumped with every change of a struct layout or of an entry point's meaning
 
 
 class NativeLibraryStale(ImportError):

@@ -343,6 +343,14 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             if (v.harm_dense == 1 && (v.harm_count & 7))
                 return sh::set_error(SH_ERR_INVALID, "voice %u: dense harmonic count %u is not a multiple of 8", i, v.harm_count);
         }
+        if (v.guard_count) {           // ABI 6: the term-by-term list behind a polynomial / Clenshaw form (the int16 boundary guard)
+            if (v.kind != SH_HARMONICS || v.harm_dense == 0 || v.fm_mode != SH_FM_NONE)
+                return sh::set_error(SH_ERR_INVALID, "voice %u: a guard list belongs to a Harmonics voice in the polynomial or Clenshaw form without FM", i);
+            if (v.guard_offset > npartials || v.guard_count > npartials - v.guard_offset)
+                return sh::set_error(SH_ERR_INVALID, "voice %u: guard list [%u,+%u) outside table of %u", i, v.guard_offset, v.guard_count, npartials);
+            if (!(v.guard_t >= 0.0 && v.guard_c >= 0.0 && v.guard_t < 1.0 && v.guard_c < 1.0))
+                return sh::set_error(SH_ERR_INVALID, "voice %u: guard bounds must be finite, >= 0 and < 1", i);
+        }
     }
     sh_bank* b = new (std::nothrow) sh_bank;
     if (!b) return sh::set_error(SH_ERR_NOMEM, "host allocation failed");

@@ -293,6 +293,10 @@ struct PrepInfo {                 // what prepare_voice found, for the classific
     uint32_t lfo_split;
     double   slope_l, slope_r;    // a record set of sloped lean records (SLOPED): gain(i) = gain + i * slope on the envelope's line
     double   poly[16];            // FL_POLY: the coefficients (read once, with the table pieces; the lean record is written from here)
+    // the int16 boundary guard of a lean polynomial-Harmonics record (sh_voice::guard_*): the voice's own list, and -- in one word --
+    // its length (low 8 bits) under the launch's tolerance as a float32 rounded UP to 24 bits (guard_t * |t| at the launch's end + guard_c)
+    uint64_t guard_ptr;
+    uint32_t guard_word;
 };
 
 // SLOPED (the record sets of a segmented transition launch): a polynomial-Harmonics voice on ONE envelope line of any slope is
@@ -382,6 +386,14 @@ __device__ __forceinline__ void prepare_voice(const BankPtrs& B, uint32_t first,
     o->dt = dt;
     o->remain = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rem;
     o->seg = lo;
+    info.guard_ptr = 0;
+    info.guard_word = 0;
+    if (v.guard_count != 0 && v.guard_count <= 255u) {
+        const double t_end = fabs(t_base) + (double)nframes * fabs(dt);     // (the pieces that follow inside the launch differ from dt by ulps)
+        const float tol = __double2float_ru(fma(v.guard_t, t_end, v.guard_c) * 1.000001);
+        info.guard_word = ((__float_as_uint(tol) + 0xFFu) & ~0xFFu) | v.guard_count;
+        info.guard_ptr = (uint64_t)(uintptr_t)(B.partials + v.guard_offset);
+    }
     if (rem >= (uint64_t)nframes) {                          // the launch stays on the piece: nothing follows inside it
 #pragma unroll
         for (int k = 0; k < NXP; ++k) o->nx_end[k] = 0xFFFFFFFFu;
@@ -664,8 +676,18 @@ __device__ __forceinline__ void prepare_chunk(const BankPtrs& B, const LaunchSet
         f->amplitude = SLOPED ? info.slope_l : info.amplitude;        // (SLOPED sets are read by the RENDER_LEAN_*_SEG kernels only)
         f->g0u = SLOPED ? info.slope_r : info.g0u;
         f->vi = vi;
-        f->pad1 = info.kind == LEAN_FM ? info.lfo_split : 0u;        // (LEAN_FM: where the LFO's table piece ends, 0xFFFFFFFF = not in this launch)
-        f->pad2 = info.kind == LEAN_FM ? info.lfo2_rot_s : 0.0;
+        // (LEAN_FM: where the LFO's table piece ends, 0xFFFFFFFF = not in this launch; LEAN_HARM: the int16 boundary guard, see PrepInfo)
+        uint32_t gw = info.guard_word;
+        if (info.kind == LEAN_HARM) {
+            // a record with a NaN or an infinity in it (amplitude, gain, coefficients, phase) gets an infinite tolerance: the int16 kernels
+            // then take every sample of it through the careful path, which raises the overflow flag for what is not a number
+            double z = (info.amplitude + info.g0u + info.t_base + info.dt + info.t0_b + info.dt_b) * 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) z = fma(info.poly[u], 0.0, z);
+            if (!(z == 0.0)) gw = 0x7F800000u | (gw & 0xFFu);
+        }
+        f->pad1 = info.kind == LEAN_FM ? info.lfo_split : info.kind == LEAN_HARM ? gw : 0u;
+        f->pad2 = info.kind == LEAN_FM ? info.lfo2_rot_s : info.kind == LEAN_HARM ? __longlong_as_double((long long)info.guard_ptr) : 0.0;
     }
     if (is_gen) S.gen_idx[c * 64 + (uint32_t)__popcll(mg & below)] = vi;
     // silent voices: listed from the END of the chunk's index slots (the render kernel never looks there; k_generate_lists
@@ -1039,6 +1061,40 @@ __device__ __forceinline__ void voice_block_at(const VoiceRegs& r, const VoiceFM
 #pragma unroll
     for (int j = 0; j < FPL; ++j)
         if (i[j] < d) x[j] = 0.0;
+}
+
+// ---- the int16 boundary guard (sh_voice::guard_*; include/synthhip.h) --------------------------------------------------------------
+// The polynomial and Clenshaw forms of a Harmonics voice lie up to T = guard_t |t| + guard_c beside the reference's term-by-term sum;
+// int(scale * v) of the two can differ only where an integer lies between them, i.e. where scale * v is within scale * T of one.
+// guard_near: is any sample of the wave's tile that close (or NaN)?  With tq = |scale| T: fract(scale v + tq) <= 2 tq.
+template <int FPL>
+__device__ __forceinline__ bool guard_near(const double (&x)[FPL], double scale, double tq) {
+    bool near = false;
+    const double tq2 = tq + tq;
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) near |= !(__builtin_amdgcn_fract(fma(scale, x[j], tq)) > tq2);
+    return __ballot(near) != 0ull;                           // (uniform)
+}
+// |scale| T of a voice's tile that ends at launch-relative frame tile_last; 0 = the voice has no guard (FM, other kinds, no list)
+__device__ __forceinline__ double guard_tq(const VoiceRegs& r, const sh_voice* __restrict__ vfull, uint32_t tile_last, double scale) {
+    if ((r.flags & (FL_POLY | FL_DENSE)) == 0 || (r.flags & (FL_FM | FL_SILENT)) != 0) return 0.0;
+    const sh_voice SH_CONST_AS* v = as_const(vfull);
+    if (v->guard_count == 0) return 0.0;
+    const double t_end = fabs(r.t_base) + ((double)tile_last + 1.0) * fabs(r.dt);
+    return fabs(scale) * (fma(v->guard_t, t_end, v->guard_c) * 1.000001);
+}
+// the tile again, term by term from the voice's own list (the general code's sparse form: sin(fl(t k)) a_k in list order)
+template <int FPL>
+__device__ __forceinline__ void voice_block_exact(VoiceRegs r, const VoiceFM* __restrict__ fmrec, const BankPtrs& B,
+                                                  const sh_voice* __restrict__ vfull, uint32_t tile_first, uint32_t tile_last,
+                                                  const uint32_t (&i)[FPL], const double (&di)[FPL],
+                                                  const double* __restrict__ fm_cumsum, const double* __restrict__ pwm,
+                                                  TrigTab trig, double (&x)[FPL]) {
+    const sh_voice SH_CONST_AS* v = as_const(vfull);
+    r.flags &= ~(FL_POLY | FL_DENSE);
+    r.harm = reinterpret_cast<const double SH_CONST_AS*>(as_const(B.partials) + v->guard_offset);
+    r.harm_cnt = v->guard_count;
+    voice_block_at<FPL, false>(r, fmrec, B, vfull, tile_first, tile_last, i, di, fm_cumsum, pwm, trig, x);
 }
 
 // One voice through the general code, accumulated into the lane's partial bus.  With more than four frames per lane

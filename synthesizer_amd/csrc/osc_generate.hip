@@ -79,6 +79,11 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate(BankPtrs B, 
                 pwm_p = pr >= 0 ? B.rows + (size_t)pr * B.row_stride : nullptr;
             }
             voice_block_at<FPL, false>(r, launch_fm + vi, B, B.voices + first + vi, tile0, tile_last, i, di, fm_p, pwm_p, trig, x);
+            if (out16) {       // the int16 boundary guard: a polynomial / Clenshaw sample whose int(scale * v) is in doubt is summed term by term
+                const double tq = guard_tq(r, B.voices + first + vi, tile_last, scale16);
+                if (tq != 0.0 && guard_near<FPL>(x, scale16, tq))
+                    voice_block_exact<FPL>(r, launch_fm + vi, B, B.voices + first + vi, tile0, tile_last, i, di, fm_p, pwm_p, trig, x);
+            }
         }
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
@@ -260,9 +265,22 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
             for (int j = 0; j < FPL; ++j) x[j] = kind == LEAN_SINE ? sn[j] : pv[j] * sn[j];
         }
 #pragma unroll
+        for (int j = 0; j < FPL; ++j) x[j] = (x[j] * amp + 0.0) * g0u;
+        if constexpr (RowOut<OutT>::I16) {
+            // the int16 boundary guard of a polynomial-Harmonics record (FastRec::pad1: the launch's tolerance above the list's length)
+            const uint32_t gword = q->pad1;
+            if (kind == LEAN_HARM && (gword & 0xFFu) != 0) {
+                const double tq = fabs(scale) * (double)__uint_as_float(gword & ~0xFFu);
+                if (guard_near<FPL>(x, scale, tq)) {
+                    const VoiceRegs r = load_record(as_const(cur.launch) + vi);
+                    voice_block_exact<FPL>(r, cur.fm + vi, B, B.voices + vi, tile0, tile_last, i, di, nullptr, nullptr, trig, x);
+                }
+            }
+        }
+#pragma unroll
         for (int j = 0; j < FPL; ++j) {
             const uint32_t raw = tile0 + j * 64 + lane;
-            if (raw < n) out32[(size_t)vi * stride + raw] = RowOut<OutT>::make((x[j] * amp + 0.0) * g0u, scale, bad);
+            if (raw < n) out32[(size_t)vi * stride + raw] = RowOut<OutT>::make(x[j], scale, bad);
         }
     }
     const uint32_t SH_CONST_AS* idx = as_const(cur.gen_idx) + c * 64;
@@ -271,6 +289,11 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
         const VoiceRegs r = load_record(as_const(cur.launch) + vi);
         double x[FPL];
         voice_block_at<FPL, false>(r, cur.fm + vi, B, B.voices + vi, tile0, tile_last, i, di, nullptr, nullptr, trig, x);
+        if constexpr (RowOut<OutT>::I16) {
+            const double tq = guard_tq(r, B.voices + vi, tile_last, scale);
+            if (tq != 0.0 && guard_near<FPL>(x, scale, tq))
+                voice_block_exact<FPL>(r, cur.fm + vi, B, B.voices + vi, tile0, tile_last, i, di, nullptr, nullptr, trig, x);
+        }
 #pragma unroll
         for (int j = 0; j < FPL; ++j) {
             const uint32_t raw = tile0 + j * 64 + lane;
@@ -318,7 +341,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 #define SH_GEN_MINW 4              // wavefronts per SIMD the compiler budgets registers for (tools/ab.py build NAME -DSH_GEN_MINW=3: the A/B of round 6)
 #endif
 template <int FPL, typename OutT = float, bool FOLD = false>
-__global__ __launch_bounds__(256, FOLD ? 3 : SH_GEN_MINW) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
+__global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3 : SH_GEN_MINW) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
                                                                uint32_t total, uint32_t seg_frames,
                                                                OutT* __restrict__ out32_all, size_t stride, SegTab tab, uint32_t rec_split,
                                                                double scale = 0.0, int* __restrict__ flag = nullptr,
@@ -379,25 +402,33 @@ __global__ __launch_bounds__(256, FOLD ? 3 : SH_GEN_MINW) void k_generate_lean_h
 #pragma unroll
         for (int m = 0; m < FPL / 2; ++m) { fL[m] = (short2p){-32768, -32768}; fU[m] = (short2p){32767, 32767}; }
     }
-    auto fold_pair = [&](int m, int a, int b) {                // frames 2m, 2m + 1 of the lane: one more voice in the chain
-        if constexpr (FOLD) {
-            const short2p s2 = __builtin_amdgcn_cvt_pk_i16(a, b);
-            fa[2 * m] += a;
-            fa[2 * m + 1] += b;
-            fL[m] = __builtin_elementwise_add_sat(fL[m], s2);
-            fU[m] = __builtin_elementwise_add_sat(fU[m], s2);
-        }
-    };
-    auto store_pair = [&](OutT* row_tile, int m, double v0, double v1) {     // frames 2m, 2m + 1 of the lane's FPL (a full tile: all lanes active)
+    // ---- int16 (rows and FOLD): a record's sixteen samples are quantised into registers first -- w[m] = frames 2m, 2m + 1 of the lane,
+    // packed -- checked against the boundary guard (below), and only then stored / folded.
+    constexpr int NQ = I16 ? (FPL / 4) : 1;                     // a record's frames in quarters of four per lane: what the guard redoes at a time
+    short2p w[I16 ? FPL / 2 : 1];
+    int qmx[NQ], qmn[NQ];                                       // largest / smallest integer of each quarter's (valid) samples
+    uint64_t nearm[NQ];                                         // (uniform) lanes with a sample of quarter h within the guard's reach of an integer
+    uint32_t nearv[NQ];                                         // the smallest high word of fract(scale v + tq) among the lane's frames of quarter h
+    double tq = 0.0;                                            // (uniform) the record's guard distance in integer units
+    double tqm = 0.0;                                           // (uniform) tq + 1.5 * 2^20
+    uint32_t near_lo = 0;                                       // (uniform) 2 tq in units of 2^-32, plus two; 0xFFFFFFFF: every sample (a record that holds a NaN)
+    const bool full_tile = tile0 + 64 * FPL <= n;
+    // frames 2m, 2m + 1 of the lane: int(scale * v) -- as int(scale v + tq): the same integer unless scale v lies within tq of one, which
+    // is what frac(scale v + tq) <= 2 tq says; those samples are redone below (the boundary guard)
+    auto quant_pair = [&](int m, double v0, double v1, bool ok0, bool ok1) {
         if constexpr (I16) {
-            const int a = (int)(scale * v0), b = (int)(scale * v1);          // float64 product, truncation toward zero
-            mx = max(mx, max(a, b));
-            mn = min(mn, min(a, b));
-            if constexpr (FOLD) { fold_pair(m, a, b); return; }
-            union { short2p v; uint32_t u; } w;
-            w.v = __builtin_amdgcn_cvt_pk_i16(a, b);
-            const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)w.u, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-            __builtin_nontemporal_store((int)__builtin_amdgcn_perm(w.u, nb, pair_sel), reinterpret_cast<int*>(row_tile) + 64 * m + pair_word);
+            const double s0q = fma(scale, v0, tq), s1q = fma(scale, v1, tq);
+            const int a = (int)s0q, b = (int)s1q;               // float64 product, truncation toward zero
+#ifndef SH_AB_NO_GUARD_CHECK            // (tools/ab.py build NAME -DSH_AB_NO_GUARD_CHECK: what the check itself costs)
+            // The fraction of scale v + tq as an integer: added to 1.5 * 2^20 (an ulp there is 2^-32) the sum's LOW WORD is
+            // frac(scale v + tq) * 2^32 -- one FMA per sample, no v_fract_f64 (a quarter-rate instruction: with it the check cost 13-17 %
+            // of the kernel, a compare per frame into a scalar register pair 18 %; profiles/r06_guard_ab.txt).  The SMALLEST low word of
+            // the quarter's samples is kept -- one v_min3_u32 per pair -- and compared once per record with 2 tq * 2^32 (+ 2: rounding).
+            nearv[m / 2] = min(nearv[m / 2], min((uint32_t)__double2loint(fma(scale, v0, tqm)), (uint32_t)__double2loint(fma(scale, v1, tqm))));
+#endif
+            qmx[m / 2] = max(qmx[m / 2], max(ok0 ? a : 0, ok1 ? b : 0));
+            qmn[m / 2] = min(qmn[m / 2], min(ok0 ? a : 0, ok1 ? b : 0));
+            w[m] = __builtin_amdgcn_cvt_pk_i16(a, b);
         }
     };
     for (uint32_t p = p_lo; p < nfast; ++p, ++q) {
@@ -437,8 +468,25 @@ __global__ __launch_bounds__(256, FOLD ? 3 : SH_GEN_MINW) void k_generate_lean_h
         const double ag = amp * g0u;
         s0 *= ag;
         s1 *= ag;
-        auto frames = [&](auto full_tile) {
-            constexpr bool FULL = decltype(full_tile)::value;
+        uint32_t gword = 0;
+        if constexpr (I16) {
+            gword = q->pad1;                                       // the boundary guard: tolerance (float32, 24 bits, rounded up) | length of the list
+            const double tol = fabs(scale) * (double)__uint_as_float(gword & ~0xFFu);
+            if (tol < 0.125) {
+                tq = tol >= 0x1p-31 ? tol : 0x1p-31;               // (at least two steps of the 2^-32 grid the check works on)
+                near_lo = (uint32_t)((tq + tq) * 0x1p32) + 2u;
+            } else {
+                // a record with a non-finite value carries an infinite tolerance (prepare_chunk), and a tolerance of 1/8 or more cannot be
+                // told from one: every sample is redone, and what is not a number is flagged there
+                tq = 0.0;
+                near_lo = 0xFFFFFFFFu;
+            }
+            tqm = tq + 0x1.8p20;
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) { qmx[h] = 0; qmn[h] = 0; nearv[h] = 0xFFFFFFFFu; }
+        }
+        auto frames = [&](auto full_tile_t) {
+            constexpr bool FULL = decltype(full_tile_t)::value;
 #pragma unroll
             for (int h = 0; h < FPL; h += 2) {
                 double p0 = fma(poly[0], c0, poly[1]), p1 = fma(poly[0], c1, poly[1]);
@@ -451,18 +499,8 @@ __global__ __launch_bounds__(256, FOLD ? 3 : SH_GEN_MINW) void k_generate_lean_h
                 if constexpr (!I16) {
                     if (FULL || i0 + (uint32_t)h * 64u < n) __builtin_nontemporal_store((float)(p0 * s0), row + h * 64);
                     if (FULL || i0 + (uint32_t)(h + 1) * 64u < n) __builtin_nontemporal_store((float)(p1 * s1), row + (h + 1) * 64);
-                } else if constexpr (FULL) {
-                    store_pair(row_tile, h / 2, p0 * s0, p1 * s1);
-                } else {                                           // the last tile of a row: frame by frame, two bytes each
-                    const int a = (int)(scale * (p0 * s0)), b = (int)(scale * (p1 * s1));
-                    if constexpr (FOLD) {                          // (frames behind the row's end are folded too and never written; not range-checked)
-                        if (i0 + (uint32_t)h * 64u < n) { mx = max(mx, a); mn = min(mn, a); }
-                        if (i0 + (uint32_t)(h + 1) * 64u < n) { mx = max(mx, b); mn = min(mn, b); }
-                        fold_pair(h / 2, a, b);
-                    } else {
-                        if (i0 + (uint32_t)h * 64u < n) { row[h * 64] = (short)a; mx = max(mx, a); mn = min(mn, a); }
-                        if (i0 + (uint32_t)(h + 1) * 64u < n) { row[(h + 1) * 64] = (short)b; mx = max(mx, b); mn = min(mn, b); }
-                    }
+                } else {                                           // (the last tile of a row: frames behind its end are quantised too, never range-checked or written)
+                    quant_pair(h / 2, p0 * s0, p1 * s1, FULL || i0 + (uint32_t)h * 64u < n, FULL || i0 + (uint32_t)(h + 1) * 64u < n);
                 }
                 if (h + 2 < FPL) {
                     if (straddle) {
@@ -478,7 +516,7 @@ __global__ __launch_bounds__(256, FOLD ? 3 : SH_GEN_MINW) void k_generate_lean_h
                 }
             }
         };
-        if (!straddle && tile0 + 64 * FPL <= n && FPL % 4 == 0) {
+        if (!straddle && full_tile && FPL % 4 == 0) {
             // the common case (a whole tile on one phase-table piece) as straight-line code (round 4): four Horner chains at a time, no
             // branch between the frames -- the general form below asks `straddle` after every pair of frames, eight uniform branches
             // per record that end a basic block each.  0.476 -> 0.458 ms per 1024 x 480 000 samples (profiles/r04_generate_ab.txt); at five
@@ -505,16 +543,99 @@ __global__ __launch_bounds__(256, FOLD ? 3 : SH_GEN_MINW) void k_generate_lean_h
                     for (int jj = 0; jj < 4; ++jj) pv[jj] = fma(pv[jj], cv[jj], poly[u]);
                 }
                 if constexpr (I16) {
-                    store_pair(row_tile, h / 2, pv[0] * sv[0], pv[1] * sv[1]);
-                    store_pair(row_tile, h / 2 + 1, pv[2] * sv[2], pv[3] * sv[3]);
+                    quant_pair(h / 2, pv[0] * sv[0], pv[1] * sv[1], true, true);
+                    quant_pair(h / 2 + 1, pv[2] * sv[2], pv[3] * sv[3], true, true);
                 } else {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) __builtin_nontemporal_store((float)(pv[jj] * sv[jj]), row + (h + jj) * 64);
                 }
             }
-            continue;
+        } else if (full_tile) {
+            frames(std::true_type());
+        } else {
+            frames(std::false_type());
         }
-        if (tile0 + 64 * FPL <= n) frames(std::true_type()); else frames(std::false_type());
+        if constexpr (I16) {
+            // ---- the boundary guard (sh_voice::guard_*): the polynomial form is sum a_k sin(k t) of the EXACT products k t, the reference
+            // rounds every t * k before its sine -- up to guard_t |t| + guard_c apart, and where scale * v lies that close to an integer the two
+            // truncate differently.  Such a sample (one record in ~10^4 of the benchmark's voices ten seconds into their notes) is summed
+            // term by term from the voice's own list, like the reference's loop: a quarter of the record (four frames per lane) at a time,
+            // every frame from a table lookup of its own, the lanes in reach of an integer through the list. ----
+            uint64_t any_near = 0;
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) {
+                nearm[h] = __builtin_amdgcn_ballot_w64(nearv[h] <= near_lo);
+                any_near |= nearm[h];
+            }
+            if (any_near != 0) {
+                const uint32_t glen = gword & 0xFFu;
+                const sh_partial SH_CONST_AS* gl = reinterpret_cast<const sh_partial SH_CONST_AS*>((uintptr_t)__double_as_longlong(q->pad2));
+#pragma unroll 1
+                for (int h = 0; h < NQ; ++h) {
+                    uint64_t nm = 0;
+#pragma unroll
+                    for (int hh = 0; hh < NQ; ++hh) nm = h == hh ? nearm[hh] : nm;
+                    if (nm == 0) continue;
+                    int aa[4], lo = 0, hi = 0;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 4 * h + jj;
+                        const double t = theta(j);
+                        double sn, cs;
+                        shm::sincos_tab(t, trig, sn, cs);
+                        double pv = fma(poly[0], cs, poly[1]);
+#pragma unroll
+                        for (int u = 2; u < 16; ++u) pv = fma(pv, cs, poly[u]);
+                        const double sq = fma(scale, pv * (sn * ag), tq);
+                        const bool nr = (uint32_t)__double2loint(fma(scale, pv * (sn * ag), tqm)) <= near_lo || !(sq == sq);
+                        int a = (int)sq;
+                        if (__ballot(nr) != 0ull) {               // (uniform) some lane's frame j is in reach of an integer
+                            if (nr) {
+                                double hs = 0.0;                   // the reference's loop: sum of sin(fl(t * k)) * a_k in list order
+                                for (uint32_t k = 0; k < glen; ++k) {
+                                    double ks, kc;
+                                    shm::sincos_tab(t * gl[k].k, trig, ks, kc);
+                                    hs += ks * gl[k].amp;
+                                }
+                                const double ex = glen ? scale * (((hs * amp) + 0.0) * g0u) : scale * (pv * (sn * ag));
+                                a = (ex >= -2147483000.0 && ex <= 2147483000.0) ? (int)ex : 0x7FFFFFFF;     // (NaN, like anything beyond int16: OverflowError)
+                            }
+                        }
+                        aa[jj] = a;
+                        const bool ok = full_tile || i0 + (uint32_t)j * 64u < n;
+                        hi = max(hi, ok ? a : 0);
+                        lo = min(lo, ok ? a : 0);
+                    }
+                    const short2p w0 = __builtin_amdgcn_cvt_pk_i16(aa[0], aa[1]), w1 = __builtin_amdgcn_cvt_pk_i16(aa[2], aa[3]);
+#pragma unroll
+                    for (int hh = 0; hh < NQ; ++hh) {
+                        if (h == hh) { w[2 * hh] = w0; w[2 * hh + 1] = w1; qmx[hh] = hi; qmn[hh] = lo; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) { mx = max(mx, qmx[h]); mn = min(mn, qmn[h]); }
+            // ---- the record's samples leave: folded into the chain (FOLD), or as 256 contiguous bytes per store instruction -- lanes 2p and
+            // 2p + 1 swap one packed pair (DPP) and a v_perm_b32 picks the two int16 that are neighbours in memory -- or, on the last tile
+            // of a row, frame by frame
+#pragma unroll
+            for (int m = 0; m < FPL / 2; ++m) {
+                if constexpr (FOLD) {
+                    fa[2 * m] += (int)w[m].x;
+                    fa[2 * m + 1] += (int)w[m].y;
+                    fL[m] = __builtin_elementwise_add_sat(fL[m], w[m]);
+                    fU[m] = __builtin_elementwise_add_sat(fU[m], w[m]);
+                } else if (full_tile) {
+                    union { short2p v; uint32_t u; } ww;
+                    ww.v = w[m];
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)ww.u, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+                    __builtin_nontemporal_store((int)__builtin_amdgcn_perm(ww.u, nb, pair_sel), reinterpret_cast<int*>(row_tile) + 64 * m + pair_word);
+                } else {
+                    if (i0 + (uint32_t)(2 * m) * 64u < n) row[2 * m * 64] = w[m].x;
+                    if (i0 + (uint32_t)(2 * m + 1) * 64u < n) row[(2 * m + 1) * 64] = w[m].y;
+                }
+            }
+        }
     }
     if (I16 && (mx > 32767 || mn < -32768)) *flag = 1;
     if constexpr (FOLD) {

@@ -258,6 +258,9 @@ class VoiceSpec:
     harm_poly: Optional[Tuple[float, ...]] = None       # 16 polynomial coefficients (all k <= 16), highest power first
     harm_dense: Optional[Tuple[float, ...]] = None      # Clenshaw coefficients, k = K..1, len % 8 == 0
     harm_sparse: Optional[Tuple[Tuple[float, float], ...]] = None
+    # the voice's own list (k, a_k) in the reference's order, carried beside a polynomial / Clenshaw form: the int16 routes recompute a
+    # sample term by term from it where int(scale * v) of the fast form lies within the forms' distance of an integer (sh_voice::guard_*)
+    harm_guard: Optional[Tuple[Tuple[float, float], ...]] = None
     env: Optional[EnvelopeSpec] = None
     needs_pwm: bool = False
     flip: bool = False                                  # SawtoothH mirrors the wave around the bias
@@ -272,6 +275,22 @@ def _with(sp: VoiceSpec, **changes) -> VoiceSpec:
     new = VoiceSpec.__new__(VoiceSpec)
     new.__dict__ = {**sp.__dict__, **changes}
     return new
+
+
+def guard_bounds(partials, poly, dense) -> Tuple[float, float]:
+    """(per unit |t|, constant) bound, at unit amplitude, of |fast form - the reference's term-by-term sum| for a harmonic list:
+    the reference rounds every product t * k (half an ulp of it: <= |t k| 2^-53 of phase, a_k of that in the sum; doubled here), the
+    fast forms evaluate sum a_k sin(k t) of the exact products -- plus what their own evaluation leaves: Horner in the monomial basis
+    (2^-50 of the coefficient mass: measured 1.6e-17 of it for a_k = 1/k, k <= 16), Clenshaw (2^-46 sum |a_k| k^2), and the rotations
+    that carry (sin t, cos t) from frame to frame (< 50 ulp of angle: 2^-46 sum |a_k k|).  tests/test_gpu_guard.py holds the measured
+    distance under half of this."""
+    A = sum(abs(a) * abs(k) for k, a in partials)
+    per_t = A * 2.0 ** -52
+    if poly is not None:
+        const = 2.0 ** -50 * sum(abs(c) for c in poly) + 2.0 ** -46 * A
+    else:
+        const = 2.0 ** -46 * sum(abs(a) * k * k for k, a in partials) + 2.0 ** -46 * A
+    return per_t, const
 
 
 def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float, float]]] = None):
@@ -347,6 +366,30 @@ def pack_voices(specs: Sequence[VoiceSpec], gains: Optional[Sequence[Tuple[float
     voices["seg_offset"], voices["seg_count"] = seg_off, seg_cnt
     voices["time_seg_offset"], voices["time_seg_count"] = tseg_off, tseg_cnt
     voices["harm_offset"], voices["harm_count"], voices["harm_dense"] = h_off, h_cnt, h_dense
+    # the int16 boundary guard of the polynomial / Clenshaw voices (not under FM: there the contract is a bound, not equality)
+    g_off, g_cnt = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    g_t, g_c = np.zeros(n), np.zeros(n)
+    bound_cache: Dict[int, Tuple[float, float]] = {}
+    for i, s in enumerate(specs):
+        if s.harm_guard is None or s.fm_mode != N.SH_FM_NONE or (s.harm_poly is None and s.harm_dense is None):
+            continue
+        if s.harm_guard not in part_index:
+            part_index[s.harm_guard] = len(part_list)
+            part_list.extend(s.harm_guard)
+        g_off[i], g_cnt[i] = part_index[s.harm_guard], len(s.harm_guard)
+        key = id(s.harm_poly) if s.harm_poly is not None else id(s.harm_dense)
+        if key not in bound_cache:
+            bound_cache[key] = guard_bounds(s.harm_guard, s.harm_poly, s.harm_dense)
+        per_t, const = bound_cache[key]
+        gmax = max(1.0, abs(s.env.sustain_level)) if s.env is not None else 1.0
+        a = abs(s.amplitude)
+        gt = gmax * a * per_t
+        gc = gmax * (a * const + 2.0 ** -50 * (3.0 * abs(s.bias) + a * sum(abs(x[1]) for x in s.harm_guard)))
+        if not (gt < 1.0 and gc < 1.0):          # (NaN / huge amplitudes: no guard -- such a voice overflows any integer format anyway)
+            g_off[i], g_cnt[i] = 0, 0
+            continue
+        g_t[i], g_c[i] = gt, gc
+    voices["guard_offset"], voices["guard_count"], voices["guard_t"], voices["guard_c"] = g_off, g_cnt, g_t, g_c
     # envelopes: a table of notes shares a handful of EnvelopeSpec objects -- one record per object, copied to its voices
     env_rows: Dict[int, List[int]] = {}
     env_objs: Dict[int, EnvelopeSpec] = {}
@@ -409,8 +452,14 @@ class Oscillator:
         return None
 
     def _get_bank(self) -> N.Bank:
+        """The one-voice bank a single oscillator renders through.  A Harmonics voice in a fast form (polynomial / Clenshaw) is summed
+        term by term here unless params.exact_harmonics is False: one voice is launch-bound whatever its form, and a float64 block
+        equal to the reference's to an ulp is what Sample.from_osc_block's truncation needs (params.py)."""
         if self._bank is None:
-            self._bank = N.Bank(*pack_voices([self.spec()]))
+            sp = self.spec()
+            if params.exact_harmonics is None and sp.harm_guard is not None and sp.fm_mode == N.SH_FM_NONE and sp.harm_sparse is None:
+                sp = _with(sp, harm_poly=None, harm_dense=None, harm_sparse=sp.harm_guard, harm_guard=None)
+            self._bank = N.Bank(*pack_voices([sp]))
         return self._bank
 
     # -- rendering ------------------------------------------------------------------------------
@@ -783,6 +832,12 @@ def _harmonic_forms(harmonics, exact=False):
     return poly, dense, sparse
 
 
+@lru_cache(maxsize=4096)
+def _guard_list(harmonics):
+    """The list as the term-by-term loop takes it (one shared tuple per distinct list: pack_voices stores it once)."""
+    return tuple((float(k), float(a)) for k, a in harmonics) or ((0.0, 0.0),)
+
+
 class Harmonics(_Carrier):
     """Additive sine series sum_k a_k sin(k*t) (upstream: oscillators.py class Harmonics)."""
     KIND = N.SH_HARMONICS
@@ -802,8 +857,11 @@ class Harmonics(_Carrier):
             # the exact treatment of the peaks (tests/test_gpu_int_mixdown.py::test_sine_peaks_on_rational_frequencies)
             return VoiceSpec(kind=N.SH_SINE, amplitude=float(self.amplitude), bias=float(self.bias), **self._phase_fields())
         poly, dense, sparse = _harmonic_forms(tuple(map(tuple, self.harmonics)), bool(params.exact_harmonics))
+        guard = _guard_list(tuple(map(tuple, self.harmonics))) if sparse is None and params.int16_guard else None
+        if guard is not None and len(guard) > 255:           # (the lean records hold the list's length in eight bits: a longer list is summed term by term)
+            poly, dense, sparse, guard = None, None, guard, None
         return VoiceSpec(kind=self.KIND, amplitude=float(self.amplitude), bias=float(self.bias),
-                         harm_poly=poly, harm_dense=dense, harm_sparse=sparse, **self._phase_fields())
+                         harm_poly=poly, harm_dense=dense, harm_sparse=sparse, harm_guard=guard, **self._phase_fields())
 
 
 class SquareH(Harmonics):

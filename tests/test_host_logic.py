@@ -74,7 +74,19 @@ def test_pack_voices_layout_and_sharing():
     # closed-form LFO constants
     d = 2.0 * math.pi * 5 / sr
     assert v["lfo_d"][3] == d and v["lfo_K"][3] == 0.02 / (2.0 * math.sin(d / 2.0))
-    assert partials.dtype == N.PARTIAL_DTYPE and len(partials) == 0
+    # the int16 boundary guard (ABI 6): the polynomial / Clenshaw voices WITHOUT FM carry their own list, shared lists stored once
+    assert partials.dtype == N.PARTIAL_DTYPE and len(partials) == 2 + 29
+    assert v["guard_count"].tolist() == [0, 0, 0, 0, 2, 29, 0] and v["guard_offset"][4] == 0 and v["guard_offset"][5] == 2
+    assert partials["k"][:2].tolist() == [1.0, 3.0] and partials["amp"][:2].tolist() == [1.0, 0.5]
+    per_t, const = G.guard_bounds(((1.0, 1.0), (3.0, 0.5)), voices[4].spec().harm_poly, None)
+    assert v["guard_t"][4] == per_t == 2.5 * 2.0 ** -52 and 0.0 < v["guard_c"][4] < 1e-9 and v["guard_t"][3] == 0.0
+    from synthesizer_amd import params
+    params.int16_guard = False
+    try:
+        v2, _s, _c, p2 = G.pack_voices([G.Harmonics(330, [(1, 1), (3, 0.5)], samplerate=sr).spec()])
+    finally:
+        params.int16_guard = True
+    assert v2["guard_count"][0] == 0 and len(p2) == 0
 
 
 def test_harmonics_form_selection():

@@ -60,3 +60,15 @@ def test_c_pcm_equals_audioop():
     voices = rng.uniform(-1, 1, (7, 300))
     gains = [(float(l), float(r)) for l, r in rng.uniform(0, 1, (7, 2))]
     assert np.array_equal(CO.mix_bus(voices, gains), np.array(O.mix_bus(voices.tolist(), gains)))
+
+
+@pytest.mark.parametrize("make", [
+    lambda: O.Harmonics(440.0, [(k, 1.0 / k) for k in range(1, 17)], 0.5, phase=0.2, samplerate=SR),
+    lambda: O.EnvelopeFilter(O.Harmonics(313.7, [(1, 1.0), (3, 0.3), (7, -0.2)], 0.8, phase=0.9, samplerate=SR), 0.01, 0.05, 1.0e6, 0.6, 0.2),
+    lambda: O.EnvelopeFilter(O.Sawtooth(300.0, samplerate=SR), 0.01, 0.02, 1000.0, 0.3, 0.02),
+])
+def test_render_window_enters_the_loop_late(make):
+    """c_oracle.render_window (the generator's loop entered at `start`: the phase brought there by `start` additions, the envelope's
+    sustain applied) equals the tail of a render from sample 0."""
+    start, n = 2 * SR + 12345, 5000
+    assert np.array_equal(CO.render_window(make(), start, n), CO.render(make(), start + n)[start:])
