@@ -475,8 +475,9 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_gen_idx_buf[k], sizeof(uint32_t) * slots);
             if (e == hipSuccess) e = hipMalloc((void**)&b->d_counts_buf[k], sizeof(uint32_t) * 4 * ((nvoices + 63) / 64));
         }
-        if (e == hipSuccess) e = hipMalloc((void**)&b->d_hint, sizeof(uint32_t) * 2 * nvoices);      // (carrier / time table pieces, then LFO table pieces)
-        if (e == hipSuccess) e = hipMemsetAsync(b->d_hint, 0, sizeof(uint32_t) * 2 * nvoices, st);
+        // (carrier / time table pieces, then LFO table pieces, then the arrival counters of self-folding launches)
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_hint, sizeof(uint32_t) * (2 * (size_t)nvoices + sh_bank::SELF_TILES));
+        if (e == hipSuccess) e = hipMemsetAsync(b->d_hint, 0, sizeof(uint32_t) * (2 * (size_t)nvoices + sh_bank::SELF_TILES), st);
         if (e != hipSuccess) rc = sh::hip_error(e, "hipMalloc(launch records)");
         b->d_launch = b->d_launch_buf[0];
         b->d_launch_fm = b->d_launch_fm_buf[0];

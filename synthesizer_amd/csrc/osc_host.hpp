@@ -22,6 +22,11 @@ struct sh_bank {
     uint32_t*   d_gen_idx_buf[NSETS] = {};
     uint32_t*   d_counts_buf[NSETS] = {};      // 4 per 64-voice chunk: lean, general, silent, -
     uint32_t*   d_hint = nullptr;
+    // one arrival counter per tile of a SELF-FOLDING launch (a render that stands alone: the last workgroup of a tile to store its
+    // partial bus folds the tile's planes itself -- no k_bus_combine behind the launch); behind d_hint's 2 * nvoices words, zero
+    // between launches (the folding workgroup resets its counter)
+    static constexpr uint32_t SELF_TILES = 16384;
+    uint32_t*   d_self() const { return d_hint + 2 * (size_t)nvoices; }
     // This bank's run of pipelined renders (same shape, consecutive blocks), the folds it still owes, and its ring of
     // partial-bus buffers: launch n writes ring slot n % 4, launch n + 2 (same stream) folds it.  Per bank, so that two banks
     // rendering turn by turn (or a bank beside a DistVoiceBank's) each keep their pipeline: only calls that can touch a bus

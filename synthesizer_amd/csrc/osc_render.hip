@@ -138,13 +138,14 @@ struct RenderLaunch {
     uint32_t nframes, tiles, groups, vpg, nchunks, prep_wgs;
     int mode, var;                    // mode: COMBINED_* (which lean kinds the bank can hold); var: waves * 100 + frames per lane * 10 + min waves per SIMD
     bool split, with_general, use_aux;
+    bool self_prepare;                // nothing resolved the launch's records: the lean kernel's workgroups do (LaunchArgs::self_prepare)
     LaunchSet cur, next;
     BusOut out;                       // the caller's buses
     double2* parts;                   // this launch's partial buses (NULL: one voice group, the kernel writes `out` itself)
     FoldIn fold;                      // the fold this launch takes over
     uint32_t* gen_valid;
     uint32_t c_lo, c_hi;              // (tile-classified launches) the chunks that can sound in this block: [c_lo, c_hi)
-    LaunchArgs args(const BankPtrs& P, const LaunchSet& set) const { return LaunchArgs{P, trig_table(), b->nvoices, vpg, set, start, nframes}; }
+    LaunchArgs args(const BankPtrs& P, const LaunchSet& set) const { return LaunchArgs{P, trig_table(), b->nvoices, vpg, set, start, nframes, self_prepare ? 1u : 0u}; }
     NextArgs next_args(const LaunchSet& nx, uint32_t wgs) const { return NextArgs{nx, next_start, wgs}; }
 };
 
@@ -491,8 +492,17 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         if (nseg < 2 || seg_first[nseg] != nframes) nseg = 0;        // nothing to cut, or more cuts than a launch carries
     }
     bool records_deferred = false;          // (a tile-classified launch without a resolved record set: its classification resolves what it needs)
+    // A plain split launch whose records nothing has resolved (a render that stands alone, the first of a run, a jump) CAN resolve them in
+    // the lean kernel itself (LaunchArgs::self_prepare: every workgroup its own voice group's records) and fold its partial buses itself
+    // (FoldIn::self).  Both are OFF (SYNTHHIP_SELF = 1 both, 2 the fold, 3 the records): round 6 built them for VERDICT r05 item 3 (the
+    // lone call, 56 -> <= 45 us) and measured 61 us with both, 63 with the fold (planes stored and loaded at agent scope; with fences at
+    // agent scope instead: 123 us -- every workgroup writes back and invalidates its XCD's L2), 57 with the records (and +7 us per
+    // launch of two or more blocks: hundreds of workgroups resolving the same sixteen chunks) against 57 for the prepare kernel +
+    // k_bus_combine: profiles/r06_run_lengths.txt.
+    const bool plain_split = split && !tiled && nseg == 0 && K.self != 0;
+    bool self_prepare = false;
     if (nseg == 0) {
-        rc = acquire_records(b, start, nframes, st, cont, tiled, tiled ? &records_deferred : nullptr);
+        rc = acquire_records(b, start, nframes, st, cont, tiled, tiled ? &records_deferred : (plain_split && K.self != 2) ? &self_prepare : nullptr);
         if (rc) return rc;
     }
     // partial buses: ring slot n % 4 (last read by the fold in launch n - 2, which is this stream's previous launch)
@@ -511,6 +521,10 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     uint32_t* gen_valid = with_general ? (uint32_t*)(parts + 2 * (size_t)groups * nframes) : nullptr;
     // the fold this launch takes over: the older of two outstanding ones (launch n - 2's)
     const bool take_over = b->npending == 2;
+    // A launch that does not continue a run and has nothing to take over folds ITSELF (FoldIn::self): the last workgroup of a tile to
+    // store its plane folds the tile -- a render that stands alone is complete when its one kernel ends (no k_bus_combine behind it),
+    // and the first launch of a run owes nobody a fold.  Only where the lean kernel writes every plane (no general-lists kernel behind it).
+    const bool self_fold = plain_split && K.self != 3 && groups > 1 && !cont && b->npending == 0 && !with_general && tiles <= sh_bank::SELF_TILES;
     const sh::PendingCombine prev = take_over ? b->pending[0] : sh::PendingCombine();
     const double2* pv_parts = take_over ? (const double2*)prev.parts : nullptr;
     float2* pv32 = take_over ? (float2*)prev.o32 : nullptr;
@@ -537,9 +551,9 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     const uint32_t nchunks = sh::div_up(b->nvoices, 64);
     const uint32_t prep_wgs = next.launch ? nchunks : 0u;
     const BusOut out{o32, o64, o16, pcm_scale};
-    const FoldIn fold{pv_parts, pv_gen, BusOut{pv32, pv64, pv16, pv_scale}};
+    const FoldIn fold = self_fold ? FoldIn{parts, nullptr, out, b->d_self()} : FoldIn{pv_parts, pv_gen, BusOut{pv32, pv64, pv16, pv_scale}, nullptr};
     const RenderLaunch L{b, st, start, next_start, nframes, tiles, groups, vpg, nchunks, prep_wgs, mode, var, split, with_general, use_aux,
-                         cur, next, out, parts, fold, gen_valid, tile_c_lo, tile_c_hi};
+                         self_prepare, cur, next, out, parts, fold, gen_valid, tile_c_lo, tile_c_hi};
     rc = tiled ? launch_tiled(L, records_deferred) : nseg ? launch_segmented(L, nseg, seg_first) : launch_plain(L);
     if (rc) return rc;
     if (use_aux) S.aux_busy = true;                         // (join_aux records the event the main stream waits for)
@@ -552,7 +566,8 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
         b->npending = 1;
         S.pending_total -= 1;
     }
-    if (groups > 1) {                                       // this launch's partial buses: folded two launches on, or by the next other API call
+    const bool writes_itself = direct || self_fold;        // the launch writes the caller's buses on its own stream
+    if (groups > 1 && !self_fold) {                         // this launch's partial buses: folded two launches on, or by the next other API call
         sh::PendingCombine& pc = b->pending[b->npending++];
         S.pending_total += 1;
         pc.parts = parts;
@@ -567,9 +582,9 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     if (S.open_runs > 0) {
         // on record while any run is open (this bank's or another's): direct writes with their stream; the buses a pending fold
         // will write from now (another bank must not slip a write in between), the stream follows when a launch takes the fold over
-        note_write(b, o32, n32, direct ? stream_bit : 0);
-        note_write(b, o64, n64, direct ? stream_bit : 0);
-        note_write(b, o16, n16, direct ? stream_bit : 0);
+        note_write(b, o32, n32, writes_itself ? stream_bit : 0);
+        note_write(b, o64, n64, writes_itself ? stream_bit : 0);
+        note_write(b, o16, n16, writes_itself ? stream_bit : 0);
     }
     if (pipelined) {
         b->run_count = n + 1;

@@ -39,6 +39,10 @@ struct FoldIn {
     const double2*  parts;
     const uint32_t* gen_valid;      // which groups' general parts (behind the lean ones) hold anything; NULL: no general parts
     BusOut          out;
+    // non-NULL: a SELF-FOLDING launch (a render that stands alone: nothing to take over, nobody behind it to leave the fold to) --
+    // `parts` are this launch's OWN partial buses, `out` its own buses, and self[tile] counts the voice groups' workgroups that have
+    // stored their plane of the tile: the last one folds the tile, in group order like k_bus_combine (bit-identical sums)
+    uint32_t*       self;
 };
 // What every render kernel needs of the launch.
 struct LaunchArgs {
@@ -48,6 +52,10 @@ struct LaunchArgs {
     LaunchSet             cur;
     uint64_t              start;
     uint32_t              nframes;
+    // 1: nothing resolved this launch's records (a render that stands alone, the first of a run): every workgroup resolves the
+    // records of its OWN voice group's chunks first -- the same values from every tile's workgroup of the group, three dependent round
+    // trips at the head of the launch instead of a prepare kernel (9-13 us) and a launch boundary in front of it (k_render_lean)
+    uint32_t              self_prepare;
 };
 // The block expected two launches on (next_start = start + 2 * nframes: the launch in between runs beside this one on the other stream
 // and got its records from this one's predecessor): its record set, and how many workgroups of this grid resolve it (0: nobody).
@@ -233,7 +241,7 @@ __device__ __forceinline__ int prep_rows_tiles(const LaunchArgs& A, const NextAr
 template <int WAVES, int FPL>
 __device__ __forceinline__ void fold_previous(const FoldIn& F, uint32_t ngroups, uint32_t nframes, uint32_t bx) {
     const bool shared = ngroups >= 32 && gridDim.x <= 12;         // (many groups, few tiles)
-    if (!F.parts || !(shared || blockIdx.y == 0)) return;
+    if (!F.parts || F.self || !(shared || blockIdx.y == 0)) return;
     const double2* __restrict__ prev_parts = F.parts;
     const uint32_t slice = shared ? (64 * FPL + ngroups - 1) / ngroups : (uint32_t)(64 * FPL), f_lo = shared ? blockIdx.y * slice : 0u;
     const uint32_t f_hi = f_lo + slice < (uint32_t)(64 * FPL) ? f_lo + slice : (uint32_t)(64 * FPL);
@@ -274,6 +282,76 @@ __device__ __forceinline__ void fold_previous(const FoldIn& F, uint32_t ngroups,
     }
 }
 
+// ---- a launch that stands alone ----------------------------------------------------------------------------------------------------
+// SELF-FOLD (FoldIn::self): behind its store of the tile's plane a workgroup takes a ticket of the tile's counter; the one that draws
+// the last ticket -- every group's plane of the tile is in memory then (release fence before the ticket, acquire fence behind it: the
+// planes were written through other XCDs' L2s) -- folds the tile in group order, the sum k_bus_combine makes, and resets the counter.
+// The idea: a render that nothing follows pays the fold in its own tail instead of a 5.6 us kernel and a launch boundary behind it.
+// Measured (profiles/r06_run_lengths.txt): 63 us per lone block against 57 -- the planes must cross XCDs inside the kernel -- so the
+// host never asks for it unless SYNTHHIP_SELF says so.
+template <int WAVES, int FPL>
+__device__ __forceinline__ void fold_own_tile(const FoldIn& F, uint32_t ngroups, uint32_t nframes, uint32_t bx, uint32_t* ticket_lds) {
+    // (ticket_lds: a word of the staging buffer, free once the planes are stored -- a word of its own would be the 160 KB + 4 bytes that
+    //  take the kernels of four workgroups per CU down to three)
+    // The planes of a self-folding launch are stored and loaded at AGENT scope (sc1: through the XCD's L2 to memory and from there) --
+    // a release / acquire fence pair at agent scope writes back and invalidates the whole L2 of the XCD, from every one of the launch's
+    // 752 workgroups: 123 us per block instead of 56 (profiles/r06_run_lengths.txt).  The stores have been acknowledged when the
+    // wavefront's counter is back at zero; then the ticket.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *ticket_lds = atomicAdd(F.self + bx, 1u);
+    __syncthreads();
+    const uint32_t ticket = *ticket_lds;
+    if (ticket != ngroups - 1) return;
+    if (threadIdx.x == 0) F.self[bx] = 0;                  // (the next self-folding launch of the bank starts from zero)
+    const double* __restrict__ own = reinterpret_cast<const double*>(F.parts);
+    auto plane = [&](uint32_t g, uint32_t raw) {
+        const double* q = own + 2 * ((size_t)g * nframes + raw);
+        return make_double2(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    for (uint32_t f = threadIdx.x; f < (uint32_t)(64 * FPL); f += WAVES * 64) {
+        const uint32_t raw = bx * (64 * FPL) + f;
+        if (raw >= nframes) continue;
+        double2 acc = plane(0, raw);
+        uint32_t g = 1;
+        for (; g + 8 <= ngroups; g += 8) {
+            double2 pp[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) pp[k] = plane(g + k, raw);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                acc.x += pp[k].x;
+                acc.y += pp[k].y;
+            }
+        }
+        for (; g < ngroups; ++g) {
+            const double2 pp = plane(g, raw);
+            acc.x += pp.x;
+            acc.y += pp.y;
+        }
+        if (F.out.bus32) F.out.bus32[raw] = make_float2((float)acc.x, (float)acc.y);
+        if (F.out.bus64) F.out.bus64[raw] = acc;
+        if (F.out.pcm16) F.out.pcm16[raw] = pcm16_frame(acc.x, acc.y, F.out.pcm_scale);
+    }
+}
+
+// SELF-PREPARE (LaunchArgs::self_prepare): the records of this workgroup's voice group, resolved by its own wavefronts (a chunk of 64
+// voices per wavefront) into the launch's record set -- every tile's workgroup of the group stores the same values there -- and read
+// back through the scalar cache, which is invalidated first (it may hold what an earlier launch kept in this set).
+template <int WAVES>
+__device__ __forceinline__ void prepare_own_group(const LaunchArgs& A, uint32_t grp) {
+    const uint32_t nchunks = (A.nvoices + 63) / 64;
+    const uint32_t c0 = (grp * A.voices_per_group) / 64;
+    uint32_t c1 = ((grp + 1) * A.voices_per_group + 63) / 64;
+    if (c1 > nchunks) c1 = nchunks;
+    for (uint32_t c = c0 + (threadIdx.x >> 6); c < c1; c += WAVES) prepare_chunk(A.B, A.cur, c, A.nvoices, A.start, A.nframes);
+    // (the workgroup reads its OWN stores back: acknowledged -- in its XCD's L2 -- when the counter is at zero; no fence at agent scope,
+    //  which would write back and invalidate that whole L2 from every workgroup of the launch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_dcache_inv();
+    __syncthreads();
+}
+
 // ---- the sum across the waves of the workgroup, and the store ---------------------------------------------------------------------
 // dst: a plane of partial buses (launch-relative frames) -- or NULL: the final bus `out` (single-group launches).  The staging buffer
 // holds RED_ROWS(FPL) rows of 64 frames per wave and channel: eight at most (32 KB at four waves -- four workgroups per CU with the
@@ -281,7 +359,7 @@ __device__ __forceinline__ void fold_previous(const FoldIn& F, uint32_t ngroups,
 constexpr int red_rows(int fpl) { return fpl <= 8 ? fpl : (fpl % 8 == 0 ? 8 : (fpl % 6 == 0 ? 6 : 4)); }
 template <int WAVES, int FPL>
 __device__ __forceinline__ void reduce_store(double (*red)[2][64 * red_rows(FPL)], const TileCtx& T, const double (&accl)[FPL], const double (&accr)[FPL],
-                                             double2* __restrict__ dst, size_t dst_off, const BusOut& out) {
+                                             double2* __restrict__ dst, size_t dst_off, const BusOut& out, bool agent_scope = false) {
     constexpr int RR = red_rows(FPL);
 #pragma unroll
     for (int r0 = 0; r0 < FPL; r0 += RR) {
@@ -304,7 +382,11 @@ __device__ __forceinline__ void reduce_store(double (*red)[2][64 * red_rows(FPL)
                     rr += red[w][1][f];
                 }
                 const size_t at = dst_off + raw;
-                if (dst) {
+                if (dst && agent_scope) {                  // (a self-folding launch: another XCD's workgroup reads the plane in this kernel)
+                    double* q = reinterpret_cast<double*>(dst + at);
+                    __hip_atomic_store(q, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(q + 1, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (dst) {
                     dst[at] = make_double2(l, rr);
                 } else {
                     if (out.bus32) out.bus32[at] = make_float2((float)l, (float)rr);
@@ -1016,6 +1098,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_render_lean(LaunchArgs A, 
     const uint32_t ngroups = groups_of_grid(N.prep_wgs);
     if (prep_rows_lists(A, N, ngroups)) return;
     fold_previous<WAVES, FPL>(F, ngroups, A.nframes, blockIdx.x);
+    if constexpr (!SEG) {
+        if (A.self_prepare) prepare_own_group<WAVES>(A, blockIdx.y);     // (first: nothing of the tile's own state is alive yet)
+    }
     SH_STAMP(A, 1);
     __shared__ double red[WAVES][2][64 * red_rows(FPL)];
     __shared__ shm::sc_pair trig[shm::TRIG_N];
@@ -1029,8 +1114,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_render_lean(LaunchArgs A, 
     lean_lists<WAVES, FPL, KINDS, SEG>(T, first, trig, accl, accr);
     SH_STAMP(A, 3);
     SH_STAMP(A, 4);
-    reduce_store<WAVES, FPL>(red, T, accl, accr, parts + (size_t)T.grp * A.nframes, T.seg_off, BusOut{});
+    reduce_store<WAVES, FPL>(red, T, accl, accr, parts + (size_t)T.grp * A.nframes, T.seg_off, BusOut{}, !SEG && F.self != nullptr);
     SH_STAMP(A, 5);
+    if constexpr (!SEG) {
+        if (F.self) fold_own_tile<WAVES, FPL>(F, ngroups, A.nframes, blockIdx.x, reinterpret_cast<uint32_t*>(&red[0][0][0]));
+    }
 }
 
 // =====================================================================================================================================

@@ -34,6 +34,7 @@ void load_knobs() {
     k.no_seg = flag("SYNTHHIP_NO_SEG");
     k.no_tiles = flag("SYNTHHIP_NO_TILES");
     k.no_small_pipeline = flag("SYNTHHIP_NO_SMALL_PIPELINE");
+    k.self = (int)num("SYNTHHIP_SELF", 0);
     k.variant = (int)num("SYNTHHIP_VARIANT", 0);
     k.groups = (int)num("SYNTHHIP_GROUPS", 0);
     k.pool_fill = (int)num("SYNTHHIP_POOL_FILL", -1);
