@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
     short2p w[I16 ? FPL / 2 : 1];
     int qmx[NQ], qmn[NQ];                                       // largest / smallest integer of each quarter's (valid) samples
     uint64_t nearm[NQ];                                         // (uniform) lanes with a sample of quarter h within the guard's reach of an integer
-    uint32_t nearv[NQ];                                         // the smallest high word of fract(scale v + tq) among the lane's frames of quarter h
+    uint32_t nearv[NQ];                                         // the smallest frac(scale v + tq) * 2^32 among the lane's frames of quarter h
     double tq = 0.0;                                            // (uniform) the record's guard distance in integer units
     double tqm = 0.0;                                           // (uniform) tq + 1.5 * 2^20
     uint32_t near_lo = 0;                                       // (uniform) 2 tq in units of 2^-32, plus two; 0xFFFFFFFF: every sample (a record that holds a NaN)
@@ -424,7 +424,14 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
             // frac(scale v + tq) * 2^32 -- one FMA per sample, no v_fract_f64 (a quarter-rate instruction: with it the check cost 13-17 %
             // of the kernel, a compare per frame into a scalar register pair 18 %; profiles/r06_guard_ab.txt).  The SMALLEST low word of
             // the quarter's samples is kept -- one v_min3_u32 per pair -- and compared once per record with 2 tq * 2^32 (+ 2: rounding).
-            nearv[m / 2] = min(nearv[m / 2], min((uint32_t)__double2loint(fma(scale, v0, tqm)), (uint32_t)__double2loint(fma(scale, v1, tqm))));
+            // ... except around the integer 0, which is no boundary of a truncation toward zero -- and a waveform that is FLAT at its zero
+            // crossing (the 1/k series of an even number of partials at t = pi: value, slope and curvature vanish) spends one sample in
+            // 10^4 within reach of it: 2 % of the quarters 5 s into the benchmark's notes, 5.5 % after 300 s, against 10^-7 of the samples in
+            // reach of a real boundary (tools/guard_count.py).  floor(scale v + tq) = 0 is the high word 0x41380000 of the same sum.
+            const double w0 = fma(scale, v0, tqm), w1 = fma(scale, v1, tqm);
+            const uint32_t k0 = __double2hiint(w0) == 0x41380000 ? 0xFFFFFFFFu : (uint32_t)__double2loint(w0);
+            const uint32_t k1 = __double2hiint(w1) == 0x41380000 ? 0xFFFFFFFFu : (uint32_t)__double2loint(w1);
+            nearv[m / 2] = min(nearv[m / 2], min(k0, k1));
 #endif
             qmx[m / 2] = max(qmx[m / 2], max(ok0 ? a : 0, ok1 ? b : 0));
             qmn[m / 2] = min(qmn[m / 2], min(ok0 ? a : 0, ok1 ? b : 0));
@@ -482,6 +489,9 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
                 near_lo = 0xFFFFFFFFu;
             }
             tqm = tq + 0x1.8p20;
+#ifdef SH_AB_COUNT
+            (void)0;
+#endif
 #pragma unroll
             for (int h = 0; h < NQ; ++h) { qmx[h] = 0; qmn[h] = 0; nearv[h] = 0xFFFFFFFFu; }
         }
@@ -576,6 +586,9 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
 #pragma unroll
                     for (int hh = 0; hh < NQ; ++hh) nm = h == hh ? nearm[hh] : nm;
                     if (nm == 0) continue;
+#ifdef SH_AB_COUNT             // (tools/ab.py build count -DSH_AB_COUNT: how often the careful path runs -- words 4.. of the flag block)
+                    if (lane == 0) { atomicAdd(flag + 4, 1); atomicAdd(flag + 5, (int)__popcll(nm)); }
+#endif
                     int aa[4], lo = 0, hi = 0;
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
@@ -587,7 +600,11 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
 #pragma unroll
                         for (int u = 2; u < 16; ++u) pv = fma(pv, cs, poly[u]);
                         const double sq = fma(scale, pv * (sn * ag), tq);
-                        const bool nr = (uint32_t)__double2loint(fma(scale, pv * (sn * ag), tqm)) <= near_lo || !(sq == sq);
+                        // (an integer in reach -- but not 0: truncation toward zero has no boundary there, and a waveform that is FLAT at
+                        //  its zero crossing, like the 1/k series of an even number of partials at t = pi, spends one sample in 10^4 within
+                        //  reach of it: 2-5 % of the quarters come here for that alone, tools/guard_count.py)
+                        const double wq = fma(scale, pv * (sn * ag), tqm);
+                        const bool nr = ((uint32_t)__double2loint(wq) <= near_lo && __double2hiint(wq) != 0x41380000) || !(sq == sq);
                         int a = (int)sq;
                         if (__ballot(nr) != 0ull) {               // (uniform) some lane's frame j is in reach of an integer
                             if (nr) {
@@ -601,6 +618,14 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
                                 a = (ex >= -2147483000.0 && ex <= 2147483000.0) ? (int)ex : 0x7FFFFFFF;     // (NaN, like anything beyond int16: OverflowError)
                             }
                         }
+#ifdef SH_AB_COUNT
+                        if (nr && atomicCAS(flag + 14, 0, 1) == 0) {      // the first sample the careful path finds near: what does it look like?
+                            const double vv = pv * (sn * ag), ww = fma(scale, vv, tqm);
+                            flag[7] = __double2loint(ww); flag[8] = __double2hiint(ww); flag[9] = __double2loint(vv); flag[10] = __double2hiint(vv);
+                            flag[11] = (int)near_lo; flag[12] = (int)lane; flag[13] = j;
+                        }
+                        if (nr && lane == (uint32_t)__ffsll((long long)__ballot(nr)) - 1u) atomicAdd(flag + 6, 1);
+#endif
                         aa[jj] = a;
                         const bool ok = full_tile || i0 + (uint32_t)j * 64u < n;
                         hi = max(hi, ok ? a : 0);
@@ -882,6 +907,15 @@ int sh_bank_generate_i16_async(sh_bank* b, uint64_t start, uint32_t nframes, dou
         return sh::set_error(SH_ERR_INVALID, "sh_bank_generate_i16: the fused quantiser truncates; under SH_OPT_QUANTISE_ROUND quantise float64 rows (sh_bank_generate_f64 + sh_quantize_f64)");
     return generate_rows<short>(b, start, nframes, (short*)voices_out->ptr, stride, scale, sh::state().flag + 1);     // (word 0: the quantisers of pcm.hip)
 }
+
+#ifdef SH_AB_COUNT
+int sh_debug_flag_words(int* out, int n) {       // (diagnostic builds only: the flag block's words, then cleared)
+    sh::State& st = sh::state();
+    if (hipMemcpy(out, st.flag, sizeof(int) * (n < 16 ? n : 16), hipMemcpyDeviceToHost) != hipSuccess) return SH_ERR_HIP;
+    (void)hipMemset(st.flag + 2, 0, sizeof(int) * 14);
+    return SH_OK;
+}
+#endif
 
 int sh_overflow_check(void) {
     SH_REQUIRE_INIT();
