@@ -922,6 +922,11 @@ def compact_line(out: dict, detail_path=None) -> str:
     for key, name in (("int16_stream", "int16_stream_ms_per_step"), ("run_of_blocks", "run_of_blocks_ms_per_step"), ("staggered_notes", "staggered_ms_per_step")):
         if key in out:
             side[name] = out[key].get("ms_per_step")
+    g16 = (out.get("two_step_i16") or {}).get("int16_guard")
+    if g16:
+        side["int16_exact_rows_ms"] = g16.get("rows_ms")
+        side["int16_exact_fused_mixdown_ms"] = g16.get("fused_mixdown_ms")
+        side["int16_guard_cost_x"] = [g16.get("rows_x"), g16.get("fused_mixdown_x")]
     if "lone_call" in out:
         side["lone_call_us_per_block"] = out["lone_call"].get("us_per_block")
     if side:
@@ -1368,6 +1373,26 @@ def main() -> int:
             "fused_mono_mixdown": fused_row,
             "roofline_mix_stereo": hbm_roof("k_mix_chain_pan_direct_s<4, 4, 8> (audioop.tostereo per voice in registers: ten float64-rate operations per frame -- VALU-bound, not HBM-bound)", p16_bytes, p16_ms, sp_p16, tp16, "bytes_per_frame", 2 * nv + 4),
         }
+        # ---- what bit-exactness costs on these routes (round 6: the int16 boundary guard is the default): the same bank built without guard
+        # lists (params.int16_guard = False: rounds 1-5, one sample in 10^6 .. 2 10^5 a step off the reference late in a note)
+        if rank == 0 and world == 1:
+            from synthesizer_amd import params as _params
+            from synthesizer_amd.mixer import VoiceBank as _VB
+            _params.int16_guard = False
+            try:
+                v_ng, g_ng = build_voices(nv)
+                plain = _VB(v_ng, gains=g_ng)
+            finally:
+                _params.int16_guard = True
+            ng16_ms = steady(N, lambda: plain.generate_i16_device(F2, Wm * F, out=rows16, stride=stride16, check=False), min_seconds=0.15, reps=3)
+            nf16_ms = steady(N, lambda: plain.mixdown_i16_device(F2, Wm * F, out=mono16, check=False), min_seconds=0.15, reps=3)
+            plain.overflow_check()
+            out["two_step_i16"]["int16_guard"] = {
+                "rows_ms": g16_ms, "rows_ms_without": ng16_ms, "rows_x": g16_ms / ng16_ms,
+                "fused_mixdown_ms": f16_ms, "fused_mixdown_ms_without": nf16_ms, "fused_mixdown_x": f16_ms / nf16_ms,
+                "note": "default: polynomial-Harmonics samples whose int(scale v) is in doubt are redone term by term (sh_voice::guard_*): equal to the "
+                        "oracle's int16 at any time into a note (tests/test_gpu_guard.py: 0 of 67 M samples differ 10 s and 300 s in; without the guard 1 and 12); "
+                        "term by term throughout (params.exact_harmonics = True) costs 9-10 x: tools/exact_cost.py"}
         for b_ in (mono16, st16, rows16, vbuf):       # (rows16 may be a window of vbuf: freed before it)
             b_.free()
 

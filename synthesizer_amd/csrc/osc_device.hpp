@@ -1072,7 +1072,12 @@ __device__ __forceinline__ bool guard_near(const double (&x)[FPL], double scale,
     bool near = false;
     const double tq2 = tq + tq;
 #pragma unroll
-    for (int j = 0; j < FPL; ++j) near |= !(__builtin_amdgcn_fract(fma(scale, x[j], tq)) > tq2);
+    for (int j = 0; j < FPL; ++j) {
+        // (not around the integer 0: no boundary of a truncation toward zero, and where a waveform is flat at its zero crossing -- the
+        //  1/k series of sixteen partials at t = pi -- one sample in 10^4 lies within reach of it: profiles/r06_guard_ab.txt)
+        const double y = fma(scale, x[j], tq);
+        near |= !(__builtin_amdgcn_fract(y) > tq2) && !(y >= 0.0 && y < 1.0);
+    }
     return __ballot(near) != 0ull;                           // (uniform)
 }
 // |scale| T of a voice's tile that ends at launch-relative frame tile_last; 0 = the voice has no guard (FM, other kinds, no list)

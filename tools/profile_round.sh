@@ -3,7 +3,7 @@
 # (run through gpurun from the repo root; afterwards, here: python tools/summarize_profiles.py gpurun_out/prof_r01 r01)
 # Kernel durations and counters are separate runs: --pmc is never combined with a runtime / sys trace.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 D=gpurun_out/prof_$TAG
