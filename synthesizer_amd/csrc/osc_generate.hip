@@ -429,8 +429,12 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
             // 10^4 within reach of it: 2 % of the quarters 5 s into the benchmark's notes, 5.5 % after 300 s, against 10^-7 of the samples in
             // reach of a real boundary (tools/guard_count.py).  floor(scale v + tq) = 0 is the high word 0x41380000 of the same sum.
             const double w0 = fma(scale, v0, tqm), w1 = fma(scale, v1, tqm);
-            const uint32_t k0 = __double2hiint(w0) == 0x41380000 ? 0xFFFFFFFFu : (uint32_t)__double2loint(w0);
-            const uint32_t k1 = __double2hiint(w1) == 0x41380000 ? 0xFFFFFFFFu : (uint32_t)__double2loint(w1);
+            uint32_t h0 = (uint32_t)__double2hiint(w0), h1 = (uint32_t)__double2hiint(w1);
+            // (the high words as opaque 32-bit values: left to itself the compiler compares the masked 64-bit patterns -- v_mov, v_cmp_eq_u64,
+            //  v_cmp_ne_u64 and two selects per sample, 76 instructions per record instead of 40)
+            asm volatile("" : "+v"(h0), "+v"(h1));
+            const uint32_t k0 = h0 == 0x41380000u ? 0xFFFFFFFFu : (uint32_t)__double2loint(w0);
+            const uint32_t k1 = h1 == 0x41380000u ? 0xFFFFFFFFu : (uint32_t)__double2loint(w1);
             nearv[m / 2] = min(nearv[m / 2], min(k0, k1));
 #endif
             qmx[m / 2] = max(qmx[m / 2], max(ok0 ? a : 0, ok1 ? b : 0));
