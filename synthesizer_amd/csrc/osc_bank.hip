@@ -356,6 +356,7 @@ int sh_bank_create(const sh_voice* voices, uint32_t nvoices, const sh_segment* s
     if (!b) return sh::set_error(SH_ERR_NOMEM, "host allocation failed");
     hipStream_t st = sh::state().stream;
     b->nvoices = nvoices;
+    for (uint32_t i = 0; i < nvoices; ++i) b->has_guard = b->has_guard || voices[i].guard_count != 0;
     b->nsegs = nsegs;
     b->ncoefs = ncoefs;
     b->npartials = npartials;

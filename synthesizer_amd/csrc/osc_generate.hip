@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, FPL >= 4 ? 4 : 6) void k_generate_lists(BankPt
 #ifndef SH_GEN_MINW
 #define SH_GEN_MINW 4              // wavefronts per SIMD the compiler budgets registers for (tools/ab.py build NAME -DSH_GEN_MINW=3: the A/B of round 6)
 #endif
-template <int FPL, typename OutT = float, bool FOLD = false>
+template <int FPL, typename OutT = float, bool FOLD = false, bool GUARD = true>
 __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3 : SH_GEN_MINW) void k_generate_lean_harm(const shm::sc_pair* __restrict__ trig_g, LaunchSet base, uint32_t nvoices,
                                                                uint32_t total, uint32_t seg_frames,
                                                                OutT* __restrict__ out32_all, size_t stride, SegTab tab, uint32_t rec_split,
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
         if constexpr (I16) {
             const double s0q = fma(scale, v0, tq), s1q = fma(scale, v1, tq);
             const int a = (int)s0q, b = (int)s1q;               // float64 product, truncation toward zero
-#ifndef SH_AB_NO_GUARD_CHECK            // (tools/ab.py build NAME -DSH_AB_NO_GUARD_CHECK: what the check itself costs)
+            if constexpr (GUARD) {       // (GUARD = false: a bank built without guard lists -- params.int16_guard = False -- quantises as rounds 1-5 did)
             // The fraction of scale v + tq as an integer: added to 1.5 * 2^20 (an ulp there is 2^-32) the sum's LOW WORD is
             // frac(scale v + tq) * 2^32 -- one FMA per sample, no v_fract_f64 (a quarter-rate instruction: with it the check cost 13-17 %
             // of the kernel, a compare per frame into a scalar register pair 18 %; profiles/r06_guard_ab.txt).  The SMALLEST low word of
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
             const uint32_t k0 = h0 == 0x41380000u ? 0xFFFFFFFFu : (uint32_t)__double2loint(w0);
             const uint32_t k1 = h1 == 0x41380000u ? 0xFFFFFFFFu : (uint32_t)__double2loint(w1);
             nearv[m / 2] = min(nearv[m / 2], min(k0, k1));
-#endif
+            }
             qmx[m / 2] = max(qmx[m / 2], max(ok0 ? a : 0, ok1 ? b : 0));
             qmn[m / 2] = min(qmn[m / 2], min(ok0 ? a : 0, ok1 ? b : 0));
             w[m] = __builtin_amdgcn_cvt_pk_i16(a, b);
@@ -483,7 +483,10 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
         if constexpr (I16) {
             gword = q->pad1;                                       // the boundary guard: tolerance (float32, 24 bits, rounded up) | length of the list
             const double tol = fabs(scale) * (double)__uint_as_float(gword & ~0xFFu);
-            if (tol < 0.125) {
+            if constexpr (!GUARD) {
+                tq = 0.0;                                          // int(scale * v) as it is
+                near_lo = 0;
+            } else if (tol < 0.125) {
                 tq = tol >= 0x1p-31 ? tol : 0x1p-31;               // (at least two steps of the 2^-32 grid the check works on)
                 near_lo = (uint32_t)((tq + tq) * 0x1p32) + 2u;
             } else {
@@ -576,12 +579,16 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
             // term by term from the voice's own list, like the reference's loop: a quarter of the record (four frames per lane) at a time,
             // every frame from a table lookup of its own, the lanes in reach of an integer through the list. ----
             uint64_t any_near = 0;
+            if constexpr (GUARD) {
 #pragma unroll
-            for (int h = 0; h < NQ; ++h) {
-                nearm[h] = __builtin_amdgcn_ballot_w64(nearv[h] <= near_lo);
-                any_near |= nearm[h];
+                for (int h = 0; h < NQ; ++h) {
+                    nearm[h] = __builtin_amdgcn_ballot_w64(nearv[h] <= near_lo);
+                    any_near |= nearm[h];
+                }
+            } else if ((gword & 0x7F800000u) == 0x7F800000u) {
+                mx = 0x7FFFFFFF;                                  // a record that holds a NaN or an infinity (prepare_chunk): OverflowError, as on the general path
             }
-            if (any_near != 0) {
+            if (GUARD && any_near != 0) {
                 const uint32_t glen = gword & 0xFFu;
                 const sh_partial SH_CONST_AS* gl = reinterpret_cast<const sh_partial SH_CONST_AS*>((uintptr_t)__double_as_longlong(q->pad2));
 #pragma unroll 1
@@ -770,10 +777,19 @@ int generate_rows(sh_bank* b, uint64_t start, uint32_t nframes, OutT* o, size_t 
         const int LF = lf;
         // workgroups per chunk of records: enough waves for several rounds of the chip's wave slots (1, 4, 8 measured: CHANGELOG item 38)
         const uint32_t rsplit = 2;
+        // (the int16 kernels in two forms: with the boundary guard's check, and -- a bank none of whose voices carries a guard list -- without)
+        constexpr bool I16_ = RowOut<OutT>::I16;
+        const bool guard = !I16_ || b->has_guard;
 #define SH_GEN_LEAN(GRID_, ...) do { \
-            if (LF == 16) hipLaunchKernelGGL((k_generate_lean_harm<16, OutT>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); \
-            else if (LF == 8) hipLaunchKernelGGL((k_generate_lean_harm<8, OutT>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); \
-            else hipLaunchKernelGGL((k_generate_lean_harm<4, OutT>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); } while (0)
+            if (!I16_ || guard) { \
+                if (LF == 16) hipLaunchKernelGGL((k_generate_lean_harm<16, OutT>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); \
+                else if (LF == 8) hipLaunchKernelGGL((k_generate_lean_harm<8, OutT>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); \
+                else hipLaunchKernelGGL((k_generate_lean_harm<4, OutT>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); \
+            } else { \
+                if (LF == 16) hipLaunchKernelGGL((k_generate_lean_harm<16, OutT, false, !I16_>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); \
+                else if (LF == 8) hipLaunchKernelGGL((k_generate_lean_harm<8, OutT, false, !I16_>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); \
+                else hipLaunchKernelGGL((k_generate_lean_harm<4, OutT, false, !I16_>), GRID_, dim3(256), 0, st, __VA_ARGS__, scale, flag); \
+            } } while (0)
         constexpr uint32_t SEG = 65536;                      // frames per segment (a multiple of the 1024-frame tile)
         hipStream_t st = sh::state().stream;
         const uint32_t nchunks = sh::div_up(b->nvoices, 64);
@@ -995,8 +1011,10 @@ int mixdown_fused(sh_bank* b, uint64_t start, uint32_t len, double scale, short*
     none.n = 0;
     const dim3 grid(sh::div_up(len, 256 * lf), nplanes);
     const uint32_t seg_frames = nseg == 1 ? (len + 1023u) / 1024u * 1024u : SEG;
-#define SH_MIXDOWN(F_) hipLaunchKernelGGL((k_generate_lean_harm<F_, short, true>), grid, dim3(256), 0, st, trig_table(), base, b->nvoices, len, seg_frames, \
-                                          (short*)nullptr, (size_t)0, none, rsplit, scale, flag, (int2v*)parts.buf.ptr, (size_t)len)
+#define SH_MIXDOWN(F_) do { if (b->has_guard) hipLaunchKernelGGL((k_generate_lean_harm<F_, short, true>), grid, dim3(256), 0, st, trig_table(), base, b->nvoices, len, seg_frames, \
+                                          (short*)nullptr, (size_t)0, none, rsplit, scale, flag, (int2v*)parts.buf.ptr, (size_t)len); \
+                            else hipLaunchKernelGGL((k_generate_lean_harm<F_, short, true, false>), grid, dim3(256), 0, st, trig_table(), base, b->nvoices, len, seg_frames, \
+                                          (short*)nullptr, (size_t)0, none, rsplit, scale, flag, (int2v*)parts.buf.ptr, (size_t)len); } while (0)
     if (lf == 16) SH_MIXDOWN(16); else if (lf == 8) SH_MIXDOWN(8); else SH_MIXDOWN(4);
 #undef SH_MIXDOWN
     SH_CHECK_LAUNCH("k_generate_lean_harm(fold)");

@@ -22,6 +22,7 @@ struct sh_bank {
     uint32_t*   d_gen_idx_buf[NSETS] = {};
     uint32_t*   d_counts_buf[NSETS] = {};      // 4 per 64-voice chunk: lean, general, silent, -
     uint32_t*   d_hint = nullptr;
+    bool        has_guard = false;         // some voice carries a guard list (sh_voice::guard_count): the int16 kernels with the boundary check
     // one arrival counter per tile of a SELF-FOLDING launch (a render that stands alone: the last workgroup of a tile to store its
     // partial bus folds the tile's planes itself -- no k_bus_combine behind the launch); behind d_hint's 2 * nvoices words, zero
     // between launches (the folding workgroup resets its counter)

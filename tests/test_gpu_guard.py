@@ -167,10 +167,16 @@ def test_a_nan_amplitude_is_an_overflow_on_every_route(gpu):
     from synthesizer_amd import _native as N
     from synthesizer_amd import oscillators as G
     from synthesizer_amd.mixer import VoiceBank
-    for n in (1000, 20000):
-        v = [G.Harmonics(440.0, H16, 0.1, samplerate=SR), G.Harmonics(550.0, H16, float("nan"), samplerate=SR)]
-        bank = VoiceBank(v)
-        with pytest.raises(OverflowError):
-            bank.generate_i16_device(n, 0)
-        with pytest.raises(OverflowError):
-            bank.mixdown_i16_device(n, 0)
+    from synthesizer_amd import params
+    for guard in (True, False):                    # (False: banks without guard lists take the int16 kernels without the check)
+        params.int16_guard = guard
+        try:
+            for n in (1000, 20000):
+                v = [G.Harmonics(440.0, H16, 0.1, samplerate=SR), G.Harmonics(550.0, H16, float("nan"), samplerate=SR)]
+                bank = VoiceBank(v)
+                with pytest.raises(OverflowError):
+                    bank.generate_i16_device(n, 0)
+                with pytest.raises(OverflowError):
+                    bank.mixdown_i16_device(n, 0)
+        finally:
+            params.int16_guard = True
