@@ -396,6 +396,25 @@ int sh_mix_chain(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint32_t
 int sh_mix_chain_gather(const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
                         uint32_t nsamples, int width, sh_buf* out, size_t out_sample_off);
 
+/* ---- the real-time lane -------------------------------------------------------------------------------------------------------
+ * Replaces: the thread upstream's playback.py runs its mixer on (the output thread pulls RealTimeMixer.chunks() while other threads
+ * make sound).  Every entry point above holds the library's one lock and enqueues on its one stream pair: a mixer turn from another
+ * thread queues behind whatever the others have enqueued, and its download holds the lock while the stream drains.  A LANE is a
+ * stream (high priority), a lock, a source-table buffer and a chunk buffer of its own: sh_rt_mix_turn -- the ordered saturating fold
+ * of sh_mix_chain_gather over the sources' current chunks (bit-identical: the same kernels) + the chunk copied to out_host --
+ * takes the lane's lock only and waits for the lane's stream only; it returns when out_host holds the chunk.  Order against the
+ * library's streams is established once per source: sh_rt_acquire(lane, src) makes the lane's next turn wait (on the device) for
+ * everything the library has been given so far -- the upload / resample / render that made `src` -- and folds first what a render
+ * still owes into it.  After that the caller must not write `src` while the lane can read it, and must not free it before the last
+ * turn that names it has returned (turns are synchronous: once sh_rt_mix_turn is back nothing of the lane is in flight).
+ * One lane per mixer; distinct lanes are independent; sh_rt_create / sh_rt_destroy / sh_rt_acquire take the library's lock. */
+typedef struct sh_rt sh_rt;
+int sh_rt_create(size_t max_chunk_bytes, uint32_t max_sources, sh_rt** out);
+int sh_rt_destroy(sh_rt* lane);
+int sh_rt_acquire(sh_rt* lane, const sh_buf* src);
+int sh_rt_mix_turn(sh_rt* lane, const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
+                   uint32_t nsamples, int width, void* out_host);
+
 /* ---- Sample.from_osc_block: int(scale*v), truncation toward zero; SH_ERR_OVERFLOW if out of range */
 int sh_quantize_f32(const sh_buf* in_f32, size_t in_off, size_t n, double scale, int width,
                     sh_buf* out_pcm, size_t out_off);

@@ -125,6 +125,10 @@ _SIGNATURES = {
     "sh_mix_chain_gather_i16": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, _P, C.c_size_t]),
     "sh_mix_chain": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_uint32, C.c_int, _P]),
     "sh_mix_chain_gather": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, _P, C.c_size_t]),
+    "sh_rt_create": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_P)]),
+    "sh_rt_destroy": (C.c_int, [_P]),
+    "sh_rt_acquire": (C.c_int, [_P, _P]),
+    "sh_rt_mix_turn": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "sh_quantize_f32": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_double, C.c_int, _P, C.c_size_t]),
     "sh_quantize_f64": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_double, C.c_int, _P, C.c_size_t]),
     "sh_quantize_clip_f32": (C.c_int, [_P, C.c_size_t, C.c_double, _P]),
@@ -303,6 +307,43 @@ def device_pci() -> str:
     buf = C.create_string_buffer(64)
     check(lib().sh_device_pci(buf, 64))
     return buf.value.decode()
+
+
+class RtLane:
+    """A real-time lane (sh_rt_*; include/synthhip.h): a stream, a lock and buffers of its own for a mixer that another thread drains
+    while the library's one stream pair is busy.  ``mix_turn`` returns the chunk as bytes and takes the lane's lock only."""
+
+    def __init__(self, max_chunk_bytes: int, max_sources: int = 1024) -> None:
+        ensure_init()
+        self._h = _P()
+        self.max_chunk_bytes = int(max_chunk_bytes)
+        check(lib().sh_rt_create(self.max_chunk_bytes, int(max_sources), C.byref(self._h)))
+        self._out = (C.c_char * self.max_chunk_bytes)()
+
+    def acquire(self, buf: "DeviceBuffer") -> None:
+        """The lane's next turn waits (on the device) for everything the library has been given so far: what made ``buf``."""
+        check(lib().sh_rt_acquire(self._h, buf.handle))
+
+    def mix_turn(self, sources, nsamples: int, width: int) -> bytes:
+        n = len(sources)
+        bufs = (C.c_void_p * max(n, 1))(*[b.handle for b, _o, _n in sources])
+        offs = (C.c_size_t * max(n, 1))(*[o for _b, o, _n in sources])
+        lens = (C.c_uint32 * max(n, 1))(*[min(k, 0xFFFFFFFF) for _b, _o, k in sources])
+        check(lib().sh_rt_mix_turn(self._h, bufs, offs, lens, n, nsamples, width, C.cast(self._out, C.c_void_p)))
+        return self._out.raw[:nsamples * width]
+
+    def close(self) -> None:
+        if self._h:
+            try:
+                lib().sh_rt_destroy(self._h)
+            finally:
+                self._h = _P()
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def debug_counters() -> dict:

@@ -7,6 +7,8 @@
 // cross-wave combine of the mixer chain.  Built with -ffp-contract=off: audioop forms
 // prev*d + cur*(outrate-d) with two roundings and a division, and so does k_resample.
 #include "common.hpp"
+#include <mutex>
+#include <string.h>
 #include <new>
 
 #define SH_PCM_CONST __attribute__((address_space(4)))
@@ -1199,15 +1201,32 @@ int sh_mix_chain_pan_i16(const sh_buf* chunks, uint32_t nvoices, size_t stride, 
     return SH_OK;
 }
 
-int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
-                            uint32_t nsamples, sh_buf* out, size_t out_sample_off) {
-    SH_REQUIRE_INIT();
-    if (!out || (nsrc && (!srcs || !sample_offsets || !nsamples_each))) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: NULL argument");
-    if (nsrc > 32768) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: at most 32768 sources");
-    if (nsamples > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: at most 2^32 - 65536 samples per call");
-    if (out_sample_off > out->bytes / 2 || nsamples > out->bytes / 2 - out_sample_off)
-        return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: output range outside buffer");
-    if (!nsamples) return SH_OK;
+}  // extern "C"
+
+namespace {
+// Where a gather fold runs: the library's stream with its grow-only scratch (the table of a turn with more than 64 sources), or a
+// real-time lane's stream with the lane's own table buffer (sh_rt: below).
+struct GatherLane {
+    hipStream_t st;
+    void*       tab_dev;          // NULL: the library's scratch (sh::ensure_scratch)
+    size_t      tab_cap;
+};
+int lane_table(const GatherLane& L, const void* host, size_t bytes, const void** dev) {
+    if (!L.tab_dev) {
+        int rc = sh::ensure_scratch(bytes);
+        if (rc) return rc;
+        *dev = sh::state().scratch;
+    } else {
+        if (bytes > L.tab_cap) return sh::set_error(SH_ERR_INVALID, "real-time lane: %zu sources, the lane was created for %zu", bytes / 16, L.tab_cap / 16);
+        *dev = L.tab_dev;
+    }
+    // the table goes through the stream (pageable source: staged before the call returns, ordered after earlier kernels)
+    SH_HIP(hipMemcpyAsync(const_cast<void*>(*dev), host, bytes, hipMemcpyHostToDevice, L.st));
+    return SH_OK;
+}
+
+int gather_i16_on(const GatherLane& L, const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
+                  uint32_t nsamples, short* op) {
     std::vector<ChainSrc> tab;
     tab.reserve(nsrc);
     for (uint32_t v = 0; v < nsrc; ++v) {
@@ -1220,8 +1239,7 @@ int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offs
         c.pad = 0;
         tab.push_back(c);
     }
-    hipStream_t st = sh::state().stream;
-    short* op = (short*)out->ptr + out_sample_off;
+    hipStream_t st = L.st;
     if (tab.empty()) {
         SH_HIP(hipMemsetAsync(op, 0, (size_t)nsamples * 2, st));
         return SH_OK;
@@ -1236,24 +1254,166 @@ int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offs
         SH_CHECK_LAUNCH("k_mix_chain_gather_args");
         return SH_OK;
     }
-    int rc = sh::ensure_scratch(tab.size() * sizeof(ChainSrc));
+    const void* dtab = nullptr;
+    int rc = lane_table(L, tab.data(), tab.size() * sizeof(ChainSrc), &dtab);
     if (rc) return rc;
-    // the table goes through the stream (pageable source: staged before the call returns, ordered after earlier kernels)
-    SH_HIP(hipMemcpyAsync(sh::state().scratch, tab.data(), tab.size() * sizeof(ChainSrc), hipMemcpyHostToDevice, st));
     const uint32_t n = (uint32_t)tab.size();
     dim3 grid(sh::div_up(nsamples, 512));
     size_t read_bytes = 0;
     for (const ChainSrc& c : tab) read_bytes += (size_t)c.n * 2;
     if (sh::div_up(nsamples, 512) >= 1536 && read_bytes > sh::STREAM_BYTES)
-        hipLaunchKernelGGL((k_mix_chain_gather_direct<8, 4, true>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
-                           (const ChainSrc*)sh::state().scratch, n, nsamples, op);
+        hipLaunchKernelGGL((k_mix_chain_gather_direct<8, 4, true>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st, (const ChainSrc*)dtab, n, nsamples, op);
     else if (sh::div_up(nsamples, 512) >= 1536)
-        hipLaunchKernelGGL((k_mix_chain_gather_direct<8, 4, false>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st,
-                           (const ChainSrc*)sh::state().scratch, n, nsamples, op);
-    else if (n >= 64) hipLaunchKernelGGL(k_mix_chain_gather<8>, grid, dim3(8 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
-    else hipLaunchKernelGGL(k_mix_chain_gather<2>, grid, dim3(2 * 64), 0, st, (const ChainSrc*)sh::state().scratch, n, nsamples, op);
+        hipLaunchKernelGGL((k_mix_chain_gather_direct<8, 4, false>), sh::grid1d(nsamples, 512 * 8), dim3(8 * 64), 0, st, (const ChainSrc*)dtab, n, nsamples, op);
+    else if (n >= 64) hipLaunchKernelGGL(k_mix_chain_gather<8>, grid, dim3(8 * 64), 0, st, (const ChainSrc*)dtab, n, nsamples, op);
+    else hipLaunchKernelGGL(k_mix_chain_gather<2>, grid, dim3(2 * 64), 0, st, (const ChainSrc*)dtab, n, nsamples, op);
     SH_CHECK_LAUNCH("k_mix_chain_gather");
     return SH_OK;
+}
+
+// widths 1, 3, 4
+int gather_w_on(const GatherLane& L, const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
+                uint32_t nsamples, int width, unsigned char* op) {
+    const size_t w = (size_t)width;
+    std::vector<ChainSrcB> tab;
+    tab.reserve(nsrc);
+    for (uint32_t v = 0; v < nsrc; ++v) {
+        if (!nsamples_each[v]) continue;                  // silence: the fold's identity
+        if (!srcs[v] || sample_offsets[v] > srcs[v]->bytes / w || nsamples_each[v] > srcs[v]->bytes / w - sample_offsets[v])
+            return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather: source %u range outside its buffer", v);
+        ChainSrcB c;
+        c.p = (const unsigned char*)srcs[v]->ptr + sample_offsets[v] * w;
+        c.n = nsamples_each[v] < nsamples ? nsamples_each[v] : nsamples;
+        c.pad = 0;
+        tab.push_back(c);
+    }
+    hipStream_t st = L.st;
+    if (tab.empty()) {
+        SH_HIP(hipMemsetAsync(op, 0, (size_t)nsamples * w, st));
+        return SH_OK;
+    }
+    const void* dtab = nullptr;
+    int rc = lane_table(L, tab.data(), tab.size() * sizeof(ChainSrcB), &dtab);
+    if (rc) return rc;
+    const uint32_t n = (uint32_t)tab.size();
+    const dim3 grid = sh::grid1d(nsamples, 1024);
+    const ChainSrcB* dt = (const ChainSrcB*)dtab;
+    if (width == 1) hipLaunchKernelGGL(k_mix_chain_gather_w<1>, grid, dim3(256), 0, st, dt, n, nsamples, op);
+    else if (width == 3) hipLaunchKernelGGL(k_mix_chain_gather_w<3>, grid, dim3(256), 0, st, dt, n, nsamples, op);
+    else hipLaunchKernelGGL(k_mix_chain_gather_w<4>, grid, dim3(256), 0, st, dt, n, nsamples, op);
+    SH_CHECK_LAUNCH("k_mix_chain_gather_w");
+    return SH_OK;
+}
+}  // namespace
+
+// ---- the real-time lane (include/synthhip.h: sh_rt_*) -----------------------------------------------------------------------------
+// The reference drives its mixer from a thread of its own (playback.py: the output thread pulls chunks) while other threads make
+// sound.  Through the library's one lock and one stream pair that thread's turn queues behind whatever the others have enqueued and
+// its download holds the lock while the stream drains.  A lane is a stream (high priority), a lock, a table buffer and a chunk
+// buffer of its own: a turn -- the gather fold + the chunk back to the host -- takes the LANE's lock only and waits for the lane's
+// stream only.  Order against the library's streams is established once per source, by sh_rt_acquire.
+struct sh_rt {
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev1 = nullptr, ev2 = nullptr;
+    std::mutex  mu;
+    void*       tab_dev = nullptr;
+    size_t      tab_cap = 0;
+    void*       out_dev = nullptr;
+    void*       out_pinned = nullptr;
+    size_t      out_cap = 0;
+};
+
+extern "C" {
+
+int sh_rt_create(size_t max_chunk_bytes, uint32_t max_sources, sh_rt** out) {
+    SH_REQUIRE_INIT();
+    if (!out || max_chunk_bytes == 0) return sh::set_error(SH_ERR_INVALID, "sh_rt_create: NULL / empty argument");
+    sh_rt* r = new (std::nothrow) sh_rt;
+    if (!r) return sh::set_error(SH_ERR_NOMEM, "host allocation failed");
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                      // (hi: the numerically lowest = most urgent)
+    hipError_t e = hipStreamCreateWithPriority(&r->stream, hipStreamNonBlocking, hi);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev1, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev2, hipEventDisableTiming);
+    r->tab_cap = (size_t)(max_sources < 64 ? 64 : max_sources) * 16;
+    r->out_cap = (max_chunk_bytes + 255) & ~(size_t)255;
+    if (e == hipSuccess) e = hipMalloc(&r->tab_dev, r->tab_cap);
+    if (e == hipSuccess) e = hipMalloc(&r->out_dev, r->out_cap);
+    if (e == hipSuccess) e = hipHostMalloc(&r->out_pinned, r->out_cap, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        sh_rt_destroy(r);
+        return sh::hip_error(e, "sh_rt_create");
+    }
+    *out = r;
+    return SH_OK;
+}
+
+int sh_rt_destroy(sh_rt* r) {
+    if (!r) return SH_OK;
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    if (r->out_pinned) (void)hipHostFree(r->out_pinned);
+    if (r->out_dev) (void)hipFree(r->out_dev);
+    if (r->tab_dev) (void)hipFree(r->tab_dev);
+    if (r->ev1) (void)hipEventDestroy(r->ev1);
+    if (r->ev2) (void)hipEventDestroy(r->ev2);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+    return SH_OK;
+}
+
+int sh_rt_acquire(sh_rt* r, const sh_buf* src) {
+    SH_API_LOCK();                                            // (the library's lock: this call looks at the library's streams)
+    if (!sh::state().initialized) return sh::set_error(SH_ERR_NOTINIT, "sh_init() has not been called");
+    if (!r || !src) return sh::set_error(SH_ERR_INVALID, "sh_rt_acquire: NULL argument");
+    int rc = sh::bind_thread_to_device();
+    if (rc) return rc;
+    if (sh::fold_owed_into(src->ptr, src->bytes)) {           // a render still owes a fold into this memory: done now
+        rc = sh::flush_pending();
+        if (rc) return rc;
+    }
+    // whatever either of the library's streams has been given so far precedes the lane's next turn (events: nobody waits on the host)
+    sh::State& S = sh::state();
+    SH_HIP(hipEventRecord(r->ev1, S.stream));
+    SH_HIP(hipStreamWaitEvent(r->stream, r->ev1, 0));
+    if (S.stream2) {
+        SH_HIP(hipEventRecord(r->ev2, S.stream2));
+        SH_HIP(hipStreamWaitEvent(r->stream, r->ev2, 0));
+    }
+    return SH_OK;
+}
+
+int sh_rt_mix_turn(sh_rt* r, const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
+                   uint32_t nsamples, int width, void* out_host) {
+    if (!r || !out_host || (nsrc && (!srcs || !sample_offsets || !nsamples_each))) return sh::set_error(SH_ERR_INVALID, "sh_rt_mix_turn: NULL argument");
+    if (width < 1 || width > 4) return sh::set_error(SH_ERR_INVALID, "sh_rt_mix_turn: width %d not in {1, 2, 3, 4}", width);
+    if (nsrc > 32768) return sh::set_error(SH_ERR_INVALID, "sh_rt_mix_turn: at most 32768 sources");
+    const size_t nbytes = (size_t)nsamples * (size_t)width;
+    if (nbytes > r->out_cap) return sh::set_error(SH_ERR_INVALID, "sh_rt_mix_turn: %zu bytes, the lane was created for chunks of %zu", nbytes, r->out_cap);
+    if (!nsamples) return SH_OK;
+    std::lock_guard<std::mutex> lane_lock(r->mu);             // the LANE's lock: the library's is not taken
+    if (!sh::state().initialized) return sh::set_error(SH_ERR_NOTINIT, "sh_init() has not been called");
+    int rc = sh::bind_thread_to_device();
+    if (rc) return rc;
+    const GatherLane L{r->stream, r->tab_dev, r->tab_cap};
+    rc = width == 2 ? gather_i16_on(L, srcs, sample_offsets, nsamples_each, nsrc, nsamples, (short*)r->out_dev)
+                    : gather_w_on(L, srcs, sample_offsets, nsamples_each, nsrc, nsamples, width, (unsigned char*)r->out_dev);
+    if (rc) return rc;
+    SH_HIP(hipMemcpyAsync(r->out_pinned, r->out_dev, nbytes, hipMemcpyDeviceToHost, r->stream));
+    SH_HIP(hipStreamSynchronize(r->stream));
+    memcpy(out_host, r->out_pinned, nbytes);
+    return SH_OK;
+}
+
+int sh_mix_chain_gather_i16(const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
+                            uint32_t nsamples, sh_buf* out, size_t out_sample_off) {
+    SH_REQUIRE_INIT();
+    if (!out || (nsrc && (!srcs || !sample_offsets || !nsamples_each))) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: NULL argument");
+    if (nsrc > 32768) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: at most 32768 sources");
+    if (nsamples > 0xFFFF0000u) return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: at most 2^32 - 65536 samples per call");
+    if (out_sample_off > out->bytes / 2 || nsamples > out->bytes / 2 - out_sample_off)
+        return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather_i16: output range outside buffer");
+    if (!nsamples) return SH_OK;
+    return gather_i16_on(GatherLane{sh::state().stream, nullptr, 0}, srcs, sample_offsets, nsamples_each, nsrc, nsamples, (short*)out->ptr + out_sample_off);
 }
 
 int sh_mix_chain_gather(const sh_buf* const* srcs, const size_t* sample_offsets, const uint32_t* nsamples_each, uint32_t nsrc,
@@ -1268,35 +1428,8 @@ int sh_mix_chain_gather(const sh_buf* const* srcs, const size_t* sample_offsets,
     if (out_sample_off > out->bytes / w || nsamples > out->bytes / w - out_sample_off)
         return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather: output range outside buffer");
     if (!nsamples) return SH_OK;
-    std::vector<ChainSrcB> tab;
-    tab.reserve(nsrc);
-    for (uint32_t v = 0; v < nsrc; ++v) {
-        if (!nsamples_each[v]) continue;                  // silence: the fold's identity
-        if (!srcs[v] || sample_offsets[v] > srcs[v]->bytes / w || nsamples_each[v] > srcs[v]->bytes / w - sample_offsets[v])
-            return sh::set_error(SH_ERR_INVALID, "sh_mix_chain_gather: source %u range outside its buffer", v);
-        ChainSrcB c;
-        c.p = (const unsigned char*)srcs[v]->ptr + sample_offsets[v] * w;
-        c.n = nsamples_each[v] < nsamples ? nsamples_each[v] : nsamples;
-        c.pad = 0;
-        tab.push_back(c);
-    }
-    hipStream_t st = sh::state().stream;
-    unsigned char* op = (unsigned char*)out->ptr + out_sample_off * w;
-    if (tab.empty()) {
-        SH_HIP(hipMemsetAsync(op, 0, (size_t)nsamples * w, st));
-        return SH_OK;
-    }
-    int rc = sh::ensure_scratch(tab.size() * sizeof(ChainSrcB));
-    if (rc) return rc;
-    SH_HIP(hipMemcpyAsync(sh::state().scratch, tab.data(), tab.size() * sizeof(ChainSrcB), hipMemcpyHostToDevice, st));
-    const uint32_t n = (uint32_t)tab.size();
-    const dim3 grid = sh::grid1d(nsamples, 1024);
-    const ChainSrcB* dt = (const ChainSrcB*)sh::state().scratch;
-    if (width == 1) hipLaunchKernelGGL(k_mix_chain_gather_w<1>, grid, dim3(256), 0, st, dt, n, nsamples, op);
-    else if (width == 3) hipLaunchKernelGGL(k_mix_chain_gather_w<3>, grid, dim3(256), 0, st, dt, n, nsamples, op);
-    else hipLaunchKernelGGL(k_mix_chain_gather_w<4>, grid, dim3(256), 0, st, dt, n, nsamples, op);
-    SH_CHECK_LAUNCH("k_mix_chain_gather_w");
-    return SH_OK;
+    return gather_w_on(GatherLane{sh::state().stream, nullptr, 0}, srcs, sample_offsets, nsamples_each, nsrc, nsamples, width,
+                       (unsigned char*)out->ptr + out_sample_off * w);
 }
 
 int sh_mix_chain(const sh_buf* chunks, uint32_t nvoices, size_t stride, uint32_t nsamples, int width, sh_buf* out) {

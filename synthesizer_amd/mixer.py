@@ -492,6 +492,7 @@ class _MixSource:
         self.loop_bytes = loop_bytes    # 0 = one-shot
         self.pos = 0
         self.delay = delay
+        self.acquired = False           # ordered behind its producers on the mixer's real-time lane (RealTimeMixer.chunks)
 
 
 class RealTimeMixer:
@@ -506,6 +507,8 @@ class RealTimeMixer:
     one kernel over a pointer table plus ``chunksize`` bytes back to the host.  ``chunks_device()`` yields the device
     buffer instead, for a consumer that keeps going on the GPU (level metering, resampling)."""
 
+    use_lane = True           # chunks() on the mixer's real-time lane; False: through the library's lock and stream (rounds 1-5; the A/B of tests/test_gpu_realtime_mixer.py)
+
     def __init__(self, chunksize: int, all_played_callback: Optional[Callable[[], None]] = None, samplewidth: int = 2) -> None:
         if samplewidth not in (1, 2, 3, 4):
             raise ValueError("samplewidth must be 1, 2, 3 or 4")
@@ -519,6 +522,7 @@ class RealTimeMixer:
         self.active_samples: Dict[int, _MixSource] = {}
         self.sample_counter = 0
         self._out = [N.DeviceBuffer(chunksize), N.DeviceBuffer(chunksize)]      # the consumer may still hold the last one
+        self._lane: Optional[N.RtLane] = None                                    # created by the first chunks() turn
 
     def add_sample(self, sample: Sample, repeat: bool = False, chunk_delay: int = 0, sid: Optional[int] = None) -> int:
         """Start playing a sample; returns its id.  ``repeat`` loops it forever, ``chunk_delay`` holds it back."""
@@ -558,9 +562,16 @@ class RealTimeMixer:
             self.active_samples.clear()
         self.all_played_callback()
 
-    def _turn(self) -> N.DeviceBuffer:
+    def _advance(self, lane: Optional[N.RtLane] = None) -> list:
+        """One turn of the play positions: the (buffer, first sample, samples available) of every source that sounds in this chunk.
+        With a real-time lane: a source the lane has not seen yet is ordered behind its producers first (sh_rt_acquire)."""
         with self.add_lock:
             active = list(self.active_samples.items())
+        if lane is not None:
+            for _sid, src in active:
+                if not src.acquired:
+                    lane.acquire(src.buf)
+                    src.acquired = True
         sources = []
         finished = []
         for sid, src in active:
@@ -584,10 +595,25 @@ class RealTimeMixer:
                 empty = not self.active_samples
             if empty:
                 self.all_played_callback()
+        return sources
+
+    def _turn(self) -> N.DeviceBuffer:
+        sources = self._advance()
         out = self._out[self.chunks_mixed & 1]
         _gather(sources, self.chunksize // self.samplewidth, out, self.samplewidth)
         self.chunks_mixed += 1
         return out
+
+    def _turn_host(self) -> bytes:
+        """One chunk on the mixer's REAL-TIME LANE (sh_rt_*): a stream, a lock and buffers of the mixer's own -- the turn neither takes the
+        library's lock nor queues behind what other threads have enqueued (a bank streaming its blocks, Sample operations); the same
+        fold kernels as ``_turn``: bit-identical chunks.  A source is ordered behind its producers once, before its first turn."""
+        if self._lane is None:
+            self._lane = N.RtLane(self.chunksize, max_sources=32768)
+        sources = self._advance(self._lane)
+        chunk = self._lane.mix_turn(sources, self.chunksize // self.samplewidth, self.samplewidth)
+        self.chunks_mixed += 1
+        return chunk
 
     def chunks_device(self) -> Generator[N.DeviceBuffer, None, None]:
         """Endless stream of mixed chunks left in HBM (valid until the turn after the next)."""
@@ -595,6 +621,6 @@ class RealTimeMixer:
             yield self._turn()
 
     def chunks(self) -> Generator[memoryview, None, None]:
-        """Endless stream of mixed chunks, ``chunksize`` bytes each."""
+        """Endless stream of mixed chunks, ``chunksize`` bytes each (on the mixer's real-time lane: see ``_turn_host``)."""
         while True:
-            yield memoryview(self._turn().download_bytes(self.chunksize))
+            yield memoryview(self._turn_host() if self.use_lane else self._turn().download_bytes(self.chunksize))
