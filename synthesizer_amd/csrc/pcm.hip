@@ -1332,7 +1332,18 @@ int sh_rt_create(size_t max_chunk_bytes, uint32_t max_sources, sh_rt** out) {
     if (!r) return sh::set_error(SH_ERR_NOMEM, "host allocation failed");
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                      // (hi: the numerically lowest = most urgent)
-    hipError_t e = hipStreamCreateWithPriority(&r->stream, hipStreamNonBlocking, hi);
+    hipError_t e;
+    const int rt_cus = sh::knobs().rt_cus;
+    if (rt_cus > 0) {                                                     // the compute units the library's streams leave out (SYNTHHIP_RT_CUS)
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, sh::state().device);
+        const int ncu = e == hipSuccess ? prop.multiProcessorCount : 0;
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int c = ncu - rt_cus; c >= 0 && c < ncu; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+        if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&r->stream, (uint32_t)mask.size(), mask.data());
+    } else {
+        e = hipStreamCreateWithPriority(&r->stream, hipStreamNonBlocking, hi);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev1, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev2, hipEventDisableTiming);
     r->tab_cap = (size_t)(max_sources < 64 ? 64 : max_sources) * 16;

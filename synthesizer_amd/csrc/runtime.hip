@@ -35,6 +35,7 @@ void load_knobs() {
     k.no_tiles = flag("SYNTHHIP_NO_TILES");
     k.no_small_pipeline = flag("SYNTHHIP_NO_SMALL_PIPELINE");
     k.self = (int)num("SYNTHHIP_SELF", 0);
+    k.rt_cus = (int)num("SYNTHHIP_RT_CUS", 0);
     k.variant = (int)num("SYNTHHIP_VARIANT", 0);
     k.groups = (int)num("SYNTHHIP_GROUPS", 0);
     k.pool_fill = (int)num("SYNTHHIP_POOL_FILL", -1);
@@ -217,8 +218,22 @@ int sh_init(int device) {
     if (n <= 0) return sh::set_error(SH_ERR_NOTINIT, "no HIP device visible");
     if (device < 0 || device >= n) return sh::set_error(SH_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
     SH_HIP(hipSetDevice(device));
-    SH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    SH_HIP(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+    // SYNTHHIP_RT_CUS=n (0: off): the last n compute units are kept for real-time lanes (sh_rt_*) -- the library's streams are created with
+    // a CU mask that leaves them out, a lane's stream with a mask of them alone: a mixer turn then never waits for wavefronts of a render
+    // launch to retire, and every render launch pays n of the chip's CUs (profiles/r06_rt_lane.txt).
+    const int rt_cus = sh::knobs().rt_cus;
+    if (rt_cus > 0) {
+        hipDeviceProp_t prop;
+        SH_HIP(hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int c = 0; c < ncu - rt_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+        SH_HIP(hipExtStreamCreateWithCUMask(&s.stream, (uint32_t)mask.size(), mask.data()));
+        SH_HIP(hipExtStreamCreateWithCUMask(&s.stream2, (uint32_t)mask.size(), mask.data()));
+    } else {
+        SH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        SH_HIP(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+    }
     SH_HIP(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
     SH_HIP(hipEventCreateWithFlags(&s.ev_aux, hipEventDisableTiming));
     SH_HIP(hipEventCreateWithFlags(&s.ev_prep, hipEventDisableTiming));
