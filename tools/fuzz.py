@@ -6,6 +6,7 @@
     late         Random single oscillators -- the five waveforms and Harmonics, plain or under a Sine LFO, some under an envelope with a long sustain --
     mix          One-off sweep: mixer.mix_samples (the saturating fold in voice order) and Sample.mix against the live audioop.add.
     ratecv       One-off sweep: Sample.resample against the live audioop.ratecv over random rates, widths, layouts and lengths.
+    int16        Random additive banks through the integer routes (generate_i16 rows, fused mixdown) against the C oracle's quantised samples: equal
     transitions  Random additive banks (shared or per-voice ADSRs, negative phases, silent and endless voices) rendered over random launches
 
 Exit status 1 when a sweep found a mismatch.  (profiles/r04_fuzz.txt: what they found in round 4.)
@@ -170,6 +171,86 @@ voices of a VoiceBank against the oracle's bus.  usage: python tools/fuzz_osc.py
     print("banks", (min(len(recipes), 96) + 11) // 12, "mismatches", bad_bank)
     return int(bool(locals().get("bad", 0) or locals().get("bad_bank", 0)))
 
+
+
+def fuzz_int16(argv):
+    """Random additive banks through the INTEGER routes -- generate_i16 rows and the fused mixdown -- against the C oracle's quantised samples and the
+live audioop chain over them: strict equality (round 6: the int16 boundary guard).  Harmonic lists: 1/k series of even and odd length (flat and
+not flat at their zero crossing), random amplitudes, repeated and negative k, dense lists beyond 16 (Clenshaw), one partial; amplitudes from
+quiet to nearly full scale; no envelope, a shared ADSR, ADSRs of their own; windows at the start of the notes (attack / decay: the general
+code), seconds and minutes in; row lengths that take every materialisation kernel.  usage: python tools/fuzz.py int16 [seed] [cases]"""
+    import audioop
+    import numpy as np
+    from oracle import c_oracle as CO
+    from oracle import synth_oracle as O
+    from synthesizer_amd import oscillators as G
+    from synthesizer_amd.mixer import VoiceBank
+    seed = int(argv[0]) if len(argv) > 0 else 0
+    cases = int(argv[1]) if len(argv) > 1 else 40
+    rng = np.random.default_rng(seed)
+    SR = 48000
+    bad = 0
+    total = 0
+    for case in range(cases):
+        nv = int(rng.choice([1, 3, 16, 64, 65, 130]))
+        kind = int(rng.integers(0, 6))
+        def harm():
+            if kind == 0:
+                return [(k, 1.0 / k) for k in range(1, 17)]
+            if kind == 1:
+                return [(k, 1.0 / k) for k in range(1, int(rng.integers(2, 16)))]
+            if kind == 2:
+                return [(k, float(rng.uniform(-1, 1))) for k in range(1, 17)]
+            if kind == 3:
+                return [(int(rng.integers(-16, 17)) or 1, float(rng.uniform(-0.5, 0.5))) for _ in range(int(rng.integers(1, 24)))]
+            if kind == 4:
+                return [(k, 1.0 / k) for k in range(1, int(rng.integers(18, 48)))]
+            return [(int(rng.integers(1, 17)), 1.0)]
+        lists = [harm() for _ in range(3)]
+        env_mode = int(rng.integers(0, 3))                 # 0 none, 1 shared, 2 own
+        late = bool(rng.integers(0, 2)) and env_mode != 2
+        start = int(rng.choice([5, 30, 300, 1800])) * SR + int(rng.integers(0, 5000)) if late else int(rng.choice([0, 0, 777, 30000]))
+        n = int(rng.choice([700, 3000, 9000, 20000, 70001, 140000])) if nv <= 16 else int(rng.choice([700, 9000, 20000]))
+        f = np.exp(rng.uniform(np.log(30.0), np.log(6000.0), nv))
+        peak = [sum(abs(a) for _k, a in h) for h in lists]
+        which = rng.integers(0, 3, nv)
+        amp = rng.uniform(0.02, 0.95, nv) / np.array([max(peak[w], 1e-9) for w in which])
+        ph = rng.uniform(-0.5, 1.0, nv)
+        shared = (0.01, 0.05, 1.0e6 if late else float(rng.uniform(0.05, 0.5)), 0.6, 0.2)
+        own = [(float(rng.uniform(0, 0.02)), float(rng.uniform(0, 0.05)), float(rng.uniform(0.01, 0.4)), float(rng.uniform(0.1, 1.0)), float(rng.uniform(0, 0.1))) for _ in range(nv)]
+
+        def make(M):
+            out = []
+            for i in range(nv):
+                o = M.Harmonics(float(f[i]), lists[which[i]], amplitude=float(amp[i]), phase=float(ph[i]), samplerate=SR)
+                if env_mode == 1:
+                    o = M.EnvelopeFilter(o, *shared)
+                elif env_mode == 2:
+                    o = M.EnvelopeFilter(o, *own[i])
+                out.append(o)
+            return out
+        ov = make(O)
+        if late:
+            want = np.stack([CO.quantise(CO.render_window(o, start, n)).astype(np.int16) for o in ov])
+        else:
+            want = np.stack([CO.quantise(CO.render(o, start + n)[start:]).astype(np.int16) for o in ov])
+        bank = VoiceBank(make(G))
+        rows, stride = bank.generate_i16_device(n, start)
+        got = rows.download(np.int16, nv * stride).reshape(nv, stride)[:, :n]
+        nd = int(np.count_nonzero(got != want))
+        chain = want[0].tobytes()
+        for r in want[1:]:
+            chain = audioop.add(chain, r.tobytes(), 2)
+        mono = bank.mixdown_i16_device(n, start).download_bytes(n * 2)
+        md = int(np.count_nonzero(np.frombuffer(mono, dtype=np.int16) != np.frombuffer(chain, dtype=np.int16)))
+        total += want.size
+        if nd or md:
+            bad += 1
+            v, j = (np.argwhere(got != want)[0] if nd else (0, 0))
+            print("case %d: %d voices, list kind %d, envelope mode %d, start %d, %d frames: %d row samples differ (first: voice %d frame %d: %d != %d), %d mixdown samples differ"
+                  % (case, nv, kind, env_mode, start, n, nd, v, j, got[v, j] if nd else 0, want[v, j] if nd else 0, md), flush=True)
+    print("int16 fuzz seed %d: %d cases, %d voice-samples, %d cases with a difference" % (seed, cases, total, bad), flush=True)
+    return 1 if bad else 0
 
 def fuzz_tiles(argv):
     """Random banks of NOTES -- every voice with an onset and an ADSR of its own (zero-length phases, envelopes that end, voices without
@@ -461,7 +542,7 @@ as launches of 8192 frames (never segmented: below the eight-frames-per-lane sha
     return int(bool(locals().get("bad", 0) or locals().get("bad_bank", 0)))
 
 
-FUZZERS = {"osc": fuzz_osc, "tiles": fuzz_tiles, "late": fuzz_late, "mix": fuzz_mix, "ratecv": fuzz_ratecv, "transitions": fuzz_transitions}
+FUZZERS = {"osc": fuzz_osc, "int16": fuzz_int16, "tiles": fuzz_tiles, "late": fuzz_late, "mix": fuzz_mix, "ratecv": fuzz_ratecv, "transitions": fuzz_transitions}
 
 if __name__ == "__main__":
     if len(sys.argv) < 2 or sys.argv[1] not in FUZZERS:
