@@ -871,7 +871,7 @@ def compact_line(out: dict, detail_path=None) -> str:
     gen_frac = (two.get("roofline_generate") or {}).get("frac")
     # the metric asks for "% HBM roofline": the fused headline kernel owes HBM 8 B per frame, so its binding roof is float64 VALU issue;
     # the HBM-regime pair (SURVEY 8(d) regime i: voices materialised, then mixed) is roofline_hbm_regime below
-    line["roofline"] = dict(pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "ops_per_voice_sample", "traffic", "avg_launch_ms", "launches_in_flight", "profile_stale")),
+    line["roofline"] = dict(pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "ops_per_voice_sample", "traffic", "avg_launch_ms", "launches_in_flight", "profile_stale", "sin_evals_per_s")),
                             algorithmic_bytes=hbm.get("algorithmic_bytes"), traffic_over_algorithmic=hbm.get("traffic_over_algorithmic"),
                             hbm=pick(hbm, ("achieved", "frac", "peak", "unit")),
                             why="fused generate-and-mix writes 8 B per frame: HBM idle by construction, float64 VALU issue binds (SURVEY 8(d) regime ii)")
@@ -1167,6 +1167,9 @@ def main() -> int:
                       "note": "the same work counted in FLOPs (FMA = 2) against the 78.6 TFLOP/s vector figure: lower, because "
                               "MUL and ADD fill an issue slot with one FLOP"},
             "traffic": traffic_bytes, "traffic_source": prof["source"],
+            # SURVEY 8(d) regime ii asks for the sine evaluations too: the algorithm's -- one per partial and voice-sample (the reference calls
+            # math.sin PARTIALS times per sample; the kernel gets them from one table lookup per sixteen frames, a recurrence and a Horner chain)
+            "sin_evals_per_s": local_voices * F * PARTIALS / kern_s,
             "avg_launch_ms": kern_s * 1e3,
             "launches_in_flight": 1 if os.environ.get("SYNTHHIP_NO_OVERLAP") == "1" else 2,
             "why": "the fused kernel writes 8 B per output frame and reads only the voice table: HBM is idle by construction "
