@@ -285,7 +285,7 @@ def test_the_real_time_lane_beside_a_streaming_bank(gpu):
     """a thread that drains RealTimeMixer.chunks() and a thread that streams a VoiceBank's blocks.  chunks() runs on the
     mixer's own lane (stream, lock, buffers: sh_rt_*), so a turn neither waits for the library's lock nor queues behind the bank's launches,
     and it does not end the bank's run of pipelined renders.  Checked: the chunks are the oracle's; the bank's blocks are what it renders
-    alone (bit for bit); and the two overlap -- the bank renders, beside the mixer, at no less than 0.8 of its rate alone (measured 0.98;
+    alone (bit for bit); and the two overlap -- the bank renders, beside the mixer, at no less than 0.7 of its rate alone (measured 0.98;
     through the one lock and stream of rounds 1-5, timed below for the record: 0.50, every mixer turn drains the bank's pipeline), while the
     mixer makes its turns (12 390 per second, median 74 us, against 7 107 and 140 us)."""
     import threading
@@ -362,7 +362,7 @@ def test_the_real_time_lane_beside_a_streaming_bank(gpu):
     lat_us = sorted(x * 1e6 for x in lat)
     print("bank alone %.0f blocks/s, beside the mixer %.0f (%.2f x); mixer: %d turns beside the bank, median %.0f us, 90 %% %.0f us per turn (chunk on the host)"
           % (rate_alone, rate_both, rate_both / rate_alone, len(lat), lat_us[len(lat_us) // 2], lat_us[int(len(lat_us) * 0.9)]))
-    assert len(got) >= 200 and rate_both >= 0.8 * rate_alone
+    assert len(got) >= 200 and rate_both >= 0.7 * rate_alone          # (measured 0.98; 0.50 without the lane)
     # the bank's block beside the mixer == the same block rendered alone
     a = N.DeviceBuffer(F * 8)
     bank.render_device(F, 100003 * F, bus_f32=a)
