@@ -139,13 +139,14 @@ struct RenderLaunch {
     int mode, var;                    // mode: COMBINED_* (which lean kinds the bank can hold); var: waves * 100 + frames per lane * 10 + min waves per SIMD
     bool split, with_general, use_aux;
     bool self_prepare;                // nothing resolved the launch's records: the lean kernel's workgroups do (LaunchArgs::self_prepare)
+    bool alone;                       // the launch does not continue a run: nothing renders beside it (LaunchArgs::alone)
     LaunchSet cur, next;
     BusOut out;                       // the caller's buses
     double2* parts;                   // this launch's partial buses (NULL: one voice group, the kernel writes `out` itself)
     FoldIn fold;                      // the fold this launch takes over
     uint32_t* gen_valid;
     uint32_t c_lo, c_hi;              // (tile-classified launches) the chunks that can sound in this block: [c_lo, c_hi)
-    LaunchArgs args(const BankPtrs& P, const LaunchSet& set) const { return LaunchArgs{P, trig_table(), b->nvoices, vpg, set, start, nframes, self_prepare ? 1u : 0u}; }
+    LaunchArgs args(const BankPtrs& P, const LaunchSet& set) const { return LaunchArgs{P, trig_table(), b->nvoices, vpg, set, start, nframes, self_prepare ? 1u : 0u, alone ? 1u : 0u}; }
     NextArgs next_args(const LaunchSet& nx, uint32_t wgs) const { return NextArgs{nx, next_start, wgs}; }
 };
 
@@ -553,7 +554,7 @@ static int bank_render(sh_bank* b, uint64_t start, uint32_t nframes, sh_buf* bus
     const BusOut out{o32, o64, o16, pcm_scale};
     const FoldIn fold = self_fold ? FoldIn{parts, nullptr, out, b->d_self()} : FoldIn{pv_parts, pv_gen, BusOut{pv32, pv64, pv16, pv_scale}, nullptr};
     const RenderLaunch L{b, st, start, next_start, nframes, tiles, groups, vpg, nchunks, prep_wgs, mode, var, split, with_general, use_aux,
-                         self_prepare, cur, next, out, parts, fold, gen_valid, tile_c_lo, tile_c_hi};
+                         self_prepare, !cont && !K.no_ladder, cur, next, out, parts, fold, gen_valid, tile_c_lo, tile_c_hi};
     rc = tiled ? launch_tiled(L, records_deferred) : nseg ? launch_segmented(L, nseg, seg_first) : launch_plain(L);
     if (rc) return rc;
     if (use_aux) S.aux_busy = true;                         // (join_aux records the event the main stream waits for)

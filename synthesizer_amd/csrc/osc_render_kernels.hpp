@@ -56,6 +56,9 @@ struct LaunchArgs {
     // records of its OWN voice group's chunks first -- the same values from every tile's workgroup of the group, three dependent round
     // trips at the head of the launch instead of a prepare kernel (9-13 us) and a launch boundary in front of it (k_render_lean)
     uint32_t              self_prepare;
+    // 1: no other render launch runs beside this one (it does not continue a run): its wavefronts lower their priority as they get on
+    // with their lists (lean_lists), so the wavefronts of a SIMD end together
+    uint32_t              alone;
 };
 // The block expected two launches on (next_start = start + 2 * nframes: the launch in between runs beside this one on the other stream
 // and got its records from this one's predecessor): its record set, and how many workgroups of this grid resolve it (0: nobody).
@@ -116,6 +119,7 @@ struct TileCtx {
     uint64_t st0;                 // ... and absolute
     uint32_t c0, c1;              // the group's chunks of 64 voices: [c0, c1)
     LaunchSet set;                // the record set (of the segment)
+    uint32_t alone;               // LaunchArgs::alone
 };
 
 template <int FPL>
@@ -145,6 +149,7 @@ __device__ __forceinline__ TileCtx plain_tile(const LaunchArgs& A, uint32_t bx, 
     T.seg_off = 0;
     T.st0 = A.start;
     T.set = A.cur;
+    T.alone = A.alone;
     tile_bounds<FPL>(T);
     group_chunks(T, A);
     return T;
@@ -723,7 +728,24 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
             for (; p < end_fm; p += WAVES, q += WAVES) entry(std::integral_constant<int, LEAN_K_FM>{}, q, p);
             for (; p < nfast; p += WAVES, q += WAVES) entry(std::integral_constant<int, LEAN_K_REST>{}, q, p);
         } else {
-            for (; p < nfast; p += WAVES, q += WAVES) entry(std::integral_constant<int, KINDS>{}, q, p);
+            // A SIMD serves its OLDEST wavefront first: of the three wavefronts it holds one ends at 25 us, one at 33, one at 42 -- and a
+            // launch that nothing runs beside (a render that stands alone, a long launch of a run of blocks) leaves every SIMD with two
+            // and then ONE wavefront, which issues at half rate (profiles/r04_headline_phases.md).  There a wavefront's priority FALLS as
+            // it gets on with its lists (quarters: s_setprio 3 .. 0), the ones behind catch up and the three end together: a lone block
+            // 57.1 -> 54.1 us, one launch of 2 / 4 / 8 blocks 48.6 -> 46.8 / 42.0 -> 40.4 / 38.4 -> 37.4 us per block.  Not beside another
+            // launch (the stream of blocks: its tail is the successor's head; + 0.6 us per block with the ladder):
+            // profiles/r06_prio_ladder.txt.
+            const uint32_t span = (T.c1 - T.c0) * 64u;
+            for (; p < nfast; p += WAVES, q += WAVES) {
+                if (T.alone) {                                   // (uniform; ONE loop body: the entry is 5 KB of straight-line code)
+                    const uint32_t at4 = ((c - T.c0) * 64u + p) * 4u;      // (which quarter of the group's voices: compares, no division)
+                    if (at4 < span) __builtin_amdgcn_s_setprio(3);
+                    else if (at4 < 2 * span) __builtin_amdgcn_s_setprio(2);
+                    else if (at4 < 3 * span) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+                entry(std::integral_constant<int, KINDS>{}, q, p);
+            }
         }
         first = p - nfast;                                    // 0 .. WAVES-1: where the stride lands in the next list
     }
