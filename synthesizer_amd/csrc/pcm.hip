@@ -938,6 +938,129 @@ __global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in
     resample_small_frames<T, VEC, FR, GROUPS>(smem, out, A, m_first, q0, r0, lo_elem, out_frames);
 }
 
+// ---- 16-bit mono between rates with a SHORT period (44.1k <-> 48k <-> 96k ...: reduced outrate <= 2048) --------------------------------
+// k_resample_small needs ~23 VALU instructions per output sample (the position's remainder stepped and wrapped, the frame pair cut out of
+// two dwords, the weights), and with its 78 % of the VALU slots taken it sits between its two roofs: 0.68 of HBM whatever one of those
+// instructions is replaced by (five variants: profiles/r06_resample_ab.txt).  But output frame m and m + outr lie at the same fraction
+// r / outr, inr input frames apart: with CHUNKS of K whole periods (L = K outr output frames, K inr input frames, starting at remainder 0)
+// thread t's sixteen frames of EVERY chunk have the same weights (outr - r, r) and the same offsets into the chunk's input span.  The
+// workgroups stay (chunk C, C + grid, ...), a thread works its sixteen (weights, offset) pairs out ONCE, and a sample is
+//      an address (offset + where the span starts in its first 16-byte vector), two sign-extending 16-bit LDS reads,
+//      u = a (outr - r) + b r + 65536 outr in two 24-bit multiply-adds, floor(u / outr) by ratecv_small_int's float64 step (3 instructions) --
+// whose low sixteen bits ARE the sample (floor(M / outr) + 65536: no bias to take off again) -- 6.5 instructions instead of 23.
+// The same integers as k_resample_small's, i.e. audioop.ratecv's (tests/test_gpu_pcm.py against the live module).
+struct PeriodArgs {
+    uint64_t in_lo, in_end;      // the input frames that are held: [in_lo, in_end) (range launches hold a window)
+    uint64_t m_base, m_end;      // the output frames this launch writes
+    uint64_t c0, c1;             // chunks [c0, c1), absolute: chunk C = output frames [C L, (C + 1) L) = input frames from C kinr on
+    uint32_t L, kinr;            // output / input frames per chunk (K periods); L is a multiple of 8: 16-byte stores
+    uint32_t inr, outr;
+    uint32_t span_vecs;          // 16-byte vectors staged per chunk
+    double   inv_outr;
+};
+
+// One 16-byte vector of a chunk's span: input elements [e0, e0 + 8), zeros outside what is held.
+__device__ __forceinline__ short8v period_load(const short* __restrict__ in, uint64_t e0, const PeriodArgs& P) {
+    short8v x;
+    if (e0 >= P.in_lo && e0 + 8 <= P.in_end) {
+        x = __builtin_nontemporal_load(reinterpret_cast<const short8v*>(in + e0));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = (e0 + k >= P.in_lo && e0 + k < P.in_end) ? in[e0 + k] : (short)0;
+    }
+    return x;
+}
+
+// NV: 16-byte vectors of the span per thread (span_vecs <= 256 NV).  The span of the NEXT chunk is loaded into registers while this one is
+// worked on (the workgroup stays: chunks C, C + grid, ...): a workgroup's loads are in flight all the time, not only between two barriers.
+template <int NV>
+__global__ __launch_bounds__(256) void k_resample_period_i16(const short* __restrict__ in, short* __restrict__ out, PeriodArgs P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t t = threadIdx.x;
+    const double half_inv = 0.5 * P.inv_outr;
+    // the thread's frames of a chunk: two runs of eight, 2048 frames apart (a wave's store instruction writes 1 KB of consecutive bytes)
+    uint32_t w0[16], w1[16], ob[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t idx = (uint32_t)(k >> 3) * 2048u + 8u * t + (uint32_t)(k & 7);
+        const uint32_t e = __umul24(idx, P.inr);                                  // < 2^12 * 2^16
+        const uint32_t dq = (uint32_t)fma((double)e, P.inv_outr, half_inv);        // floor(e / outr), exact (ratecv_small_int)
+        const uint32_t r = e - dq * P.outr;
+        w0[k] = P.outr - r;
+        w1[k] = r;
+        ob[k] = dq * 2u;
+    }
+    const int nv[2] = {(int)P.L - (int)(8u * t), (int)P.L - 2048 - (int)(8u * t)};   // frames of each run that lie inside the chunk (>= 8: all)
+    const int acc = (int)(65536u * P.outr);
+    uint64_t C = P.c0 + blockIdx.x;
+    if (C >= P.c1) return;
+    short8v pre[NV];
+    {
+        const uint64_t lo = (C * (uint64_t)P.kinr) & ~(uint64_t)7;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (t + 256u * i < P.span_vecs) pre[i] = period_load(in, lo + 8ull * (t + 256u * i), P);
+    }
+    for (; C < P.c1; C += gridDim.x) {
+        const uint64_t q_start = C * (uint64_t)P.kinr;
+        const uint32_t rel0b = (uint32_t)(q_start & 7) * 2u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (t + 256u * i < P.span_vecs) reinterpret_cast<short8v*>(smem)[t + 256u * i] = pre[i];
+        __syncthreads();
+        if (C + gridDim.x < P.c1) {
+            const uint64_t lo = ((C + gridDim.x) * (uint64_t)P.kinr) & ~(uint64_t)7;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (t + 256u * i < P.span_vecs) pre[i] = period_load(in, lo + 8ull * (t + 256u * i), P);
+        }
+        const uint64_t mC = C * (uint64_t)P.L;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint64_t m0 = mC + (uint64_t)(g * 2048) + 8u * t;
+            if (nv[g] > 0 && m0 < P.m_end && m0 + 8 > P.m_base) {
+                // the run's eight frame pairs (a, b): sixteen sign-extending 16-bit LDS reads, by hand.  Written as plain loads the compiler
+                // fuses each pair into ONE ds_read_b32 at a 2-byte-aligned address, which the LDS serves at a fraction of the rate (0.87 ms
+                // for the 900 MB row against 0.44 for k_resample_small); `volatile` loads become FLAT loads; and the D16 forms that would
+                // fill the halves of one register for a v_dot2 clear the other half on this chip (SRAM ECC).  The reads are waited for
+                // inside the statement (the compiler's counters do not see them).
+                uint32_t at[8];
+                int a[8], b[8];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) at[f] = ob[8 * g + f] + rel0b;
+                asm volatile(
+                    "ds_read_i16 %0, %16\n\tds_read_i16 %8, %16 offset:2\n\t"
+                    "ds_read_i16 %1, %17\n\tds_read_i16 %9, %17 offset:2\n\t"
+                    "ds_read_i16 %2, %18\n\tds_read_i16 %10, %18 offset:2\n\t"
+                    "ds_read_i16 %3, %19\n\tds_read_i16 %11, %19 offset:2\n\t"
+                    "ds_read_i16 %4, %20\n\tds_read_i16 %12, %20 offset:2\n\t"
+                    "ds_read_i16 %5, %21\n\tds_read_i16 %13, %21 offset:2\n\t"
+                    "ds_read_i16 %6, %22\n\tds_read_i16 %14, %22 offset:2\n\t"
+                    "ds_read_i16 %7, %23\n\tds_read_i16 %15, %23 offset:2\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
+                      "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
+                    : "v"(at[0]), "v"(at[1]), "v"(at[2]), "v"(at[3]), "v"(at[4]), "v"(at[5]), "v"(at[6]), "v"(at[7])
+                    : "memory");
+                short8v res;
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    const uint32_t u = (uint32_t)__mul24(a[f], (int)w0[8 * g + f]) + (uint32_t)(__mul24(b[f], (int)w1[8 * g + f]) + acc);
+                    res[f] = (short)(uint32_t)fma((double)u, P.inv_outr, half_inv);
+                }
+                if (nv[g] >= 8 && m0 >= P.m_base && m0 + 8 <= P.m_end) {
+                    __builtin_nontemporal_store(res, reinterpret_cast<short8v*>(out + m0));
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 8; ++f)
+                        if (f < nv[g] && m0 + f >= P.m_base && m0 + f < P.m_end) out[m0 + f] = res[f];
+                }
+            }
+        }
+        __syncthreads();                                   // (the span is overwritten by the next chunk's)
+    }
+}
+
 uint64_t gcd_u64(uint64_t a, uint64_t b) {
     while (b) {
         uint64_t t = a % b;
@@ -1469,23 +1592,24 @@ size_t sh_resample_out_frames(size_t in_frames, int inrate, int outrate) {
 // the frames they do not hold: never dereferenced outside [held input), [m_base, m_end)).  in_frames = end of the
 // held input, m_base / m_end = output frame range.
 static int resample_launch(const void* in, size_t in_frames, int nch, int width, int is_float, int inrate, int outrate,
-                           void* out, size_t m_base, size_t m_end);
+                           void* out, size_t m_base, size_t m_end, size_t in_lo);
 
 // Output ranges of any length: one launch per 2^30 output samples at most (a dispatch holds fewer than 2^32 work-items per grid
 // dimension; the kernels work from absolute output positions, so a range cut at multiples of 4096 frames is the same range)
+// (in_lo: the first input frame that is held -- range launches; the kernels that stage whole chunks must not read below it)
 static int resample_dev(const void* in, size_t in_frames, int nch, int width, int is_float, int inrate, int outrate,
-                        void* out, size_t m_base, size_t m_end) {
+                        void* out, size_t m_base, size_t m_end, size_t in_lo = 0) {
     size_t chunk = (((size_t)1 << 30) / (size_t)nch) & ~(size_t)4095;
     if (chunk < 4096) chunk = 4096;
     for (size_t m = m_base; m < m_end; m += chunk) {
-        const int rc = resample_launch(in, in_frames, nch, width, is_float, inrate, outrate, out, m, m_end - m < chunk ? m_end : m + chunk);
+        const int rc = resample_launch(in, in_frames, nch, width, is_float, inrate, outrate, out, m, m_end - m < chunk ? m_end : m + chunk, in_lo);
         if (rc) return rc;
     }
     return SH_OK;
 }
 
 static int resample_launch(const void* in, size_t in_frames, int nch, int width, int is_float, int inrate, int outrate,
-                           void* out, size_t m_base, size_t m_end) {
+                           void* out, size_t m_base, size_t m_end, size_t in_lo) {
     const size_t out_frames = m_end - m_base;        // frames this launch writes
     uint64_t g = gcd_u64((uint64_t)inrate, (uint64_t)outrate);
     RatecvArgs A;
@@ -1515,6 +1639,42 @@ static int resample_launch(const void* in, size_t in_frames, int nch, int width,
         // 16-bit mono through the LDS kernel: 16 frames (two 16-byte stores) per thread -- the per-thread set-up (position of the
         // first frame, staging loop) is a fifth of the instructions at 8 frames; +4 % (stereo, already at 16 bytes per 4 frames: -5 %)
         // (only when the doubled input span still fits the LDS budget of that kernel: the other kernels keep 8 frames)
+        // 16-bit mono with a short period: chunks of whole periods, the weights loop-invariant per thread (k_resample_period_i16)
+        if (small && width == 2 && nch == 1 && A.inr < 65536u && A.outr <= 2048u && !sh::knobs().no_period) {
+            const uint32_t s_out = 8u / (uint32_t)gcd_u64(A.outr, 8);             // L = K outr must be a multiple of 8 (16-byte stores)
+            uint32_t K = 4096u / A.outr;
+            const uint32_t k_span = 14336u / A.inr;                               // ... and the chunk's input span at most 28 KB
+            if (K > k_span) K = k_span;
+            K -= K % s_out;
+            const uint32_t L = K * A.outr;
+            if (L >= 3072u) {                                                     // (three quarters of the threads' frames in use, at least)
+                PeriodArgs P;
+                P.in_lo = (uint64_t)in_lo; P.in_end = (uint64_t)in_frames;
+                P.m_base = (uint64_t)m_base; P.m_end = (uint64_t)m_end;
+                P.c0 = (uint64_t)m_base / L; P.c1 = ((uint64_t)m_end + L - 1) / L;
+                P.L = L; P.kinr = K * A.inr; P.inr = A.inr; P.outr = A.outr; P.inv_outr = A.inv_outr;
+                const uint32_t off_max = (uint32_t)(((uint64_t)(L - 1) * A.inr) / A.outr);
+                P.span_vecs = (7u + off_max + 2u + 7u) / 8u;
+                const uint32_t lds_bytes = P.span_vecs * 16u;
+                // the workgroups stay: as many as the chip holds at once (registers and LDS decide), chunk C to workgroup C mod grid
+                const int nvk = P.span_vecs <= 512u ? 2 : P.span_vecs <= 1024u ? 4 : 8;
+                int per_cu = 0;
+                hipError_t oe = nvk == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_resample_period_i16<2>, 256, lds_bytes)
+                              : nvk == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_resample_period_i16<4>, 256, lds_bytes)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_resample_period_i16<8>, 256, lds_bytes);
+                if (oe != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; }
+                hipDeviceProp_t prop;
+                static int ncu = 0;
+                if (!ncu) ncu = hipGetDeviceProperties(&prop, sh::state().device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+                const uint64_t nchunks = P.c1 - P.c0, resident = (uint64_t)ncu * (uint64_t)per_cu;
+                const dim3 gp((uint32_t)(nchunks < resident ? nchunks : resident));
+                if (nvk == 2) hipLaunchKernelGGL(k_resample_period_i16<2>, gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P);
+                else if (nvk == 4) hipLaunchKernelGGL(k_resample_period_i16<4>, gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P);
+                else hipLaunchKernelGGL(k_resample_period_i16<8>, gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P);
+                SH_CHECK_LAUNCH("k_resample_period_i16");
+                return SH_OK;
+            }
+        }
         bool wide = false;
         if (small && width == 2 && nch == 1 && A.inr < 65536u) {
             const uint64_t sf2 = ((uint64_t)256 * 2 * fr * A.inr + A.outr - 1) / A.outr + 3;
@@ -1677,7 +1837,7 @@ int sh_resample_range(const sh_buf* in, size_t in_first, size_t in_held, int nch
     if (width == 3) return resample24(in->ptr, in_held, in_first, nchannels, inrate, outrate, out->ptr, out_first, out_n);
     const char* in0 = (const char*)in->ptr - in_first * fb;        // where input frame 0 would be
     char* out0 = (char*)out->ptr - out_first * fb;                  // where output frame 0 would be
-    return resample_dev(in0, in_first + in_held, nchannels, width, is_float, inrate, outrate, out0, out_first, out_first + out_n);
+    return resample_dev(in0, in_first + in_held, nchannels, width, is_float, inrate, outrate, out0, out_first, out_first + out_n, in_first);
 }
 
 int sh_resample_host(const void* in, size_t in_frames, int nchannels, int width, int is_float,

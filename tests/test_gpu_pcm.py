@@ -363,6 +363,29 @@ for frames, inr, outr in ((100003, 44100, 48000), (250001, 96000, 44100), (77777
     want, _ = audioop.ratecv(x.tobytes(), 2, 1, inr, outr, None)
     got = dst.download_bytes(nout * 2)
     assert len(want) == len(got) and got == want, (frames, inr, outr)
+# chunk edges of the short-period kernel (k_resample_period_i16: chunks of K whole periods -- 4000 output frames for 44.1 -> 48 kHz): outputs
+# that end just before / on / just behind a chunk boundary, inputs of a few frames, and ranges that start inside a chunk
+import ctypes as C
+for inr, outr in ((44100, 48000), (48000, 44100), (96000, 44100), (8000, 44100), (44100, 32000), (1, 2), (2, 1), (3, 2), (44100, 96000)):
+    for frames in (1, 2, 9, 3674, 3675, 3676, 7351, 12345, 40001):
+        x = rng.integers(-32768, 32768, frames).astype(np.int16)
+        src = N.DeviceBuffer.from_array(x)
+        nout = L.sh_resample_out_frames(frames, inr, outr)
+        dst = N.DeviceBuffer(max(nout, 1) * 2)
+        N.check(L.sh_resample(src.handle, frames, 1, 2, 0, inr, outr, dst.handle, None))
+        want, _ = audioop.ratecv(x.tobytes(), 2, 1, inr, outr, None)
+        assert dst.download_bytes(nout * 2) == want, (frames, inr, outr)
+        if frames == 40001:
+            for out_first, out_n in ((16, 100), (3984, 48), (4000 - 16, 8000), (nout - nout %% 16 - 160, 160 + nout %% 16), (4096, 1)):
+                if out_first < 0 or out_first + out_n > nout:
+                    continue
+                a, b = C.c_size_t(), C.c_size_t()
+                N.check(L.sh_resample_span(frames, inr, outr, out_first, out_n, C.byref(a), C.byref(b)))
+                part = N.DeviceBuffer.from_array(x[a.value:a.value + b.value])
+                o = N.DeviceBuffer(out_n * 2)
+                N.check(L.sh_resample_range(part.handle, a.value, b.value, 1, 2, 0, inr, outr, out_first, out_n, o.handle))
+                assert o.download_bytes(out_n * 2) == want[out_first * 2:(out_first + out_n) * 2], (inr, outr, out_first, out_n)
+        src.free(); dst.free()
 print("ok")
 '''
 
@@ -376,6 +399,6 @@ def test_resample_mono16_kernel_vs_live_audioop(gpu):
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     clean = {k: v for k, v in os.environ.items() if not k.startswith("SYNTHHIP_") or k in ("SYNTHHIP_LIB", "SYNTHHIP_DEVICE")}
-    for env in ({},):
+    for env in ({}, {"SYNTHHIP_NO_PERIOD": "1"}):      # (short periods: k_resample_period_i16, round 6; and k_resample_small, which other rates still take)
         p = subprocess.run([sys.executable, "-c", _RESAMPLE_CHILD % str(root)], env=dict(clean, **env), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (env, p.stderr[-2000:])

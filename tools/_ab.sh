@@ -1,2 +1,2 @@
-for m in 0 1; do echo "== SYNTHHIP_NO_LADDER=$m"; SYNTHHIP_NO_LADDER=$m python tools/probe.py run-lengths 2>&1; done
-for m in 0 1; do echo "== SYNTHHIP_NO_LADDER=$m (headline)"; SYNTHHIP_NO_LADDER=$m python bench.py --no-pcm-rows --no-two-step --no-configs --cpu-frames 0 --min-seconds 1.5 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step']*1e3, d['passes'])"; done
+python -m pytest tests/test_gpu_pcm.py -x -q 2>&1 | tail -3
+for m in 0 1; do echo "== SYNTHHIP_NO_PERIOD=$m"; SYNTHHIP_NO_PERIOD=$m python tools/resample_ab.py 2>&1; done
