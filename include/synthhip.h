@@ -188,8 +188,8 @@ typedef struct sh_counters {
 int  sh_debug_counters(sh_counters* out);
 
 /* Measurement knobs: environment variables read ONCE, by sh_init.  None changes a result -- they choose between schedules of the same
- * arithmetic, so that A/B timings can be taken with one library (tests/test_gpu_pipeline.py::test_knobs_change_no_result).  Nine of
- * them; the fifteen others that rounds 1-3 accumulated selected paths that had lost their A/B and were removed with those paths in
+ * arithmetic, so that A/B timings can be taken with one library (tests/test_gpu_pipeline.py::test_knobs_change_no_result).  The
+ * fifteen others that rounds 1-3 accumulated selected paths that had lost their A/B and were removed with those paths in
  * round 4 (CHANGELOG.md keeps what each measured):
  *   SYNTHHIP_NO_OVERLAP=1         consecutive renders of a bank stay on one stream
  *   SYNTHHIP_NO_SPECULATION=1     launch records by a prepare kernel in front of every render (no records two launches ahead)
@@ -204,6 +204,16 @@ int  sh_debug_counters(sh_counters* out);
  *   SYNTHHIP_GROUPS=n             voice groups of a render launch
  *   SYNTHHIP_POOL_FILL=0..255     device blocks that grow are filled with this byte first (diagnostics: a kernel that reads what it
  *                                 should have written shows)
+ *   (round 6)
+ *   SYNTHHIP_SELF=1|2|3           a render that stands alone resolves its records (1, 3) / folds its partial buses (1, 2) inside its one kernel
+ *                                 (off: measured slower, profiles/r06_run_lengths.txt)
+ *   SYNTHHIP_NO_LADDER=1          a render launch that nothing runs beside keeps its wavefronts at one priority (default: the priority falls as a
+ *                                 wavefront gets on with its voice lists, profiles/r06_prio_ladder.txt)
+ *   SYNTHHIP_RT_CUS=n             the last n compute units are kept for real-time lanes (sh_rt_*); 0 = off (profiles/r06_rt_lane.txt)
+ *   SYNTHHIP_NO_PERIOD=1          16-bit mono resampling between rates with a short period (reduced outrate <= 2048: 44.1 / 48 / 96 kHz ...)
+ *                                 goes through k_resample_small like any other pair of rates, not through k_resample_period_i16
+ *   SYNTHHIP_PERIOD_CHUNKS=n      consecutive chunks per workgroup of k_resample_period_i16 (default: 1, 2 or 4 by the rates' ratio;
+ *                                 profiles/r06_resample_period.txt)
  * (SYNTHHIP_LIB, read by the Python binding, names another build of this library to load; SYNTHHIP_ALLOW_STALE=1 lets it load a
  * library whose sources have changed when rebuilding fails.) */
 

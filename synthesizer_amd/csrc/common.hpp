@@ -75,6 +75,7 @@ struct Knobs {
     int  self = 0;                 // SYNTHHIP_SELF: a render that stands alone resolves its records (1, 3) / folds its partial buses (1, 2) inside its one kernel.  Off: measured slower than the prepare kernel + k_bus_combine (profiles/r06_run_lengths.txt)
     bool no_ladder = false;        // SYNTHHIP_NO_LADDER=1: a launch that stands alone keeps its wavefronts at one priority (LaunchArgs::alone; profiles/r06_prio_ladder.txt)
     bool no_period = false;        // SYNTHHIP_NO_PERIOD=1: 16-bit mono resampling between rates with a short period goes through k_resample_small (rounds 1-5), not k_resample_period_i16
+    int  period_chunks = 0;        // SYNTHHIP_PERIOD_CHUNKS=n: consecutive chunks per workgroup of k_resample_period_i16 (0: by the rates' ratio)
     int  rt_cus = 0;               // SYNTHHIP_RT_CUS=n: the last n compute units are kept for real-time lanes (the library's streams leave them out)
     bool no_small_pipeline = false;// SYNTHHIP_NO_SMALL_PIPELINE=1: single-group banks render on one stream (round-2 behaviour)
     int  variant = 0;              // SYNTHHIP_VARIANT=WFM: waves, frames per lane, min waves per SIMD of the render kernel (484, 444, 844, 821, 421, 211)

@@ -950,29 +950,37 @@ __global__ __launch_bounds__(256) void k_resample_small(const T* __restrict__ in
 // whose low sixteen bits ARE the sample (floor(M / outr) + 65536: no bias to take off again) -- 6.5 instructions instead of 23.
 // The same integers as k_resample_small's, i.e. audioop.ratecv's (tests/test_gpu_pcm.py against the live module).
 struct PeriodArgs {
-    uint64_t in_lo, in_end;      // the input frames that are held: [in_lo, in_end) (range launches hold a window)
-    uint64_t m_base, m_end;      // the output frames this launch writes
-    uint64_t c0, c1;             // chunks [c0, c1), absolute: chunk C = output frames [C L, (C + 1) L) = input frames from C kinr on
+    uint64_t c0, c1;             // chunks [c0, c1), absolute: chunk C = output frames [C L, (C + 1) L) = input frames from C kinr on.  The host
+                                 // passes INTERIOR chunks only -- span wholly inside the held input, frames wholly inside the launch's range --
+                                 // so the kernel tests nothing; what lies in front of and behind them goes through k_resample_small
     uint32_t L, kinr;            // output / input frames per chunk (K periods); L is a multiple of 8: 16-byte stores
     uint32_t inr, outr;
     uint32_t span_vecs;          // 16-byte vectors staged per chunk
+    uint32_t per_wg;             // consecutive chunks per workgroup
     double   inv_outr;
 };
 
-// One 16-byte vector of a chunk's span: input elements [e0, e0 + 8), zeros outside what is held.
-__device__ __forceinline__ short8v period_load(const short* __restrict__ in, uint64_t e0, const PeriodArgs& P) {
-    short8v x;
-    if (e0 >= P.in_lo && e0 + 8 <= P.in_end) {
-        x = __builtin_nontemporal_load(reinterpret_cast<const short8v*>(in + e0));
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = (e0 + k >= P.in_lo && e0 + k < P.in_end) ? in[e0 + k] : (short)0;
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
     }
-    return x;
 }
 
-// NV: 16-byte vectors of the span per thread (span_vecs <= 256 NV).  The span of the NEXT chunk is loaded into registers while this one is
-// worked on (the workgroup stays: chunks C, C + grid, ...): a workgroup's loads are in flight all the time, not only between two barriers.
+// NV: 16-byte vectors of the span per thread (span_vecs <= 256 NV).  A workgroup works through per_wg CONSECUTIVE chunks and ends; the
+// span of the next chunk is loaded into registers while this one is worked on.  What the shape of the loop is for
+// (profiles/r06_resample_period.txt):
+//  * this chip counts loads and stores in ONE in-order counter (vmcnt): "wait for my loads" also waits for every store issued before
+//    them.  The next span's loads are therefore issued BEFORE the chunk's stores and waited for at the END of the turn, where the wait
+//    the compiler inserts is vmcnt(stores of this turn): the stores stay in flight across the barrier.  That needs a turn without a
+//    branch around a memory instruction (a path with fewer stores, and the count drops to zero): lanes beyond the span load its last
+//    vector again, lanes beyond the chunk's last run do that run again (same frames, same values, same address), and L is a multiple
+//    of 8, so a run is whole or absent;
+//  * workgroups that STAY for the whole call (chunks C, C + grid, ...) march in step -- all load, all compute, all store -- and reach 0.63-0.70
+//    of HBM on the 44.1 -> 48 kHz row where workgroups of ONE chunk each (dispatched as others end, their phases mixed) reach 0.72;
+//    but one chunk per workgroup pays the sixteen (weights, offset) set-ups for sixteen samples (upsampling 44.1 -> 96 kHz: 0.60
+//    against 0.70).  A few chunks per workgroup keep both.
 template <int NV>
 __global__ __launch_bounds__(256) void k_resample_period_i16(const short* __restrict__ in, short* __restrict__ out, PeriodArgs P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -980,84 +988,82 @@ __global__ __launch_bounds__(256) void k_resample_period_i16(const short* __rest
     const double half_inv = 0.5 * P.inv_outr;
     // the thread's frames of a chunk: two runs of eight, 2048 frames apart (a wave's store instruction writes 1 KB of consecutive bytes)
     uint32_t w0[16], w1[16], ob[16];
+    // (the last run of each half that lies inside the chunk: L >= 3072, a multiple of 8)
+    const uint32_t last0 = P.L / 8u - 1u, last1 = (P.L - 2048u) / 8u - 1u;
+    const uint32_t run0[2] = {8u * (t < last0 ? t : last0), 2048u + 8u * (t < last1 ? t : last1)};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const uint32_t idx = (uint32_t)(k >> 3) * 2048u + 8u * t + (uint32_t)(k & 7);
-        const uint32_t e = __umul24(idx, P.inr);                                  // < 2^12 * 2^16
+        const uint32_t e = __umul24(run0[k >> 3] + (uint32_t)(k & 7), P.inr);    // < 2^12 * 2^16
         const uint32_t dq = (uint32_t)fma((double)e, P.inv_outr, half_inv);        // floor(e / outr), exact (ratecv_small_int)
         const uint32_t r = e - dq * P.outr;
         w0[k] = P.outr - r;
         w1[k] = r;
         ob[k] = dq * 2u;
     }
-    const int nv[2] = {(int)P.L - (int)(8u * t), (int)P.L - 2048 - (int)(8u * t)};   // frames of each run that lie inside the chunk (>= 8: all)
     const int acc = (int)(65536u * P.outr);
-    uint64_t C = P.c0 + blockIdx.x;
+    uint64_t C = P.c0 + (uint64_t)blockIdx.x * P.per_wg;
     if (C >= P.c1) return;
+    const uint64_t c_end = C + P.per_wg < P.c1 ? C + P.per_wg : P.c1;
     short8v pre[NV];
+    uint32_t vi[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) vi[i] = t + 256u * i < P.span_vecs ? t + 256u * i : P.span_vecs - 1u;
     {
-        const uint64_t lo = (C * (uint64_t)P.kinr) & ~(uint64_t)7;
+        const short8v* __restrict__ src = reinterpret_cast<const short8v*>(in + ((C * (uint64_t)P.kinr) & ~(uint64_t)7));
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (t + 256u * i < P.span_vecs) pre[i] = period_load(in, lo + 8ull * (t + 256u * i), P);
+        for (int i = 0; i < NV; ++i) pre[i] = __builtin_nontemporal_load(src + vi[i]);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) reinterpret_cast<short8v*>(smem)[vi[i]] = pre[i];
     }
-    for (; C < P.c1; C += gridDim.x) {
-        const uint64_t q_start = C * (uint64_t)P.kinr;
-        const uint32_t rel0b = (uint32_t)(q_start & 7) * 2u;
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (t + 256u * i < P.span_vecs) reinterpret_cast<short8v*>(smem)[t + 256u * i] = pre[i];
-        __syncthreads();
-        if (C + gridDim.x < P.c1) {
-            const uint64_t lo = ((C + gridDim.x) * (uint64_t)P.kinr) & ~(uint64_t)7;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (t + 256u * i < P.span_vecs) pre[i] = period_load(in, lo + 8ull * (t + 256u * i), P);
+    for (;;) {
+        __syncthreads();                                   // the chunk's span is in LDS
+        const bool more = C + 1 < c_end;                   // (uniform)
+        if (more) {
+            const short8v* __restrict__ src = reinterpret_cast<const short8v*>(in + (((C + 1) * (uint64_t)P.kinr) & ~(uint64_t)7));
+            static_for<0, NV>([&](auto i_) { constexpr int i = decltype(i_)::value; pre[i] = __builtin_nontemporal_load(src + vi[i]); });
         }
-        const uint64_t mC = C * (uint64_t)P.L;
+        const uint32_t rel0b = (uint32_t)((C * (uint64_t)P.kinr) & 7) * 2u;
+        short* __restrict__ outC = out + C * (uint64_t)P.L;
+        auto run = [&](auto g_) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_)::value;
+            // the run's eight frame pairs (a, b): sixteen sign-extending 16-bit LDS reads, by hand.  Written as plain loads the compiler
+            // fuses each pair into ONE ds_read_b32 at a 2-byte-aligned address, which the LDS serves at a fraction of the rate (0.87 ms
+            // for the 900 MB row against 0.44 for k_resample_small); `volatile` loads become FLAT loads; and the D16 forms that would
+            // fill the halves of one register for a v_dot2 clear the other half on this chip (SRAM ECC).  The reads are waited for
+            // inside the statement (the compiler's counters do not see them).
+            uint32_t at[8];
+            int a[8], b[8];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const uint64_t m0 = mC + (uint64_t)(g * 2048) + 8u * t;
-            if (nv[g] > 0 && m0 < P.m_end && m0 + 8 > P.m_base) {
-                // the run's eight frame pairs (a, b): sixteen sign-extending 16-bit LDS reads, by hand.  Written as plain loads the compiler
-                // fuses each pair into ONE ds_read_b32 at a 2-byte-aligned address, which the LDS serves at a fraction of the rate (0.87 ms
-                // for the 900 MB row against 0.44 for k_resample_small); `volatile` loads become FLAT loads; and the D16 forms that would
-                // fill the halves of one register for a v_dot2 clear the other half on this chip (SRAM ECC).  The reads are waited for
-                // inside the statement (the compiler's counters do not see them).
-                uint32_t at[8];
-                int a[8], b[8];
+            for (int f = 0; f < 8; ++f) at[f] = ob[8 * g + f] + rel0b;
+            asm volatile(
+                "ds_read_i16 %0, %16\n\tds_read_i16 %8, %16 offset:2\n\t"
+                "ds_read_i16 %1, %17\n\tds_read_i16 %9, %17 offset:2\n\t"
+                "ds_read_i16 %2, %18\n\tds_read_i16 %10, %18 offset:2\n\t"
+                "ds_read_i16 %3, %19\n\tds_read_i16 %11, %19 offset:2\n\t"
+                "ds_read_i16 %4, %20\n\tds_read_i16 %12, %20 offset:2\n\t"
+                "ds_read_i16 %5, %21\n\tds_read_i16 %13, %21 offset:2\n\t"
+                "ds_read_i16 %6, %22\n\tds_read_i16 %14, %22 offset:2\n\t"
+                "ds_read_i16 %7, %23\n\tds_read_i16 %15, %23 offset:2\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
+                  "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
+                : "v"(at[0]), "v"(at[1]), "v"(at[2]), "v"(at[3]), "v"(at[4]), "v"(at[5]), "v"(at[6]), "v"(at[7])
+                : "memory");
+            short8v res;
 #pragma unroll
-                for (int f = 0; f < 8; ++f) at[f] = ob[8 * g + f] + rel0b;
-                asm volatile(
-                    "ds_read_i16 %0, %16\n\tds_read_i16 %8, %16 offset:2\n\t"
-                    "ds_read_i16 %1, %17\n\tds_read_i16 %9, %17 offset:2\n\t"
-                    "ds_read_i16 %2, %18\n\tds_read_i16 %10, %18 offset:2\n\t"
-                    "ds_read_i16 %3, %19\n\tds_read_i16 %11, %19 offset:2\n\t"
-                    "ds_read_i16 %4, %20\n\tds_read_i16 %12, %20 offset:2\n\t"
-                    "ds_read_i16 %5, %21\n\tds_read_i16 %13, %21 offset:2\n\t"
-                    "ds_read_i16 %6, %22\n\tds_read_i16 %14, %22 offset:2\n\t"
-                    "ds_read_i16 %7, %23\n\tds_read_i16 %15, %23 offset:2\n\t"
-                    "s_waitcnt lgkmcnt(0)"
-                    : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
-                      "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
-                    : "v"(at[0]), "v"(at[1]), "v"(at[2]), "v"(at[3]), "v"(at[4]), "v"(at[5]), "v"(at[6]), "v"(at[7])
-                    : "memory");
-                short8v res;
-#pragma unroll
-                for (int f = 0; f < 8; ++f) {
-                    const uint32_t u = (uint32_t)__mul24(a[f], (int)w0[8 * g + f]) + (uint32_t)(__mul24(b[f], (int)w1[8 * g + f]) + acc);
-                    res[f] = (short)(uint32_t)fma((double)u, P.inv_outr, half_inv);
-                }
-                if (nv[g] >= 8 && m0 >= P.m_base && m0 + 8 <= P.m_end) {
-                    __builtin_nontemporal_store(res, reinterpret_cast<short8v*>(out + m0));
-                } else {
-#pragma unroll
-                    for (int f = 0; f < 8; ++f)
-                        if (f < nv[g] && m0 + f >= P.m_base && m0 + f < P.m_end) out[m0 + f] = res[f];
-                }
+            for (int f = 0; f < 8; ++f) {
+                const uint32_t u = (uint32_t)__mul24(a[f], (int)w0[8 * g + f]) + (uint32_t)(__mul24(b[f], (int)w1[8 * g + f]) + acc);
+                res[f] = (short)(uint32_t)fma((double)u, P.inv_outr, half_inv);
             }
-        }
-        __syncthreads();                                   // (the span is overwritten by the next chunk's)
+            __builtin_nontemporal_store(res, reinterpret_cast<short8v*>(outC + run0[g]));
+        };
+        run(std::integral_constant<int, 0>{});
+        run(std::integral_constant<int, 1>{});
+        __syncthreads();                                   // everybody has read the span
+        if (!more) break;
+        // (waits for the loads; this turn's stores stay in flight)
+        static_for<0, NV>([&](auto i_) { constexpr int i = decltype(i_)::value; reinterpret_cast<short8v*>(smem)[vi[i]] = pre[i]; });
+        C += 1;
     }
 }
 
@@ -1592,7 +1598,7 @@ size_t sh_resample_out_frames(size_t in_frames, int inrate, int outrate) {
 // the frames they do not hold: never dereferenced outside [held input), [m_base, m_end)).  in_frames = end of the
 // held input, m_base / m_end = output frame range.
 static int resample_launch(const void* in, size_t in_frames, int nch, int width, int is_float, int inrate, int outrate,
-                           void* out, size_t m_base, size_t m_end, size_t in_lo);
+                           void* out, size_t m_base, size_t m_end, size_t in_lo, bool allow_period = true);
 
 // Output ranges of any length: one launch per 2^30 output samples at most (a dispatch holds fewer than 2^32 work-items per grid
 // dimension; the kernels work from absolute output positions, so a range cut at multiples of 4096 frames is the same range)
@@ -1609,7 +1615,7 @@ static int resample_dev(const void* in, size_t in_frames, int nch, int width, in
 }
 
 static int resample_launch(const void* in, size_t in_frames, int nch, int width, int is_float, int inrate, int outrate,
-                           void* out, size_t m_base, size_t m_end, size_t in_lo) {
+                           void* out, size_t m_base, size_t m_end, size_t in_lo, bool allow_period) {
     const size_t out_frames = m_end - m_base;        // frames this launch writes
     uint64_t g = gcd_u64((uint64_t)inrate, (uint64_t)outrate);
     RatecvArgs A;
@@ -1640,7 +1646,7 @@ static int resample_launch(const void* in, size_t in_frames, int nch, int width,
         // first frame, staging loop) is a fifth of the instructions at 8 frames; +4 % (stereo, already at 16 bytes per 4 frames: -5 %)
         // (only when the doubled input span still fits the LDS budget of that kernel: the other kernels keep 8 frames)
         // 16-bit mono with a short period: chunks of whole periods, the weights loop-invariant per thread (k_resample_period_i16)
-        if (small && width == 2 && nch == 1 && A.inr < 65536u && A.outr <= 2048u && !sh::knobs().no_period) {
+        if (allow_period && small && width == 2 && nch == 1 && A.inr < 65536u && A.outr <= 2048u && !sh::knobs().no_period) {
             const uint32_t s_out = 8u / (uint32_t)gcd_u64(A.outr, 8);             // L = K outr must be a multiple of 8 (16-byte stores)
             uint32_t K = 4096u / A.outr;
             const uint32_t k_span = 14336u / A.inr;                               // ... and the chunk's input span at most 28 KB
@@ -1649,30 +1655,31 @@ static int resample_launch(const void* in, size_t in_frames, int nch, int width,
             const uint32_t L = K * A.outr;
             if (L >= 3072u) {                                                     // (three quarters of the threads' frames in use, at least)
                 PeriodArgs P;
-                P.in_lo = (uint64_t)in_lo; P.in_end = (uint64_t)in_frames;
-                P.m_base = (uint64_t)m_base; P.m_end = (uint64_t)m_end;
-                P.c0 = (uint64_t)m_base / L; P.c1 = ((uint64_t)m_end + L - 1) / L;
                 P.L = L; P.kinr = K * A.inr; P.inr = A.inr; P.outr = A.outr; P.inv_outr = A.inv_outr;
                 const uint32_t off_max = (uint32_t)(((uint64_t)(L - 1) * A.inr) / A.outr);
                 P.span_vecs = (7u + off_max + 2u + 7u) / 8u;
                 const uint32_t lds_bytes = P.span_vecs * 16u;
-                // the workgroups stay: as many as the chip holds at once (registers and LDS decide), chunk C to workgroup C mod grid
+                // the interior chunks: frames wholly inside [m_base, m_end), span wholly inside the held input [in_lo, in_frames)
+                uint64_t cA = ((uint64_t)m_base + L - 1) / L, cB = (uint64_t)m_end / L;
+                while (cA < cB && ((cA * P.kinr) & ~(uint64_t)7) < (uint64_t)in_lo) ++cA;
+                while (cB > cA && (((cB - 1) * P.kinr) & ~(uint64_t)7) + 8ull * P.span_vecs > (uint64_t)in_frames) --cB;
+                if (cB > cA + 1) {
+                P.c0 = cA; P.c1 = cB;
+                // consecutive chunks per workgroup: two -- one where the input is the larger side (nothing to amortise the set-up against
+                // but reads), four where the output is (upsampling by two or more): profiles/r06_resample_period.txt.  SYNTHHIP_PERIOD_CHUNKS overrides.
+                P.per_wg = sh::knobs().period_chunks > 0 ? (uint32_t)sh::knobs().period_chunks : A.inr >= 2 * A.outr ? 1u : A.outr >= 2 * A.inr ? 4u : 2u;
                 const int nvk = P.span_vecs <= 512u ? 2 : P.span_vecs <= 1024u ? 4 : 8;
-                int per_cu = 0;
-                hipError_t oe = nvk == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_resample_period_i16<2>, 256, lds_bytes)
-                              : nvk == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_resample_period_i16<4>, 256, lds_bytes)
-                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_resample_period_i16<8>, 256, lds_bytes);
-                if (oe != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; }
-                hipDeviceProp_t prop;
-                static int ncu = 0;
-                if (!ncu) ncu = hipGetDeviceProperties(&prop, sh::state().device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-                const uint64_t nchunks = P.c1 - P.c0, resident = (uint64_t)ncu * (uint64_t)per_cu;
-                const dim3 gp((uint32_t)(nchunks < resident ? nchunks : resident));
+                const dim3 gp((uint32_t)((cB - cA + P.per_wg - 1) / P.per_wg));
                 if (nvk == 2) hipLaunchKernelGGL(k_resample_period_i16<2>, gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P);
                 else if (nvk == 4) hipLaunchKernelGGL(k_resample_period_i16<4>, gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P);
                 else hipLaunchKernelGGL(k_resample_period_i16<8>, gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P);
                 SH_CHECK_LAUNCH("k_resample_period_i16");
-                return SH_OK;
+                // ... and what lies in front of the first and behind the last interior chunk: k_resample_small (allow_period = false)
+                int rc = SH_OK;
+                if ((uint64_t)m_base < cA * L) rc = resample_launch(in, in_frames, nch, width, is_float, inrate, outrate, out, m_base, (size_t)(cA * L), in_lo, false);
+                if (!rc && cB * L < (uint64_t)m_end) rc = resample_launch(in, in_frames, nch, width, is_float, inrate, outrate, out, (size_t)(cB * L), m_end, in_lo, false);
+                return rc;
+                }
             }
         }
         bool wide = false;

@@ -38,6 +38,7 @@ void load_knobs() {
     k.rt_cus = (int)num("SYNTHHIP_RT_CUS", 0);
     k.no_ladder = flag("SYNTHHIP_NO_LADDER");
     k.no_period = flag("SYNTHHIP_NO_PERIOD");
+    k.period_chunks = (int)num("SYNTHHIP_PERIOD_CHUNKS", 0);
     k.variant = (int)num("SYNTHHIP_VARIANT", 0);
     k.groups = (int)num("SYNTHHIP_GROUPS", 0);
     k.pool_fill = (int)num("SYNTHHIP_POOL_FILL", -1);

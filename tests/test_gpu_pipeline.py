@@ -182,12 +182,12 @@ np.savez(sys.argv[1], **out)
 
 
 def test_knobs_change_no_result(gpu, tmp_path):
-    """SYNTHHIP_NO_SMALL_PIPELINE / SYNTHHIP_NO_OVERLAP / SYNTHHIP_NO_SPECULATION select
+    """SYNTHHIP_NO_SMALL_PIPELINE / SYNTHHIP_NO_OVERLAP / SYNTHHIP_NO_SPECULATION / SYNTHHIP_NO_LADDER select
     other schedules of the same work: the buses -- of small and large lock-step banks and of a table of notes -- are bit-identical
     with the default's."""
     outs = {}
     for name, env in (("default", {}), ("no_small", {"SYNTHHIP_NO_SMALL_PIPELINE": "1"}), ("no_overlap", {"SYNTHHIP_NO_OVERLAP": "1"}),
-                      ("no_spec", {"SYNTHHIP_NO_SPECULATION": "1"})):
+                      ("no_spec", {"SYNTHHIP_NO_SPECULATION": "1"}), ("no_ladder", {"SYNTHHIP_NO_LADDER": "1"})):
         path = tmp_path / (name + ".npz")
         clean = {k: v for k, v in os.environ.items() if not k.startswith("SYNTHHIP_") or k in ("SYNTHHIP_LIB", "SYNTHHIP_DEVICE")}
         p = subprocess.run([sys.executable, "-c", _CHILD % str(ROOT), str(path)], env=dict(clean, **env),

@@ -30,18 +30,17 @@ def main():
         nout = L.sh_resample_out_frames(frames, inr, outr)
         dst = N.DeviceBuffer(nout * 2)
         call = lambda: N.check(L.sh_resample(src.handle, frames, 1, 2, 0, inr, outr, dst.handle, None))
-        for _ in range(3):
+        for _ in range(30):                       # (clocks up: the first dozen launches of a memory-bound kernel run 10-20 % slow)
             call()
         N.sync()
-        best, tot, n = 1e9, 0.0, 0
-        for _ in range(5):
+        runs = []
+        for _ in range(12):
             N.timer_start()
-            for _ in range(4):
+            for _ in range(10):
                 call()
-            ms = N.timer_stop() / 4
-            best = min(best, ms)
-            tot += ms
-            n += 1
+            runs.append(N.timer_stop() / 10)
+        runs.sort()
+        best, tot, n = runs[0], runs[len(runs) // 2], 1     # (tot / n: the median run)
         nbytes = (frames + nout) * 2
         # parity on three windows of the result against the live module (the reference's own arithmetic)
         ok = True
@@ -66,7 +65,7 @@ def main():
                 ok = False
                 bad = np.nonzero(ref[:m] != got[:m])[0]
                 print("   MISMATCH %s: %d of %d differ, first at %s" % (name, len(bad), m, bad[:5]), flush=True)
-        print("%6d -> %6d: %.4f ms avg, %.4f best, %.3f of 8 TB/s (best %.3f)  parity %s" %
+        print("%6d -> %6d: %.4f ms median, %.4f best, %.3f of 8 TB/s (best %.3f)  parity %s" %
               (inr, outr, tot / n, best, nbytes / (tot / n * 1e-3) / 8e12, nbytes / (best * 1e-3) / 8e12, "ok" if ok else "FAILED"), flush=True)
         dst.free()
 
