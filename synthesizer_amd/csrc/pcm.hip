@@ -981,24 +981,27 @@ __device__ __forceinline__ void static_for(F&& f) {
 //    of HBM on the 44.1 -> 48 kHz row where workgroups of ONE chunk each (dispatched as others end, their phases mixed) reach 0.72;
 //    but one chunk per workgroup pays the sixteen (weights, offset) set-ups for sixteen samples (upsampling 44.1 -> 96 kHz: 0.60
 //    against 0.70).  A few chunks per workgroup keep both.
-template <int NV>
+// VEC: channels (1: mono, a run = 8 frames; 2: stereo, a run = 4 frames -- 16 bytes either way).  All positions below are in FRAMES; a frame
+// is VEC shorts.
+template <int VEC, int NV>
 __global__ __launch_bounds__(256) void k_resample_period_i16(const short* __restrict__ in, short* __restrict__ out, PeriodArgs P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int FPR = 8 / VEC;                      // frames per run
+    constexpr uint32_t RUN2 = 256u * FPR;             // the second run lies this many frames behind the first: a wave's store instruction writes 1 KB of consecutive bytes
     const uint32_t t = threadIdx.x;
     const double half_inv = 0.5 * P.inv_outr;
-    // the thread's frames of a chunk: two runs of eight, 2048 frames apart (a wave's store instruction writes 1 KB of consecutive bytes)
-    uint32_t w0[16], w1[16], ob[16];
-    // (the last run of each half that lies inside the chunk: L >= 3072, a multiple of 8)
-    const uint32_t last0 = P.L / 8u - 1u, last1 = (P.L - 2048u) / 8u - 1u;
-    const uint32_t run0[2] = {8u * (t < last0 ? t : last0), 2048u + 8u * (t < last1 ? t : last1)};
+    // the thread's frames of a chunk: two runs (the last run of each half that lies inside the chunk: L >= RUN2 + FPR, a multiple of FPR)
+    uint32_t w0[2 * FPR], w1[2 * FPR], ob[2 * FPR];
+    const uint32_t last0 = P.L / FPR - 1u, last1 = (P.L - RUN2) / FPR - 1u;
+    const uint32_t run0[2] = {(uint32_t)FPR * (t < last0 ? t : last0), RUN2 + (uint32_t)FPR * (t < last1 ? t : last1)};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t e = __umul24(run0[k >> 3] + (uint32_t)(k & 7), P.inr);    // < 2^12 * 2^16
+    for (int k = 0; k < 2 * FPR; ++k) {
+        const uint32_t e = __umul24(run0[k / FPR] + (uint32_t)(k % FPR), P.inr);  // < 2^12 * 2^16
         const uint32_t dq = (uint32_t)fma((double)e, P.inv_outr, half_inv);        // floor(e / outr), exact (ratecv_small_int)
         const uint32_t r = e - dq * P.outr;
         w0[k] = P.outr - r;
         w1[k] = r;
-        ob[k] = dq * 2u;
+        ob[k] = dq * (uint32_t)(2 * VEC);              // bytes
     }
     const int acc = (int)(65536u * P.outr);
     uint64_t C = P.c0 + (uint64_t)blockIdx.x * P.per_wg;
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_resample_period_i16(const short* __rest
 #pragma unroll
     for (int i = 0; i < NV; ++i) vi[i] = t + 256u * i < P.span_vecs ? t + 256u * i : P.span_vecs - 1u;
     {
-        const short8v* __restrict__ src = reinterpret_cast<const short8v*>(in + ((C * (uint64_t)P.kinr) & ~(uint64_t)7));
+        const short8v* __restrict__ src = reinterpret_cast<const short8v*>(in + ((C * (uint64_t)P.kinr * VEC) & ~(uint64_t)7));
 #pragma unroll
         for (int i = 0; i < NV; ++i) pre[i] = __builtin_nontemporal_load(src + vi[i]);
 #pragma unroll
@@ -1019,43 +1022,64 @@ __global__ __launch_bounds__(256) void k_resample_period_i16(const short* __rest
         __syncthreads();                                   // the chunk's span is in LDS
         const bool more = C + 1 < c_end;                   // (uniform)
         if (more) {
-            const short8v* __restrict__ src = reinterpret_cast<const short8v*>(in + (((C + 1) * (uint64_t)P.kinr) & ~(uint64_t)7));
+            const short8v* __restrict__ src = reinterpret_cast<const short8v*>(in + (((C + 1) * (uint64_t)P.kinr * VEC) & ~(uint64_t)7));
             static_for<0, NV>([&](auto i_) { constexpr int i = decltype(i_)::value; pre[i] = __builtin_nontemporal_load(src + vi[i]); });
         }
-        const uint32_t rel0b = (uint32_t)((C * (uint64_t)P.kinr) & 7) * 2u;
-        short* __restrict__ outC = out + C * (uint64_t)P.L;
+        const uint32_t rel0b = (uint32_t)((C * (uint64_t)P.kinr * VEC) & 7) * 2u;
+        short* __restrict__ outC = out + C * (uint64_t)P.L * VEC;
         auto run = [&](auto g_) __attribute__((always_inline)) {
             constexpr int g = decltype(g_)::value;
-            // the run's eight frame pairs (a, b): sixteen sign-extending 16-bit LDS reads, by hand.  Written as plain loads the compiler
-            // fuses each pair into ONE ds_read_b32 at a 2-byte-aligned address, which the LDS serves at a fraction of the rate (0.87 ms
-            // for the 900 MB row against 0.44 for k_resample_small); `volatile` loads become FLAT loads; and the D16 forms that would
-            // fill the halves of one register for a v_dot2 clear the other half on this chip (SRAM ECC).  The reads are waited for
-            // inside the statement (the compiler's counters do not see them).
-            uint32_t at[8];
-            int a[8], b[8];
+            // The run's frame pairs (a, b) out of LDS, by hand.  Mono: two sign-extending 16-bit reads per frame -- written as plain loads the
+            // compiler fuses each pair into ONE ds_read_b32 at a 2-byte-aligned address, which the LDS serves at a fraction of the rate
+            // (0.87 ms for the 900 MB row against 0.44 for k_resample_small); `volatile` loads become FLAT loads; and the D16 forms that
+            // would fill the halves of one register for a v_dot2 clear the other half on this chip (SRAM ECC).  Stereo: frames are dwords,
+            // one ds_read2_b32 per pair.  The reads are waited for inside the statement (the compiler's counters do not see them).
+            uint32_t at[FPR];
 #pragma unroll
-            for (int f = 0; f < 8; ++f) at[f] = ob[8 * g + f] + rel0b;
-            asm volatile(
-                "ds_read_i16 %0, %16\n\tds_read_i16 %8, %16 offset:2\n\t"
-                "ds_read_i16 %1, %17\n\tds_read_i16 %9, %17 offset:2\n\t"
-                "ds_read_i16 %2, %18\n\tds_read_i16 %10, %18 offset:2\n\t"
-                "ds_read_i16 %3, %19\n\tds_read_i16 %11, %19 offset:2\n\t"
-                "ds_read_i16 %4, %20\n\tds_read_i16 %12, %20 offset:2\n\t"
-                "ds_read_i16 %5, %21\n\tds_read_i16 %13, %21 offset:2\n\t"
-                "ds_read_i16 %6, %22\n\tds_read_i16 %14, %22 offset:2\n\t"
-                "ds_read_i16 %7, %23\n\tds_read_i16 %15, %23 offset:2\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
-                  "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
-                : "v"(at[0]), "v"(at[1]), "v"(at[2]), "v"(at[3]), "v"(at[4]), "v"(at[5]), "v"(at[6]), "v"(at[7])
-                : "memory");
+            for (int f = 0; f < FPR; ++f) at[f] = ob[FPR * g + f] + rel0b;
             short8v res;
+            if constexpr (VEC == 1) {
+                int a[8], b[8];
+                asm volatile(
+                    "ds_read_i16 %0, %16\n\tds_read_i16 %8, %16 offset:2\n\t"
+                    "ds_read_i16 %1, %17\n\tds_read_i16 %9, %17 offset:2\n\t"
+                    "ds_read_i16 %2, %18\n\tds_read_i16 %10, %18 offset:2\n\t"
+                    "ds_read_i16 %3, %19\n\tds_read_i16 %11, %19 offset:2\n\t"
+                    "ds_read_i16 %4, %20\n\tds_read_i16 %12, %20 offset:2\n\t"
+                    "ds_read_i16 %5, %21\n\tds_read_i16 %13, %21 offset:2\n\t"
+                    "ds_read_i16 %6, %22\n\tds_read_i16 %14, %22 offset:2\n\t"
+                    "ds_read_i16 %7, %23\n\tds_read_i16 %15, %23 offset:2\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
+                      "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
+                    : "v"(at[0]), "v"(at[1]), "v"(at[2]), "v"(at[3]), "v"(at[4]), "v"(at[5]), "v"(at[6]), "v"(at[7])
+                    : "memory");
 #pragma unroll
-            for (int f = 0; f < 8; ++f) {
-                const uint32_t u = (uint32_t)__mul24(a[f], (int)w0[8 * g + f]) + (uint32_t)(__mul24(b[f], (int)w1[8 * g + f]) + acc);
-                res[f] = (short)(uint32_t)fma((double)u, P.inv_outr, half_inv);
+                for (int f = 0; f < 8; ++f) {
+                    const uint32_t u = (uint32_t)__mul24(a[f], (int)w0[8 * g + f]) + (uint32_t)(__mul24(b[f], (int)w1[8 * g + f]) + acc);
+                    res[f] = (short)(uint32_t)fma((double)u, P.inv_outr, half_inv);
+                }
+            } else {
+                uint64_t ab[4];                            // low dword: frame q (L | R << 16), high dword: frame q + 1
+                asm volatile(
+                    "ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %5 offset1:1\n\t"
+                    "ds_read2_b32 %2, %6 offset1:1\n\tds_read2_b32 %3, %7 offset1:1\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(ab[0]), "=&v"(ab[1]), "=&v"(ab[2]), "=&v"(ab[3])
+                    : "v"(at[0]), "v"(at[1]), "v"(at[2]), "v"(at[3])
+                    : "memory");
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int fa = (int)(uint32_t)ab[f], fb = (int)(uint32_t)(ab[f] >> 32);
+                    const int la = (int)(short)fa, ra = fa >> 16, lb = (int)(short)fb, rb = fb >> 16;
+                    const int k0 = (int)w0[4 * g + f], k1 = (int)w1[4 * g + f];
+                    const uint32_t ul = (uint32_t)__mul24(la, k0) + (uint32_t)(__mul24(lb, k1) + acc);
+                    const uint32_t ur = (uint32_t)__mul24(ra, k0) + (uint32_t)(__mul24(rb, k1) + acc);
+                    res[2 * f] = (short)(uint32_t)fma((double)ul, P.inv_outr, half_inv);
+                    res[2 * f + 1] = (short)(uint32_t)fma((double)ur, P.inv_outr, half_inv);
+                }
             }
-            __builtin_nontemporal_store(res, reinterpret_cast<short8v*>(outC + run0[g]));
+            __builtin_nontemporal_store(res, reinterpret_cast<short8v*>(outC + (size_t)run0[g] * VEC));
         };
         run(std::integral_constant<int, 0>{});
         run(std::integral_constant<int, 1>{});
@@ -1645,34 +1669,38 @@ static int resample_launch(const void* in, size_t in_frames, int nch, int width,
         // 16-bit mono through the LDS kernel: 16 frames (two 16-byte stores) per thread -- the per-thread set-up (position of the
         // first frame, staging loop) is a fifth of the instructions at 8 frames; +4 % (stereo, already at 16 bytes per 4 frames: -5 %)
         // (only when the doubled input span still fits the LDS budget of that kernel: the other kernels keep 8 frames)
-        // 16-bit mono with a short period: chunks of whole periods, the weights loop-invariant per thread (k_resample_period_i16)
-        if (allow_period && small && width == 2 && nch == 1 && A.inr < 65536u && A.outr <= 2048u && !sh::knobs().no_period) {
-            const uint32_t s_out = 8u / (uint32_t)gcd_u64(A.outr, 8);             // L = K outr must be a multiple of 8 (16-byte stores)
-            uint32_t K = 4096u / A.outr;
-            const uint32_t k_span = 14336u / A.inr;                               // ... and the chunk's input span at most 28 KB
+        // 16-bit mono / stereo between rates with a short period: chunks of whole periods, the weights loop-invariant per thread (k_resample_period_i16)
+        if (allow_period && small && width == 2 && (nch == 1 || nch == 2) && A.inr < 65536u && A.outr <= 2048u && !sh::knobs().no_period) {
+            const uint32_t V = (uint32_t)nch, fpr = 8u / V, lmax = 512u * fpr;         // a run = 16 bytes; two runs per thread
+            const uint32_t s_out = fpr / (uint32_t)gcd_u64(A.outr, fpr);                // L = K outr must be a multiple of a run (16-byte stores)
+            uint32_t K = lmax / A.outr;
+            const uint32_t k_span = (14336u / V) / A.inr;                               // ... and the chunk's input span at most 28 KB
             if (K > k_span) K = k_span;
             K -= K % s_out;
             const uint32_t L = K * A.outr;
-            if (L >= 3072u) {                                                     // (three quarters of the threads' frames in use, at least)
+            if (L >= lmax / 4u * 3u) {                                                  // (three quarters of the threads' frames in use, at least)
                 PeriodArgs P;
                 P.L = L; P.kinr = K * A.inr; P.inr = A.inr; P.outr = A.outr; P.inv_outr = A.inv_outr;
                 const uint32_t off_max = (uint32_t)(((uint64_t)(L - 1) * A.inr) / A.outr);
-                P.span_vecs = (7u + off_max + 2u + 7u) / 8u;
+                P.span_vecs = (7u + (off_max + 2u) * V + 7u) / 8u;
                 const uint32_t lds_bytes = P.span_vecs * 16u;
                 // the interior chunks: frames wholly inside [m_base, m_end), span wholly inside the held input [in_lo, in_frames)
                 uint64_t cA = ((uint64_t)m_base + L - 1) / L, cB = (uint64_t)m_end / L;
-                while (cA < cB && ((cA * P.kinr) & ~(uint64_t)7) < (uint64_t)in_lo) ++cA;
-                while (cB > cA && (((cB - 1) * P.kinr) & ~(uint64_t)7) + 8ull * P.span_vecs > (uint64_t)in_frames) --cB;
+                while (cA < cB && ((cA * P.kinr * V) & ~(uint64_t)7) < (uint64_t)in_lo * V) ++cA;
+                while (cB > cA && (((cB - 1) * P.kinr * V) & ~(uint64_t)7) + 8ull * P.span_vecs > (uint64_t)in_frames * V) --cB;
                 if (cB > cA + 1) {
                 P.c0 = cA; P.c1 = cB;
-                // consecutive chunks per workgroup: two -- one where the input is the larger side (nothing to amortise the set-up against
-                // but reads), four where the output is (upsampling by two or more): profiles/r06_resample_period.txt.  SYNTHHIP_PERIOD_CHUNKS overrides.
-                P.per_wg = sh::knobs().period_chunks > 0 ? (uint32_t)sh::knobs().period_chunks : A.inr >= 2 * A.outr ? 1u : A.outr >= 2 * A.inr ? 4u : 2u;
+                // consecutive chunks per workgroup (profiles/r06_resample_period.txt; SYNTHHIP_PERIOD_CHUNKS overrides).  Mono: two -- one where
+                // the input is the larger side (nothing to amortise the set-up against but reads), four where the output is (upsampling by
+                // two or more).  Stereo: one (a thread's set-up is eight entries, and the longer a workgroup stays the more of them march in step).
+                P.per_wg = sh::knobs().period_chunks > 0 ? (uint32_t)sh::knobs().period_chunks
+                         : nch == 2 || A.inr >= 2 * A.outr ? 1u : A.outr >= 2 * A.inr ? 4u : 2u;
                 const int nvk = P.span_vecs <= 512u ? 2 : P.span_vecs <= 1024u ? 4 : 8;
                 const dim3 gp((uint32_t)((cB - cA + P.per_wg - 1) / P.per_wg));
-                if (nvk == 2) hipLaunchKernelGGL(k_resample_period_i16<2>, gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P);
-                else if (nvk == 4) hipLaunchKernelGGL(k_resample_period_i16<4>, gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P);
-                else hipLaunchKernelGGL(k_resample_period_i16<8>, gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P);
+#define SH_RP(V_, N_) hipLaunchKernelGGL((k_resample_period_i16<V_, N_>), gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P)
+                if (nch == 1) { if (nvk == 2) SH_RP(1, 2); else if (nvk == 4) SH_RP(1, 4); else SH_RP(1, 8); }
+                else { if (nvk == 2) SH_RP(2, 2); else if (nvk == 4) SH_RP(2, 4); else SH_RP(2, 8); }
+#undef SH_RP
                 SH_CHECK_LAUNCH("k_resample_period_i16");
                 // ... and what lies in front of the first and behind the last interior chunk: k_resample_small (allow_period = false)
                 int rc = SH_OK;

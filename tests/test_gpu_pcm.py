@@ -363,28 +363,30 @@ for frames, inr, outr in ((100003, 44100, 48000), (250001, 96000, 44100), (77777
     want, _ = audioop.ratecv(x.tobytes(), 2, 1, inr, outr, None)
     got = dst.download_bytes(nout * 2)
     assert len(want) == len(got) and got == want, (frames, inr, outr)
-# chunk edges of the short-period kernel (k_resample_period_i16: chunks of K whole periods -- 4000 output frames for 44.1 -> 48 kHz): outputs
+# chunk edges of the short-period kernel (k_resample_period_i16: chunks of K whole periods -- 4000 mono / 1920 stereo output frames for 44.1 -> 48 kHz): outputs
 # that end just before / on / just behind a chunk boundary, inputs of a few frames, and ranges that start inside a chunk
 import ctypes as C
-for inr, outr in ((44100, 48000), (48000, 44100), (96000, 44100), (8000, 44100), (44100, 32000), (1, 2), (2, 1), (3, 2), (44100, 96000)):
-    for frames in (1, 2, 9, 3674, 3675, 3676, 7351, 12345, 40001):
-        x = rng.integers(-32768, 32768, frames).astype(np.int16)
+for nch in (1, 2):
+  for inr, outr in ((44100, 48000), (48000, 44100), (96000, 44100), (8000, 44100), (44100, 32000), (1, 2), (2, 1), (3, 2), (44100, 96000)):
+    for frames in (1, 2, 9, 1837, 1838, 3674, 3675, 3676, 7351, 12345, 40001):
+        x = rng.integers(-32768, 32768, frames * nch).astype(np.int16)
+        x[:6] = (32767, -32768, -32768, 32767, 32767, 32767)[:min(6, x.size)]
         src = N.DeviceBuffer.from_array(x)
         nout = L.sh_resample_out_frames(frames, inr, outr)
-        dst = N.DeviceBuffer(max(nout, 1) * 2)
-        N.check(L.sh_resample(src.handle, frames, 1, 2, 0, inr, outr, dst.handle, None))
-        want, _ = audioop.ratecv(x.tobytes(), 2, 1, inr, outr, None)
-        assert dst.download_bytes(nout * 2) == want, (frames, inr, outr)
+        dst = N.DeviceBuffer(max(nout, 1) * 2 * nch)
+        N.check(L.sh_resample(src.handle, frames, nch, 2, 0, inr, outr, dst.handle, None))
+        want, _ = audioop.ratecv(x.tobytes(), 2, nch, inr, outr, None)
+        assert dst.download_bytes(nout * 2 * nch) == want, (nch, frames, inr, outr)
         if frames == 40001:
-            for out_first, out_n in ((16, 100), (3984, 48), (4000 - 16, 8000), (nout - nout %% 16 - 160, 160 + nout %% 16), (4096, 1)):
+            for out_first, out_n in ((16, 100), (3984, 48), (4000 - 16, 8000), (nout - nout %% 16 - 160, 160 + nout %% 16), (4096, 1), (1920, 2100)):
                 if out_first < 0 or out_first + out_n > nout:
                     continue
                 a, b = C.c_size_t(), C.c_size_t()
                 N.check(L.sh_resample_span(frames, inr, outr, out_first, out_n, C.byref(a), C.byref(b)))
-                part = N.DeviceBuffer.from_array(x[a.value:a.value + b.value])
-                o = N.DeviceBuffer(out_n * 2)
-                N.check(L.sh_resample_range(part.handle, a.value, b.value, 1, 2, 0, inr, outr, out_first, out_n, o.handle))
-                assert o.download_bytes(out_n * 2) == want[out_first * 2:(out_first + out_n) * 2], (inr, outr, out_first, out_n)
+                part = N.DeviceBuffer.from_array(x[a.value * nch:(a.value + b.value) * nch])
+                o = N.DeviceBuffer(out_n * 2 * nch)
+                N.check(L.sh_resample_range(part.handle, a.value, b.value, nch, 2, 0, inr, outr, out_first, out_n, o.handle))
+                assert o.download_bytes(out_n * 2 * nch) == want[out_first * 2 * nch:(out_first + out_n) * 2 * nch], (nch, inr, outr, out_first, out_n)
         src.free(); dst.free()
 print("ok")
 '''
