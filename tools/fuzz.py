@@ -6,6 +6,7 @@
     late         Random single oscillators -- the five waveforms and Harmonics, plain or under a Sine LFO, some under an envelope with a long sustain --
     mix          One-off sweep: mixer.mix_samples (the saturating fold in voice order) and Sample.mix against the live audioop.add.
     ratecv       One-off sweep: Sample.resample against the live audioop.ratecv over random rates, widths, layouts and lengths.
+    period       One-off sweep: 16-bit mono / stereo resampling between rates with a short period (k_resample_period_i16), whole calls and ranges.
     int16        Random additive banks through the integer routes (generate_i16 rows, fused mixdown) against the C oracle's quantised samples: equal
     transitions  Random additive banks (shared or per-voice ADSRs, negative phases, silent and endless voices) rendered over random launches
 
@@ -489,6 +490,67 @@ def fuzz_ratecv(argv):
     return int(bool(locals().get("bad", 0) or locals().get("bad_bank", 0)))
 
 
+def fuzz_period(argv):
+    """One-off sweep of the short-period resample kernel (k_resample_period_i16): 16-bit mono / stereo, rates whose reduced outrate is <= 2048,
+    whole calls and ranges (sh_resample_range at random 16-frame-aligned starts), against the live audioop.ratecv."""
+    import audioop
+    import ctypes as C
+
+    import numpy as np
+    from synthesizer_amd import _native as N
+
+    N.ensure_init(0)
+    L = N.lib()
+    rng = np.random.default_rng(int(argv[0]) if len(argv) > 0 else 0)
+    ncases = int(argv[1]) if len(argv) > 1 else 400
+    bad = 0
+    eligible = 0
+    for case in range(ncases):
+        nch = int(rng.choice([1, 2]))
+        kind = rng.random()
+        if kind < 0.4:
+            i, o = (int(x) for x in rng.choice([8000, 11025, 16000, 22050, 32000, 44100, 48000, 88200, 96000, 192000], 2))
+        elif kind < 0.8:
+            i, o = int(rng.integers(1, 3000)), int(rng.integers(1, 2049))
+        else:
+            g = int(rng.integers(1, 60))
+            i, o = g * int(rng.integers(1, 700)), g * int(rng.integers(1, 2049))
+        frames = int(rng.choice([1, 2, 9, 1000, 3675, 4097, 8192, 20011, 65536, 100003, 300007]))
+        if frames * o / i > 4e6:
+            frames = max(1, int(4e6 * i / o))
+        x = rng.integers(-32768, 32768, frames * nch).astype(np.int16)
+        if rng.random() < 0.3:
+            x[:] = rng.choice(np.array([-32768, 32767, -1, 0, 1], dtype=np.int16), size=x.size)
+        want = audioop.ratecv(x.tobytes(), 2, nch, i, o, None)[0]
+        nout = L.sh_resample_out_frames(frames, i, o)
+        gg = int(np.gcd(i, o))
+        eligible += int(o // gg <= 2048 and i // gg < 65536)
+        src = N.DeviceBuffer.from_array(x)
+        dst = N.DeviceBuffer(max(nout, 1) * 2 * nch)
+        N.check(L.sh_resample(src.handle, frames, nch, 2, 0, i, o, dst.handle, None))
+        got = dst.download_bytes(nout * 2 * nch)
+        ok = got == want
+        if ok and nout > 64:
+            for _ in range(3):
+                out_first = int(rng.integers(0, nout // 16)) * 16
+                out_n = int(rng.integers(1, nout - out_first + 1))
+                a, b = C.c_size_t(), C.c_size_t()
+                N.check(L.sh_resample_span(frames, i, o, out_first, out_n, C.byref(a), C.byref(b)))
+                part = N.DeviceBuffer.from_array(x[a.value * nch:(a.value + b.value) * nch])
+                od = N.DeviceBuffer(out_n * 2 * nch)
+                N.check(L.sh_resample_range(part.handle, a.value, b.value, nch, 2, 0, i, o, out_first, out_n, od.handle))
+                if od.download_bytes(out_n * 2 * nch) != want[out_first * 2 * nch:(out_first + out_n) * 2 * nch]:
+                    ok = False
+                    print("RANGE MISMATCH", nch, i, o, frames, out_first, out_n)
+                part.free(); od.free()
+        if not ok:
+            bad += 1
+            print("MISMATCH", nch, i, o, frames)
+        src.free(); dst.free()
+    print("cases %d (short period: %d) mismatches %d" % (ncases, eligible, bad))
+    return int(bool(bad))
+
+
 def fuzz_transitions(argv):
     """Random additive banks (shared or per-voice ADSRs, negative phases, silent and endless voices) rendered over random launches
 around their transitions -- long launches take the segmented path (csrc/osc.hip RENDER_*_SEG) -- against the same frames rendered
@@ -542,7 +604,7 @@ as launches of 8192 frames (never segmented: below the eight-frames-per-lane sha
     return int(bool(locals().get("bad", 0) or locals().get("bad_bank", 0)))
 
 
-FUZZERS = {"osc": fuzz_osc, "int16": fuzz_int16, "tiles": fuzz_tiles, "late": fuzz_late, "mix": fuzz_mix, "ratecv": fuzz_ratecv, "transitions": fuzz_transitions}
+FUZZERS = {"osc": fuzz_osc, "int16": fuzz_int16, "tiles": fuzz_tiles, "late": fuzz_late, "mix": fuzz_mix, "ratecv": fuzz_ratecv, "period": fuzz_period, "transitions": fuzz_transitions}
 
 if __name__ == "__main__":
     if len(sys.argv) < 2 or sys.argv[1] not in FUZZERS:
