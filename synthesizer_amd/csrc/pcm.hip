@@ -1004,6 +1004,8 @@ __global__ __launch_bounds__(256) void k_resample_period_i16(const short* __rest
         ob[k] = dq * (uint32_t)(2 * VEC);              // bytes
     }
     const int acc = (int)(65536u * P.outr);
+    // (the LDS address of the staged span for the hand-written reads below: 0 in this kernel -- it has no other shared memory -- but asked for, not assumed)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     uint64_t C = P.c0 + (uint64_t)blockIdx.x * P.per_wg;
     if (C >= P.c1) return;
     const uint64_t c_end = C + P.per_wg < P.c1 ? C + P.per_wg : P.c1;
@@ -1036,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_resample_period_i16(const short* __rest
             // one ds_read2_b32 per pair.  The reads are waited for inside the statement (the compiler's counters do not see them).
             uint32_t at[FPR];
 #pragma unroll
-            for (int f = 0; f < FPR; ++f) at[f] = ob[FPR * g + f] + rel0b;
+            for (int f = 0; f < FPR; ++f) at[f] = ob[FPR * g + f] + rel0b + lds0;
             short8v res;
             if constexpr (VEC == 1) {
                 int a[8], b[8];
