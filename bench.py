@@ -914,7 +914,7 @@ def compact_line(out: dict, detail_path=None) -> str:
         side["config1_ms_to_host"] = c1.get("ms")
     pr = out.get("pcm_rows") or {}
     for key, name in (("resample_f32_8ch_600s_96k_to_44k1", "config5_resample_f32_frac_hbm"), ("resample_i16_mono_44k1_to_48k_900MB", "resample_i16_mono_frac_hbm"),
-                      ("mix_chain_i16_1024v_10s_stereo", "mix_chain_i16_frac_hbm")):
+                      ("resample_i16_stereo_44k1_to_48k_900MB", "resample_i16_stereo_frac_hbm"), ("mix_chain_i16_1024v_10s_stereo", "mix_chain_i16_frac_hbm")):
         if key in pr:
             side[name] = pr[key].get("frac_hbm")
     if "resample_f32_8ch_600s_96k_to_44k1" in pr:
@@ -1267,6 +1267,28 @@ def main() -> int:
                                 "note": "K blocks per call (VoiceBank.render_run): a launch of K x %d frames renders them -- fewer voice groups per "
                                         "launch (fewer float64 partial-bus planes), one tail per K blocks instead of one per block" % F}
         del cont
+
+    # ---- a render call that stands alone (a caller that does not stream: VERDICT r05 item 3): the device synchronised in front of it, a few
+    # pipelined renders before that so that the clocks are what a busy caller sees; HIP events around the one call ----
+    if world == 1 and not dry and not args.no_runs:
+        ring = [N.DeviceBuffer(F * 8) for _ in range(4)]
+        lpos = [step0 + 7 * K]
+        got = []
+        for _ in range(30):
+            for _ in range(3):
+                bank.local.render_device(F, lpos[0] * F, bus_f32=ring[lpos[0] & 3])
+                lpos[0] += 1
+            N.sync()
+            N.timer_start()
+            bank.local.render_device(F, lpos[0] * F, bus_f32=ring[lpos[0] & 3])
+            got.append(N.timer_stop() * 1e3)
+            lpos[0] += 1
+        got.sort()
+        out["lone_call"] = {"us_per_block": got[len(got) // 2], "min_us": got[0], "max_us": got[-1], "calls": len(got), "x_headline": got[len(got) // 2] / (wall * 1e6 / K),
+                            "note": "one sh_bank_render of one block with nothing in flight beside it: its own kernel (wavefront priorities falling with progress, "
+                                    "LaunchArgs::alone) + k_bus_combine + launch latency; a streaming caller pays ms_per_step, a caller that asks for runs of blocks run_of_blocks"}
+        for b_ in ring:
+            b_.free()
 
     # ---- notes that do not move in lock-step: 1024 players re-triggering SURVEY 8(d)'s literal note (0.76 s of sound) every second,
     # onsets spread uniformly over the second; one-second blocks 1 .. 20 of the piece ----
