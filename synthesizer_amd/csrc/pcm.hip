@@ -1691,24 +1691,24 @@ static int resample_launch(const void* in, size_t in_frames, int nch, int width,
                 while (cA < cB && ((cA * P.kinr * V) & ~(uint64_t)7) < (uint64_t)in_lo * V) ++cA;
                 while (cB > cA && (((cB - 1) * P.kinr * V) & ~(uint64_t)7) + 8ull * P.span_vecs > (uint64_t)in_frames * V) --cB;
                 if (cB > cA + 1) {
-                P.c0 = cA; P.c1 = cB;
-                // consecutive chunks per workgroup (profiles/r06_resample_period.txt; SYNTHHIP_PERIOD_CHUNKS overrides).  Mono: two -- one where
-                // the input is the larger side (nothing to amortise the set-up against but reads), four where the output is (upsampling by
-                // two or more).  Stereo: one (a thread's set-up is eight entries, and the longer a workgroup stays the more of them march in step).
-                P.per_wg = sh::knobs().period_chunks > 0 ? (uint32_t)sh::knobs().period_chunks
-                         : nch == 2 || A.inr >= 2 * A.outr ? 1u : A.outr >= 2 * A.inr ? 4u : 2u;
-                const int nvk = P.span_vecs <= 512u ? 2 : P.span_vecs <= 1024u ? 4 : 8;
-                const dim3 gp((uint32_t)((cB - cA + P.per_wg - 1) / P.per_wg));
+                    P.c0 = cA; P.c1 = cB;
+                    // consecutive chunks per workgroup (profiles/r06_resample_period.txt; SYNTHHIP_PERIOD_CHUNKS overrides).  Mono: two -- one where
+                    // the input is the larger side (nothing to amortise the set-up against but reads), four where the output is (upsampling by
+                    // two or more).  Stereo: one (a thread's set-up is eight entries, and the longer a workgroup stays the more of them march in step).
+                    P.per_wg = sh::knobs().period_chunks > 0 ? (uint32_t)sh::knobs().period_chunks
+                             : nch == 2 || A.inr >= 2 * A.outr ? 1u : A.outr >= 2 * A.inr ? 4u : 2u;
+                    const int nvk = P.span_vecs <= 512u ? 2 : P.span_vecs <= 1024u ? 4 : 8;
+                    const dim3 gp((uint32_t)((cB - cA + P.per_wg - 1) / P.per_wg));
 #define SH_RP(V_, N_) hipLaunchKernelGGL((k_resample_period_i16<V_, N_>), gp, dim3(256), lds_bytes, st, (const short*)in, (short*)out, P)
-                if (nch == 1) { if (nvk == 2) SH_RP(1, 2); else if (nvk == 4) SH_RP(1, 4); else SH_RP(1, 8); }
-                else { if (nvk == 2) SH_RP(2, 2); else if (nvk == 4) SH_RP(2, 4); else SH_RP(2, 8); }
+                    if (nch == 1) { if (nvk == 2) SH_RP(1, 2); else if (nvk == 4) SH_RP(1, 4); else SH_RP(1, 8); }
+                    else { if (nvk == 2) SH_RP(2, 2); else if (nvk == 4) SH_RP(2, 4); else SH_RP(2, 8); }
 #undef SH_RP
-                SH_CHECK_LAUNCH("k_resample_period_i16");
-                // ... and what lies in front of the first and behind the last interior chunk: k_resample_small (allow_period = false)
-                int rc = SH_OK;
-                if ((uint64_t)m_base < cA * L) rc = resample_launch(in, in_frames, nch, width, is_float, inrate, outrate, out, m_base, (size_t)(cA * L), in_lo, false);
-                if (!rc && cB * L < (uint64_t)m_end) rc = resample_launch(in, in_frames, nch, width, is_float, inrate, outrate, out, (size_t)(cB * L), m_end, in_lo, false);
-                return rc;
+                    SH_CHECK_LAUNCH("k_resample_period_i16");
+                    // ... and what lies in front of the first and behind the last interior chunk: k_resample_small (allow_period = false)
+                    int rc = SH_OK;
+                    if ((uint64_t)m_base < cA * L) rc = resample_launch(in, in_frames, nch, width, is_float, inrate, outrate, out, m_base, (size_t)(cA * L), in_lo, false);
+                    if (!rc && cB * L < (uint64_t)m_end) rc = resample_launch(in, in_frames, nch, width, is_float, inrate, outrate, out, (size_t)(cB * L), m_end, in_lo, false);
+                    return rc;
                 }
             }
         }
