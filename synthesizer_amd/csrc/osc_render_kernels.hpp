@@ -731,17 +731,20 @@ __device__ __forceinline__ void lean_lists(const TileCtx& T, uint32_t& first, Tr
             // A SIMD serves its OLDEST wavefront first: of the three wavefronts it holds one ends at 25 us, one at 33, one at 42 -- and a
             // launch that nothing runs beside (a render that stands alone, a long launch of a run of blocks) leaves every SIMD with two
             // and then ONE wavefront, which issues at half rate (profiles/r04_headline_phases.md).  There a wavefront's priority FALLS as
-            // it gets on with its lists (quarters: s_setprio 3 .. 0), the ones behind catch up and the three end together: a lone block
+            // it gets on with its lists (s_setprio 3 .. 0), the ones behind catch up and the three end together: a lone block
             // 57.1 -> 54.1 us, one launch of 2 / 4 / 8 blocks 48.6 -> 46.8 / 42.0 -> 40.4 / 38.4 -> 37.4 us per block.  Not beside another
             // launch (the stream of blocks: its tail is the successor's head; + 0.6 us per block with the ladder):
             // profiles/r06_prio_ladder.txt.
             const uint32_t span = (T.c1 - T.c0) * 64u;
             for (; p < nfast; p += WAVES, q += WAVES) {
                 if (T.alone) {                                   // (uniform; ONE loop body: the entry is 5 KB of straight-line code)
-                    const uint32_t at4 = ((c - T.c0) * 64u + p) * 4u;      // (which quarter of the group's voices: compares, no division)
-                    if (at4 < span) __builtin_amdgcn_s_setprio(3);
-                    else if (at4 < 2 * span) __builtin_amdgcn_s_setprio(2);
-                    else if (at4 < 3 * span) __builtin_amdgcn_s_setprio(1);
+                    // GEOMETRIC steps -- half, a quarter, an eighth, an eighth of the group's voices: the wavefronts of a SIMD can be one step
+                    // apart at most, and what matters is how far apart they END (quarters: lone 53.0, one launch of 16 blocks 33.6 us per
+                    // block; geometric: 52.3 and 33.0)
+                    const uint32_t at8 = ((c - T.c0) * 64u + p) * 8u;      // (compares, no division)
+                    if (at8 < 4 * span) __builtin_amdgcn_s_setprio(3);
+                    else if (at8 < 6 * span) __builtin_amdgcn_s_setprio(2);
+                    else if (at8 < 7 * span) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
                 }
                 entry(std::integral_constant<int, KINDS>{}, q, p);
