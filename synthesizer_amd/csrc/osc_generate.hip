@@ -433,12 +433,20 @@ __global__ __launch_bounds__(256, (FOLD || (RowOut<OutT>::I16 && FPL == 16)) ? 3
             // (the high words as opaque 32-bit values: left to itself the compiler compares the masked 64-bit patterns -- v_mov, v_cmp_eq_u64,
             //  v_cmp_ne_u64 and two selects per sample, 76 instructions per record instead of 40)
             asm volatile("" : "+v"(h0), "+v"(h1));
-            const uint32_t k0 = h0 == 0x41380000u ? 0xFFFFFFFFu : (uint32_t)__double2loint(w0);
-            const uint32_t k1 = h1 == 0x41380000u ? 0xFFFFFFFFu : (uint32_t)__double2loint(w1);
-            nearv[m / 2] = min(nearv[m / 2], min(k0, k1));
+            uint32_t k0 = h0 == 0x41380000u ? 0xFFFFFFFFu : (uint32_t)__double2loint(w0);
+            uint32_t k1 = h1 == 0x41380000u ? 0xFFFFFFFFu : (uint32_t)__double2loint(w1);
+            // (the running minimum -- and the maxima below -- as ONE three-operand instruction per pair, v_min3_u32 / v_max3_i32 / v_min3_i32:
+            //  left to itself the compiler balances the trees into a two-operand instruction per pair and a three-operand one per quarter --
+            //  twelve instructions of a record's ninety-two beside its float64 ones; rows 0.528 -> 0.522 ms, fused mixdown 0.492 -> 0.481)
+            asm volatile("" : "+v"(k0), "+v"(k1));
+            uint32_t nv_ = min(min(nearv[m / 2], k0), k1);
+            asm volatile("" : "+v"(nv_));
+            nearv[m / 2] = nv_;
             }
-            qmx[m / 2] = max(qmx[m / 2], max(ok0 ? a : 0, ok1 ? b : 0));
-            qmn[m / 2] = min(qmn[m / 2], min(ok0 ? a : 0, ok1 ? b : 0));
+            int mx_ = max(max(qmx[m / 2], ok0 ? a : 0), ok1 ? b : 0), mn_ = min(min(qmn[m / 2], ok0 ? a : 0), ok1 ? b : 0);
+            asm volatile("" : "+v"(mx_), "+v"(mn_));
+            qmx[m / 2] = mx_;
+            qmn[m / 2] = mn_;
             w[m] = __builtin_amdgcn_cvt_pk_i16(a, b);
         }
     };
